@@ -1,0 +1,113 @@
+"""Generic MFMA GEMM (csrc/gemm.hip) vs numpy float64: every operand layout, edge shapes, batching,
+epilogues, split-K atomics, both compute types."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(M, N, K, a_k, b_k, bf16, flags_extra=0, nz=(1, 1), splitk=1, beta=0.0, alpha=1.0, seed=0, src_bf16=False):
+    from ttmi import ops
+    rng = np.random.default_rng(seed)
+    nb = nz[0] * nz[1]
+    A = rng.integers(-4, 5, size=(nb, M, K)).astype(np.float32) if seed == 99 else rng.normal(size=(nb, M, K)).astype(np.float32)
+    B = rng.integers(-4, 5, size=(nb, N, K)).astype(np.float32) if seed == 99 else rng.normal(size=(nb, N, K)).astype(np.float32)
+    C0 = rng.normal(size=(nb, M, N)).astype(np.float32)
+    bias = rng.normal(size=(N,)).astype(np.float32)
+    aux = rng.normal(size=(nb, M, N)).astype(np.float32)
+    Am = A if a_k else np.ascontiguousarray(A.transpose(0, 2, 1))     # stored [M,K] or [K,M]
+    Bm = B if b_k else np.ascontiguousarray(B.transpose(0, 2, 1))     # stored [N,K] or [K,N]
+    dt = torch.bfloat16 if src_bf16 else torch.float32
+    tA = torch.tensor(Am, device="cuda").to(dt)
+    tB = torch.tensor(Bm, device="cuda").to(dt)
+    if src_bf16:
+        A = tA.float().cpu().numpy() if a_k else tA.float().cpu().numpy().transpose(0, 2, 1)
+        B = tB.float().cpu().numpy() if b_k else tB.float().cpu().numpy().transpose(0, 2, 1)
+    tC = torch.tensor(C0, device="cuda")
+    flags = flags_extra | (ops.GEMM_A_KMAJOR if a_k else 0) | (ops.GEMM_B_KMAJOR if b_k else 0) | (ops.GEMM_BF16_MFMA if bf16 else 0)
+    tb = torch.tensor(bias, device="cuda") if flags & ops.GEMM_BIAS else None
+    ta = torch.tensor(aux, device="cuda") if flags & ops.GEMM_MASK_AUX else None
+    lda = K if a_k else M
+    ldb = K if b_k else N
+    ops.gemm(tA, tB, tC, M, N, K, lda, ldb, N, flags, bias=tb, aux=ta, alpha=alpha, beta=beta, nz1=nz[0], nz2=nz[1],
+             sA=(nz[1] * M * K, M * K), sB=(nz[1] * N * K, N * K), sC=(nz[1] * M * N, M * N), splitk=splitk)
+    torch.cuda.synchronize()
+    want = alpha * np.einsum("zmk,znk->zmn", A.astype(np.float64), B.astype(np.float64))
+    if flags & ops.GEMM_BIAS:
+        want = want + bias
+    if flags & ops.GEMM_ATOMIC:
+        want = want + C0
+    else:
+        want = want + beta * C0
+        if flags & ops.GEMM_RELU:
+            want = np.maximum(want, 0)
+        if flags & ops.GEMM_MASK_AUX:
+            want = np.where(aux > 0, want, 0)
+    return tC.cpu().numpy(), want
+
+
+LAYOUTS = [(True, True), (True, False), (False, False), (False, True)]
+
+
+@pytest.mark.parametrize("a_k,b_k", LAYOUTS)
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 130, 51), (37, 300, 17), (1, 5, 3), (129, 257, 100), (64, 36, 7)])
+def test_layouts_and_edges(a_k, b_k, bf16, M, N, K):
+    got, want = _run(M, N, K, a_k, b_k, bf16, seed=M + N + K)
+    assert rel_err(got, want) < (1e-2 if bf16 else 2e-6)
+
+
+@pytest.mark.parametrize("a_k,b_k", LAYOUTS)
+def test_exact_small_integers_bf16(a_k, b_k):
+    """integer operands are exact in bf16: catches any fragment/lane-map permutation error bit-for-bit"""
+    got, want = _run(160, 96, 80, a_k, b_k, True, seed=99)
+    assert np.array_equal(got, want.astype(np.float32))
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_epilogues(bf16):
+    from ttmi import ops
+    tol = 1e-2 if bf16 else 2e-6
+    got, want = _run(150, 70, 40, True, True, bf16, flags_extra=ops.GEMM_BIAS | ops.GEMM_RELU, seed=1)
+    assert rel_err(got, want) < tol
+    got, want = _run(150, 70, 40, True, False, bf16, flags_extra=ops.GEMM_MASK_AUX, seed=2)
+    assert rel_err(got, want) < tol
+    got, want = _run(150, 70, 40, True, True, bf16, beta=1.0, alpha=0.5, seed=3)
+    assert rel_err(got, want) < tol
+    got, want = _run(90, 70, 1000, False, False, bf16, flags_extra=ops.GEMM_ATOMIC, splitk=5, seed=4)
+    assert rel_err(got, want) < tol
+    got, want = _run(90, 70, 1000, False, False, bf16, flags_extra=ops.GEMM_ATOMIC | ops.GEMM_BIAS, splitk=3, seed=5)
+    assert rel_err(got, want) < tol
+
+
+@pytest.mark.parametrize("a_k,b_k", LAYOUTS[:3])
+def test_batched(a_k, b_k):
+    got, want = _run(70, 45, 36, a_k, b_k, False, nz=(3, 4), seed=7)
+    assert rel_err(got, want) < 2e-6
+
+
+@pytest.mark.parametrize("a_k,b_k", LAYOUTS[:3])
+def test_bf16_sources(a_k, b_k):
+    got, want = _run(130, 140, 72, a_k, b_k, True, seed=8, src_bf16=True)
+    assert rel_err(got, want) < 1e-5      # operands exactly representable -> only f32 accumulation error
+
+
+def test_linearity_large():
+    """size-independent property at a joint-sized K panel: GEMM(A1 + A2) == GEMM(A1) + GEMM(A2) (f32 path)"""
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    M, N, K = 4096, 4334, 1024
+    A1 = torch.randn(M, K, device="cuda", generator=g)
+    A2 = torch.randn(M, K, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g)
+    f = ops.GEMM_A_KMAJOR | ops.GEMM_B_KMAJOR
+    out = [torch.empty(M, N, device="cuda") for _ in range(3)]
+    for X, C in zip((A1, A2, A1 + A2), out):
+        ops.gemm(X, W, C, M, N, K, K, K, N, f)
+    err = (out[0] + out[1] - out[2]).norm() / out[2].norm()
+    assert float(err) < 1e-5
+    ref = A1.double() @ W.double().t()      # torch fp64 matmul as an independent check of one product
+    assert float((out[0].double() - ref).norm() / ref.norm()) < 2e-6

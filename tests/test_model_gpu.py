@@ -1,0 +1,153 @@
+"""HIP model path (tt.* over libttmi) vs the golden fixtures produced by the imported reference and vs
+the numpy oracle.  fp32 tolerance 1e-4 rel (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import tt_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def tiny_config(sd):
+    from tt.utils import AttrDict
+    k_enc = sd["encoder.layers.0.r_emb"].shape[0]
+    k_dec = sd["decoder.layers.0.r_emb"].shape[0]
+    side = dict(n_layer=2, d_model=96, n_head=4, d_head=24, d_inner=160)
+    return AttrDict(dict(enc=dict(side, max_input_length=k_enc), dec=dict(side, max_target_length=k_dec),
+                         joint=dict(input_size=192, inner_size=80), vocab_size=48, dropout=0.0))
+
+
+def build(sd):
+    from tt.model import Transducer
+    model = Transducer(tiny_config(sd)).cuda().eval()
+    missing = model.load_state_dict({k: torch.tensor(v) for k, v in sd.items()}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return model
+
+
+@pytest.fixture(params=["tiny_klong", "tiny_kshort"])
+def gm(request):
+    z, sd = load_golden(request.param)
+    return z, sd, build(sd)
+
+
+def test_encoder_layers_forward(gm):
+    z, sd, model = gm
+    from ttmi.ops import MaskSpec
+    x = torch.tensor(z["inputs"], device="cuda")
+    for i, layer in enumerate(model.encoder.layers):
+        x = layer.forward_bm(x, MaskSpec(0))
+        assert rel_err(x.detach().cpu().numpy(), z["enc_layer%d" % i]) < TOL, i
+
+
+def test_time_major_layer_contract(gm):
+    """the reference's layer-level API is time-major [L,B,d] with a [L,L,1] mask tensor"""
+    z, sd, model = gm
+    from tt.utils import context_mask
+    x = torch.tensor(z["inputs"], device="cuda")
+    m = context_mask(x, 10, 2)[:, :, None]
+    y = x.transpose(0, 1)
+    for layer in model.encoder.layers:
+        y = layer(y, m)
+    assert rel_err(y.transpose(0, 1).detach().cpu().numpy(), z["mask/band_10_2/enc_out"]) < TOL
+
+
+def test_label_encoder(gm):
+    z, sd, model = gm
+    from tt.utils import look_ahead_mask
+    tg = torch.nn.functional.pad(torch.tensor(z["targets"], device="cuda"), [1, 0, 0, 0], value=0)
+    y = model.decoder(tg, look_ahead_mask(tg)[:, :, None])
+    assert rel_err(y.detach().cpu().numpy(), z["dec_masked"]) < TOL
+    y = model.decoder(tg)
+    assert rel_err(y.detach().cpu().numpy(), z["dec_unmasked"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["full", "ragged"])
+def test_logits_loss_and_every_gradient(gm, tag):
+    z, sd, model = gm
+    from warprnnt_pytorch import RNNTLoss
+    model.zero_grad()
+    inp = torch.tensor(z["inputs"], device="cuda", requires_grad=True)
+    tgt = torch.tensor(z["targets"], device="cuda")
+    logits = model(inp, tgt)
+    assert rel_err(logits.detach().cpu().numpy(), z["logits"]) < TOL
+    loss = RNNTLoss(check_lengths=False)(logits, tgt.int(), torch.tensor(z[tag + "/act_lens"], device="cuda"),
+                                         torch.tensor(z[tag + "/label_lens"], device="cuda"))
+    assert abs(float(loss) - float(z[tag + "/loss"])) / float(z[tag + "/loss"]) < TOL
+    loss.backward()
+    assert rel_err(inp.grad.cpu().numpy(), z[tag + "/dinputs"]) < TOL
+    worst = 0.0
+    for name, p in model.named_parameters():
+        e = rel_err(p.grad.cpu().numpy(), z["%s/grad/%s" % (tag, name)])
+        worst = max(worst, e)
+        assert e < TOL, (name, e)
+    print("worst grad rel err", worst)
+
+
+@pytest.mark.parametrize("mname", ["band_10_2", "left_8_0", "chunk_8_16"])
+def test_streaming_masks(gm, mname):
+    z, sd, model = gm
+    from ttmi.ops import MaskSpec
+    model.zero_grad()
+    inp = torch.tensor(z["inputs"], device="cuda", requires_grad=True)
+    mask = torch.tensor(z["mask/%s/mask" % mname], device="cuda").float()[:, :, None]
+    y = model.encoder(inp, mask)
+    assert rel_err(y.detach().cpu().numpy(), z["mask/%s/enc_out" % mname]) < TOL
+    (y * torch.tensor(z["enc_cotangent"], device="cuda")).sum().backward()
+    assert rel_err(inp.grad.cpu().numpy(), z["mask/%s/dinputs" % mname]) < TOL
+    for name, p in model.encoder.named_parameters():
+        key = "mask/%s/grad/encoder.%s" % (mname, name)
+        if key in z.files:
+            assert rel_err(p.grad.cpu().numpy(), z[key]) < TOL, name
+    if mname != "chunk_8_16":     # parametric band mask == the same mask given as a tensor
+        left, right = (10, 2) if mname == "band_10_2" else (8, 0)
+        y2 = model.encoder(inp.detach(), MaskSpec(2, left=left, right=right))
+        assert torch.equal(y2, y.detach())
+
+
+def test_greedy_decode_identical_tokens(gm):
+    z, sd, model = gm
+    hyp = model.recognize(torch.tensor(z["inputs"], device="cuda"), torch.tensor(z["greedy/lens"]))
+    for b, h in enumerate(hyp):
+        assert h == z["greedy/tokens%d" % b].tolist()
+
+
+def test_bf16_mode_close(gm, monkeypatch):
+    z, sd, model = gm
+    monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    logits = model(torch.tensor(z["inputs"], device="cuda"), torch.tensor(z["targets"], device="cuda"))
+    e = rel_err(logits.detach().cpu().numpy(), z["logits"])
+    print("bf16 logits rel err", e)
+    assert e < 5e-2
+
+
+def test_vs_oracle_odd_shapes():
+    """shapes no fixture covers: B=3, T=70 (> one 64-lane row chunk), U=9, both K branches in one model"""
+    from tt.model import Transducer
+    from tt.utils import AttrDict
+    from warprnnt_pytorch import RNNTLoss
+    cfg = AttrDict(dict(enc=dict(n_layer=1, d_model=40, n_head=2, d_head=12, d_inner=52, max_input_length=33),
+                        dec=dict(n_layer=1, d_model=40, n_head=2, d_head=12, d_inner=52, max_target_length=64),
+                        joint=dict(input_size=80, inner_size=36), vocab_size=21, dropout=0.0))
+    torch.manual_seed(3)
+    model = Transducer(cfg).cuda().eval()
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    B, T, U = 3, 70, 9
+    g = torch.Generator().manual_seed(4)
+    inp = torch.randn(B, T, 40, generator=g)
+    tgt = torch.randint(1, 21, (B, U), generator=g)
+    tl, ul = np.array([70, 55, 70], dtype=np.int32), np.array([9, 9, 4], dtype=np.int32)
+    sd64 = {k: v.astype(np.float64) if v.dtype == np.float32 else v for k, v in sd.items()}
+    want = O.transducer_loss_and_grads(inp.numpy().astype(np.float64), tgt.numpy(), tl, ul, sd64)
+    x = inp.cuda().requires_grad_(True)
+    logits = model(x, tgt.cuda())
+    loss = RNNTLoss()(logits, tgt.int().cuda(), torch.tensor(tl).cuda(), torch.tensor(ul).cuda())
+    loss.backward()
+    assert rel_err(logits.detach().cpu().numpy(), want["logits"]) < TOL
+    assert abs(float(loss) - want["loss"]) / want["loss"] < TOL
+    assert rel_err(x.grad.cpu().numpy(), want["dinputs"]) < TOL
+    for name, p in model.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), want["grads"][name]) < TOL, name

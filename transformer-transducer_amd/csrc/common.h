@@ -1,0 +1,56 @@
+// Shared device/host helpers for libttmi (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define TTMI_OK 0
+#define TTMI_EINVAL (-1)
+
+extern "C" const char* ttmi_last_error(void);
+void ttmi_set_error(const char* fmt, ...);
+
+#define TTMI_REQUIRE(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            ttmi_set_error(__VA_ARGS__);        \
+            return TTMI_EINVAL;                 \
+        }                                       \
+    } while (0)
+
+// launch check: returns hipError_t (>0) through the C ABI, never throws
+#define TTMI_LAUNCH_CHECK(name)                                              \
+    do {                                                                     \
+        hipError_t e__ = hipGetLastError();                                  \
+        if (e__ != hipSuccess) {                                             \
+            ttmi_set_error("%s: %s", name, hipGetErrorString(e__));          \
+            return (int)e__;                                                 \
+        }                                                                    \
+    } while (0)
+
+typedef uint16_t bf16_t;   // raw bf16 bits in memory
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even; plain cast lets hipcc emit v_cvt_pk_bf16_f32 (NaN-safe)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    __hip_bfloat16 b = __float2bfloat16(f);
+    return *reinterpret_cast<bf16_t*>(&b);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

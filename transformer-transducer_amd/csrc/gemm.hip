@@ -1,0 +1,360 @@
+// Generic MFMA GEMM for gfx950:  C[z] = alpha * op(A[z]) . op(B[z]) + beta * C[z]  (+bias, ReLU, mask, atomics)
+//
+// One kernel family serves every dense contraction on the Transformer-Transducer path
+// (QKV / output / FFN / joint projections, the attention score products and all their
+// backward forms): operands may be K-major or M/N-major (so dgrad and wgrad need no
+// transposed copies), f32 or bf16 in memory, batched with two-level strides.
+//
+//   compute = bf16 : v_mfma_f32_32x32x16_bf16, f32 accumulate   (throughput path)
+//   compute = f32  : v_mfma_f32_32x32x2_f32, bit-exact fmaf chain (parity path, 1e-4 gate)
+//
+// Block tile 128x128, 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles of 32x32.  Operands are
+// register-staged (global -> VGPR -> convert -> LDS) so any source layout/dtype lands in the
+// same K-contiguous LDS image; M/N-major sources are transposed in registers (4x4 blocks) on the
+// way in.  LDS rows are padded (80 B for bf16, 17 dwords for f32) so the ds_read_b128 / ds_read_b32
+// fragment reads are bank-conflict free.  Global loads for tile k+1 are issued before the MFMAs of
+// tile k (double-buffered LDS, one barrier per K-step).
+#include "gemm.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BM = 128, BN = 128, NT = 256;
+
+template <bool BF16C>
+struct Cfg {
+    static constexpr int BK = BF16C ? 32 : 16;
+    static constexpr int LD = BF16C ? 40 : 17;                 // LDS row pitch in elements
+    static constexpr int ESZ = BF16C ? 2 : 4;
+    static constexpr int TILE_BYTES = 128 * LD * ESZ;          // one operand tile
+};
+
+struct KParams {
+    const void* A;
+    const void* B;
+    void* C;
+    const float* bias;
+    const float* aux;
+    int M, N, K;
+    long lda, ldb, ldc;
+    int nz2;
+    long sA1, sA2, sB1, sB2, sC1, sC2, sBias1, sBias2;
+    float alpha, beta;
+    int flags;
+    int splitk, kchunk;
+    int vecA, vecB;
+};
+
+template <typename S>
+__device__ __forceinline__ float ld1(const S* p);
+template <>
+__device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+
+// 4 consecutive source elements starting at p (nvalid of them in range), as floats
+template <typename S>
+__device__ __forceinline__ float4 load4(const S* p, int nvalid, bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nvalid >= 4 && vec) {
+        if constexpr (sizeof(S) == 4) {
+            v = *reinterpret_cast<const float4*>(p);
+        } else {
+            const uint2 w = *reinterpret_cast<const uint2*>(p);
+            v.x = __uint_as_float(w.x << 16);
+            v.y = __uint_as_float(w.x & 0xffff0000u);
+            v.z = __uint_as_float(w.y << 16);
+            v.w = __uint_as_float(w.y & 0xffff0000u);
+        }
+    } else {
+        if (nvalid > 0) v.x = ld1<S>(p);
+        if (nvalid > 1) v.y = ld1<S>(p + 1);
+        if (nvalid > 2) v.z = ld1<S>(p + 2);
+        if (nvalid > 3) v.w = ld1<S>(p + 3);
+    }
+    return v;
+}
+
+// Staging of one 128 x BK operand tile.  KMAJOR: element (r,k) at src[r*ld + k]; else src[k*ld + r].
+template <typename S, bool KMAJOR, bool BF16C>
+struct Stager {
+    using C = Cfg<BF16C>;
+    static constexpr int NV = KMAJOR ? (128 * C::BK / 4) / NT : ((C::BK / 4) * 32 + NT - 1) / NT;   // float4 groups / thread
+    float4 v[KMAJOR ? NV : 4 * NV];
+
+    __device__ __forceinline__ void load(const S* src, long ld, int r0, int R, int k0, int Kend, bool vec, int tid) {
+        if constexpr (KMAJOR) {
+#pragma unroll
+            for (int s = 0; s < NV; ++s) {
+                const int idx = tid + NT * s;
+                const int row = idx / (C::BK / 4), kq = idx % (C::BK / 4);
+                const int gr = r0 + row, gk = k0 + kq * 4;
+                const int nvalid = (gr < R) ? (Kend - gk) : 0;
+                v[s] = load4<S>(src + (long)gr * ld + gk, nvalid, vec);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < NV; ++s) {
+                const int idx = tid + NT * s;
+                const int kb = idx / 32, rb = idx % 32;
+                const bool on = idx < (C::BK / 4) * 32;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int gk = k0 + kb * 4 + kk, gr = r0 + rb * 4;
+                    const int nvalid = (on && gk < Kend) ? (R - gr) : 0;
+                    v[s * 4 + kk] = load4<S>(src + (long)gk * ld + gr, nvalid, vec);
+                }
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(char* lds, int tid) const {
+        if constexpr (KMAJOR) {
+#pragma unroll
+            for (int s = 0; s < NV; ++s) {
+                const int idx = tid + NT * s;
+                const int row = idx / (C::BK / 4), kq = idx % (C::BK / 4);
+                if constexpr (BF16C) {
+                    uint2 w;
+                    w.x = pack_bf16x2(v[s].x, v[s].y);
+                    w.y = pack_bf16x2(v[s].z, v[s].w);
+                    *reinterpret_cast<uint2*>(lds + (row * C::LD + kq * 4) * 2) = w;
+                } else {
+                    float* d = reinterpret_cast<float*>(lds) + row * C::LD + kq * 4;
+                    d[0] = v[s].x; d[1] = v[s].y; d[2] = v[s].z; d[3] = v[s].w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < NV; ++s) {
+                const int idx = tid + NT * s;
+                const int kb = idx / 32, rb = idx % 32;
+                if (idx < (C::BK / 4) * 32) {
+                    const float4 a = v[s * 4 + 0], b = v[s * 4 + 1], c = v[s * 4 + 2], d = v[s * 4 + 3];
+                    const float t0[4] = {a.x, b.x, c.x, d.x}, t1[4] = {a.y, b.y, c.y, d.y};
+                    const float t2[4] = {a.z, b.z, c.z, d.z}, t3[4] = {a.w, b.w, c.w, d.w};
+                    const float* tr[4] = {t0, t1, t2, t3};
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int row = rb * 4 + rr;
+                        if constexpr (BF16C) {
+                            uint2 w;
+                            w.x = pack_bf16x2(tr[rr][0], tr[rr][1]);
+                            w.y = pack_bf16x2(tr[rr][2], tr[rr][3]);
+                            *reinterpret_cast<uint2*>(lds + (row * C::LD + kb * 4) * 2) = w;
+                        } else {
+                            float* dd = reinterpret_cast<float*>(lds) + row * C::LD + kb * 4;
+                            dd[0] = tr[rr][0]; dd[1] = tr[rr][1]; dd[2] = tr[rr][2]; dd[3] = tr[rr][3];
+                        }
+                    }
+                }
+            }
+        }
+    }
+};
+
+template <typename SA, typename SB, typename TC, bool AK, bool BKM, bool BF16C>
+__global__ __launch_bounds__(NT) void gemm_kernel(const KParams p) {
+    using C = Cfg<BF16C>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // layout: [buf0: A | B][buf1: A | B]
+    auto ldsA = [&](int buf) -> char* { return smem + buf * 2 * C::TILE_BYTES; };
+    auto ldsB = [&](int buf) -> char* { return smem + buf * 2 * C::TILE_BYTES + C::TILE_BYTES; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+    const int z = blockIdx.z / p.splitk, ks = blockIdx.z % p.splitk;
+    const int z1 = z / p.nz2, z2 = z % p.nz2;
+    const SA* A = reinterpret_cast<const SA*>(p.A) + z1 * p.sA1 + z2 * p.sA2;
+    const SB* B = reinterpret_cast<const SB*>(p.B) + z1 * p.sB1 + z2 * p.sB2;
+    TC* Cp = reinterpret_cast<TC*>(p.C) + z1 * p.sC1 + z2 * p.sC2;
+    const int kbeg = ks * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int nk = (kend - kbeg + C::BK - 1) / C::BK;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    Stager<SA, AK, BF16C> sa;
+    Stager<SB, BKM, BF16C> sb;
+    if (nk > 0) {
+        sa.load(A, p.lda, bm, p.M, kbeg, kend, p.vecA, tid);
+        sb.load(B, p.ldb, bn, p.N, kbeg, kend, p.vecB, tid);
+        sa.store(ldsA(0), tid);
+        sb.store(ldsB(0), tid);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            sa.load(A, p.lda, bm, p.M, kbeg + (kt + 1) * C::BK, kend, p.vecA, tid);
+            sb.load(B, p.ldb, bn, p.N, kbeg + (kt + 1) * C::BK, kend, p.vecB, tid);
+        }
+        const char* la = ldsA(cur);
+        const char* lb = ldsB(cur);
+        if constexpr (BF16C) {
+#pragma unroll
+            for (int kk = 0; kk < C::BK / 16; ++kk) {
+                bf16x8 af[2], bf[2];
+                const int kof = kk * 16 + 8 * (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = wm * 64 + i * 32 + (lane & 31);
+                    af[i] = *reinterpret_cast<const bf16x8*>(la + (row * C::LD + kof) * 2);
+                    const int col = wn * 64 + i * 32 + (lane & 31);
+                    bf[i] = *reinterpret_cast<const bf16x8*>(lb + (col * C::LD + kof) * 2);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            const float* fa = reinterpret_cast<const float*>(la);
+            const float* fb = reinterpret_cast<const float*>(lb);
+#pragma unroll
+            for (int kk = 0; kk < C::BK / 2; ++kk) {
+                float af[2], bf[2];
+                const int kof = kk * 2 + (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i] = fa[(wm * 64 + i * 32 + (lane & 31)) * C::LD + kof];
+                    bf[i] = fb[(wn * 64 + i * 32 + (lane & 31)) * C::LD + kof];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) {
+            sa.store(ldsA(cur ^ 1), tid);
+            sb.store(ldsB(cur ^ 1), tid);
+        }
+        __syncthreads();
+    }
+
+    // epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const float* bias = (p.flags & GEMM_BIAS) ? p.bias + z1 * p.sBias1 + z2 * p.sBias2 : nullptr;
+    const float* aux = (p.flags & GEMM_MASK_AUX) ? p.aux + z1 * p.sC1 + z2 * p.sC2 : nullptr;
+    const bool first_split = (ks == 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = bn + wn * 64 + j * 32 + (lane & 31);
+            if (n >= p.N) continue;
+            const float bv = (bias && first_split) ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= p.M) continue;
+                const long ci = (long)m * p.ldc + n;
+                float v = p.alpha * acc[i][j][r] + bv;
+                if constexpr (sizeof(TC) == 4) {
+                    if (p.flags & GEMM_ATOMIC) {
+                        atomicAdd(reinterpret_cast<float*>(Cp) + ci, v);
+                        continue;
+                    }
+                    if (p.beta != 0.f) v += p.beta * reinterpret_cast<const float*>(Cp)[ci];
+                } else {
+                    if (p.beta != 0.f) v += p.beta * bf16_to_f32(reinterpret_cast<const bf16_t*>(Cp)[ci]);
+                }
+                if (p.flags & GEMM_RELU) v = fmaxf(v, 0.f);
+                if (aux) v = aux[ci] > 0.f ? v : 0.f;
+                if constexpr (sizeof(TC) == 4) reinterpret_cast<float*>(Cp)[ci] = v;
+                else reinterpret_cast<bf16_t*>(Cp)[ci] = f32_to_bf16(v);
+            }
+        }
+}
+
+template <typename SA, typename SB, typename TC, bool AK, bool BKM, bool BF16C>
+int launch_t(const KParams& p, dim3 grid, hipStream_t st) {
+    const size_t lds = 4 * Cfg<BF16C>::TILE_BYTES;
+    hipLaunchKernelGGL((gemm_kernel<SA, SB, TC, AK, BKM, BF16C>), grid, dim3(NT), lds, st, p);
+    TTMI_LAUNCH_CHECK("gemm_kernel");
+    return TTMI_OK;
+}
+
+template <typename SA, typename SB, typename TC, bool BF16C>
+int launch_layout(const KParams& p, dim3 grid, hipStream_t st) {
+    const bool ak = p.flags & GEMM_A_KMAJOR, bk = p.flags & GEMM_B_KMAJOR;
+    if (ak && bk) return launch_t<SA, SB, TC, true, true, BF16C>(p, grid, st);
+    if (ak && !bk) return launch_t<SA, SB, TC, true, false, BF16C>(p, grid, st);
+    if (!ak && !bk) return launch_t<SA, SB, TC, false, false, BF16C>(p, grid, st);
+    return launch_t<SA, SB, TC, false, true, BF16C>(p, grid, st);
+}
+
+}  // namespace
+
+int ttmi_launch_gemm(const GemmDesc& d, hipStream_t st) {
+    TTMI_REQUIRE(d.A && d.B && d.C, "gemm: null operand");
+    TTMI_REQUIRE(d.M > 0 && d.N > 0 && d.K >= 0, "gemm: bad shape M=%d N=%d K=%d", d.M, d.N, d.K);
+    TTMI_REQUIRE(d.nz1 > 0 && d.nz2 > 0 && d.splitk > 0, "gemm: bad batch/splitk");
+    TTMI_REQUIRE(!(d.flags & GEMM_BIAS) || d.bias, "gemm: GEMM_BIAS without bias pointer");
+    TTMI_REQUIRE(!(d.flags & GEMM_MASK_AUX) || d.aux, "gemm: GEMM_MASK_AUX without aux pointer");
+    TTMI_REQUIRE(!(d.flags & GEMM_ATOMIC) || d.c_dtype == DT_F32, "gemm: atomic epilogue needs f32 C");
+    TTMI_REQUIRE(d.splitk == 1 || (d.flags & GEMM_ATOMIC), "gemm: splitk>1 needs GEMM_ATOMIC");
+    const bool bf16c = d.flags & GEMM_BF16_MFMA;
+    TTMI_REQUIRE(bf16c || (d.a_dtype == DT_F32 && d.b_dtype == DT_F32), "gemm: f32 compute needs f32 operands");
+    KParams p;
+    p.A = d.A; p.B = d.B; p.C = d.C; p.bias = d.bias; p.aux = d.aux;
+    p.M = d.M; p.N = d.N; p.K = d.K; p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc;
+    p.nz2 = d.nz2;
+    p.sA1 = d.sA1; p.sA2 = d.sA2; p.sB1 = d.sB1; p.sB2 = d.sB2; p.sC1 = d.sC1; p.sC2 = d.sC2;
+    p.sBias1 = d.sBias1; p.sBias2 = d.sBias2;
+    p.alpha = d.alpha; p.beta = d.beta; p.flags = d.flags; p.splitk = d.splitk;
+    const int bk = bf16c ? 32 : 16;
+    int kchunk = (d.K + d.splitk - 1) / d.splitk;
+    kchunk = (kchunk + bk - 1) / bk * bk;
+    p.kchunk = kchunk > 0 ? kchunk : bk;
+    const size_t ea = d.a_dtype == DT_F32 ? 4 : 2, eb = d.b_dtype == DT_F32 ? 4 : 2;
+    auto vec_ok = [](const void* ptr, size_t es, long ld, long s1, long s2) {
+        const size_t q = 4;   // 4 elements per vector access
+        return ((reinterpret_cast<uintptr_t>(ptr) % (q * es)) == 0) && (ld % q == 0) && (s1 % q == 0) && (s2 % q == 0);
+    };
+    p.vecA = vec_ok(d.A, ea, d.lda, d.sA1, d.sA2);
+    p.vecB = vec_ok(d.B, eb, d.ldb, d.sB1, d.sB2);
+    dim3 grid(cdiv(d.N, BN), cdiv(d.M, BM), d.nz1 * d.nz2 * d.splitk);
+    TTMI_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large (M tiles %u, batch %u)", grid.y, grid.z);
+    const int key = (bf16c ? 8 : 0) | (d.a_dtype << 2) | (d.b_dtype << 1) | d.c_dtype;
+    switch (key) {
+        case 0: return launch_layout<float, float, float, false>(p, grid, st);
+        case 8: return launch_layout<float, float, float, true>(p, grid, st);
+        case 8 | 1: return launch_layout<float, float, bf16_t, true>(p, grid, st);
+        case 8 | 4: return launch_layout<bf16_t, float, float, true>(p, grid, st);
+        case 8 | 2: return launch_layout<float, bf16_t, float, true>(p, grid, st);
+        case 8 | 6: return launch_layout<bf16_t, bf16_t, float, true>(p, grid, st);
+        case 8 | 7: return launch_layout<bf16_t, bf16_t, bf16_t, true>(p, grid, st);
+        case 8 | 3: return launch_layout<float, bf16_t, bf16_t, true>(p, grid, st);
+        case 8 | 5: return launch_layout<bf16_t, float, bf16_t, true>(p, grid, st);
+        default: break;
+    }
+    ttmi_set_error("gemm: unsupported dtype combination a=%d b=%d c=%d bf16=%d", d.a_dtype, d.b_dtype, d.c_dtype, (int)bf16c);
+    return TTMI_EINVAL;
+}
+
+extern "C" {
+// Test/bring-up entry point for the generic GEMM (dtype codes: 0 = f32, 1 = bf16; flags = GemmFlags).
+int ttmi_gemm(const void* A, const void* B, void* C, const float* bias, const float* aux, int a_dtype, int b_dtype,
+              int c_dtype, int M, int N, int K, long lda, long ldb, long ldc, int nz1, int nz2, long sA1, long sA2,
+              long sB1, long sB2, long sC1, long sC2, float alpha, float beta, int flags, int splitk, void* stream) {
+    GemmDesc d;
+    d.A = A; d.B = B; d.C = C; d.bias = bias; d.aux = aux;
+    d.a_dtype = a_dtype; d.b_dtype = b_dtype; d.c_dtype = c_dtype;
+    d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc;
+    d.nz1 = nz1; d.nz2 = nz2; d.sA1 = sA1; d.sA2 = sA2; d.sB1 = sB1; d.sB2 = sB2; d.sC1 = sC1; d.sC2 = sC2;
+    d.alpha = alpha; d.beta = beta; d.flags = flags; d.splitk = splitk;
+    return ttmi_launch_gemm(d, static_cast<hipStream_t>(stream));
+}
+}

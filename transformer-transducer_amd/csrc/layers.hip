@@ -1,0 +1,371 @@
+// Sub-layer drivers behind the C ABI: relative-position self-attention, position-wise FFN and the
+// joint network, forward and backward.  Each driver is a fixed sequence of asynchronous launches
+// (MFMA GEMMs from gemm.hip + HBM-bound row kernels from rowops.hip) on the caller's stream; it
+// allocates nothing: `ctx` (saved for backward) and `ws` (scratch) are caller-provided.
+//
+// Relative shift without a kernel: the reference builds BD = _rel_shift(q.E^T + c)
+// (tt/transformer.py:82-89,143-145) by zero-padding a column, re-viewing [L, L+1] as [L+1, L] and
+// dropping the first row.  Here the q.E^T GEMM writes straight into a slab with row pitch L+1 and
+// column offset 1 (column 0 zeroed once); the SAME memory read at offset L with pitch L is the shifted
+// matrix, so the content GEMM accumulates onto it in place and the softmax runs on that view.  The
+// backward uses the mirror image: dS written through the pitch-L view IS dG in the pitch-(L+1) layout.
+#include "gemm.h"
+#include "rowops.h"
+
+namespace {
+
+constexpr int NT_ = GEMM_A_KMAJOR | GEMM_B_KMAJOR;   // C = A . B^T   (Linear forward)
+constexpr int NN_ = GEMM_A_KMAJOR;                   // C = A . B     (dgrad)
+constexpr int TN_ = 0;                               // C = A^T . B   (wgrad)
+
+inline size_t al4(size_t n) { return (n + 3) & ~size_t(3); }
+
+GemmDesc mk(const float* A, const float* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int flags, int prec) {
+    GemmDesc d;
+    d.A = A; d.B = B; d.C = C; d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc;
+    d.flags = flags | (prec ? GEMM_BF16_MFMA : 0);
+    return d;
+}
+
+// weight-gradient GEMMs reduce over a long K with few output tiles: split K over workgroups, combine by f32 atomics
+int pick_splitk(int M, int N, int K, int nbatch) {
+    const long tiles = (long)cdiv(M, 128) * cdiv(N, 128) * nbatch;
+    if (tiles >= 384) return 1;
+    long s = (768 + tiles - 1) / tiles;
+    const long kmax = K / 128 > 0 ? K / 128 : 1;
+    if (s > kmax) s = kmax;
+    return (int)(s < 1 ? 1 : s);
+}
+
+int wgrad(const float* dY, const float* X, float* gW, int M, int N, int K, long lda, long ldb, long ldc, int prec,
+          hipStream_t st) {
+    GemmDesc d = mk(dY, X, gW, M, N, K, lda, ldb, ldc, TN_ | GEMM_ATOMIC, prec);
+    d.splitk = pick_splitk(M, N, K, 1);
+    return ttmi_launch_gemm(d, st);
+}
+
+#define CK(expr)                 \
+    do {                         \
+        int rc__ = (expr);       \
+        if (rc__) return rc__;   \
+    } while (0)
+
+struct AttnDims {
+    int B, L, d, H, Dh, K;
+    long BL, HD, W3, slab;
+    AttnDims(int B_, int L_, int d_, int H_, int Dh_, int K_) : B(B_), L(L_), d(d_), H(H_), Dh(Dh_), K(K_) {
+        BL = (long)B * L; HD = (long)H * Dh; W3 = 3 * HD; slab = (long)L * (L + 1);
+    }
+};
+
+struct AttnCtx {   // saved for backward, all f32
+    float *qkv, *qu, *P, *O, *s1, *mean, *rstd;
+    static size_t floats(const AttnDims& a) {
+        return al4(a.BL * a.W3) + al4(a.BL * a.HD) + al4((size_t)a.B * a.H * a.slab) + al4(a.BL * a.HD) + al4(a.BL * a.d) +
+               2 * al4(a.BL);
+    }
+    AttnCtx(float* p, const AttnDims& a) {
+        qkv = p; p += al4(a.BL * a.W3);
+        qu = p; p += al4(a.BL * a.HD);
+        P = p; p += al4((size_t)a.B * a.H * a.slab);
+        O = p; p += al4(a.BL * a.HD);
+        s1 = p; p += al4(a.BL * a.d);
+        mean = p; p += al4(a.BL);
+        rstd = p;
+    }
+};
+
+struct AttnWs {   // scratch
+    float *E, *cT, *a, *dO, *dS, *dqkv, *dE, *dcT;
+    static size_t floats(const AttnDims& a) {
+        return 2 * al4((size_t)a.L * a.HD) + 2 * al4((size_t)a.H * a.L) + al4(a.BL * a.d) + al4(a.BL * a.HD) +
+               al4((size_t)a.B * a.H * a.slab) + al4(a.BL * a.W3);
+    }
+    AttnWs(float* p, const AttnDims& a) {
+        E = p; p += al4((size_t)a.L * a.HD);
+        cT = p; p += al4((size_t)a.H * a.L);
+        dE = p; p += al4((size_t)a.L * a.HD);
+        dcT = p; p += al4((size_t)a.H * a.L);
+        this->a = p; p += al4(a.BL * a.d);
+        dO = p; p += al4(a.BL * a.HD);
+        dS = p; p += al4((size_t)a.B * a.H * a.slab);
+        dqkv = p;
+    }
+};
+
+int memset2d(void* p, size_t pitch, size_t width, size_t height, hipStream_t st) {
+    hipError_t e = hipMemset2DAsync(p, pitch, 0, width, height, st);
+    if (e != hipSuccess) {
+        ttmi_set_error("memset2d: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return TTMI_OK;
+}
+
+// batched over (b, h): z1 = b, z2 = h
+void batch_bh(GemmDesc& g, const AttnDims& a, long sA1, long sA2, long sB1, long sB2, long sC1, long sC2) {
+    g.nz1 = a.B; g.nz2 = a.H;
+    g.sA1 = sA1; g.sA2 = sA2; g.sB1 = sB1; g.sB2 = sB2; g.sC1 = sC1; g.sC2 = sC2;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ttmi_attn_ctx_floats(int B, int L, int d, int H, int Dh) { return AttnCtx::floats(AttnDims(B, L, d, H, Dh, 1)); }
+size_t ttmi_attn_ws_floats(int B, int L, int d, int H, int Dh) { return AttnWs::floats(AttnDims(B, L, d, H, Dh, 1)); }
+
+// RelLearnableMultiHeadAttn.forward (tt/transformer.py:106-177), batch-major: x,y f32 [B,L,d].
+// mask_kind: 0 none, 1 causal (look_ahead_mask), 2 band(left,right) (context_mask), 3 uint8 tensor (b,i,j) at
+// mask[b*mask_sb + i*mask_si + j], nonzero = masked.  prec: 0 = exact-f32 MFMA, 1 = bf16 MFMA.
+int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const float* ln_g, const float* ln_b,
+                  const float* r_emb, const float* r_w_bias, const float* r_bias, int B, int L, int d, int H, int Dh, int K,
+                  int mask_kind, int mask_left, int mask_right, const unsigned char* mask, long mask_sb, long mask_si,
+                  int prec, float* ctx, float* ws, float* y, void* stream) {
+    TTMI_REQUIRE(x && qkv_w && o_w && ln_g && ln_b && r_emb && r_w_bias && r_bias && ctx && ws && y, "attn_fwd: null pointer");
+    TTMI_REQUIRE(B > 0 && L > 0 && d > 0 && H > 0 && Dh > 0 && K > 0, "attn_fwd: bad dims");
+    TTMI_REQUIRE(mask_kind >= 0 && mask_kind <= 3, "attn_fwd: bad mask kind %d", mask_kind);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const AttnDims a(B, L, d, H, Dh, K);
+    AttnCtx c(ctx, a);
+    AttnWs w(ws, a);
+    const float scale = 1.0f / sqrtf((float)Dh);
+    // 1. qkv = x Wqkv^T
+    CK(ttmi_launch_gemm(mk(x, qkv_w, c.qkv, (int)a.BL, (int)a.W3, d, d, d, a.W3, NT_, prec), st));
+    // 2. qu = q + r_w_bias
+    CK(add_row_bias(c.qkv, a.W3, r_w_bias, a.BL, (int)a.HD, c.qu, a.HD, st));
+    // 3. effective tables for this length (clamped rows when L > K)
+    CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st));
+    // 4. G = q E^T + c into the pitch-(L+1) slab, column 0 zero
+    CK(memset2d(c.P, (size_t)(L + 1) * 4, 4, (size_t)B * H * L, st));
+    {
+        GemmDesc g = mk(c.qkv, w.E, c.P + 1, L, L, Dh, a.W3, a.HD, L + 1, NT_ | GEMM_BIAS, prec);
+        batch_bh(g, a, L * a.W3, Dh, 0, Dh, H * a.slab, a.slab);
+        g.bias = w.cT; g.sBias1 = 0; g.sBias2 = L;
+        CK(ttmi_launch_gemm(g, st));
+    }
+    // 5. S = shifted(G) + (q+u) k^T, accumulated through the pitch-L view
+    {
+        GemmDesc g = mk(c.qu, c.qkv + a.HD, c.P + L, L, L, Dh, a.HD, a.W3, L, NT_, prec);
+        batch_bh(g, a, L * a.HD, Dh, L * a.W3, Dh, H * a.slab, a.slab);
+        g.beta = 1.f;
+        CK(ttmi_launch_gemm(g, st));
+    }
+    // 6. P = softmax(scale * S, masked)
+    MaskDesc m;
+    m.kind = mask_kind; m.left = mask_left; m.right = mask_right; m.ptr = mask; m.sb = mask_sb; m.si = mask_si;
+    CK(softmax_fwd(c.P + L, B, H, L, L, a.slab, scale, m, st));
+    // 7. O = P V
+    {
+        GemmDesc g = mk(c.P + L, c.qkv + 2 * a.HD, c.O, L, Dh, L, L, a.W3, a.HD, NN_, prec);
+        batch_bh(g, a, H * a.slab, a.slab, L * a.W3, Dh, L * a.HD, Dh);
+        CK(ttmi_launch_gemm(g, st));
+    }
+    // 8. a = O Wo^T ; 9. y = LN(x + a)
+    CK(ttmi_launch_gemm(mk(c.O, o_w, w.a, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, NT_, prec), st));
+    CK(ln_fwd(x, w.a, ln_g, ln_b, a.BL, d, 1e-5f, c.s1, y, c.mean, c.rstd, st));
+    return TTMI_OK;
+}
+
+// Backward of ttmi_attn_fwd.  dx is written; every g_* buffer is ACCUMULATED into (zero them per step).
+int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const float* o_w, const float* ln_g,
+                  const float* r_emb, const float* r_bias, int B, int L, int d, int H, int Dh, int K, int prec,
+                  const float* ctx, float* ws, float* dx, float* g_qkv_w, float* g_o_w, float* g_ln_g, float* g_ln_b,
+                  float* g_r_emb, float* g_r_w_bias, float* g_r_bias, void* stream) {
+    TTMI_REQUIRE(dy && x && qkv_w && o_w && ln_g && r_emb && r_bias && ctx && ws && dx, "attn_bwd: null pointer");
+    TTMI_REQUIRE(g_qkv_w && g_o_w && g_ln_g && g_ln_b && g_r_emb && g_r_w_bias && g_r_bias, "attn_bwd: null gradient pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const AttnDims a(B, L, d, H, Dh, K);
+    AttnCtx c(const_cast<float*>(ctx), a);
+    AttnWs w(ws, a);
+    const float scale = 1.0f / sqrtf((float)Dh);
+    // 1. dres = LN'(dy) -> dx (doubles as the residual gradient)
+    CK(ln_bwd(dy, c.s1, c.mean, c.rstd, ln_g, nullptr, a.BL, d, dx, g_ln_g, g_ln_b, st));
+    // 2. gWo += dres^T O ; 3. dO = dres Wo
+    CK(wgrad(dx, c.O, g_o_w, d, (int)a.HD, (int)a.BL, d, a.HD, a.HD, prec, st));
+    CK(ttmi_launch_gemm(mk(dx, o_w, w.dO, (int)a.BL, (int)a.HD, d, d, a.HD, a.HD, NN_, prec), st));
+    // 4. dP = dO V^T through the pitch-L view of the dS slab (first L floats of each slab are outside the view)
+    CK(memset2d(w.dS, (size_t)a.slab * 4, (size_t)L * 4, (size_t)B * H, st));
+    {
+        GemmDesc g = mk(w.dO, c.qkv + 2 * a.HD, w.dS + L, L, L, Dh, a.HD, a.W3, L, NT_, prec);
+        batch_bh(g, a, L * a.HD, Dh, L * a.W3, Dh, H * a.slab, a.slab);
+        CK(ttmi_launch_gemm(g, st));
+    }
+    // 5. dV = P^T dO
+    {
+        GemmDesc g = mk(c.P + L, w.dO, w.dqkv + 2 * a.HD, L, Dh, L, L, a.HD, a.W3, TN_, prec);
+        batch_bh(g, a, H * a.slab, a.slab, L * a.HD, Dh, L * a.W3, Dh);
+        CK(ttmi_launch_gemm(g, st));
+    }
+    // 6. dS = P (dP - rowsum(dP P)) scale
+    CK(softmax_bwd(w.dS + L, c.P + L, B * H, L, L, a.slab, scale, st));
+    // 7. dq(content) = dS K -> dqkv[q]
+    {
+        GemmDesc g = mk(w.dS + L, c.qkv + a.HD, w.dqkv, L, Dh, L, L, a.W3, a.W3, NN_, prec);
+        batch_bh(g, a, H * a.slab, a.slab, L * a.W3, Dh, L * a.W3, Dh);
+        CK(ttmi_launch_gemm(g, st));
+    }
+    // 8. g r_w_bias += column sums of dq(content)
+    CK(colsum(w.dqkv, a.W3, a.BL, (int)a.HD, 1, 1, 0, 0, 0, 0, g_r_w_bias, st));
+    // 9. dK = dS^T (q + u)
+    {
+        GemmDesc g = mk(w.dS + L, c.qu, w.dqkv + a.HD, L, Dh, L, L, a.HD, a.W3, TN_, prec);
+        batch_bh(g, a, H * a.slab, a.slab, L * a.HD, Dh, L * a.W3, Dh);
+        CK(ttmi_launch_gemm(g, st));
+    }
+    // 10. dq += dG E   (dG = the same slab read with pitch L+1, column offset 1)
+    CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st));
+    {
+        GemmDesc g = mk(w.dS + 1, w.E, w.dqkv, L, Dh, L, L + 1, a.HD, a.W3, NN_, prec);
+        batch_bh(g, a, H * a.slab, a.slab, 0, Dh, L * a.W3, Dh);
+        g.beta = 1.f;
+        CK(ttmi_launch_gemm(g, st));
+    }
+    // 11. dE[p,h,:] = sum_b dG^T q ; 12. dc[h][p] = sum_b colsum(dG) ; 13. fold onto the K-row tables
+    CK(fill_zero(w.dE, sizeof(float) * (al4((size_t)L * a.HD) + al4((size_t)H * L)), st));   // dE and dcT are adjacent
+    {
+        GemmDesc g = mk(w.dS + 1, c.qkv, w.dE, L, Dh, L, L + 1, a.W3, a.HD, TN_ | GEMM_ATOMIC, prec);
+        batch_bh(g, a, H * a.slab, a.slab, L * a.W3, Dh, 0, Dh);
+        CK(ttmi_launch_gemm(g, st));
+    }
+    CK(colsum(w.dS + 1, L + 1, L, L, B, H, H * a.slab, a.slab, 0, L, w.dcT, st));
+    CK(relpos_scatter(w.dE, w.dcT, K, L, H, Dh, g_r_emb, g_r_bias, st));
+    // 14. gWqkv += dqkv^T x ; 15. dx += dqkv Wqkv
+    CK(wgrad(w.dqkv, x, g_qkv_w, (int)a.W3, d, (int)a.BL, a.W3, d, d, prec, st));
+    {
+        GemmDesc g = mk(w.dqkv, qkv_w, dx, (int)a.BL, d, (int)a.W3, a.W3, d, d, NN_, prec);
+        g.beta = 1.f;
+        CK(ttmi_launch_gemm(g, st));
+    }
+    return TTMI_OK;
+}
+
+// ------------------------------------------------------------------ position-wise FFN (tt/transformer.py:54-58)
+size_t ttmi_ffn_ctx_floats(long rows, int d, int Di) { return 2 * al4(rows * d) + al4(rows * Di) + 4 * al4(rows); }
+size_t ttmi_ffn_ws_floats(long rows, int d, int Di) { return 2 * al4(rows * d) + al4(rows * Di); }
+
+// z = LN(y + W2 relu(W1 LN(y) + b1) + b2), the SAME (ln_g, ln_b) in both norms.
+int ttmi_ffn_fwd(const float* y, const float* w1, const float* b1, const float* w2, const float* b2, const float* ln_g,
+                 const float* ln_b, long rows, int d, int Di, int prec, float* ctx, float* ws, float* z, void* stream) {
+    TTMI_REQUIRE(y && w1 && b1 && w2 && b2 && ln_g && ln_b && ctx && ws && z, "ffn_fwd: null pointer");
+    TTMI_REQUIRE(rows > 0 && rows < (1L << 31) && d > 0 && Di > 0, "ffn_fwd: bad dims");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* h = ctx;
+    float* s2 = h + al4(rows * d);
+    float* a1 = s2 + al4(rows * d);
+    float* mean1 = a1 + al4(rows * Di);
+    float* rstd1 = mean1 + al4(rows);
+    float* mean2 = rstd1 + al4(rows);
+    float* rstd2 = mean2 + al4(rows);
+    float* f = ws;
+    CK(ln_fwd(y, nullptr, ln_g, ln_b, rows, d, 1e-5f, nullptr, h, mean1, rstd1, st));
+    {
+        GemmDesc g = mk(h, w1, a1, (int)rows, Di, d, d, d, Di, NT_ | GEMM_BIAS | GEMM_RELU, prec);
+        g.bias = b1;
+        CK(ttmi_launch_gemm(g, st));
+    }
+    {
+        GemmDesc g = mk(a1, w2, f, (int)rows, d, Di, Di, Di, d, NT_ | GEMM_BIAS, prec);
+        g.bias = b2;
+        CK(ttmi_launch_gemm(g, st));
+    }
+    CK(ln_fwd(y, f, ln_g, ln_b, rows, d, 1e-5f, s2, z, mean2, rstd2, st));
+    return TTMI_OK;
+}
+
+int ttmi_ffn_bwd(const float* dz, const float* y, const float* w1, const float* w2, const float* ln_g, long rows, int d, int Di,
+                 int prec, const float* ctx, float* ws, float* dy, float* g_w1, float* g_b1, float* g_w2, float* g_b2,
+                 float* g_ln_g, float* g_ln_b, void* stream) {
+    TTMI_REQUIRE(dz && y && w1 && w2 && ln_g && ctx && ws && dy && g_w1 && g_b1 && g_w2 && g_b2 && g_ln_g && g_ln_b,
+                 "ffn_bwd: null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float* h = ctx;
+    const float* s2 = h + al4(rows * d);
+    const float* a1 = s2 + al4(rows * d);
+    const float* mean1 = a1 + al4(rows * Di);
+    const float* rstd1 = mean1 + al4(rows);
+    const float* mean2 = rstd1 + al4(rows);
+    const float* rstd2 = mean2 + al4(rows);
+    float* dres = ws;
+    float* dh = dres + al4(rows * d);
+    float* da1 = dh + al4(rows * d);
+    CK(ln_bwd(dz, s2, mean2, rstd2, ln_g, nullptr, rows, d, dres, g_ln_g, g_ln_b, st));
+    CK(colsum(dres, d, rows, d, 1, 1, 0, 0, 0, 0, g_b2, st));
+    CK(wgrad(dres, a1, g_w2, d, Di, (int)rows, d, Di, Di, prec, st));
+    {
+        GemmDesc g = mk(dres, w2, da1, (int)rows, Di, d, d, Di, Di, NN_ | GEMM_MASK_AUX, prec);
+        g.aux = a1;
+        CK(ttmi_launch_gemm(g, st));
+    }
+    CK(colsum(da1, Di, rows, Di, 1, 1, 0, 0, 0, 0, g_b1, st));
+    CK(wgrad(da1, h, g_w1, Di, d, (int)rows, Di, d, d, prec, st));
+    CK(ttmi_launch_gemm(mk(da1, w1, dh, (int)rows, d, Di, Di, d, d, NN_, prec), st));
+    CK(ln_bwd(dh, y, mean1, rstd1, ln_g, dres, rows, d, dy, g_ln_g, g_ln_b, st));
+    return TTMI_OK;
+}
+
+// ------------------------------------------------------------------ joint network (tt/model.py:20-39)
+// z[b,t,u,:] = Wp tanh(We enc[b,t] + Wd dec[b,u] + bf) + bp, forward_layer.weight = [We | Wd] ([J, de+dd]).
+// The reference repeats enc/dec to [B,T,U1,de+dd] and concatenates; the split-weight form is the same
+// arithmetic without the 3 x [B,T,U1,*] temporaries.
+size_t ttmi_joint_ctx_floats(int B, int T, int U1, int J) { return al4((size_t)B * T * U1 * J); }
+size_t ttmi_joint_ws_floats(int B, int T, int U1, int J) {
+    return al4((size_t)B * T * U1 * J) + 2 * al4((size_t)B * T * J) + 2 * al4((size_t)B * U1 * J);
+}
+
+int ttmi_joint_fwd(const float* enc, const float* dec, const float* wf, const float* bf, const float* wp, const float* bp,
+                   int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx, float* ws, float* logits,
+                   void* stream) {
+    TTMI_REQUIRE(enc && dec && wf && bf && wp && bp && ctx && ws && logits, "joint_fwd: null pointer");
+    TTMI_REQUIRE(B > 0 && T > 0 && U1 > 0 && de > 0 && dd > 0 && J > 0 && V > 0, "joint_fwd: bad dims");
+    TTMI_REQUIRE((long)B * T * U1 < (1L << 31), "joint_fwd: B*T*(U+1) too large");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* Hh = ctx;
+    float* PE = ws + al4((size_t)B * T * U1 * J);
+    float* PD = PE + al4((size_t)B * T * J);
+    const int din = de + dd;
+    CK(ttmi_launch_gemm(mk(enc, wf, PE, B * T, J, de, de, din, J, NT_, prec), st));
+    CK(ttmi_launch_gemm(mk(dec, wf + de, PD, B * U1, J, dd, dd, din, J, NT_, prec), st));
+    CK(joint_tanh_fwd(PE, PD, bf, B, T, U1, J, Hh, 0, st));
+    {
+        GemmDesc g = mk(Hh, wp, logits, B * T * U1, V, J, J, J, V, NT_ | GEMM_BIAS, prec);
+        g.bias = bp;
+        CK(ttmi_launch_gemm(g, st));
+    }
+    return TTMI_OK;
+}
+
+int ttmi_joint_bwd(const float* dlogits, const float* enc, const float* dec, const float* wf, const float* wp, int B, int T,
+                   int U1, int de, int dd, int J, int V, int prec, const float* ctx, float* ws, float* denc, float* ddec,
+                   float* g_wf, float* g_bf, float* g_wp, float* g_bp, void* stream) {
+    TTMI_REQUIRE(dlogits && enc && dec && wf && wp && ctx && ws && denc && ddec && g_wf && g_bf && g_wp && g_bp,
+                 "joint_bwd: null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float* Hh = ctx;
+    float* dH = ws;
+    float* dPE = ws + al4((size_t)B * T * U1 * J);
+    float* dPD = dPE + 2 * al4((size_t)B * T * J);
+    const int din = de + dd;
+    const int M = B * T * U1;
+    CK(colsum(dlogits, V, M, V, 1, 1, 0, 0, 0, 0, g_bp, st));
+    CK(wgrad(dlogits, Hh, g_wp, V, J, M, V, J, J, prec, st));
+    CK(ttmi_launch_gemm(mk(dlogits, wp, dH, M, J, V, V, J, J, NN_, prec), st));
+    CK(fill_zero(dPD, sizeof(float) * (size_t)B * U1 * J, st));
+    CK(joint_tanh_bwd(dH, Hh, 0, B, T, U1, J, dPE, dPD, st));
+    CK(colsum(dPE, J, (long)B * T, J, 1, 1, 0, 0, 0, 0, g_bf, st));
+    CK(wgrad(dPE, enc, g_wf, J, de, B * T, J, de, din, prec, st));
+    CK(wgrad(dPD, dec, g_wf + de, J, dd, B * U1, J, dd, din, prec, st));
+    CK(ttmi_launch_gemm(mk(dPE, wf, denc, B * T, de, J, J, din, de, NN_, prec), st));
+    CK(ttmi_launch_gemm(mk(dPD, wf + de, ddec, B * U1, dd, J, J, din, dd, NN_, prec), st));
+    return TTMI_OK;
+}
+
+// ------------------------------------------------------------------ embedding (tt/decoder.py:26,39)
+int ttmi_embed_fwd(const long* tokens, const float* W, long n, int d, int V, float* out, void* stream) {
+    return embed_fwd(tokens, W, n, d, V, out, static_cast<hipStream_t>(stream));
+}
+int ttmi_embed_bwd(const long* tokens, const float* dout, long n, int d, int V, int padding_idx, float* gW, void* stream) {
+    return embed_bwd(tokens, dout, n, d, V, padding_idx, gW, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

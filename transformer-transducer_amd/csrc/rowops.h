@@ -1,0 +1,43 @@
+// Internal launchers of the HBM-bound row kernels (rowops.hip).  Not part of the C ABI.
+#pragma once
+#include "common.h"
+
+enum MaskKind { MASK_NONE = 0, MASK_CAUSAL = 1, MASK_BAND = 2, MASK_TENSOR = 3 };
+
+struct MaskDesc {
+    int kind = MASK_NONE;
+    int left = 0, right = 0;            // MASK_BAND: masked iff j > i + right or j < i - left
+    const uint8_t* ptr = nullptr;       // MASK_TENSOR: nonzero = masked, element (b,i,j) at ptr[b*sb + i*si + j]
+    long sb = 0, si = 0;
+};
+
+// y = LN(x + res) * g + b ; optionally stores s = x + res, mean, rstd (for backward)
+int ln_fwd(const float* x, const float* res, const float* g, const float* b, long rows, int d, float eps, float* s_out,
+           float* y, float* mean, float* rstd, hipStream_t st);
+// dx = dadd + LN'(dy) ; dgamma/dbeta accumulated atomically (caller zeroes them once per step)
+int ln_bwd(const float* dy, const float* s, const float* mean, const float* rstd, const float* g, const float* dadd, long rows,
+           int d, float* dx, float* dgamma, float* dbeta, hipStream_t st);
+// in-place P = softmax_j(scale * S) over the batched score view (nb slabs, L rows of ld floats each)
+int softmax_fwd(float* S, int nb, int nh, int L, long ld, long slab, float scale, const MaskDesc& m, hipStream_t st);
+// in-place dS = P * (dP - sum_j dP*P) * scale
+int softmax_bwd(float* dP, const float* P, int nb, int L, long ld, long slab, float scale, hipStream_t st);
+// out[r, c] = in[r*ldi + c] + bias[c]
+int add_row_bias(const float* in, long ldi, const float* bias, long rows, int cols, float* out, long ldo, hipStream_t st);
+// out[z][c] += sum_r in[z][r*ld + c]   (atomic; out zeroed by the caller).  z = z1*nz2+z2 with strides; the
+// output offset for batch z is z2*so2 (z1 always accumulates into the same row) unless so1 != 0.
+int colsum(const float* in, long ld, long rows, int cols, int nz1, int nz2, long si1, long si2, long so1, long so2, float* out,
+           hipStream_t st);
+// E[p,h,:] = r_emb[e(p),h,:], cT[h][p] = r_bias[e(p),h], e(p) = max(0, p + K - L)
+int relpos_gather(const float* r_emb, const float* r_bias, int K, int L, int H, int Dh, float* E, float* cT, hipStream_t st);
+// g_r_emb[e(p),h,:] += dE[p,h,:], g_r_bias[e(p),h] += dcT[h][p]
+int relpos_scatter(const float* dE, const float* dcT, int K, int L, int H, int Dh, float* g_r_emb, float* g_r_bias,
+                   hipStream_t st);
+int embed_fwd(const long* tokens, const float* W, long n, int d, int V, float* out, hipStream_t st);
+int embed_bwd(const long* tokens, const float* dout, long n, int d, int V, int padding_idx, float* gW, hipStream_t st);
+// H[b,t,u,:] = tanh(PE[b,t,:] + PD[b,u,:] + bias)    (H f32 or bf16)
+int joint_tanh_fwd(const float* PE, const float* PD, const float* bias, int B, int T, int U1, int J, void* H, int h_dtype,
+                   hipStream_t st);
+// dpre = dH * (1 - H^2);  dPE[b,t,:] = sum_u dpre, dPD[b,u,:] += sum_t dpre (atomic; caller zeroes dPD)
+int joint_tanh_bwd(const void* dH, const void* H, int h_dtype, int B, int T, int U1, int J, float* dPE, float* dPD,
+                   hipStream_t st);
+int fill_zero(void* p, size_t bytes, hipStream_t st);

@@ -1,0 +1,439 @@
+// HBM-bound row kernels of the Transformer-Transducer path (LayerNorm, masked softmax over the
+// relative-position score view, bias/column reductions, relative-position table gather/scatter,
+// embedding, joint tanh).  One wave (64 lanes) per row, 16-byte accesses where alignment allows,
+// wave reductions by __shfl_xor; cross-row reductions finish with float atomics (agent scope).
+// Reference arithmetic: tt/transformer.py:52-58,148-175, tt/decoder.py:26,39, tt/model.py:33-37.
+#include "rowops.h"
+
+namespace {
+
+constexpr int WPB = 4;   // waves per block for the wave-per-row kernels
+
+__device__ __forceinline__ long wave_row() { return (long)blockIdx.x * WPB + (threadIdx.x >> 6); }
+
+// ------------------------------------------------------------------ LayerNorm
+__global__ __launch_bounds__(WPB * 64) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                          const float* __restrict__ g, const float* __restrict__ b, long rows,
+                                                          int d, float eps, float* __restrict__ s_out, float* __restrict__ y,
+                                                          float* __restrict__ mean_o, float* __restrict__ rstd_o, int vec) {
+    const long r = wave_row();
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + r * d;
+    const float* rr = res ? res + r * d : nullptr;
+    float* sr = s_out ? s_out + r * d : nullptr;
+    float* yr = y + r * d;
+    float sum = 0.f;
+    if (vec) {
+        for (int i = lane * 4; i < d; i += 256) {
+            float4 v = *reinterpret_cast<const float4*>(xr + i);
+            if (rr) {
+                const float4 w = *reinterpret_cast<const float4*>(rr + i);
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
+            if (sr) *reinterpret_cast<float4*>(sr + i) = v;
+            sum += (v.x + v.y) + (v.z + v.w);
+        }
+    } else {
+        for (int i = lane; i < d; i += 64) {
+            float v = xr[i] + (rr ? rr[i] : 0.f);
+            if (sr) sr[i] = v;
+            sum += v;
+        }
+    }
+    const float mean = wave_sum(sum) / d;
+    float sq = 0.f;
+    auto val = [&](int i) -> float { return xr[i] + (rr ? rr[i] : 0.f); };
+    if (vec) {
+        for (int i = lane * 4; i < d; i += 256) {
+            float4 v = *reinterpret_cast<const float4*>(xr + i);
+            if (rr) {
+                const float4 w = *reinterpret_cast<const float4*>(rr + i);
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
+            const float a = v.x - mean, bq = v.y - mean, c = v.z - mean, e = v.w - mean;
+            sq += (a * a + bq * bq) + (c * c + e * e);
+        }
+    } else {
+        for (int i = lane; i < d; i += 64) {
+            const float a = val(i) - mean;
+            sq += a * a;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / d + eps);
+    if (lane == 0) {
+        if (mean_o) mean_o[r] = mean;
+        if (rstd_o) rstd_o[r] = rstd;
+    }
+    if (vec) {
+        for (int i = lane * 4; i < d; i += 256) {
+            float4 v = *reinterpret_cast<const float4*>(xr + i);
+            if (rr) {
+                const float4 w = *reinterpret_cast<const float4*>(rr + i);
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
+            const float4 gg = *reinterpret_cast<const float4*>(g + i);
+            const float4 bb = *reinterpret_cast<const float4*>(b + i);
+            float4 o;
+            o.x = (v.x - mean) * rstd * gg.x + bb.x;
+            o.y = (v.y - mean) * rstd * gg.y + bb.y;
+            o.z = (v.z - mean) * rstd * gg.z + bb.z;
+            o.w = (v.w - mean) * rstd * gg.w + bb.w;
+            *reinterpret_cast<float4*>(yr + i) = o;
+        }
+    } else {
+        for (int i = lane; i < d; i += 64) yr[i] = (val(i) - mean) * rstd * g[i] + b[i];
+    }
+}
+
+__global__ __launch_bounds__(WPB * 64) void ln_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ s,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const float* __restrict__ g, const float* __restrict__ dadd,
+                                                             long rows, int d, float* __restrict__ dx) {
+    const long r = wave_row();
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float mu = mean[r], rs = rstd[r];
+    const float* dyr = dy + r * d;
+    const float* sr = s + r * d;
+    float m1 = 0.f, m2 = 0.f;
+    for (int i = lane; i < d; i += 64) {
+        const float dxh = dyr[i] * g[i];
+        const float xh = (sr[i] - mu) * rs;
+        m1 += dxh;
+        m2 += dxh * xh;
+    }
+    m1 = wave_sum(m1) / d;
+    m2 = wave_sum(m2) / d;
+    for (int i = lane; i < d; i += 64) {
+        const float dxh = dyr[i] * g[i];
+        const float xh = (sr[i] - mu) * rs;
+        float v = rs * (dxh - m1 - xh * m2);
+        if (dadd) v += dadd[r * d + i];
+        dx[r * d + i] = v;
+    }
+}
+
+constexpr int LNP_ROWS = 64;
+__global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restrict__ dy, const float* __restrict__ s,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            long rows, int d, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    const long r0 = (long)blockIdx.y * LNP_ROWS;
+    const long r1 = r0 + LNP_ROWS < rows ? r0 + LNP_ROWS : rows;
+    float ag = 0.f, ab = 0.f;
+    for (long r = r0; r < r1; ++r) {
+        const float v = dy[r * d + c];
+        ag += v * (s[r * d + c] - mean[r]) * rstd[r];
+        ab += v;
+    }
+    atomicAdd(dgamma + c, ag);
+    atomicAdd(dbeta + c, ab);
+}
+
+// ------------------------------------------------------------------ masked softmax on the score view
+__device__ __forceinline__ bool masked_at(const MaskDesc& m, int b, int i, int j) {
+    switch (m.kind) {
+        case MASK_CAUSAL: return j > i;
+        case MASK_BAND: return (j > i + m.right) || (j < i - m.left);
+        case MASK_TENSOR: return m.ptr[(long)b * m.sb + (long)i * m.si + j] != 0;
+        default: return false;
+    }
+}
+
+__global__ __launch_bounds__(WPB * 64) void softmax_fwd_kernel(float* __restrict__ S, long nrows, int nh, int L, long ld,
+                                                               long slab, float scale, const MaskDesc m) {
+    const long r = wave_row();
+    if (r >= nrows) return;
+    const int lane = threadIdx.x & 63;
+    const int i = (int)(r % L);
+    const long sl = r / L;
+    const int b = (int)(sl / nh);
+    float* row = S + sl * slab + (long)i * ld;
+    float mx = -INFINITY;
+    for (int j = lane; j < L; j += 64) {
+        const float v = masked_at(m, b, i, j) ? -INFINITY : row[j] * scale;
+        mx = fmaxf(mx, v);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < L; j += 64) {
+        const float v = masked_at(m, b, i, j) ? -INFINITY : row[j] * scale;
+        sum += __expf(v - mx);
+    }
+    const float inv = 1.f / wave_sum(sum);
+    for (int j = lane; j < L; j += 64) {
+        const float v = masked_at(m, b, i, j) ? -INFINITY : row[j] * scale;
+        row[j] = __expf(v - mx) * inv;
+    }
+}
+
+__global__ __launch_bounds__(WPB * 64) void softmax_bwd_kernel(float* __restrict__ dP, const float* __restrict__ P, long nrows,
+                                                               int L, long ld, long slab, float scale) {
+    const long r = wave_row();
+    if (r >= nrows) return;
+    const int lane = threadIdx.x & 63;
+    const int i = (int)(r % L);
+    const long sl = r / L;
+    float* drow = dP + sl * slab + (long)i * ld;
+    const float* prow = P + sl * slab + (long)i * ld;
+    float dot = 0.f;
+    for (int j = lane; j < L; j += 64) dot += drow[j] * prow[j];
+    dot = wave_sum(dot);
+    for (int j = lane; j < L; j += 64) drow[j] = prow[j] * (drow[j] - dot) * scale;
+}
+
+// ------------------------------------------------------------------ small elementwise / reductions
+__global__ void add_row_bias_kernel(const float* __restrict__ in, long ldi, const float* __restrict__ bias, long rows, int cols,
+                                    float* __restrict__ out, long ldo) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const long r = idx / cols;
+    const int c = (int)(idx % cols);
+    out[r * ldo + c] = in[r * ldi + c] + bias[c];
+}
+
+constexpr int CS_ROWS = 128;
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, long ld, long rows, int cols, int nz2,
+                                                     long si1, long si2, long so1, long so2, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const int z = blockIdx.z, z1 = z / nz2, z2 = z % nz2;
+    const float* p = in + z1 * si1 + z2 * si2;
+    const long r0 = (long)blockIdx.y * CS_ROWS;
+    const long r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
+    float a = 0.f;
+    for (long r = r0; r < r1; ++r) a += p[r * ld + c];
+    atomicAdd(out + z1 * so1 + z2 * so2 + c, a);
+}
+
+__global__ void relpos_gather_kernel(const float* __restrict__ r_emb, const float* __restrict__ r_bias, int K, int L, int H,
+                                     int Dh, float* __restrict__ E, float* __restrict__ cT) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)L * H * Dh;
+    if (idx < n) {
+        const int p = (int)(idx / (H * Dh));
+        const int e = max(0, p + K - L);
+        E[idx] = r_emb[(long)e * H * Dh + idx % (H * Dh)];
+    }
+    if (idx < (long)L * H) {
+        const int h = (int)(idx / L), p = (int)(idx % L);
+        const int e = max(0, p + K - L);
+        cT[idx] = r_bias[(long)e * H + h];
+    }
+}
+
+__global__ void relpos_scatter_kernel(const float* __restrict__ dE, const float* __restrict__ dcT, int K, int L, int H, int Dh,
+                                      float* __restrict__ g_emb, float* __restrict__ g_bias) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)L * H * Dh;
+    if (idx < n) {
+        const int p = (int)(idx / (H * Dh));
+        const int e = max(0, p + K - L);
+        atomicAdd(g_emb + (long)e * H * Dh + idx % (H * Dh), dE[idx]);
+    }
+    if (idx < (long)L * H) {
+        const int h = (int)(idx / L), p = (int)(idx % L);
+        const int e = max(0, p + K - L);
+        atomicAdd(g_bias + (long)e * H + h, dcT[idx]);
+    }
+}
+
+__global__ void embed_fwd_kernel(const long* __restrict__ tok, const float* __restrict__ W, long n, int d, int V,
+                                 float* __restrict__ out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * d) return;
+    const long r = idx / d;
+    long t = tok[r];
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    out[idx] = W[t * d + idx % d];
+}
+
+__global__ void embed_bwd_kernel(const long* __restrict__ tok, const float* __restrict__ dout, long n, int d, int V, int pad,
+                                 float* __restrict__ gW) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * d) return;
+    const long r = idx / d;
+    const long t = tok[r];
+    if (t == pad || t < 0 || t >= V) return;
+    atomicAdd(gW + t * d + idx % d, dout[idx]);
+}
+
+// ------------------------------------------------------------------ joint: H = tanh(PE[b,t] + PD[b,u] + bias)
+template <typename TH>
+__global__ __launch_bounds__(256) void joint_tanh_fwd_kernel(const float* __restrict__ PE, const float* __restrict__ PD,
+                                                             const float* __restrict__ bias, int T, int U1, int J,
+                                                             TH* __restrict__ H) {
+    const long bt = blockIdx.x;            // (b, t)
+    const int b = (int)(bt / T);
+    const float* pe = PE + bt * J;
+    for (int j = threadIdx.x; j < J; j += 256) {
+        const float e = pe[j] + bias[j];
+        for (int u = 0; u < U1; ++u) {
+            const float v = tanhf(e + PD[((long)b * U1 + u) * J + j]);
+            const long o = (bt * U1 + u) * J + j;
+            if constexpr (sizeof(TH) == 4) H[o] = v;
+            else H[o] = f32_to_bf16(v);
+        }
+    }
+}
+
+constexpr int JT_TC = 16;
+template <typename TH>
+__global__ __launch_bounds__(256) void joint_tanh_bwd_kernel(const TH* __restrict__ dH, const TH* __restrict__ H, int T, int U1,
+                                                             int J, float* __restrict__ dPE, float* __restrict__ dPD) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= J) return;
+    const int t0 = blockIdx.y * JT_TC;
+    const int b = blockIdx.z;
+    float accE[JT_TC];
+#pragma unroll
+    for (int i = 0; i < JT_TC; ++i) accE[i] = 0.f;
+    for (int u = 0; u < U1; ++u) {
+        float accD = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < JT_TC; ++tt) {
+            const int t = t0 + tt;
+            if (t < T) {
+                const long o = (((long)b * T + t) * U1 + u) * J + j;
+                float h, g;
+                if constexpr (sizeof(TH) == 4) { h = H[o]; g = dH[o]; }
+                else { h = bf16_to_f32(H[o]); g = bf16_to_f32(dH[o]); }
+                const float v = g * (1.f - h * h);
+                accE[tt] += v;
+                accD += v;
+            }
+        }
+        atomicAdd(dPD + ((long)b * U1 + u) * J + j, accD);
+    }
+#pragma unroll
+    for (int tt = 0; tt < JT_TC; ++tt)
+        if (t0 + tt < T) dPE[((long)b * T + t0 + tt) * J + j] = accE[tt];
+}
+
+}  // namespace
+
+int ln_fwd(const float* x, const float* res, const float* g, const float* b, long rows, int d, float eps, float* s_out,
+           float* y, float* mean, float* rstd, hipStream_t st) {
+    TTMI_REQUIRE(x && g && b && y && rows > 0 && d > 0, "ln_fwd: bad arguments");
+    const int vec = (d % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(g) && aligned16(b) && (!res || aligned16(res)) &&
+                    (!s_out || aligned16(s_out));
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(rows, WPB)), dim3(WPB * 64), 0, st, x, res, g, b, rows, d, eps, s_out, y, mean,
+                       rstd, vec);
+    TTMI_LAUNCH_CHECK("ln_fwd_kernel");
+    return TTMI_OK;
+}
+
+int ln_bwd(const float* dy, const float* s, const float* mean, const float* rstd, const float* g, const float* dadd, long rows,
+           int d, float* dx, float* dgamma, float* dbeta, hipStream_t st) {
+    TTMI_REQUIRE(dy && s && mean && rstd && g && dx && dgamma && dbeta && rows > 0 && d > 0, "ln_bwd: bad arguments");
+    hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3(cdiv(rows, WPB)), dim3(WPB * 64), 0, st, dy, s, mean, rstd, g, dadd, rows, d, dx);
+    TTMI_LAUNCH_CHECK("ln_bwd_dx_kernel");
+    hipLaunchKernelGGL(ln_bwd_params_kernel, dim3(cdiv(d, 256), cdiv(rows, LNP_ROWS)), dim3(256), 0, st, dy, s, mean, rstd, rows,
+                       d, dgamma, dbeta);
+    TTMI_LAUNCH_CHECK("ln_bwd_params_kernel");
+    return TTMI_OK;
+}
+
+int softmax_fwd(float* S, int nb, int nh, int L, long ld, long slab, float scale, const MaskDesc& m, hipStream_t st) {
+    TTMI_REQUIRE(S && nb > 0 && nh > 0 && L > 0, "softmax_fwd: bad arguments");
+    TTMI_REQUIRE(m.kind != MASK_TENSOR || m.ptr, "softmax_fwd: tensor mask without pointer");
+    const long nrows = (long)nb * nh * L;
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3(cdiv(nrows, WPB)), dim3(WPB * 64), 0, st, S, nrows, nh, L, ld, slab, scale, m);
+    TTMI_LAUNCH_CHECK("softmax_fwd_kernel");
+    return TTMI_OK;
+}
+
+int softmax_bwd(float* dP, const float* P, int nb, int L, long ld, long slab, float scale, hipStream_t st) {
+    TTMI_REQUIRE(dP && P && nb > 0 && L > 0, "softmax_bwd: bad arguments");
+    const long nrows = (long)nb * L;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(cdiv(nrows, WPB)), dim3(WPB * 64), 0, st, dP, P, nrows, L, ld, slab, scale);
+    TTMI_LAUNCH_CHECK("softmax_bwd_kernel");
+    return TTMI_OK;
+}
+
+int add_row_bias(const float* in, long ldi, const float* bias, long rows, int cols, float* out, long ldo, hipStream_t st) {
+    TTMI_REQUIRE(in && bias && out && rows > 0 && cols > 0, "add_row_bias: bad arguments");
+    hipLaunchKernelGGL(add_row_bias_kernel, dim3(cdiv(rows * cols, 256)), dim3(256), 0, st, in, ldi, bias, rows, cols, out, ldo);
+    TTMI_LAUNCH_CHECK("add_row_bias_kernel");
+    return TTMI_OK;
+}
+
+int colsum(const float* in, long ld, long rows, int cols, int nz1, int nz2, long si1, long si2, long so1, long so2, float* out,
+           hipStream_t st) {
+    TTMI_REQUIRE(in && out && rows > 0 && cols > 0 && nz1 > 0 && nz2 > 0, "colsum: bad arguments");
+    dim3 grid(cdiv(cols, 256), cdiv(rows, CS_ROWS), nz1 * nz2);
+    TTMI_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "colsum: grid too large");
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, in, ld, rows, cols, nz2, si1, si2, so1, so2, out);
+    TTMI_LAUNCH_CHECK("colsum_kernel");
+    return TTMI_OK;
+}
+
+int relpos_gather(const float* r_emb, const float* r_bias, int K, int L, int H, int Dh, float* E, float* cT, hipStream_t st) {
+    TTMI_REQUIRE(r_emb && r_bias && E && cT && K > 0 && L > 0, "relpos_gather: bad arguments");
+    hipLaunchKernelGGL(relpos_gather_kernel, dim3(cdiv((long)L * H * Dh, 256)), dim3(256), 0, st, r_emb, r_bias, K, L, H, Dh, E,
+                       cT);
+    TTMI_LAUNCH_CHECK("relpos_gather_kernel");
+    return TTMI_OK;
+}
+
+int relpos_scatter(const float* dE, const float* dcT, int K, int L, int H, int Dh, float* g_r_emb, float* g_r_bias,
+                   hipStream_t st) {
+    TTMI_REQUIRE(dE && dcT && g_r_emb && g_r_bias, "relpos_scatter: bad arguments");
+    hipLaunchKernelGGL(relpos_scatter_kernel, dim3(cdiv((long)L * H * Dh, 256)), dim3(256), 0, st, dE, dcT, K, L, H, Dh, g_r_emb,
+                       g_r_bias);
+    TTMI_LAUNCH_CHECK("relpos_scatter_kernel");
+    return TTMI_OK;
+}
+
+int embed_fwd(const long* tokens, const float* W, long n, int d, int V, float* out, hipStream_t st) {
+    TTMI_REQUIRE(tokens && W && out && n > 0 && d > 0 && V > 0, "embed_fwd: bad arguments");
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(cdiv(n * d, 256)), dim3(256), 0, st, tokens, W, n, d, V, out);
+    TTMI_LAUNCH_CHECK("embed_fwd_kernel");
+    return TTMI_OK;
+}
+
+int embed_bwd(const long* tokens, const float* dout, long n, int d, int V, int padding_idx, float* gW, hipStream_t st) {
+    TTMI_REQUIRE(tokens && dout && gW && n > 0 && d > 0 && V > 0, "embed_bwd: bad arguments");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(cdiv(n * d, 256)), dim3(256), 0, st, tokens, dout, n, d, V, padding_idx, gW);
+    TTMI_LAUNCH_CHECK("embed_bwd_kernel");
+    return TTMI_OK;
+}
+
+int joint_tanh_fwd(const float* PE, const float* PD, const float* bias, int B, int T, int U1, int J, void* H, int h_dtype,
+                   hipStream_t st) {
+    TTMI_REQUIRE(PE && PD && bias && H && B > 0 && T > 0 && U1 > 0 && J > 0, "joint_tanh_fwd: bad arguments");
+    if (h_dtype == 0)
+        hipLaunchKernelGGL(joint_tanh_fwd_kernel<float>, dim3(B * T), dim3(256), 0, st, PE, PD, bias, T, U1, J,
+                           static_cast<float*>(H));
+    else
+        hipLaunchKernelGGL(joint_tanh_fwd_kernel<bf16_t>, dim3(B * T), dim3(256), 0, st, PE, PD, bias, T, U1, J,
+                           static_cast<bf16_t*>(H));
+    TTMI_LAUNCH_CHECK("joint_tanh_fwd_kernel");
+    return TTMI_OK;
+}
+
+int joint_tanh_bwd(const void* dH, const void* H, int h_dtype, int B, int T, int U1, int J, float* dPE, float* dPD,
+                   hipStream_t st) {
+    TTMI_REQUIRE(dH && H && dPE && dPD && B > 0 && T > 0 && U1 > 0 && J > 0, "joint_tanh_bwd: bad arguments");
+    dim3 grid(cdiv(J, 256), cdiv(T, JT_TC), B);
+    if (h_dtype == 0)
+        hipLaunchKernelGGL(joint_tanh_bwd_kernel<float>, grid, dim3(256), 0, st, static_cast<const float*>(dH),
+                           static_cast<const float*>(H), T, U1, J, dPE, dPD);
+    else
+        hipLaunchKernelGGL(joint_tanh_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, static_cast<const bf16_t*>(dH),
+                           static_cast<const bf16_t*>(H), T, U1, J, dPE, dPD);
+    TTMI_LAUNCH_CHECK("joint_tanh_bwd_kernel");
+    return TTMI_OK;
+}
+
+int fill_zero(void* p, size_t bytes, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(p, 0, bytes, st);
+    if (e != hipSuccess) {
+        ttmi_set_error("fill_zero: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return TTMI_OK;
+}

@@ -1,0 +1,56 @@
+"""Label encoder stack (reference tt/decoder.py): Embedding(V, d, padding_idx=0) named `dec_embedding`
++ N layers of the same relative-position block; BuildDecoder(config)(tokens[B,U], mask=None) -> [B,U,d]."""
+import torch
+import torch.nn as nn
+
+from ttmi import ops
+from tt.transformer import RelLearnableDecoderLayer, as_mask_spec
+
+
+class _EmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tokens, weight, padding_idx):
+        tokens = tokens.contiguous()
+        ctx.save_for_backward(tokens)
+        ctx.shape, ctx.padding_idx = weight.shape, padding_idx
+        return ops.embed_fwd(tokens, weight.detach())
+
+    @staticmethod
+    def backward(ctx, dout):
+        (tokens,) = ctx.saved_tensors
+        gW = torch.zeros(ctx.shape, dtype=torch.float32, device=dout.device)
+        ops.embed_bwd(tokens, dout.contiguous(), ctx.shape[0], ctx.padding_idx, gW)
+        return None, gW, None
+
+
+class BaseDecoder(nn.Module):
+    def __init__(self, vocab_size, n_layer, k_len, n_head, d_model, d_head, d_inner, dropout, **kwargs):
+        super().__init__()
+        self.r_emb = nn.Parameter(torch.randn((k_len, n_head, d_head), dtype=torch.float32))
+        self.r_w_bias = nn.Parameter(torch.randn((n_head, d_head), dtype=torch.float32))
+        self.r_bias = nn.Parameter(torch.randn((k_len, n_head), dtype=torch.float32))
+        self.MultiHeadAttention = RelLearnableDecoderLayer(n_head, d_model, d_head, d_inner, dropout, **kwargs)
+
+    def forward_bm(self, x, mask):
+        return self.MultiHeadAttention.forward_bm(x, self.r_emb, self.r_w_bias, self.r_bias, mask)
+
+    def forward(self, inputs, attn_mask=None):          # reference contract: time-major [U, B, d]
+        return self.MultiHeadAttention(inputs, self.r_emb, self.r_w_bias, self.r_bias, attn_mask)
+
+
+class BuildDecoder(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dec_embedding = nn.Embedding(config.vocab_size, config.dec.d_model, padding_idx=0)
+        self.layers = nn.ModuleList([
+            BaseDecoder(vocab_size=config.vocab_size, n_layer=config.dec.n_layer, k_len=config.dec.max_target_length,
+                        n_head=config.dec.n_head, d_model=config.dec.d_model, d_head=config.dec.d_head,
+                        d_inner=config.dec.d_inner, dropout=config.dropout)
+            for _ in range(config.dec.n_layer)])
+
+    def forward(self, inputs, mask=None):
+        spec = as_mask_spec(mask, inputs.size(0), inputs.size(1))
+        x = _EmbedFn.apply(inputs, self.dec_embedding.weight, self.dec_embedding.padding_idx)
+        for layer in self.layers:
+            x = layer.forward_bm(x, spec)
+        return x

@@ -1,0 +1,160 @@
+"""Transducer / JointNet with the reference's API surface (tt/model.py): .encoder/.decoder/.joint,
+forward(inputs[B,T,d], targets[B,U]) -> logits[B,T,U+1,V], decode/recognize (greedy), beam search."""
+import copy
+import heapq
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ttmi import ops
+from ttmi.ops import MaskSpec
+from tt.decoder import BuildDecoder
+from tt.encoder import BuildEncoder
+from tt.transformer import default_precision
+from tt.utils import context_mask, look_ahead_mask  # noqa: F401  (re-exported like the reference module)
+
+
+class _JointFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc, dec, wf, bf, wp, bp, prec):
+        enc, dec = enc.contiguous(), dec.contiguous()
+        wf, bf, wp, bp = (t.detach() for t in (wf, bf, wp, bp))
+        logits, saved = ops.joint_fwd(enc, dec, wf, bf, wp, bp, prec)
+        ctx.save_for_backward(enc, dec, wf, wp, saved)
+        ctx.prec = prec
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        enc, dec, wf, wp, saved = ctx.saved_tensors
+        g = dict(wf=torch.zeros_like(wf), bf=torch.zeros(wf.shape[0], dtype=wf.dtype, device=wf.device),
+                 wp=torch.zeros_like(wp), bp=torch.zeros(wp.shape[0], dtype=wp.dtype, device=wp.device))
+        denc, ddec = ops.joint_bwd(dlogits.contiguous(), enc, dec, wf, wp, saved, ctx.prec, g)
+        return denc, ddec, g["wf"], g["bf"], g["wp"], g["bp"], None
+
+
+class JointNet(nn.Module):
+    """logits = project_layer(tanh(forward_layer(cat(enc, dec)))) evaluated in split-weight form
+    (forward_layer.weight = [W_enc | W_dec]); accepts [B,T,de]/[B,U,dd] (lattice) or two 1-D vectors (decode)."""
+
+    def __init__(self, input_size, inner_dim, vocab_size):
+        super().__init__()
+        self.forward_layer = nn.Linear(input_size, inner_dim, bias=True)
+        self.tanh = nn.Tanh()
+        self.project_layer = nn.Linear(inner_dim, vocab_size, bias=True)
+
+    def forward(self, enc_state, dec_state):
+        if enc_state.dim() == 3 and dec_state.dim() == 3:
+            squeeze = None
+        else:
+            assert enc_state.dim() == dec_state.dim()
+            squeeze = enc_state.shape[:-1]
+            enc_state = enc_state.reshape(-1, 1, enc_state.shape[-1])     # N vectors -> N lattices of 1 x 1
+            dec_state = dec_state.reshape(-1, 1, dec_state.shape[-1])
+        out = _JointFn.apply(enc_state, dec_state, self.forward_layer.weight, self.forward_layer.bias,
+                             self.project_layer.weight, self.project_layer.bias, default_precision())
+        return out if squeeze is None else out.reshape(*squeeze, out.shape[-1])
+
+
+class Transducer(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.encoder = BuildEncoder(config)
+        self.decoder = BuildDecoder(config)
+        self.joint = JointNet(input_size=config.joint.input_size, inner_dim=config.joint.inner_size,
+                              vocab_size=config.vocab_size)
+        if config.share_embedding:
+            # the reference's branch dereferences self.decoder.embedding, which does not exist (tt/model.py:53-56)
+            raise AttributeError("'BuildDecoder' object has no attribute 'embedding' (share_embedding is broken upstream)")
+
+    def forward(self, inputs, targets):
+        targets = F.pad(targets, pad=[1, 0, 0, 0], value=0)                 # leading blank / SOS
+        audio_mask = self._audio_mask(inputs)
+        enc_state = self.encoder(inputs, audio_mask)
+        dec_state = self.decoder(targets, MaskSpec(1))                      # == look_ahead_mask(targets)[:, :, None]
+        return self.joint(enc_state, dec_state)
+
+    def _audio_mask(self, inputs):
+        """Reference behaviour is audio_mask=None (tt/model.py:60-61).  Opt-in `config.streaming` (absent in the
+        reference YAMLs => None => off): {'left': l, 'right': r} band mask or {'chunk': c, 'left': l} block mask."""
+        s = self.config.streaming
+        if not s:
+            return None
+        if "chunk" in s:
+            from tt.utils import chunk_mask
+            return chunk_mask(inputs, s["chunk"], s.get("left", 0))[:, :, None]
+        return MaskSpec(2, left=int(s.get("left", 0)), right=int(s.get("right", 0)))
+
+    @torch.no_grad()
+    def decode(self, enc_state, lengths):
+        """Greedy: <= 1 symbol per frame, label encoder re-run on the whole history WITHOUT look-ahead mask."""
+        token_list = [0]
+        dev = enc_state.device
+        dec_state = self.decoder(torch.tensor([token_list], dtype=torch.long, device=dev))[:, -1, :]
+        for t in range(int(lengths)):
+            logits = self.joint(enc_state[t].view(-1), dec_state.view(-1))
+            pred = int(torch.argmax(logits, dim=0).item())                  # argmax(softmax(x)) == argmax(x)
+            if pred != 0:
+                token_list.append(pred)
+                dec_state = self.decoder(torch.tensor([token_list], dtype=torch.long, device=dev))[:, -1, :]
+        return token_list[1:]
+
+    @torch.no_grad()
+    def recognize(self, inputs, inputs_length=None, audio_mask=None):
+        enc_states = self.encoder(inputs, audio_mask)
+        return [self.decode(enc_states[b], inputs_length[b]) for b in range(inputs.size(0))]
+
+    @torch.no_grad()
+    def beam_search(self, enc_state, lengths, beam_width=5):
+        """Restatement of the reference's beam search (tt/model.py:110-179) including its quirks: frames advance on the
+        currently most probable hypothesis; expansion happens only when that hypothesis predicts a non-blank; child
+        token lists persist across expansions (they are appended to, never re-seeded from their parents)."""
+        dev = enc_state.device
+
+        def posterior(tokens, t):
+            d = self.decoder(torch.tensor([tokens], dtype=torch.long, device=dev))[:, -1, :]
+            return F.softmax(self.joint(enc_state[t].view(-1), d.view(-1)), dim=0)
+
+        hyps = [[0] for _ in range(beam_width)]
+        score = np.zeros((beam_width,), dtype=float)
+        child = [[[0] for _ in range(beam_width)] for _ in range(beam_width)]
+        child_score = np.zeros((beam_width, beam_width), dtype=float)
+        first = True
+        for t in range(int(lengths)):
+            lead = int(score.argmax())
+            if int(torch.argmax(posterior(hyps[lead], t)).item()) == 0:
+                continue
+            for k in range(beam_width):
+                values, indices = torch.topk(posterior(hyps[k], t), k=beam_width + 1, dim=0)
+                values, indices = values.tolist(), indices.tolist()
+                drop = indices.index(0) if 0 in indices else len(indices) - 1
+                indices.pop(drop)
+                values.pop(drop)
+                for i, tok in enumerate(indices):
+                    if first:
+                        child[i][k].append(tok)
+                    else:
+                        child[k][i].append(tok)
+                if first:
+                    child_score[:, k] = np.log(values)
+                else:
+                    child_score[k] = score[k] + np.log(values)
+            if first:
+                first = False
+                for i in range(beam_width):
+                    hyps[i] = copy.deepcopy(child[i][0])
+                    score[i] = child_score[i, 0]
+            else:
+                best = heapq.nlargest(beam_width, range(beam_width ** 2), child_score.take)
+                for i, idx in enumerate(best):
+                    score[i] = child_score[idx // beam_width, idx % beam_width]
+                    hyps[i] = copy.deepcopy(child[idx // beam_width][idx % beam_width])
+        return hyps[int(score.argmax())][1:]
+
+    @torch.no_grad()
+    def recognize_beam_search(self, inputs, inputs_length, audio_mask=None):
+        enc_states = self.encoder(inputs, audio_mask)
+        return [self.beam_search(enc_states[b], inputs_length[b], beam_width=5) for b in range(inputs.size(0))]

@@ -1,0 +1,151 @@
+"""Layer math of the reference's tt/transformer.py on MI355X.
+
+Same classes and parameter names (`qkv_net`, `o_net`, `layer_norm`, `CoreNet.0/3`), same forward
+contracts on time-major [L, B, d] tensors.  The modules are parameter containers; forward dispatches
+to one autograd Function per sub-layer whose forward/backward are single C-ABI calls into libttmi
+(csrc/layers.hip).  Encoder/decoder stacks call the batch-major entry points directly and skip the
+[L,B,d] <-> [B,L,d] transposes the reference performs per call (tt/encoder.py:45,50).
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from ttmi import ops
+from ttmi.ops import MaskSpec
+
+
+def default_precision():
+    """0 = exact-f32 MFMA (parity path), 1 = bf16 MFMA with f32 accumulate (throughput path)."""
+    return 1 if os.environ.get("TTMI_PRECISION", "fp32").lower() in ("bf16", "1") else 0
+
+
+def as_mask_spec(mask, B, L):
+    """Reference mask conventions (tt/transformer.py:154-159): None; 2-D = (klen, bsz) key mask broadcast over
+    queries; 3-D = (qlen, klen, bsz|1).  Nonzero / True = masked.  Returns a MaskSpec for the kernels."""
+    if mask is None:
+        return MaskSpec(0)
+    if isinstance(mask, MaskSpec):
+        return mask
+    m = mask != 0
+    if m.dim() == 2:
+        t = m.t().unsqueeze(1)                    # [b, 1, j]
+    elif m.dim() == 3:
+        t = m.permute(2, 0, 1)                    # [b|1, i, j]
+    else:
+        raise ValueError("attn_mask must be 2-D (klen, bsz) or 3-D (qlen, klen, bsz)")
+    return MaskSpec(3, tensor=t.to(torch.uint8).contiguous())
+
+
+class _AttnFn(torch.autograd.Function):
+    NAMES = ("qkv_w", "o_w", "ln_g", "ln_b", "r_emb", "r_w_bias", "r_bias")
+
+    @staticmethod
+    def forward(ctx, x, qkv_w, o_w, ln_g, ln_b, r_emb, r_w_bias, r_bias, mask, prec):
+        x = x.contiguous()
+        p = dict(zip(_AttnFn.NAMES, (t.detach() for t in (qkv_w, o_w, ln_g, ln_b, r_emb, r_w_bias, r_bias))))
+        y, saved = ops.attn_fwd(x, p, mask, prec)
+        ctx.save_for_backward(x, saved, *p.values())
+        ctx.prec = prec
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, saved, *ps = ctx.saved_tensors
+        p = dict(zip(_AttnFn.NAMES, ps))
+        grads = {k: torch.zeros_like(v) for k, v in p.items()}
+        dx = ops.attn_bwd(dy.contiguous(), x, p, saved, ctx.prec, grads)
+        return (dx, *[grads[k] for k in _AttnFn.NAMES], None, None)
+
+
+class _FFNFn(torch.autograd.Function):
+    NAMES = ("ff_w1", "ff_b1", "ff_w2", "ff_b2", "ff_ln_g", "ff_ln_b")
+
+    @staticmethod
+    def forward(ctx, y, w1, b1, w2, b2, ln_g, ln_b, prec):
+        y = y.contiguous()
+        p = dict(zip(_FFNFn.NAMES, (t.detach() for t in (w1, b1, w2, b2, ln_g, ln_b))))
+        z, saved = ops.ffn_fwd(y, p, prec)
+        ctx.save_for_backward(y, saved, *p.values())
+        ctx.prec = prec
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        y, saved, *ps = ctx.saved_tensors
+        p = dict(zip(_FFNFn.NAMES, ps))
+        grads = {k: torch.zeros_like(v) for k, v in p.items()}
+        dy = ops.ffn_bwd(dz.contiguous(), y, p, saved, ctx.prec, grads)
+        return (dy, *[grads[k] for k in _FFNFn.NAMES], None)
+
+
+def _no_dropout(module, p):
+    if module.training and p:
+        raise NotImplementedError(
+            "dropout > 0 in training mode is not wired into the fused HIP sub-layers yet; "
+            "use model.eval() or config.dropout = 0")
+
+
+class PositionwiseFF(nn.Module):
+    """y = LN(x + W2 drop(relu(W1 LN(x) + b1)) + b2) with ONE LayerNorm used twice (tt/transformer.py:36-58)."""
+
+    def __init__(self, d_model, d_inner, dropout, layer_norm_epsilon=1e-5):
+        super().__init__()
+        self.d_model, self.d_inner, self.dropout = d_model, d_inner, dropout
+        self.CoreNet = nn.Sequential(nn.Linear(d_model, d_inner), nn.ReLU(inplace=True), nn.Dropout(dropout),
+                                     nn.Linear(d_inner, d_model), nn.Dropout(dropout))
+        self.layer_norm = nn.LayerNorm(d_model, eps=layer_norm_epsilon)
+
+    def forward(self, inp, prec=None):
+        _no_dropout(self, self.dropout)
+        c = self.CoreNet
+        return _FFNFn.apply(inp, c[0].weight, c[0].bias, c[3].weight, c[3].bias, self.layer_norm.weight,
+                            self.layer_norm.bias, default_precision() if prec is None else prec)
+
+
+class RelMultiHeadAttn(nn.Module):
+    def __init__(self, n_head, d_model, d_head, dropout, dropatt=0, tgt_len=None, ext_len=None, mem_len=None):
+        super().__init__()
+        self.n_head, self.d_model, self.d_head, self.dropout = n_head, d_model, d_head, dropout
+        self.qkv_net = nn.Linear(d_model, 3 * n_head * d_head, bias=False)
+        self.drop = nn.Dropout(dropout)
+        self.dropatt = nn.Dropout(dropatt)
+        self.o_net = nn.Linear(n_head * d_head, d_model, bias=False)
+        self.layer_norm = nn.LayerNorm(d_model)
+        self.scale = 1 / (d_head ** 0.5)
+
+    def forward(self, w, r_emb, r_w_bias, r_bias, attn_mask=None):
+        raise NotImplementedError
+
+
+class RelLearnableMultiHeadAttn(RelMultiHeadAttn):
+    """Learnable-relative-position attention incl. the reference's exact _rel_shift semantics
+    (tt/transformer.py:82-89,106-177)."""
+
+    def forward_bm(self, x, r_emb, r_w_bias, r_bias, mask, prec=None):
+        """batch-major [B, L, d] in/out; mask: MaskSpec."""
+        _no_dropout(self, self.dropout)
+        return _AttnFn.apply(x, self.qkv_net.weight, self.o_net.weight, self.layer_norm.weight, self.layer_norm.bias,
+                             r_emb, r_w_bias, r_bias, mask, default_precision() if prec is None else prec)
+
+    def forward(self, w, r_emb, r_w_bias, r_bias, attn_mask=None):
+        """reference contract: w [L, B, d] time-major."""
+        L, B = w.size(0), w.size(1)
+        y = self.forward_bm(w.transpose(0, 1), r_emb, r_w_bias, r_bias, as_mask_spec(attn_mask, B, L))
+        return y.transpose(0, 1)
+
+
+class RelLearnableDecoderLayer(nn.Module):
+    def __init__(self, n_head, d_model, d_head, d_inner, dropout, **kwargs):
+        super().__init__()
+        self.dec_attn = RelLearnableMultiHeadAttn(n_head, d_model, d_head, dropout, **kwargs)
+        self.pos_ff = PositionwiseFF(d_model, d_inner, dropout)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward_bm(self, x, r_emb, r_w_bias, r_bias, mask, prec=None):
+        _no_dropout(self, self.dropout.p)
+        return self.pos_ff(self.dec_attn.forward_bm(x, r_emb, r_w_bias, r_bias, mask, prec), prec)
+
+    def forward(self, input, r_emb, r_w_bias, r_bias, attn_mask=None):
+        L, B = input.size(0), input.size(1)
+        return self.forward_bm(input.transpose(0, 1), r_emb, r_w_bias, r_bias, as_mask_spec(attn_mask, B, L)).transpose(0, 1)

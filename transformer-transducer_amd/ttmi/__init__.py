@@ -1,0 +1,41 @@
+"""ttmi - loader for libttmi.so (hand-written gfx950 HIP kernels behind a C ABI).
+
+There is NO fallback: if the shared library is missing or a symbol is absent the
+import of the ops fails loudly.  Build with `python __graft_entry__.py` or
+`make -C transformer-transducer_amd/csrc`.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libttmi.so")
+_lib = None
+
+
+class TTMIError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TTMIError(
+                "libttmi.so not found at %s - the HIP extension is required (no CPU/PyTorch fallback). "
+                "Build it: make -C transformer-transducer_amd/csrc" % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.ttmi_last_error.restype = ctypes.c_char_p
+        _lib.ttmi_rnnt_workspace_bytes.restype = ctypes.c_size_t
+    return _lib
+
+
+def last_error():
+    return lib().ttmi_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise ValueError("%s: %s" % (what, last_error()))
+    raise TTMIError("%s: HIP error %d: %s" % (what, rc, last_error()))

@@ -1,0 +1,207 @@
+"""Thin typed wrappers: torch tensors -> raw device pointers -> libttmi C ABI.
+
+torch is plumbing only (device memory, current stream).  Every function here
+launches hand-written HIP kernels; none has a PyTorch/CPU fallback.
+"""
+import ctypes
+
+import torch
+
+from . import check, lib
+
+c_int, c_long, c_float, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
+
+
+def _p(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise ValueError("ttmi ops need device tensors (no CPU fallback); got a %s tensor" % t.device)
+
+
+# ----------------------------------------------------------------------------- RNN-T loss
+def rnnt_workspace(B, T, U1, device):
+    n = lib().ttmi_rnnt_workspace_bytes(c_int(B), c_int(T), c_int(U1))
+    return torch.empty((n + 3) // 4, dtype=torch.float32, device=device)
+
+
+def rnnt_loss_fwd(logits, labels, act_lens, label_lens, blank, workspace):
+    _need_cuda(logits, labels, act_lens, label_lens, workspace)
+    B, T, U1, V = logits.shape
+    costs = torch.empty(B, dtype=torch.float32, device=logits.device)
+    check(lib().ttmi_rnnt_loss_fwd(_p(logits), _p(labels), _p(act_lens), _p(label_lens), c_int(B), c_int(T), c_int(U1),
+                                   c_int(V), c_int(blank), _p(workspace), _p(costs), _stream()), "ttmi_rnnt_loss_fwd")
+    return costs
+
+
+def rnnt_loss_bwd(logits, labels, act_lens, label_lens, blank, workspace, grad_out, grad_out_stride, scale, out=None):
+    _need_cuda(logits, labels, act_lens, label_lens, workspace, grad_out)
+    B, T, U1, V = logits.shape
+    grad = torch.empty_like(logits) if out is None else out
+    check(lib().ttmi_rnnt_loss_bwd(_p(logits), _p(labels), _p(act_lens), _p(label_lens), c_int(B), c_int(T), c_int(U1),
+                                   c_int(V), c_int(blank), _p(workspace), _p(grad_out), c_int(grad_out_stride),
+                                   c_float(scale), _p(grad), _stream()), "ttmi_rnnt_loss_bwd")
+    return grad
+
+
+# ----------------------------------------------------------------------------- generic GEMM (tests / bring-up)
+GEMM_BIAS, GEMM_RELU, GEMM_ATOMIC, GEMM_MASK_AUX, GEMM_A_KMAJOR, GEMM_B_KMAJOR, GEMM_BF16_MFMA = 1, 2, 4, 8, 16, 32, 64
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def gemm(A, B, C, M, N, K, lda, ldb, ldc, flags, bias=None, aux=None, alpha=1.0, beta=0.0, nz1=1, nz2=1,
+         sA=(0, 0), sB=(0, 0), sC=(0, 0), splitk=1):
+    _need_cuda(A, B, C, bias, aux)
+    check(lib().ttmi_gemm(_p(A), _p(B), _p(C), _p(bias), _p(aux), c_int(_DT[A.dtype]), c_int(_DT[B.dtype]),
+                          c_int(_DT[C.dtype]), c_int(M), c_int(N), c_int(K), c_long(lda), c_long(ldb), c_long(ldc),
+                          c_int(nz1), c_int(nz2), c_long(sA[0]), c_long(sA[1]), c_long(sB[0]), c_long(sB[1]),
+                          c_long(sC[0]), c_long(sC[1]), c_float(alpha), c_float(beta), c_int(flags), c_int(splitk),
+                          _stream()), "ttmi_gemm")
+    return C
+
+
+# ----------------------------------------------------------------------------- sub-layers
+class MaskSpec:
+    """Attention mask handed to the kernels as parameters: kind 0 none, 1 causal
+    (look_ahead_mask), 2 band (context_mask left/right), 3 arbitrary uint8 tensor [B|1, L, L]."""
+    __slots__ = ("kind", "left", "right", "tensor")
+
+    def __init__(self, kind=0, left=0, right=0, tensor=None):
+        self.kind, self.left, self.right, self.tensor = kind, left, right, tensor
+
+    def args(self):
+        t = self.tensor
+        if self.kind != 3:
+            return c_int(self.kind), c_int(self.left), c_int(self.right), c_void_p(0), c_long(0), c_long(0)
+        sb = t.stride(0) if t.shape[0] > 1 else 0
+        si = t.stride(1) if t.shape[1] > 1 else 0
+        return c_int(3), c_int(0), c_int(0), _p(t), c_long(sb), c_long(si)
+
+
+def _f32(n, device):
+    return torch.empty(int(n), dtype=torch.float32, device=device)
+
+
+_ws_cache = {}
+
+
+def scratch(n, device):
+    """One grow-only scratch arena per device: sub-layer drivers run back to back on one stream, so the
+    scratch of one call is dead when the next call starts."""
+    key = (device.type, device.index)
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < n:
+        t = _ws_cache[key] = _f32(max(int(n), 1 << 20), device)
+    return t
+
+
+def attn_fwd(x, p, mask, prec):
+    """p: dict of parameter tensors (qkv_w, o_w, ln_g, ln_b, r_emb, r_w_bias, r_bias)."""
+    _need_cuda(x)
+    B, L, d = x.shape
+    K, H, Dh = p["r_emb"].shape
+    L_ = lib()
+    L_.ttmi_attn_ctx_floats.restype = ctypes.c_size_t
+    L_.ttmi_attn_ws_floats.restype = ctypes.c_size_t
+    ctx = _f32(L_.ttmi_attn_ctx_floats(c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh)), x.device)
+    ws = scratch(L_.ttmi_attn_ws_floats(c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh)), x.device)
+    y = torch.empty_like(x)
+    check(L_.ttmi_attn_fwd(_p(x), _p(p["qkv_w"]), _p(p["o_w"]), _p(p["ln_g"]), _p(p["ln_b"]), _p(p["r_emb"]),
+                           _p(p["r_w_bias"]), _p(p["r_bias"]), c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh), c_int(K),
+                           *mask.args(), c_int(prec), _p(ctx), _p(ws), _p(y), _stream()), "ttmi_attn_fwd")
+    return y, ctx
+
+
+def attn_bwd(dy, x, p, ctx, prec, grads):
+    """grads: dict of ZERO-INITIALISED (or running) f32 buffers, accumulated into."""
+    B, L, d = x.shape
+    K, H, Dh = p["r_emb"].shape
+    L_ = lib()
+    L_.ttmi_attn_ws_floats.restype = ctypes.c_size_t
+    ws = scratch(L_.ttmi_attn_ws_floats(c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh)), x.device)
+    dx = torch.empty_like(x)
+    check(L_.ttmi_attn_bwd(_p(dy), _p(x), _p(p["qkv_w"]), _p(p["o_w"]), _p(p["ln_g"]), _p(p["r_emb"]), _p(p["r_bias"]),
+                           c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh), c_int(K), c_int(prec), _p(ctx), _p(ws), _p(dx),
+                           _p(grads["qkv_w"]), _p(grads["o_w"]), _p(grads["ln_g"]), _p(grads["ln_b"]), _p(grads["r_emb"]),
+                           _p(grads["r_w_bias"]), _p(grads["r_bias"]), _stream()), "ttmi_attn_bwd")
+    return dx
+
+
+def ffn_fwd(y, p, prec):
+    rows, d = y.numel() // y.shape[-1], y.shape[-1]
+    Di = p["ff_w1"].shape[0]
+    L_ = lib()
+    L_.ttmi_ffn_ctx_floats.restype = ctypes.c_size_t
+    L_.ttmi_ffn_ws_floats.restype = ctypes.c_size_t
+    ctx = _f32(L_.ttmi_ffn_ctx_floats(c_long(rows), c_int(d), c_int(Di)), y.device)
+    ws = scratch(L_.ttmi_ffn_ws_floats(c_long(rows), c_int(d), c_int(Di)), y.device)
+    z = torch.empty_like(y)
+    check(L_.ttmi_ffn_fwd(_p(y), _p(p["ff_w1"]), _p(p["ff_b1"]), _p(p["ff_w2"]), _p(p["ff_b2"]), _p(p["ff_ln_g"]),
+                          _p(p["ff_ln_b"]), c_long(rows), c_int(d), c_int(Di), c_int(prec), _p(ctx), _p(ws), _p(z), _stream()),
+          "ttmi_ffn_fwd")
+    return z, ctx
+
+
+def ffn_bwd(dz, y, p, ctx, prec, grads):
+    rows, d = y.numel() // y.shape[-1], y.shape[-1]
+    Di = p["ff_w1"].shape[0]
+    L_ = lib()
+    L_.ttmi_ffn_ws_floats.restype = ctypes.c_size_t
+    ws = scratch(L_.ttmi_ffn_ws_floats(c_long(rows), c_int(d), c_int(Di)), y.device)
+    dy = torch.empty_like(y)
+    check(L_.ttmi_ffn_bwd(_p(dz), _p(y), _p(p["ff_w1"]), _p(p["ff_w2"]), _p(p["ff_ln_g"]), c_long(rows), c_int(d), c_int(Di),
+                          c_int(prec), _p(ctx), _p(ws), _p(dy), _p(grads["ff_w1"]), _p(grads["ff_b1"]), _p(grads["ff_w2"]),
+                          _p(grads["ff_b2"]), _p(grads["ff_ln_g"]), _p(grads["ff_ln_b"]), _stream()), "ttmi_ffn_bwd")
+    return dy
+
+
+def joint_fwd(enc, dec, wf, bf, wp, bp, prec):
+    B, T, de = enc.shape
+    U1, dd = dec.shape[1], dec.shape[2]
+    J, V = wf.shape[0], wp.shape[0]
+    L_ = lib()
+    L_.ttmi_joint_ctx_floats.restype = ctypes.c_size_t
+    L_.ttmi_joint_ws_floats.restype = ctypes.c_size_t
+    ctx = _f32(L_.ttmi_joint_ctx_floats(c_int(B), c_int(T), c_int(U1), c_int(J)), enc.device)
+    ws = scratch(L_.ttmi_joint_ws_floats(c_int(B), c_int(T), c_int(U1), c_int(J)), enc.device)
+    logits = torch.empty(B, T, U1, V, dtype=torch.float32, device=enc.device)
+    check(L_.ttmi_joint_fwd(_p(enc), _p(dec), _p(wf), _p(bf), _p(wp), _p(bp), c_int(B), c_int(T), c_int(U1), c_int(de),
+                            c_int(dd), c_int(J), c_int(V), c_int(prec), _p(ctx), _p(ws), _p(logits), _stream()),
+          "ttmi_joint_fwd")
+    return logits, ctx
+
+
+def joint_bwd(dlogits, enc, dec, wf, wp, ctx, prec, grads):
+    B, T, de = enc.shape
+    U1, dd = dec.shape[1], dec.shape[2]
+    J, V = wf.shape[0], wp.shape[0]
+    L_ = lib()
+    L_.ttmi_joint_ws_floats.restype = ctypes.c_size_t
+    ws = scratch(L_.ttmi_joint_ws_floats(c_int(B), c_int(T), c_int(U1), c_int(J)), enc.device)
+    denc, ddec = torch.empty_like(enc), torch.empty_like(dec)
+    check(L_.ttmi_joint_bwd(_p(dlogits), _p(enc), _p(dec), _p(wf), _p(wp), c_int(B), c_int(T), c_int(U1), c_int(de), c_int(dd),
+                            c_int(J), c_int(V), c_int(prec), _p(ctx), _p(ws), _p(denc), _p(ddec), _p(grads["wf"]),
+                            _p(grads["bf"]), _p(grads["wp"]), _p(grads["bp"]), _stream()), "ttmi_joint_bwd")
+    return denc, ddec
+
+
+def embed_fwd(tokens, W):
+    _need_cuda(tokens, W)
+    n, (V, d) = tokens.numel(), W.shape
+    out = torch.empty(*tokens.shape, d, dtype=torch.float32, device=W.device)
+    check(lib().ttmi_embed_fwd(_p(tokens), _p(W), c_long(n), c_int(d), c_int(V), _p(out), _stream()), "ttmi_embed_fwd")
+    return out
+
+
+def embed_bwd(tokens, dout, V, padding_idx, gW):
+    n, d = tokens.numel(), dout.shape[-1]
+    check(lib().ttmi_embed_bwd(_p(tokens), _p(dout), c_long(n), c_int(d), c_int(V), c_int(padding_idx), _p(gW), _stream()),
+          "ttmi_embed_bwd")
+    return gW
