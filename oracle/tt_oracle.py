@@ -122,6 +122,25 @@ def rel_shift_index(L):
     return row, col, (low | up)
 
 
+def rel_shift_flat(G):
+    """The same shift as rel_shift_index, as ONE reinterpretation of memory: prepend a zero column to
+    G [.., L, L] -> [.., L, L+1]; the flat buffer read from offset L with pitch L is BD.  (This is what the
+    reference's pad/view/drop computes and what the HIP path does with GEMM pitches.)  Equality with the
+    index form is asserted in tests/test_oracle_golden.py."""
+    L = G.shape[-1]
+    lead = G.shape[:-2]
+    Gp = np.concatenate([np.zeros(lead + (L, 1), dtype=G.dtype), G], -1).reshape(lead + (L * (L + 1),))
+    return Gp[..., L:].reshape(lead + (L, L))
+
+
+def rel_shift_flat_bwd(dBD):
+    """adjoint of rel_shift_flat: dG [.., L, L] from dBD [.., L, L]"""
+    L = dBD.shape[-1]
+    lead = dBD.shape[:-2]
+    flat = np.concatenate([np.zeros(lead + (L,), dtype=dBD.dtype), dBD.reshape(lead + (L * L,))], -1)
+    return flat.reshape(lead + (L, L + 1))[..., 1:]
+
+
 def rel_attn_fwd(w, p, mask=None):
     """w [B,L,d]; p: dict with qkv_w [3HD,d], o_w [d,HD], ln_g, ln_b,
     r_emb [K,H,D], r_w_bias [H,D], r_bias [K,H]."""
@@ -132,10 +151,10 @@ def rel_attn_fwd(w, p, mask=None):
     e = rel_table_index(L, K)
     E = p["r_emb"][e]                                         # [L,H,D]
     c = p["r_bias"][e]                                        # [L,H]
-    AC = np.einsum("bihd,bjhd->bhij", q + p["r_w_bias"], k)   # :140-142
-    G = np.einsum("bihd,phd->bhip", q, E) + c.T[None, :, None, :]   # :143-144
-    row, col, valid = rel_shift_index(L)
-    BD = G[:, :, row, col] * valid                            # :145
+    qh, kh, vh = (t.transpose(0, 2, 1, 3) for t in (q, k, v))            # [B,H,L,D]
+    AC = (qh + p["r_w_bias"][None, :, None, :]) @ kh.transpose(0, 1, 3, 2)   # :140-142
+    G = qh @ E.transpose(1, 2, 0)[None] + c.T[None, :, None, :]            # :143-144  [B,H,L,L(p)]
+    BD = rel_shift_flat(G)                                    # :145
     scale = 1.0 / np.sqrt(D)
     S = (AC + BD) * scale                                     # :148-149
     m = normalize_mask(mask, B, L)
@@ -144,7 +163,7 @@ def rel_attn_fwd(w, p, mask=None):
     Smax = S.max(-1, keepdims=True)
     Pn = np.exp(S - Smax)
     P = Pn / Pn.sum(-1, keepdims=True)                        # :164
-    O = np.einsum("bhij,bjhd->bihd", P, v).reshape(B, L, H * D)   # :167-170
+    O = (P @ vh).transpose(0, 2, 1, 3).reshape(B, L, H * D)   # :167-170
     a = O @ p["o_w"].T                                        # :172
     y, lnc = layer_norm_fwd(w + a, p["ln_g"], p["ln_b"])      # :175
     cache = dict(w=w, q=q, k=k, v=v, E=E, e=e, P=P, O=O, lnc=lnc, m=m)
@@ -161,19 +180,18 @@ def rel_attn_bwd(dy, cache, p):
     dw = dres.copy()
     da = dres
     g["o_w"] = da.reshape(-1, d).T @ O.reshape(-1, H * D)
-    dO = (da @ p["o_w"]).reshape(B, L, H, D)
-    dP = np.einsum("bihd,bjhd->bhij", dO, v)
-    dv = np.einsum("bhij,bihd->bjhd", P, dO)
+    dO = (da @ p["o_w"]).reshape(B, L, H, D).transpose(0, 2, 1, 3)      # [B,H,L,D]
+    qh, kh, vh = (t.transpose(0, 2, 1, 3) for t in (q, k, v))
+    dP = dO @ vh.transpose(0, 1, 3, 2)
+    dv = (P.transpose(0, 1, 3, 2) @ dO).transpose(0, 2, 1, 3)
     dS = P * (dP - (dP * P).sum(-1, keepdims=True)) * scale   # zero where masked (P = 0)
-    qu = q + p["r_w_bias"]
-    dq = np.einsum("bhij,bjhd->bihd", dS, k)                  # AC wrt (q+u)
-    g["r_w_bias"] = dq.sum((0, 1))
-    dk = np.einsum("bhij,bihd->bjhd", dS, qu)
-    row, col, valid = rel_shift_index(L)
-    dG = np.zeros((B, H, L, L), dtype=w.dtype)
-    np.add.at(dG, (slice(None), slice(None), row, col), dS * valid)
-    dq = dq + np.einsum("bhip,phd->bihd", dG, E)
-    dE = np.einsum("bhip,bihd->phd", dG, q)
+    dqh = dS @ kh                                             # AC wrt (q+u)
+    g["r_w_bias"] = dqh.sum((0, 2))
+    dk = (dS.transpose(0, 1, 3, 2) @ (qh + p["r_w_bias"][None, :, None, :])).transpose(0, 2, 1, 3)
+    dG = rel_shift_flat_bwd(dS)
+    dqh = dqh + dG @ E.transpose(1, 0, 2)[None]               # [B,H,L,L(p)] @ [H,L(p),D]
+    dq = dqh.transpose(0, 2, 1, 3)
+    dE = (dG.transpose(0, 1, 3, 2) @ qh).sum(0).transpose(1, 0, 2)        # [L(p),H,D]
     dc = dG.sum((0, 2)).T                                     # [L(p), H]
     g["r_emb"] = np.zeros_like(p["r_emb"])
     g["r_bias"] = np.zeros_like(p["r_bias"])
@@ -314,7 +332,7 @@ def joint_fwd(enc, dec, sd):
         h = np.tanh(pe + pd + bf)
         return h @ Wp.T + bp, None
     h = np.tanh(pe[:, :, None, :] + pd[:, None, :, :] + bf)
-    z = h @ Wp.T + bp
+    z = (h.reshape(-1, h.shape[-1]) @ Wp.T + bp).reshape(h.shape[:-1] + (Wp.shape[0],))
     return z, dict(enc=enc, dec=dec, h=h)
 
 
@@ -327,7 +345,7 @@ def joint_bwd(dz, cache, sd, grads):
     V = dz.shape[-1]
     grads["joint.project_layer.bias"] = dz.reshape(-1, V).sum(0)
     grads["joint.project_layer.weight"] = dz.reshape(-1, V).T @ h.reshape(-1, J)
-    dpre = (dz @ Wp) * (1 - h * h)
+    dpre = (dz.reshape(-1, V) @ Wp).reshape(h.shape) * (1 - h * h)
     dpe = dpre.sum(2)                                         # [B,T,J]
     dpd = dpre.sum(1)                                         # [B,U1,J]
     grads["joint.forward_layer.bias"] = dpe.reshape(-1, J).sum(0)

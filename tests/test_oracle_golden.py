@@ -76,3 +76,15 @@ def test_float64_oracle_close_to_float32(golden):
     assert abs(r32["loss"] - r64["loss"]) / abs(r64["loss"]) < 1e-6
     for k in r64["grads"]:
         assert rel_err(r32["grads"][k], r64["grads"][k]) < 2e-5, k
+
+
+def test_flat_view_shift_equals_index_form():
+    rng = np.random.default_rng(0)
+    for L in (1, 2, 5, 17):
+        G = rng.normal(size=(2, 3, L, L))
+        row, col, valid = O.rel_shift_index(L)
+        assert np.array_equal(O.rel_shift_flat(G), G[:, :, row, col] * valid)
+        dBD = rng.normal(size=(2, 3, L, L))
+        dG = np.zeros_like(G)
+        np.add.at(dG, (slice(None), slice(None), row, col), dBD * valid)
+        assert np.allclose(O.rel_shift_flat_bwd(dBD), dG, atol=0, rtol=0)

@@ -12,6 +12,9 @@
 #include "gemm.h"
 #include "rowops.h"
 
+void ttmi_probe_begin(int slot, hipStream_t st);
+void ttmi_probe_end(int slot, hipStream_t st);
+
 namespace {
 
 constexpr int NT_ = GEMM_A_KMAJOR | GEMM_B_KMAJOR;   // C = A . B^T   (Linear forward)
@@ -330,7 +333,10 @@ int ttmi_joint_fwd(const float* enc, const float* dec, const float* wf, const fl
     {
         GemmDesc g = mk(Hh, wp, logits, B * T * U1, V, J, J, J, V, NT_ | GEMM_BIAS, prec);
         g.bias = bp;
-        CK(ttmi_launch_gemm(g, st));
+        ttmi_probe_begin(0, st);
+        const int rc = ttmi_launch_gemm(g, st);
+        ttmi_probe_end(0, st);
+        CK(rc);
     }
     return TTMI_OK;
 }

@@ -1,0 +1,135 @@
+// Training-step tail on flat f32 buffers: global grad-norm, clip, SGD(momentum)/Adam update.
+// Mirrors train.py:62-65 (clip_grad_norm_(max_grad_norm) then optimizer.step()) and tt/optim.py:57-73
+// (SGD momentum / Adam betas (0.9, 0.98), eps 1e-8).  HBM-bound streaming kernels, 16-byte accesses.
+// The clip coefficient is computed ON DEVICE from the reduced norm: no host sync in the step.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+    float acc = 0.f;
+    const long n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = x4[i];
+        acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc += x[i] * x[i];
+    acc = wave_sum(acc);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+// coef = grad_scale * min(1, max_norm / (grad_scale * sqrt(normsq) + 1e-6))   (torch.nn.utils.clip_grad_norm_)
+__device__ __forceinline__ float clip_coef(const float* normsq, float max_norm, float grad_scale) {
+    if (!normsq || max_norm <= 0.f) return grad_scale;
+    const float c = max_norm / (grad_scale * sqrtf(*normsq) + 1e-6f);
+    return grad_scale * fminf(c, 1.f);
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom,
+                                                  long n, float lr, float momentum, float wd, int nesterov, float max_norm,
+                                                  const float* __restrict__ normsq, float grad_scale) {
+    const float coef = clip_coef(normsq, max_norm, grad_scale);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float gi = g[i] * coef + wd * p[i];
+        if (momentum != 0.f) {
+            const float b = momentum * mom[i] + gi;
+            mom[i] = b;
+            gi = nesterov ? gi + momentum * b : b;
+        }
+        p[i] -= lr * gi;
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                   float wd, float bc1, float bc2, float max_norm,
+                                                   const float* __restrict__ normsq, float grad_scale) {
+    const float coef = clip_coef(normsq, max_norm, grad_scale);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i] * coef + wd * p[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+    }
+}
+
+int grid_for(long n) {
+    long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+// *out += sum(x^2)   (out must be zeroed by the caller; accumulates so several buffers can share it)
+int ttmi_sumsq(const float* x, long n, float* out, void* stream) {
+    TTMI_REQUIRE(x && out && n > 0, "sumsq: bad arguments");
+    TTMI_REQUIRE(aligned16(x), "sumsq: x must be 16-byte aligned");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, static_cast<hipStream_t>(stream), x, n, out);
+    TTMI_LAUNCH_CHECK("sumsq_kernel");
+    return TTMI_OK;
+}
+
+// torch.optim.SGD step on a flat buffer with the gradient clip folded in (normsq may be NULL = no clipping).
+// The effective gradient is g * grad_scale (e.g. 1/world_size after a SUM all-reduce), clipped to max_norm.
+int ttmi_sgd_step(float* p, const float* g, float* mom, long n, float lr, float momentum, float weight_decay, int nesterov,
+                  float max_norm, const float* normsq, float grad_scale, void* stream) {
+    TTMI_REQUIRE(p && g && n > 0 && (mom || momentum == 0.f), "sgd_step: bad arguments");
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, mom, n, lr,
+                       momentum, weight_decay, nesterov, max_norm, normsq, grad_scale);
+    TTMI_LAUNCH_CHECK("sgd_kernel");
+    return TTMI_OK;
+}
+
+// torch.optim.Adam step (step counts from 1)
+int ttmi_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, float max_norm, const float* normsq, float grad_scale, void* stream) {
+    TTMI_REQUIRE(p && g && m && v && n > 0 && step > 0, "adam_step: bad arguments");
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n, lr, beta1,
+                       beta2, eps, weight_decay, bc1, bc2, max_norm, normsq, grad_scale);
+    TTMI_LAUNCH_CHECK("adam_kernel");
+    return TTMI_OK;
+}
+
+// ---- timing probes: HIP events recorded on the launch stream around one named kernel launch ----------------
+// slot 0 = joint vocabulary projection GEMM (forward).  Events are owned by the library.
+static hipEvent_t g_probe[8][2];
+static int g_probe_armed[8];
+
+int ttmi_probe_arm(int slot) {
+    TTMI_REQUIRE(slot >= 0 && slot < 8, "probe: bad slot");
+    if (!g_probe[slot][0]) {
+        (void)hipEventCreate(&g_probe[slot][0]);
+        (void)hipEventCreate(&g_probe[slot][1]);
+    }
+    g_probe_armed[slot] = 1;
+    return TTMI_OK;
+}
+// blocks until the stop event has completed; returns elapsed milliseconds (or <0 if the probe never fired)
+float ttmi_probe_read_ms(int slot) {
+    if (slot < 0 || slot >= 8 || !g_probe[slot][0] || g_probe_armed[slot] != 2) return -1.f;
+    float ms = -1.f;
+    (void)hipEventSynchronize(g_probe[slot][1]);
+    (void)hipEventElapsedTime(&ms, g_probe[slot][0], g_probe[slot][1]);
+    g_probe_armed[slot] = 0;
+    return ms;
+}
+}
+
+void ttmi_probe_begin(int slot, hipStream_t st) {
+    if (g_probe_armed[slot] == 1) (void)hipEventRecord(g_probe[slot][0], st);
+}
+void ttmi_probe_end(int slot, hipStream_t st) {
+    if (g_probe_armed[slot] == 1) {
+        (void)hipEventRecord(g_probe[slot][1], st);
+        g_probe_armed[slot] = 2;
+    }
+}

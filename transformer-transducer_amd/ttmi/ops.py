@@ -205,3 +205,30 @@ def embed_bwd(tokens, dout, V, padding_idx, gW):
     check(lib().ttmi_embed_bwd(_p(tokens), _p(dout), c_long(n), c_int(d), c_int(V), c_int(padding_idx), _p(gW), _stream()),
           "ttmi_embed_bwd")
     return gW
+
+
+# ----------------------------------------------------------------------------- optimiser tail / probes
+def sumsq(x, out):
+    check(lib().ttmi_sumsq(_p(x), c_long(x.numel()), _p(out), _stream()), "ttmi_sumsq")
+
+
+def sgd_step(p, g, mom, lr, momentum, weight_decay, nesterov, max_norm, normsq, grad_scale):
+    check(lib().ttmi_sgd_step(_p(p), _p(g), _p(mom), c_long(p.numel()), c_float(lr), c_float(momentum), c_float(weight_decay),
+                              c_int(1 if nesterov else 0), c_float(max_norm), _p(normsq), c_float(grad_scale), _stream()),
+          "ttmi_sgd_step")
+
+
+def adam_step(p, g, m, v, lr, betas, eps, weight_decay, step, max_norm, normsq, grad_scale):
+    check(lib().ttmi_adam_step(_p(p), _p(g), _p(m), _p(v), c_long(p.numel()), c_float(lr), c_float(betas[0]), c_float(betas[1]),
+                               c_float(eps), c_float(weight_decay), c_int(step), c_float(max_norm), _p(normsq),
+                               c_float(grad_scale), _stream()), "ttmi_adam_step")
+
+
+def probe_arm(slot=0):
+    check(lib().ttmi_probe_arm(c_int(slot)), "ttmi_probe_arm")
+
+
+def probe_read_ms(slot=0):
+    f = lib().ttmi_probe_read_ms
+    f.restype = ctypes.c_float
+    return float(f(c_int(slot)))
