@@ -1,0 +1,57 @@
+"""Throughput bf16 GEMMs (csrc/gemm_fast.hip: glds staging, XOR-swizzled LDS, ds_read_b64_tr_b16) vs exact references."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ints(shape, g):
+    return torch.randint(-4, 5, shape, device="cuda", generator=g).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 200, 192), (1000, 4334, 1024), (77, 130, 64)])
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_nt_exact_integers(M, N, K, cdt):
+    """small-integer operands: products and sums are exact in f32, so any lane-map / swizzle error shows bit-for-bit"""
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A, B = _ints((M, K), g), _ints((N, K), g)
+    bias = torch.randint(-3, 4, (N,), device="cuda", generator=g).float()
+    C = torch.full((M, N), 7.0, device="cuda", dtype=cdt)
+    ops.gemm_nt_bf16(A, B, C, bias)
+    want = (A.float() @ B.float().t() + bias).to(cdt)
+    assert torch.equal(C, want)
+
+
+def test_nt_padded_pitch_and_random():
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(1)
+    M, N, K = 500, 333, 256
+    Ab = torch.randn(M, K + 64, device="cuda", generator=g).to(torch.bfloat16)
+    Bb = torch.randn(N, K + 8, device="cuda", generator=g).to(torch.bfloat16)
+    Cb = torch.zeros(M, N + 19, device="cuda")
+    ops.gemm_nt_bf16(Ab[:, :K], Bb[:, :K], Cb[:, :N])
+    want = Ab[:, :K].double() @ Bb[:, :K].double().t()
+    assert float((Cb[:, :N].double() - want).norm() / want.norm()) < 1e-6
+    assert float(Cb[:, N:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 128, 256), (4334, 1024, 4096), (200, 72, 640), (130, 1000, 128)])
+def test_tn_exact_integers(M, N, K):
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    lda, ldb = (M + 7) // 8 * 8 + 8, (N + 7) // 8 * 8
+    Ab, Bb = _ints((K, lda), g), _ints((K, ldb), g)
+    C = torch.zeros(M, N, device="cuda")
+    ops.gemm_tn_bf16(Ab[:, :M], Bb[:, :N], C, accumulate=True)
+    want = Ab[:, :M].float().t() @ Bb[:, :N].float()
+    assert torch.equal(C, want)
+    ops.gemm_tn_bf16(Ab[:, :M], Bb[:, :N], C, accumulate=True)       # accumulates
+    assert torch.equal(C, 2 * want)
+
+
+def test_rejects_unsupported_shapes():
+    from ttmi import ops
+    A = torch.zeros(64, 100, device="cuda", dtype=torch.bfloat16)     # K not a multiple of 64
+    with pytest.raises(ValueError):
+        ops.gemm_nt_bf16(A, A, torch.zeros(64, 64, device="cuda"))

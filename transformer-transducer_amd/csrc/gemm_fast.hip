@@ -1,0 +1,298 @@
+// Throughput GEMMs for the bf16 pipeline (gfx950).  Operands are bf16 in HBM, f32 accumulate.
+//
+//   gemm_nt_bf16   C[M,N] = A[M,K] . B[N,K]^T (+bias)      forward / dgrad (weights pre-transposed, tiny)
+//   gemm_tn_bf16   C[M,N] += A[K,M]^T . B[K,N]             wgrad: both operands reduction-major; the transposed
+//                                                           fragments come from ds_read_b64_tr_b16, no transposed copies
+//
+// Structure (both): 128x128x64 block tile, 4 waves (2x2) x (2x2 v_mfma_f32_32x32x16_bf16), operands staged
+// HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double-buffered, one barrier per K-step with
+// the next tile's loads in flight under the MFMAs.  LDS images are linear per wave-instruction (a glds
+// constraint) and XOR-swizzled through the per-lane SOURCE address so every fragment read is conflict-free:
+//   NT: 128-B rows [row][k]:   chunk' = chunk ^ ((row >> 1) & 7)      (ds_read_b128)
+//   TN: 256-B rows [k][col]:   chunk' = chunk ^ ((k & 3) << 2)        (ds_read_b64_tr_b16)
+// Workgroups are renumbered so the 8 that share an XCD (ids equal mod 8) walk a compact 8x8-tile window
+// (A and B panels of ~2 MB each stay in that XCD's 4 MB L2).
+#include "gemm_fast.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TM = 128, TN_ = 128, TK = 64, NTH = 256;
+constexpr int TILE_B = 128 * 64 * 2;        // 16 KiB per operand tile
+constexpr int GROUP_M = 8;
+
+struct FP {
+    const bf16_t* A;
+    const bf16_t* B;
+    void* C;
+    const float* bias;
+    int M, N, K;
+    long lda, ldb, ldc;
+    int tiles_m, tiles_n, splitk, ksteps;   // ksteps per split
+    int atomic;
+};
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// tile id -> (tm, tn): XCD-aware bijective renumbering + grouped (GROUP_M tall) ordering
+__device__ __forceinline__ void tile_of(int bid, int nwg, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    const int per_group = GROUP_M * tiles_n;
+    const int group = id / per_group, in = id % per_group;
+    const int first = group * GROUP_M;
+    const int gsz = min(tiles_m - first, GROUP_M);
+    tm = first + in % gsz;
+    tn = in / gsz;
+}
+
+template <typename TC>
+__device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], const FP& p, TC* C, int bm, int bn, int wm, int wn,
+                                           int lane, bool add_bias) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = bn + wn * 64 + j * 32 + (lane & 31);
+            if (n >= p.N) continue;
+            const float bv = add_bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= p.M) continue;
+                const float v = acc[i][j][r] + bv;
+                const long ci = (long)m * p.ldc + n;
+                if constexpr (sizeof(TC) == 4) {
+                    if (p.atomic) atomicAdd(reinterpret_cast<float*>(C) + ci, v);
+                    else reinterpret_cast<float*>(C)[ci] = v;
+                } else {
+                    reinterpret_cast<bf16_t*>(C)[ci] = f32_to_bf16(v);
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------ NT: A[M,K], B[N,K], K contiguous in both
+template <typename TC>
+__global__ __launch_bounds__(NTH, 2) void gemm_nt_bf16_kernel(const FP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A 16K | B 16K]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int tm, tn;
+    tile_of(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+    const int bm = tm * TM, bn = tn * TN_;
+
+    // staging: wave w, instruction j covers tile rows R = (4w + j) * 8 + (lane >> 3), LDS slot = lane & 7,
+    // which must hold source chunk slot ^ ((R >> 1) & 7)
+    const bf16_t* asrc[4];
+    const bf16_t* bsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int R = (wave * 4 + j) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((R >> 1) & 7);
+        const int ra = min(bm + R, p.M - 1), rb = min(bn + R, p.N - 1);
+        asrc[j] = p.A + (long)ra * p.lda + chunk * 8;
+        bsrc[j] = p.B + (long)rb * p.ldb + chunk * 8;
+    }
+    auto issue = [&](int buf, int kt) {
+        char* base = smem + buf * 2 * TILE_B + wave * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(asrc[j] + (long)kt * TK, base + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(bsrc[j] + (long)kt * TK, base + TILE_B + j * 1024);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / TK;
+    const int sw = (lane >> 1) & 7;                 // ((row >> 1) & 7) for row = ... + (lane & 31)
+    const int rowa = wm * 64 + (lane & 31), rowb = wn * 64 + (lane & 31);
+    issue(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) issue(cur ^ 1, kt + 1);
+        const char* la = smem + cur * 2 * TILE_B;
+        const char* lb = la + TILE_B;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int c = ((kk * 2 + (lane >> 5)) ^ sw) << 4;
+            bf16x8 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(la + (rowa + i * 32) * 128 + c);
+                bf[i] = *reinterpret_cast<const bf16x8*>(lb + (rowb + i * 32) * 128 + c);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();       // drains the prefetch (vmcnt(0)) and fences the buffer swap
+    }
+    store_tile<TC>(acc, p, reinterpret_cast<TC*>(p.C), bm, bn, wm, wn, lane, p.bias != nullptr);
+}
+
+// ------------------------------------------------------------------ TN: A[K,M], B[K,N], reduction index is the slow one
+__device__ __forceinline__ bf16x4 ds_read_tr16(const char* lds_addr) {
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_addr);
+    return __builtin_bit_cast(bf16x4, v);
+}
+
+__global__ __launch_bounds__(NTH, 2) void gemm_tn_bf16_kernel(const FP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ks = blockIdx.y;
+    int tm, tn;
+    tile_of(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+    const int bm = tm * TM, bn = tn * TN_;
+
+    // staging: one wave-instruction = 4 k-rows x 256 B.  wave w, instruction j: k-row kr = (4w + j) * 4 + (lane >> 4),
+    // LDS slot = lane & 15 holds source chunk slot ^ ((kr & 3) << 2).  Column chunks are clamped into the row
+    // (columns beyond M/N feed only output rows/cols that are never stored).
+    const long k0 = (long)ks * p.ksteps * TK;
+    const bf16_t* asrc[4];
+    const bf16_t* bsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int kr = (wave * 4 + j) * 4 + (lane >> 4);
+        const int chunk = (lane & 15) ^ ((kr & 3) << 2);
+        const long ca = min((long)bm + chunk * 8, p.lda - 8), cb = min((long)bn + chunk * 8, p.ldb - 8);
+        asrc[j] = p.A + (k0 + kr) * p.lda + ca;
+        bsrc[j] = p.B + (k0 + kr) * p.ldb + cb;
+    }
+    auto issue = [&](int buf, int kt) {
+        char* base = smem + buf * 2 * TILE_B + wave * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(asrc[j] + (long)kt * TK * p.lda, base + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(bsrc[j] + (long)kt * TK * p.ldb, base + TILE_B + j * 1024);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposed fragment read: 16-lane group g = lane >> 4 reads the 4 x 16 block (k rows 8h + 4s + q, 16 columns),
+    // lane 4q + p of the group supplies the address of row q, columns 4p..4p+3; lane i receives column i.
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, h = g >> 1;
+    const int cola = wm * 64 + 16 * (g & 1) + 4 * pp, colb = wn * 64 + 16 * (g & 1) + 4 * pp;
+    const int nk = p.ksteps;
+    issue(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) issue(cur ^ 1, kt + 1);
+        const char* la = smem + cur * 2 * TILE_B;
+        const char* lb = la + TILE_B;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                bf16x4 a0, a1, b0, b1;
+                {
+                    const int kr = kk * 16 + 8 * h + q;            // s = 0 ; (kr & 3) == q
+                    const int ca = cola + i * 32, cb = colb + i * 32;
+                    a0 = ds_read_tr16(la + kr * 256 + ((((ca >> 3) ^ (q << 2))) << 4) + (ca & 7) * 2);
+                    b0 = ds_read_tr16(lb + kr * 256 + ((((cb >> 3) ^ (q << 2))) << 4) + (cb & 7) * 2);
+                    a1 = ds_read_tr16(la + (kr + 4) * 256 + ((((ca >> 3) ^ (q << 2))) << 4) + (ca & 7) * 2);
+                    b1 = ds_read_tr16(lb + (kr + 4) * 256 + ((((cb >> 3) ^ (q << 2))) << 4) + (cb & 7) * 2);
+                }
+                af[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                bf[i] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    store_tile<float>(acc, p, reinterpret_cast<float*>(p.C), bm, bn, wm, wn, lane, false);
+}
+
+}  // namespace
+
+bool gemm_fast_nt_ok(const void* A, const void* B, const void* C, int M, int N, int K, long lda, long ldb) {
+    return aligned16(A) && aligned16(B) && C && M > 0 && N > 0 && K >= TK && K % TK == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+           lda >= K && ldb >= K;
+}
+
+int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const float* bias, int M, int N, int K, long lda,
+                 long ldb, long ldc, hipStream_t st) {
+    TTMI_REQUIRE(gemm_fast_nt_ok(A, B, C, M, N, K, lda, ldb), "gemm_nt_bf16: shape/alignment not supported (M=%d N=%d K=%d)", M,
+                 N, K);
+    FP p;
+    p.A = A; p.B = B; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.tiles_m = cdiv(M, TM); p.tiles_n = cdiv(N, TN_); p.splitk = 1; p.ksteps = K / TK; p.atomic = 0;
+    const long nwg = (long)p.tiles_m * p.tiles_n;
+    TTMI_REQUIRE(nwg < (1L << 31), "gemm_nt_bf16: too many tiles");
+    if (c_dtype == 0)
+        hipLaunchKernelGGL(gemm_nt_bf16_kernel<float>, dim3((unsigned)nwg), dim3(NTH), 4 * TILE_B, st, p);
+    else
+        hipLaunchKernelGGL(gemm_nt_bf16_kernel<bf16_t>, dim3((unsigned)nwg), dim3(NTH), 4 * TILE_B, st, p);
+    TTMI_LAUNCH_CHECK("gemm_nt_bf16_kernel");
+    return TTMI_OK;
+}
+
+bool gemm_fast_tn_ok(const void* A, const void* B, const void* C, int M, int N, int K, long lda, long ldb) {
+    return aligned16(A) && aligned16(B) && C && M > 0 && N > 0 && K >= TK && K % TK == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+           lda >= ((M + 7) & ~7) && ldb >= ((N + 7) & ~7);
+}
+
+// C (f32) += A^T B by atomics when splitk > 1 or accumulate != 0, else C = A^T B
+int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
+                 hipStream_t st) {
+    TTMI_REQUIRE(gemm_fast_tn_ok(A, B, C, M, N, K, lda, ldb), "gemm_tn_bf16: shape/alignment not supported (M=%d N=%d K=%d)", M,
+                 N, K);
+    FP p;
+    p.A = A; p.B = B; p.C = C; p.bias = nullptr; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.tiles_m = cdiv(M, TM); p.tiles_n = cdiv(N, TN_);
+    const long tiles = (long)p.tiles_m * p.tiles_n;
+    const int ksteps_total = K / TK;
+    int splitk = 1;
+    if (tiles < 1024) {
+        splitk = (int)((2048 + tiles - 1) / tiles);
+        if (splitk > ksteps_total / 4) splitk = ksteps_total / 4;
+        if (splitk < 1) splitk = 1;
+    }
+    while (ksteps_total % splitk) --splitk;       // equal splits (K is a multiple of 64; worst case splitk = 1)
+    p.splitk = splitk; p.ksteps = ksteps_total / splitk;
+    p.atomic = (splitk > 1 || accumulate) ? 1 : 0;
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3((unsigned)tiles, splitk), dim3(NTH), 4 * TILE_B, st, p);
+    TTMI_LAUNCH_CHECK("gemm_tn_bf16_kernel");
+    return TTMI_OK;
+}
+
+extern "C" {
+// bring-up / test entry points (dtype codes 0 = f32, 1 = bf16)
+int ttmi_gemm_nt_bf16(const void* A, const void* B, void* C, int c_dtype, const float* bias, int M, int N, int K, long lda,
+                      long ldb, long ldc, void* stream) {
+    return gemm_nt_bf16(static_cast<const bf16_t*>(A), static_cast<const bf16_t*>(B), C, c_dtype, bias, M, N, K, lda, ldb, ldc,
+                        static_cast<hipStream_t>(stream));
+}
+int ttmi_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
+                      void* stream) {
+    return gemm_tn_bf16(static_cast<const bf16_t*>(A), static_cast<const bf16_t*>(B), C, M, N, K, lda, ldb, ldc, accumulate,
+                        static_cast<hipStream_t>(stream));
+}
+}

@@ -232,3 +232,22 @@ def probe_read_ms(slot=0):
     f = lib().ttmi_probe_read_ms
     f.restype = ctypes.c_float
     return float(f(c_int(slot)))
+
+
+# ----------------------------------------------------------------------------- throughput bf16 GEMMs (tests / tools)
+def gemm_nt_bf16(A, B, C, bias=None):
+    """C[M,N] = A[M,K] @ B[N,K]^T (+bias).  A, B bf16 row-major (row pitch = stride(0)); C f32 or bf16."""
+    M, K = A.shape
+    N = B.shape[0]
+    check(lib().ttmi_gemm_nt_bf16(_p(A), _p(B), _p(C), c_int(_DT[C.dtype]), _p(bias), c_int(M), c_int(N), c_int(K),
+                                  c_long(A.stride(0)), c_long(B.stride(0)), c_long(C.stride(0)), _stream()), "ttmi_gemm_nt_bf16")
+    return C
+
+
+def gemm_tn_bf16(A, B, C, accumulate=False):
+    """C[M,N] (f32) (+)= A[K,M]^T @ B[K,N].  A, B bf16 row-major."""
+    K, M = A.shape
+    N = B.shape[1]
+    check(lib().ttmi_gemm_tn_bf16(_p(A), _p(B), _p(C), c_int(M), c_int(N), c_int(K), c_long(A.stride(0)), c_long(B.stride(0)),
+                                  c_long(C.stride(0)), c_int(1 if accumulate else 0), _stream()), "ttmi_gemm_tn_bf16")
+    return C
