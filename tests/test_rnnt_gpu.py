@@ -127,3 +127,33 @@ def test_full_size_properties():
                                 reduction="sum")
         assert abs(float(costs[b]) - cb[0]) / cb[0] < TOL
         assert rel_err(gr[b].cpu().numpy(), gb[0]) < TOL
+
+
+@pytest.mark.parametrize("B,T,U,V", [(2, 30, 7, 48), (3, 21, 12, 131), (1, 9, 3, 4334)])
+def test_bf16_row_padded_logits(B, T, U, V):
+    """the bf16 pipeline hands the loss a [..., :V] view of a pitch-roundup(V,64) bf16 buffer and gets a gradient
+    of the same layout back, pad columns exactly zero"""
+    from warprnnt_pytorch import RNNTLoss
+    rng = np.random.default_rng(V)
+    Vp = (V + 63) // 64 * 64
+    buf = torch.zeros(B, T, U + 1, Vp, device="cuda", dtype=torch.bfloat16)
+    buf[..., :V] = torch.tensor(rng.normal(size=(B, T, U + 1, V)) * 2, device="cuda").to(torch.bfloat16)
+    buf[..., V:] = 77.0                                     # poison the pad: must never be read
+    acts = buf[..., :V].detach().requires_grad_(True)
+    y = rng.integers(1, V, size=(B, U))
+    tl = np.full(B, T, dtype=np.int32)
+    ul = np.full(B, U, dtype=np.int32)
+    if B > 1:
+        tl[1], ul[1] = T - 4, U - 2
+    raw = []
+    acts.register_hook(raw.append)          # the gradient exactly as the loss's backward hands it to its producer
+    loss = RNNTLoss()(acts, torch.tensor(y, dtype=torch.int32, device="cuda"), torch.tensor(tl, device="cuda"),
+                      torch.tensor(ul, device="cuda"))
+    loss.backward()
+    g = raw[0]
+    assert g.dtype is torch.bfloat16 and g.stride(-2) == Vp
+    want = O.rnnt_loss(buf[..., :V].float().cpu().numpy().astype(np.float64), y, tl, ul)
+    assert abs(float(loss) - want[0]) / want[0] < 1e-5       # the loss itself is computed in f32/f64 from the bf16 values
+    assert rel_err(g.float().cpu().numpy(), want[2]) < 6e-3  # gradient rounded to bf16 (2^-9 relative)
+    full = torch.as_strided(g, (B, T, U + 1, Vp), g.stride())
+    assert float(full[..., V:].float().abs().max()) == 0

@@ -4,9 +4,22 @@
 
 bool gemm_fast_nt_ok(const void* A, const void* B, const void* C, int M, int N, int K, long lda, long ldb);
 bool gemm_fast_tn_ok(const void* A, const void* B, const void* C, int M, int N, int K, long lda, long ldb);
-// C[M,N] = A[M,K] . B[N,K]^T (+ bias[n]); c_dtype 0 = f32, 1 = bf16
-int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const float* bias, int M, int N, int K, long lda,
+// epilogue of the NT kernel: v = acc (+ bias[n]) (+ addend[m*ldc+n]); relu; v = mask[m*ldc+n] > 0 ? v : 0
+struct NtEpilogue {
+    const float* bias = nullptr;
+    const float* addend = nullptr;   // f32, same layout as C (residual add)
+    const bf16_t* mask = nullptr;    // bf16, same layout as C (ReLU backward)
+    int relu = 0;
+};
+// C[M,N] = epilogue(A[M,K] . B[N,K]^T); c_dtype 0 = f32, 1 = bf16
+int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const NtEpilogue& epi, int M, int N, int K, long lda,
                  long ldb, long ldc, hipStream_t st);
+inline int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const float* bias, int M, int N, int K,
+                        long lda, long ldb, long ldc, hipStream_t st) {
+    NtEpilogue e;
+    e.bias = bias;
+    return gemm_nt_bf16(A, B, C, c_dtype, e, M, N, K, lda, ldb, ldc, st);
+}
 // C[M,N] (f32) (+)= A[K,M]^T . B[K,N]; with accumulate != 0 (or internal split-K) the result is ADDED atomically to C
 int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
                  hipStream_t st);

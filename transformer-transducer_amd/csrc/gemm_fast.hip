@@ -25,11 +25,17 @@ constexpr int TM = 128, TN_ = 128, TK = 64, NTH = 256;
 constexpr int TILE_B = 128 * 64 * 2;        // 16 KiB per operand tile
 constexpr int GROUP_M = 8;
 
+// 16 zero bytes in global memory: glds source for out-of-range K rows/chunks (the source address is per lane)
+__device__ __attribute__((aligned(16))) const uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
 struct FP {
     const bf16_t* A;
     const bf16_t* B;
     void* C;
     const float* bias;
+    const float* addend;
+    const bf16_t* mask;
+    int relu;
     int M, N, K;
     long lda, ldb, ldc;
     int tiles_m, tiles_n, splitk, ksteps;   // ksteps per split
@@ -67,8 +73,11 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], const FP& 
             for (int r = 0; r < 16; ++r) {
                 const int m = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m >= p.M) continue;
-                const float v = acc[i][j][r] + bv;
+                float v = acc[i][j][r] + bv;
                 const long ci = (long)m * p.ldc + n;
+                if (p.addend) v += p.addend[ci];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.mask) v = bf16_to_f32(p.mask[ci]) > 0.f ? v : 0.f;
                 if constexpr (sizeof(TC) == 4) {
                     if (p.atomic) atomicAdd(reinterpret_cast<float*>(C) + ci, v);
                     else reinterpret_cast<float*>(C)[ci] = v;
@@ -101,12 +110,23 @@ __global__ __launch_bounds__(NTH, 2) void gemm_nt_bf16_kernel(const FP p) {
         asrc[j] = p.A + (long)ra * p.lda + chunk * 8;
         bsrc[j] = p.B + (long)rb * p.ldb + chunk * 8;
     }
+    int kchunk[4];                                   // source chunk (k offset / 8) of this lane per instruction
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kchunk[j] = (lane & 7) ^ ((((wave * 4 + j) * 8 + (lane >> 3)) >> 1) & 7);
+    const void* zsrc = &g_zero16;
     auto issue = [&](int buf, int kt) {
         char* base = smem + buf * 2 * TILE_B + wave * 4096;
+        const bool tail = (kt + 1) * TK > p.K;       // wave-uniform: only the last K-step can be partial
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(asrc[j] + (long)kt * TK, base + j * 1024);
+        for (int j = 0; j < 4; ++j) {
+            const bool zero = tail && (kt * TK + kchunk[j] * 8 >= p.K);
+            glds16(zero ? zsrc : (const void*)(asrc[j] + (long)kt * TK), base + j * 1024);
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(bsrc[j] + (long)kt * TK, base + TILE_B + j * 1024);
+        for (int j = 0; j < 4; ++j) {
+            const bool zero = tail && (kt * TK + kchunk[j] * 8 >= p.K);
+            glds16(zero ? zsrc : (const void*)(bsrc[j] + (long)kt * TK), base + TILE_B + j * 1024);
+        }
     };
 
     f32x16 acc[2][2];
@@ -117,7 +137,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_nt_bf16_kernel(const FP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = p.K / TK;
+    const int nk = (p.K + TK - 1) / TK;
     const int sw = (lane >> 1) & 7;                 // ((row >> 1) & 7) for row = ... + (lane & 31)
     const int rowa = wm * 64 + (lane & 31), rowb = wn * 64 + (lane & 31);
     issue(0, 0);
@@ -175,12 +195,21 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_bf16_kernel(const FP p) {
         asrc[j] = p.A + (k0 + kr) * p.lda + ca;
         bsrc[j] = p.B + (k0 + kr) * p.ldb + cb;
     }
+    const void* zsrc = &g_zero16;
     auto issue = [&](int buf, int kt) {
         char* base = smem + buf * 2 * TILE_B + wave * 4096;
+        const long kbase = k0 + (long)kt * TK;
+        const bool tail = kbase + TK > p.K;          // wave-uniform
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(asrc[j] + (long)kt * TK * p.lda, base + j * 1024);
+        for (int j = 0; j < 4; ++j) {
+            const bool zero = tail && (kbase + (wave * 4 + j) * 4 + (lane >> 4) >= p.K);
+            glds16(zero ? zsrc : (const void*)(asrc[j] + (long)kt * TK * p.lda), base + j * 1024);
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(bsrc[j] + (long)kt * TK * p.ldb, base + TILE_B + j * 1024);
+        for (int j = 0; j < 4; ++j) {
+            const bool zero = tail && (kbase + (wave * 4 + j) * 4 + (lane >> 4) >= p.K);
+            glds16(zero ? zsrc : (const void*)(bsrc[j] + (long)kt * TK * p.ldb), base + TILE_B + j * 1024);
+        }
     };
 
     f32x16 acc[2][2];
@@ -195,7 +224,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_bf16_kernel(const FP p) {
     // lane 4q + p of the group supplies the address of row q, columns 4p..4p+3; lane i receives column i.
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, h = g >> 1;
     const int cola = wm * 64 + 16 * (g & 1) + 4 * pp, colb = wn * 64 + 16 * (g & 1) + 4 * pp;
-    const int nk = p.ksteps;
+    const int nk = min(p.ksteps, (int)((p.K - k0 + TK - 1) / TK));
     issue(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -233,17 +262,18 @@ __global__ __launch_bounds__(NTH, 2) void gemm_tn_bf16_kernel(const FP p) {
 }  // namespace
 
 bool gemm_fast_nt_ok(const void* A, const void* B, const void* C, int M, int N, int K, long lda, long ldb) {
-    return aligned16(A) && aligned16(B) && C && M > 0 && N > 0 && K >= TK && K % TK == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+    return aligned16(A) && aligned16(B) && C && M > 0 && N > 0 && K >= 8 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
            lda >= K && ldb >= K;
 }
 
-int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const float* bias, int M, int N, int K, long lda,
+int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const NtEpilogue& epi, int M, int N, int K, long lda,
                  long ldb, long ldc, hipStream_t st) {
     TTMI_REQUIRE(gemm_fast_nt_ok(A, B, C, M, N, K, lda, ldb), "gemm_nt_bf16: shape/alignment not supported (M=%d N=%d K=%d)", M,
                  N, K);
     FP p;
-    p.A = A; p.B = B; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    p.tiles_m = cdiv(M, TM); p.tiles_n = cdiv(N, TN_); p.splitk = 1; p.ksteps = K / TK; p.atomic = 0;
+    p.A = A; p.B = B; p.C = C; p.bias = epi.bias; p.addend = epi.addend; p.mask = epi.mask; p.relu = epi.relu;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.tiles_m = cdiv(M, TM); p.tiles_n = cdiv(N, TN_); p.splitk = 1; p.ksteps = cdiv(K, TK); p.atomic = 0;
     const long nwg = (long)p.tiles_m * p.tiles_n;
     TTMI_REQUIRE(nwg < (1L << 31), "gemm_nt_bf16: too many tiles");
     if (c_dtype == 0)
@@ -255,7 +285,7 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const f
 }
 
 bool gemm_fast_tn_ok(const void* A, const void* B, const void* C, int M, int N, int K, long lda, long ldb) {
-    return aligned16(A) && aligned16(B) && C && M > 0 && N > 0 && K >= TK && K % TK == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+    return aligned16(A) && aligned16(B) && C && M > 0 && N > 0 && K >= 1 && lda % 8 == 0 && ldb % 8 == 0 &&
            lda >= ((M + 7) & ~7) && ldb >= ((N + 7) & ~7);
 }
 
@@ -265,18 +295,20 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
     TTMI_REQUIRE(gemm_fast_tn_ok(A, B, C, M, N, K, lda, ldb), "gemm_tn_bf16: shape/alignment not supported (M=%d N=%d K=%d)", M,
                  N, K);
     FP p;
-    p.A = A; p.B = B; p.C = C; p.bias = nullptr; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.A = A; p.B = B; p.C = C; p.bias = nullptr; p.addend = nullptr; p.mask = nullptr; p.relu = 0;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.tiles_m = cdiv(M, TM); p.tiles_n = cdiv(N, TN_);
     const long tiles = (long)p.tiles_m * p.tiles_n;
-    const int ksteps_total = K / TK;
+    const int ksteps_total = cdiv(K, TK);
     int splitk = 1;
     if (tiles < 1024) {
         splitk = (int)((2048 + tiles - 1) / tiles);
         if (splitk > ksteps_total / 4) splitk = ksteps_total / 4;
         if (splitk < 1) splitk = 1;
     }
-    while (ksteps_total % splitk) --splitk;       // equal splits (K is a multiple of 64; worst case splitk = 1)
-    p.splitk = splitk; p.ksteps = ksteps_total / splitk;
+    p.ksteps = cdiv(ksteps_total, splitk);         // the last split may be short; rows >= K are zero-filled
+    splitk = cdiv(ksteps_total, p.ksteps);
+    p.splitk = splitk;
     p.atomic = (splitk > 1 || accumulate) ? 1 : 0;
     hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3((unsigned)tiles, splitk), dim3(NTH), 4 * TILE_B, st, p);
     TTMI_LAUNCH_CHECK("gemm_tn_bf16_kernel");
@@ -287,7 +319,9 @@ extern "C" {
 // bring-up / test entry points (dtype codes 0 = f32, 1 = bf16)
 int ttmi_gemm_nt_bf16(const void* A, const void* B, void* C, int c_dtype, const float* bias, int M, int N, int K, long lda,
                       long ldb, long ldc, void* stream) {
-    return gemm_nt_bf16(static_cast<const bf16_t*>(A), static_cast<const bf16_t*>(B), C, c_dtype, bias, M, N, K, lda, ldb, ldc,
+    NtEpilogue e;
+    e.bias = bias;
+    return gemm_nt_bf16(static_cast<const bf16_t*>(A), static_cast<const bf16_t*>(B), C, c_dtype, e, M, N, K, lda, ldb, ldc,
                         static_cast<hipStream_t>(stream));
 }
 int ttmi_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,

@@ -11,6 +11,7 @@
 // backward uses the mirror image: dS written through the pitch-L view IS dG in the pitch-(L+1) layout.
 #include "gemm.h"
 #include "rowops.h"
+#include "gemm_fast.h"
 
 void ttmi_probe_begin(int slot, hipStream_t st);
 void ttmi_probe_end(int slot, hipStream_t st);
@@ -61,38 +62,74 @@ struct AttnDims {
     }
 };
 
-struct AttnCtx {   // saved for backward, all f32
-    float *qkv, *qu, *P, *O, *s1, *mean, *rstd;
-    static size_t floats(const AttnDims& a) {
-        return al4(a.BL * a.W3) + al4(a.BL * a.HD) + al4((size_t)a.B * a.H * a.slab) + al4(a.BL * a.HD) + al4(a.BL * a.d) +
-               2 * al4(a.BL);
+// bump carving of caller-provided arenas; with base == nullptr it only measures
+struct Bump {
+    char* base;
+    size_t off = 0;
+    explicit Bump(void* b) : base(static_cast<char*>(b)) {}
+    template <typename T>
+    T* take(size_t n) {
+        off = (off + 255) & ~size_t(255);
+        T* r = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return r;
     }
-    AttnCtx(float* p, const AttnDims& a) {
-        qkv = p; p += al4(a.BL * a.W3);
-        qu = p; p += al4(a.BL * a.HD);
-        P = p; p += al4((size_t)a.B * a.H * a.slab);
-        O = p; p += al4(a.BL * a.HD);
-        s1 = p; p += al4(a.BL * a.d);
-        mean = p; p += al4(a.BL);
-        rstd = p;
+    size_t floats() const { return (off + 255) / 4 + 64; }
+};
+
+// "fast" = bf16 activation pipeline on the glds kernels (prec 1 and 16-byte-aligned row pitches)
+inline bool attn_fast(int prec, int d, int H, int Dh) { return prec == 1 && d % 8 == 0 && (H * Dh) % 8 == 0 && Dh % 4 == 0; }
+inline bool ffn_fast(int prec, int d, int Di) { return prec == 1 && d % 8 == 0 && Di % 8 == 0; }
+
+// element-typed pointer arithmetic on buffers that are f32 (parity path) or bf16 (fast path)
+inline void* eoff(void* p, int dt, long n) { return static_cast<char*>(p) + n * (dt == DT_BF16 ? 2 : 4); }
+inline const void* eoff(const void* p, int dt, long n) { return static_cast<const char*>(p) + n * (dt == DT_BF16 ? 2 : 4); }
+
+GemmDesc mkx(const void* A, int adt, const void* B, int bdt, void* C, int cdt, int M, int N, int K, long lda, long ldb, long ldc,
+             int flags, int prec) {
+    GemmDesc d;
+    d.A = A; d.B = B; d.C = C; d.a_dtype = adt; d.b_dtype = bdt; d.c_dtype = cdt;
+    d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc;
+    d.flags = flags | (prec ? GEMM_BF16_MFMA : 0);
+    return d;
+}
+
+struct AttnCtx {   // saved for backward.  act = f32 (parity) or bf16 (fast)
+    void *qkv, *qu, *O;
+    float *P, *s1, *mean, *rstd;
+    AttnCtx(Bump& b, const AttnDims& a, bool fast) {
+        const size_t es = fast ? 2 : 4;
+        qkv = b.take<char>(a.BL * a.W3 * es);
+        qu = b.take<char>(a.BL * a.HD * es);
+        O = b.take<char>(a.BL * a.HD * es);
+        P = b.take<float>((size_t)a.B * a.H * a.slab);
+        s1 = b.take<float>(a.BL * a.d);
+        mean = b.take<float>(a.BL);
+        rstd = b.take<float>(a.BL);
     }
 };
 
-struct AttnWs {   // scratch
-    float *E, *cT, *a, *dO, *dS, *dqkv, *dE, *dcT;
-    static size_t floats(const AttnDims& a) {
-        return 2 * al4((size_t)a.L * a.HD) + 2 * al4((size_t)a.H * a.L) + al4(a.BL * a.d) + al4(a.BL * a.HD) +
-               al4((size_t)a.B * a.H * a.slab) + al4(a.BL * a.W3);
-    }
-    AttnWs(float* p, const AttnDims& a) {
-        E = p; p += al4((size_t)a.L * a.HD);
-        cT = p; p += al4((size_t)a.H * a.L);
-        dE = p; p += al4((size_t)a.L * a.HD);
-        dcT = p; p += al4((size_t)a.H * a.L);
-        this->a = p; p += al4(a.BL * a.d);
-        dO = p; p += al4(a.BL * a.HD);
-        dS = p; p += al4((size_t)a.B * a.H * a.slab);
-        dqkv = p;
+struct AttnWs {   // scratch (union of forward and backward needs)
+    float *E, *cT, *dE, *dcT, *a, *dS, *dqkv;
+    void* dO;
+    bf16_t *x16, *wqkv16, *wo16, *dqkv16, *dres16;
+    AttnWs(Bump& b, const AttnDims& a, bool fast) {
+        E = b.take<float>((size_t)a.L * a.HD);
+        cT = b.take<float>((size_t)a.H * a.L);
+        dE = b.take<float>((size_t)a.L * a.HD + (size_t)a.H * a.L + 64);   // dE and dcT zeroed together
+        dcT = dE + (size_t)a.L * a.HD;
+        this->a = b.take<float>(a.BL * a.d);
+        dS = b.take<float>((size_t)a.B * a.H * a.slab);
+        dqkv = b.take<float>(a.BL * a.W3);
+        dO = b.take<char>(a.BL * a.HD * (fast ? 2 : 4));
+        x16 = wqkv16 = wo16 = dqkv16 = dres16 = nullptr;
+        if (fast) {
+            x16 = b.take<bf16_t>(a.BL * a.d);
+            wqkv16 = b.take<bf16_t>(a.W3 * a.d);
+            wo16 = b.take<bf16_t>(a.HD * a.d);
+            dqkv16 = b.take<bf16_t>(a.BL * a.W3);
+            dres16 = b.take<bf16_t>(a.BL * a.d);
+        }
     }
 };
 
@@ -115,12 +152,21 @@ void batch_bh(GemmDesc& g, const AttnDims& a, long sA1, long sA2, long sB1, long
 
 extern "C" {
 
-size_t ttmi_attn_ctx_floats(int B, int L, int d, int H, int Dh) { return AttnCtx::floats(AttnDims(B, L, d, H, Dh, 1)); }
-size_t ttmi_attn_ws_floats(int B, int L, int d, int H, int Dh) { return AttnWs::floats(AttnDims(B, L, d, H, Dh, 1)); }
+size_t ttmi_attn_ctx_floats(int B, int L, int d, int H, int Dh, int prec) {
+    Bump b(nullptr);
+    AttnCtx c(b, AttnDims(B, L, d, H, Dh, 1), attn_fast(prec, d, H, Dh));
+    return b.floats();
+}
+size_t ttmi_attn_ws_floats(int B, int L, int d, int H, int Dh, int prec) {
+    Bump b(nullptr);
+    AttnWs w(b, AttnDims(B, L, d, H, Dh, 1), attn_fast(prec, d, H, Dh));
+    return b.floats();
+}
 
 // RelLearnableMultiHeadAttn.forward (tt/transformer.py:106-177), batch-major: x,y f32 [B,L,d].
 // mask_kind: 0 none, 1 causal (look_ahead_mask), 2 band(left,right) (context_mask), 3 uint8 tensor (b,i,j) at
-// mask[b*mask_sb + i*mask_si + j], nonzero = masked.  prec: 0 = exact-f32 MFMA, 1 = bf16 MFMA.
+// mask[b*mask_sb + i*mask_si + j], nonzero = masked.  prec: 0 = exact-f32 MFMA, 1 = bf16 MFMA (bf16 q/k/v/O in HBM,
+// dense projections on the glds kernels).  ctx/ws must be 256-byte aligned.
 int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const float* ln_g, const float* ln_b,
                   const float* r_emb, const float* r_w_bias, const float* r_bias, int B, int L, int d, int H, int Dh, int K,
                   int mask_kind, int mask_left, int mask_right, const unsigned char* mask, long mask_sb, long mask_si,
@@ -128,28 +174,38 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
     TTMI_REQUIRE(x && qkv_w && o_w && ln_g && ln_b && r_emb && r_w_bias && r_bias && ctx && ws && y, "attn_fwd: null pointer");
     TTMI_REQUIRE(B > 0 && L > 0 && d > 0 && H > 0 && Dh > 0 && K > 0, "attn_fwd: bad dims");
     TTMI_REQUIRE(mask_kind >= 0 && mask_kind <= 3, "attn_fwd: bad mask kind %d", mask_kind);
+    TTMI_REQUIRE(((reinterpret_cast<uintptr_t>(ctx) | reinterpret_cast<uintptr_t>(ws)) & 255) == 0, "attn_fwd: ctx/ws must be 256-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const AttnDims a(B, L, d, H, Dh, K);
-    AttnCtx c(ctx, a);
-    AttnWs w(ws, a);
+    const bool fast = attn_fast(prec, d, H, Dh);
+    const int adt = fast ? DT_BF16 : DT_F32;
+    Bump bc(ctx), bw(ws);
+    AttnCtx c(bc, a, fast);
+    AttnWs w(bw, a, fast);
     const float scale = 1.0f / sqrtf((float)Dh);
-    // 1. qkv = x Wqkv^T
-    CK(ttmi_launch_gemm(mk(x, qkv_w, c.qkv, (int)a.BL, (int)a.W3, d, d, d, a.W3, NT_, prec), st));
-    // 2. qu = q + r_w_bias
-    CK(add_row_bias(c.qkv, a.W3, r_w_bias, a.BL, (int)a.HD, c.qu, a.HD, st));
+    // 1. qkv = x Wqkv^T ; 2. qu = q + r_w_bias
+    if (fast) {
+        CK(convert_bf16(x, w.x16, a.BL * d, st));
+        CK(convert_bf16(qkv_w, w.wqkv16, a.W3 * d, st));
+        CK(gemm_nt_bf16(w.x16, w.wqkv16, c.qkv, 1, nullptr, (int)a.BL, (int)a.W3, d, d, d, a.W3, st));
+        CK(add_row_bias_bf16(static_cast<bf16_t*>(c.qkv), a.W3, r_w_bias, a.BL, (int)a.HD, static_cast<bf16_t*>(c.qu), a.HD, st));
+    } else {
+        CK(ttmi_launch_gemm(mk(x, qkv_w, static_cast<float*>(c.qkv), (int)a.BL, (int)a.W3, d, d, d, a.W3, NT_, prec), st));
+        CK(add_row_bias(static_cast<float*>(c.qkv), a.W3, r_w_bias, a.BL, (int)a.HD, static_cast<float*>(c.qu), a.HD, st));
+    }
     // 3. effective tables for this length (clamped rows when L > K)
     CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st));
     // 4. G = q E^T + c into the pitch-(L+1) slab, column 0 zero
     CK(memset2d(c.P, (size_t)(L + 1) * 4, 4, (size_t)B * H * L, st));
     {
-        GemmDesc g = mk(c.qkv, w.E, c.P + 1, L, L, Dh, a.W3, a.HD, L + 1, NT_ | GEMM_BIAS, prec);
+        GemmDesc g = mkx(c.qkv, adt, w.E, DT_F32, c.P + 1, DT_F32, L, L, Dh, a.W3, a.HD, L + 1, NT_ | GEMM_BIAS, prec);
         batch_bh(g, a, L * a.W3, Dh, 0, Dh, H * a.slab, a.slab);
         g.bias = w.cT; g.sBias1 = 0; g.sBias2 = L;
         CK(ttmi_launch_gemm(g, st));
     }
     // 5. S = shifted(G) + (q+u) k^T, accumulated through the pitch-L view
     {
-        GemmDesc g = mk(c.qu, c.qkv + a.HD, c.P + L, L, L, Dh, a.HD, a.W3, L, NT_, prec);
+        GemmDesc g = mkx(c.qu, adt, eoff(c.qkv, adt, a.HD), adt, c.P + L, DT_F32, L, L, Dh, a.HD, a.W3, L, NT_, prec);
         batch_bh(g, a, L * a.HD, Dh, L * a.W3, Dh, H * a.slab, a.slab);
         g.beta = 1.f;
         CK(ttmi_launch_gemm(g, st));
@@ -160,12 +216,17 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
     CK(softmax_fwd(c.P + L, B, H, L, L, a.slab, scale, m, st));
     // 7. O = P V
     {
-        GemmDesc g = mk(c.P + L, c.qkv + 2 * a.HD, c.O, L, Dh, L, L, a.W3, a.HD, NN_, prec);
+        GemmDesc g = mkx(c.P + L, DT_F32, eoff(c.qkv, adt, 2 * a.HD), adt, c.O, adt, L, Dh, L, L, a.W3, a.HD, NN_, prec);
         batch_bh(g, a, H * a.slab, a.slab, L * a.W3, Dh, L * a.HD, Dh);
         CK(ttmi_launch_gemm(g, st));
     }
     // 8. a = O Wo^T ; 9. y = LN(x + a)
-    CK(ttmi_launch_gemm(mk(c.O, o_w, w.a, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, NT_, prec), st));
+    if (fast) {
+        CK(convert_bf16(o_w, w.wo16, (long)d * a.HD, st));
+        CK(gemm_nt_bf16(static_cast<bf16_t*>(c.O), w.wo16, w.a, 0, nullptr, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, st));
+    } else {
+        CK(ttmi_launch_gemm(mk(static_cast<float*>(c.O), o_w, w.a, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, NT_, prec), st));
+    }
     CK(ln_fwd(x, w.a, ln_g, ln_b, a.BL, d, 1e-5f, c.s1, y, c.mean, c.rstd, st));
     return TTMI_OK;
 }
@@ -179,24 +240,34 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
     TTMI_REQUIRE(g_qkv_w && g_o_w && g_ln_g && g_ln_b && g_r_emb && g_r_w_bias && g_r_bias, "attn_bwd: null gradient pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const AttnDims a(B, L, d, H, Dh, K);
-    AttnCtx c(const_cast<float*>(ctx), a);
-    AttnWs w(ws, a);
+    const bool fast = attn_fast(prec, d, H, Dh);
+    const int adt = fast ? DT_BF16 : DT_F32;
+    Bump bc(const_cast<float*>(ctx)), bw(ws);
+    AttnCtx c(bc, a, fast);
+    AttnWs w(bw, a, fast);
     const float scale = 1.0f / sqrtf((float)Dh);
     // 1. dres = LN'(dy) -> dx (doubles as the residual gradient)
     CK(ln_bwd(dy, c.s1, c.mean, c.rstd, ln_g, nullptr, a.BL, d, dx, g_ln_g, g_ln_b, st));
     // 2. gWo += dres^T O ; 3. dO = dres Wo
-    CK(wgrad(dx, c.O, g_o_w, d, (int)a.HD, (int)a.BL, d, a.HD, a.HD, prec, st));
-    CK(ttmi_launch_gemm(mk(dx, o_w, w.dO, (int)a.BL, (int)a.HD, d, d, a.HD, a.HD, NN_, prec), st));
+    if (fast) {
+        CK(convert_bf16(dx, w.dres16, a.BL * d, st));
+        CK(gemm_tn_bf16(w.dres16, static_cast<bf16_t*>(c.O), g_o_w, d, (int)a.HD, (int)a.BL, d, a.HD, a.HD, 1, st));
+        CK(transpose_convert_bf16(o_w, d, (int)a.HD, w.wo16, d, st));                          // Wo^T [HD, d]
+        CK(gemm_nt_bf16(w.dres16, w.wo16, w.dO, 1, nullptr, (int)a.BL, (int)a.HD, d, d, d, a.HD, st));
+    } else {
+        CK(wgrad(dx, static_cast<float*>(c.O), g_o_w, d, (int)a.HD, (int)a.BL, d, a.HD, a.HD, prec, st));
+        CK(ttmi_launch_gemm(mk(dx, o_w, static_cast<float*>(w.dO), (int)a.BL, (int)a.HD, d, d, a.HD, a.HD, NN_, prec), st));
+    }
     // 4. dP = dO V^T through the pitch-L view of the dS slab (first L floats of each slab are outside the view)
     CK(memset2d(w.dS, (size_t)a.slab * 4, (size_t)L * 4, (size_t)B * H, st));
     {
-        GemmDesc g = mk(w.dO, c.qkv + 2 * a.HD, w.dS + L, L, L, Dh, a.HD, a.W3, L, NT_, prec);
+        GemmDesc g = mkx(w.dO, adt, eoff(c.qkv, adt, 2 * a.HD), adt, w.dS + L, DT_F32, L, L, Dh, a.HD, a.W3, L, NT_, prec);
         batch_bh(g, a, L * a.HD, Dh, L * a.W3, Dh, H * a.slab, a.slab);
         CK(ttmi_launch_gemm(g, st));
     }
     // 5. dV = P^T dO
     {
-        GemmDesc g = mk(c.P + L, w.dO, w.dqkv + 2 * a.HD, L, Dh, L, L, a.HD, a.W3, TN_, prec);
+        GemmDesc g = mkx(c.P + L, DT_F32, w.dO, adt, w.dqkv + 2 * a.HD, DT_F32, L, Dh, L, L, a.HD, a.W3, TN_, prec);
         batch_bh(g, a, H * a.slab, a.slab, L * a.HD, Dh, L * a.W3, Dh);
         CK(ttmi_launch_gemm(g, st));
     }
@@ -204,7 +275,7 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
     CK(softmax_bwd(w.dS + L, c.P + L, B * H, L, L, a.slab, scale, st));
     // 7. dq(content) = dS K -> dqkv[q]
     {
-        GemmDesc g = mk(w.dS + L, c.qkv + a.HD, w.dqkv, L, Dh, L, L, a.W3, a.W3, NN_, prec);
+        GemmDesc g = mkx(w.dS + L, DT_F32, eoff(c.qkv, adt, a.HD), adt, w.dqkv, DT_F32, L, Dh, L, L, a.W3, a.W3, NN_, prec);
         batch_bh(g, a, H * a.slab, a.slab, L * a.W3, Dh, L * a.W3, Dh);
         CK(ttmi_launch_gemm(g, st));
     }
@@ -212,30 +283,38 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
     CK(colsum(w.dqkv, a.W3, a.BL, (int)a.HD, 1, 1, 0, 0, 0, 0, g_r_w_bias, st));
     // 9. dK = dS^T (q + u)
     {
-        GemmDesc g = mk(w.dS + L, c.qu, w.dqkv + a.HD, L, Dh, L, L, a.HD, a.W3, TN_, prec);
+        GemmDesc g = mkx(w.dS + L, DT_F32, c.qu, adt, w.dqkv + a.HD, DT_F32, L, Dh, L, L, a.HD, a.W3, TN_, prec);
         batch_bh(g, a, H * a.slab, a.slab, L * a.HD, Dh, L * a.W3, Dh);
         CK(ttmi_launch_gemm(g, st));
     }
     // 10. dq += dG E   (dG = the same slab read with pitch L+1, column offset 1)
     CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st));
     {
-        GemmDesc g = mk(w.dS + 1, w.E, w.dqkv, L, Dh, L, L + 1, a.HD, a.W3, NN_, prec);
+        GemmDesc g = mkx(w.dS + 1, DT_F32, w.E, DT_F32, w.dqkv, DT_F32, L, Dh, L, L + 1, a.HD, a.W3, NN_, prec);
         batch_bh(g, a, H * a.slab, a.slab, 0, Dh, L * a.W3, Dh);
         g.beta = 1.f;
         CK(ttmi_launch_gemm(g, st));
     }
     // 11. dE[p,h,:] = sum_b dG^T q ; 12. dc[h][p] = sum_b colsum(dG) ; 13. fold onto the K-row tables
-    CK(fill_zero(w.dE, sizeof(float) * (al4((size_t)L * a.HD) + al4((size_t)H * L)), st));   // dE and dcT are adjacent
+    CK(fill_zero(w.dE, sizeof(float) * ((size_t)L * a.HD + (size_t)H * L), st));
     {
-        GemmDesc g = mk(w.dS + 1, c.qkv, w.dE, L, Dh, L, L + 1, a.W3, a.HD, TN_ | GEMM_ATOMIC, prec);
+        GemmDesc g = mkx(w.dS + 1, DT_F32, c.qkv, adt, w.dE, DT_F32, L, Dh, L, L + 1, a.W3, a.HD, TN_ | GEMM_ATOMIC, prec);
         batch_bh(g, a, H * a.slab, a.slab, L * a.W3, Dh, 0, Dh);
         CK(ttmi_launch_gemm(g, st));
     }
     CK(colsum(w.dS + 1, L + 1, L, L, B, H, H * a.slab, a.slab, 0, L, w.dcT, st));
     CK(relpos_scatter(w.dE, w.dcT, K, L, H, Dh, g_r_emb, g_r_bias, st));
     // 14. gWqkv += dqkv^T x ; 15. dx += dqkv Wqkv
-    CK(wgrad(w.dqkv, x, g_qkv_w, (int)a.W3, d, (int)a.BL, a.W3, d, d, prec, st));
-    {
+    if (fast) {
+        CK(convert_bf16(w.dqkv, w.dqkv16, a.BL * a.W3, st));
+        CK(convert_bf16(x, w.x16, a.BL * d, st));
+        CK(gemm_tn_bf16(w.dqkv16, w.x16, g_qkv_w, (int)a.W3, d, (int)a.BL, a.W3, d, d, 1, st));
+        CK(transpose_convert_bf16(qkv_w, (int)a.W3, d, w.wqkv16, a.W3, st));                   // Wqkv^T [d, W3]
+        NtEpilogue e;
+        e.addend = dx;
+        CK(gemm_nt_bf16(w.dqkv16, w.wqkv16, dx, 0, e, (int)a.BL, d, (int)a.W3, a.W3, a.W3, d, st));
+    } else {
+        CK(wgrad(w.dqkv, x, g_qkv_w, (int)a.W3, d, (int)a.BL, a.W3, d, d, prec, st));
         GemmDesc g = mk(w.dqkv, qkv_w, dx, (int)a.BL, d, (int)a.W3, a.W3, d, d, NN_, prec);
         g.beta = 1.f;
         CK(ttmi_launch_gemm(g, st));
@@ -244,35 +323,80 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
 }
 
 // ------------------------------------------------------------------ position-wise FFN (tt/transformer.py:54-58)
-size_t ttmi_ffn_ctx_floats(long rows, int d, int Di) { return 2 * al4(rows * d) + al4(rows * Di) + 4 * al4(rows); }
-size_t ttmi_ffn_ws_floats(long rows, int d, int Di) { return 2 * al4(rows * d) + al4(rows * Di); }
+namespace {
+struct FfnCtx {
+    void *h, *a1;      // f32 (parity) or bf16 (fast)
+    float *s2, *mean1, *rstd1, *mean2, *rstd2;
+    FfnCtx(Bump& b, long rows, int d, int Di, bool fast) {
+        const size_t es = fast ? 2 : 4;
+        h = b.take<char>(rows * d * es);
+        a1 = b.take<char>(rows * Di * es);
+        s2 = b.take<float>(rows * d);
+        mean1 = b.take<float>(rows); rstd1 = b.take<float>(rows);
+        mean2 = b.take<float>(rows); rstd2 = b.take<float>(rows);
+    }
+};
+struct FfnWs {
+    float *f, *dres, *dh;
+    void* da1;
+    bf16_t *w1_16, *w2_16, *dres16;
+    FfnWs(Bump& b, long rows, int d, int Di, bool fast) {
+        f = b.take<float>(rows * d);
+        dres = b.take<float>(rows * d);
+        dh = b.take<float>(rows * d);
+        da1 = b.take<char>(rows * Di * (fast ? 2 : 4));
+        w1_16 = w2_16 = dres16 = nullptr;
+        if (fast) {
+            w1_16 = b.take<bf16_t>((size_t)Di * d);
+            w2_16 = b.take<bf16_t>((size_t)Di * d);
+            dres16 = b.take<bf16_t>(rows * d);
+        }
+    }
+};
+}  // namespace
+
+size_t ttmi_ffn_ctx_floats(long rows, int d, int Di, int prec) {
+    Bump b(nullptr);
+    FfnCtx c(b, rows, d, Di, ffn_fast(prec, d, Di));
+    return b.floats();
+}
+size_t ttmi_ffn_ws_floats(long rows, int d, int Di, int prec) {
+    Bump b(nullptr);
+    FfnWs w(b, rows, d, Di, ffn_fast(prec, d, Di));
+    return b.floats();
+}
 
 // z = LN(y + W2 relu(W1 LN(y) + b1) + b2), the SAME (ln_g, ln_b) in both norms.
 int ttmi_ffn_fwd(const float* y, const float* w1, const float* b1, const float* w2, const float* b2, const float* ln_g,
                  const float* ln_b, long rows, int d, int Di, int prec, float* ctx, float* ws, float* z, void* stream) {
     TTMI_REQUIRE(y && w1 && b1 && w2 && b2 && ln_g && ln_b && ctx && ws && z, "ffn_fwd: null pointer");
     TTMI_REQUIRE(rows > 0 && rows < (1L << 31) && d > 0 && Di > 0, "ffn_fwd: bad dims");
+    TTMI_REQUIRE(((reinterpret_cast<uintptr_t>(ctx) | reinterpret_cast<uintptr_t>(ws)) & 255) == 0, "ffn_fwd: ctx/ws must be 256-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    float* h = ctx;
-    float* s2 = h + al4(rows * d);
-    float* a1 = s2 + al4(rows * d);
-    float* mean1 = a1 + al4(rows * Di);
-    float* rstd1 = mean1 + al4(rows);
-    float* mean2 = rstd1 + al4(rows);
-    float* rstd2 = mean2 + al4(rows);
-    float* f = ws;
-    CK(ln_fwd(y, nullptr, ln_g, ln_b, rows, d, 1e-5f, nullptr, h, mean1, rstd1, st));
-    {
+    const bool fast = ffn_fast(prec, d, Di);
+    Bump bc(ctx), bw(ws);
+    FfnCtx c(bc, rows, d, Di, fast);
+    FfnWs w(bw, rows, d, Di, fast);
+    if (fast) {
+        CK(ln_fwd(y, nullptr, ln_g, ln_b, rows, d, 1e-5f, nullptr, nullptr, c.mean1, c.rstd1, st, static_cast<bf16_t*>(c.h)));
+        CK(convert_bf16(w1, w.w1_16, (long)Di * d, st));
+        CK(convert_bf16(w2, w.w2_16, (long)Di * d, st));
+        NtEpilogue e1;
+        e1.bias = b1; e1.relu = 1;
+        CK(gemm_nt_bf16(static_cast<bf16_t*>(c.h), w.w1_16, c.a1, 1, e1, (int)rows, Di, d, d, d, Di, st));
+        CK(gemm_nt_bf16(static_cast<bf16_t*>(c.a1), w.w2_16, w.f, 0, b2, (int)rows, d, Di, Di, Di, d, st));
+    } else {
+        float* h = static_cast<float*>(c.h);
+        float* a1 = static_cast<float*>(c.a1);
+        CK(ln_fwd(y, nullptr, ln_g, ln_b, rows, d, 1e-5f, nullptr, h, c.mean1, c.rstd1, st));
         GemmDesc g = mk(h, w1, a1, (int)rows, Di, d, d, d, Di, NT_ | GEMM_BIAS | GEMM_RELU, prec);
         g.bias = b1;
         CK(ttmi_launch_gemm(g, st));
+        GemmDesc g2 = mk(a1, w2, w.f, (int)rows, d, Di, Di, Di, d, NT_ | GEMM_BIAS, prec);
+        g2.bias = b2;
+        CK(ttmi_launch_gemm(g2, st));
     }
-    {
-        GemmDesc g = mk(a1, w2, f, (int)rows, d, Di, Di, Di, d, NT_ | GEMM_BIAS, prec);
-        g.bias = b2;
-        CK(ttmi_launch_gemm(g, st));
-    }
-    CK(ln_fwd(y, f, ln_g, ln_b, rows, d, 1e-5f, s2, z, mean2, rstd2, st));
+    CK(ln_fwd(y, w.f, ln_g, ln_b, rows, d, 1e-5f, c.s2, z, c.mean2, c.rstd2, st));
     return TTMI_OK;
 }
 
@@ -282,28 +406,39 @@ int ttmi_ffn_bwd(const float* dz, const float* y, const float* w1, const float* 
     TTMI_REQUIRE(dz && y && w1 && w2 && ln_g && ctx && ws && dy && g_w1 && g_b1 && g_w2 && g_b2 && g_ln_g && g_ln_b,
                  "ffn_bwd: null pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const float* h = ctx;
-    const float* s2 = h + al4(rows * d);
-    const float* a1 = s2 + al4(rows * d);
-    const float* mean1 = a1 + al4(rows * Di);
-    const float* rstd1 = mean1 + al4(rows);
-    const float* mean2 = rstd1 + al4(rows);
-    const float* rstd2 = mean2 + al4(rows);
-    float* dres = ws;
-    float* dh = dres + al4(rows * d);
-    float* da1 = dh + al4(rows * d);
-    CK(ln_bwd(dz, s2, mean2, rstd2, ln_g, nullptr, rows, d, dres, g_ln_g, g_ln_b, st));
-    CK(colsum(dres, d, rows, d, 1, 1, 0, 0, 0, 0, g_b2, st));
-    CK(wgrad(dres, a1, g_w2, d, Di, (int)rows, d, Di, Di, prec, st));
-    {
-        GemmDesc g = mk(dres, w2, da1, (int)rows, Di, d, d, Di, Di, NN_ | GEMM_MASK_AUX, prec);
+    const bool fast = ffn_fast(prec, d, Di);
+    Bump bc(const_cast<float*>(ctx)), bw(ws);
+    FfnCtx c(bc, rows, d, Di, fast);
+    FfnWs w(bw, rows, d, Di, fast);
+    CK(ln_bwd(dz, c.s2, c.mean2, c.rstd2, ln_g, nullptr, rows, d, w.dres, g_ln_g, g_ln_b, st));
+    CK(colsum(w.dres, d, rows, d, 1, 1, 0, 0, 0, 0, g_b2, st));
+    if (fast) {
+        bf16_t* a1 = static_cast<bf16_t*>(c.a1);
+        bf16_t* h = static_cast<bf16_t*>(c.h);
+        bf16_t* da1 = static_cast<bf16_t*>(w.da1);
+        CK(convert_bf16(w.dres, w.dres16, rows * d, st));
+        CK(gemm_tn_bf16(w.dres16, a1, g_w2, d, Di, (int)rows, d, Di, Di, 1, st));
+        CK(transpose_convert_bf16(w2, d, Di, w.w2_16, d, st));                                 // W2^T [Di, d]
+        NtEpilogue e;
+        e.mask = a1;
+        CK(gemm_nt_bf16(w.dres16, w.w2_16, da1, 1, e, (int)rows, Di, d, d, d, Di, st));
+        CK(colsum_bf16(da1, Di, rows, Di, g_b1, st));
+        CK(gemm_tn_bf16(da1, h, g_w1, Di, d, (int)rows, Di, d, d, 1, st));
+        CK(transpose_convert_bf16(w1, Di, d, w.w1_16, Di, st));                                // W1^T [d, Di]
+        CK(gemm_nt_bf16(da1, w.w1_16, w.dh, 0, nullptr, (int)rows, d, Di, Di, Di, d, st));
+    } else {
+        const float* a1 = static_cast<const float*>(c.a1);
+        const float* h = static_cast<const float*>(c.h);
+        float* da1 = static_cast<float*>(w.da1);
+        CK(wgrad(w.dres, a1, g_w2, d, Di, (int)rows, d, Di, Di, prec, st));
+        GemmDesc g = mk(w.dres, w2, da1, (int)rows, Di, d, d, Di, Di, NN_ | GEMM_MASK_AUX, prec);
         g.aux = a1;
         CK(ttmi_launch_gemm(g, st));
+        CK(colsum(da1, Di, rows, Di, 1, 1, 0, 0, 0, 0, g_b1, st));
+        CK(wgrad(da1, h, g_w1, Di, d, (int)rows, Di, d, d, prec, st));
+        CK(ttmi_launch_gemm(mk(da1, w1, w.dh, (int)rows, d, Di, Di, d, d, NN_, prec), st));
     }
-    CK(colsum(da1, Di, rows, Di, 1, 1, 0, 0, 0, 0, g_b1, st));
-    CK(wgrad(da1, h, g_w1, Di, d, (int)rows, Di, d, d, prec, st));
-    CK(ttmi_launch_gemm(mk(da1, w1, dh, (int)rows, d, Di, Di, d, d, NN_, prec), st));
-    CK(ln_bwd(dh, y, mean1, rstd1, ln_g, dres, rows, d, dy, g_ln_g, g_ln_b, st));
+    CK(ln_bwd(w.dh, y, c.mean1, c.rstd1, ln_g, w.dres, rows, d, dy, g_ln_g, g_ln_b, st));
     return TTMI_OK;
 }
 
@@ -311,53 +446,92 @@ int ttmi_ffn_bwd(const float* dz, const float* y, const float* w1, const float* 
 // z[b,t,u,:] = Wp tanh(We enc[b,t] + Wd dec[b,u] + bf) + bp, forward_layer.weight = [We | Wd] ([J, de+dd]).
 // The reference repeats enc/dec to [B,T,U1,de+dd] and concatenates; the split-weight form is the same
 // arithmetic without the 3 x [B,T,U1,*] temporaries.
+//
+// prec 0: everything f32 (exact-f32 MFMA).  prec 1 with J % 8 == 0 ("fast"): H, logits and dlogits are bf16 in HBM,
+// the vocabulary projection / its dgrad / its wgrad run on the glds-staged kernels of gemm_fast.hip; logits rows
+// have pitch ldv >= V (callers use a multiple of 64) and dlogits must be zero in columns [V, ldv).
+static inline bool joint_fast(int prec, int J) { return prec == 1 && J % 8 == 0; }
+// dtype of the logits this configuration produces / expects: 0 = f32, 1 = bf16
+int ttmi_joint_logits_dtype(int prec, int J) { return joint_fast(prec, J) ? 1 : 0; }
+
 size_t ttmi_joint_ctx_floats(int B, int T, int U1, int J) { return al4((size_t)B * T * U1 * J); }
-size_t ttmi_joint_ws_floats(int B, int T, int U1, int J) {
-    return al4((size_t)B * T * U1 * J) + 2 * al4((size_t)B * T * J) + 2 * al4((size_t)B * U1 * J);
+size_t ttmi_joint_ws_floats(int B, int T, int U1, int J, int V) {
+    return al4((size_t)B * T * U1 * J) + 2 * al4((size_t)B * T * J) + 2 * al4((size_t)B * U1 * J) +
+           al4((size_t)J * (((size_t)V + 63) / 64 * 64));
 }
 
 int ttmi_joint_fwd(const float* enc, const float* dec, const float* wf, const float* bf, const float* wp, const float* bp,
-                   int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx, float* ws, float* logits,
+                   int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx, float* ws, void* logits, long ldv,
                    void* stream) {
     TTMI_REQUIRE(enc && dec && wf && bf && wp && bp && ctx && ws && logits, "joint_fwd: null pointer");
-    TTMI_REQUIRE(B > 0 && T > 0 && U1 > 0 && de > 0 && dd > 0 && J > 0 && V > 0, "joint_fwd: bad dims");
+    TTMI_REQUIRE(B > 0 && T > 0 && U1 > 0 && de > 0 && dd > 0 && J > 0 && V > 0 && ldv >= V, "joint_fwd: bad dims");
     TTMI_REQUIRE((long)B * T * U1 < (1L << 31), "joint_fwd: B*T*(U+1) too large");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    float* Hh = ctx;
+    const bool fast = joint_fast(prec, J);
     float* PE = ws + al4((size_t)B * T * U1 * J);
     float* PD = PE + al4((size_t)B * T * J);
     const int din = de + dd;
+    const int M = B * T * U1;
     CK(ttmi_launch_gemm(mk(enc, wf, PE, B * T, J, de, de, din, J, NT_, prec), st));
     CK(ttmi_launch_gemm(mk(dec, wf + de, PD, B * U1, J, dd, dd, din, J, NT_, prec), st));
-    CK(joint_tanh_fwd(PE, PD, bf, B, T, U1, J, Hh, 0, st));
-    {
-        GemmDesc g = mk(Hh, wp, logits, B * T * U1, V, J, J, J, V, NT_ | GEMM_BIAS, prec);
+    if (!fast) {
+        float* Hh = ctx;
+        CK(joint_tanh_fwd(PE, PD, bf, B, T, U1, J, Hh, 0, st));
+        GemmDesc g = mk(Hh, wp, static_cast<float*>(logits), M, V, J, J, J, ldv, NT_ | GEMM_BIAS, prec);
         g.bias = bp;
         ttmi_probe_begin(0, st);
         const int rc = ttmi_launch_gemm(g, st);
         ttmi_probe_end(0, st);
         CK(rc);
+        return TTMI_OK;
     }
+    TTMI_REQUIRE(ldv % 8 == 0 && aligned16(logits), "joint_fwd: bf16 logits need a 16-byte aligned base and pitch %% 8 == 0");
+    bf16_t* H16 = reinterpret_cast<bf16_t*>(ctx);
+    bf16_t* Wp16 = reinterpret_cast<bf16_t*>(PD + 2 * al4((size_t)B * U1 * J));
+    CK(joint_tanh_fwd(PE, PD, bf, B, T, U1, J, H16, 1, st));
+    CK(convert_bf16(wp, Wp16, (long)V * J, st));
+    ttmi_probe_begin(0, st);
+    const int rc = gemm_nt_bf16(H16, Wp16, logits, 1, bp, M, V, J, J, J, ldv, st);
+    ttmi_probe_end(0, st);
+    CK(rc);
     return TTMI_OK;
 }
 
-int ttmi_joint_bwd(const float* dlogits, const float* enc, const float* dec, const float* wf, const float* wp, int B, int T,
-                   int U1, int de, int dd, int J, int V, int prec, const float* ctx, float* ws, float* denc, float* ddec,
+int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float* dec, const float* wf, const float* wp, int B,
+                   int T, int U1, int de, int dd, int J, int V, int prec, const float* ctx, float* ws, float* denc, float* ddec,
                    float* g_wf, float* g_bf, float* g_wp, float* g_bp, void* stream) {
     TTMI_REQUIRE(dlogits && enc && dec && wf && wp && ctx && ws && denc && ddec && g_wf && g_bf && g_wp && g_bp,
                  "joint_bwd: null pointer");
+    TTMI_REQUIRE(ldg >= V, "joint_bwd: bad pitch");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const float* Hh = ctx;
-    float* dH = ws;
+    const bool fast = joint_fast(prec, J);
     float* dPE = ws + al4((size_t)B * T * U1 * J);
     float* dPD = dPE + 2 * al4((size_t)B * T * J);
     const int din = de + dd;
     const int M = B * T * U1;
-    CK(colsum(dlogits, V, M, V, 1, 1, 0, 0, 0, 0, g_bp, st));
-    CK(wgrad(dlogits, Hh, g_wp, V, J, M, V, J, J, prec, st));
-    CK(ttmi_launch_gemm(mk(dlogits, wp, dH, M, J, V, V, J, J, NN_, prec), st));
-    CK(fill_zero(dPD, sizeof(float) * (size_t)B * U1 * J, st));
-    CK(joint_tanh_bwd(dH, Hh, 0, B, T, U1, J, dPE, dPD, st));
+    if (!fast) {
+        const float* Hh = ctx;
+        const float* dZ = static_cast<const float*>(dlogits);
+        float* dH = ws;
+        CK(colsum(dZ, ldg, M, V, 1, 1, 0, 0, 0, 0, g_bp, st));
+        CK(wgrad(dZ, Hh, g_wp, V, J, M, ldg, J, J, prec, st));
+        CK(ttmi_launch_gemm(mk(dZ, wp, dH, M, J, V, ldg, J, J, NN_, prec), st));
+        CK(fill_zero(dPD, sizeof(float) * (size_t)B * U1 * J, st));
+        CK(joint_tanh_bwd(dH, Hh, 0, B, T, U1, J, dPE, dPD, st));
+    } else {
+        TTMI_REQUIRE(ldg % 8 == 0 && aligned16(dlogits), "joint_bwd: bf16 dlogits need 16-byte alignment and pitch %% 8 == 0");
+        const bf16_t* H16 = reinterpret_cast<const bf16_t*>(ctx);
+        const bf16_t* dZ = static_cast<const bf16_t*>(dlogits);
+        bf16_t* dH16 = reinterpret_cast<bf16_t*>(ws);
+        bf16_t* WpT16 = reinterpret_cast<bf16_t*>(dPD + 2 * al4((size_t)B * U1 * J));    // [J, ldg], zero beyond V
+        TTMI_REQUIRE((size_t)J * ldg <= 2 * al4((size_t)J * (((size_t)V + 63) / 64 * 64)), "joint_bwd: pitch %ld too large for the workspace", ldg);
+        CK(colsum_bf16(dZ, ldg, M, V, g_bp, st));
+        CK(gemm_tn_bf16(dZ, H16, g_wp, V, J, M, ldg, J, J, 1, st));
+        CK(transpose_convert_bf16(wp, V, J, WpT16, ldg, st));
+        CK(gemm_nt_bf16(dZ, WpT16, dH16, 1, nullptr, M, J, (int)ldg, ldg, ldg, J, st));
+        CK(fill_zero(dPD, sizeof(float) * (size_t)B * U1 * J, st));
+        CK(joint_tanh_bwd(dH16, H16, 1, B, T, U1, J, dPE, dPD, st));
+    }
     CK(colsum(dPE, J, (long)B * T, J, 1, 1, 0, 0, 0, 0, g_bf, st));
     CK(wgrad(dPE, enc, g_wf, J, de, B * T, J, de, din, prec, st));
     CK(wgrad(dPD, dec, g_wf + de, J, dd, B * U1, J, dd, din, prec, st));

@@ -49,11 +49,60 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // size in floats of one utterance's diagonal-major array
 __host__ __device__ __forceinline__ long diag_stride(int T, int U1) { return (long)(T + U1 - 1) * U1; }
 
+// ------------------------------------------------------------------ row access helpers (f32 or bf16 logits)
+template <typename TL>
+struct Vec16 {                                   // one 16-byte access = NV elements
+    static constexpr int NV = 16 / sizeof(TL);
+    float f[NV];
+    __device__ __forceinline__ void load(const TL* p) {
+        const uint4 w = *reinterpret_cast<const uint4*>(p);
+        if constexpr (sizeof(TL) == 4) {
+            f[0] = __uint_as_float(w.x); f[1] = __uint_as_float(w.y); f[2] = __uint_as_float(w.z); f[3] = __uint_as_float(w.w);
+        } else {
+            const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f[2 * i] = __uint_as_float(u[i] << 16);
+                f[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+            }
+        }
+    }
+    __device__ __forceinline__ void store(TL* p) const {
+        uint4 w;
+        if constexpr (sizeof(TL) == 4) {
+            w.x = __float_as_uint(f[0]); w.y = __float_as_uint(f[1]); w.z = __float_as_uint(f[2]); w.w = __float_as_uint(f[3]);
+        } else {
+            w.x = pack_bf16x2(f[0], f[1]); w.y = pack_bf16x2(f[2], f[3]);
+            w.z = pack_bf16x2(f[4], f[5]); w.w = pack_bf16x2(f[6], f[7]);
+        }
+        *reinterpret_cast<uint4*>(p) = w;
+    }
+};
+template <typename TL>
+__device__ __forceinline__ float ldf(const TL* p) {
+    if constexpr (sizeof(TL) == 4) return *p;
+    else return bf16_to_f32(*p);
+}
+template <typename TL>
+__device__ __forceinline__ void stf(TL* p, float v) {
+    if constexpr (sizeof(TL) == 4) *p = v;
+    else *p = f32_to_bf16(v);
+}
+// elements before the first 16-byte boundary of row pointer r (all V when vectors are not allowed)
+template <typename TL>
+__device__ __forceinline__ int row_head(const TL* r, int V, int vec_ok) {
+    constexpr int NV = 16 / sizeof(TL);
+    int head = vec_ok ? (int)((NV - ((reinterpret_cast<uintptr_t>(r) / sizeof(TL)) % NV)) % NV) : V;
+    return head > V ? V : head;
+}
+
 // ------------------------------------------------------------------ lse + gather
+template <typename TL>
 __global__ __launch_bounds__(LSE_WAVES * 64) void rnnt_lse_kernel(
-    const float* __restrict__ logits, const int* __restrict__ labels, const int* __restrict__ act_lens,
+    const TL* __restrict__ logits, long ldv, const int* __restrict__ labels, const int* __restrict__ act_lens,
     const int* __restrict__ label_lens, int B, int T, int U1, int V, int blank, int vec_ok,
     float* __restrict__ lse, float* __restrict__ lpb_d, float* __restrict__ lpl_d) {
+    constexpr int NV = 16 / sizeof(TL);
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * LSE_WAVES + (threadIdx.x >> 6);
     if (row >= (long)B * T * U1) return;
@@ -63,44 +112,42 @@ __global__ __launch_bounds__(LSE_WAVES * 64) void rnnt_lse_kernel(
     const int b = (int)(bt / T);
     const int Tb = clampi(act_lens[b], 1, T), Ub = clampi(label_lens[b], 0, U1 - 1);
     if (t >= Tb || u > Ub) return;
-    const float* r = logits + row * V;
+    const TL* r = logits + row * ldv;
     float m = NEG, s = 0.f;
-    int head = vec_ok ? (int)((4 - ((reinterpret_cast<uintptr_t>(r) >> 2) & 3)) & 3) : V;
-    if (head > V) head = V;
-    if (lane < head) { m = r[lane]; s = 1.f; }
-    for (int i = 64 + lane; i < head; i += 64) {      // only when !vec_ok (scalar path)
-        float x = r[i];
-        float mn = fmaxf(m, x);
+    auto upd = [&](float x) {
+        const float mn = fmaxf(m, x);
         s = s * __expf(m - mn) + __expf(x - mn);
         m = mn;
-    }
-    const int nvec = (V - head) >> 2;
-    const float4* rv = reinterpret_cast<const float4*>(r + head);
+    };
+    const int head = row_head<TL>(r, V, vec_ok);
+    for (int i = lane; i < head; i += 64) upd(ldf<TL>(r + i));
+    const int nvec = (V - head) / NV;
     for (int i = lane; i < nvec; i += 64) {
-        float4 x = rv[i];
-        float mn = fmaxf(fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w)), m);
-        s = s * __expf(m - mn) + (__expf(x.x - mn) + __expf(x.y - mn)) + (__expf(x.z - mn) + __expf(x.w - mn));
+        Vec16<TL> x;
+        x.load(r + head + i * NV);
+        float mx = x.f[0];
+#pragma unroll
+        for (int k = 1; k < NV; ++k) mx = fmaxf(mx, x.f[k]);
+        const float mn = fmaxf(m, mx);
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) acc += __expf(x.f[k] - mn);
+        s = s * __expf(m - mn) + acc;
         m = mn;
     }
-    const int tail0 = head + (nvec << 2);
-    if (tail0 + lane < V) {
-        float x = r[tail0 + lane];
-        float mn = fmaxf(m, x);
-        s = s * __expf(m - mn) + __expf(x - mn);
-        m = mn;
-    }
+    for (int i = head + nvec * NV + lane; i < V; i += 64) upd(ldf<TL>(r + i));
     const float M = wave_max(m);
     s = wave_sum(s * __expf(m - M));
     if (lane == 0) {
         const float l = M + __logf(s);
         lse[row] = l;
         const long di = (long)b * diag_stride(T, U1) + (long)(t + u) * U1 + u;
-        lpb_d[di] = r[blank] - l;
+        lpb_d[di] = ldf<TL>(r + blank) - l;
         float pl = NEG;
         if (u < Ub) {
             int y = labels[(long)b * (U1 - 1) + u];
             y = clampi(y, 0, V - 1);
-            pl = r[y] - l;
+            pl = ldf<TL>(r + y) - l;
         }
         lpl_d[di] = pl;
     }
@@ -262,11 +309,13 @@ __global__ __launch_bounds__(64) void rnnt_alphabeta_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------ gradient
+template <typename TL>
 __global__ __launch_bounds__(LSE_WAVES * 64) void rnnt_grad_kernel(
-    const float* logits, const int* __restrict__ labels, const int* __restrict__ act_lens,
+    const TL* logits, long ldv, const int* __restrict__ labels, const int* __restrict__ act_lens,
     const int* __restrict__ label_lens, int B, int T, int U1, int V, int blank, int vec_ok, const float* __restrict__ lse,
     const acc_t* __restrict__ alpha_d, const acc_t* __restrict__ beta_d, const acc_t* __restrict__ ll,
-    const float* __restrict__ grad_out, int grad_out_stride, float scale, float* grad) {
+    const float* __restrict__ grad_out, int grad_out_stride, float scale, TL* grad, long ldg) {
+    constexpr int NV = 16 / sizeof(TL);
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * LSE_WAVES + (threadIdx.x >> 6);
     if (row >= (long)B * T * U1) return;
@@ -276,8 +325,8 @@ __global__ __launch_bounds__(LSE_WAVES * 64) void rnnt_grad_kernel(
     const int b = (int)(bt / T);
     const int Tb = clampi(act_lens[b], 1, T), Ub = clampi(label_lens[b], 0, U1 - 1);
     const bool valid = (t < Tb) && (u <= Ub);
-    const float* r = logits + row * V;
-    float* g = grad + row * V;
+    const TL* r = logits + row * ldv;
+    TL* g = grad + row * ldg;
     float c = 0.f, eb = 0.f, el = 0.f, gs = 0.f;
     int yv = -1;
     if (valid) {
@@ -288,15 +337,15 @@ __global__ __launch_bounds__(LSE_WAVES * 64) void rnnt_grad_kernel(
         const acc_t a = al[di] - ll[b * 2];                                     // alpha - ll, fp64
         c = (float)(a + be[di]) - l;
         gs = scale * grad_out[(long)b * grad_out_stride];
-        const float lpb = r[blank] - l;
+        const float lpb = ldf<TL>(r + blank) - l;
         if (t == Tb - 1 && u == Ub) eb = __expf((float)a + lpb);
         else if (t < Tb - 1) eb = __expf((float)(a + be[di + U1]) + lpb);       // beta[t+1,u]
         if (u < Ub) {
             yv = clampi(labels[(long)b * (U1 - 1) + u], 0, V - 1);
-            el = __expf((float)(a + be[di + U1 + 1]) + (r[yv] - l));            // beta[t,u+1]
+            el = __expf((float)(a + be[di + U1 + 1]) + (ldf<TL>(r + yv) - l));  // beta[t,u+1]
         }
     }
-    // every lane must have read r[blank], r[yv] before any lane overwrites them (in-place use)
+    // every lane has read r[blank], r[yv] before any lane overwrites them (in-place use)
     __builtin_amdgcn_wave_barrier();
     auto f = [&](float x, int v) -> float {
         float e = __expf(x + c);
@@ -304,24 +353,20 @@ __global__ __launch_bounds__(LSE_WAVES * 64) void rnnt_grad_kernel(
         e -= (v == yv) ? el : 0.f;
         return valid ? gs * e : 0.f;
     };
-    int head = vec_ok ? (int)((4 - ((reinterpret_cast<uintptr_t>(r) >> 2) & 3)) & 3) : V;
-    if (head > V) head = V;
-    for (int i = lane; i < head; i += 64) g[i] = f(r[i], i);
-    const int nvec = (V - head) >> 2;
-    const float4* rv = reinterpret_cast<const float4*>(r + head);
-    float4* gv = reinterpret_cast<float4*>(g + head);
+    const int head = row_head<TL>(r, V, vec_ok);
+    for (int i = lane; i < head; i += 64) stf<TL>(g + i, f(valid ? ldf<TL>(r + i) : 0.f, i));
+    const int nvec = (V - head) / NV;
     for (int i = lane; i < nvec; i += 64) {
-        float4 x = valid ? rv[i] : make_float4(0, 0, 0, 0);
-        const int v0 = head + (i << 2);
-        float4 o;
-        o.x = f(x.x, v0);
-        o.y = f(x.y, v0 + 1);
-        o.z = f(x.z, v0 + 2);
-        o.w = f(x.w, v0 + 3);
-        gv[i] = o;
+        Vec16<TL> x;
+        const int v0 = head + i * NV;
+        if (valid) x.load(r + v0);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) x.f[k] = f(valid ? x.f[k] : 0.f, v0 + k);
+        x.store(g + v0);
     }
-    const int tail0 = head + (nvec << 2);
-    if (tail0 + lane < V) g[tail0 + lane] = f(r[tail0 + lane], tail0 + lane);
+    for (int i = head + nvec * NV + lane; i < V; i += 64) stf<TL>(g + i, f(valid ? ldf<TL>(r + i) : 0.f, i));
+    // padded pitch: columns [V, ldg) are zeroed so that the joint's dgrad GEMM may run over the full pitch
+    for (int i = V + lane; i < ldg; i += 64) stf<TL>(g + i, 0.f);
 }
 
 template <int R, int PF>
@@ -358,22 +403,30 @@ size_t ttmi_rnnt_workspace_bytes(int B, int T, int U1) {
            sizeof(acc_t) * (2 * (size_t)B * diag_stride(T, U1) + 2 * (size_t)B) + 64;
 }
 
-// Forward: per-utterance costs[B] = -log P(y|x).  logits f32 [B,T,U1,V] contiguous,
-// labels i32 [B,U1-1], act_lens/label_lens i32 [B] (all device pointers).  Fills the
-// workspace (lse, alpha, beta, ll) that ttmi_rnnt_loss_bwd consumes.
-int ttmi_rnnt_loss_fwd(const float* logits, const int* labels, const int* act_lens, const int* label_lens, int B, int T,
-                       int U1, int V, int blank, void* workspace, float* costs, void* stream) {
+// Forward: per-utterance costs[B] = -log P(y|x).  logits [B,T,U1,V] (dtype 0 = f32, 1 = bf16) with row pitch ldv >= V
+// elements (rows (b,t,u) at logits + ((b*T+t)*U1+u)*ldv), labels i32 [B,U1-1], act_lens/label_lens i32 [B] (device
+// pointers).  Fills the workspace (lse, alpha, beta, ll) that ttmi_rnnt_loss_bwd consumes.
+int ttmi_rnnt_loss_fwd(const void* logits, int dtype, long ldv, const int* labels, const int* act_lens, const int* label_lens,
+                       int B, int T, int U1, int V, int blank, void* workspace, float* costs, void* stream) {
     TTMI_REQUIRE(logits && (labels || U1 == 1) && act_lens && label_lens && workspace && costs, "rnnt_loss_fwd: null pointer");
     TTMI_REQUIRE(B > 0 && T > 0 && U1 > 0 && V > 0, "rnnt_loss_fwd: bad shape B=%d T=%d U1=%d V=%d", B, T, U1, V);
+    TTMI_REQUIRE(ldv >= V && (dtype == 0 || dtype == 1), "rnnt_loss_fwd: bad pitch/dtype");
     TTMI_REQUIRE(blank >= 0 && blank < V, "rnnt_loss_fwd: blank %d outside [0,%d)", blank, V);
     TTMI_REQUIRE(U1 <= 1024, "rnnt_loss_fwd: U+1=%d > 1024 unsupported", U1);
     TTMI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, "rnnt_loss_fwd: workspace must be 8-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     Ws w = carve(workspace, B, T, U1);
     const long rows = (long)B * T * U1;
-    const int vec_ok = aligned16(logits) ? 1 : 0;
-    hipLaunchKernelGGL(rnnt_lse_kernel, dim3(cdiv(rows, LSE_WAVES)), dim3(LSE_WAVES * 64), 0, st, logits, labels, act_lens,
-                       label_lens, B, T, U1, V, blank, vec_ok, w.lse, w.lpb, w.lpl);
+    const size_t es = dtype == 0 ? 4 : 2;
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(logits) % es) == 0) ? 1 : 0;
+    if (dtype == 0)
+        hipLaunchKernelGGL(rnnt_lse_kernel<float>, dim3(cdiv(rows, LSE_WAVES)), dim3(LSE_WAVES * 64), 0, st,
+                           static_cast<const float*>(logits), ldv, labels, act_lens, label_lens, B, T, U1, V, blank, vec_ok,
+                           w.lse, w.lpb, w.lpl);
+    else
+        hipLaunchKernelGGL(rnnt_lse_kernel<bf16_t>, dim3(cdiv(rows, LSE_WAVES)), dim3(LSE_WAVES * 64), 0, st,
+                           static_cast<const bf16_t*>(logits), ldv, labels, act_lens, label_lens, B, T, U1, V, blank, vec_ok,
+                           w.lse, w.lpb, w.lpl);
     TTMI_LAUNCH_CHECK("rnnt_lse_kernel");
     if (U1 <= 64) launch_alphabeta<1, 8>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
     else if (U1 <= 128) launch_alphabeta<2, 8>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
@@ -384,22 +437,32 @@ int ttmi_rnnt_loss_fwd(const float* logits, const int* labels, const int* act_le
     return TTMI_OK;
 }
 
-// Backward: grad[b,t,u,v] = scale * grad_out[b*grad_out_stride] * d cost_b / d logits.
-// grad may alias logits (in-place).  Cells outside [0,T_b) x [0,U_b] get exact zeros.
-int ttmi_rnnt_loss_bwd(const float* logits, const int* labels, const int* act_lens, const int* label_lens, int B, int T,
-                       int U1, int V, int blank, const void* workspace, const float* grad_out, int grad_out_stride,
-                       float scale, float* grad, void* stream) {
+// Backward: grad[b,t,u,v] = scale * grad_out[b*grad_out_stride] * d costs[b] / d logits, same dtype as the logits, row
+// pitch ldg (columns [V, ldg) are written as zeros).  grad may alias logits (in-place) when ldg == ldv.  Cells outside
+// [0,T_b) x [0,U_b] get exact zeros.
+int ttmi_rnnt_loss_bwd(const void* logits, int dtype, long ldv, const int* labels, const int* act_lens, const int* label_lens,
+                       int B, int T, int U1, int V, int blank, const void* workspace, const float* grad_out,
+                       int grad_out_stride, float scale, void* grad, long ldg, void* stream) {
     TTMI_REQUIRE(logits && (labels || U1 == 1) && act_lens && label_lens && workspace && grad_out && grad,
                  "rnnt_loss_bwd: null pointer");
     TTMI_REQUIRE(B > 0 && T > 0 && U1 > 0 && V > 0, "rnnt_loss_bwd: bad shape");
+    TTMI_REQUIRE(ldv >= V && ldg >= V && (dtype == 0 || dtype == 1), "rnnt_loss_bwd: bad pitch/dtype");
     TTMI_REQUIRE(blank >= 0 && blank < V, "rnnt_loss_bwd: blank %d outside [0,%d)", blank, V);
     hipStream_t st = static_cast<hipStream_t>(stream);
     Ws w = carve(const_cast<void*>(workspace), B, T, U1);
     const long rows = (long)B * T * U1;
-    const int vec_ok = (aligned16(logits) && aligned16(grad)) ? 1 : 0;
-    hipLaunchKernelGGL(rnnt_grad_kernel, dim3(cdiv(rows, LSE_WAVES)), dim3(LSE_WAVES * 64), 0, st, logits, labels, act_lens,
-                       label_lens, B, T, U1, V, blank, vec_ok, w.lse, w.alpha, w.beta, w.ll, grad_out, grad_out_stride, scale,
-                       grad);
+    const size_t es = dtype == 0 ? 4 : 2;
+    // vector path needs logits and grad rows to share their 16-byte phase
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(logits) % 16) == (reinterpret_cast<uintptr_t>(grad) % 16) &&
+                        ((ldv - ldg) * (long)es) % 16 == 0 && (reinterpret_cast<uintptr_t>(logits) % es) == 0) ? 1 : 0;
+    if (dtype == 0)
+        hipLaunchKernelGGL(rnnt_grad_kernel<float>, dim3(cdiv(rows, LSE_WAVES)), dim3(LSE_WAVES * 64), 0, st,
+                           static_cast<const float*>(logits), ldv, labels, act_lens, label_lens, B, T, U1, V, blank, vec_ok,
+                           w.lse, w.alpha, w.beta, w.ll, grad_out, grad_out_stride, scale, static_cast<float*>(grad), ldg);
+    else
+        hipLaunchKernelGGL(rnnt_grad_kernel<bf16_t>, dim3(cdiv(rows, LSE_WAVES)), dim3(LSE_WAVES * 64), 0, st,
+                           static_cast<const bf16_t*>(logits), ldv, labels, act_lens, label_lens, B, T, U1, V, blank, vec_ok,
+                           w.lse, w.alpha, w.beta, w.ll, grad_out, grad_out_stride, scale, static_cast<bf16_t*>(grad), ldg);
     TTMI_LAUNCH_CHECK("rnnt_grad_kernel");
     return TTMI_OK;
 }

@@ -12,8 +12,9 @@ struct MaskDesc {
 };
 
 // y = LN(x + res) * g + b ; optionally stores s = x + res, mean, rstd (for backward)
+// y (f32, optional) and/or y16 (bf16, optional) receive the normalised output
 int ln_fwd(const float* x, const float* res, const float* g, const float* b, long rows, int d, float eps, float* s_out,
-           float* y, float* mean, float* rstd, hipStream_t st);
+           float* y, float* mean, float* rstd, hipStream_t st, bf16_t* y16 = nullptr);
 // dx = dadd + LN'(dy) ; dgamma/dbeta accumulated atomically (caller zeroes them once per step)
 int ln_bwd(const float* dy, const float* s, const float* mean, const float* rstd, const float* g, const float* dadd, long rows,
            int d, float* dx, float* dgamma, float* dbeta, hipStream_t st);
@@ -23,6 +24,7 @@ int softmax_fwd(float* S, int nb, int nh, int L, long ld, long slab, float scale
 int softmax_bwd(float* dP, const float* P, int nb, int L, long ld, long slab, float scale, hipStream_t st);
 // out[r, c] = in[r*ldi + c] + bias[c]
 int add_row_bias(const float* in, long ldi, const float* bias, long rows, int cols, float* out, long ldo, hipStream_t st);
+int add_row_bias_bf16(const bf16_t* in, long ldi, const float* bias, long rows, int cols, bf16_t* out, long ldo, hipStream_t st);
 // out[z][c] += sum_r in[z][r*ld + c]   (atomic; out zeroed by the caller).  z = z1*nz2+z2 with strides; the
 // output offset for batch z is z2*so2 (z1 always accumulates into the same row) unless so1 != 0.
 int colsum(const float* in, long ld, long rows, int cols, int nz1, int nz2, long si1, long si2, long so1, long so2, float* out,
@@ -41,3 +43,9 @@ int joint_tanh_fwd(const float* PE, const float* PD, const float* bias, int B, i
 int joint_tanh_bwd(const void* dH, const void* H, int h_dtype, int B, int T, int U1, int J, float* dPE, float* dPD,
                    hipStream_t st);
 int fill_zero(void* p, size_t bytes, hipStream_t st);
+// dst (bf16) = src (f32), n elements
+int convert_bf16(const float* src, bf16_t* dst, long n, hipStream_t st);
+// dst[c, r] (bf16, pitch ldd >= R, columns [R, ldd) zero) = src[r, c] (f32, [R, C] dense)
+int transpose_convert_bf16(const float* src, int R, int C, bf16_t* dst, long ldd, hipStream_t st);
+// out[c] += sum_r in[r*ld + c] for a bf16 matrix (atomic; caller zeroes / accumulates)
+int colsum_bf16(const bf16_t* in, long ld, long rows, int cols, float* out, hipStream_t st);

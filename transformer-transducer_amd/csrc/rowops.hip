@@ -15,14 +15,16 @@ __device__ __forceinline__ long wave_row() { return (long)blockIdx.x * WPB + (th
 __global__ __launch_bounds__(WPB * 64) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                           const float* __restrict__ g, const float* __restrict__ b, long rows,
                                                           int d, float eps, float* __restrict__ s_out, float* __restrict__ y,
-                                                          float* __restrict__ mean_o, float* __restrict__ rstd_o, int vec) {
+                                                          float* __restrict__ mean_o, float* __restrict__ rstd_o, int vec,
+                                                          bf16_t* __restrict__ y16) {
     const long r = wave_row();
     if (r >= rows) return;
     const int lane = threadIdx.x & 63;
     const float* xr = x + r * d;
     const float* rr = res ? res + r * d : nullptr;
     float* sr = s_out ? s_out + r * d : nullptr;
-    float* yr = y + r * d;
+    float* yr = y ? y + r * d : nullptr;
+    bf16_t* y16r = y16 ? y16 + r * d : nullptr;
     float sum = 0.f;
     if (vec) {
         for (int i = lane * 4; i < d; i += 256) {
@@ -79,10 +81,20 @@ __global__ __launch_bounds__(WPB * 64) void ln_fwd_kernel(const float* __restric
             o.y = (v.y - mean) * rstd * gg.y + bb.y;
             o.z = (v.z - mean) * rstd * gg.z + bb.z;
             o.w = (v.w - mean) * rstd * gg.w + bb.w;
-            *reinterpret_cast<float4*>(yr + i) = o;
+            if (yr) *reinterpret_cast<float4*>(yr + i) = o;
+            if (y16r) {
+                uint2 w;
+                w.x = pack_bf16x2(o.x, o.y);
+                w.y = pack_bf16x2(o.z, o.w);
+                *reinterpret_cast<uint2*>(y16r + i) = w;
+            }
         }
     } else {
-        for (int i = lane; i < d; i += 64) yr[i] = (val(i) - mean) * rstd * g[i] + b[i];
+        for (int i = lane; i < d; i += 64) {
+            const float o = (val(i) - mean) * rstd * g[i] + b[i];
+            if (yr) yr[i] = o;
+            if (y16r) y16r[i] = f32_to_bf16(o);
+        }
     }
 }
 
@@ -193,6 +205,15 @@ __global__ void add_row_bias_kernel(const float* __restrict__ in, long ldi, cons
     const long r = idx / cols;
     const int c = (int)(idx % cols);
     out[r * ldo + c] = in[r * ldi + c] + bias[c];
+}
+
+__global__ void add_row_bias_bf16_kernel(const bf16_t* __restrict__ in, long ldi, const float* __restrict__ bias, long rows,
+                                         int cols, bf16_t* __restrict__ out, long ldo) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols) return;
+    const long r = idx / cols;
+    const int c = (int)(idx % cols);
+    out[r * ldo + c] = f32_to_bf16(bf16_to_f32(in[r * ldi + c]) + bias[c]);
 }
 
 constexpr int CS_ROWS = 128;
@@ -313,15 +334,69 @@ __global__ __launch_bounds__(256) void joint_tanh_bwd_kernel(const TH* __restric
         if (t0 + tt < T) dPE[((long)b * T + t0 + tt) * J + j] = accE[tt];
 }
 
+__global__ void convert_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 v = *reinterpret_cast<const float4*>(src + i);
+        uint2 w;
+        w.x = pack_bf16x2(v.x, v.y);
+        w.y = pack_bf16x2(v.z, v.w);
+        *reinterpret_cast<uint2*>(dst + i) = w;
+    } else {
+        for (long k = i; k < n; ++k) dst[k] = f32_to_bf16(src[k]);
+    }
+}
+
+// 32x32 tile transpose through LDS
+__global__ __launch_bounds__(256) void transpose_convert_kernel(const float* __restrict__ src, int R, int C,
+                                                                bf16_t* __restrict__ dst, long ldd) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? src[(long)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < ldd) dst[(long)c * ldd + r] = f32_to_bf16(tile[tx][i]);
+    }
+}
+
+constexpr int CSB_ROWS = 256;
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ in, long ld, long rows, int cols,
+                                                          float* __restrict__ out) {
+    // each thread owns 2 adjacent columns (one 4-byte load); a wave covers 128 columns = 256 B per row
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 2;
+    if (c >= cols) return;
+    const long r0 = (long)blockIdx.y * CSB_ROWS;
+    const long r1 = r0 + CSB_ROWS < rows ? r0 + CSB_ROWS : rows;
+    float a0 = 0.f, a1 = 0.f;
+    const bool pair = (c + 1 < cols) && ((ld & 1) == 0);
+    for (long r = r0; r < r1; ++r) {
+        if (pair) {
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(in + r * ld + c);
+            a0 += __uint_as_float(w << 16);
+            a1 += __uint_as_float(w & 0xffff0000u);
+        } else {
+            a0 += bf16_to_f32(in[r * ld + c]);
+            if (c + 1 < cols) a1 += bf16_to_f32(in[r * ld + c + 1]);
+        }
+    }
+    atomicAdd(out + c, a0);
+    if (c + 1 < cols) atomicAdd(out + c + 1, a1);
+}
+
 }  // namespace
 
 int ln_fwd(const float* x, const float* res, const float* g, const float* b, long rows, int d, float eps, float* s_out,
-           float* y, float* mean, float* rstd, hipStream_t st) {
-    TTMI_REQUIRE(x && g && b && y && rows > 0 && d > 0, "ln_fwd: bad arguments");
-    const int vec = (d % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(g) && aligned16(b) && (!res || aligned16(res)) &&
-                    (!s_out || aligned16(s_out));
+           float* y, float* mean, float* rstd, hipStream_t st, bf16_t* y16) {
+    TTMI_REQUIRE(x && g && b && (y || y16) && rows > 0 && d > 0, "ln_fwd: bad arguments");
+    const int vec = (d % 4 == 0) && aligned16(x) && (!y || aligned16(y)) && aligned16(g) && aligned16(b) && (!res || aligned16(res)) &&
+                    (!s_out || aligned16(s_out)) && (!y16 || (reinterpret_cast<uintptr_t>(y16) & 7) == 0);
     hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(rows, WPB)), dim3(WPB * 64), 0, st, x, res, g, b, rows, d, eps, s_out, y, mean,
-                       rstd, vec);
+                       rstd, vec, y16);
     TTMI_LAUNCH_CHECK("ln_fwd_kernel");
     return TTMI_OK;
 }
@@ -435,5 +510,36 @@ int fill_zero(void* p, size_t bytes, hipStream_t st) {
         ttmi_set_error("fill_zero: %s", hipGetErrorString(e));
         return (int)e;
     }
+    return TTMI_OK;
+}
+
+int convert_bf16(const float* src, bf16_t* dst, long n, hipStream_t st) {
+    TTMI_REQUIRE(src && dst && n > 0 && aligned16(src) && (reinterpret_cast<uintptr_t>(dst) & 7) == 0, "convert_bf16: bad arguments");
+    hipLaunchKernelGGL(convert_bf16_kernel, dim3(cdiv((n + 3) / 4, 256)), dim3(256), 0, st, src, dst, n);
+    TTMI_LAUNCH_CHECK("convert_bf16_kernel");
+    return TTMI_OK;
+}
+
+int transpose_convert_bf16(const float* src, int R, int C, bf16_t* dst, long ldd, hipStream_t st) {
+    TTMI_REQUIRE(src && dst && R > 0 && C > 0 && ldd >= R, "transpose_convert_bf16: bad arguments");
+    hipLaunchKernelGGL(transpose_convert_kernel, dim3(cdiv(C, 32), cdiv(ldd, 32)), dim3(256), 0, st, src, R, C, dst, ldd);
+    TTMI_LAUNCH_CHECK("transpose_convert_kernel");
+    return TTMI_OK;
+}
+
+int colsum_bf16(const bf16_t* in, long ld, long rows, int cols, float* out, hipStream_t st) {
+    TTMI_REQUIRE(in && out && rows > 0 && cols > 0 && (reinterpret_cast<uintptr_t>(in) & 3) == 0, "colsum_bf16: bad arguments");
+    dim3 grid(cdiv(cols, 512), cdiv(rows, CSB_ROWS));
+    TTMI_REQUIRE(grid.y <= 65535, "colsum_bf16: too many rows");
+    hipLaunchKernelGGL(colsum_bf16_kernel, grid, dim3(256), 0, st, in, ld, rows, cols, out);
+    TTMI_LAUNCH_CHECK("colsum_bf16_kernel");
+    return TTMI_OK;
+}
+
+int add_row_bias_bf16(const bf16_t* in, long ldi, const float* bias, long rows, int cols, bf16_t* out, long ldo, hipStream_t st) {
+    TTMI_REQUIRE(in && bias && out && rows > 0 && cols > 0, "add_row_bias_bf16: bad arguments");
+    hipLaunchKernelGGL(add_row_bias_bf16_kernel, dim3(cdiv(rows * cols, 256)), dim3(256), 0, st, in, ldi, bias, rows, cols, out,
+                       ldo);
+    TTMI_LAUNCH_CHECK("add_row_bias_bf16_kernel");
     return TTMI_OK;
 }

@@ -31,7 +31,7 @@ class _JointFn(torch.autograd.Function):
         enc, dec, wf, wp, saved = ctx.saved_tensors
         g = dict(wf=torch.zeros_like(wf), bf=torch.zeros(wf.shape[0], dtype=wf.dtype, device=wf.device),
                  wp=torch.zeros_like(wp), bp=torch.zeros(wp.shape[0], dtype=wp.dtype, device=wp.device))
-        denc, ddec = ops.joint_bwd(dlogits.contiguous(), enc, dec, wf, wp, saved, ctx.prec, g)
+        denc, ddec = ops.joint_bwd(dlogits, enc, dec, wf, wp, saved, ctx.prec, g)
         return denc, ddec, g["wf"], g["bf"], g["wp"], g["bp"], None
 
 

@@ -26,6 +26,33 @@ def _need_cuda(*ts):
             raise ValueError("ttmi ops need device tensors (no CPU fallback); got a %s tensor" % t.device)
 
 
+# ----------------------------------------------------------------------------- row-padded views
+def row_pitch(t):
+    """t [..., V] -> pitch (elements between consecutive rows) if t is a dense tensor or a [..., :V] view of a dense
+    [..., pitch] buffer (what the bf16 joint produces: pitch = V rounded up to 64); else None."""
+    if t.dim() < 2 or t.stride(-1) != 1:
+        return None
+    ld = t.stride(-2)
+    if ld < t.shape[-1]:
+        return None
+    for i in range(t.dim() - 2):
+        if t.shape[i] > 1 and t.stride(i) != t.stride(i + 1) * t.shape[i + 1]:
+            return None
+    return ld
+
+
+def padded_empty(shape, dtype, device, multiple=64):
+    """dense [..., roundup(V, multiple)] buffer and its [..., :V] view"""
+    V = shape[-1]
+    Vp = (V + multiple - 1) // multiple * multiple
+    buf = torch.empty(*shape[:-1], Vp, dtype=dtype, device=device)
+    return buf, buf[..., :V]
+
+
+# gradients written by rnnt_loss_bwd carry exact zeros in their pad columns; the joint's fast dgrad relies on that
+_zero_padded = {}
+
+
 # ----------------------------------------------------------------------------- RNN-T loss
 def rnnt_workspace(B, T, U1, device):
     n = lib().ttmi_rnnt_workspace_bytes(c_int(B), c_int(T), c_int(U1))
@@ -33,21 +60,36 @@ def rnnt_workspace(B, T, U1, device):
 
 
 def rnnt_loss_fwd(logits, labels, act_lens, label_lens, blank, workspace):
+    """logits: f32/bf16 [B,T,U1,V], dense or row-padded view"""
     _need_cuda(logits, labels, act_lens, label_lens, workspace)
     B, T, U1, V = logits.shape
+    ld = row_pitch(logits)
+    assert ld is not None
     costs = torch.empty(B, dtype=torch.float32, device=logits.device)
-    check(lib().ttmi_rnnt_loss_fwd(_p(logits), _p(labels), _p(act_lens), _p(label_lens), c_int(B), c_int(T), c_int(U1),
-                                   c_int(V), c_int(blank), _p(workspace), _p(costs), _stream()), "ttmi_rnnt_loss_fwd")
+    check(lib().ttmi_rnnt_loss_fwd(_p(logits), c_int(_DT[logits.dtype]), c_long(ld), _p(labels), _p(act_lens), _p(label_lens),
+                                   c_int(B), c_int(T), c_int(U1), c_int(V), c_int(blank), _p(workspace), _p(costs), _stream()),
+          "ttmi_rnnt_loss_fwd")
     return costs
 
 
-def rnnt_loss_bwd(logits, labels, act_lens, label_lens, blank, workspace, grad_out, grad_out_stride, scale, out=None):
+def rnnt_loss_bwd(logits, labels, act_lens, label_lens, blank, workspace, grad_out, grad_out_stride, scale):
     _need_cuda(logits, labels, act_lens, label_lens, workspace, grad_out)
     B, T, U1, V = logits.shape
-    grad = torch.empty_like(logits) if out is None else out
-    check(lib().ttmi_rnnt_loss_bwd(_p(logits), _p(labels), _p(act_lens), _p(label_lens), c_int(B), c_int(T), c_int(U1),
-                                   c_int(V), c_int(blank), _p(workspace), _p(grad_out), c_int(grad_out_stride),
-                                   c_float(scale), _p(grad), _stream()), "ttmi_rnnt_loss_bwd")
+    ld = row_pitch(logits)
+    if ld == V:
+        buf = grad = torch.empty_like(logits)
+        ldg = V
+    else:
+        buf = torch.empty(B, T, U1, ld, dtype=logits.dtype, device=logits.device)
+        grad, ldg = buf[..., :V], ld
+    check(lib().ttmi_rnnt_loss_bwd(_p(logits), c_int(_DT[logits.dtype]), c_long(ld), _p(labels), _p(act_lens), _p(label_lens),
+                                   c_int(B), c_int(T), c_int(U1), c_int(V), c_int(blank), _p(workspace), _p(grad_out),
+                                   c_int(grad_out_stride), c_float(scale), _p(grad), c_long(ldg), _stream()),
+          "ttmi_rnnt_loss_bwd")
+    if ldg != V:
+        if len(_zero_padded) > 64:
+            _zero_padded.clear()
+        _zero_padded[grad.data_ptr()] = ldg
     return grad
 
 
@@ -110,8 +152,8 @@ def attn_fwd(x, p, mask, prec):
     L_ = lib()
     L_.ttmi_attn_ctx_floats.restype = ctypes.c_size_t
     L_.ttmi_attn_ws_floats.restype = ctypes.c_size_t
-    ctx = _f32(L_.ttmi_attn_ctx_floats(c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh)), x.device)
-    ws = scratch(L_.ttmi_attn_ws_floats(c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh)), x.device)
+    ctx = _f32(L_.ttmi_attn_ctx_floats(c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh), c_int(prec)), x.device)
+    ws = scratch(L_.ttmi_attn_ws_floats(c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh), c_int(prec)), x.device)
     y = torch.empty_like(x)
     check(L_.ttmi_attn_fwd(_p(x), _p(p["qkv_w"]), _p(p["o_w"]), _p(p["ln_g"]), _p(p["ln_b"]), _p(p["r_emb"]),
                            _p(p["r_w_bias"]), _p(p["r_bias"]), c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh), c_int(K),
@@ -125,7 +167,7 @@ def attn_bwd(dy, x, p, ctx, prec, grads):
     K, H, Dh = p["r_emb"].shape
     L_ = lib()
     L_.ttmi_attn_ws_floats.restype = ctypes.c_size_t
-    ws = scratch(L_.ttmi_attn_ws_floats(c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh)), x.device)
+    ws = scratch(L_.ttmi_attn_ws_floats(c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh), c_int(prec)), x.device)
     dx = torch.empty_like(x)
     check(L_.ttmi_attn_bwd(_p(dy), _p(x), _p(p["qkv_w"]), _p(p["o_w"]), _p(p["ln_g"]), _p(p["r_emb"]), _p(p["r_bias"]),
                            c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh), c_int(K), c_int(prec), _p(ctx), _p(ws), _p(dx),
@@ -140,8 +182,8 @@ def ffn_fwd(y, p, prec):
     L_ = lib()
     L_.ttmi_ffn_ctx_floats.restype = ctypes.c_size_t
     L_.ttmi_ffn_ws_floats.restype = ctypes.c_size_t
-    ctx = _f32(L_.ttmi_ffn_ctx_floats(c_long(rows), c_int(d), c_int(Di)), y.device)
-    ws = scratch(L_.ttmi_ffn_ws_floats(c_long(rows), c_int(d), c_int(Di)), y.device)
+    ctx = _f32(L_.ttmi_ffn_ctx_floats(c_long(rows), c_int(d), c_int(Di), c_int(prec)), y.device)
+    ws = scratch(L_.ttmi_ffn_ws_floats(c_long(rows), c_int(d), c_int(Di), c_int(prec)), y.device)
     z = torch.empty_like(y)
     check(L_.ttmi_ffn_fwd(_p(y), _p(p["ff_w1"]), _p(p["ff_b1"]), _p(p["ff_w2"]), _p(p["ff_b2"]), _p(p["ff_ln_g"]),
                           _p(p["ff_ln_b"]), c_long(rows), c_int(d), c_int(Di), c_int(prec), _p(ctx), _p(ws), _p(z), _stream()),
@@ -154,7 +196,7 @@ def ffn_bwd(dz, y, p, ctx, prec, grads):
     Di = p["ff_w1"].shape[0]
     L_ = lib()
     L_.ttmi_ffn_ws_floats.restype = ctypes.c_size_t
-    ws = scratch(L_.ttmi_ffn_ws_floats(c_long(rows), c_int(d), c_int(Di)), y.device)
+    ws = scratch(L_.ttmi_ffn_ws_floats(c_long(rows), c_int(d), c_int(Di), c_int(prec)), y.device)
     dy = torch.empty_like(y)
     check(L_.ttmi_ffn_bwd(_p(dz), _p(y), _p(p["ff_w1"]), _p(p["ff_w2"]), _p(p["ff_ln_g"]), c_long(rows), c_int(d), c_int(Di),
                           c_int(prec), _p(ctx), _p(ws), _p(dy), _p(grads["ff_w1"]), _p(grads["ff_b1"]), _p(grads["ff_w2"]),
@@ -162,7 +204,12 @@ def ffn_bwd(dz, y, p, ctx, prec, grads):
     return dy
 
 
+def joint_logits_dtype(prec, J):
+    return torch.bfloat16 if lib().ttmi_joint_logits_dtype(c_int(prec), c_int(J)) == 1 else torch.float32
+
+
 def joint_fwd(enc, dec, wf, bf, wp, bp, prec):
+    """-> logits [B,T,U1,V]: f32 dense (prec 0), or bf16 as a [..., :V] view of a pitch-roundup(V,64) buffer (prec 1)"""
     B, T, de = enc.shape
     U1, dd = dec.shape[1], dec.shape[2]
     J, V = wf.shape[0], wp.shape[0]
@@ -170,10 +217,16 @@ def joint_fwd(enc, dec, wf, bf, wp, bp, prec):
     L_.ttmi_joint_ctx_floats.restype = ctypes.c_size_t
     L_.ttmi_joint_ws_floats.restype = ctypes.c_size_t
     ctx = _f32(L_.ttmi_joint_ctx_floats(c_int(B), c_int(T), c_int(U1), c_int(J)), enc.device)
-    ws = scratch(L_.ttmi_joint_ws_floats(c_int(B), c_int(T), c_int(U1), c_int(J)), enc.device)
-    logits = torch.empty(B, T, U1, V, dtype=torch.float32, device=enc.device)
+    ws = scratch(L_.ttmi_joint_ws_floats(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(V)), enc.device)
+    dt = joint_logits_dtype(prec, J)
+    if dt is torch.bfloat16:
+        buf, logits = padded_empty((B, T, U1, V), dt, enc.device)
+        ldv = buf.shape[-1]
+    else:
+        logits = torch.empty(B, T, U1, V, dtype=dt, device=enc.device)
+        ldv = V
     check(L_.ttmi_joint_fwd(_p(enc), _p(dec), _p(wf), _p(bf), _p(wp), _p(bp), c_int(B), c_int(T), c_int(U1), c_int(de),
-                            c_int(dd), c_int(J), c_int(V), c_int(prec), _p(ctx), _p(ws), _p(logits), _stream()),
+                            c_int(dd), c_int(J), c_int(V), c_int(prec), _p(ctx), _p(ws), _p(logits), c_long(ldv), _stream()),
           "ttmi_joint_fwd")
     return logits, ctx
 
@@ -184,10 +237,24 @@ def joint_bwd(dlogits, enc, dec, wf, wp, ctx, prec, grads):
     J, V = wf.shape[0], wp.shape[0]
     L_ = lib()
     L_.ttmi_joint_ws_floats.restype = ctypes.c_size_t
-    ws = scratch(L_.ttmi_joint_ws_floats(c_int(B), c_int(T), c_int(U1), c_int(J)), enc.device)
+    ws = scratch(L_.ttmi_joint_ws_floats(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(V)), enc.device)
+    dt = joint_logits_dtype(prec, J)
+    ldg = row_pitch(dlogits)
+    if dt is torch.bfloat16:
+        ok = (dlogits.dtype is dt and ldg is not None and ldg % 8 == 0 and dlogits.data_ptr() % 16 == 0 and
+              (ldg == V or _zero_padded.pop(dlogits.data_ptr(), None) == ldg))
+        if not ok:                                  # foreign gradient: repack into a zero-padded bf16 buffer
+            buf, view = padded_empty((B, T, U1, V), dt, enc.device)
+            buf.zero_()
+            view.copy_(dlogits)
+            dlogits, ldg = view, buf.shape[-1]
+    else:
+        if dlogits.dtype is not dt or ldg is None:
+            dlogits = dlogits.to(dt).contiguous()
+            ldg = V
     denc, ddec = torch.empty_like(enc), torch.empty_like(dec)
-    check(L_.ttmi_joint_bwd(_p(dlogits), _p(enc), _p(dec), _p(wf), _p(wp), c_int(B), c_int(T), c_int(U1), c_int(de), c_int(dd),
-                            c_int(J), c_int(V), c_int(prec), _p(ctx), _p(ws), _p(denc), _p(ddec), _p(grads["wf"]),
+    check(L_.ttmi_joint_bwd(_p(dlogits), c_long(ldg), _p(enc), _p(dec), _p(wf), _p(wp), c_int(B), c_int(T), c_int(U1), c_int(de),
+                            c_int(dd), c_int(J), c_int(V), c_int(prec), _p(ctx), _p(ws), _p(denc), _p(ddec), _p(grads["wf"]),
                             _p(grads["bf"]), _p(grads["wp"]), _p(grads["bp"]), _stream()), "ttmi_joint_bwd")
     return denc, ddec
 

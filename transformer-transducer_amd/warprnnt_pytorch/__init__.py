@@ -24,8 +24,8 @@ def _certify(acts, labels, act_lens, label_lens, check_lengths):
             raise TypeError("%s must be int32" % name)
         if not t.is_contiguous():
             raise ValueError("%s must be contiguous" % name)
-    if acts.dtype is not torch.float32:
-        raise TypeError("acts must be float32")
+    if acts.dtype not in (torch.float32, torch.bfloat16):       # bf16: the MI355X bf16 pipeline's own logits
+        raise TypeError("acts must be float32 (or the bf16 logits of the bf16 pipeline)")
     if acts.dim() != 4:
         raise ValueError("acts must have 4 dimensions (batch, T, U+1, vocab)")
     if labels.dim() != 2 or act_lens.dim() != 1 or label_lens.dim() != 1:
@@ -45,7 +45,7 @@ class _RNNTLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, acts, labels, act_lens, label_lens, blank, reduction):
         B, T, U1, _ = acts.shape
-        acts_c = acts.contiguous()
+        acts_c = acts if ops.row_pitch(acts) is not None else acts.contiguous()     # row-padded views are consumed in place
         ws = ops.rnnt_workspace(B, T, U1, acts.device)
         costs = ops.rnnt_loss_fwd(acts_c, labels, act_lens, label_lens, blank, ws)
         ctx.save_for_backward(acts_c, labels, act_lens, label_lens, ws)
