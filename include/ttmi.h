@@ -2,8 +2,9 @@
  *
  * Every entry point: plain pointers and sizes, no torch types; all pointers are
  * DEVICE pointers unless noted; `stream` is a hipStream_t (0 = default stream);
- * nothing is allocated or freed inside (workspaces are caller-provided, sizes via
- * *_workspace_bytes); launches are asynchronous on `stream`, no device-wide sync.
+ * nothing is allocated or freed inside (ctx / workspace arenas are caller-provided,
+ * sizes via the *_floats / *_bytes queries, 256-byte aligned); launches are
+ * asynchronous on `stream`, no device-wide sync.
  * Return value: 0 ok, <0 invalid argument (message in ttmi_last_error()), >0 a
  * hipError_t.  No C++ exception crosses the boundary.
  *
@@ -11,6 +12,17 @@
  * layer; each function cites the reference lines whose arithmetic it replaces
  * (paths relative to the reference root).  The Python classes that bind these are
  * in transformer-transducer_amd/{tt,warprnnt_pytorch}; see INTEGRATION.md.
+ *
+ * Conventions
+ *   prec        0 = exact-f32 MFMA (v_mfma_f32_32x32x2_f32), all activations f32:
+ *                   the parity path (loss/grads within 1e-4 rel of the reference).
+ *               1 = bf16 MFMA, f32 accumulate; activations that feed GEMMs are bf16
+ *                   in HBM (q/k/v, attention output, FFN inner, joint hidden, logits),
+ *                   residual stream / LayerNorm / softmax / lattice stay f32(/f64).
+ *   g_*         parameter-gradient buffers are ACCUMULATED into (+=): zero them once
+ *               per optimiser step (optimizer.zero_grad()).
+ *   batch-major activations are [B, L, d] row-major (the reference's [L, B, d] layout is
+ *               only a transpose away and no op mixes batch elements).
  */
 #ifndef TTMI_H
 #define TTMI_H
@@ -22,15 +34,86 @@ extern "C" {
 int ttmi_version(void);
 const char* ttmi_last_error(void);   /* thread-local, valid until the next failing call */
 
-/* ---- RNN-T loss: replaces warprnnt_pytorch.RNNTLoss (train.py:13,53,231) ------------- */
+/* ---- relative-position self-attention sub-layer ------------------------------------------------------
+ * RelLearnableMultiHeadAttn.forward incl. _rel_shift, mask, softmax, o_net, residual + LayerNorm
+ * (tt/transformer.py:82-89,106-177).  x,y f32 [B,L,d]; qkv_w [3*H*Dh, d]; o_w [d, H*Dh]; r_emb [K,H,Dh];
+ * r_w_bias [H,Dh]; r_bias [K,H].  mask_kind 0 none | 1 causal (tt/utils.py:233-239) | 2 band: masked iff
+ * j > i+right or j < i-left (tt/utils.py:242-251) | 3 uint8 tensor, element (b,i,j) at
+ * mask[b*mask_sb + i*mask_si + j], nonzero = masked (any [L,L,1] / [L,L,B] / (klen,bsz) mask of
+ * tt/transformer.py:154-159 after a permute). */
+size_t ttmi_attn_ctx_floats(int B, int L, int d, int H, int Dh, int prec);
+size_t ttmi_attn_ws_floats(int B, int L, int d, int H, int Dh, int prec);
+int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const float* ln_g, const float* ln_b,
+                  const float* r_emb, const float* r_w_bias, const float* r_bias, int B, int L, int d, int H, int Dh, int K,
+                  int mask_kind, int mask_left, int mask_right, const unsigned char* mask, long mask_sb, long mask_si,
+                  int prec, float* ctx, float* ws, float* y, void* stream);
+int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const float* o_w, const float* ln_g,
+                  const float* r_emb, const float* r_bias, int B, int L, int d, int H, int Dh, int K, int prec,
+                  const float* ctx, float* ws, float* dx, float* g_qkv_w, float* g_o_w, float* g_ln_g, float* g_ln_b,
+                  float* g_r_emb, float* g_r_w_bias, float* g_r_bias, void* stream);
+
+/* ---- position-wise feed-forward sub-layer -----------------------------------------------------------------
+ * PositionwiseFF.forward: z = LN(y + W2 relu(W1 LN(y) + b1) + b2), ONE LayerNorm used twice
+ * (tt/transformer.py:36-58).  rows = B*L; w1 [Di,d]; w2 [d,Di]. */
+size_t ttmi_ffn_ctx_floats(long rows, int d, int Di, int prec);
+size_t ttmi_ffn_ws_floats(long rows, int d, int Di, int prec);
+int ttmi_ffn_fwd(const float* y, const float* w1, const float* b1, const float* w2, const float* b2, const float* ln_g,
+                 const float* ln_b, long rows, int d, int Di, int prec, float* ctx, float* ws, float* z, void* stream);
+int ttmi_ffn_bwd(const float* dz, const float* y, const float* w1, const float* w2, const float* ln_g, long rows, int d, int Di,
+                 int prec, const float* ctx, float* ws, float* dy, float* g_w1, float* g_b1, float* g_w2, float* g_b2,
+                 float* g_ln_g, float* g_ln_b, void* stream);
+
+/* ---- label-encoder embedding: nn.Embedding(V, d, padding_idx=0) (tt/decoder.py:26,39) ------------------------ */
+int ttmi_embed_fwd(const long* tokens, const float* W, long n, int d, int V, float* out, void* stream);
+int ttmi_embed_bwd(const long* tokens, const float* dout, long n, int d, int V, int padding_idx, float* gW, void* stream);
+
+/* ---- joint network: JointNet.forward (tt/model.py:20-39) in split-weight form ---------------------------------
+ * logits[b,t,u,:] = wp tanh(wf[:, :de] enc[b,t] + wf[:, de:] dec[b,u] + bf) + bp.  enc [B,T,de], dec [B,U1,dd],
+ * wf [J, de+dd], wp [V,J].  ttmi_joint_logits_dtype(prec,J): 0 -> logits/dlogits are f32, 1 -> bf16.  Rows
+ * (b,t,u) of logits/dlogits have pitch ldv/ldg >= V elements; in the bf16 case the pitch must be a multiple of 8,
+ * the base 16-byte aligned, and dlogits must be ZERO in columns [V, ldg) (ttmi_rnnt_loss_bwd guarantees it). */
+int ttmi_joint_logits_dtype(int prec, int J);
+size_t ttmi_joint_ctx_floats(int B, int T, int U1, int J);
+size_t ttmi_joint_ws_floats(int B, int T, int U1, int J, int V);
+int ttmi_joint_fwd(const float* enc, const float* dec, const float* wf, const float* bf, const float* wp, const float* bp,
+                   int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx, float* ws, void* logits, long ldv,
+                   void* stream);
+int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float* dec, const float* wf, const float* wp, int B,
+                   int T, int U1, int de, int dd, int J, int V, int prec, const float* ctx, float* ws, float* denc, float* ddec,
+                   float* g_wf, float* g_bf, float* g_wp, float* g_bp, void* stream);
+
+/* ---- RNN-T loss: replaces warprnnt_pytorch.RNNTLoss (train.py:13,53,231) --------------------------------------
+ * logits [B,T,U1,V] (dtype 0 = f32, 1 = bf16), row pitch ldv; labels i32 [B,U1-1]; act_lens,label_lens i32 [B];
+ * costs f32 [B] = -log P(y|x).  bwd: grad = scale * grad_out[b*grad_out_stride] * d costs[b]/d logits in the logits'
+ * dtype with row pitch ldg (columns [V,ldg) zeroed); grad may alias logits when ldg == ldv. */
 size_t ttmi_rnnt_workspace_bytes(int B, int T, int U1);
-/* logits f32 [B,T,U1,V]; labels i32 [B,U1-1]; act_lens,label_lens i32 [B]; costs f32 [B] */
-int ttmi_rnnt_loss_fwd(const float* logits, const int* labels, const int* act_lens, const int* label_lens, int B, int T,
-                       int U1, int V, int blank, void* workspace, float* costs, void* stream);
-/* grad[b] = scale * grad_out[b*grad_out_stride] * d costs[b] / d logits; grad may alias logits */
-int ttmi_rnnt_loss_bwd(const float* logits, const int* labels, const int* act_lens, const int* label_lens, int B, int T,
-                       int U1, int V, int blank, const void* workspace, const float* grad_out, int grad_out_stride,
-                       float scale, float* grad, void* stream);
+int ttmi_rnnt_loss_fwd(const void* logits, int dtype, long ldv, const int* labels, const int* act_lens, const int* label_lens,
+                       int B, int T, int U1, int V, int blank, void* workspace, float* costs, void* stream);
+int ttmi_rnnt_loss_bwd(const void* logits, int dtype, long ldv, const int* labels, const int* act_lens, const int* label_lens,
+                       int B, int T, int U1, int V, int blank, const void* workspace, const float* grad_out,
+                       int grad_out_stride, float scale, void* grad, long ldg, void* stream);
+
+/* ---- training-step tail on flat f32 buffers: clip_grad_norm_ + optimizer.step (train.py:62-65, tt/optim.py:57-73)
+ * normsq: device scalar holding sum(g^2) over ALL gradients (ttmi_sumsq accumulates into it); NULL = no clipping.
+ * The effective gradient is g * grad_scale (1/world_size after a SUM all-reduce) clipped to max_norm. */
+int ttmi_sumsq(const float* x, long n, float* out, void* stream);
+int ttmi_sgd_step(float* p, const float* g, float* mom, long n, float lr, float momentum, float weight_decay, int nesterov,
+                  float max_norm, const float* normsq, float grad_scale, void* stream);
+int ttmi_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, float max_norm, const float* normsq, float grad_scale, void* stream);
+
+/* ---- bring-up / measurement helpers ------------------------------------------------------------------------------
+ * generic MFMA GEMM (every layout / dtype / epilogue; flags = GemmFlags of csrc/gemm.h) and the two throughput
+ * kernels; HIP-event probes recorded on the launch stream around one kernel (slot 0 = joint vocabulary projection). */
+int ttmi_gemm(const void* A, const void* B, void* C, const float* bias, const float* aux, int a_dtype, int b_dtype,
+              int c_dtype, int M, int N, int K, long lda, long ldb, long ldc, int nz1, int nz2, long sA1, long sA2,
+              long sB1, long sB2, long sC1, long sC2, float alpha, float beta, int flags, int splitk, void* stream);
+int ttmi_gemm_nt_bf16(const void* A, const void* B, void* C, int c_dtype, const float* bias, int M, int N, int K, long lda,
+                      long ldb, long ldc, void* stream);
+int ttmi_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
+                      void* stream);
+int ttmi_probe_arm(int slot);
+float ttmi_probe_read_ms(int slot);
 
 #ifdef __cplusplus
 }
