@@ -36,7 +36,7 @@ def c2_config(n_enc=12, n_dec=6):
     return AttrDict(dict(type="transducer",
                          enc=dict(side, type="attention", max_input_length=410, left_context=10, right_context=2, n_layer=n_enc),
                          dec=dict(side, type="attention", max_target_length=42, n_layer=n_dec),
-                         joint=dict(input_size=1024, inner_size=1024), vocab_size=4334, share_weight=False, dropout=0.0))
+                         joint=dict(input_size=1024, inner_size=1024), vocab_size=4334, share_weight=False, dropout=0.1))
 
 
 def flops_per_utt(cfg, T, U1):
@@ -171,7 +171,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: full T-T 12 audio / 6 label layers d_model=512 V=4334 "
-                                   "(48.2M params), T=%d U=%d, batch %d/GPU, SGD+clip; dropout 0" % (T, U, B),
+                                   "(48.2M params), T=%d U=%d, batch %d/GPU, dropout 0.1, SGD momentum + clip 200" % (T, U, B),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
             "model_tflops": round(flops_per_utt(cfg, T, U1) * utt_s / 1e12, 2),
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel (joint vocabulary projection, M=%d N=%d K=%d)" % (B * T * U1, V, J),

@@ -19,6 +19,11 @@
  *               1 = bf16 MFMA, f32 accumulate; activations that feed GEMMs are bf16
  *                   in HBM (q/k/v, attention output, FFN inner, joint hidden, logits),
  *                   residual stream / LayerNorm / softmax / lattice stay f32(/f64).
+ *   dropout     p_drop / p_layer = drop probabilities (0 in eval).  Masks are counter-based: element i of site s is kept
+ *               iff hash(seed ^ salt_s, i) >= p * 2^32 and scaled by 1/(1-p); backward regenerates them from the same
+ *               seed.  Sites (reference modules): attention `drop` (tt/transformer.py:173) salt 0xA1, FFN CoreNet.2 /
+ *               CoreNet.4 (:47,49) salts 0xB2 / 0xC3, RelLearnableDecoderLayer.dropout (:196) salt 0xD4 (p_layer,
+ *               fused into the FFN's output LayerNorm).  ttmi_dropout_apply exposes the same masks.
  *   g_*         parameter-gradient buffers are ACCUMULATED into (+=): zero them once
  *               per optimiser step (optimizer.zero_grad()).
  *   batch-major activations are [B, L, d] row-major (the reference's [L, B, d] layout is
@@ -46,11 +51,11 @@ size_t ttmi_attn_ws_floats(int B, int L, int d, int H, int Dh, int prec);
 int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const float* ln_g, const float* ln_b,
                   const float* r_emb, const float* r_w_bias, const float* r_bias, int B, int L, int d, int H, int Dh, int K,
                   int mask_kind, int mask_left, int mask_right, const unsigned char* mask, long mask_sb, long mask_si,
-                  int prec, float* ctx, float* ws, float* y, void* stream);
+                  int prec, float p_drop, unsigned seed, float* ctx, float* ws, float* y, void* stream);
 int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const float* o_w, const float* ln_g,
                   const float* r_emb, const float* r_bias, int B, int L, int d, int H, int Dh, int K, int prec,
-                  const float* ctx, float* ws, float* dx, float* g_qkv_w, float* g_o_w, float* g_ln_g, float* g_ln_b,
-                  float* g_r_emb, float* g_r_w_bias, float* g_r_bias, void* stream);
+                  float p_drop, unsigned seed, const float* ctx, float* ws, float* dx, float* g_qkv_w, float* g_o_w,
+                  float* g_ln_g, float* g_ln_b, float* g_r_emb, float* g_r_w_bias, float* g_r_bias, void* stream);
 
 /* ---- position-wise feed-forward sub-layer -----------------------------------------------------------------
  * PositionwiseFF.forward: z = LN(y + W2 relu(W1 LN(y) + b1) + b2), ONE LayerNorm used twice
@@ -58,10 +63,11 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
 size_t ttmi_ffn_ctx_floats(long rows, int d, int Di, int prec);
 size_t ttmi_ffn_ws_floats(long rows, int d, int Di, int prec);
 int ttmi_ffn_fwd(const float* y, const float* w1, const float* b1, const float* w2, const float* b2, const float* ln_g,
-                 const float* ln_b, long rows, int d, int Di, int prec, float* ctx, float* ws, float* z, void* stream);
+                 const float* ln_b, long rows, int d, int Di, int prec, float p_drop, float p_layer, unsigned seed, float* ctx,
+                 float* ws, float* z, void* stream);
 int ttmi_ffn_bwd(const float* dz, const float* y, const float* w1, const float* w2, const float* ln_g, long rows, int d, int Di,
-                 int prec, const float* ctx, float* ws, float* dy, float* g_w1, float* g_b1, float* g_w2, float* g_b2,
-                 float* g_ln_g, float* g_ln_b, void* stream);
+                 int prec, float p_drop, float p_layer, unsigned seed, const float* ctx, float* ws, float* dy, float* g_w1,
+                 float* g_b1, float* g_w2, float* g_b2, float* g_ln_g, float* g_ln_b, void* stream);
 
 /* ---- label-encoder embedding: nn.Embedding(V, d, padding_idx=0) (tt/decoder.py:26,39) ------------------------ */
 int ttmi_embed_fwd(const long* tokens, const float* W, long n, int d, int V, float* out, void* stream);
@@ -112,6 +118,7 @@ int ttmi_gemm_nt_bf16(const void* A, const void* B, void* C, int c_dtype, const 
                       long ldb, long ldc, void* stream);
 int ttmi_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
                       void* stream);
+int ttmi_dropout_apply(const float* in, long n, float p, unsigned seed, float* out, void* stream);
 int ttmi_probe_arm(int slot);
 float ttmi_probe_read_ms(int slot);
 

@@ -32,7 +32,9 @@ Reference lines followed (relative to /root/reference):
 All tensors are batch-major [B, L, ...] internally (the reference transposes to
 [L, B, ...]; every op on the path is independent per batch element so the
 layout is immaterial to the numbers).  dtype follows the inputs (float32 or
-float64).  Dropout is not modelled: parity runs use p = 0 / eval().
+float64).  Dropout: the layer functions take optional multiplier arrays (0 or
+1/(1-p)) under the keys drop_attn / drop_ff_in / drop_ff_out / drop_layer, so a
+test can feed them the exact masks the HIP kernels drew; absent = no dropout.
 """
 import numpy as np
 
@@ -165,6 +167,9 @@ def rel_attn_fwd(w, p, mask=None):
     P = Pn / Pn.sum(-1, keepdims=True)                        # :164
     O = (P @ vh).transpose(0, 2, 1, 3).reshape(B, L, H * D)   # :167-170
     a = O @ p["o_w"].T                                        # :172
+    dm = p.get("drop_attn")                                   # optional dropout multipliers (0 or 1/(1-p)), [B,L,d]; :173
+    if dm is not None:
+        a = a * dm
     y, lnc = layer_norm_fwd(w + a, p["ln_g"], p["ln_b"])      # :175
     cache = dict(w=w, q=q, k=k, v=v, E=E, e=e, P=P, O=O, lnc=lnc, m=m)
     return y, cache
@@ -178,7 +183,7 @@ def rel_attn_bwd(dy, cache, p):
     g = {}
     dres, g["ln_g"], g["ln_b"] = layer_norm_bwd(dy, cache["lnc"], p["ln_g"])
     dw = dres.copy()
-    da = dres
+    da = dres if p.get("drop_attn") is None else dres * p["drop_attn"]
     g["o_w"] = da.reshape(-1, d).T @ O.reshape(-1, H * D)
     dO = (da @ p["o_w"]).reshape(B, L, H, D).transpose(0, 2, 1, 3)      # [B,H,L,D]
     qh, kh, vh = (t.transpose(0, 2, 1, 3) for t in (q, k, v))
@@ -210,21 +215,24 @@ def rel_attn_bwd(dy, cache, p):
 def ffn_fwd(x, p):
     h, c1 = layer_norm_fwd(x, p["ff_ln_g"], p["ff_ln_b"])
     a = np.maximum(h @ p["ff_w1"].T + p["ff_b1"], 0)
-    f = a @ p["ff_w2"].T + p["ff_b2"]
+    one = np.ones((), dtype=x.dtype)                          # optional dropout multipliers: CoreNet.2, CoreNet.4, layer (:47,49,196)
+    m_in, m_out, m_layer = (p.get(k, one) if p.get(k) is not None else one for k in ("drop_ff_in", "drop_ff_out", "drop_layer"))
+    a = a * m_in
+    f = (a @ p["ff_w2"].T + p["ff_b2"]) * m_out
     y, c2 = layer_norm_fwd(x + f, p["ff_ln_g"], p["ff_ln_b"])
-    return y, dict(x=x, h=h, a=a, c1=c1, c2=c2)
+    return y * m_layer, dict(x=x, h=h, a=a, c1=c1, c2=c2, m_in=m_in, m_out=m_out, m_layer=m_layer)
 
 
 def ffn_bwd(dy, cache, p):
     x, h, a = cache["x"], cache["h"], cache["a"]
     d = x.shape[-1]
     g = {}
-    dres, dg2, db2 = layer_norm_bwd(dy, cache["c2"], p["ff_ln_g"])
+    dres, dg2, db2 = layer_norm_bwd(dy * cache["m_layer"], cache["c2"], p["ff_ln_g"])
     dx = dres.copy()
-    df = dres
+    df = dres * cache["m_out"]
     g["ff_b2"] = df.reshape(-1, d).sum(0)
     g["ff_w2"] = df.reshape(-1, d).T @ a.reshape(-1, a.shape[-1])
-    da = (df @ p["ff_w2"]) * (a > 0)
+    da = (df @ p["ff_w2"]) * cache["m_in"] * (a > 0)
     g["ff_b1"] = da.reshape(-1, a.shape[-1]).sum(0)
     g["ff_w1"] = da.reshape(-1, a.shape[-1]).T @ h.reshape(-1, d)
     dh = da @ p["ff_w1"]

@@ -1,0 +1,66 @@
+"""Training-mode dropout of the fused sub-layers (5 reference sites) vs the numpy oracle fed the EXACT masks the HIP
+kernels drew (ttmi_dropout_apply exposes them): forward, input gradient and every parameter gradient."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import tt_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _layer(d=64, H=2, Dh=32, Di=96, K=16, p=0.3):
+    from tt.encoder import BaseEncoder
+    torch.manual_seed(11)
+    return BaseEncoder(k_len=K, n_head=H, d_model=d, d_head=Dh, d_inner=Di, dropout=p).cuda().train()
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-4), ("bf16", 6e-2)])
+def test_layer_with_dropout_matches_oracle_with_same_masks(prec, tol, monkeypatch):
+    from ttmi import ops
+    from ttmi.ops import MaskSpec
+    monkeypatch.setenv("TTMI_PRECISION", prec)
+    p, B, L, d, Di = 0.3, 3, 21, 64, 96
+    layer = _layer(p=p)
+    x = torch.randn(B, L, d, generator=torch.Generator().manual_seed(3))
+    cot = torch.randn(B, L, d, generator=torch.Generator().manual_seed(4))
+    torch.manual_seed(77)
+    s_attn = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    s_ffn = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    torch.manual_seed(77)                                   # the layer will draw the same two seeds
+    xg = x.cuda().requires_grad_(True)
+    y = layer.forward_bm(xg, MaskSpec(0))
+    (y * cot.cuda()).sum().backward()
+
+    def mult(n, seed, shape):
+        return ops.dropout_multipliers(n, p, seed, "cuda").cpu().numpy().astype(np.float64).reshape(shape)
+
+    sd = {"encoder.layers.0." + k: v.detach().cpu().numpy().astype(np.float64) for k, v in layer.state_dict().items()}
+    prm = O.layer_params(sd, "encoder.", 0)
+    prm["drop_attn"] = mult(B * L * d, s_attn ^ 0xA1, (B, L, d))
+    prm["drop_ff_in"] = mult(B * L * Di, s_ffn ^ 0xB2, (B, L, Di))
+    prm["drop_ff_out"] = mult(B * L * d, s_ffn ^ 0xC3, (B, L, d))
+    prm["drop_layer"] = mult(B * L * d, s_ffn ^ 0xD4, (B, L, d))
+    for k in ("drop_attn", "drop_ff_in", "drop_ff_out", "drop_layer"):
+        frac = float((prm[k] == 0).mean())
+        assert abs(frac - p) < 0.03, (k, frac)                # Bernoulli(p) and the four sites are decorrelated
+        assert np.allclose(prm[k][prm[k] != 0], 1 / (1 - p))
+    assert not np.array_equal(prm["drop_attn"], prm["drop_ff_out"])
+    want, cache = O.layer_fwd(x.numpy().astype(np.float64), prm, None)
+    dx, g = O.layer_bwd(cot.numpy().astype(np.float64), cache, prm)
+    assert rel_err(y.detach().cpu().numpy(), want) < tol
+    assert rel_err(xg.grad.cpu().numpy(), dx) < tol
+    names = {v: k for k, v in O._LAYER_KEYS.items()}
+    for n, prm_t in layer.named_parameters():
+        assert rel_err(prm_t.grad.cpu().numpy(), g[names[n]]) < tol, n
+
+
+def test_eval_mode_is_deterministic_and_dropout_free():
+    from ttmi.ops import MaskSpec
+    layer = _layer(p=0.5).eval()
+    x = torch.randn(2, 9, 64, device="cuda")
+    assert torch.equal(layer.forward_bm(x, MaskSpec(0)), layer.forward_bm(x, MaskSpec(0)))
+    layer.train()
+    a, b = layer.forward_bm(x, MaskSpec(0)), layer.forward_bm(x, MaskSpec(0))
+    assert not torch.equal(a, b)                               # fresh seeds per call in training mode

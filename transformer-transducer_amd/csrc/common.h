@@ -52,5 +52,22 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Counter-based dropout: keep element `idx` of dropout site `seed` iff hash(seed, idx) >= p * 2^32.
+// Stateless, so the backward pass regenerates the identical mask from (seed, idx).  Returns 0 or 1/(1-p).
+struct DropSpec {
+    float p = 0.f;            // drop probability (0 = disabled)
+    unsigned seed = 0;
+};
+__host__ __device__ __forceinline__ unsigned ttmi_hash32(unsigned seed, unsigned long long idx) {
+    unsigned x = (unsigned)idx * 0x9E3779B1u ^ seed ^ ((unsigned)(idx >> 32) * 0x7F4A7C15u);
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ float drop_mult(const DropSpec& d, unsigned long long idx) {
+    if (d.p <= 0.f) return 1.f;
+    const unsigned thresh = (unsigned)(d.p * 4294967296.0);
+    return ttmi_hash32(d.seed, idx) >= thresh ? 1.f / (1.f - d.p) : 0.f;
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

@@ -28,6 +28,7 @@ struct GemmDesc {
     float alpha = 1.f, beta = 0.f;   // C = alpha*A.B + beta*C_old (+bias, relu...)
     int flags = GEMM_A_KMAJOR | GEMM_B_KMAJOR;
     int splitk = 1;                  // >1 requires GEMM_ATOMIC
+    DropSpec drop;                   // dropout on the epilogue result (after ReLU), element index m*ldc + n
 };
 
 // returns 0 / <0 invalid / >0 hipError_t

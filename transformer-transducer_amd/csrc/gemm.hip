@@ -45,6 +45,7 @@ struct KParams {
     int flags;
     int splitk, kchunk;
     int vecA, vecB;
+    DropSpec drop;
 };
 
 template <typename S>
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const KParams p) {
                 }
                 if (p.flags & GEMM_RELU) v = fmaxf(v, 0.f);
                 if (aux) v = aux[ci] > 0.f ? v : 0.f;
+                v *= drop_mult(p.drop, (unsigned long long)ci);
                 if constexpr (sizeof(TC) == 4) reinterpret_cast<float*>(Cp)[ci] = v;
                 else reinterpret_cast<bf16_t*>(Cp)[ci] = f32_to_bf16(v);
             }
@@ -313,7 +315,7 @@ int ttmi_launch_gemm(const GemmDesc& d, hipStream_t st) {
     p.nz2 = d.nz2;
     p.sA1 = d.sA1; p.sA2 = d.sA2; p.sB1 = d.sB1; p.sB2 = d.sB2; p.sC1 = d.sC1; p.sC2 = d.sC2;
     p.sBias1 = d.sBias1; p.sBias2 = d.sBias2;
-    p.alpha = d.alpha; p.beta = d.beta; p.flags = d.flags; p.splitk = d.splitk;
+    p.alpha = d.alpha; p.beta = d.beta; p.flags = d.flags; p.splitk = d.splitk; p.drop = d.drop;
     const int bk = bf16c ? 32 : 16;
     int kchunk = (d.K + d.splitk - 1) / d.splitk;
     kchunk = (kchunk + bk - 1) / bk * bk;

@@ -10,6 +10,8 @@ struct NtEpilogue {
     const float* addend = nullptr;   // f32, same layout as C (residual add)
     const bf16_t* mask = nullptr;    // bf16, same layout as C (ReLU backward)
     int relu = 0;
+    float scale = 1.f;               // applied to the masked result (1/(1-p) of a dropped ReLU in backward)
+    DropSpec drop;                   // dropout on the result (after ReLU), element index m*ldc + n
 };
 // C[M,N] = epilogue(A[M,K] . B[N,K]^T); c_dtype 0 = f32, 1 = bf16
 int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const NtEpilogue& epi, int M, int N, int K, long lda,

@@ -36,6 +36,8 @@ struct FP {
     const float* addend;
     const bf16_t* mask;
     int relu;
+    float scale;
+    DropSpec drop;
     int M, N, K;
     long lda, ldb, ldc;
     int tiles_m, tiles_n, splitk, ksteps;   // ksteps per split
@@ -77,7 +79,8 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], const FP& 
                 const long ci = (long)m * p.ldc + n;
                 if (p.addend) v += p.addend[ci];
                 if (p.relu) v = fmaxf(v, 0.f);
-                if (p.mask) v = bf16_to_f32(p.mask[ci]) > 0.f ? v : 0.f;
+                if (p.mask) v = bf16_to_f32(p.mask[ci]) > 0.f ? v * p.scale : 0.f;
+                v *= drop_mult(p.drop, (unsigned long long)ci);
                 if constexpr (sizeof(TC) == 4) {
                     if (p.atomic) atomicAdd(reinterpret_cast<float*>(C) + ci, v);
                     else reinterpret_cast<float*>(C)[ci] = v;
@@ -271,7 +274,7 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     TTMI_REQUIRE(gemm_fast_nt_ok(A, B, C, M, N, K, lda, ldb), "gemm_nt_bf16: shape/alignment not supported (M=%d N=%d K=%d)", M,
                  N, K);
     FP p;
-    p.A = A; p.B = B; p.C = C; p.bias = epi.bias; p.addend = epi.addend; p.mask = epi.mask; p.relu = epi.relu;
+    p.A = A; p.B = B; p.C = C; p.bias = epi.bias; p.addend = epi.addend; p.mask = epi.mask; p.relu = epi.relu; p.scale = epi.scale; p.drop = epi.drop;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.tiles_m = cdiv(M, TM); p.tiles_n = cdiv(N, TN_); p.splitk = 1; p.ksteps = cdiv(K, TK); p.atomic = 0;
     const long nwg = (long)p.tiles_m * p.tiles_n;
@@ -295,7 +298,7 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
     TTMI_REQUIRE(gemm_fast_tn_ok(A, B, C, M, N, K, lda, ldb), "gemm_tn_bf16: shape/alignment not supported (M=%d N=%d K=%d)", M,
                  N, K);
     FP p;
-    p.A = A; p.B = B; p.C = C; p.bias = nullptr; p.addend = nullptr; p.mask = nullptr; p.relu = 0;
+    p.A = A; p.B = B; p.C = C; p.bias = nullptr; p.addend = nullptr; p.mask = nullptr; p.relu = 0; p.scale = 1.f; p.drop = DropSpec();
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.tiles_m = cdiv(M, TM); p.tiles_n = cdiv(N, TN_);
     const long tiles = (long)p.tiles_m * p.tiles_n;

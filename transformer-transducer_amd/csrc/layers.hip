@@ -170,8 +170,9 @@ size_t ttmi_attn_ws_floats(int B, int L, int d, int H, int Dh, int prec) {
 int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const float* ln_g, const float* ln_b,
                   const float* r_emb, const float* r_w_bias, const float* r_bias, int B, int L, int d, int H, int Dh, int K,
                   int mask_kind, int mask_left, int mask_right, const unsigned char* mask, long mask_sb, long mask_si,
-                  int prec, float* ctx, float* ws, float* y, void* stream) {
+                  int prec, float p_drop, unsigned seed, float* ctx, float* ws, float* y, void* stream) {
     TTMI_REQUIRE(x && qkv_w && o_w && ln_g && ln_b && r_emb && r_w_bias && r_bias && ctx && ws && y, "attn_fwd: null pointer");
+    TTMI_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "attn_fwd: dropout probability %f outside [0,1)", p_drop);
     TTMI_REQUIRE(B > 0 && L > 0 && d > 0 && H > 0 && Dh > 0 && K > 0, "attn_fwd: bad dims");
     TTMI_REQUIRE(mask_kind >= 0 && mask_kind <= 3, "attn_fwd: bad mask kind %d", mask_kind);
     TTMI_REQUIRE(((reinterpret_cast<uintptr_t>(ctx) | reinterpret_cast<uintptr_t>(ws)) & 255) == 0, "attn_fwd: ctx/ws must be 256-byte aligned");
@@ -227,15 +228,17 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
     } else {
         CK(ttmi_launch_gemm(mk(static_cast<float*>(c.O), o_w, w.a, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, NT_, prec), st));
     }
-    CK(ln_fwd(x, w.a, ln_g, ln_b, a.BL, d, 1e-5f, c.s1, y, c.mean, c.rstd, st));
+    DropSpec rd;                                            // self.drop(attn_out), tt/transformer.py:173
+    rd.p = p_drop; rd.seed = seed ^ 0xA1u;
+    CK(ln_fwd(x, w.a, ln_g, ln_b, a.BL, d, 1e-5f, c.s1, y, c.mean, c.rstd, st, nullptr, rd));
     return TTMI_OK;
 }
 
 // Backward of ttmi_attn_fwd.  dx is written; every g_* buffer is ACCUMULATED into (zero them per step).
 int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const float* o_w, const float* ln_g,
                   const float* r_emb, const float* r_bias, int B, int L, int d, int H, int Dh, int K, int prec,
-                  const float* ctx, float* ws, float* dx, float* g_qkv_w, float* g_o_w, float* g_ln_g, float* g_ln_b,
-                  float* g_r_emb, float* g_r_w_bias, float* g_r_bias, void* stream) {
+                  float p_drop, unsigned seed, const float* ctx, float* ws, float* dx, float* g_qkv_w, float* g_o_w,
+                  float* g_ln_g, float* g_ln_b, float* g_r_emb, float* g_r_w_bias, float* g_r_bias, void* stream) {
     TTMI_REQUIRE(dy && x && qkv_w && o_w && ln_g && r_emb && r_bias && ctx && ws && dx, "attn_bwd: null pointer");
     TTMI_REQUIRE(g_qkv_w && g_o_w && g_ln_g && g_ln_b && g_r_emb && g_r_w_bias && g_r_bias, "attn_bwd: null gradient pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -248,15 +251,22 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
     const float scale = 1.0f / sqrtf((float)Dh);
     // 1. dres = LN'(dy) -> dx (doubles as the residual gradient)
     CK(ln_bwd(dy, c.s1, c.mean, c.rstd, ln_g, nullptr, a.BL, d, dx, g_ln_g, g_ln_b, st));
-    // 2. gWo += dres^T O ; 3. dO = dres Wo
+    // 2. gWo += da^T O ; 3. dO = da Wo, with da = dres * dropout mask of the forward (dres itself stays the residual grad)
+    DropSpec rd;
+    rd.p = p_drop; rd.seed = seed ^ 0xA1u;
+    const float* da = dx;
+    if (!fast && p_drop > 0.f) {
+        CK(dropout_apply(dx, a.BL * d, rd, w.a, nullptr, st));
+        da = w.a;
+    }
     if (fast) {
-        CK(convert_bf16(dx, w.dres16, a.BL * d, st));
+        CK(dropout_apply(dx, a.BL * d, rd, nullptr, w.dres16, st));
         CK(gemm_tn_bf16(w.dres16, static_cast<bf16_t*>(c.O), g_o_w, d, (int)a.HD, (int)a.BL, d, a.HD, a.HD, 1, st));
         CK(transpose_convert_bf16(o_w, d, (int)a.HD, w.wo16, d, st));                          // Wo^T [HD, d]
         CK(gemm_nt_bf16(w.dres16, w.wo16, w.dO, 1, nullptr, (int)a.BL, (int)a.HD, d, d, d, a.HD, st));
     } else {
-        CK(wgrad(dx, static_cast<float*>(c.O), g_o_w, d, (int)a.HD, (int)a.BL, d, a.HD, a.HD, prec, st));
-        CK(ttmi_launch_gemm(mk(dx, o_w, static_cast<float*>(w.dO), (int)a.BL, (int)a.HD, d, d, a.HD, a.HD, NN_, prec), st));
+        CK(wgrad(da, static_cast<float*>(c.O), g_o_w, d, (int)a.HD, (int)a.BL, d, a.HD, a.HD, prec, st));
+        CK(ttmi_launch_gemm(mk(da, o_w, static_cast<float*>(w.dO), (int)a.BL, (int)a.HD, d, d, a.HD, a.HD, NN_, prec), st));
     }
     // 4. dP = dO V^T through the pitch-L view of the dS slab (first L floats of each slab are outside the view)
     CK(memset2d(w.dS, (size_t)a.slab * 4, (size_t)L * 4, (size_t)B * H, st));
@@ -368,8 +378,14 @@ size_t ttmi_ffn_ws_floats(long rows, int d, int Di, int prec) {
 
 // z = LN(y + W2 relu(W1 LN(y) + b1) + b2), the SAME (ln_g, ln_b) in both norms.
 int ttmi_ffn_fwd(const float* y, const float* w1, const float* b1, const float* w2, const float* b2, const float* ln_g,
-                 const float* ln_b, long rows, int d, int Di, int prec, float* ctx, float* ws, float* z, void* stream) {
+                 const float* ln_b, long rows, int d, int Di, int prec, float p_drop, float p_layer, unsigned seed, float* ctx,
+                 float* ws, float* z, void* stream) {
     TTMI_REQUIRE(y && w1 && b1 && w2 && b2 && ln_g && ln_b && ctx && ws && z, "ffn_fwd: null pointer");
+    TTMI_REQUIRE(p_drop >= 0.f && p_drop < 1.f && p_layer >= 0.f && p_layer < 1.f, "ffn_fwd: dropout probability outside [0,1)");
+    DropSpec d_in, d_out, d_layer;          // CoreNet.2, CoreNet.4 (tt/transformer.py:47,49) and the layer's own dropout (:196)
+    d_in.p = p_drop; d_in.seed = seed ^ 0xB2u;
+    d_out.p = p_drop; d_out.seed = seed ^ 0xC3u;
+    d_layer.p = p_layer; d_layer.seed = seed ^ 0xD4u;
     TTMI_REQUIRE(rows > 0 && rows < (1L << 31) && d > 0 && Di > 0, "ffn_fwd: bad dims");
     TTMI_REQUIRE(((reinterpret_cast<uintptr_t>(ctx) | reinterpret_cast<uintptr_t>(ws)) & 255) == 0, "ffn_fwd: ctx/ws must be 256-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -382,7 +398,7 @@ int ttmi_ffn_fwd(const float* y, const float* w1, const float* b1, const float* 
         CK(convert_bf16(w1, w.w1_16, (long)Di * d, st));
         CK(convert_bf16(w2, w.w2_16, (long)Di * d, st));
         NtEpilogue e1;
-        e1.bias = b1; e1.relu = 1;
+        e1.bias = b1; e1.relu = 1; e1.drop = d_in;
         CK(gemm_nt_bf16(static_cast<bf16_t*>(c.h), w.w1_16, c.a1, 1, e1, (int)rows, Di, d, d, d, Di, st));
         CK(gemm_nt_bf16(static_cast<bf16_t*>(c.a1), w.w2_16, w.f, 0, b2, (int)rows, d, Di, Di, Di, d, st));
     } else {
@@ -390,19 +406,19 @@ int ttmi_ffn_fwd(const float* y, const float* w1, const float* b1, const float* 
         float* a1 = static_cast<float*>(c.a1);
         CK(ln_fwd(y, nullptr, ln_g, ln_b, rows, d, 1e-5f, nullptr, h, c.mean1, c.rstd1, st));
         GemmDesc g = mk(h, w1, a1, (int)rows, Di, d, d, d, Di, NT_ | GEMM_BIAS | GEMM_RELU, prec);
-        g.bias = b1;
+        g.bias = b1; g.drop = d_in;
         CK(ttmi_launch_gemm(g, st));
         GemmDesc g2 = mk(a1, w2, w.f, (int)rows, d, Di, Di, Di, d, NT_ | GEMM_BIAS, prec);
         g2.bias = b2;
         CK(ttmi_launch_gemm(g2, st));
     }
-    CK(ln_fwd(y, w.f, ln_g, ln_b, rows, d, 1e-5f, c.s2, z, c.mean2, c.rstd2, st));
+    CK(ln_fwd(y, w.f, ln_g, ln_b, rows, d, 1e-5f, c.s2, z, c.mean2, c.rstd2, st, nullptr, d_out, d_layer));
     return TTMI_OK;
 }
 
 int ttmi_ffn_bwd(const float* dz, const float* y, const float* w1, const float* w2, const float* ln_g, long rows, int d, int Di,
-                 int prec, const float* ctx, float* ws, float* dy, float* g_w1, float* g_b1, float* g_w2, float* g_b2,
-                 float* g_ln_g, float* g_ln_b, void* stream) {
+                 int prec, float p_drop, float p_layer, unsigned seed, const float* ctx, float* ws, float* dy, float* g_w1,
+                 float* g_b1, float* g_w2, float* g_b2, float* g_ln_g, float* g_ln_b, void* stream) {
     TTMI_REQUIRE(dz && y && w1 && w2 && ln_g && ctx && ws && dy && g_w1 && g_b1 && g_w2 && g_b2 && g_ln_g && g_ln_b,
                  "ffn_bwd: null pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -410,17 +426,26 @@ int ttmi_ffn_bwd(const float* dz, const float* y, const float* w1, const float* 
     Bump bc(const_cast<float*>(ctx)), bw(ws);
     FfnCtx c(bc, rows, d, Di, fast);
     FfnWs w(bw, rows, d, Di, fast);
-    CK(ln_bwd(dz, c.s2, c.mean2, c.rstd2, ln_g, nullptr, rows, d, w.dres, g_ln_g, g_ln_b, st));
-    CK(colsum(w.dres, d, rows, d, 1, 1, 0, 0, 0, 0, g_b2, st));
+    DropSpec d_out, d_layer;
+    d_out.p = p_drop; d_out.seed = seed ^ 0xC3u;
+    d_layer.p = p_layer; d_layer.seed = seed ^ 0xD4u;
+    const float inv_keep = 1.f / (1.f - p_drop);
+    CK(ln_bwd(dz, c.s2, c.mean2, c.rstd2, ln_g, nullptr, rows, d, w.dres, g_ln_g, g_ln_b, st, d_layer));
+    // df = dres * mask(CoreNet.4); dres itself remains the residual-branch gradient
+    const float* df = w.dres;
+    if (p_drop > 0.f || fast) {
+        CK(dropout_apply(w.dres, rows * d, d_out, p_drop > 0.f ? w.f : nullptr, fast ? w.dres16 : nullptr, st));
+        if (p_drop > 0.f) df = w.f;
+    }
+    CK(colsum(df, d, rows, d, 1, 1, 0, 0, 0, 0, g_b2, st));
     if (fast) {
         bf16_t* a1 = static_cast<bf16_t*>(c.a1);
         bf16_t* h = static_cast<bf16_t*>(c.h);
         bf16_t* da1 = static_cast<bf16_t*>(w.da1);
-        CK(convert_bf16(w.dres, w.dres16, rows * d, st));
         CK(gemm_tn_bf16(w.dres16, a1, g_w2, d, Di, (int)rows, d, Di, Di, 1, st));
         CK(transpose_convert_bf16(w2, d, Di, w.w2_16, d, st));                                 // W2^T [Di, d]
         NtEpilogue e;
-        e.mask = a1;
+        e.mask = a1; e.scale = inv_keep;                   // a1 is stored post-dropout: a1 > 0 <=> ReLU active AND kept
         CK(gemm_nt_bf16(w.dres16, w.w2_16, da1, 1, e, (int)rows, Di, d, d, d, Di, st));
         CK(colsum_bf16(da1, Di, rows, Di, g_b1, st));
         CK(gemm_tn_bf16(da1, h, g_w1, Di, d, (int)rows, Di, d, d, 1, st));
@@ -430,9 +455,9 @@ int ttmi_ffn_bwd(const float* dz, const float* y, const float* w1, const float* 
         const float* a1 = static_cast<const float*>(c.a1);
         const float* h = static_cast<const float*>(c.h);
         float* da1 = static_cast<float*>(w.da1);
-        CK(wgrad(w.dres, a1, g_w2, d, Di, (int)rows, d, Di, Di, prec, st));
-        GemmDesc g = mk(w.dres, w2, da1, (int)rows, Di, d, d, Di, Di, NN_ | GEMM_MASK_AUX, prec);
-        g.aux = a1;
+        CK(wgrad(df, a1, g_w2, d, Di, (int)rows, d, Di, Di, prec, st));
+        GemmDesc g = mk(df, w2, da1, (int)rows, Di, d, d, Di, Di, NN_ | GEMM_MASK_AUX, prec);
+        g.aux = a1; g.alpha = inv_keep;
         CK(ttmi_launch_gemm(g, st));
         CK(colsum(da1, Di, rows, Di, 1, 1, 0, 0, 0, 0, g_b1, st));
         CK(wgrad(da1, h, g_w1, Di, d, (int)rows, Di, d, d, prec, st));
@@ -538,6 +563,15 @@ int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float*
     CK(ttmi_launch_gemm(mk(dPE, wf, denc, B * T, de, J, J, din, de, NN_, prec), st));
     CK(ttmi_launch_gemm(mk(dPD, wf + de, ddec, B * U1, dd, J, J, din, dd, NN_, prec), st));
     return TTMI_OK;
+}
+
+// out[i] = in[i] * (0 or 1/(1-p)) with the library's counter-based mask for (seed, i): lets tests and callers
+// reproduce the exact masks the fused sub-layers use (sites: attention out seed^0xA1, FFN inner ^0xB2, FFN out ^0xC3,
+// layer out ^0xD4; element index = row * width + column of the masked [rows, width] tensor).
+int ttmi_dropout_apply(const float* in, long n, float p, unsigned seed, float* out, void* stream) {
+    DropSpec ds;
+    ds.p = p; ds.seed = seed;
+    return dropout_apply(in, n, ds, out, nullptr, static_cast<hipStream_t>(stream));
 }
 
 // ------------------------------------------------------------------ embedding (tt/decoder.py:26,39)

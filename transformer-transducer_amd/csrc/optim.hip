@@ -6,7 +6,12 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+// Two-stage, fixed-order reduction: every rank must obtain the bit-identical norm from identical (all-reduced)
+// gradients, otherwise the clip coefficient - and with it the replicas - drift apart.  No atomics here.
+constexpr int SUMSQ_BLOCKS = 1024;
+__device__ float g_sumsq_partials[SUMSQ_BLOCKS];
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n) {
     float acc = 0.f;
     const long n4 = n >> 2;
     const float4* x4 = reinterpret_cast<const float4*>(x);
@@ -19,7 +24,14 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     __shared__ float part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
+    if (threadIdx.x == 0) g_sumsq_partials[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(64) void sumsq_final_kernel(int nblocks, float* __restrict__ out) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 64) acc += g_sumsq_partials[i];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) *out += acc;
 }
 
 // coef = grad_scale * min(1, max_norm / (grad_scale * sqrt(normsq) + 1e-6))   (torch.nn.utils.clip_grad_norm_)
@@ -68,11 +80,14 @@ int grid_for(long n) {
 
 extern "C" {
 
-// *out += sum(x^2)   (out must be zeroed by the caller; accumulates so several buffers can share it)
+// *out += sum(x^2), deterministic (fixed reduction order; calls on one stream only - the partials buffer is shared)
 int ttmi_sumsq(const float* x, long n, float* out, void* stream) {
     TTMI_REQUIRE(x && out && n > 0, "sumsq: bad arguments");
     TTMI_REQUIRE(aligned16(x), "sumsq: x must be 16-byte aligned");
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, static_cast<hipStream_t>(stream), x, n, out);
+    int nb = grid_for(n >> 2);
+    if (nb > SUMSQ_BLOCKS) nb = SUMSQ_BLOCKS;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(stream), x, n);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), nb, out);
     TTMI_LAUNCH_CHECK("sumsq_kernel");
     return TTMI_OK;
 }

@@ -13,11 +13,16 @@ struct MaskDesc {
 
 // y = LN(x + res) * g + b ; optionally stores s = x + res, mean, rstd (for backward)
 // y (f32, optional) and/or y16 (bf16, optional) receive the normalised output
+// res_drop: dropout applied to `res` before the add; out_drop: dropout applied to the normalised output
 int ln_fwd(const float* x, const float* res, const float* g, const float* b, long rows, int d, float eps, float* s_out,
-           float* y, float* mean, float* rstd, hipStream_t st, bf16_t* y16 = nullptr);
+           float* y, float* mean, float* rstd, hipStream_t st, bf16_t* y16 = nullptr, DropSpec res_drop = DropSpec(),
+           DropSpec out_drop = DropSpec());
 // dx = dadd + LN'(dy) ; dgamma/dbeta accumulated atomically (caller zeroes them once per step)
+// dy_drop: the forward applied dropout to the LN output, so dy is masked/scaled identically on the way in
 int ln_bwd(const float* dy, const float* s, const float* mean, const float* rstd, const float* g, const float* dadd, long rows,
-           int d, float* dx, float* dgamma, float* dbeta, hipStream_t st);
+           int d, float* dx, float* dgamma, float* dbeta, hipStream_t st, DropSpec dy_drop = DropSpec());
+// out[i] = in[i] * dropout_multiplier(i)  (out f32 and/or bf16); with p = 0 this is the plain f32 -> bf16 conversion
+int dropout_apply(const float* in, long n, DropSpec ds, float* out32, bf16_t* out16, hipStream_t st);
 // in-place P = softmax_j(scale * S) over the batched score view (nb slabs, L rows of ld floats each)
 int softmax_fwd(float* S, int nb, int nh, int L, long ld, long slab, float scale, const MaskDesc& m, hipStream_t st);
 // in-place dS = P * (dP - sum_j dP*P) * scale

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(WPB * 64) void ln_fwd_kernel(const float* __restric
                                                           const float* __restrict__ g, const float* __restrict__ b, long rows,
                                                           int d, float eps, float* __restrict__ s_out, float* __restrict__ y,
                                                           float* __restrict__ mean_o, float* __restrict__ rstd_o, int vec,
-                                                          bf16_t* __restrict__ y16) {
+                                                          bf16_t* __restrict__ y16, DropSpec rdrop, DropSpec odrop) {
     const long r = wave_row();
     if (r >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -26,33 +26,37 @@ __global__ __launch_bounds__(WPB * 64) void ln_fwd_kernel(const float* __restric
     float* yr = y ? y + r * d : nullptr;
     bf16_t* y16r = y16 ? y16 + r * d : nullptr;
     float sum = 0.f;
+    const unsigned long long base = (unsigned long long)r * d;
+    auto load4 = [&](int i) -> float4 {
+        float4 v = *reinterpret_cast<const float4*>(xr + i);
+        if (rr) {
+            const float4 w = *reinterpret_cast<const float4*>(rr + i);
+            v.x += w.x * drop_mult(rdrop, base + i);
+            v.y += w.y * drop_mult(rdrop, base + i + 1);
+            v.z += w.z * drop_mult(rdrop, base + i + 2);
+            v.w += w.w * drop_mult(rdrop, base + i + 3);
+        }
+        return v;
+    };
+    auto val = [&](int i) -> float { return xr[i] + (rr ? rr[i] * drop_mult(rdrop, base + i) : 0.f); };
     if (vec) {
         for (int i = lane * 4; i < d; i += 256) {
-            float4 v = *reinterpret_cast<const float4*>(xr + i);
-            if (rr) {
-                const float4 w = *reinterpret_cast<const float4*>(rr + i);
-                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-            }
+            const float4 v = load4(i);
             if (sr) *reinterpret_cast<float4*>(sr + i) = v;
             sum += (v.x + v.y) + (v.z + v.w);
         }
     } else {
         for (int i = lane; i < d; i += 64) {
-            float v = xr[i] + (rr ? rr[i] : 0.f);
+            const float v = val(i);
             if (sr) sr[i] = v;
             sum += v;
         }
     }
     const float mean = wave_sum(sum) / d;
     float sq = 0.f;
-    auto val = [&](int i) -> float { return xr[i] + (rr ? rr[i] : 0.f); };
     if (vec) {
         for (int i = lane * 4; i < d; i += 256) {
-            float4 v = *reinterpret_cast<const float4*>(xr + i);
-            if (rr) {
-                const float4 w = *reinterpret_cast<const float4*>(rr + i);
-                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-            }
+            const float4 v = load4(i);
             const float a = v.x - mean, bq = v.y - mean, c = v.z - mean, e = v.w - mean;
             sq += (a * a + bq * bq) + (c * c + e * e);
         }
@@ -69,18 +73,14 @@ __global__ __launch_bounds__(WPB * 64) void ln_fwd_kernel(const float* __restric
     }
     if (vec) {
         for (int i = lane * 4; i < d; i += 256) {
-            float4 v = *reinterpret_cast<const float4*>(xr + i);
-            if (rr) {
-                const float4 w = *reinterpret_cast<const float4*>(rr + i);
-                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-            }
+            const float4 v = load4(i);
             const float4 gg = *reinterpret_cast<const float4*>(g + i);
             const float4 bb = *reinterpret_cast<const float4*>(b + i);
             float4 o;
-            o.x = (v.x - mean) * rstd * gg.x + bb.x;
-            o.y = (v.y - mean) * rstd * gg.y + bb.y;
-            o.z = (v.z - mean) * rstd * gg.z + bb.z;
-            o.w = (v.w - mean) * rstd * gg.w + bb.w;
+            o.x = ((v.x - mean) * rstd * gg.x + bb.x) * drop_mult(odrop, base + i);
+            o.y = ((v.y - mean) * rstd * gg.y + bb.y) * drop_mult(odrop, base + i + 1);
+            o.z = ((v.z - mean) * rstd * gg.z + bb.z) * drop_mult(odrop, base + i + 2);
+            o.w = ((v.w - mean) * rstd * gg.w + bb.w) * drop_mult(odrop, base + i + 3);
             if (yr) *reinterpret_cast<float4*>(yr + i) = o;
             if (y16r) {
                 uint2 w;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(WPB * 64) void ln_fwd_kernel(const float* __restric
         }
     } else {
         for (int i = lane; i < d; i += 64) {
-            const float o = (val(i) - mean) * rstd * g[i] + b[i];
+            const float o = ((val(i) - mean) * rstd * g[i] + b[i]) * drop_mult(odrop, base + i);
             if (yr) yr[i] = o;
             if (y16r) y16r[i] = f32_to_bf16(o);
         }
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(WPB * 64) void ln_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(WPB * 64) void ln_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ s,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const float* __restrict__ g, const float* __restrict__ dadd,
-                                                             long rows, int d, float* __restrict__ dx) {
+                                                             long rows, int d, float* __restrict__ dx, DropSpec ddrop) {
     const long r = wave_row();
     if (r >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -109,8 +109,9 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_dx_kernel(const float* __rest
     const float* dyr = dy + r * d;
     const float* sr = s + r * d;
     float m1 = 0.f, m2 = 0.f;
+    const unsigned long long base = (unsigned long long)r * d;
     for (int i = lane; i < d; i += 64) {
-        const float dxh = dyr[i] * g[i];
+        const float dxh = dyr[i] * drop_mult(ddrop, base + i) * g[i];
         const float xh = (sr[i] - mu) * rs;
         m1 += dxh;
         m2 += dxh * xh;
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_dx_kernel(const float* __rest
     m1 = wave_sum(m1) / d;
     m2 = wave_sum(m2) / d;
     for (int i = lane; i < d; i += 64) {
-        const float dxh = dyr[i] * g[i];
+        const float dxh = dyr[i] * drop_mult(ddrop, base + i) * g[i];
         const float xh = (sr[i] - mu) * rs;
         float v = rs * (dxh - m1 - xh * m2);
         if (dadd) v += dadd[r * d + i];
@@ -130,14 +131,14 @@ constexpr int LNP_ROWS = 64;
 __global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restrict__ dy, const float* __restrict__ s,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             long rows, int d, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta) {
+                                                            float* __restrict__ dbeta, DropSpec ddrop) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= d) return;
     const long r0 = (long)blockIdx.y * LNP_ROWS;
     const long r1 = r0 + LNP_ROWS < rows ? r0 + LNP_ROWS : rows;
     float ag = 0.f, ab = 0.f;
     for (long r = r0; r < r1; ++r) {
-        const float v = dy[r * d + c];
+        const float v = dy[r * d + c] * drop_mult(ddrop, (unsigned long long)r * d + c);
         ag += v * (s[r * d + c] - mean[r]) * rstd[r];
         ab += v;
     }
@@ -347,6 +348,15 @@ __global__ void convert_bf16_kernel(const float* __restrict__ src, bf16_t* __res
     }
 }
 
+__global__ void dropout_apply_kernel(const float* __restrict__ in, long n, DropSpec ds, float* __restrict__ o32,
+                                     bf16_t* __restrict__ o16) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = in[i] * drop_mult(ds, (unsigned long long)i);
+    if (o32) o32[i] = v;
+    if (o16) o16[i] = f32_to_bf16(v);
+}
+
 // 32x32 tile transpose through LDS
 __global__ __launch_bounds__(256) void transpose_convert_kernel(const float* __restrict__ src, int R, int C,
                                                                 bf16_t* __restrict__ dst, long ldd) {
@@ -391,23 +401,24 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
 }  // namespace
 
 int ln_fwd(const float* x, const float* res, const float* g, const float* b, long rows, int d, float eps, float* s_out,
-           float* y, float* mean, float* rstd, hipStream_t st, bf16_t* y16) {
+           float* y, float* mean, float* rstd, hipStream_t st, bf16_t* y16, DropSpec res_drop, DropSpec out_drop) {
     TTMI_REQUIRE(x && g && b && (y || y16) && rows > 0 && d > 0, "ln_fwd: bad arguments");
     const int vec = (d % 4 == 0) && aligned16(x) && (!y || aligned16(y)) && aligned16(g) && aligned16(b) && (!res || aligned16(res)) &&
                     (!s_out || aligned16(s_out)) && (!y16 || (reinterpret_cast<uintptr_t>(y16) & 7) == 0);
     hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(rows, WPB)), dim3(WPB * 64), 0, st, x, res, g, b, rows, d, eps, s_out, y, mean,
-                       rstd, vec, y16);
+                       rstd, vec, y16, res_drop, out_drop);
     TTMI_LAUNCH_CHECK("ln_fwd_kernel");
     return TTMI_OK;
 }
 
 int ln_bwd(const float* dy, const float* s, const float* mean, const float* rstd, const float* g, const float* dadd, long rows,
-           int d, float* dx, float* dgamma, float* dbeta, hipStream_t st) {
+           int d, float* dx, float* dgamma, float* dbeta, hipStream_t st, DropSpec dy_drop) {
     TTMI_REQUIRE(dy && s && mean && rstd && g && dx && dgamma && dbeta && rows > 0 && d > 0, "ln_bwd: bad arguments");
-    hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3(cdiv(rows, WPB)), dim3(WPB * 64), 0, st, dy, s, mean, rstd, g, dadd, rows, d, dx);
+    hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3(cdiv(rows, WPB)), dim3(WPB * 64), 0, st, dy, s, mean, rstd, g, dadd, rows, d, dx,
+                       dy_drop);
     TTMI_LAUNCH_CHECK("ln_bwd_dx_kernel");
     hipLaunchKernelGGL(ln_bwd_params_kernel, dim3(cdiv(d, 256), cdiv(rows, LNP_ROWS)), dim3(256), 0, st, dy, s, mean, rstd, rows,
-                       d, dgamma, dbeta);
+                       d, dgamma, dbeta, dy_drop);
     TTMI_LAUNCH_CHECK("ln_bwd_params_kernel");
     return TTMI_OK;
 }
@@ -541,5 +552,12 @@ int add_row_bias_bf16(const bf16_t* in, long ldi, const float* bias, long rows, 
     hipLaunchKernelGGL(add_row_bias_bf16_kernel, dim3(cdiv(rows * cols, 256)), dim3(256), 0, st, in, ldi, bias, rows, cols, out,
                        ldo);
     TTMI_LAUNCH_CHECK("add_row_bias_bf16_kernel");
+    return TTMI_OK;
+}
+
+int dropout_apply(const float* in, long n, DropSpec ds, float* out32, bf16_t* out16, hipStream_t st) {
+    TTMI_REQUIRE(in && (out32 || out16) && n > 0, "dropout_apply: bad arguments");
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, in, n, ds, out32, out16);
+    TTMI_LAUNCH_CHECK("dropout_apply_kernel");
     return TTMI_OK;
 }

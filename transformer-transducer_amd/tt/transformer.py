@@ -41,12 +41,12 @@ class _AttnFn(torch.autograd.Function):
     NAMES = ("qkv_w", "o_w", "ln_g", "ln_b", "r_emb", "r_w_bias", "r_bias")
 
     @staticmethod
-    def forward(ctx, x, qkv_w, o_w, ln_g, ln_b, r_emb, r_w_bias, r_bias, mask, prec):
+    def forward(ctx, x, qkv_w, o_w, ln_g, ln_b, r_emb, r_w_bias, r_bias, mask, prec, p_drop, seed):
         x = x.contiguous()
         p = dict(zip(_AttnFn.NAMES, (t.detach() for t in (qkv_w, o_w, ln_g, ln_b, r_emb, r_w_bias, r_bias))))
-        y, saved = ops.attn_fwd(x, p, mask, prec)
+        y, saved = ops.attn_fwd(x, p, mask, prec, p_drop, seed)
         ctx.save_for_backward(x, saved, *p.values())
-        ctx.prec = prec
+        ctx.prec, ctx.p_drop, ctx.seed = prec, p_drop, seed
         return y
 
     @staticmethod
@@ -54,20 +54,20 @@ class _AttnFn(torch.autograd.Function):
         x, saved, *ps = ctx.saved_tensors
         p = dict(zip(_AttnFn.NAMES, ps))
         grads = {k: torch.zeros_like(v) for k, v in p.items()}
-        dx = ops.attn_bwd(dy.contiguous(), x, p, saved, ctx.prec, grads)
-        return (dx, *[grads[k] for k in _AttnFn.NAMES], None, None)
+        dx = ops.attn_bwd(dy.contiguous(), x, p, saved, ctx.prec, grads, ctx.p_drop, ctx.seed)
+        return (dx, *[grads[k] for k in _AttnFn.NAMES], None, None, None, None)
 
 
 class _FFNFn(torch.autograd.Function):
     NAMES = ("ff_w1", "ff_b1", "ff_w2", "ff_b2", "ff_ln_g", "ff_ln_b")
 
     @staticmethod
-    def forward(ctx, y, w1, b1, w2, b2, ln_g, ln_b, prec):
+    def forward(ctx, y, w1, b1, w2, b2, ln_g, ln_b, prec, p_drop, p_layer, seed):
         y = y.contiguous()
         p = dict(zip(_FFNFn.NAMES, (t.detach() for t in (w1, b1, w2, b2, ln_g, ln_b))))
-        z, saved = ops.ffn_fwd(y, p, prec)
+        z, saved = ops.ffn_fwd(y, p, prec, p_drop, p_layer, seed)
         ctx.save_for_backward(y, saved, *p.values())
-        ctx.prec = prec
+        ctx.prec, ctx.drop = prec, (p_drop, p_layer, seed)
         return z
 
     @staticmethod
@@ -75,15 +75,19 @@ class _FFNFn(torch.autograd.Function):
         y, saved, *ps = ctx.saved_tensors
         p = dict(zip(_FFNFn.NAMES, ps))
         grads = {k: torch.zeros_like(v) for k, v in p.items()}
-        dy = ops.ffn_bwd(dz.contiguous(), y, p, saved, ctx.prec, grads)
-        return (dy, *[grads[k] for k in _FFNFn.NAMES], None)
+        dy = ops.ffn_bwd(dz.contiguous(), y, p, saved, ctx.prec, grads, *ctx.drop)
+        return (dy, *[grads[k] for k in _FFNFn.NAMES], None, None, None, None)
 
 
-def _no_dropout(module, p):
-    if module.training and p:
-        raise NotImplementedError(
-            "dropout > 0 in training mode is not wired into the fused HIP sub-layers yet; "
-            "use model.eval() or config.dropout = 0")
+def _drop_p(module, p):
+    """dropout probability in effect (nn.Dropout semantics: active only in training mode)"""
+    return float(p) if (module.training and p) else 0.0
+
+
+def _new_seed(*ps):
+    """one 31-bit seed per sub-layer call from torch's CPU generator (reproducible under torch.manual_seed); the HIP
+    kernels derive their counter-based masks from it and regenerate them in backward"""
+    return int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if any(ps) else 0
 
 
 class PositionwiseFF(nn.Module):
@@ -96,11 +100,13 @@ class PositionwiseFF(nn.Module):
                                      nn.Linear(d_inner, d_model), nn.Dropout(dropout))
         self.layer_norm = nn.LayerNorm(d_model, eps=layer_norm_epsilon)
 
-    def forward(self, inp, prec=None):
-        _no_dropout(self, self.dropout)
+    def forward(self, inp, prec=None, p_layer=0.0):
+        """p_layer: dropout the enclosing RelLearnableDecoderLayer applies to this block's output (fused here)"""
         c = self.CoreNet
+        p = _drop_p(self, self.dropout)
         return _FFNFn.apply(inp, c[0].weight, c[0].bias, c[3].weight, c[3].bias, self.layer_norm.weight,
-                            self.layer_norm.bias, default_precision() if prec is None else prec)
+                            self.layer_norm.bias, default_precision() if prec is None else prec, p, p_layer,
+                            _new_seed(p, p_layer))
 
 
 class RelMultiHeadAttn(nn.Module):
@@ -124,9 +130,9 @@ class RelLearnableMultiHeadAttn(RelMultiHeadAttn):
 
     def forward_bm(self, x, r_emb, r_w_bias, r_bias, mask, prec=None):
         """batch-major [B, L, d] in/out; mask: MaskSpec."""
-        _no_dropout(self, self.dropout)
+        p = _drop_p(self, self.dropout)
         return _AttnFn.apply(x, self.qkv_net.weight, self.o_net.weight, self.layer_norm.weight, self.layer_norm.bias,
-                             r_emb, r_w_bias, r_bias, mask, default_precision() if prec is None else prec)
+                             r_emb, r_w_bias, r_bias, mask, default_precision() if prec is None else prec, p, _new_seed(p))
 
     def forward(self, w, r_emb, r_w_bias, r_bias, attn_mask=None):
         """reference contract: w [L, B, d] time-major."""
@@ -143,8 +149,8 @@ class RelLearnableDecoderLayer(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward_bm(self, x, r_emb, r_w_bias, r_bias, mask, prec=None):
-        _no_dropout(self, self.dropout.p)
-        return self.pos_ff(self.dec_attn.forward_bm(x, r_emb, r_w_bias, r_bias, mask, prec), prec)
+        return self.pos_ff(self.dec_attn.forward_bm(x, r_emb, r_w_bias, r_bias, mask, prec), prec,
+                           _drop_p(self, self.dropout.p))
 
     def forward(self, input, r_emb, r_w_bias, r_bias, attn_mask=None):
         L, B = input.size(0), input.size(1)

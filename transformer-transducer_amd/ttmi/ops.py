@@ -144,7 +144,7 @@ def scratch(n, device):
     return t
 
 
-def attn_fwd(x, p, mask, prec):
+def attn_fwd(x, p, mask, prec, p_drop=0.0, seed=0):
     """p: dict of parameter tensors (qkv_w, o_w, ln_g, ln_b, r_emb, r_w_bias, r_bias)."""
     _need_cuda(x)
     B, L, d = x.shape
@@ -157,11 +157,12 @@ def attn_fwd(x, p, mask, prec):
     y = torch.empty_like(x)
     check(L_.ttmi_attn_fwd(_p(x), _p(p["qkv_w"]), _p(p["o_w"]), _p(p["ln_g"]), _p(p["ln_b"]), _p(p["r_emb"]),
                            _p(p["r_w_bias"]), _p(p["r_bias"]), c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh), c_int(K),
-                           *mask.args(), c_int(prec), _p(ctx), _p(ws), _p(y), _stream()), "ttmi_attn_fwd")
+                           *mask.args(), c_int(prec), c_float(p_drop), ctypes.c_uint(seed), _p(ctx), _p(ws), _p(y), _stream()),
+          "ttmi_attn_fwd")
     return y, ctx
 
 
-def attn_bwd(dy, x, p, ctx, prec, grads):
+def attn_bwd(dy, x, p, ctx, prec, grads, p_drop=0.0, seed=0):
     """grads: dict of ZERO-INITIALISED (or running) f32 buffers, accumulated into."""
     B, L, d = x.shape
     K, H, Dh = p["r_emb"].shape
@@ -170,13 +171,14 @@ def attn_bwd(dy, x, p, ctx, prec, grads):
     ws = scratch(L_.ttmi_attn_ws_floats(c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh), c_int(prec)), x.device)
     dx = torch.empty_like(x)
     check(L_.ttmi_attn_bwd(_p(dy), _p(x), _p(p["qkv_w"]), _p(p["o_w"]), _p(p["ln_g"]), _p(p["r_emb"]), _p(p["r_bias"]),
-                           c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh), c_int(K), c_int(prec), _p(ctx), _p(ws), _p(dx),
+                           c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh), c_int(K), c_int(prec), c_float(p_drop), ctypes.c_uint(seed),
+                           _p(ctx), _p(ws), _p(dx),
                            _p(grads["qkv_w"]), _p(grads["o_w"]), _p(grads["ln_g"]), _p(grads["ln_b"]), _p(grads["r_emb"]),
                            _p(grads["r_w_bias"]), _p(grads["r_bias"]), _stream()), "ttmi_attn_bwd")
     return dx
 
 
-def ffn_fwd(y, p, prec):
+def ffn_fwd(y, p, prec, p_drop=0.0, p_layer=0.0, seed=0):
     rows, d = y.numel() // y.shape[-1], y.shape[-1]
     Di = p["ff_w1"].shape[0]
     L_ = lib()
@@ -186,12 +188,13 @@ def ffn_fwd(y, p, prec):
     ws = scratch(L_.ttmi_ffn_ws_floats(c_long(rows), c_int(d), c_int(Di), c_int(prec)), y.device)
     z = torch.empty_like(y)
     check(L_.ttmi_ffn_fwd(_p(y), _p(p["ff_w1"]), _p(p["ff_b1"]), _p(p["ff_w2"]), _p(p["ff_b2"]), _p(p["ff_ln_g"]),
-                          _p(p["ff_ln_b"]), c_long(rows), c_int(d), c_int(Di), c_int(prec), _p(ctx), _p(ws), _p(z), _stream()),
+                          _p(p["ff_ln_b"]), c_long(rows), c_int(d), c_int(Di), c_int(prec), c_float(p_drop), c_float(p_layer),
+                          ctypes.c_uint(seed), _p(ctx), _p(ws), _p(z), _stream()),
           "ttmi_ffn_fwd")
     return z, ctx
 
 
-def ffn_bwd(dz, y, p, ctx, prec, grads):
+def ffn_bwd(dz, y, p, ctx, prec, grads, p_drop=0.0, p_layer=0.0, seed=0):
     rows, d = y.numel() // y.shape[-1], y.shape[-1]
     Di = p["ff_w1"].shape[0]
     L_ = lib()
@@ -199,7 +202,7 @@ def ffn_bwd(dz, y, p, ctx, prec, grads):
     ws = scratch(L_.ttmi_ffn_ws_floats(c_long(rows), c_int(d), c_int(Di), c_int(prec)), y.device)
     dy = torch.empty_like(y)
     check(L_.ttmi_ffn_bwd(_p(dz), _p(y), _p(p["ff_w1"]), _p(p["ff_w2"]), _p(p["ff_ln_g"]), c_long(rows), c_int(d), c_int(Di),
-                          c_int(prec), _p(ctx), _p(ws), _p(dy), _p(grads["ff_w1"]), _p(grads["ff_b1"]), _p(grads["ff_w2"]),
+                          c_int(prec), c_float(p_drop), c_float(p_layer), ctypes.c_uint(seed), _p(ctx), _p(ws), _p(dy), _p(grads["ff_w1"]), _p(grads["ff_b1"]), _p(grads["ff_w2"]),
                           _p(grads["ff_b2"]), _p(grads["ff_ln_g"]), _p(grads["ff_ln_b"]), _stream()), "ttmi_ffn_bwd")
     return dy
 
@@ -318,3 +321,11 @@ def gemm_tn_bf16(A, B, C, accumulate=False):
     check(lib().ttmi_gemm_tn_bf16(_p(A), _p(B), _p(C), c_int(M), c_int(N), c_int(K), c_long(A.stride(0)), c_long(B.stride(0)),
                                   c_long(C.stride(0)), c_int(1 if accumulate else 0), _stream()), "ttmi_gemm_tn_bf16")
     return C
+
+
+def dropout_multipliers(n, p, seed, device):
+    """the exact 0 / 1/(1-p) multipliers the fused sub-layers use for dropout site `seed` (tests, debugging)"""
+    ones = torch.ones(n, dtype=torch.float32, device=device)
+    out = torch.empty_like(ones)
+    check(lib().ttmi_dropout_apply(_p(ones), c_long(n), c_float(p), ctypes.c_uint(seed), _p(out), _stream()), "ttmi_dropout_apply")
+    return out
