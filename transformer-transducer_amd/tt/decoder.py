@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 
 from ttmi import ops
-from tt.transformer import RelLearnableDecoderLayer, as_mask_spec
+from tt.transformer import RelLearnableDecoderLayer, as_mask_spec, grad_targets
 
 
 class _EmbedFn(torch.autograd.Function):
@@ -12,15 +12,17 @@ class _EmbedFn(torch.autograd.Function):
     def forward(ctx, tokens, weight, padding_idx):
         tokens = tokens.contiguous()
         ctx.save_for_backward(tokens)
-        ctx.shape, ctx.padding_idx = weight.shape, padding_idx
+        ctx.shape, ctx.padding_idx, ctx.params = weight.shape, padding_idx, (weight,)
         return ops.embed_fwd(tokens, weight.detach())
 
     @staticmethod
     def backward(ctx, dout):
         (tokens,) = ctx.saved_tensors
-        gW = torch.zeros(ctx.shape, dtype=torch.float32, device=dout.device)
-        ops.embed_bwd(tokens, dout.contiguous(), ctx.shape[0], ctx.padding_idx, gW)
-        return None, gW, None
+        g, rets, after = grad_targets(ctx.params, ("w",))
+        ops.embed_bwd(tokens, dout.contiguous(), ctx.shape[0], ctx.padding_idx, g["w"])
+        for cb in after:
+            cb()
+        return None, rets[0], None
 
 
 class BaseDecoder(nn.Module):

@@ -12,7 +12,7 @@ from ttmi import ops
 from ttmi.ops import MaskSpec
 from tt.decoder import BuildDecoder
 from tt.encoder import BuildEncoder
-from tt.transformer import default_precision
+from tt.transformer import default_precision, grad_targets
 from tt.utils import context_mask, look_ahead_mask  # noqa: F401  (re-exported like the reference module)
 
 
@@ -20,19 +20,22 @@ class _JointFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, enc, dec, wf, bf, wp, bp, prec):
         enc, dec = enc.contiguous(), dec.contiguous()
+        params = (wf, bf, wp, bp)
         wf, bf, wp, bp = (t.detach() for t in (wf, bf, wp, bp))
         logits, saved = ops.joint_fwd(enc, dec, wf, bf, wp, bp, prec)
         ctx.save_for_backward(enc, dec, wf, wp, saved)
         ctx.prec = prec
+        ctx.params = params
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
         enc, dec, wf, wp, saved = ctx.saved_tensors
-        g = dict(wf=torch.zeros_like(wf), bf=torch.zeros(wf.shape[0], dtype=wf.dtype, device=wf.device),
-                 wp=torch.zeros_like(wp), bp=torch.zeros(wp.shape[0], dtype=wp.dtype, device=wp.device))
+        g, rets, after = grad_targets(ctx.params, ("wf", "bf", "wp", "bp"))
         denc, ddec = ops.joint_bwd(dlogits, enc, dec, wf, wp, saved, ctx.prec, g)
-        return denc, ddec, g["wf"], g["bf"], g["wp"], g["bp"], None
+        for cb in after:
+            cb()
+        return (denc, ddec, *rets, None)
 
 
 class JointNet(nn.Module):

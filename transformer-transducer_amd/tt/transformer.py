@@ -37,6 +37,25 @@ def as_mask_spec(mask, B, L):
     return MaskSpec(3, tensor=t.to(torch.uint8).contiguous())
 
 
+def grad_targets(params, names):
+    """Gradient buffers for a sub-layer's backward.  Parameters that `ttmi.train.FlatModel` manages (attribute
+    `_ttmi_direct`, .grad = view of the flat gradient buffer) are accumulated into IN PLACE by the HIP kernels (their
+    gradient semantics are += anyway) and autograd gets None for them; everything else gets a fresh zero buffer that is
+    returned to autograd.  Returns (buffers by name, tuple to return to autograd, callbacks to run afterwards)."""
+    bufs, rets, after = {}, [], []
+    for n, prm in zip(names, params):
+        if getattr(prm, "_ttmi_direct", False) and prm.grad is not None:
+            bufs[n] = prm.grad
+            rets.append(None)
+            cb = getattr(prm, "_ttmi_on_grad", None)
+            if cb is not None:
+                after.append(cb)
+        else:
+            bufs[n] = torch.zeros_like(prm)
+            rets.append(bufs[n])
+    return bufs, tuple(rets), after
+
+
 class _AttnFn(torch.autograd.Function):
     NAMES = ("qkv_w", "o_w", "ln_g", "ln_b", "r_emb", "r_w_bias", "r_bias")
 
@@ -47,15 +66,18 @@ class _AttnFn(torch.autograd.Function):
         y, saved = ops.attn_fwd(x, p, mask, prec, p_drop, seed)
         ctx.save_for_backward(x, saved, *p.values())
         ctx.prec, ctx.p_drop, ctx.seed = prec, p_drop, seed
+        ctx.params = (qkv_w, o_w, ln_g, ln_b, r_emb, r_w_bias, r_bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, saved, *ps = ctx.saved_tensors
         p = dict(zip(_AttnFn.NAMES, ps))
-        grads = {k: torch.zeros_like(v) for k, v in p.items()}
+        grads, rets, after = grad_targets(ctx.params, _AttnFn.NAMES)
         dx = ops.attn_bwd(dy.contiguous(), x, p, saved, ctx.prec, grads, ctx.p_drop, ctx.seed)
-        return (dx, *[grads[k] for k in _AttnFn.NAMES], None, None, None, None)
+        for cb in after:
+            cb()
+        return (dx, *rets, None, None, None, None)
 
 
 class _FFNFn(torch.autograd.Function):
@@ -68,15 +90,18 @@ class _FFNFn(torch.autograd.Function):
         z, saved = ops.ffn_fwd(y, p, prec, p_drop, p_layer, seed)
         ctx.save_for_backward(y, saved, *p.values())
         ctx.prec, ctx.drop = prec, (p_drop, p_layer, seed)
+        ctx.params = (w1, b1, w2, b2, ln_g, ln_b)
         return z
 
     @staticmethod
     def backward(ctx, dz):
         y, saved, *ps = ctx.saved_tensors
         p = dict(zip(_FFNFn.NAMES, ps))
-        grads = {k: torch.zeros_like(v) for k, v in p.items()}
+        grads, rets, after = grad_targets(ctx.params, _FFNFn.NAMES)
         dy = ops.ffn_bwd(dz.contiguous(), y, p, saved, ctx.prec, grads, *ctx.drop)
-        return (dy, *[grads[k] for k in _FFNFn.NAMES], None, None, None, None)
+        for cb in after:
+            cb()
+        return (dy, *rets, None, None, None, None)
 
 
 def _drop_p(module, p):

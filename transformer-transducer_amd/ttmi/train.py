@@ -32,6 +32,7 @@ class FlatModel:
             v.copy_(p.data)
             p.data = v
             p.grad = self.grad[o:o + p.numel()].view_as(p)
+            p._ttmi_direct = True           # the HIP backward kernels accumulate straight into p.grad (tt.transformer.grad_targets)
         self.numel = n
 
     def zero_grad(self):
@@ -61,13 +62,19 @@ class GradSync:
                 self.buckets.append((start, end, len(members)))
                 start, members = end, []
         self.pending = [0] * len(self.buckets)
+        self.seen = [False] * len(flat.params)
         self.works = []
         if self.world > 1:
             for i, p in enumerate(flat.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+                hook = self._make_hook(i)
+                p.register_post_accumulate_grad_hook(hook)      # gradients that arrive through autograd
+                p._ttmi_on_grad = hook                           # gradients written in place by the HIP backward kernels
 
     def _make_hook(self, i):
-        def hook(_param):
+        def hook(_param=None):
+            if self.seen[i]:                # a parameter reports once per step, whichever path (in-place / autograd) is first
+                return
+            self.seen[i] = True
             b = self.bucket_of[i]
             self.pending[b] += 1
             if self.pending[b] == self.buckets[b][2]:
@@ -77,6 +84,7 @@ class GradSync:
 
     def start_step(self):
         self.pending = [0] * len(self.buckets)
+        self.seen = [False] * len(self.flat.params)
         self.works = []
 
     def finish(self):
