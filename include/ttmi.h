@@ -53,7 +53,8 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
                   int mask_kind, int mask_left, int mask_right, const unsigned char* mask, long mask_sb, long mask_si,
                   int prec, float p_drop, unsigned seed, float* ctx, float* ws, float* y, void* stream);
 int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const float* o_w, const float* ln_g,
-                  const float* r_emb, const float* r_bias, int B, int L, int d, int H, int Dh, int K, int prec,
+                  const float* r_emb, const float* r_bias, int B, int L, int d, int H, int Dh, int K, int mask_kind,
+                  int mask_left, int mask_right, const unsigned char* mask, long mask_sb, long mask_si, int prec,
                   float p_drop, unsigned seed, const float* ctx, float* ws, float* dx, float* g_qkv_w, float* g_o_w,
                   float* g_ln_g, float* g_ln_b, float* g_r_emb, float* g_r_w_bias, float* g_r_bias, void* stream);
 
@@ -118,6 +119,7 @@ int ttmi_gemm_nt_bf16(const void* A, const void* B, void* C, int c_dtype, const 
                       long ldb, long ldc, void* stream);
 int ttmi_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
                       void* stream);
+int ttmi_set_option(int key, int value);   /* key 0: 1 = disable the fused attention kernels (A/B measurements) */
 int ttmi_dropout_apply(const float* in, long n, float p, unsigned seed, float* out, void* stream);
 int ttmi_probe_arm(int slot);
 float ttmi_probe_read_ms(int slot);

@@ -1,0 +1,60 @@
+"""Fused attention kernels (csrc/attn_flash.hip) in the bf16 pipeline: one encoder layer vs the float64 oracle and vs
+the unfused GEMM+softmax chain, head dims 32/64, lengths off the tile grid, both table branches, every mask kind."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import tt_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(layer, x, cot, mask):
+    layer.zero_grad()
+    xg = x.clone().requires_grad_(True)
+    y = layer.forward_bm(xg, mask)
+    (y * cot).sum().backward()
+    return y.detach(), xg.grad.clone(), {n: p.grad.clone() for n, p in layer.named_parameters()}
+
+
+@pytest.mark.parametrize("Dh,H,L,K,mk", [(64, 2, 70, 128, "none"), (64, 2, 150, 40, "none"), (32, 4, 33, 64, "causal"),
+                                          (64, 1, 129, 16, "band"), (32, 2, 96, 200, "tensor"), (64, 2, 500, 410, "none")])
+def test_layer_fused_vs_oracle_and_unfused(Dh, H, L, K, mk, monkeypatch):
+    from tt.encoder import BaseEncoder
+    from ttmi import ops
+    from ttmi.ops import MaskSpec
+    monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    d, Di, B = H * Dh, 96, 2
+    torch.manual_seed(L + Dh)
+    layer = BaseEncoder(k_len=K, n_head=H, d_model=d, d_head=Dh, d_inner=Di, dropout=0.0).cuda().eval()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, L, d, generator=g).cuda()
+    cot = torch.randn(B, L, d, generator=g).cuda()
+    omask = None
+    if mk == "none":
+        mask = MaskSpec(0)
+    elif mk == "causal":
+        mask, omask = MaskSpec(1), O.look_ahead_mask(L)[:, :, None]
+    elif mk == "band":
+        mask, omask = MaskSpec(2, left=20, right=3), O.context_mask(L, 20, 3)[:, :, None]
+    else:
+        m = O.chunk_mask(L, 16, 32)
+        mask, omask = MaskSpec(3, tensor=torch.tensor(m[None].astype(np.uint8)).cuda()), m[:, :, None]
+    ops.set_option(0, 0)
+    y1, dx1, g1 = _run(layer, x, cot, mask)
+    ops.set_option(0, 1)
+    y0, dx0, g0 = _run(layer, x, cot, mask)            # unfused reference chain, same bf16 pipeline
+    ops.set_option(0, 0)
+    sd = {"encoder.layers.0." + k: v.detach().cpu().numpy().astype(np.float64) for k, v in layer.state_dict().items()}
+    prm = O.layer_params(sd, "encoder.", 0)
+    want, cache = O.layer_fwd(x.cpu().numpy().astype(np.float64), prm, omask)
+    dxo, go = O.layer_bwd(cot.cpu().numpy().astype(np.float64), cache, prm)
+    names = {v: k for k, v in O._LAYER_KEYS.items()}
+    e_f = rel_err(y1.cpu().numpy(), want)
+    e_u = rel_err(y0.cpu().numpy(), want)
+    worst_f = max([rel_err(dx1.cpu().numpy(), dxo)] + [rel_err(g1[n].cpu().numpy(), go[names[n]]) for n in g1])
+    worst_u = max([rel_err(dx0.cpu().numpy(), dxo)] + [rel_err(g0[n].cpu().numpy(), go[names[n]]) for n in g0])
+    print("fused: out %.2e worst grad %.2e | unfused: out %.2e worst grad %.2e" % (e_f, worst_f, e_u, worst_u))
+    assert e_f < 3e-2 and worst_f < 8e-2
+    assert e_f < 2.5 * e_u + 1e-3 and worst_f < 2.5 * worst_u + 1e-3     # the fused kernels are as accurate as the unfused chain

@@ -1,0 +1,31 @@
+// Internal: fused relative-position attention kernels (attn_flash.hip).  Not part of the C ABI.
+#pragma once
+#include "common.h"
+
+struct FlashParams {
+    // bf16 activations; row (b, i) of a [B*L, ld] buffer, head h at column h*Dh
+    const bf16_t* qu = nullptr;   // q + r_w_bias
+    const bf16_t* k = nullptr;
+    const bf16_t* v = nullptr;
+    long ld_qu = 0, ld_kv = 0, ld_o = 0;
+    const float* bd = nullptr;    // shifted position scores: element (z, i, j) at bd[z*slab + i*L + j]  (z = b*H + h)
+    long slab = 0;
+    bf16_t* o = nullptr;          // attention output (fwd: written, bwd: read)
+    float* lse = nullptr;         // [B*H, L] log-sum-exp of the scaled, masked scores
+    // backward only
+    const bf16_t* dO = nullptr;
+    float* delta = nullptr;       // [B*H, L] scratch
+    float* dS = nullptr;          // same addressing as bd
+    float* dK = nullptr;          // f32 [B*L, ld_dkv] (+ h*Dh)
+    float* dV = nullptr;
+    long ld_dkv = 0;
+    int B = 0, L = 0, H = 0, Dh = 0;
+    float scale = 1.f;
+    int mask_kind = 0, mask_left = 0, mask_right = 0;
+    const unsigned char* mask = nullptr;
+    long mask_sb = 0, mask_si = 0;
+};
+
+bool flash_supported(int Dh, long ld_qu, long ld_kv, long ld_o);
+int flash_attn_fwd(const FlashParams& p, hipStream_t st);
+int flash_attn_bwd(const FlashParams& p, hipStream_t st);

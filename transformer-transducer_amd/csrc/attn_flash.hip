@@ -1,0 +1,335 @@
+// Fused relative-position attention for the bf16 pipeline (gfx950): scores are never materialised as
+// probabilities in HBM.
+//
+//   flash_fwd_kernel   S^T = K.(q+u)^T + BD^T  (bias = the shifted position term read through the pitch-L view of
+//                      the G slab, tt/transformer.py:140-149), mask as kernel parameters (:154-159), online softmax
+//                      (:164), O^T += V^T.P^T (:167).  Keys live on the MFMA rows, the query on the lane, so every
+//                      softmax statistic is lane-local (one __shfl_xor 32 per tile) and the S^T accumulator is the B
+//                      operand of the PV product with no lane movement; V^T fragments come from ds_read_b64_tr_b16.
+//   flash_bwd_kernel   recomputes P from (q+u), k, BD and the saved log-sum-exp; dP = dO.V^T; dS = P(dP - delta)scale is
+//                      written once (pitch-L view of the dS slab == dG in the pitch-(L+1) layout, consumed by the position
+//                      GEMMs); dV^T += dO^T.P and dK^T += (q+u)^T.dS accumulate in registers (key on the lane: P and dS
+//                      accumulators are the B operands as they stand; dO^T / (q+u)^T fragments by transposed LDS reads).
+//                      No atomics: each wave owns 32 keys.
+//
+// 4 waves per workgroup; a wave owns 32 queries (fwd) / 32 keys (bwd); K/V (fwd) or (q+u)/dO (bwd) tiles are staged in
+// LDS with the row XOR swizzle chunk ^= (row >> 1) & (chunks-1).  Head dims 32 and 64.
+#include "attn_flash.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr float NEGBIG = -1e30f;
+
+__device__ __forceinline__ bf16x4 tr16(const char* lds_addr) {
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_addr);
+    return __builtin_bit_cast(bf16x4, v);
+}
+
+__device__ __forceinline__ bool is_masked(const FlashParams& p, int b, int i, int j) {
+    switch (p.mask_kind) {
+        case 1: return j > i;
+        case 2: return (j > i + p.mask_right) || (j < i - p.mask_left);
+        case 3: return p.mask[(long)b * p.mask_sb + (long)i * p.mask_si + j] != 0;
+        default: return false;
+    }
+}
+
+template <int DH>
+struct Tile {                                    // [rows][DH] bf16 LDS image, 16-byte chunks XOR-swizzled per row
+    static constexpr int NCH = DH / 8;
+    static constexpr int ROWB = DH * 2;
+    __device__ static __forceinline__ int off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & (NCH - 1))) << 4); }
+};
+
+// cooperative copy of `nrows` rows (global row r0 + row, clamped to rmax) of DH bf16 into a swizzled LDS tile
+template <int DH>
+__device__ __forceinline__ void stage_rows(char* lds, const bf16_t* g, long ld, int r0, int rmax, int nrows, int tid) {
+    using T = Tile<DH>;
+    for (int c = tid; c < nrows * T::NCH; c += 256) {
+        const int row = c / T::NCH, ch = c % T::NCH;
+        const int gr = min(r0 + row, rmax);
+        const uint4 v = *reinterpret_cast<const uint4*>(g + (long)gr * ld + ch * 8);
+        *reinterpret_cast<uint4*>(lds + T::off(row, ch)) = v;
+    }
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int base) {
+    bf16x8 r;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = (__bf16)v[base + k];
+    return r;
+}
+
+// transposed A-operand fragment of a [rows = reduction][cols = DH] tile: A[m = col c0 + (lane & 31)][k], k order
+// = rows rbase + 8 (j >> 2) + 4 h + (j & 3), j = 0..7 (the order of an accumulator tile used as the B operand)
+template <int DH>
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rbase, int c0, int lane) {
+    using T = Tile<DH>;
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, h = g >> 1;
+    const int col = c0 + 16 * (g & 1) + 4 * pp;
+    const int r_lo = rbase + 4 * h + q, r_hi = r_lo + 8;
+    const bf16x4 lo = tr16(tile + T::off(r_lo, col >> 3) + (col & 7) * 2);
+    const bf16x4 hi = tr16(tile + T::off(r_hi, col >> 3) + (col & 7) * 2);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// ------------------------------------------------------------------ forward
+template <int DH>
+__global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashParams p) {
+    using T = Tile<DH>;
+    constexpr int KS = DH / 16, DT = DH / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ktile = smem;
+    char* vtile = smem + 64 * T::ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int z = blockIdx.y, b = z / p.H, h = z % p.H;
+    const int L = p.L;
+    const int i = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const int ic = min(i, L - 1);
+    const bf16_t* qrow = p.qu + ((long)b * L + ic) * p.ld_qu + h * DH;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks + 8 * hh);
+    f32x16 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m = NEGBIG, l = 0.f;
+    const float* bd_row = p.bd + (long)z * p.slab + (long)ic * L;
+    const bf16_t* kbase = p.k + (long)b * L * p.ld_kv + h * DH;
+    const bf16_t* vbase = p.v + (long)b * L * p.ld_kv + h * DH;
+
+    for (int j0 = 0; j0 < L; j0 += 64) {
+        __syncthreads();
+        stage_rows<DH>(ktile, kbase, p.ld_kv, j0, L - 1, 64, tid);
+        stage_rows<DH>(vtile, vbase, p.ld_kv, j0, L - 1, 64, tid);
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int jb = j0 + 32 * sub;
+            if (jb >= L) break;                                   // block-uniform
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ktile + T::off(32 * sub + (lane & 31), 2 * ks + hh));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+            }
+            float pmax = NEGBIG;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float v = NEGBIG;
+                if (j < L && !is_masked(p, b, ic, j)) v = (s[r] + bd_row[j]) * p.scale;
+                s[r] = v;
+                pmax = fmaxf(pmax, v);
+            }
+            pmax = fmaxf(pmax, __shfl_xor(pmax, 32, 64));
+            const float mn = fmaxf(m, pmax);
+            const float alpha = __expf(m - mn);
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pr = s[r] > 0.5f * NEGBIG ? __expf(s[r] - mn) : 0.f;
+                s[r] = pr;
+                psum += pr;
+            }
+            l = l * alpha + psum;
+            m = mn;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pb = pack8(s, 8 * s2);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const bf16x8 vf = tr_frag<DH>(vtile, 32 * sub + 16 * s2, 32 * dt, lane);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (i < L) {
+        const float inv = 1.f / l;
+        bf16_t* orow = p.o + ((long)b * L + i) * p.ld_o + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = 32 * dt + 8 * g4 + 4 * hh;
+                uint2 w;
+                w.x = pack_bf16x2(o[dt][4 * g4] * inv, o[dt][4 * g4 + 1] * inv);
+                w.y = pack_bf16x2(o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
+                *reinterpret_cast<uint2*>(orow + d) = w;
+            }
+        if (hh == 0) p.lse[(long)z * L + i] = m + __logf(l);
+    }
+}
+
+// ------------------------------------------------------------------ backward (dK, dV, dS)
+template <int DH>
+__global__ __launch_bounds__(256) void flash_bwd_kernel(const FlashParams p) {
+    using T = Tile<DH>;
+    constexpr int KS = DH / 16, DT = DH / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* qtile = smem;                          // (q+u) rows of the current query tile
+    char* dotile = smem + 32 * T::ROWB;          // dO rows
+    float* lse_s = reinterpret_cast<float*>(smem + 64 * T::ROWB);
+    float* del_s = lse_s + 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int z = blockIdx.y, b = z / p.H, h = z % p.H;
+    const int L = p.L;
+    const int j = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const int jc = min(j, L - 1);
+    const bool kvalid = j < L;
+    const bf16_t* krow = p.k + ((long)b * L + jc) * p.ld_kv + h * DH;
+    const bf16_t* vrow = p.v + ((long)b * L + jc) * p.ld_kv + h * DH;
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = *reinterpret_cast<const bf16x8*>(krow + 16 * ks + 8 * hh);
+        vf[ks] = *reinterpret_cast<const bf16x8*>(vrow + 16 * ks + 8 * hh);
+    }
+    f32x16 dk[DT], dv[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+    const bf16_t* qbase = p.qu + (long)b * L * p.ld_qu + h * DH;
+    const bf16_t* dobase = p.dO + (long)b * L * p.ld_o + h * DH;
+    const float* bd = p.bd + (long)z * p.slab;
+    float* dsout = p.dS + (long)z * p.slab;
+
+    for (int i0 = 0; i0 < L; i0 += 32) {
+        __syncthreads();
+        stage_rows<DH>(qtile, qbase, p.ld_qu, i0, L - 1, 32, tid);
+        stage_rows<DH>(dotile, dobase, p.ld_o, i0, L - 1, 32, tid);
+        if (tid < 32) {
+            const int ii = min(i0 + tid, L - 1);
+            lse_s[tid] = p.lse[(long)z * L + ii];
+            del_s[tid] = p.delta[(long)z * L + ii];
+        }
+        __syncthreads();
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 qa = *reinterpret_cast<const bf16x8*>(qtile + T::off(lane & 31, 2 * ks + hh));
+            const bf16x8 da = *reinterpret_cast<const bf16x8*>(dotile + T::off(lane & 31, 2 * ks + hh));
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const int i = i0 + q;
+            const bool inb = (i < L) && kvalid;
+            float pr = 0.f, ds = 0.f;
+            if (inb) {
+                if (!is_masked(p, b, i, j)) {
+                    const float sc = (s[r] + bd[(long)i * L + j]) * p.scale;
+                    pr = __expf(sc - lse_s[q]);
+                    ds = pr * (dp[r] - del_s[q]) * p.scale;
+                }
+                dsout[(long)i * L + j] = ds;
+            }
+            s[r] = pr;
+            dp[r] = ds;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pb = pack8(s, 8 * s2);
+            const bf16x8 dsb = pack8(dp, 8 * s2);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16x8 a_do = tr_frag<DH>(dotile, 16 * s2, 32 * dt, lane);
+                const bf16x8 a_qu = tr_frag<DH>(qtile, 16 * s2, 32 * dt, lane);
+                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_do, pb, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_qu, dsb, dk[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (kvalid) {
+        float* dkrow = p.dK + ((long)b * L + j) * p.ld_dkv + h * DH;
+        float* dvrow = p.dV + ((long)b * L + j) * p.ld_dkv + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = 32 * dt + 8 * g4 + 4 * hh;
+                *reinterpret_cast<float4*>(dkrow + d) = make_float4(dk[dt][4 * g4], dk[dt][4 * g4 + 1], dk[dt][4 * g4 + 2], dk[dt][4 * g4 + 3]);
+                *reinterpret_cast<float4*>(dvrow + d) = make_float4(dv[dt][4 * g4], dv[dt][4 * g4 + 1], dv[dt][4 * g4 + 2], dv[dt][4 * g4 + 3]);
+            }
+    }
+}
+
+// delta[z, i] = sum_d dO[b,i,h,d] * O[b,i,h,d]
+template <int DH>
+__global__ __launch_bounds__(256) void flash_delta_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O, long ld, int B,
+                                                          int L, int H, float* __restrict__ delta) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;          // (b, i, h)
+    if (idx >= (long)B * L * H) return;
+    const int h = (int)(idx % H);
+    const long bi = idx / H;
+    const int i = (int)(bi % L), b = (int)(bi / L);
+    const bf16_t* a = dO + bi * ld + h * DH;
+    const bf16_t* c = O + bi * ld + h * DH;
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < DH; d += 8) {
+        const uint4 x = *reinterpret_cast<const uint4*>(a + d);
+        const uint4 y = *reinterpret_cast<const uint4*>(c + d);
+        const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            acc += __uint_as_float(xs[k] << 16) * __uint_as_float(ys[k] << 16) +
+                   __uint_as_float(xs[k] & 0xffff0000u) * __uint_as_float(ys[k] & 0xffff0000u);
+    }
+    delta[((long)b * H + h) * L + i] = acc;
+}
+
+}  // namespace
+
+bool flash_supported(int Dh, long ld_qu, long ld_kv, long ld_o) {
+    return (Dh == 32 || Dh == 64) && ld_qu % 8 == 0 && ld_kv % 8 == 0 && ld_o % 8 == 0;
+}
+
+int flash_attn_fwd(const FlashParams& p, hipStream_t st) {
+    TTMI_REQUIRE(p.qu && p.k && p.v && p.bd && p.o && p.lse, "flash_attn_fwd: null pointer");
+    TTMI_REQUIRE(flash_supported(p.Dh, p.ld_qu, p.ld_kv, p.ld_o), "flash_attn_fwd: unsupported head dim %d / pitches", p.Dh);
+    TTMI_REQUIRE(aligned16(p.qu) && aligned16(p.k) && aligned16(p.v) && (reinterpret_cast<uintptr_t>(p.o) & 7) == 0, "flash_attn_fwd: alignment");
+    dim3 grid(cdiv(p.L, 128), p.B * p.H);
+    TTMI_REQUIRE(grid.y <= 65535, "flash_attn_fwd: B*H too large");
+    if (p.Dh == 64) hipLaunchKernelGGL(flash_fwd_kernel<64>, grid, dim3(256), 2 * 64 * 128, st, p);
+    else hipLaunchKernelGGL(flash_fwd_kernel<32>, grid, dim3(256), 2 * 64 * 64, st, p);
+    TTMI_LAUNCH_CHECK("flash_fwd_kernel");
+    return TTMI_OK;
+}
+
+int flash_attn_bwd(const FlashParams& p, hipStream_t st) {
+    TTMI_REQUIRE(p.qu && p.k && p.v && p.bd && p.o && p.lse && p.dO && p.delta && p.dS && p.dK && p.dV, "flash_attn_bwd: null pointer");
+    TTMI_REQUIRE(flash_supported(p.Dh, p.ld_qu, p.ld_kv, p.ld_o) && p.ld_dkv % 4 == 0, "flash_attn_bwd: unsupported head dim %d / pitches", p.Dh);
+    TTMI_REQUIRE(aligned16(p.qu) && aligned16(p.k) && aligned16(p.v) && aligned16(p.dO) && aligned16(p.dK) && aligned16(p.dV), "flash_attn_bwd: alignment");
+    const long n = (long)p.B * p.L * p.H;
+    dim3 grid(cdiv(p.L, 128), p.B * p.H);
+    if (p.Dh == 64) {
+        hipLaunchKernelGGL(flash_delta_kernel<64>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta);
+        hipLaunchKernelGGL(flash_bwd_kernel<64>, grid, dim3(256), 64 * 128 + 256, st, p);
+    } else {
+        hipLaunchKernelGGL(flash_delta_kernel<32>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta);
+        hipLaunchKernelGGL(flash_bwd_kernel<32>, grid, dim3(256), 64 * 64 + 256, st, p);
+    }
+    TTMI_LAUNCH_CHECK("flash_bwd_kernel");
+    return TTMI_OK;
+}

@@ -12,6 +12,7 @@
 #include "gemm.h"
 #include "rowops.h"
 #include "gemm_fast.h"
+#include "attn_flash.h"
 
 void ttmi_probe_begin(int slot, hipStream_t st);
 void ttmi_probe_end(int slot, hipStream_t st);
@@ -96,7 +97,7 @@ GemmDesc mkx(const void* A, int adt, const void* B, int bdt, void* C, int cdt, i
 
 struct AttnCtx {   // saved for backward.  act = f32 (parity) or bf16 (fast)
     void *qkv, *qu, *O;
-    float *P, *s1, *mean, *rstd;
+    float *P, *s1, *mean, *rstd, *lse;     // P: probabilities (unfused path) or the G slab (fused path)
     AttnCtx(Bump& b, const AttnDims& a, bool fast) {
         const size_t es = fast ? 2 : 4;
         qkv = b.take<char>(a.BL * a.W3 * es);
@@ -106,11 +107,12 @@ struct AttnCtx {   // saved for backward.  act = f32 (parity) or bf16 (fast)
         s1 = b.take<float>(a.BL * a.d);
         mean = b.take<float>(a.BL);
         rstd = b.take<float>(a.BL);
+        lse = b.take<float>((size_t)a.B * a.H * a.L);
     }
 };
 
 struct AttnWs {   // scratch (union of forward and backward needs)
-    float *E, *cT, *dE, *dcT, *a, *dS, *dqkv;
+    float *E, *cT, *dE, *dcT, *a, *dS, *dqkv, *delta;
     void* dO;
     bf16_t *x16, *wqkv16, *wo16, *dqkv16, *dres16;
     AttnWs(Bump& b, const AttnDims& a, bool fast) {
@@ -121,6 +123,7 @@ struct AttnWs {   // scratch (union of forward and backward needs)
         this->a = b.take<float>(a.BL * a.d);
         dS = b.take<float>((size_t)a.B * a.H * a.slab);
         dqkv = b.take<float>(a.BL * a.W3);
+        delta = b.take<float>((size_t)a.B * a.H * a.L);
         dO = b.take<char>(a.BL * a.HD * (fast ? 2 : 4));
         x16 = wqkv16 = wo16 = dqkv16 = dres16 = nullptr;
         if (fast) {
@@ -132,6 +135,28 @@ struct AttnWs {   // scratch (union of forward and backward needs)
         }
     }
 };
+
+// fused (flash-style) attention core: bf16 pipeline, head dim 32/64
+int g_disable_fused_attention = 0;      // ttmi_set_option(0, 1): A/B switch back to the unfused GEMM + softmax chain
+inline bool attn_fused(bool fast, const AttnDims& a) {
+    return fast && !g_disable_fused_attention && flash_supported(a.Dh, a.HD, a.W3, a.HD);
+}
+
+FlashParams flash_params(const AttnDims& a, const AttnCtx& c, float scale, int mask_kind, int mask_left, int mask_right,
+                         const unsigned char* mask, long mask_sb, long mask_si) {
+    FlashParams f;
+    f.qu = static_cast<const bf16_t*>(c.qu);
+    f.k = static_cast<const bf16_t*>(c.qkv) + a.HD;
+    f.v = static_cast<const bf16_t*>(c.qkv) + 2 * a.HD;
+    f.ld_qu = a.HD; f.ld_kv = a.W3; f.ld_o = a.HD;
+    f.bd = c.P + a.L; f.slab = a.slab;
+    f.o = static_cast<bf16_t*>(c.O);
+    f.lse = c.lse;
+    f.B = a.B; f.L = a.L; f.H = a.H; f.Dh = a.Dh; f.scale = scale;
+    f.mask_kind = mask_kind; f.mask_left = mask_left; f.mask_right = mask_right;
+    f.mask = mask; f.mask_sb = mask_sb; f.mask_si = mask_si;
+    return f;
+}
 
 int memset2d(void* p, size_t pitch, size_t width, size_t height, hipStream_t st) {
     hipError_t e = hipMemset2DAsync(p, pitch, 0, width, height, st);
@@ -204,22 +229,27 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
         g.bias = w.cT; g.sBias1 = 0; g.sBias2 = L;
         CK(ttmi_launch_gemm(g, st));
     }
-    // 5. S = shifted(G) + (q+u) k^T, accumulated through the pitch-L view
-    {
-        GemmDesc g = mkx(c.qu, adt, eoff(c.qkv, adt, a.HD), adt, c.P + L, DT_F32, L, L, Dh, a.HD, a.W3, L, NT_, prec);
-        batch_bh(g, a, L * a.HD, Dh, L * a.W3, Dh, H * a.slab, a.slab);
-        g.beta = 1.f;
-        CK(ttmi_launch_gemm(g, st));
-    }
-    // 6. P = softmax(scale * S, masked)
-    MaskDesc m;
-    m.kind = mask_kind; m.left = mask_left; m.right = mask_right; m.ptr = mask; m.sb = mask_sb; m.si = mask_si;
-    CK(softmax_fwd(c.P + L, B, H, L, L, a.slab, scale, m, st));
-    // 7. O = P V
-    {
-        GemmDesc g = mkx(c.P + L, DT_F32, eoff(c.qkv, adt, 2 * a.HD), adt, c.O, adt, L, Dh, L, L, a.W3, a.HD, NN_, prec);
-        batch_bh(g, a, H * a.slab, a.slab, L * a.W3, Dh, L * a.HD, Dh);
-        CK(ttmi_launch_gemm(g, st));
+    if (attn_fused(fast, a)) {
+        // 5-7 fused: softmax((q+u) k^T + shifted(G)) V without materialising the probabilities
+        CK(flash_attn_fwd(flash_params(a, c, scale, mask_kind, mask_left, mask_right, mask, mask_sb, mask_si), st));
+    } else {
+        // 5. S = shifted(G) + (q+u) k^T, accumulated through the pitch-L view
+        {
+            GemmDesc g = mkx(c.qu, adt, eoff(c.qkv, adt, a.HD), adt, c.P + L, DT_F32, L, L, Dh, a.HD, a.W3, L, NT_, prec);
+            batch_bh(g, a, L * a.HD, Dh, L * a.W3, Dh, H * a.slab, a.slab);
+            g.beta = 1.f;
+            CK(ttmi_launch_gemm(g, st));
+        }
+        // 6. P = softmax(scale * S, masked)
+        MaskDesc m;
+        m.kind = mask_kind; m.left = mask_left; m.right = mask_right; m.ptr = mask; m.sb = mask_sb; m.si = mask_si;
+        CK(softmax_fwd(c.P + L, B, H, L, L, a.slab, scale, m, st));
+        // 7. O = P V
+        {
+            GemmDesc g = mkx(c.P + L, DT_F32, eoff(c.qkv, adt, 2 * a.HD), adt, c.O, adt, L, Dh, L, L, a.W3, a.HD, NN_, prec);
+            batch_bh(g, a, H * a.slab, a.slab, L * a.W3, Dh, L * a.HD, Dh);
+            CK(ttmi_launch_gemm(g, st));
+        }
     }
     // 8. a = O Wo^T ; 9. y = LN(x + a)
     if (fast) {
@@ -236,7 +266,8 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
 
 // Backward of ttmi_attn_fwd.  dx is written; every g_* buffer is ACCUMULATED into (zero them per step).
 int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const float* o_w, const float* ln_g,
-                  const float* r_emb, const float* r_bias, int B, int L, int d, int H, int Dh, int K, int prec,
+                  const float* r_emb, const float* r_bias, int B, int L, int d, int H, int Dh, int K, int mask_kind,
+                  int mask_left, int mask_right, const unsigned char* mask, long mask_sb, long mask_si, int prec,
                   float p_drop, unsigned seed, const float* ctx, float* ws, float* dx, float* g_qkv_w, float* g_o_w,
                   float* g_ln_g, float* g_ln_b, float* g_r_emb, float* g_r_w_bias, float* g_r_bias, void* stream) {
     TTMI_REQUIRE(dy && x && qkv_w && o_w && ln_g && r_emb && r_bias && ctx && ws && dx, "attn_bwd: null pointer");
@@ -268,21 +299,33 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
         CK(wgrad(da, static_cast<float*>(c.O), g_o_w, d, (int)a.HD, (int)a.BL, d, a.HD, a.HD, prec, st));
         CK(ttmi_launch_gemm(mk(da, o_w, static_cast<float*>(w.dO), (int)a.BL, (int)a.HD, d, d, a.HD, a.HD, NN_, prec), st));
     }
-    // 4. dP = dO V^T through the pitch-L view of the dS slab (first L floats of each slab are outside the view)
+    const bool fused = attn_fused(fast, a);
+    // first L floats of each dS slab lie outside the pitch-L view but inside dG's row 0: zero them
     CK(memset2d(w.dS, (size_t)a.slab * 4, (size_t)L * 4, (size_t)B * H, st));
-    {
-        GemmDesc g = mkx(w.dO, adt, eoff(c.qkv, adt, 2 * a.HD), adt, w.dS + L, DT_F32, L, L, Dh, a.HD, a.W3, L, NT_, prec);
-        batch_bh(g, a, L * a.HD, Dh, L * a.W3, Dh, H * a.slab, a.slab);
-        CK(ttmi_launch_gemm(g, st));
+    if (fused) {
+        // 4-6 + 9 fused: recompute P, dS = P (dP - delta) scale -> slab, dK and dV straight into dqkv
+        FlashParams f = flash_params(a, c, scale, mask_kind, mask_left, mask_right, mask, mask_sb, mask_si);
+        f.dO = static_cast<const bf16_t*>(w.dO);
+        f.delta = w.delta;
+        f.dS = w.dS + L;
+        f.dK = w.dqkv + a.HD; f.dV = w.dqkv + 2 * a.HD; f.ld_dkv = a.W3;
+        CK(flash_attn_bwd(f, st));
+    } else {
+        // 4. dP = dO V^T through the pitch-L view of the dS slab (first L floats of each slab are outside the view)
+        {
+            GemmDesc g = mkx(w.dO, adt, eoff(c.qkv, adt, 2 * a.HD), adt, w.dS + L, DT_F32, L, L, Dh, a.HD, a.W3, L, NT_, prec);
+            batch_bh(g, a, L * a.HD, Dh, L * a.W3, Dh, H * a.slab, a.slab);
+            CK(ttmi_launch_gemm(g, st));
+        }
+        // 5. dV = P^T dO
+        {
+            GemmDesc g = mkx(c.P + L, DT_F32, w.dO, adt, w.dqkv + 2 * a.HD, DT_F32, L, Dh, L, L, a.HD, a.W3, TN_, prec);
+            batch_bh(g, a, H * a.slab, a.slab, L * a.HD, Dh, L * a.W3, Dh);
+            CK(ttmi_launch_gemm(g, st));
+        }
+        // 6. dS = P (dP - rowsum(dP P)) scale
+        CK(softmax_bwd(w.dS + L, c.P + L, B * H, L, L, a.slab, scale, st));
     }
-    // 5. dV = P^T dO
-    {
-        GemmDesc g = mkx(c.P + L, DT_F32, w.dO, adt, w.dqkv + 2 * a.HD, DT_F32, L, Dh, L, L, a.HD, a.W3, TN_, prec);
-        batch_bh(g, a, H * a.slab, a.slab, L * a.HD, Dh, L * a.W3, Dh);
-        CK(ttmi_launch_gemm(g, st));
-    }
-    // 6. dS = P (dP - rowsum(dP P)) scale
-    CK(softmax_bwd(w.dS + L, c.P + L, B * H, L, L, a.slab, scale, st));
     // 7. dq(content) = dS K -> dqkv[q]
     {
         GemmDesc g = mkx(w.dS + L, DT_F32, eoff(c.qkv, adt, a.HD), adt, w.dqkv, DT_F32, L, Dh, L, L, a.W3, a.W3, NN_, prec);
@@ -291,11 +334,13 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
     }
     // 8. g r_w_bias += column sums of dq(content)
     CK(colsum(w.dqkv, a.W3, a.BL, (int)a.HD, 1, 1, 0, 0, 0, 0, g_r_w_bias, st));
-    // 9. dK = dS^T (q + u)
-    {
-        GemmDesc g = mkx(w.dS + L, DT_F32, c.qu, adt, w.dqkv + a.HD, DT_F32, L, Dh, L, L, a.HD, a.W3, TN_, prec);
-        batch_bh(g, a, H * a.slab, a.slab, L * a.HD, Dh, L * a.W3, Dh);
-        CK(ttmi_launch_gemm(g, st));
+    if (!fused) {
+        // 9. dK = dS^T (q + u)
+        {
+            GemmDesc g = mkx(w.dS + L, DT_F32, c.qu, adt, w.dqkv + a.HD, DT_F32, L, Dh, L, L, a.HD, a.W3, TN_, prec);
+            batch_bh(g, a, H * a.slab, a.slab, L * a.HD, Dh, L * a.W3, Dh);
+            CK(ttmi_launch_gemm(g, st));
+        }
     }
     // 10. dq += dG E   (dG = the same slab read with pitch L+1, column offset 1)
     CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st));
@@ -562,6 +607,13 @@ int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float*
     CK(wgrad(dPD, dec, g_wf + de, J, dd, B * U1, J, dd, din, prec, st));
     CK(ttmi_launch_gemm(mk(dPE, wf, denc, B * T, de, J, J, din, de, NN_, prec), st));
     CK(ttmi_launch_gemm(mk(dPD, wf + de, ddec, B * U1, dd, J, J, din, dd, NN_, prec), st));
+    return TTMI_OK;
+}
+
+// process-wide switches for A/B measurements.  key 0: 1 = disable the fused attention kernels (bf16 pipeline only)
+int ttmi_set_option(int key, int value) {
+    TTMI_REQUIRE(key == 0, "set_option: unknown key %d", key);
+    g_disable_fused_attention = value;
     return TTMI_OK;
 }
 

@@ -65,7 +65,7 @@ class _AttnFn(torch.autograd.Function):
         p = dict(zip(_AttnFn.NAMES, (t.detach() for t in (qkv_w, o_w, ln_g, ln_b, r_emb, r_w_bias, r_bias))))
         y, saved = ops.attn_fwd(x, p, mask, prec, p_drop, seed)
         ctx.save_for_backward(x, saved, *p.values())
-        ctx.prec, ctx.p_drop, ctx.seed = prec, p_drop, seed
+        ctx.prec, ctx.p_drop, ctx.seed, ctx.mask = prec, p_drop, seed, mask
         ctx.params = (qkv_w, o_w, ln_g, ln_b, r_emb, r_w_bias, r_bias)
         return y
 
@@ -74,7 +74,7 @@ class _AttnFn(torch.autograd.Function):
         x, saved, *ps = ctx.saved_tensors
         p = dict(zip(_AttnFn.NAMES, ps))
         grads, rets, after = grad_targets(ctx.params, _AttnFn.NAMES)
-        dx = ops.attn_bwd(dy.contiguous(), x, p, saved, ctx.prec, grads, ctx.p_drop, ctx.seed)
+        dx = ops.attn_bwd(dy.contiguous(), x, p, saved, ctx.prec, grads, ctx.p_drop, ctx.seed, ctx.mask)
         for cb in after:
             cb()
         return (dx, *rets, None, None, None, None)

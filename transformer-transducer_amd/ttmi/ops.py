@@ -162,7 +162,7 @@ def attn_fwd(x, p, mask, prec, p_drop=0.0, seed=0):
     return y, ctx
 
 
-def attn_bwd(dy, x, p, ctx, prec, grads, p_drop=0.0, seed=0):
+def attn_bwd(dy, x, p, ctx, prec, grads, p_drop=0.0, seed=0, mask=None):
     """grads: dict of ZERO-INITIALISED (or running) f32 buffers, accumulated into."""
     B, L, d = x.shape
     K, H, Dh = p["r_emb"].shape
@@ -171,8 +171,8 @@ def attn_bwd(dy, x, p, ctx, prec, grads, p_drop=0.0, seed=0):
     ws = scratch(L_.ttmi_attn_ws_floats(c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh), c_int(prec)), x.device)
     dx = torch.empty_like(x)
     check(L_.ttmi_attn_bwd(_p(dy), _p(x), _p(p["qkv_w"]), _p(p["o_w"]), _p(p["ln_g"]), _p(p["r_emb"]), _p(p["r_bias"]),
-                           c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh), c_int(K), c_int(prec), c_float(p_drop), ctypes.c_uint(seed),
-                           _p(ctx), _p(ws), _p(dx),
+                           c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh), c_int(K), *(mask or MaskSpec()).args(), c_int(prec),
+                           c_float(p_drop), ctypes.c_uint(seed), _p(ctx), _p(ws), _p(dx),
                            _p(grads["qkv_w"]), _p(grads["o_w"]), _p(grads["ln_g"]), _p(grads["ln_b"]), _p(grads["r_emb"]),
                            _p(grads["r_w_bias"]), _p(grads["r_bias"]), _stream()), "ttmi_attn_bwd")
     return dx
@@ -329,3 +329,8 @@ def dropout_multipliers(n, p, seed, device):
     out = torch.empty_like(ones)
     check(lib().ttmi_dropout_apply(_p(ones), c_long(n), c_float(p), ctypes.c_uint(seed), _p(out), _stream()), "ttmi_dropout_apply")
     return out
+
+
+def set_option(key, value):
+    """process-wide A/B switches (key 0: 1 disables the fused attention kernels of the bf16 pipeline)"""
+    check(lib().ttmi_set_option(c_int(key), c_int(value)), "ttmi_set_option")
