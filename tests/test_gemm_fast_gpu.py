@@ -9,7 +9,8 @@ def _ints(shape, g):
     return torch.randint(-4, 5, shape, device="cuda", generator=g).to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 200, 192), (1000, 4334, 1024), (77, 130, 64)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 200, 192), (1000, 4334, 1024), (77, 130, 64),
+                                   (2048, 300, 192), (1500, 4334, 1024), (1024, 128, 64), (3001, 257, 72)])   # last four: 256x128 3-stage kernel
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
 def test_nt_exact_integers(M, N, K, cdt):
     """small-integer operands: products and sums are exact in f32, so any lane-map / swizzle error shows bit-for-bit"""
@@ -36,7 +37,8 @@ def test_nt_padded_pitch_and_random():
     assert float(Cb[:, N:].abs().max()) == 0
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 128, 256), (4334, 1024, 4096), (200, 72, 640), (130, 1000, 128)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 128, 256), (4334, 1024, 4096), (200, 72, 640), (130, 1000, 128),
+                                   (300, 130, 4100), (512, 512, 8192)])                                       # K >= 4096: 256x128 3-stage kernel
 def test_tn_exact_integers(M, N, K):
     from ttmi import ops
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
@@ -55,3 +57,21 @@ def test_rejects_unsupported_shapes():
     A = torch.zeros(64, 100, device="cuda", dtype=torch.bfloat16)     # K not a multiple of 64
     with pytest.raises(ValueError):
         ops.gemm_nt_bf16(A, A, torch.zeros(64, 64, device="cuda"))
+
+
+def test_both_kernel_generations_agree():
+    """ttmi_set_option(1, v): every kernel generation gives the identical (exact) result"""
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(9)
+    A, B = _ints((4096, 512), g), _ints((640, 512), g)
+    At, Bt = _ints((8192, 520), g), _ints((8192, 264), g)
+    want_nt, want_tn = A.float() @ B.float().t(), At[:, :512].float().t() @ Bt[:, :260].float()
+    for v in (1, 2, 3, 4):
+        ops.set_option(1, v)
+        C = torch.zeros(4096, 640, device="cuda")
+        ops.gemm_nt_bf16(A, B, C)
+        assert torch.equal(C, want_nt), v
+        D = torch.zeros(512, 260, device="cuda")
+        ops.gemm_tn_bf16(At[:, :512], Bt[:, :260], D, accumulate=True)
+        assert torch.equal(D, want_tn), v
+    ops.set_option(1, 4)

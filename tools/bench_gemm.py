@@ -22,6 +22,13 @@ def timeit(fn, n=5):
 
 
 def main():
+    for ver in [int(v) for v in os.environ.get("GEMM_VERSIONS", "1,2,3,4").split(",")]:
+        ops.set_option(1, ver)
+        print("---- throughput-GEMM version", ver, flush=True)
+        run()
+
+
+def run():
     M, V, Vp, J = 32 * 500 * 51, 4334, 4352, 1024
     g = torch.Generator(device="cuda").manual_seed(0)
     H = torch.randn(M, J, device="cuda", generator=g).to(torch.bfloat16)

@@ -25,3 +25,4 @@ inline int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, 
 // C[M,N] (f32) (+)= A[K,M]^T . B[K,N]; with accumulate != 0 (or internal split-K) the result is ADDED atomically to C
 int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
                  hipStream_t st);
+void gemm_fast_set_version(int v);   // kernel generation for A/B runs, see gemm_fast.hip (default 4)

@@ -610,10 +610,12 @@ int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float*
     return TTMI_OK;
 }
 
-// process-wide switches for A/B measurements.  key 0: 1 = disable the fused attention kernels (bf16 pipeline only)
+// process-wide switches for A/B measurements.  key 0: 1 = disable the fused attention kernels (bf16 pipeline only);
+// key 1: throughput-GEMM generation (1 = 128x128 two-stage only, 2 = 256x128 three-stage where the shape allows)
 int ttmi_set_option(int key, int value) {
-    TTMI_REQUIRE(key == 0, "set_option: unknown key %d", key);
-    g_disable_fused_attention = value;
+    TTMI_REQUIRE(key == 0 || key == 1, "set_option: unknown key %d", key);
+    if (key == 0) g_disable_fused_attention = value;
+    else gemm_fast_set_version(value);
     return TTMI_OK;
 }
 
