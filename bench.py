@@ -165,6 +165,11 @@ def main():
         k_ms = float(np.mean([m for m in probe_ms if m > 0])) if probe_ms else float("nan")
         peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
         ach = flop_launch / (k_ms * 1e-3) / 1e12
+        traffic = None          # HBM-side bytes of one launch from the committed PMC passes (only valid for the default workload)
+        pmc = os.path.join(ROOT, "profiles", "pmc_joint_projection.json")
+        if os.path.exists(pmc) and (B, T, U) == (32, 500, 50) and args.precision == "bf16":
+            j = json.load(open(pmc))
+            traffic = (2.0 * j["fetch_size_kb"] + j["write_size_kb"]) * 1024.0
         out = {
             "metric": "utterances/sec (fwd+bwd) on 80-d fbank T=%d U=%d" % (T, U), "value": round(utt_s, 3), "unit": "utt/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
@@ -174,9 +179,9 @@ def main():
                                    "(48.2M params), T=%d U=%d, batch %d/GPU, dropout 0.1, SGD momentum + clip 200" % (T, U, B),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
             "model_tflops": round(flops_per_utt(cfg, T, U1) * utt_s / 1e12, 2),
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel (joint vocabulary projection, M=%d N=%d K=%d)" % (B * T * U1, V, J),
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel (joint vocabulary projection, M=%d N=%d K=%d)" % (B * T * U1, V, J),
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                         "traffic": None, "kernel_ms": round(k_ms, 4)},
+                         "traffic": traffic, "kernel_ms": round(k_ms, 4)},
             "final_loss": round(float(last), 4),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -42,6 +42,7 @@ struct FP {
     long lda, ldb, ldc;
     int tiles_m, tiles_n, splitk, ksteps;   // ksteps per split
     int atomic;
+    int gm;                                 // TN: tiles per co-resident group along M
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
@@ -216,9 +217,26 @@ __global__ __launch_bounds__(NTH, NBUF == 1 ? 4 : 2) void gemm_tn_bf16_kernel(co
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int ks = blockIdx.y;
-    int tm, tn;
-    tile_of(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+    // Workgroups are dispatched round-robin over the 8 XCDs, so ids equal mod 8 share an L2.  With splitk a multiple of 8,
+    // ks = id % splitk puts ONE K-range on each XCD: its workgroups stream the same rows of A and B (wgrad: tiny output,
+    // huge K), instead of every XCD re-streaming most of both operands for its share of output tiles (PMC: 33 -> GB fetched).
+    int ks, tm, tn;
+    if (p.splitk % 8 == 0) {
+        const int tid_flat = blockIdx.x / p.splitk;
+        ks = blockIdx.x % p.splitk;
+        // an XCD holds 32 CUs x 4 (NBUF 1) or 2 (NBUF 2) workgroups: make one co-resident wave of tiles GM tall x tiles_n wide
+        const int GM = p.gm;
+        const int per_group = GM * p.tiles_n;
+        const int group = tid_flat / per_group, in = tid_flat % per_group;
+        const int first = group * GM;
+        const int gsz = min(p.tiles_m - first, GM);
+        tm = first + in % gsz;
+        tn = in / gsz;
+    } else {
+        const int ntile = p.tiles_m * p.tiles_n;
+        ks = blockIdx.x / ntile;
+        tile_of(blockIdx.x % ntile, ntile, p.tiles_m, p.tiles_n, tm, tn);
+    }
     const int bm = tm * TM, bn = tn * TN_;
 
     // staging: one wave-instruction = 4 k-rows x 256 B.  wave w, instruction j: k-row kr = (4w + j) * 4 + (lane >> 4),
@@ -505,8 +523,8 @@ __global__ __launch_bounds__(NTH2, 1) void gemm_tn_bf16_v2_kernel(const FP p) {
 }
 
 // ttmi_set_option(1, v) - A/B measurements: 1 = 128x128 double-buffered, 2 = 256x128 three-stage ring (8 waves),
-// 3 = v1 + software-pipelined fragment reads, 4 (default) = NT: single 32 KiB buffer, 4 workgroups per CU, pipelined
-// fragments (+15 % at the joint shapes); TN stays double-buffered (5 = TN single-buffered too, slower)
+// 3 = v1 + software-pipelined fragment reads, 4 (default) = single 32 KiB buffer, 4 workgroups per CU, pipelined
+// fragments (NT +15 % at the joint shapes; TN +8 % once each XCD owns a K-range)
 int g_gemm_fast_version = 4;
 
 template <typename K>
@@ -534,7 +552,7 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     FP p;
     p.A = A; p.B = B; p.C = C; p.bias = epi.bias; p.addend = epi.addend; p.mask = epi.mask; p.relu = epi.relu; p.scale = epi.scale; p.drop = epi.drop;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    p.tiles_m = cdiv(M, TM); p.tiles_n = cdiv(N, TN_); p.splitk = 1; p.ksteps = cdiv(K, TK); p.atomic = 0;
+    p.tiles_m = cdiv(M, TM); p.tiles_n = cdiv(N, TN_); p.splitk = 1; p.ksteps = cdiv(K, TK); p.atomic = 0; p.gm = GROUP_M;
     if (g_gemm_fast_version == 2 && M >= 1024 && N >= 128) {
         p.tiles_m = cdiv(M, T2M);
         const long nwg2 = (long)p.tiles_m * p.tiles_n;
@@ -590,18 +608,20 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
         if (splitk > ksteps_total / 4) splitk = ksteps_total / 4;
         if (splitk < 1) splitk = 1;
     }
+    if (splitk >= 8) splitk = splitk / 8 * 8;      // one K-range per XCD (see the kernel)
     p.ksteps = cdiv(ksteps_total, splitk);         // the last split may be short; rows >= K are zero-filled
-    splitk = cdiv(ksteps_total, p.ksteps);
+    if (splitk < 8) splitk = cdiv(ksteps_total, p.ksteps);
     p.splitk = splitk;
     p.atomic = (splitk > 1 || accumulate) ? 1 : 0;
+    p.gm = GROUP_M;                                 // 8 x tiles_n co-resident tiles per K-range measured best (16: -7 %)
     if (v2) {
         if (int rc = enable_big_lds(gemm_tn_bf16_v2_kernel)) return rc;
         hipLaunchKernelGGL(gemm_tn_bf16_v2_kernel, dim3((unsigned)tiles, splitk), dim3(NTH2), 3 * STAGE2, st, p);
     } else {
-        if (g_gemm_fast_version == 5)       // measured slower than the double-buffered form (564 vs 583 TFLOP/s): kept for A/B only
-            hipLaunchKernelGGL(gemm_tn_bf16_kernel<1>, dim3((unsigned)tiles, splitk), dim3(NTH), 2 * TILE_B, st, p);
+        if (g_gemm_fast_version >= 4)
+            hipLaunchKernelGGL(gemm_tn_bf16_kernel<1>, dim3((unsigned)(tiles * splitk)), dim3(NTH), 2 * TILE_B, st, p);
         else
-            hipLaunchKernelGGL(gemm_tn_bf16_kernel<2>, dim3((unsigned)tiles, splitk), dim3(NTH), 4 * TILE_B, st, p);
+            hipLaunchKernelGGL(gemm_tn_bf16_kernel<2>, dim3((unsigned)(tiles * splitk)), dim3(NTH), 4 * TILE_B, st, p);
     }
     TTMI_LAUNCH_CHECK("gemm_tn_bf16_kernel");
     return TTMI_OK;
