@@ -66,7 +66,7 @@ def test_both_kernel_generations_agree():
     A, B = _ints((4096, 512), g), _ints((640, 512), g)
     At, Bt = _ints((8192, 520), g), _ints((8192, 264), g)
     want_nt, want_tn = A.float() @ B.float().t(), At[:, :512].float().t() @ Bt[:, :260].float()
-    for v in (1, 2, 3, 4):
+    for v in (1, 2, 3, 4, 6):
         ops.set_option(1, v)
         C = torch.zeros(4096, 640, device="cuda")
         ops.gemm_nt_bf16(A, B, C)

@@ -15,7 +15,14 @@ struct FlashParams {
     // backward only
     const bf16_t* dO = nullptr;
     float* delta = nullptr;       // [B*H, L] scratch
-    float* dS = nullptr;          // same addressing as bd
+    float* dS = nullptr;          // (unused by the kernels since the bf16 outputs below exist; kept for A/B)
+    // dS is emitted twice in bf16 with 16-byte aligned rows (pitch ldp, multiple of 8):
+    //   dS16[z][i][j]            -> content-term dgrad  dq = dS k
+    //   dG16[z][r][c-1], (r, c) = divmod((i+1) L + j, L+1), c >= 1  -> position-term grads (dq += dG E, dE, dc);
+    //   this is _rel_shift's adjoint written straight into an aligned [L][ldp] matrix (row 0 is pre-zeroed by the caller)
+    bf16_t* dS16 = nullptr;
+    bf16_t* dG16 = nullptr;
+    long ldp = 0, slab16 = 0;
     float* dK = nullptr;          // f32 [B*L, ld_dkv] (+ h*Dh)
     float* dV = nullptr;
     long ld_dkv = 0;
@@ -24,6 +31,7 @@ struct FlashParams {
     int mask_kind = 0, mask_left = 0, mask_right = 0;
     const unsigned char* mask = nullptr;
     long mask_sb = 0, mask_si = 0;
+    int debug = 0;                // measurement only (ttmi_set_option(2, bits)): 1 = skip the bias read, 2 = skip the dS write
 };
 
 bool flash_supported(int Dh, long ld_qu, long ld_kv, long ld_o);

@@ -58,6 +58,30 @@ __device__ __forceinline__ void stage_rows(char* lds, const bf16_t* g, long ld, 
     }
 }
 
+// register-staged variant: issue the global loads of the NEXT tile early, write them to LDS after the barrier that
+// retires the current tile (T14 split).  NPT = 16-byte chunks per thread.
+template <int DH, int NROWS>
+struct RowStage {
+    using T = Tile<DH>;
+    static constexpr int NPT = (NROWS * T::NCH + 255) / 256;
+    uint4 v[NPT];
+    __device__ __forceinline__ void load(const bf16_t* g, long ld, int r0, int rmax, int tid) {
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const int c = tid + 256 * k;
+            const int row = min(c / T::NCH, NROWS - 1), ch = c % T::NCH;
+            v[k] = *reinterpret_cast<const uint4*>(g + (long)min(r0 + row, rmax) * ld + ch * 8);
+        }
+    }
+    __device__ __forceinline__ void store(char* lds, int tid) const {
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+            const int c = tid + 256 * k;
+            if (c < NROWS * T::NCH) *reinterpret_cast<uint4*>(lds + T::off(c / T::NCH, c % T::NCH)) = v[k];
+        }
+    }
+};
+
 __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int base) {
     bf16x8 r;
 #pragma unroll
@@ -105,58 +129,86 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashParams p) {
     const bf16_t* kbase = p.k + (long)b * L * p.ld_kv + h * DH;
     const bf16_t* vbase = p.v + (long)b * L * p.ld_kv + h * DH;
 
-    for (int j0 = 0; j0 < L; j0 += 64) {
-        __syncthreads();
-        stage_rows<DH>(ktile, kbase, p.ld_kv, j0, L - 1, 64, tid);
-        stage_rows<DH>(vtile, vbase, p.ld_kv, j0, L - 1, 64, tid);
-        __syncthreads();
+    // bias of one 32-key sub-tile for this lane's query: keys jb + 4 hh + 8 g + (0..3), g = 0..3  ->  4 float4 when aligned
+    const bool bvec = (L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.bd) & 15) == 0) && (p.slab % 4 == 0);
+    auto load_bias = [&](int jb, float (&bv)[16]) {
+        if (p.debug & 1) {
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int jb = j0 + 32 * sub;
-            if (jb >= L) break;                                   // block-uniform
-            f32x16 s;
+            for (int r = 0; r < 16; ++r) bv[r] = 0.f;
+            return;
+        }
+        if (bvec && jb + 32 <= L) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ktile + T::off(32 * sub + (lane & 31), 2 * ks + hh));
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 t = *reinterpret_cast<const float4*>(bd_row + jb + 4 * hh + 8 * g4);
+                bv[4 * g4] = t.x; bv[4 * g4 + 1] = t.y; bv[4 * g4 + 2] = t.z; bv[4 * g4 + 3] = t.w;
             }
-            float pmax = NEGBIG;
+        } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                float v = NEGBIG;
-                if (j < L && !is_masked(p, b, ic, j)) v = (s[r] + bd_row[j]) * p.scale;
-                s[r] = v;
-                pmax = fmaxf(pmax, v);
-            }
-            pmax = fmaxf(pmax, __shfl_xor(pmax, 32, 64));
-            const float mn = fmaxf(m, pmax);
-            const float alpha = __expf(m - mn);
-            float psum = 0.f;
+            for (int r = 0; r < 16; ++r) bv[r] = bd_row[min(jb + (r & 3) + 8 * (r >> 2) + 4 * hh, L - 1)];
+        }
+    };
+    auto sub_step = [&](int jb, int sub, float (&bcur)[16], float (&bnxt)[16]) {
+        if (jb + 32 < L) load_bias(jb + 32, bnxt);            // prefetch the next sub-tile's bias
+        f32x16 s;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pr = s[r] > 0.5f * NEGBIG ? __expf(s[r] - mn) : 0.f;
-                s[r] = pr;
-                psum += pr;
-            }
-            l = l * alpha + psum;
-            m = mn;
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ktile + T::off(32 * sub + (lane & 31), 2 * ks + hh));
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+        }
+        float pmax = NEGBIG;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        for (int r = 0; r < 16; ++r) {
+            const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            float v = NEGBIG;
+            if (j < L && !is_masked(p, b, ic, j)) v = (s[r] + bcur[r]) * p.scale;
+            s[r] = v;
+            pmax = fmaxf(pmax, v);
+        }
+        pmax = fmaxf(pmax, __shfl_xor(pmax, 32, 64));
+        const float mn = fmaxf(m, pmax);
+        const float alpha = __expf(m - mn);
+        float psum = 0.f;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 pb = pack8(s, 8 * s2);
+        for (int r = 0; r < 16; ++r) {
+            const float pr = s[r] > 0.5f * NEGBIG ? __expf(s[r] - mn) : 0.f;
+            s[r] = pr;
+            psum += pr;
+        }
+        l = l * alpha + psum;
+        m = mn;
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    const bf16x8 vf = tr_frag<DH>(vtile, 32 * sub + 16 * s2, 32 * dt, lane);
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o[dt], 0, 0, 0);
-                }
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pb = pack8(s, 8 * s2);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16x8 vf = tr_frag<DH>(vtile, 32 * sub + 16 * s2, 32 * dt, lane);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o[dt], 0, 0, 0);
             }
         }
+    };
+    RowStage<DH, 64> stK, stV;
+    stK.load(kbase, p.ld_kv, 0, L - 1, tid);
+    stV.load(vbase, p.ld_kv, 0, L - 1, tid);
+    float bias0[16], bias1[16];
+    load_bias(0, bias0);
+    for (int j0 = 0; j0 < L; j0 += 64) {
+        __syncthreads();                                            // everyone is done reading the previous tile
+        stK.store(ktile, tid);
+        stV.store(vtile, tid);
+        __syncthreads();
+        if (j0 + 64 < L) {                                          // next tile's loads fly under this tile's MFMAs
+            stK.load(kbase, p.ld_kv, j0 + 64, L - 1, tid);
+            stV.load(vbase, p.ld_kv, j0 + 64, L - 1, tid);
+        }
+        sub_step(j0, 0, bias0, bias1);
+        if (j0 + 32 < L) sub_step(j0 + 32, 1, bias1, bias0);
     }
     l += __shfl_xor(l, 32, 64);
     if (i < L) {
@@ -178,7 +230,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashParams p) {
 
 // ------------------------------------------------------------------ backward (dK, dV, dS)
 template <int DH>
-__global__ __launch_bounds__(256) void flash_bwd_kernel(const FlashParams p) {
+__global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) {
     using T = Tile<DH>;
     constexpr int KS = DH / 16, DT = DH / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -208,18 +260,37 @@ __global__ __launch_bounds__(256) void flash_bwd_kernel(const FlashParams p) {
     const bf16_t* qbase = p.qu + (long)b * L * p.ld_qu + h * DH;
     const bf16_t* dobase = p.dO + (long)b * L * p.ld_o + h * DH;
     const float* bd = p.bd + (long)z * p.slab;
-    float* dsout = p.dS + (long)z * p.slab;
+    bf16_t* ds16 = p.dS16 + (long)z * p.slab16;
+    bf16_t* dg16 = p.dG16 + (long)z * p.slab16;
 
-    for (int i0 = 0; i0 < L; i0 += 32) {
+    // bias of one 32-query tile for this lane's key: rows i0 + q_r, column jc (coalesced across the lanes)
+    auto load_bias = [&](int i0, float (&bv)[16]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = min(i0 + (r & 3) + 8 * (r >> 2) + 4 * hh, L - 1);
+            bv[r] = (p.debug & 1) ? 0.f : bd[(long)i * L + jc];
+        }
+    };
+    RowStage<DH, 32> stQ, stO;
+    stQ.load(qbase, p.ld_qu, 0, L - 1, tid);
+    stO.load(dobase, p.ld_o, 0, L - 1, tid);
+    float biasA[16], biasB[16];
+    load_bias(0, biasA);
+    auto step = [&](int i0, float (&bcur)[16], float (&bnext)[16]) {
         __syncthreads();
-        stage_rows<DH>(qtile, qbase, p.ld_qu, i0, L - 1, 32, tid);
-        stage_rows<DH>(dotile, dobase, p.ld_o, i0, L - 1, 32, tid);
+        stQ.store(qtile, tid);
+        stO.store(dotile, tid);
         if (tid < 32) {
             const int ii = min(i0 + tid, L - 1);
             lse_s[tid] = p.lse[(long)z * L + ii];
             del_s[tid] = p.delta[(long)z * L + ii];
         }
         __syncthreads();
+        if (i0 + 32 < L) {                                          // next tile's operands and bias fly under this tile's MFMAs
+            stQ.load(qbase, p.ld_qu, i0 + 32, L - 1, tid);
+            stO.load(dobase, p.ld_o, i0 + 32, L - 1, tid);
+            load_bias(i0 + 32, bnext);
+        }
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -238,11 +309,17 @@ __global__ __launch_bounds__(256) void flash_bwd_kernel(const FlashParams p) {
             float pr = 0.f, ds = 0.f;
             if (inb) {
                 if (!is_masked(p, b, i, j)) {
-                    const float sc = (s[r] + bd[(long)i * L + j]) * p.scale;
+                    const float sc = (s[r] + bcur[r]) * p.scale;
                     pr = __expf(sc - lse_s[q]);
                     ds = pr * (dp[r] - del_s[q]) * p.scale;
                 }
-                dsout[(long)i * L + j] = ds;
+                if (!(p.debug & 2)) {
+                    const bf16_t d16 = f32_to_bf16(ds);
+                    ds16[(long)i * p.ldp + j] = d16;
+                    // (r, c) = divmod((i+1) L + j, L+1) without the division: j <= i -> (i, L-i+j); j > i -> (i+1, j-i-1)
+                    const int rr = j <= i ? i : i + 1, cc = j <= i ? L - i + j : j - i - 1;
+                    if (cc > 0) dg16[(long)rr * p.ldp + cc - 1] = d16;
+                }
             }
             s[r] = pr;
             dp[r] = ds;
@@ -259,6 +336,10 @@ __global__ __launch_bounds__(256) void flash_bwd_kernel(const FlashParams p) {
                 dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_qu, dsb, dk[dt], 0, 0, 0);
             }
         }
+    };
+    for (int i0 = 0; i0 < L; i0 += 64) {
+        step(i0, biasA, biasB);
+        if (i0 + 32 < L) step(i0 + 32, biasB, biasA);
     }
     if (kvalid) {
         float* dkrow = p.dK + ((long)b * L + j) * p.ld_dkv + h * DH;
@@ -318,7 +399,8 @@ int flash_attn_fwd(const FlashParams& p, hipStream_t st) {
 }
 
 int flash_attn_bwd(const FlashParams& p, hipStream_t st) {
-    TTMI_REQUIRE(p.qu && p.k && p.v && p.bd && p.o && p.lse && p.dO && p.delta && p.dS && p.dK && p.dV, "flash_attn_bwd: null pointer");
+    TTMI_REQUIRE(p.qu && p.k && p.v && p.bd && p.o && p.lse && p.dO && p.delta && p.dS16 && p.dG16 && p.dK && p.dV, "flash_attn_bwd: null pointer");
+    TTMI_REQUIRE(p.ldp >= p.L && p.ldp % 8 == 0 && (long)p.L * (p.L + 1) < (1L << 31), "flash_attn_bwd: bad dS pitch / L too large");
     TTMI_REQUIRE(flash_supported(p.Dh, p.ld_qu, p.ld_kv, p.ld_o) && p.ld_dkv % 4 == 0, "flash_attn_bwd: unsupported head dim %d / pitches", p.Dh);
     TTMI_REQUIRE(aligned16(p.qu) && aligned16(p.k) && aligned16(p.v) && aligned16(p.dO) && aligned16(p.dK) && aligned16(p.dV), "flash_attn_bwd: alignment");
     const long n = (long)p.B * p.L * p.H;

@@ -522,6 +522,123 @@ __global__ __launch_bounds__(NTH2, 1) void gemm_tn_bf16_v2_kernel(const FP p) {
     store_tile<float>(acc, p, reinterpret_cast<float*>(p.C), bm, bn, wm, wn, lane, false);
 }
 
+// =====================================================================================================================
+// v6: 256x256x64 tile, 8 waves (4x2), each wave 64x128 (2x4 MFMA tiles, 128 accumulator registers), double-buffered
+// 2 x 64 KiB LDS, one workgroup per CU.  Half the L2->LDS bytes per FLOP of the 128x128 kernels.
+// =====================================================================================================================
+constexpr int T6 = 256, NTH6 = 512, STAGE6 = 2 * 256 * 64 * 2;   // 64 KiB per stage (A 32 KiB | B 32 KiB)
+
+template <typename TC>
+__global__ __launch_bounds__(NTH6, 1) void gemm_nt_bf16_v6_kernel(const FP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                       // 4 x 2 waves, wave tile 64 (M) x 128 (N)
+    int tm, tn;
+    tile_of(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+    const int bm = tm * T6, bn = tn * T6;
+
+    const bf16_t* asrc[4];
+    const bf16_t* bsrc[4];
+    int chunkk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int R = (wave * 4 + j) * 8 + (lane >> 3);            // 0..255
+        chunkk[j] = (lane & 7) ^ ((R >> 1) & 7);
+        asrc[j] = p.A + (long)min(bm + R, p.M - 1) * p.lda + chunkk[j] * 8;
+        bsrc[j] = p.B + (long)min(bn + R, p.N - 1) * p.ldb + chunkk[j] * 8;
+    }
+    const void* zsrc = &g_zero16;
+    auto issue = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE6;
+        const bool tail = (kt + 1) * TK > p.K;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool zero = tail && (kt * TK + chunkk[j] * 8 >= p.K);
+            glds16(zero ? zsrc : (const void*)(asrc[j] + (long)kt * TK), base + (wave * 4 + j) * 1024);
+            glds16(zero ? zsrc : (const void*)(bsrc[j] + (long)kt * TK), base + STAGE6 / 2 + (wave * 4 + j) * 1024);
+        }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (p.K + TK - 1) / TK;
+    const int sw = (lane >> 1) & 7;
+    const int rowa = wm * 64 + (lane & 31), rowb = wn * 128 + (lane & 31);
+    auto frag = [&](const char* la, const char* lb, int kk, bf16x8 (&af)[2], bf16x8 (&bf)[4]) {
+        const int c = ((kk * 2 + (lane >> 5)) ^ sw) << 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(la + (rowa + i * 32) * 128 + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(lb + (rowb + j * 32) * 128 + c);
+    };
+    auto mma = [&](const bf16x8 (&af)[2], const bf16x8 (&bf)[4]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    };
+    issue(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) issue(cur ^ 1, kt + 1);
+        const char* la = smem + cur * STAGE6;
+        const char* lb = la + STAGE6 / 2;
+        bf16x8 a0[2], b0[4], a1[2], b1[4];
+        frag(la, lb, 0, a0, b0);
+        frag(la, lb, 1, a1, b1);
+        __builtin_amdgcn_s_setprio(1);
+        mma(a0, b0);
+        __builtin_amdgcn_s_setprio(0);
+        frag(la, lb, 2, a0, b0);
+        __builtin_amdgcn_s_setprio(1);
+        mma(a1, b1);
+        __builtin_amdgcn_s_setprio(0);
+        frag(la, lb, 3, a1, b1);
+        __builtin_amdgcn_s_setprio(1);
+        mma(a0, b0);
+        mma(a1, b1);
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+    }
+    // epilogue (wave tile 64 x 128)
+    TC* C = reinterpret_cast<TC*>(p.C);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = bn + wn * 128 + j * 32 + (lane & 31);
+            if (n >= p.N) continue;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bv;
+                const long ci = (long)m * p.ldc + n;
+                if (p.addend) v += p.addend[ci];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.mask) v = bf16_to_f32(p.mask[ci]) > 0.f ? v * p.scale : 0.f;
+                v *= drop_mult(p.drop, (unsigned long long)ci);
+                if constexpr (sizeof(TC) == 4) reinterpret_cast<float*>(C)[ci] = v;
+                else reinterpret_cast<bf16_t*>(C)[ci] = f32_to_bf16(v);
+            }
+        }
+}
+
+template <typename K>
+int enable_lds(K kernel, int bytes) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) { ttmi_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    return TTMI_OK;
+}
+
 // ttmi_set_option(1, v) - A/B measurements: 1 = 128x128 double-buffered, 2 = 256x128 three-stage ring (8 waves),
 // 3 = v1 + software-pipelined fragment reads, 4 (default) = single 32 KiB buffer, 4 workgroups per CU, pipelined
 // fragments (NT +15 % at the joint shapes; TN +8 % once each XCD owns a K-range)
@@ -553,6 +670,22 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     p.A = A; p.B = B; p.C = C; p.bias = epi.bias; p.addend = epi.addend; p.mask = epi.mask; p.relu = epi.relu; p.scale = epi.scale; p.drop = epi.drop;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.tiles_m = cdiv(M, TM); p.tiles_n = cdiv(N, TN_); p.splitk = 1; p.ksteps = cdiv(K, TK); p.atomic = 0; p.gm = GROUP_M;
+    // 256x256 tiles pay off when the K loop is long enough to amortise the un-overlapped epilogue of a one-workgroup-per-CU
+    // kernel and there are enough tiles to fill the chip (joint dgrad: K = 4352 -> 954 vs 880 TFLOP/s; short-K forward: worse)
+    const bool big = (g_gemm_fast_version == 6) || (g_gemm_fast_version == 4 && K >= 2048 && (long)cdiv(M, T6) * cdiv(N, T6) >= 1024);
+    if (big && M >= 1024 && N >= 256) {
+        p.tiles_m = cdiv(M, T6); p.tiles_n = cdiv(N, T6);
+        const long nwg6 = (long)p.tiles_m * p.tiles_n;
+        if (c_dtype == 0) {
+            if (int rc = enable_lds(gemm_nt_bf16_v6_kernel<float>, 2 * STAGE6)) return rc;
+            hipLaunchKernelGGL(gemm_nt_bf16_v6_kernel<float>, dim3((unsigned)nwg6), dim3(NTH6), 2 * STAGE6, st, p);
+        } else {
+            if (int rc = enable_lds(gemm_nt_bf16_v6_kernel<bf16_t>, 2 * STAGE6)) return rc;
+            hipLaunchKernelGGL(gemm_nt_bf16_v6_kernel<bf16_t>, dim3((unsigned)nwg6), dim3(NTH6), 2 * STAGE6, st, p);
+        }
+        TTMI_LAUNCH_CHECK("gemm_nt_bf16_v6_kernel");
+        return TTMI_OK;
+    }
     if (g_gemm_fast_version == 2 && M >= 1024 && N >= 128) {
         p.tiles_m = cdiv(M, T2M);
         const long nwg2 = (long)p.tiles_m * p.tiles_n;

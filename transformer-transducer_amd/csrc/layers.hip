@@ -114,7 +114,8 @@ struct AttnCtx {   // saved for backward.  act = f32 (parity) or bf16 (fast)
 struct AttnWs {   // scratch (union of forward and backward needs)
     float *E, *cT, *dE, *dcT, *a, *dS, *dqkv, *delta;
     void* dO;
-    bf16_t *x16, *wqkv16, *wo16, *dqkv16, *dres16;
+    bf16_t *x16, *wqkv16, *wo16, *dqkv16, *dres16, *dS16, *dG16;
+    long ldp, slab16;
     AttnWs(Bump& b, const AttnDims& a, bool fast) {
         E = b.take<float>((size_t)a.L * a.HD);
         cT = b.take<float>((size_t)a.H * a.L);
@@ -125,8 +126,12 @@ struct AttnWs {   // scratch (union of forward and backward needs)
         dqkv = b.take<float>(a.BL * a.W3);
         delta = b.take<float>((size_t)a.B * a.H * a.L);
         dO = b.take<char>(a.BL * a.HD * (fast ? 2 : 4));
-        x16 = wqkv16 = wo16 = dqkv16 = dres16 = nullptr;
+        x16 = wqkv16 = wo16 = dqkv16 = dres16 = dS16 = dG16 = nullptr;
+        ldp = (a.L + 7) / 8 * 8;
+        slab16 = (long)a.L * ldp;
         if (fast) {
+            dS16 = b.take<bf16_t>((size_t)a.B * a.H * slab16);
+            dG16 = b.take<bf16_t>((size_t)a.B * a.H * slab16);
             x16 = b.take<bf16_t>(a.BL * a.d);
             wqkv16 = b.take<bf16_t>(a.W3 * a.d);
             wo16 = b.take<bf16_t>(a.HD * a.d);
@@ -137,6 +142,7 @@ struct AttnWs {   // scratch (union of forward and backward needs)
 };
 
 // fused (flash-style) attention core: bf16 pipeline, head dim 32/64
+int g_flash_debug = 0;
 int g_disable_fused_attention = 0;      // ttmi_set_option(0, 1): A/B switch back to the unfused GEMM + softmax chain
 inline bool attn_fused(bool fast, const AttnDims& a) {
     return fast && !g_disable_fused_attention && flash_supported(a.Dh, a.HD, a.W3, a.HD);
@@ -155,6 +161,7 @@ FlashParams flash_params(const AttnDims& a, const AttnCtx& c, float scale, int m
     f.B = a.B; f.L = a.L; f.H = a.H; f.Dh = a.Dh; f.scale = scale;
     f.mask_kind = mask_kind; f.mask_left = mask_left; f.mask_right = mask_right;
     f.mask = mask; f.mask_sb = mask_sb; f.mask_si = mask_si;
+    f.debug = g_flash_debug;
     return f;
 }
 
@@ -300,17 +307,19 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
         CK(ttmi_launch_gemm(mk(da, o_w, static_cast<float*>(w.dO), (int)a.BL, (int)a.HD, d, d, a.HD, a.HD, NN_, prec), st));
     }
     const bool fused = attn_fused(fast, a);
-    // first L floats of each dS slab lie outside the pitch-L view but inside dG's row 0: zero them
-    CK(memset2d(w.dS, (size_t)a.slab * 4, (size_t)L * 4, (size_t)B * H, st));
     if (fused) {
-        // 4-6 + 9 fused: recompute P, dS = P (dP - delta) scale -> slab, dK and dV straight into dqkv
+        // 4-6 + 9 fused: recompute P, dS = P (dP - delta) scale, dK and dV straight into dqkv.  dS leaves the kernel twice in
+        // bf16 with aligned rows: [i][j] for the content dgrad and the shifted [r][c-1] form (= dG) for the position grads.
+        CK(memset2d(w.dG16, (size_t)w.slab16 * 2, (size_t)w.ldp * 2, (size_t)B * H, st));       // dG row 0 is (almost) never written
         FlashParams f = flash_params(a, c, scale, mask_kind, mask_left, mask_right, mask, mask_sb, mask_si);
         f.dO = static_cast<const bf16_t*>(w.dO);
         f.delta = w.delta;
-        f.dS = w.dS + L;
+        f.dS16 = w.dS16; f.dG16 = w.dG16; f.ldp = w.ldp; f.slab16 = w.slab16;
         f.dK = w.dqkv + a.HD; f.dV = w.dqkv + 2 * a.HD; f.ld_dkv = a.W3;
         CK(flash_attn_bwd(f, st));
     } else {
+        // first L floats of each dS slab lie outside the pitch-L view but inside dG's row 0: zero them
+        CK(memset2d(w.dS, (size_t)a.slab * 4, (size_t)L * 4, (size_t)B * H, st));
         // 4. dP = dO V^T through the pitch-L view of the dS slab (first L floats of each slab are outside the view)
         {
             GemmDesc g = mkx(w.dO, adt, eoff(c.qkv, adt, 2 * a.HD), adt, w.dS + L, DT_F32, L, L, Dh, a.HD, a.W3, L, NT_, prec);
@@ -328,8 +337,10 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
     }
     // 7. dq(content) = dS K -> dqkv[q]
     {
-        GemmDesc g = mkx(w.dS + L, DT_F32, eoff(c.qkv, adt, a.HD), adt, w.dqkv, DT_F32, L, Dh, L, L, a.W3, a.W3, NN_, prec);
-        batch_bh(g, a, H * a.slab, a.slab, L * a.W3, Dh, L * a.W3, Dh);
+        GemmDesc g = fused ? mkx(w.dS16, DT_BF16, eoff(c.qkv, adt, a.HD), adt, w.dqkv, DT_F32, L, Dh, L, w.ldp, a.W3, a.W3, NN_, prec)
+                           : mkx(w.dS + L, DT_F32, eoff(c.qkv, adt, a.HD), adt, w.dqkv, DT_F32, L, Dh, L, L, a.W3, a.W3, NN_, prec);
+        if (fused) batch_bh(g, a, H * w.slab16, w.slab16, L * a.W3, Dh, L * a.W3, Dh);
+        else batch_bh(g, a, H * a.slab, a.slab, L * a.W3, Dh, L * a.W3, Dh);
         CK(ttmi_launch_gemm(g, st));
     }
     // 8. g r_w_bias += column sums of dq(content)
@@ -345,19 +356,24 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
     // 10. dq += dG E   (dG = the same slab read with pitch L+1, column offset 1)
     CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st));
     {
-        GemmDesc g = mkx(w.dS + 1, DT_F32, w.E, DT_F32, w.dqkv, DT_F32, L, Dh, L, L + 1, a.HD, a.W3, NN_, prec);
-        batch_bh(g, a, H * a.slab, a.slab, 0, Dh, L * a.W3, Dh);
+        GemmDesc g = fused ? mkx(w.dG16, DT_BF16, w.E, DT_F32, w.dqkv, DT_F32, L, Dh, L, w.ldp, a.HD, a.W3, NN_, prec)
+                           : mkx(w.dS + 1, DT_F32, w.E, DT_F32, w.dqkv, DT_F32, L, Dh, L, L + 1, a.HD, a.W3, NN_, prec);
+        if (fused) batch_bh(g, a, H * w.slab16, w.slab16, 0, Dh, L * a.W3, Dh);
+        else batch_bh(g, a, H * a.slab, a.slab, 0, Dh, L * a.W3, Dh);
         g.beta = 1.f;
         CK(ttmi_launch_gemm(g, st));
     }
     // 11. dE[p,h,:] = sum_b dG^T q ; 12. dc[h][p] = sum_b colsum(dG) ; 13. fold onto the K-row tables
     CK(fill_zero(w.dE, sizeof(float) * ((size_t)L * a.HD + (size_t)H * L), st));
     {
-        GemmDesc g = mkx(w.dS + 1, DT_F32, c.qkv, adt, w.dE, DT_F32, L, Dh, L, L + 1, a.W3, a.HD, TN_ | GEMM_ATOMIC, prec);
-        batch_bh(g, a, H * a.slab, a.slab, L * a.W3, Dh, 0, Dh);
+        GemmDesc g = fused ? mkx(w.dG16, DT_BF16, c.qkv, adt, w.dE, DT_F32, L, Dh, L, w.ldp, a.W3, a.HD, TN_ | GEMM_ATOMIC, prec)
+                           : mkx(w.dS + 1, DT_F32, c.qkv, adt, w.dE, DT_F32, L, Dh, L, L + 1, a.W3, a.HD, TN_ | GEMM_ATOMIC, prec);
+        if (fused) batch_bh(g, a, H * w.slab16, w.slab16, L * a.W3, Dh, 0, Dh);
+        else batch_bh(g, a, H * a.slab, a.slab, L * a.W3, Dh, 0, Dh);
         CK(ttmi_launch_gemm(g, st));
     }
-    CK(colsum(w.dS + 1, L + 1, L, L, B, H, H * a.slab, a.slab, 0, L, w.dcT, st));
+    if (fused) CK(colsum_bf16(w.dG16, w.ldp, L, L, w.dcT, st, B, H, H * w.slab16, w.slab16, L));
+    else CK(colsum(w.dS + 1, L + 1, L, L, B, H, H * a.slab, a.slab, 0, L, w.dcT, st));
     CK(relpos_scatter(w.dE, w.dcT, K, L, H, Dh, g_r_emb, g_r_bias, st));
     // 14. gWqkv += dqkv^T x ; 15. dx += dqkv Wqkv
     if (fast) {
@@ -613,9 +629,10 @@ int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float*
 // process-wide switches for A/B measurements.  key 0: 1 = disable the fused attention kernels (bf16 pipeline only);
 // key 1: throughput-GEMM generation (1 = 128x128 two-stage only, 2 = 256x128 three-stage where the shape allows)
 int ttmi_set_option(int key, int value) {
-    TTMI_REQUIRE(key == 0 || key == 1, "set_option: unknown key %d", key);
+    TTMI_REQUIRE(key >= 0 && key <= 2, "set_option: unknown key %d", key);
     if (key == 0) g_disable_fused_attention = value;
-    else gemm_fast_set_version(value);
+    else if (key == 1) gemm_fast_set_version(value);
+    else g_flash_debug = value;
     return TTMI_OK;
 }
 

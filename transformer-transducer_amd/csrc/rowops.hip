@@ -375,8 +375,10 @@ __global__ __launch_bounds__(256) void transpose_convert_kernel(const float* __r
 }
 
 constexpr int CSB_ROWS = 256;
-__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ in, long ld, long rows, int cols,
-                                                          float* __restrict__ out) {
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ in_, long ld, long rows, int cols,
+                                                          float* __restrict__ out_, int nz2, long si1, long si2, long so2) {
+    const bf16_t* in = in_ + (blockIdx.z / nz2) * si1 + (blockIdx.z % nz2) * si2;
+    float* out = out_ + (blockIdx.z % nz2) * so2;
     // each thread owns 2 adjacent columns (one 4-byte load); a wave covers 128 columns = 256 B per row
     const int c = (blockIdx.x * 256 + threadIdx.x) * 2;
     if (c >= cols) return;
@@ -538,11 +540,12 @@ int transpose_convert_bf16(const float* src, int R, int C, bf16_t* dst, long ldd
     return TTMI_OK;
 }
 
-int colsum_bf16(const bf16_t* in, long ld, long rows, int cols, float* out, hipStream_t st) {
+int colsum_bf16(const bf16_t* in, long ld, long rows, int cols, float* out, hipStream_t st, int nz1, int nz2, long si1, long si2,
+                long so2) {
     TTMI_REQUIRE(in && out && rows > 0 && cols > 0 && (reinterpret_cast<uintptr_t>(in) & 3) == 0, "colsum_bf16: bad arguments");
-    dim3 grid(cdiv(cols, 512), cdiv(rows, CSB_ROWS));
-    TTMI_REQUIRE(grid.y <= 65535, "colsum_bf16: too many rows");
-    hipLaunchKernelGGL(colsum_bf16_kernel, grid, dim3(256), 0, st, in, ld, rows, cols, out);
+    dim3 grid(cdiv(cols, 512), cdiv(rows, CSB_ROWS), nz1 * nz2);
+    TTMI_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "colsum_bf16: grid too large");
+    hipLaunchKernelGGL(colsum_bf16_kernel, grid, dim3(256), 0, st, in, ld, rows, cols, out, nz2, si1, si2, so2);
     TTMI_LAUNCH_CHECK("colsum_bf16_kernel");
     return TTMI_OK;
 }
