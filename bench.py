@@ -36,7 +36,8 @@ def c2_config(n_enc=12, n_dec=6):
     return AttrDict(dict(type="transducer",
                          enc=dict(side, type="attention", max_input_length=410, left_context=10, right_context=2, n_layer=n_enc),
                          dec=dict(side, type="attention", max_target_length=42, n_layer=n_dec),
-                         joint=dict(input_size=1024, inner_size=1024), vocab_size=4334, share_weight=False, dropout=0.1))
+                         joint=dict(input_size=1024, inner_size=1024), vocab_size=4334, share_weight=False, dropout=0.1,
+                         overlap_label_encoder=True))
 
 
 def flops_per_utt(cfg, T, U1):

@@ -182,3 +182,28 @@ def test_vs_oracle_odd_shapes():
     assert rel_err(x.grad.cpu().numpy(), want["dinputs"]) < TOL
     for name, p in model.named_parameters():
         assert rel_err(p.grad.cpu().numpy(), want["grads"][name]) < TOL, name
+
+
+def test_label_encoder_on_side_stream_same_results(gm):
+    """config.overlap_label_encoder runs the label encoder on a side stream: logits and gradients are unchanged"""
+    z, sd, model = gm
+    from ttmi import ops
+    from warprnnt_pytorch import RNNTLoss
+    tgt = torch.tensor(z["targets"], device="cuda")
+    res = []
+    for overlap in (False, True):
+        model.config["overlap_label_encoder"] = overlap
+        model.zero_grad()
+        inp = torch.tensor(z["inputs"], device="cuda", requires_grad=True)
+        logits = model(inp, tgt)
+        loss = RNNTLoss(check_lengths=False)(logits, tgt.int(), torch.tensor(z["full/act_lens"], device="cuda"),
+                                             torch.tensor(z["full/label_lens"], device="cuda"))
+        loss.backward()
+        ops.join_side_streams()
+        torch.cuda.synchronize()
+        res.append((logits.detach().clone(), inp.grad.clone(), {n: p.grad.clone() for n, p in model.named_parameters()}))
+    model.config["overlap_label_encoder"] = False
+    assert torch.equal(res[0][0], res[1][0])
+    assert rel_err(res[1][1].cpu().numpy(), res[0][1].cpu().numpy()) < 1e-6
+    for n in res[0][2]:
+        assert rel_err(res[1][2][n].cpu().numpy(), res[0][2][n].cpu().numpy()) < 1e-5, n

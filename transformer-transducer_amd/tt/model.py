@@ -76,8 +76,19 @@ class Transducer(nn.Module):
     def forward(self, inputs, targets):
         targets = F.pad(targets, pad=[1, 0, 0, 0], value=0)                 # leading blank / SOS
         audio_mask = self._audio_mask(inputs)
-        enc_state = self.encoder(inputs, audio_mask)
-        dec_state = self.decoder(targets, MaskSpec(1))                      # == look_ahead_mask(targets)[:, :, None]
+        if self.config.overlap_label_encoder and inputs.is_cuda:
+            # the label encoder (tiny, launch-latency-bound kernels) is independent of the audio encoder until the joint:
+            # run it on a side stream so both fill the chip together; autograd replays the same streams in backward
+            main, side = torch.cuda.current_stream(inputs.device), ops.side_stream(inputs.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                dec_state = self.decoder(targets, MaskSpec(1))
+            enc_state = self.encoder(inputs, audio_mask)
+            main.wait_stream(side)
+            dec_state.record_stream(main)
+        else:
+            enc_state = self.encoder(inputs, audio_mask)
+            dec_state = self.decoder(targets, MaskSpec(1))                  # == look_ahead_mask(targets)[:, :, None]
         return self.joint(enc_state, dec_state)
 
     def _audio_mask(self, inputs):

@@ -132,12 +132,13 @@ def _f32(n, device):
 
 
 _ws_cache = {}
+_side_streams = {}
 
 
 def scratch(n, device):
-    """One grow-only scratch arena per device: sub-layer drivers run back to back on one stream, so the
-    scratch of one call is dead when the next call starts."""
-    key = (device.type, device.index)
+    """One grow-only scratch arena per (device, stream): sub-layer drivers run back to back on a stream, so the
+    scratch of one call is dead when the next call on that stream starts; concurrent streams get their own arena."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     t = _ws_cache.get(key)
     if t is None or t.numel() < n:
         t = _ws_cache[key] = _f32(max(int(n), 1 << 20), device)
@@ -334,3 +335,19 @@ def dropout_multipliers(n, p, seed, device):
 def set_option(key, value):
     """process-wide A/B switches (key 0: 1 disables the fused attention kernels of the bf16 pipeline)"""
     check(lib().ttmi_set_option(c_int(key), c_int(value)), "ttmi_set_option")
+
+
+def side_stream(device):
+    """the per-device side stream on which the label encoder runs concurrently with the audio encoder"""
+    key = (device.type, device.index)
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def join_side_streams():
+    """make the current stream wait for everything queued on the side streams (call before consuming gradients that
+    backward nodes running on a side stream wrote in place, e.g. before the optimiser step / gradient all-reduce)"""
+    for st in _side_streams.values():
+        torch.cuda.current_stream(st.device).wait_stream(st)

@@ -90,6 +90,7 @@ class GradSync:
     def finish(self):
         """Wait for outstanding bucket reductions (stream-level wait, no host block on the GPU work);
         reduces any bucket whose hooks did not all fire (parameters unused in this step)."""
+        ops.join_side_streams()             # label-encoder gradients are written in place on the side stream
         if self.world == 1:
             return
         for b, (s, e, n) in enumerate(self.buckets):
@@ -114,6 +115,7 @@ class FusedOptimizer:
     def step(self):
         """gradients in flat.grad are SUMS over ranks; the 1/world averaging is folded into the update."""
         self.global_step += 1
+        ops.join_side_streams()
         scale = 1.0 / self.world
         self.normsq.zero_()
         ops.sumsq(self.flat.grad, self.normsq)
