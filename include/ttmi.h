@@ -118,7 +118,7 @@ int ttmi_gemm(const void* A, const void* B, void* C, const float* bias, const fl
 int ttmi_gemm_nt_bf16(const void* A, const void* B, void* C, int c_dtype, const float* bias, int M, int N, int K, long lda,
                       long ldb, long ldc, void* stream);
 int ttmi_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
-                      void* stream);
+                      float* colsum_a /* nullable: colsum_a[m] += sum_k A[k][m] */, void* stream);
 int ttmi_set_option(int key, int value);   /* key 0: 1 = disable the fused attention kernels (A/B measurements) */
 int ttmi_dropout_apply(const float* in, long n, float p, unsigned seed, float* out, void* stream);
 int ttmi_probe_arm(int slot);

@@ -48,8 +48,10 @@ def test_tn_exact_integers(M, N, K):
     ops.gemm_tn_bf16(Ab[:, :M], Bb[:, :N], C, accumulate=True)
     want = Ab[:, :M].float().t() @ Bb[:, :N].float()
     assert torch.equal(C, want)
-    ops.gemm_tn_bf16(Ab[:, :M], Bb[:, :N], C, accumulate=True)       # accumulates
+    cs = torch.full((M,), 3.0, device="cuda")
+    ops.gemm_tn_bf16(Ab[:, :M], Bb[:, :N], C, accumulate=True, colsum_a=cs)       # accumulates; fused column sums of A
     assert torch.equal(C, 2 * want)
+    assert torch.equal(cs, 3.0 + Ab[:, :M].float().sum(0))
 
 
 def test_rejects_unsupported_shapes():

@@ -23,6 +23,8 @@ inline int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, 
     return gemm_nt_bf16(A, B, C, c_dtype, e, M, N, K, lda, ldb, ldc, st);
 }
 // C[M,N] (f32) (+)= A[K,M]^T . B[K,N]; with accumulate != 0 (or internal split-K) the result is ADDED atomically to C
+// colsum_a (nullable, f32 [M], accumulated atomically): column sums of A over K - the bias gradient that belongs to this wgrad -
+// taken from the LDS tiles the kernel stages anyway (no extra pass over A)
 int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
-                 hipStream_t st);
+                 hipStream_t st, float* colsum_a = nullptr);
 void gemm_fast_set_version(int v);   // kernel generation for A/B runs, see gemm_fast.hip (default 4)

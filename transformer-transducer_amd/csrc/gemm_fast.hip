@@ -43,6 +43,7 @@ struct FP {
     int tiles_m, tiles_n, splitk, ksteps;   // ksteps per split
     int atomic;
     int gm;                                 // TN: tiles per co-resident group along M
+    float* colsum;                          // TN: if set, colsum[m] += sum_k A[k][m] (taken from the LDS tiles by the tn == 0 blocks)
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
@@ -318,6 +319,19 @@ __global__ __launch_bounds__(NTH, NBUF == 1 ? 4 : 2) void gemm_tn_bf16_kernel(co
         mma(a1, b1);
         __builtin_amdgcn_s_setprio(0);
     };
+    // optional column sums of A (the bias gradient of a Linear whose wgrad this is): tn == 0 blocks only, from LDS
+    const bool do_cs = p.colsum != nullptr && tn == 0;
+    float cs = 0.f;
+    auto colsum_tile = [&](const char* la) {
+        if (do_cs) {
+            const int col = tid & 127, r0 = (tid >> 7) * 32;
+#pragma unroll 8
+            for (int rr = 0; rr < 32; ++rr) {
+                const int kr = r0 + rr;
+                cs += bf16_to_f32(*reinterpret_cast<const bf16_t*>(la + kr * 256 + ((((col >> 3) ^ ((kr & 3) << 2))) << 4) + (col & 7) * 2));
+            }
+        }
+    };
     if constexpr (NBUF == 2) {
         issue(0, 0);
         __syncthreads();
@@ -326,6 +340,7 @@ __global__ __launch_bounds__(NTH, NBUF == 1 ? 4 : 2) void gemm_tn_bf16_kernel(co
             if (kt + 1 < nk) issue(cur ^ 1, kt + 1);
             const char* la = smem + cur * 2 * TILE_B;
             compute(la, la + TILE_B);
+            colsum_tile(la);
             __syncthreads();
         }
     } else {
@@ -333,9 +348,11 @@ __global__ __launch_bounds__(NTH, NBUF == 1 ? 4 : 2) void gemm_tn_bf16_kernel(co
             issue(0, kt);
             __syncthreads();
             compute(smem, smem + TILE_B);
+            colsum_tile(smem);
             __syncthreads();
         }
     }
+    if (do_cs && bm + (tid & 127) < p.M) atomicAdd(p.colsum + bm + (tid & 127), cs);
     store_tile<float>(acc, p, reinterpret_cast<float*>(p.C), bm, bn, wm, wn, lane, false);
 }
 
@@ -669,7 +686,7 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     FP p;
     p.A = A; p.B = B; p.C = C; p.bias = epi.bias; p.addend = epi.addend; p.mask = epi.mask; p.relu = epi.relu; p.scale = epi.scale; p.drop = epi.drop;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    p.tiles_m = cdiv(M, TM); p.tiles_n = cdiv(N, TN_); p.splitk = 1; p.ksteps = cdiv(K, TK); p.atomic = 0; p.gm = GROUP_M;
+    p.tiles_m = cdiv(M, TM); p.tiles_n = cdiv(N, TN_); p.splitk = 1; p.ksteps = cdiv(K, TK); p.atomic = 0; p.gm = GROUP_M; p.colsum = nullptr;
     // 256x256 tiles pay off when the K loop is long enough to amortise the un-overlapped epilogue of a one-workgroup-per-CU
     // kernel and there are enough tiles to fill the chip (joint dgrad: K = 4352 -> 954 vs 880 TFLOP/s; short-K forward: worse)
     const bool big = (g_gemm_fast_version == 6) || (g_gemm_fast_version == 4 && K >= 2048 && (long)cdiv(M, T6) * cdiv(N, T6) >= 1024);
@@ -725,13 +742,14 @@ bool gemm_fast_tn_ok(const void* A, const void* B, const void* C, int M, int N, 
 
 // C (f32) += A^T B by atomics when splitk > 1 or accumulate != 0, else C = A^T B
 int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
-                 hipStream_t st) {
+                 hipStream_t st, float* colsum_a) {
     TTMI_REQUIRE(gemm_fast_tn_ok(A, B, C, M, N, K, lda, ldb), "gemm_tn_bf16: shape/alignment not supported (M=%d N=%d K=%d)", M,
                  N, K);
     FP p;
     p.A = A; p.B = B; p.C = C; p.bias = nullptr; p.addend = nullptr; p.mask = nullptr; p.relu = 0; p.scale = 1.f; p.drop = DropSpec();
+    p.colsum = colsum_a;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    const bool v2 = g_gemm_fast_version == 2 && M >= 256 && N >= 128 && K >= 4096;
+    const bool v2 = g_gemm_fast_version == 2 && M >= 256 && N >= 128 && K >= 4096 && !colsum_a;
     p.tiles_m = cdiv(M, v2 ? T2M : TM); p.tiles_n = cdiv(N, TN_);
     const long tiles = (long)p.tiles_m * p.tiles_n;
     const int ksteps_total = cdiv(K, TK);
@@ -772,8 +790,8 @@ int ttmi_gemm_nt_bf16(const void* A, const void* B, void* C, int c_dtype, const 
                         static_cast<hipStream_t>(stream));
 }
 int ttmi_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
-                      void* stream) {
+                      float* colsum_a, void* stream) {
     return gemm_tn_bf16(static_cast<const bf16_t*>(A), static_cast<const bf16_t*>(B), C, M, N, K, lda, ldb, ldc, accumulate,
-                        static_cast<hipStream_t>(stream));
+                        static_cast<hipStream_t>(stream), colsum_a);
 }
 }

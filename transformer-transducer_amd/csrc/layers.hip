@@ -508,8 +508,7 @@ int ttmi_ffn_bwd(const float* dz, const float* y, const float* w1, const float* 
         NtEpilogue e;
         e.mask = a1; e.scale = inv_keep;                   // a1 is stored post-dropout: a1 > 0 <=> ReLU active AND kept
         CK(gemm_nt_bf16(w.dres16, w.w2_16, da1, 1, e, (int)rows, Di, d, d, d, Di, st));
-        CK(colsum_bf16(da1, Di, rows, Di, g_b1, st));
-        CK(gemm_tn_bf16(da1, h, g_w1, Di, d, (int)rows, Di, d, d, 1, st));
+        CK(gemm_tn_bf16(da1, h, g_w1, Di, d, (int)rows, Di, d, d, 1, st, g_b1));   // g_b1 = column sums of da1, fused
         CK(transpose_convert_bf16(w1, Di, d, w.w1_16, Di, st));                                // W1^T [d, Di]
         CK(gemm_nt_bf16(da1, w.w1_16, w.dh, 0, nullptr, (int)rows, d, Di, Di, Di, d, st));
     } else {
@@ -611,8 +610,7 @@ int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float*
         bf16_t* dH16 = reinterpret_cast<bf16_t*>(ws);
         bf16_t* WpT16 = reinterpret_cast<bf16_t*>(dPD + 2 * al4((size_t)B * U1 * J));    // [J, ldg], zero beyond V
         TTMI_REQUIRE((size_t)J * ldg <= 2 * al4((size_t)J * (((size_t)V + 63) / 64 * 64)), "joint_bwd: pitch %ld too large for the workspace", ldg);
-        CK(colsum_bf16(dZ, ldg, M, V, g_bp, st));
-        CK(gemm_tn_bf16(dZ, H16, g_wp, V, J, M, ldg, J, J, 1, st));
+        CK(gemm_tn_bf16(dZ, H16, g_wp, V, J, M, ldg, J, J, 1, st, g_bp));      // g_bp = column sums of dZ, fused
         CK(transpose_convert_bf16(wp, V, J, WpT16, ldg, st));
         CK(gemm_nt_bf16(dZ, WpT16, dH16, 1, nullptr, M, J, (int)ldg, ldg, ldg, J, st));
         CK(fill_zero(dPD, sizeof(float) * (size_t)B * U1 * J, st));

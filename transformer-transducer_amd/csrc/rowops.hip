@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void transpose_convert_kernel(const float* __r
     }
 }
 
-constexpr int CSB_ROWS = 256;
+constexpr int CSB_ROWS = 128;
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ in_, long ld, long rows, int cols,
                                                           float* __restrict__ out_, int nz2, long si1, long si2, long so2) {
     const bf16_t* in = in_ + (blockIdx.z / nz2) * si1 + (blockIdx.z % nz2) * si2;
@@ -386,7 +386,23 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
     const long r1 = r0 + CSB_ROWS < rows ? r0 + CSB_ROWS : rows;
     float a0 = 0.f, a1 = 0.f;
     const bool pair = (c + 1 < cols) && ((ld & 1) == 0);
-    for (long r = r0; r < r1; ++r) {
+    long r = r0;
+    if (pair) {                                    // 4 independent loads in flight per thread
+        float b0 = 0.f, b1 = 0.f, c0 = 0.f, c1 = 0.f, d0 = 0.f, d1 = 0.f;
+        for (; r + 3 < r1; r += 4) {
+            const uint32_t w0 = *reinterpret_cast<const uint32_t*>(in + r * ld + c);
+            const uint32_t w1 = *reinterpret_cast<const uint32_t*>(in + (r + 1) * ld + c);
+            const uint32_t w2 = *reinterpret_cast<const uint32_t*>(in + (r + 2) * ld + c);
+            const uint32_t w3 = *reinterpret_cast<const uint32_t*>(in + (r + 3) * ld + c);
+            a0 += __uint_as_float(w0 << 16); a1 += __uint_as_float(w0 & 0xffff0000u);
+            b0 += __uint_as_float(w1 << 16); b1 += __uint_as_float(w1 & 0xffff0000u);
+            c0 += __uint_as_float(w2 << 16); c1 += __uint_as_float(w2 & 0xffff0000u);
+            d0 += __uint_as_float(w3 << 16); d1 += __uint_as_float(w3 & 0xffff0000u);
+        }
+        a0 += (b0 + c0) + d0;
+        a1 += (b1 + c1) + d1;
+    }
+    for (; r < r1; ++r) {
         if (pair) {
             const uint32_t w = *reinterpret_cast<const uint32_t*>(in + r * ld + c);
             a0 += __uint_as_float(w << 16);

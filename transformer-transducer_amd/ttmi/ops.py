@@ -315,12 +315,12 @@ def gemm_nt_bf16(A, B, C, bias=None):
     return C
 
 
-def gemm_tn_bf16(A, B, C, accumulate=False):
-    """C[M,N] (f32) (+)= A[K,M]^T @ B[K,N].  A, B bf16 row-major."""
+def gemm_tn_bf16(A, B, C, accumulate=False, colsum_a=None):
+    """C[M,N] (f32) (+)= A[K,M]^T @ B[K,N].  A, B bf16 row-major.  colsum_a (f32 [M]) += column sums of A."""
     K, M = A.shape
     N = B.shape[1]
     check(lib().ttmi_gemm_tn_bf16(_p(A), _p(B), _p(C), c_int(M), c_int(N), c_int(K), c_long(A.stride(0)), c_long(B.stride(0)),
-                                  c_long(C.stride(0)), c_int(1 if accumulate else 0), _stream()), "ttmi_gemm_tn_bf16")
+                                  c_long(C.stride(0)), c_int(1 if accumulate else 0), _p(colsum_a), _stream()), "ttmi_gemm_tn_bf16")
     return C
 
 
