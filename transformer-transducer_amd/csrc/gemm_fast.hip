@@ -357,189 +357,6 @@ __global__ __launch_bounds__(NTH, NBUF == 1 ? 4 : 2) void gemm_tn_bf16_kernel(co
 }
 
 // =====================================================================================================================
-// v2: 256x128x64 tile, 8 waves (4x2, each 64x64), 3-stage LDS ring (144 KiB, one workgroup per CU), two K-steps of
-// global_load_lds in flight across a raw s_barrier with a COUNTED s_waitcnt vmcnt (never 0 inside the loop).
-// Order per K-step: wait for this stage (leave the next stage's 6 loads per wave in flight) -> barrier (every wave's
-// loads of this stage have landed AND every wave has finished reading the stage that is about to be overwritten)
-// -> issue stage kt+2 -> MFMAs of stage kt.
-// =====================================================================================================================
-constexpr int T2M = 256, T2N = 128, NTH2 = 512;
-constexpr int STAGE_A = 256 * 64 * 2, STAGE_B = 128 * 64 * 2, STAGE2 = STAGE_A + STAGE_B;   // 32 + 16 KiB
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-}
-
-template <typename TC>
-__global__ __launch_bounds__(NTH2, 1) void gemm_nt_bf16_v2_kernel(const FP p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    int tm, tn;
-    tile_of(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
-    const int bm = tm * T2M, bn = tn * T2N;
-
-    const bf16_t* asrc[4];
-    const bf16_t* bsrc[2];
-    int achunk[4], bchunk[2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int R = (wave * 4 + j) * 8 + (lane >> 3);
-        achunk[j] = (lane & 7) ^ ((R >> 1) & 7);
-        asrc[j] = p.A + (long)min(bm + R, p.M - 1) * p.lda + achunk[j] * 8;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int R = (wave * 2 + j) * 8 + (lane >> 3);
-        bchunk[j] = (lane & 7) ^ ((R >> 1) & 7);
-        bsrc[j] = p.B + (long)min(bn + R, p.N - 1) * p.ldb + bchunk[j] * 8;
-    }
-    const void* zsrc = &g_zero16;
-    auto issue = [&](int buf, int kt) {
-        char* base = smem + buf * STAGE2;
-        const bool tail = (kt + 1) * TK > p.K;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool zero = tail && (kt * TK + achunk[j] * 8 >= p.K);
-            glds16(zero ? zsrc : (const void*)(asrc[j] + (long)kt * TK), base + (wave * 4 + j) * 1024);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const bool zero = tail && (kt * TK + bchunk[j] * 8 >= p.K);
-            glds16(zero ? zsrc : (const void*)(bsrc[j] + (long)kt * TK), base + STAGE_A + (wave * 2 + j) * 1024);
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nk = (p.K + TK - 1) / TK;
-    const int sw = (lane >> 1) & 7;
-    const int rowa = wm * 64 + (lane & 31), rowb = wn * 64 + (lane & 31);
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) wait_vmcnt<6>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) issue(buf >= 1 ? buf - 1 : 2, kt + 2);         // (buf + 2) % 3
-        const char* la = smem + buf * STAGE2;
-        const char* lb = la + STAGE_A;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int c = ((kk * 2 + (lane >> 5)) ^ sw) << 4;
-            bf16x8 af[2], bf[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8*>(la + (rowa + i * 32) * 128 + c);
-                bf[i] = *reinterpret_cast<const bf16x8*>(lb + (rowb + i * 32) * 128 + c);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        buf = buf == 2 ? 0 : buf + 1;
-    }
-    store_tile<TC>(acc, p, reinterpret_cast<TC*>(p.C), bm, bn, wm, wn, lane, p.bias != nullptr);
-}
-
-__global__ __launch_bounds__(NTH2, 1) void gemm_tn_bf16_v2_kernel(const FP p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int ks = blockIdx.y;
-    int tm, tn;
-    tile_of(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
-    const int bm = tm * T2M, bn = tn * T2N;
-    const long k0 = (long)ks * p.ksteps * TK;
-
-    // A stage: 64 k-rows x 512 B (256 columns): one wave-instruction = 2 rows; B stage: 64 k-rows x 256 B: 4 rows
-    const bf16_t* asrc[4];
-    const bf16_t* bsrc[2];
-    int akr[4], bkr[2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        akr[j] = (wave * 4 + j) * 2 + (lane >> 5);
-        const int chunk = (lane & 31) ^ ((akr[j] & 3) << 2);
-        asrc[j] = p.A + (k0 + akr[j]) * p.lda + min((long)bm + chunk * 8, p.lda - 8);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        bkr[j] = (wave * 2 + j) * 4 + (lane >> 4);
-        const int chunk = (lane & 15) ^ ((bkr[j] & 3) << 2);
-        bsrc[j] = p.B + (k0 + bkr[j]) * p.ldb + min((long)bn + chunk * 8, p.ldb - 8);
-    }
-    const void* zsrc = &g_zero16;
-    auto issue = [&](int buf, int kt) {
-        char* base = smem + buf * STAGE2;
-        const long kbase = k0 + (long)kt * TK;
-        const bool tail = kbase + TK > p.K;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool zero = tail && (kbase + akr[j] >= p.K);
-            glds16(zero ? zsrc : (const void*)(asrc[j] + (long)kt * TK * p.lda), base + (wave * 4 + j) * 1024);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const bool zero = tail && (kbase + bkr[j] >= p.K);
-            glds16(zero ? zsrc : (const void*)(bsrc[j] + (long)kt * TK * p.ldb), base + STAGE_A + (wave * 2 + j) * 1024);
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, h = g >> 1;
-    const int cola = wm * 64 + 16 * (g & 1) + 4 * pp, colb = wn * 64 + 16 * (g & 1) + 4 * pp;
-    const int nk = min(p.ksteps, (int)((p.K - k0 + TK - 1) / TK));
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) wait_vmcnt<6>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) issue(buf >= 1 ? buf - 1 : 2, kt + 2);
-        const char* la = smem + buf * STAGE2;
-        const char* lb = la + STAGE_A;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 af[2], bf[2];
-            const int kr = kk * 16 + 8 * h + q;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int ca = cola + i * 32, cb = colb + i * 32;
-                const int oa = (((ca >> 3) ^ (q << 2)) << 4) + (ca & 7) * 2, ob = (((cb >> 3) ^ (q << 2)) << 4) + (cb & 7) * 2;
-                const bf16x4 a0 = ds_read_tr16(la + kr * 512 + oa), a1 = ds_read_tr16(la + (kr + 4) * 512 + oa);
-                const bf16x4 b0 = ds_read_tr16(lb + kr * 256 + ob), b1 = ds_read_tr16(lb + (kr + 4) * 256 + ob);
-                af[i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-                bf[i] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        buf = buf == 2 ? 0 : buf + 1;
-    }
-    store_tile<float>(acc, p, reinterpret_cast<float*>(p.C), bm, bn, wm, wn, lane, false);
-}
-
-// =====================================================================================================================
 // v6: 256x256x64 tile, 8 waves (4x2), each wave 64x128 (2x4 MFMA tiles, 128 accumulator registers), double-buffered
 // 2 x 64 KiB LDS, one workgroup per CU.  Half the L2->LDS bytes per FLOP of the 128x128 kernels.
 // =====================================================================================================================
@@ -656,21 +473,13 @@ int enable_lds(K kernel, int bytes) {
     return TTMI_OK;
 }
 
-// ttmi_set_option(1, v) - A/B measurements: 1 = 128x128 double-buffered, 2 = 256x128 three-stage ring (8 waves),
-// 3 = v1 + software-pipelined fragment reads, 4 (default) = single 32 KiB buffer, 4 workgroups per CU, pipelined
-// fragments (NT +15 % at the joint shapes; TN +8 % once each XCD owns a K-range)
+// ttmi_set_option(1, v) - A/B measurements: 1 = 128x128 double-buffered, 3 = 1 + software-pipelined fragment reads,
+// 4 (default) = single 32 KiB buffer, 4 workgroups per CU, pipelined fragments (NT +15 % at the joint shapes; TN +8 % once
+// each XCD owns a K-range) with the 256x256 kernel for long-K shapes, 6 = 256x256 wherever it fits.
+// Measured and dropped (same box, joint projection M=816000 N=4334 K=1024, v4 = 720 TFLOP/s): 256x128 3-stage ring with
+// counted vmcnt 621; persistent 256x256 with a 4-slice ring that never drains 668 (dgrad K=4352: 904 vs 938 for v6).
 int g_gemm_fast_version = 4;
 
-template <typename K>
-int enable_big_lds(K kernel) {
-    static bool done = false;     // per instantiation
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE2);
-        if (e != hipSuccess) { ttmi_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-        done = true;
-    }
-    return TTMI_OK;
-}
 
 }  // namespace
 
@@ -701,20 +510,6 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
             hipLaunchKernelGGL(gemm_nt_bf16_v6_kernel<bf16_t>, dim3((unsigned)nwg6), dim3(NTH6), 2 * STAGE6, st, p);
         }
         TTMI_LAUNCH_CHECK("gemm_nt_bf16_v6_kernel");
-        return TTMI_OK;
-    }
-    if (g_gemm_fast_version == 2 && M >= 1024 && N >= 128) {
-        p.tiles_m = cdiv(M, T2M);
-        const long nwg2 = (long)p.tiles_m * p.tiles_n;
-        TTMI_REQUIRE(nwg2 < (1L << 31), "gemm_nt_bf16: too many tiles");
-        if (c_dtype == 0) {
-            if (int rc = enable_big_lds(gemm_nt_bf16_v2_kernel<float>)) return rc;
-            hipLaunchKernelGGL(gemm_nt_bf16_v2_kernel<float>, dim3((unsigned)nwg2), dim3(NTH2), 3 * STAGE2, st, p);
-        } else {
-            if (int rc = enable_big_lds(gemm_nt_bf16_v2_kernel<bf16_t>)) return rc;
-            hipLaunchKernelGGL(gemm_nt_bf16_v2_kernel<bf16_t>, dim3((unsigned)nwg2), dim3(NTH2), 3 * STAGE2, st, p);
-        }
-        TTMI_LAUNCH_CHECK("gemm_nt_bf16_v2_kernel");
         return TTMI_OK;
     }
     const long nwg = (long)p.tiles_m * p.tiles_n;
@@ -749,13 +544,12 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
     p.A = A; p.B = B; p.C = C; p.bias = nullptr; p.addend = nullptr; p.mask = nullptr; p.relu = 0; p.scale = 1.f; p.drop = DropSpec();
     p.colsum = colsum_a;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    const bool v2 = g_gemm_fast_version == 2 && M >= 256 && N >= 128 && K >= 4096 && !colsum_a;
-    p.tiles_m = cdiv(M, v2 ? T2M : TM); p.tiles_n = cdiv(N, TN_);
+    p.tiles_m = cdiv(M, TM); p.tiles_n = cdiv(N, TN_);
     const long tiles = (long)p.tiles_m * p.tiles_n;
     const int ksteps_total = cdiv(K, TK);
     int splitk = 1;
-    if (tiles < (v2 ? 512 : 1024)) {
-        splitk = (int)(((v2 ? 1024 : 2048) + tiles - 1) / tiles);
+    if (tiles < 1024) {
+        splitk = (int)((2048 + tiles - 1) / tiles);
         if (splitk > ksteps_total / 4) splitk = ksteps_total / 4;
         if (splitk < 1) splitk = 1;
     }
@@ -765,15 +559,10 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
     p.splitk = splitk;
     p.atomic = (splitk > 1 || accumulate) ? 1 : 0;
     p.gm = GROUP_M;                                 // 8 x tiles_n co-resident tiles per K-range measured best (16: -7 %)
-    if (v2) {
-        if (int rc = enable_big_lds(gemm_tn_bf16_v2_kernel)) return rc;
-        hipLaunchKernelGGL(gemm_tn_bf16_v2_kernel, dim3((unsigned)tiles, splitk), dim3(NTH2), 3 * STAGE2, st, p);
-    } else {
         if (g_gemm_fast_version >= 4)
             hipLaunchKernelGGL(gemm_tn_bf16_kernel<1>, dim3((unsigned)(tiles * splitk)), dim3(NTH), 2 * TILE_B, st, p);
         else
             hipLaunchKernelGGL(gemm_tn_bf16_kernel<2>, dim3((unsigned)(tiles * splitk)), dim3(NTH), 4 * TILE_B, st, p);
-    }
     TTMI_LAUNCH_CHECK("gemm_tn_bf16_kernel");
     return TTMI_OK;
 }
