@@ -40,6 +40,19 @@ def c2_config(n_enc=12, n_dec=6):
                          overlap_label_encoder=True))
 
 
+def c4_config(streaming):
+    """config/joint_streaming.yaml model section (BASELINE configs[3]): 18 audio / 2 label layers, d_inner 2048, joint inner
+    2048, V=6485 (85.6 M params).  streaming: 'band' = context_mask(left=64,right=0), 'chunk' = 16-frame blocks + 64 left."""
+    from tt.utils import AttrDict
+    side = dict(d_inner=2048, n_head=8, d_model=512, d_head=64)
+    st = dict(left=64, right=0) if streaming == "band" else dict(chunk=16, left=64)
+    return AttrDict(dict(type="transducer",
+                         enc=dict(side, type="attention", max_input_length=410, left_context=10, right_context=2, n_layer=18),
+                         dec=dict(side, type="attention", max_target_length=42, n_layer=2),
+                         joint=dict(input_size=1024, inner_size=2048), vocab_size=6485, share_weight=False, dropout=0.1,
+                         overlap_label_encoder=True, streaming=st))
+
+
 def flops_per_utt(cfg, T, U1):
     def layer(L, c):
         d, H, Dh, Di = c["d_model"], c["n_head"], c["d_head"], c["d_inner"]
@@ -81,6 +94,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-utts", type=int, default=1)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI)")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c4-band", "c4-chunk", "c5"],
+                    help="c2 = BASELINE configs[1] (headline, default); c4-* = streaming model configs[3]; c5 = configs[4] "
+                         "long-utterance stress (T=2000 U=200 batch 8)")
     args = ap.parse_args()
     os.environ["TTMI_PRECISION"] = args.precision
 
@@ -103,7 +119,9 @@ def main():
     from ttmi.train import FlatModel, FusedOptimizer, GradSync
     from warprnnt_pytorch import RNNTLoss
 
-    cfg = c2_config()
+    if args.workload == "c5":
+        args.T, args.U, args.batch = 2000, 200, 8
+    cfg = c2_config() if args.workload in ("c2", "c5") else c4_config(args.workload.split("-")[1])
     torch.manual_seed(1)                                   # config/aishell.yaml:55 - same init on every rank
     model = Transducer(cfg).to(dev).train()
     flat = FlatModel(model)
@@ -168,7 +186,7 @@ def main():
         ach = flop_launch / (k_ms * 1e-3) / 1e12
         traffic = None          # HBM-side bytes of one launch from the committed PMC passes (only valid for the default workload)
         pmc = os.path.join(ROOT, "profiles", "pmc_joint_projection.json")
-        if os.path.exists(pmc) and (B, T, U) == (32, 500, 50) and args.precision == "bf16":
+        if os.path.exists(pmc) and args.workload == "c2" and (B, T, U) == (32, 500, 50) and args.precision == "bf16":
             j = json.load(open(pmc))
             traffic = (2.0 * j["fetch_size_kb"] + j["write_size_kb"]) * 1024.0
         out = {
@@ -176,8 +194,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: full T-T 12 audio / 6 label layers d_model=512 V=4334 "
-                                   "(48.2M params), T=%d U=%d, batch %d/GPU, dropout 0.1, SGD momentum + clip 200" % (T, U, B),
+            "config": {"workload": ("BASELINE configs[1]: full T-T 12 audio / 6 label layers d_model=512 V=4334 (48.2M params)"
+                                    if args.workload in ("c2", "c5") else
+                                    "BASELINE configs[3]: joint_streaming.yaml 18/2 layers V=6485 (85.6M params), %s mask"
+                                    % args.workload.split("-")[1]) +
+                                   ", T=%d U=%d, batch %d/GPU, dropout 0.1, SGD momentum + clip 200" % (T, U, B),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
             "model_tflops": round(flops_per_utt(cfg, T, U1) * utt_s / 1e12, 2),
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel (joint vocabulary projection, M=%d N=%d K=%d)" % (B * T * U1, V, J),

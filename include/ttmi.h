@@ -100,6 +100,10 @@ int ttmi_rnnt_loss_bwd(const void* logits, int dtype, long ldv, const int* label
                        int B, int T, int U1, int V, int blank, const void* workspace, const float* grad_out,
                        int grad_out_stride, float scale, void* grad, long ldg, void* stream);
 
+/* ---- greedy decoding support (Transducer.decode, tt/model.py:70-90): logits rows = consecutive frames against one label
+ * state; *out (device u64) = (first row whose argmax != blank) << 32 | symbol, or n << 32 if all rows are blank. */
+int ttmi_greedy_scan(const void* logits, int dtype, long ld, int n, int V, int blank, unsigned long long* out, void* stream);
+
 /* ---- training-step tail on flat f32 buffers: clip_grad_norm_ + optimizer.step (train.py:62-65, tt/optim.py:57-73)
  * normsq: device scalar holding sum(g^2) over ALL gradients (ttmi_sumsq accumulates into it); NULL = no clipping.
  * The effective gradient is g * grad_scale (1/world_size after a SUM all-reduce) clipped to max_norm. */

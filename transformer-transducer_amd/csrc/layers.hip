@@ -643,6 +643,12 @@ int ttmi_dropout_apply(const float* in, long n, float p, unsigned seed, float* o
     return dropout_apply(in, n, ds, out, nullptr, static_cast<hipStream_t>(stream));
 }
 
+// greedy decoding support (tt/model.py:76-83): rows = joint logits of consecutive frames against ONE label state; returns in
+// *out the first frame whose argmax is not blank and the symbol, so the host syncs once per emitted symbol, not per frame.
+int ttmi_greedy_scan(const void* logits, int dtype, long ld, int n, int V, int blank, unsigned long long* out, void* stream) {
+    return greedy_scan(logits, dtype, ld, n, V, blank, out, static_cast<hipStream_t>(stream));
+}
+
 // ------------------------------------------------------------------ embedding (tt/decoder.py:26,39)
 int ttmi_embed_fwd(const long* tokens, const float* W, long n, int d, int V, float* out, void* stream) {
     return embed_fwd(tokens, W, n, d, V, out, static_cast<hipStream_t>(stream));

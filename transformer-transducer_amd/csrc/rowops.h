@@ -55,3 +55,5 @@ int transpose_convert_bf16(const float* src, int R, int C, bf16_t* dst, long ldd
 // out[c] += sum_r in[r*ld + c] for a bf16 matrix (atomic; caller zeroes / accumulates)
 int colsum_bf16(const bf16_t* in, long ld, long rows, int cols, float* out, hipStream_t st, int nz1 = 1, int nz2 = 1, long si1 = 0,
                 long si2 = 0, long so2 = 0);   // batch z = z1*nz2+z2 reads in + z1*si1 + z2*si2, adds into out + z2*so2
+// out (device u64) = (first row whose argmax != blank) << 32 | that argmax, or n << 32 when every row is blank
+int greedy_scan(const void* logits, int dtype, long ld, int n, int V, int blank, unsigned long long* out, hipStream_t st);

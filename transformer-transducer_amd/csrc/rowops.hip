@@ -416,6 +416,32 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
     if (c + 1 < cols) atomicAdd(out + c + 1, a1);
 }
 
+// greedy scan: rows of logits (f32 or bf16, pitch ld); out[0] = first row whose argmax != blank (or n), out[1] = that argmax.
+// One wave per row computes the argmax (first maximal index, like torch.argmax); the rows' results go through a single
+// atomicMin on the packed (row << 32 | token) key, so one 8-byte D2H read tells the host where the next symbol is.
+template <typename TL>
+__global__ __launch_bounds__(256) void greedy_scan_kernel(const TL* __restrict__ logits, long ld, int n, int V, int blank,
+                                                          unsigned long long* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const TL* r = logits + (long)row * ld;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int v = lane; v < V; v += 64) {
+        float x;
+        if constexpr (sizeof(TL) == 4) x = r[v];
+        else x = bf16_to_f32(r[v]);
+        if (x > best) { best = x; bi = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0 && bi != blank) atomicMin(out, ((unsigned long long)row << 32) | (unsigned)bi);
+}
+
 }  // namespace
 
 int ln_fwd(const float* x, const float* res, const float* g, const float* b, long rows, int d, float eps, float* s_out,
@@ -578,5 +604,18 @@ int dropout_apply(const float* in, long n, DropSpec ds, float* out32, bf16_t* ou
     TTMI_REQUIRE(in && (out32 || out16) && n > 0, "dropout_apply: bad arguments");
     hipLaunchKernelGGL(dropout_apply_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, in, n, ds, out32, out16);
     TTMI_LAUNCH_CHECK("dropout_apply_kernel");
+    return TTMI_OK;
+}
+
+int greedy_scan(const void* logits, int dtype, long ld, int n, int V, int blank, unsigned long long* out, hipStream_t st) {
+    TTMI_REQUIRE(logits && out && n > 0 && V > 0 && ld >= V, "greedy_scan: bad arguments");
+    const unsigned long long none = ((unsigned long long)n << 32);
+    hipError_t e = hipMemcpyAsync(out, &none, 8, hipMemcpyHostToDevice, st);      // pageable 8-byte copy: staged immediately
+    if (e != hipSuccess) { ttmi_set_error("greedy_scan: %s", hipGetErrorString(e)); return (int)e; }
+    if (dtype == 0)
+        hipLaunchKernelGGL(greedy_scan_kernel<float>, dim3(cdiv(n, 4)), dim3(256), 0, st, static_cast<const float*>(logits), ld, n, V, blank, out);
+    else
+        hipLaunchKernelGGL(greedy_scan_kernel<bf16_t>, dim3(cdiv(n, 4)), dim3(256), 0, st, static_cast<const bf16_t*>(logits), ld, n, V, blank, out);
+    TTMI_LAUNCH_CHECK("greedy_scan_kernel");
     return TTMI_OK;
 }

@@ -103,17 +103,26 @@ class Transducer(nn.Module):
         return MaskSpec(2, left=int(s.get("left", 0)), right=int(s.get("right", 0)))
 
     @torch.no_grad()
-    def decode(self, enc_state, lengths):
-        """Greedy: <= 1 symbol per frame, label encoder re-run on the whole history WITHOUT look-ahead mask."""
+    def decode(self, enc_state, lengths, block=64):
+        """Greedy: <= 1 symbol per frame, label encoder re-run on the whole history WITHOUT look-ahead mask (tt/model.py:70-90).
+        Same token sequence as the reference's per-frame loop, but frames are scored `block` at a time against the current
+        label state and the first non-blank frame is found on the device (ttmi_greedy_scan): one host sync per emitted
+        symbol instead of one per frame."""
         token_list = [0]
         dev = enc_state.device
-        dec_state = self.decoder(torch.tensor([token_list], dtype=torch.long, device=dev))[:, -1, :]
-        for t in range(int(lengths)):
-            logits = self.joint(enc_state[t].view(-1), dec_state.view(-1))
-            pred = int(torch.argmax(logits, dim=0).item())                  # argmax(softmax(x)) == argmax(x)
-            if pred != 0:
-                token_list.append(pred)
-                dec_state = self.decoder(torch.tensor([token_list], dtype=torch.long, device=dev))[:, -1, :]
+        T = int(lengths)
+        dec_state = self.decoder(torch.tensor([token_list], dtype=torch.long, device=dev))[:, -1:, :]      # [1, 1, d]
+        t = 0
+        while t < T:
+            n = min(block, T - t)
+            logits = self.joint(enc_state[t:t + n].unsqueeze(0), dec_state)                                  # [1, n, 1, V]
+            row, tok = ops.greedy_scan(logits[0, :, 0, :])
+            if tok is None:
+                t += n
+                continue
+            token_list.append(tok)
+            dec_state = self.decoder(torch.tensor([token_list], dtype=torch.long, device=dev))[:, -1:, :]
+            t += row + 1                                                    # the emitting frame is consumed
         return token_list[1:]
 
     @torch.no_grad()

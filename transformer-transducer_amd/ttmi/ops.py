@@ -351,3 +351,15 @@ def join_side_streams():
     backward nodes running on a side stream wrote in place, e.g. before the optimiser step / gradient all-reduce)"""
     for st in _side_streams.values():
         torch.cuda.current_stream(st.device).wait_stream(st)
+
+
+def greedy_scan(logits2d, blank=0):
+    """logits2d [n, V] (f32/bf16, row pitch = stride(0)) -> (first row whose argmax != blank, symbol) or (n, None); one 8-byte
+    D2H read."""
+    n, V = logits2d.shape
+    out = torch.empty(1, dtype=torch.int64, device=logits2d.device)
+    check(lib().ttmi_greedy_scan(_p(logits2d), c_int(_DT[logits2d.dtype]), c_long(logits2d.stride(0)), c_int(n), c_int(V),
+                                 c_int(blank), _p(out), _stream()), "ttmi_greedy_scan")
+    key = int(out.item())
+    row, tok = key >> 32, key & 0xffffffff
+    return (row, tok) if row < n else (n, None)
