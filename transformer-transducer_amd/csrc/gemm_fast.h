@@ -5,6 +5,12 @@
 bool gemm_fast_nt_ok(const void* A, const void* B, const void* C, int M, int N, int K, long lda, long ldb);
 bool gemm_fast_tn_ok(const void* A, const void* B, const void* C, int M, int N, int K, long lda, long ldb);
 // epilogue of the NT kernel: v = acc (+ bias[n]) (+ addend[m*ldc+n]); relu; v = mask[m*ldc+n] > 0 ? v : 0
+// two-level batch: z = z1 * nz2 + z2; element offsets added to A / B / C (and bias, colsum) per batch index
+struct FastBatch {
+    int nz1 = 1, nz2 = 1;
+    long sA1 = 0, sA2 = 0, sB1 = 0, sB2 = 0, sC1 = 0, sC2 = 0, sV1 = 0, sV2 = 0;   // sV*: bias (NT) / colsum_a (TN) strides
+};
+
 struct NtEpilogue {
     const float* bias = nullptr;
     const float* addend = nullptr;   // f32, same layout as C (residual add)
@@ -15,7 +21,7 @@ struct NtEpilogue {
 };
 // C[M,N] = epilogue(A[M,K] . B[N,K]^T); c_dtype 0 = f32, 1 = bf16
 int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const NtEpilogue& epi, int M, int N, int K, long lda,
-                 long ldb, long ldc, hipStream_t st);
+                 long ldb, long ldc, hipStream_t st, const FastBatch& batch = FastBatch());
 inline int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const float* bias, int M, int N, int K,
                         long lda, long ldb, long ldc, hipStream_t st) {
     NtEpilogue e;
@@ -26,5 +32,5 @@ inline int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, 
 // colsum_a (nullable, f32 [M], accumulated atomically): column sums of A over K - the bias gradient that belongs to this wgrad -
 // taken from the LDS tiles the kernel stages anyway (no extra pass over A)
 int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
-                 hipStream_t st, float* colsum_a = nullptr);
+                 hipStream_t st, float* colsum_a = nullptr, const FastBatch& batch = FastBatch());
 void gemm_fast_set_version(int v);   // kernel generation for A/B runs, see gemm_fast.hip (default 4)

@@ -44,6 +44,8 @@ struct FP {
     int atomic;
     int gm;                                 // TN: tiles per co-resident group along M
     float* colsum;                          // TN: if set, colsum[m] += sum_k A[k][m] (taken from the LDS tiles by the tn == 0 blocks)
+    int nz2;                                // batch z = blockIdx.y = z1 * nz2 + z2
+    long sA1, sA2, sB1, sB2, sC1, sC2, sV1, sV2;
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
@@ -95,13 +97,24 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], const FP& 
 
 // ------------------------------------------------------------------ NT: A[M,K], B[N,K], K contiguous in both
 template <typename TC, int NBUF, bool PIPE>
-__global__ __launch_bounds__(NTH, NBUF == 1 ? 4 : 2) void gemm_nt_bf16_kernel(const FP p) {
+__global__ __launch_bounds__(NTH, NBUF == 1 ? 4 : 2) void gemm_nt_bf16_kernel(const FP p_) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [NBUF buffers][A 16K | B 16K]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    FP p = p_;
     int tm, tn;
     tile_of(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
     const int bm = tm * TM, bn = tn * TN_;
+    {
+        const int z1 = blockIdx.y / p.nz2, z2 = blockIdx.y % p.nz2;
+        p.A += z1 * p.sA1 + z2 * p.sA2;
+        p.B += z1 * p.sB1 + z2 * p.sB2;
+        const long co = z1 * p.sC1 + z2 * p.sC2;
+        p.C = static_cast<char*>(p.C) + co * (long)sizeof(TC);
+        if (p.addend) p.addend += co;
+        if (p.mask) p.mask += co;
+        if (p.bias) p.bias += z1 * p.sV1 + z2 * p.sV2;
+    }
 
     // staging: wave w, instruction j covers tile rows R = (4w + j) * 8 + (lane >> 3), LDS slot = lane & 7,
     // which must hold source chunk slot ^ ((R >> 1) & 7)
@@ -214,7 +227,15 @@ __device__ __forceinline__ bf16x4 ds_read_tr16(const char* lds_addr) {
 }
 
 template <int NBUF>
-__global__ __launch_bounds__(NTH, NBUF == 1 ? 4 : 2) void gemm_tn_bf16_kernel(const FP p) {
+__global__ __launch_bounds__(NTH, NBUF == 1 ? 4 : 2) void gemm_tn_bf16_kernel(const FP p_) {
+    FP p = p_;
+    {
+        const int z1 = blockIdx.y / p.nz2, z2 = blockIdx.y % p.nz2;
+        p.A += z1 * p.sA1 + z2 * p.sA2;
+        p.B += z1 * p.sB1 + z2 * p.sB2;
+        p.C = static_cast<char*>(p.C) + (z1 * p.sC1 + z2 * p.sC2) * (long)sizeof(float);
+        if (p.colsum) p.colsum += z1 * p.sV1 + z2 * p.sV2;
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -488,18 +509,25 @@ bool gemm_fast_nt_ok(const void* A, const void* B, const void* C, int M, int N, 
            lda >= K && ldb >= K;
 }
 
+static void fill_batch(FP& p, const FastBatch& b) {
+    p.nz2 = b.nz2; p.sA1 = b.sA1; p.sA2 = b.sA2; p.sB1 = b.sB1; p.sB2 = b.sB2; p.sC1 = b.sC1; p.sC2 = b.sC2; p.sV1 = b.sV1; p.sV2 = b.sV2;
+}
+
 int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const NtEpilogue& epi, int M, int N, int K, long lda,
-                 long ldb, long ldc, hipStream_t st) {
+                 long ldb, long ldc, hipStream_t st, const FastBatch& batch) {
     TTMI_REQUIRE(gemm_fast_nt_ok(A, B, C, M, N, K, lda, ldb), "gemm_nt_bf16: shape/alignment not supported (M=%d N=%d K=%d)", M,
                  N, K);
     FP p;
     p.A = A; p.B = B; p.C = C; p.bias = epi.bias; p.addend = epi.addend; p.mask = epi.mask; p.relu = epi.relu; p.scale = epi.scale; p.drop = epi.drop;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.tiles_m = cdiv(M, TM); p.tiles_n = cdiv(N, TN_); p.splitk = 1; p.ksteps = cdiv(K, TK); p.atomic = 0; p.gm = GROUP_M; p.colsum = nullptr;
+    fill_batch(p, batch);
+    const int nbatch = batch.nz1 * batch.nz2;
+    TTMI_REQUIRE(nbatch >= 1 && nbatch <= 65535, "gemm_nt_bf16: bad batch count %d", nbatch);
     // 256x256 tiles pay off when the K loop is long enough to amortise the un-overlapped epilogue of a one-workgroup-per-CU
     // kernel and there are enough tiles to fill the chip (joint dgrad: K = 4352 -> 954 vs 880 TFLOP/s; short-K forward: worse)
     const bool big = (g_gemm_fast_version == 6) || (g_gemm_fast_version == 4 && K >= 2048 && (long)cdiv(M, T6) * cdiv(N, T6) >= 1024);
-    if (big && M >= 1024 && N >= 256) {
+    if (big && M >= 1024 && N >= 256 && nbatch == 1) {
         p.tiles_m = cdiv(M, T6); p.tiles_n = cdiv(N, T6);
         const long nwg6 = (long)p.tiles_m * p.tiles_n;
         if (c_dtype == 0) {
@@ -515,7 +543,7 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     const long nwg = (long)p.tiles_m * p.tiles_n;
     TTMI_REQUIRE(nwg < (1L << 31), "gemm_nt_bf16: too many tiles");
     const int ver = g_gemm_fast_version;
-#define NT_LAUNCH(TCT, NB, PP) hipLaunchKernelGGL((gemm_nt_bf16_kernel<TCT, NB, PP>), dim3((unsigned)nwg), dim3(NTH), 2 * NB * TILE_B, st, p)
+#define NT_LAUNCH(TCT, NB, PP) hipLaunchKernelGGL((gemm_nt_bf16_kernel<TCT, NB, PP>), dim3((unsigned)nwg, nbatch), dim3(NTH), 2 * NB * TILE_B, st, p)
     if (c_dtype == 0) {
         if (ver >= 4) NT_LAUNCH(float, 1, true);
         else if (ver == 3) NT_LAUNCH(float, 2, true);
@@ -537,19 +565,22 @@ bool gemm_fast_tn_ok(const void* A, const void* B, const void* C, int M, int N, 
 
 // C (f32) += A^T B by atomics when splitk > 1 or accumulate != 0, else C = A^T B
 int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
-                 hipStream_t st, float* colsum_a) {
+                 hipStream_t st, float* colsum_a, const FastBatch& batch) {
     TTMI_REQUIRE(gemm_fast_tn_ok(A, B, C, M, N, K, lda, ldb), "gemm_tn_bf16: shape/alignment not supported (M=%d N=%d K=%d)", M,
                  N, K);
     FP p;
     p.A = A; p.B = B; p.C = C; p.bias = nullptr; p.addend = nullptr; p.mask = nullptr; p.relu = 0; p.scale = 1.f; p.drop = DropSpec();
     p.colsum = colsum_a;
+    fill_batch(p, batch);
+    const int nbatch = batch.nz1 * batch.nz2;
+    TTMI_REQUIRE(nbatch >= 1 && nbatch <= 65535, "gemm_tn_bf16: bad batch count %d", nbatch);
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.tiles_m = cdiv(M, TM); p.tiles_n = cdiv(N, TN_);
     const long tiles = (long)p.tiles_m * p.tiles_n;
     const int ksteps_total = cdiv(K, TK);
     int splitk = 1;
-    if (tiles < 1024) {
-        splitk = (int)((2048 + tiles - 1) / tiles);
+    if (tiles * nbatch < 1024) {
+        splitk = (int)((2048 + tiles * nbatch - 1) / (tiles * nbatch));
         if (splitk > ksteps_total / 4) splitk = ksteps_total / 4;
         if (splitk < 1) splitk = 1;
     }
@@ -560,9 +591,9 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
     p.atomic = (splitk > 1 || accumulate) ? 1 : 0;
     p.gm = GROUP_M;                                 // 8 x tiles_n co-resident tiles per K-range measured best (16: -7 %)
         if (g_gemm_fast_version >= 4)
-            hipLaunchKernelGGL(gemm_tn_bf16_kernel<1>, dim3((unsigned)(tiles * splitk)), dim3(NTH), 2 * TILE_B, st, p);
+            hipLaunchKernelGGL(gemm_tn_bf16_kernel<1>, dim3((unsigned)(tiles * splitk), nbatch), dim3(NTH), 2 * TILE_B, st, p);
         else
-            hipLaunchKernelGGL(gemm_tn_bf16_kernel<2>, dim3((unsigned)(tiles * splitk)), dim3(NTH), 4 * TILE_B, st, p);
+            hipLaunchKernelGGL(gemm_tn_bf16_kernel<2>, dim3((unsigned)(tiles * splitk), nbatch), dim3(NTH), 4 * TILE_B, st, p);
     TTMI_LAUNCH_CHECK("gemm_tn_bf16_kernel");
     return TTMI_OK;
 }
@@ -576,11 +607,11 @@ int ttmi_gemm_nt_bf16(const void* A, const void* B, void* C, int c_dtype, const 
     NtEpilogue e;
     e.bias = bias;
     return gemm_nt_bf16(static_cast<const bf16_t*>(A), static_cast<const bf16_t*>(B), C, c_dtype, e, M, N, K, lda, ldb, ldc,
-                        static_cast<hipStream_t>(stream));
+                        static_cast<hipStream_t>(stream), FastBatch());
 }
 int ttmi_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
                       float* colsum_a, void* stream) {
     return gemm_tn_bf16(static_cast<const bf16_t*>(A), static_cast<const bf16_t*>(B), C, M, N, K, lda, ldb, ldc, accumulate,
-                        static_cast<hipStream_t>(stream), colsum_a);
+                        static_cast<hipStream_t>(stream), colsum_a, FastBatch());
 }
 }

@@ -114,7 +114,7 @@ struct AttnCtx {   // saved for backward.  act = f32 (parity) or bf16 (fast)
 struct AttnWs {   // scratch (union of forward and backward needs)
     float *E, *cT, *dE, *dcT, *a, *dS, *dqkv, *delta;
     void* dO;
-    bf16_t *x16, *wqkv16, *wo16, *dqkv16, *dres16, *dS16, *dG16;
+    bf16_t *x16, *wqkv16, *wo16, *dqkv16, *dres16, *dS16, *dG16, *E16, *kT16, *ET16;
     long ldp, slab16;
     AttnWs(Bump& b, const AttnDims& a, bool fast) {
         E = b.take<float>((size_t)a.L * a.HD);
@@ -126,12 +126,15 @@ struct AttnWs {   // scratch (union of forward and backward needs)
         dqkv = b.take<float>(a.BL * a.W3);
         delta = b.take<float>((size_t)a.B * a.H * a.L);
         dO = b.take<char>(a.BL * a.HD * (fast ? 2 : 4));
-        x16 = wqkv16 = wo16 = dqkv16 = dres16 = dS16 = dG16 = nullptr;
+        x16 = wqkv16 = wo16 = dqkv16 = dres16 = dS16 = dG16 = E16 = kT16 = ET16 = nullptr;
         ldp = (a.L + 7) / 8 * 8;
         slab16 = (long)a.L * ldp;
         if (fast) {
             dS16 = b.take<bf16_t>((size_t)a.B * a.H * slab16);
             dG16 = b.take<bf16_t>((size_t)a.B * a.H * slab16);
+            E16 = b.take<bf16_t>((size_t)a.L * a.HD);
+            kT16 = b.take<bf16_t>((size_t)a.B * a.H * a.Dh * ldp);
+            ET16 = b.take<bf16_t>((size_t)a.H * a.Dh * ldp);
             x16 = b.take<bf16_t>(a.BL * a.d);
             wqkv16 = b.take<bf16_t>(a.W3 * a.d);
             wo16 = b.take<bf16_t>(a.HD * a.d);
@@ -230,7 +233,16 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
     CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st));
     // 4. G = q E^T + c into the pitch-(L+1) slab, column 0 zero
     CK(memset2d(c.P, (size_t)(L + 1) * 4, 4, (size_t)B * H * L, st));
-    {
+    if (attn_fused(fast, a) && Dh % 8 == 0) {
+        // on the glds kernel: q (bf16, in place in qkv) x E16^T, batched over (b, h), bias c, pitch-(L+1) f32 output
+        CK(convert_bf16(w.E, w.E16, (long)L * a.HD, st));
+        FastBatch fb;
+        fb.nz1 = B; fb.nz2 = H; fb.sA1 = L * a.W3; fb.sA2 = Dh; fb.sB1 = 0; fb.sB2 = Dh; fb.sC1 = H * a.slab; fb.sC2 = a.slab;
+        fb.sV1 = 0; fb.sV2 = L;
+        NtEpilogue e;
+        e.bias = w.cT;
+        CK(gemm_nt_bf16(static_cast<const bf16_t*>(c.qkv), w.E16, c.P + 1, 0, e, L, L, Dh, a.W3, a.HD, L + 1, st, fb));
+    } else {
         GemmDesc g = mkx(c.qkv, adt, w.E, DT_F32, c.P + 1, DT_F32, L, L, Dh, a.W3, a.HD, L + 1, NT_ | GEMM_BIAS, prec);
         batch_bh(g, a, L * a.W3, Dh, 0, Dh, H * a.slab, a.slab);
         g.bias = w.cT; g.sBias1 = 0; g.sBias2 = L;
@@ -336,12 +348,25 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
         CK(softmax_bwd(w.dS + L, c.P + L, B * H, L, L, a.slab, scale, st));
     }
     // 7. dq(content) = dS K -> dqkv[q]
-    {
-        GemmDesc g = fused ? mkx(w.dS16, DT_BF16, eoff(c.qkv, adt, a.HD), adt, w.dqkv, DT_F32, L, Dh, L, w.ldp, a.W3, a.W3, NN_, prec)
-                           : mkx(w.dS + L, DT_F32, eoff(c.qkv, adt, a.HD), adt, w.dqkv, DT_F32, L, Dh, L, L, a.W3, a.W3, NN_, prec);
-        if (fused) batch_bh(g, a, H * w.slab16, w.slab16, L * a.W3, Dh, L * a.W3, Dh);
-        else batch_bh(g, a, H * a.slab, a.slab, L * a.W3, Dh, L * a.W3, Dh);
-        CK(ttmi_launch_gemm(g, st));
+    const bool fastpos = fused && Dh % 8 == 0;      // position/content products on the glds kernels (K-major transposed k, E)
+    if (fastpos) {
+        if (w.ldp > L) {                             // K runs over the padded pitch: pad columns of dS16 / dG16 must be zero
+            CK(memset2d(w.dS16 + L, (size_t)w.ldp * 2, (size_t)(w.ldp - L) * 2, (size_t)B * H * L, st));
+            CK(memset2d(w.dG16 + L, (size_t)w.ldp * 2, (size_t)(w.ldp - L) * 2, (size_t)B * H * L, st));
+        }
+        CK(transpose_bf16_batched(static_cast<const bf16_t*>(c.qkv) + a.HD, 1, a.W3, B, H, L * a.W3, Dh, L, Dh, w.kT16, w.ldp, st));
+        FastBatch fb;
+        fb.nz1 = B; fb.nz2 = H; fb.sA1 = H * w.slab16; fb.sA2 = w.slab16; fb.sB1 = (long)H * Dh * w.ldp; fb.sB2 = (long)Dh * w.ldp;
+        fb.sC1 = L * a.W3; fb.sC2 = Dh;
+        CK(gemm_nt_bf16(w.dS16, w.kT16, w.dqkv, 0, NtEpilogue(), L, Dh, (int)w.ldp, w.ldp, w.ldp, a.W3, st, fb));
+    } else {
+        {
+            GemmDesc g = fused ? mkx(w.dS16, DT_BF16, eoff(c.qkv, adt, a.HD), adt, w.dqkv, DT_F32, L, Dh, L, w.ldp, a.W3, a.W3, NN_, prec)
+                               : mkx(w.dS + L, DT_F32, eoff(c.qkv, adt, a.HD), adt, w.dqkv, DT_F32, L, Dh, L, L, a.W3, a.W3, NN_, prec);
+            if (fused) batch_bh(g, a, H * w.slab16, w.slab16, L * a.W3, Dh, L * a.W3, Dh);
+            else batch_bh(g, a, H * a.slab, a.slab, L * a.W3, Dh, L * a.W3, Dh);
+            CK(ttmi_launch_gemm(g, st));
+        }
     }
     // 8. g r_w_bias += column sums of dq(content)
     CK(colsum(w.dqkv, a.W3, a.BL, (int)a.HD, 1, 1, 0, 0, 0, 0, g_r_w_bias, st));
@@ -353,27 +378,40 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
             CK(ttmi_launch_gemm(g, st));
         }
     }
-    // 10. dq += dG E   (dG = the same slab read with pitch L+1, column offset 1)
+    // 10. dq += dG E ; 11. dE[p,h,:] = sum_b dG^T q ; 12. dc[h][p] = sum_b colsum(dG) ; 13. fold onto the K-row tables
     CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st));
-    {
-        GemmDesc g = fused ? mkx(w.dG16, DT_BF16, w.E, DT_F32, w.dqkv, DT_F32, L, Dh, L, w.ldp, a.HD, a.W3, NN_, prec)
-                           : mkx(w.dS + 1, DT_F32, w.E, DT_F32, w.dqkv, DT_F32, L, Dh, L, L + 1, a.HD, a.W3, NN_, prec);
-        if (fused) batch_bh(g, a, H * w.slab16, w.slab16, 0, Dh, L * a.W3, Dh);
-        else batch_bh(g, a, H * a.slab, a.slab, 0, Dh, L * a.W3, Dh);
-        g.beta = 1.f;
-        CK(ttmi_launch_gemm(g, st));
-    }
-    // 11. dE[p,h,:] = sum_b dG^T q ; 12. dc[h][p] = sum_b colsum(dG) ; 13. fold onto the K-row tables
     CK(fill_zero(w.dE, sizeof(float) * ((size_t)L * a.HD + (size_t)H * L), st));
-    {
-        GemmDesc g = fused ? mkx(w.dG16, DT_BF16, c.qkv, adt, w.dE, DT_F32, L, Dh, L, w.ldp, a.W3, a.HD, TN_ | GEMM_ATOMIC, prec)
-                           : mkx(w.dS + 1, DT_F32, c.qkv, adt, w.dE, DT_F32, L, Dh, L, L + 1, a.W3, a.HD, TN_ | GEMM_ATOMIC, prec);
-        if (fused) batch_bh(g, a, H * w.slab16, w.slab16, L * a.W3, Dh, 0, Dh);
-        else batch_bh(g, a, H * a.slab, a.slab, L * a.W3, Dh, 0, Dh);
-        CK(ttmi_launch_gemm(g, st));
+    if (fastpos) {
+        CK(transpose_bf16_batched(w.E, 0, a.HD, 1, H, 0, Dh, L, Dh, w.ET16, w.ldp, st));
+        FastBatch fb;
+        fb.nz1 = B; fb.nz2 = H; fb.sA1 = H * w.slab16; fb.sA2 = w.slab16; fb.sB1 = 0; fb.sB2 = (long)Dh * w.ldp;
+        fb.sC1 = L * a.W3; fb.sC2 = Dh;
+        NtEpilogue e;
+        e.addend = w.dqkv;
+        CK(gemm_nt_bf16(w.dG16, w.ET16, w.dqkv, 0, e, L, Dh, (int)w.ldp, w.ldp, w.ldp, a.W3, st, fb));
+        FastBatch tb;
+        tb.nz1 = B; tb.nz2 = H; tb.sA1 = H * w.slab16; tb.sA2 = w.slab16; tb.sB1 = L * a.W3; tb.sB2 = Dh; tb.sC1 = 0; tb.sC2 = Dh;
+        tb.sV1 = 0; tb.sV2 = L;
+        CK(gemm_tn_bf16(w.dG16, static_cast<const bf16_t*>(c.qkv), w.dE, L, Dh, L, w.ldp, a.W3, a.HD, 1, st, w.dcT, tb));
+    } else {
+        {
+            GemmDesc g = fused ? mkx(w.dG16, DT_BF16, w.E, DT_F32, w.dqkv, DT_F32, L, Dh, L, w.ldp, a.HD, a.W3, NN_, prec)
+                               : mkx(w.dS + 1, DT_F32, w.E, DT_F32, w.dqkv, DT_F32, L, Dh, L, L + 1, a.HD, a.W3, NN_, prec);
+            if (fused) batch_bh(g, a, H * w.slab16, w.slab16, 0, Dh, L * a.W3, Dh);
+            else batch_bh(g, a, H * a.slab, a.slab, 0, Dh, L * a.W3, Dh);
+            g.beta = 1.f;
+            CK(ttmi_launch_gemm(g, st));
+        }
+        {
+            GemmDesc g = fused ? mkx(w.dG16, DT_BF16, c.qkv, adt, w.dE, DT_F32, L, Dh, L, w.ldp, a.W3, a.HD, TN_ | GEMM_ATOMIC, prec)
+                               : mkx(w.dS + 1, DT_F32, c.qkv, adt, w.dE, DT_F32, L, Dh, L, L + 1, a.W3, a.HD, TN_ | GEMM_ATOMIC, prec);
+            if (fused) batch_bh(g, a, H * w.slab16, w.slab16, L * a.W3, Dh, 0, Dh);
+            else batch_bh(g, a, H * a.slab, a.slab, L * a.W3, Dh, 0, Dh);
+            CK(ttmi_launch_gemm(g, st));
+        }
+        if (fused) CK(colsum_bf16(w.dG16, w.ldp, L, L, w.dcT, st, B, H, H * w.slab16, w.slab16, L));
+        else CK(colsum(w.dS + 1, L + 1, L, L, B, H, H * a.slab, a.slab, 0, L, w.dcT, st));
     }
-    if (fused) CK(colsum_bf16(w.dG16, w.ldp, L, L, w.dcT, st, B, H, H * w.slab16, w.slab16, L));
-    else CK(colsum(w.dS + 1, L + 1, L, L, B, H, H * a.slab, a.slab, 0, L, w.dcT, st));
     CK(relpos_scatter(w.dE, w.dcT, K, L, H, Dh, g_r_emb, g_r_bias, st));
     // 14. gWqkv += dqkv^T x ; 15. dx += dqkv Wqkv
     if (fast) {

@@ -416,6 +416,31 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
     if (c + 1 < cols) atomicAdd(out + c + 1, a1);
 }
 
+template <typename TS>
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const TS* __restrict__ src, long ld, int nz2, long s1, long s2, int R,
+                                                                int C, bf16_t* __restrict__ dst, long ldd) {
+    __shared__ float tile[32][33];
+    const int z = blockIdx.z, z1 = z / nz2, z2 = z % nz2;
+    const TS* sp = src + z1 * s1 + z2 * s2;
+    bf16_t* dp = dst + (long)z * C * ldd;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        float v = 0.f;
+        if (r < R && c < C) {
+            if constexpr (sizeof(TS) == 4) v = sp[(long)r * ld + c];
+            else v = bf16_to_f32(sp[(long)r * ld + c]);
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < ldd) dp[(long)c * ldd + r] = f32_to_bf16(tile[tx][i]);
+    }
+}
+
 // greedy scan: rows of logits (f32 or bf16, pitch ld); out[0] = first row whose argmax != blank (or n), out[1] = that argmax.
 // One wave per row computes the argmax (first maximal index, like torch.argmax); the rows' results go through a single
 // atomicMin on the packed (row << 32 | token) key, so one 8-byte D2H read tells the host where the next symbol is.
@@ -617,5 +642,18 @@ int greedy_scan(const void* logits, int dtype, long ld, int n, int V, int blank,
     else
         hipLaunchKernelGGL(greedy_scan_kernel<bf16_t>, dim3(cdiv(n, 4)), dim3(256), 0, st, static_cast<const bf16_t*>(logits), ld, n, V, blank, out);
     TTMI_LAUNCH_CHECK("greedy_scan_kernel");
+    return TTMI_OK;
+}
+
+int transpose_bf16_batched(const void* src, int src_dtype, long ld, int nz1, int nz2, long s1, long s2, int R, int C, bf16_t* dst,
+                           long ldd, hipStream_t st) {
+    TTMI_REQUIRE(src && dst && R > 0 && C > 0 && ldd >= R && nz1 > 0 && nz2 > 0, "transpose_bf16_batched: bad arguments");
+    dim3 grid(cdiv(C, 32), cdiv(ldd, 32), nz1 * nz2);
+    TTMI_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "transpose_bf16_batched: grid too large");
+    if (src_dtype == 0)
+        hipLaunchKernelGGL(transpose_batched_kernel<float>, grid, dim3(256), 0, st, static_cast<const float*>(src), ld, nz2, s1, s2, R, C, dst, ldd);
+    else
+        hipLaunchKernelGGL(transpose_batched_kernel<bf16_t>, grid, dim3(256), 0, st, static_cast<const bf16_t*>(src), ld, nz2, s1, s2, R, C, dst, ldd);
+    TTMI_LAUNCH_CHECK("transpose_batched_kernel");
     return TTMI_OK;
 }
