@@ -226,7 +226,7 @@ __device__ __forceinline__ bf16x4 ds_read_tr16(const char* lds_addr) {
     return __builtin_bit_cast(bf16x4, v);
 }
 
-template <int NBUF>
+template <int NBUF, bool CS>
 __global__ __launch_bounds__(NTH, NBUF == 1 ? 4 : 2) void gemm_tn_bf16_kernel(const FP p_) {
     FP p = p_;
     {
@@ -324,27 +324,40 @@ __global__ __launch_bounds__(NTH, NBUF == 1 ? 4 : 2) void gemm_tn_bf16_kernel(co
             for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     };
     auto compute = [&](const char* la, const char* lb) {
-        bf16x8 a0[2], b0[2], a1[2], b1[2];
-        frag(la, lb, 0, a0, b0);
-        frag(la, lb, 1, a1, b1);
-        __builtin_amdgcn_s_setprio(1);
-        mma(a0, b0);
-        __builtin_amdgcn_s_setprio(0);
-        frag(la, lb, 2, a0, b0);
-        __builtin_amdgcn_s_setprio(1);
-        mma(a1, b1);
-        __builtin_amdgcn_s_setprio(0);
-        frag(la, lb, 3, a1, b1);
-        __builtin_amdgcn_s_setprio(1);
-        mma(a0, b0);
-        mma(a1, b1);
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (NBUF == 1) {
+            // 4 workgroups per CU already overlap each other's LDS latency; one fragment set keeps the kernel under the
+            // 128-VGPR budget of that occupancy without spills
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                bf16x8 a0[2], b0[2];
+                frag(la, lb, kk, a0, b0);
+                __builtin_amdgcn_s_setprio(1);
+                mma(a0, b0);
+                __builtin_amdgcn_s_setprio(0);
+            }
+        } else {
+            bf16x8 a0[2], b0[2], a1[2], b1[2];
+            frag(la, lb, 0, a0, b0);
+            frag(la, lb, 1, a1, b1);
+            __builtin_amdgcn_s_setprio(1);
+            mma(a0, b0);
+            __builtin_amdgcn_s_setprio(0);
+            frag(la, lb, 2, a0, b0);
+            __builtin_amdgcn_s_setprio(1);
+            mma(a1, b1);
+            __builtin_amdgcn_s_setprio(0);
+            frag(la, lb, 3, a1, b1);
+            __builtin_amdgcn_s_setprio(1);
+            mma(a0, b0);
+            mma(a1, b1);
+            __builtin_amdgcn_s_setprio(0);
+        }
     };
-    // optional column sums of A (the bias gradient of a Linear whose wgrad this is): tn == 0 blocks only, from LDS
-    const bool do_cs = p.colsum != nullptr && tn == 0;
+    // optional column sums of A (the bias gradient of the Linear whose wgrad this is), taken from the staged LDS tile.  The
+    // tiles_n blocks that share an A tile split the K-steps between them (kt % tiles_n == tn), so no block is slower than the rest
     float cs = 0.f;
-    auto colsum_tile = [&](const char* la) {
-        if (do_cs) {
+    auto colsum_tile = [&](const char* la, int kt) {
+        if (CS && (kt % p.tiles_n) == tn) {
             const int col = tid & 127, r0 = (tid >> 7) * 32;
 #pragma unroll 8
             for (int rr = 0; rr < 32; ++rr) {
@@ -361,7 +374,7 @@ __global__ __launch_bounds__(NTH, NBUF == 1 ? 4 : 2) void gemm_tn_bf16_kernel(co
             if (kt + 1 < nk) issue(cur ^ 1, kt + 1);
             const char* la = smem + cur * 2 * TILE_B;
             compute(la, la + TILE_B);
-            colsum_tile(la);
+            colsum_tile(la, kt);
             __syncthreads();
         }
     } else {
@@ -369,11 +382,11 @@ __global__ __launch_bounds__(NTH, NBUF == 1 ? 4 : 2) void gemm_tn_bf16_kernel(co
             issue(0, kt);
             __syncthreads();
             compute(smem, smem + TILE_B);
-            colsum_tile(smem);
+            colsum_tile(smem, kt);
             __syncthreads();
         }
     }
-    if (do_cs && bm + (tid & 127) < p.M) atomicAdd(p.colsum + bm + (tid & 127), cs);
+    if (CS && bm + (tid & 127) < p.M) atomicAdd(p.colsum + bm + (tid & 127), cs);
     store_tile<float>(acc, p, reinterpret_cast<float*>(p.C), bm, bn, wm, wn, lane, false);
 }
 
@@ -495,8 +508,8 @@ int enable_lds(K kernel, int bytes) {
 }
 
 // ttmi_set_option(1, v) - A/B measurements: 1 = 128x128 double-buffered, 3 = 1 + software-pipelined fragment reads,
-// 4 (default) = single 32 KiB buffer, 4 workgroups per CU, pipelined fragments (NT +15 % at the joint shapes; TN +8 % once
-// each XCD owns a K-range) with the 256x256 kernel for long-K shapes, 6 = 256x256 wherever it fits.
+// 4 (default) = single 32 KiB buffer, 4 workgroups per CU, one fragment set (stays under 128 VGPRs without spills; NT +15 % at
+// the joint shapes; TN +8 % once each XCD owns a K-range) with the 256x256 kernel for long-K shapes, 6 = 256x256 wherever it fits.
 // Measured and dropped (same box, joint projection M=816000 N=4334 K=1024, v4 = 720 TFLOP/s): 256x128 3-stage ring with
 // counted vmcnt 621; persistent 256x256 with a 4-slice ring that never drains 668 (dgrad K=4352: 904 vs 938 for v6).
 int g_gemm_fast_version = 4;
@@ -545,11 +558,11 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     const int ver = g_gemm_fast_version;
 #define NT_LAUNCH(TCT, NB, PP) hipLaunchKernelGGL((gemm_nt_bf16_kernel<TCT, NB, PP>), dim3((unsigned)nwg, nbatch), dim3(NTH), 2 * NB * TILE_B, st, p)
     if (c_dtype == 0) {
-        if (ver >= 4) NT_LAUNCH(float, 1, true);
+        if (ver >= 4) NT_LAUNCH(float, 1, false);
         else if (ver == 3) NT_LAUNCH(float, 2, true);
         else NT_LAUNCH(float, 2, false);
     } else {
-        if (ver >= 4) NT_LAUNCH(bf16_t, 1, true);
+        if (ver >= 4) NT_LAUNCH(bf16_t, 1, false);
         else if (ver == 3) NT_LAUNCH(bf16_t, 2, true);
         else NT_LAUNCH(bf16_t, 2, false);
     }
@@ -590,10 +603,15 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
     p.splitk = splitk;
     p.atomic = (splitk > 1 || accumulate) ? 1 : 0;
     p.gm = GROUP_M;                                 // 8 x tiles_n co-resident tiles per K-range measured best (16: -7 %)
-        if (g_gemm_fast_version >= 4)
-            hipLaunchKernelGGL(gemm_tn_bf16_kernel<1>, dim3((unsigned)(tiles * splitk), nbatch), dim3(NTH), 2 * TILE_B, st, p);
-        else
-            hipLaunchKernelGGL(gemm_tn_bf16_kernel<2>, dim3((unsigned)(tiles * splitk), nbatch), dim3(NTH), 4 * TILE_B, st, p);
+#define TN_LAUNCH(NB, CSF) hipLaunchKernelGGL((gemm_tn_bf16_kernel<NB, CSF>), dim3((unsigned)(tiles * splitk), nbatch), dim3(NTH), 2 * NB * TILE_B, st, p)
+        if (g_gemm_fast_version >= 4) {
+            if (colsum_a) TN_LAUNCH(1, true);
+            else TN_LAUNCH(1, false);
+        } else {
+            if (colsum_a) TN_LAUNCH(2, true);
+            else TN_LAUNCH(2, false);
+        }
+#undef TN_LAUNCH
     TTMI_LAUNCH_CHECK("gemm_tn_bf16_kernel");
     return TTMI_OK;
 }
