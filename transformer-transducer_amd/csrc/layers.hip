@@ -55,6 +55,53 @@ int wgrad(const float* dY, const float* X, float* gW, int M, int N, int K, long 
         if (rc__) return rc__;   \
     } while (0)
 
+// ---- intra-call concurrency: weight-gradient GEMMs feed nothing downstream inside a backward call, so they are forked onto a
+// library-owned side stream (one per caller stream) and joined before the call returns (scratch buffers they read are reused by
+// the next call).  ttmi_set_option(3, 0) disables it.
+int g_fork_wgrad = 1;
+struct SideCtx {
+    hipStream_t main = nullptr, side = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    int next = 0;
+    bool used = false;
+};
+SideCtx g_side[8];
+int g_nside = 0;
+
+SideCtx* side_for(hipStream_t main) {
+    for (int i = 0; i < g_nside; ++i)
+        if (g_side[i].main == main) return &g_side[i];
+    if (g_nside == 8) return nullptr;
+    SideCtx& c = g_side[g_nside];
+    if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    for (auto& e : c.ev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    c.main = main;
+    ++g_nside;
+    return &c;
+}
+
+// returns the stream to launch the forked work on (the side stream after making it wait for everything queued on `main`
+// so far), or `main` itself when forking is disabled / unavailable
+hipStream_t fork_stream(hipStream_t main) {
+    if (!g_fork_wgrad) return main;
+    SideCtx* c = side_for(main);
+    if (!c) return main;
+    hipEvent_t e = c->ev[c->next];
+    c->next ^= 1;
+    if (hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(c->side, e, 0) != hipSuccess) return main;
+    c->used = true;
+    return c->side;
+}
+
+// make `main` wait for everything forked during this call
+void join_stream(hipStream_t main) {
+    SideCtx* c = g_fork_wgrad ? side_for(main) : nullptr;
+    if (!c || !c->used) return;
+    if (hipEventRecord(c->ev[2], c->side) == hipSuccess) (void)hipStreamWaitEvent(main, c->ev[2], 0);
+    c->used = false;
+}
+
 struct AttnDims {
     int B, L, d, H, Dh, K;
     long BL, HD, W3, slab;
@@ -311,7 +358,7 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
     }
     if (fast) {
         CK(dropout_apply(dx, a.BL * d, rd, nullptr, w.dres16, st));
-        CK(gemm_tn_bf16(w.dres16, static_cast<bf16_t*>(c.O), g_o_w, d, (int)a.HD, (int)a.BL, d, a.HD, a.HD, 1, st));
+        CK(gemm_tn_bf16(w.dres16, static_cast<bf16_t*>(c.O), g_o_w, d, (int)a.HD, (int)a.BL, d, a.HD, a.HD, 1, fork_stream(st)));
         CK(transpose_convert_bf16(o_w, d, (int)a.HD, w.wo16, d, st));                          // Wo^T [HD, d]
         CK(gemm_nt_bf16(w.dres16, w.wo16, w.dO, 1, nullptr, (int)a.BL, (int)a.HD, d, d, d, a.HD, st));
     } else {
@@ -417,7 +464,7 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
     if (fast) {
         CK(convert_bf16(w.dqkv, w.dqkv16, a.BL * a.W3, st));
         CK(convert_bf16(x, w.x16, a.BL * d, st));
-        CK(gemm_tn_bf16(w.dqkv16, w.x16, g_qkv_w, (int)a.W3, d, (int)a.BL, a.W3, d, d, 1, st));
+        CK(gemm_tn_bf16(w.dqkv16, w.x16, g_qkv_w, (int)a.W3, d, (int)a.BL, a.W3, d, d, 1, fork_stream(st)));
         CK(transpose_convert_bf16(qkv_w, (int)a.W3, d, w.wqkv16, a.W3, st));                   // Wqkv^T [d, W3]
         NtEpilogue e;
         e.addend = dx;
@@ -428,6 +475,7 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
         g.beta = 1.f;
         CK(ttmi_launch_gemm(g, st));
     }
+    join_stream(st);
     return TTMI_OK;
 }
 
@@ -541,12 +589,12 @@ int ttmi_ffn_bwd(const float* dz, const float* y, const float* w1, const float* 
         bf16_t* a1 = static_cast<bf16_t*>(c.a1);
         bf16_t* h = static_cast<bf16_t*>(c.h);
         bf16_t* da1 = static_cast<bf16_t*>(w.da1);
-        CK(gemm_tn_bf16(w.dres16, a1, g_w2, d, Di, (int)rows, d, Di, Di, 1, st));
+        CK(gemm_tn_bf16(w.dres16, a1, g_w2, d, Di, (int)rows, d, Di, Di, 1, fork_stream(st)));
         CK(transpose_convert_bf16(w2, d, Di, w.w2_16, d, st));                                 // W2^T [Di, d]
         NtEpilogue e;
         e.mask = a1; e.scale = inv_keep;                   // a1 is stored post-dropout: a1 > 0 <=> ReLU active AND kept
         CK(gemm_nt_bf16(w.dres16, w.w2_16, da1, 1, e, (int)rows, Di, d, d, d, Di, st));
-        CK(gemm_tn_bf16(da1, h, g_w1, Di, d, (int)rows, Di, d, d, 1, st, g_b1));   // g_b1 = column sums of da1, fused
+        CK(gemm_tn_bf16(da1, h, g_w1, Di, d, (int)rows, Di, d, d, 1, fork_stream(st), g_b1));   // g_b1 = column sums of da1, fused
         CK(transpose_convert_bf16(w1, Di, d, w.w1_16, Di, st));                                // W1^T [d, Di]
         CK(gemm_nt_bf16(da1, w.w1_16, w.dh, 0, nullptr, (int)rows, d, Di, Di, Di, d, st));
     } else {
@@ -562,6 +610,7 @@ int ttmi_ffn_bwd(const float* dz, const float* y, const float* w1, const float* 
         CK(ttmi_launch_gemm(mk(da1, w1, w.dh, (int)rows, d, Di, Di, d, d, NN_, prec), st));
     }
     CK(ln_bwd(w.dh, y, c.mean1, c.rstd1, ln_g, w.dres, rows, d, dy, g_ln_g, g_ln_b, st));
+    join_stream(st);
     return TTMI_OK;
 }
 
@@ -663,12 +712,13 @@ int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float*
 }
 
 // process-wide switches for A/B measurements.  key 0: 1 = disable the fused attention kernels (bf16 pipeline only);
-// key 1: throughput-GEMM generation (1 = 128x128 two-stage only, 2 = 256x128 three-stage where the shape allows)
+// key 1: throughput-GEMM generation (see gemm_fast.hip); key 2: flash-kernel timing switches; key 3: 0 = no wgrad fork
 int ttmi_set_option(int key, int value) {
-    TTMI_REQUIRE(key >= 0 && key <= 2, "set_option: unknown key %d", key);
+    TTMI_REQUIRE(key >= 0 && key <= 3, "set_option: unknown key %d", key);
     if (key == 0) g_disable_fused_attention = value;
     else if (key == 1) gemm_fast_set_version(value);
-    else g_flash_debug = value;
+    else if (key == 2) g_flash_debug = value;
+    else g_fork_wgrad = value;
     return TTMI_OK;
 }
 
