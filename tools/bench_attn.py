@@ -14,6 +14,8 @@ from ttmi.ops import MaskSpec
 
 ops.set_option(2, int(os.environ.get("TTMI_FLASH_DEBUG", "0")))
 ops.set_option(0, int(os.environ.get("TTMI_NO_FLASH", "0")))
+ops.set_option(4, int(os.environ.get("TTMI_TN_TARGET", "512")))
+ops.set_option(3, int(os.environ.get("TTMI_FORK", "1")))
 B, L = int(os.environ.get("B", 32)), int(os.environ.get("L", 500))
 torch.manual_seed(0)
 layer = BaseEncoder(k_len=410, n_head=8, d_model=512, d_head=64, d_inner=1024, dropout=0.0).cuda()

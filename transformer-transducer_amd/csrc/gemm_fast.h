@@ -34,3 +34,4 @@ inline int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, 
 int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
                  hipStream_t st, float* colsum_a = nullptr, const FastBatch& batch = FastBatch());
 void gemm_fast_set_version(int v);   // kernel generation for A/B runs, see gemm_fast.hip (default 4)
+void gemm_fast_set_tn_target(int n);

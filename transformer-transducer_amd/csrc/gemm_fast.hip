@@ -513,6 +513,7 @@ int enable_lds(K kernel, int bytes) {
 // Measured and dropped (same box, joint projection M=816000 N=4334 K=1024, v4 = 720 TFLOP/s): 256x128 3-stage ring with
 // counted vmcnt 621; persistent 256x256 with a 4-slice ring that never drains 668 (dgrad K=4352: 904 vs 938 for v6).
 int g_gemm_fast_version = 4;
+int g_tn_target_blocks = 512;     // split-K aims at this many workgroups for small outputs (ttmi_set_option(4, n))
 
 
 }  // namespace
@@ -591,9 +592,13 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
     p.tiles_m = cdiv(M, TM); p.tiles_n = cdiv(N, TN_);
     const long tiles = (long)p.tiles_m * p.tiles_n;
     const int ksteps_total = cdiv(K, TK);
+    // split-K: enough workgroups to fill the chip, but every split adds a tile of f32 atomics (measured on the encoder wgrads:
+    // aiming at 512 workgroups beats 2048 by 10 % of the layer time).  Long reductions always get >= 8 splits, in multiples of
+    // 8, so that each XCD owns a K-range (see the kernel).
     int splitk = 1;
     if (tiles * nbatch < 1024) {
-        splitk = (int)((2048 + tiles * nbatch - 1) / (tiles * nbatch));
+        splitk = (int)((g_tn_target_blocks + tiles * nbatch - 1) / (tiles * nbatch));
+        if (ksteps_total >= 1024 && splitk < 8) splitk = 8;
         if (splitk > ksteps_total / 4) splitk = ksteps_total / 4;
         if (splitk < 1) splitk = 1;
     }
@@ -617,6 +622,7 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
 }
 
 void gemm_fast_set_version(int v) { g_gemm_fast_version = v; }
+void gemm_fast_set_tn_target(int n) { g_tn_target_blocks = n; }
 
 extern "C" {
 // bring-up / test entry points (dtype codes 0 = f32, 1 = bf16)

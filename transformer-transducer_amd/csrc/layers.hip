@@ -714,7 +714,8 @@ int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float*
 // process-wide switches for A/B measurements.  key 0: 1 = disable the fused attention kernels (bf16 pipeline only);
 // key 1: throughput-GEMM generation (see gemm_fast.hip); key 2: flash-kernel timing switches; key 3: 0 = no wgrad fork
 int ttmi_set_option(int key, int value) {
-    TTMI_REQUIRE(key >= 0 && key <= 3, "set_option: unknown key %d", key);
+    TTMI_REQUIRE(key >= 0 && key <= 4, "set_option: unknown key %d", key);
+    if (key == 4) { gemm_fast_set_tn_target(value); return TTMI_OK; }
     if (key == 0) g_disable_fused_attention = value;
     else if (key == 1) gemm_fast_set_version(value);
     else if (key == 2) g_flash_debug = value;
