@@ -1,7 +1,44 @@
 """Hot-path subset of the reference's tt/utils.py: AttrDict (tt/utils.py:11-27) and the two mask
 builders (tt/utils.py:233-251).  Feature extraction / logging / checkpoint helpers of that file are
 outside the accelerated path."""
+import importlib.util
+import os
+import sys
+
 import torch
+
+_REF = None
+
+
+def _reference_utils():
+    """the reference's own tt/utils.py (another `tt/utils.py` further down sys.path), loaded on first use"""
+    global _REF
+    if _REF is None:
+        here = os.path.dirname(os.path.abspath(__file__))
+        for entry in sys.path:
+            cand = os.path.join(entry or ".", "tt", "utils.py")
+            if os.path.isfile(cand) and os.path.dirname(os.path.abspath(cand)) != here:
+                spec = importlib.util.spec_from_file_location("tt._reference_utils", cand)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)     # needs the reference's own dependencies (librosa, editdistance, ...)
+                _REF = mod
+                break
+        else:
+            raise ImportError("no reference tt/utils.py found on sys.path behind the ttmi overlay")
+    return _REF
+
+
+def __getattr__(name):
+    """PEP 562: names this hot-path subset does not define (init_logger, save_model, get_feature, computer_cer, ...) are
+    served by the reference's tt/utils.py, so `from tt.utils import AttrDict, init_logger, ...` keeps working unchanged"""
+    if name.startswith("__"):
+        raise AttributeError(name)
+    try:
+        return getattr(_reference_utils(), name)
+    except ImportError as e:
+        raise AttributeError("tt.utils.%s is not part of the accelerated path and the reference's tt/utils.py could not be "
+                             "loaded (%s)" % (name, e)) from e
+
 
 
 class AttrDict(dict):
