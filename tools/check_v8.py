@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Bring-up check of one throughput-GEMM generation (GEMM_V, default 8): exact-integer parity on awkward shapes, then TFLOP/s
+at the joint shapes next to the default generation.  GPU box only."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "transformer-transducer_amd"))
+import torch
+from ttmi import ops
+
+V = int(os.environ.get("GEMM_V", "8"))
+
+
+def ints(shape, g):
+    return torch.randint(-4, 5, shape, device="cuda", generator=g).to(torch.bfloat16)
+
+
+def check():
+    g = torch.Generator(device="cuda").manual_seed(5)
+    bad = 0
+    for (M, N, K, pad) in [(1024, 256, 64, 0), (1024, 256, 128, 0), (1024, 256, 192, 0), (1030, 700, 72, 3), (2048, 260, 320, 4),
+                           (5000, 4334, 1024, 18), (3000, 1024, 4352, 0), (1025, 257, 1000, 0)]:
+        A, B = ints((M, K), g), ints((N, K), g)
+        bias = torch.randint(-3, 4, (N,), device="cuda", generator=g).float()
+        for cdt in (torch.float32, torch.bfloat16):
+            Cfull = torch.full((M, N + pad), 5.0, device="cuda", dtype=cdt)
+            C = Cfull[:, :N]
+            ops.set_option(1, V)
+            ops.gemm_nt_bf16(A, B, C, bias)
+            ops.set_option(1, 4)
+            want = (A.float() @ B.float().t() + bias).to(cdt)
+            ok = torch.equal(C, want) and (pad == 0 or bool((Cfull[:, N:] == 5.0).all()))
+            if not ok:
+                bad += 1
+                d = (C.float() - want.float()).abs()
+                idx = (d > 0).nonzero()
+                print("MISMATCH", M, N, K, pad, cdt, "n_bad", idx.shape[0], "first", idx[:4].tolist(), flush=True)
+            else:
+                print("ok", M, N, K, pad, cdt, flush=True)
+    return bad
+
+
+def timeit(fn, n=5):
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+
+def bench():
+    M, Vv, Vp, J = 32 * 500 * 51, 4334, 4352, 1024
+    g = torch.Generator(device="cuda").manual_seed(0)
+    H = torch.randn(M, J, device="cuda", generator=g).to(torch.bfloat16)
+    Wp = torch.randn(Vv, J, device="cuda", generator=g).to(torch.bfloat16)
+    WpT = torch.zeros(J, Vp, device="cuda", dtype=torch.bfloat16)
+    WpT[:, :Vv] = Wp.t()
+    bias = torch.randn(Vv, device="cuda")
+    Z = torch.empty(M, Vp, device="cuda", dtype=torch.bfloat16)
+    dH = torch.empty(M, J, device="cuda", dtype=torch.bfloat16)
+    A4 = torch.randn(4096, 4096, device="cuda", generator=g).to(torch.bfloat16)
+    C4 = torch.empty(4096, 4096, device="cuda", dtype=torch.bfloat16)
+    A8 = torch.randn(8192, 8192, device="cuda", generator=g).to(torch.bfloat16)
+    C8 = torch.empty(8192, 8192, device="cuda", dtype=torch.bfloat16)
+    for ver in [int(x) for x in os.environ.get('GEMM_BENCH', '4,%d' % V).split(',')]:
+        ops.set_option(1, ver)
+        for name, fn, f in [
+            ("joint fwd  M=%d N=%d K=%d" % (M, Vv, J), lambda: ops.gemm_nt_bf16(H, Wp, Z[:, :Vv], bias), 2.0 * M * Vv * J),
+            ("joint dgrad M=%d N=%d K=%d" % (M, J, Vp), lambda: ops.gemm_nt_bf16(Z, WpT, dH), 2.0 * M * Vp * J),
+            ("4096^3", lambda: ops.gemm_nt_bf16(A4, A4, C4), 2.0 * 4096 ** 3),
+            ("8192^3", lambda: ops.gemm_nt_bf16(A8, A8, C8), 2.0 * 8192 ** 3),
+        ]:
+            ms = timeit(fn)
+            print("v%d %-40s %8.3f ms  %7.1f TFLOP/s" % (ver, name, ms, f / ms / 1e9), flush=True)
+    ops.set_option(1, 4)
+
+
+if __name__ == "__main__":
+    bad = check()
+    if bad:
+        sys.exit(1)
+    bench()

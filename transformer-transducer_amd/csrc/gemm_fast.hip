@@ -500,6 +500,255 @@ __global__ __launch_bounds__(NTH6, 1) void gemm_nt_bf16_v6_kernel(const FP p) {
         }
 }
 
+// =====================================================================================================================
+// v8: persistent 256x256x64 kernel, one 512-thread workgroup per CU, 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 = 8 x 4
+// v_mfma_f32_16x16x32_bf16 tiles (128 accumulator registers), 2 x 64 KiB operand buffers + 32 KiB epilogue staging in LDS.
+// A K-tile is staged as four 16 KiB half-tiles (A rows with (row>>6)&1 = h, B columns with (col>>5)&1 = h) and consumed in
+// four phases, one 64x32 accumulator quadrant x K=64 (16 MFMAs) each:
+//     phase 0: read A(h0) B(h0) | mma (0,0)      phase 1: read B(h1) | mma (0,1)
+//     phase 2: read A(h1)       | mma (1,1)      phase 3:            | mma (1,0)
+// Every phase = [LDS reads + one half-tile of global_load_lds + s_waitcnt lgkmcnt(0)] s_barrier [16 MFMAs] s_barrier.  Waves
+// 4-7 (the SIMD partners of waves 0-3) run one barrier behind, so in every barrier interval one wave per SIMD issues MFMAs
+// while its partner reads LDS / issues the prefetch.  Loads are never drained inside the loop: each half-tile region is
+// re-staged one phase after its last read (A(h0) of tile t+2 in phase 1, B(h0) in 2, B(h1) in 3, A(h1) in phase 0 of t+1),
+// and one counted s_waitcnt vmcnt(6) per K-tile (phase 3: three half-tiles stay in flight) followed by a barrier orders the
+// LDS-DMA of tile t+1 before its first read in the next phase.  (Stores of the previous output tile may still be counted by
+// vmcnt: loads retire in order among themselves, so a counted wait can only be conservative.)
+// Output: the MFMA takes the B fragment as its row operand, so a lane holds 4 consecutive columns of one C row; each wave
+// passes its accumulators 16 rows at a time through a private 4 KiB f32 LDS image (XOR-swizzled) and writes whole 128-byte
+// (bf16) / 256-byte (f32) row segments.  The next output tile's first seven half-tiles are already in flight while the
+// epilogue runs, and its stores drain under the next tile's MFMAs.
+// =====================================================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int T8 = 256, NTH8 = 512, HT8 = 128 * 64 * 2, BUF8 = 4 * HT8;   // buffer: [A h0 | A h1 | B h0 | B h1]
+constexpr int LDS8 = 2 * BUF8 + 8 * 4096;
+
+template <typename TC>
+__global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int nk = (p.K + TK - 1) / TK;
+    const void* zsrc = &g_zero16;
+
+    // persistent tile walk: in every round the 32 workgroups of one XCD (ids equal mod 8) take 32 consecutive ids = an
+    // 8-tall x 4-wide window of the GROUP_M-grouped order
+    auto tile_id = [&](int it) { return (long)it * gridDim.x + (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3); };
+    auto coords = [&](long id, int& bm, int& bn) {
+        const int per_group = GROUP_M * p.tiles_n;
+        const int group = (int)(id / per_group), in = (int)(id % per_group);
+        const int first = group * GROUP_M;
+        const int gsz = min(p.tiles_m - first, GROUP_M);
+        bm = (first + in % gsz) * T8;
+        bn = (in / gsz) * T8;
+    };
+    // staging: instruction j of wave w fills half-tile rows rho = (2w + j) * 8 + (lane >> 3), 16-byte slot lane & 7, which must
+    // hold source chunk slot ^ ((rho >> 1) & 7)
+    const bf16_t* sA[2][2];
+    const bf16_t* sB[2][2];
+    int kch[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) kch[j] = (lane & 7) ^ ((((wave * 2 + j) * 8 + (lane >> 3)) >> 1) & 7);
+    auto sources = [&](int bm, int bn) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rho = (wave * 2 + j) * 8 + (lane >> 3);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ra = bm + (rho >> 6) * 128 + h * 64 + (rho & 63);
+                const int rb = bn + (rho >> 5) * 64 + h * 32 + (rho & 31);
+                sA[h][j] = p.A + (long)min(ra, p.M - 1) * p.lda + kch[j] * 8;
+                sB[h][j] = p.B + (long)min(rb, p.N - 1) * p.ldb + kch[j] * 8;
+            }
+        }
+    };
+    // kind: 0 = A h0, 1 = A h1, 2 = B h0, 3 = B h1 (also the region index inside a buffer)
+    auto stage = [&](int kind, int buf, int kt) {
+        char* dst = smem + buf * BUF8 + kind * HT8 + wave * 2048;
+        const bool tail = (kt + 1) * TK > p.K;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bf16_t* s = kind == 0 ? sA[0][j] : kind == 1 ? sA[1][j] : kind == 2 ? sB[0][j] : sB[1][j];
+            const bool zero = tail && (kt * TK + kch[j] * 8 >= p.K);
+            glds16(zero ? zsrc : (const void*)(s + (long)kt * TK), dst + j * 1024);
+        }
+    };
+    auto prologue = [&]() {                       // K-tile 0 complete + three half-tiles of K-tile 1
+        stage(0, 0, 0); stage(2, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
+        if (nk > 1) { stage(0, 1, 1); stage(2, 1, 1); stage(3, 1, 1); }
+    };
+
+    // fragment addresses: row rho = wr*64 + mt*16 + (lane & 15) (A) / wc*32 + nt*16 + (lane & 15) (B); (rho >> 1) & 7 = (lane >> 1) & 7
+    const int sw = (lane >> 1) & 7;
+    int aoff[2], boff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int c = ((ks * 4 + (lane >> 4)) ^ sw) << 4;
+        aoff[ks] = (wr * 64 + (lane & 15)) * 128 + c;
+        boff[ks] = (wc * 32 + (lane & 15)) * 128 + c;
+    }
+    f32x4 acc[8][4];
+    bf16x8 af[4][2], bfr[2][2][2];
+    auto read_a = [&](const char* base, int h) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) af[mt][ks] = *reinterpret_cast<const bf16x8*>(base + h * HT8 + aoff[ks] + mt * 2048);
+    };
+    auto read_b = [&](const char* base, int h) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                bfr[h][nt][ks] = *reinterpret_cast<const bf16x8*>(base + (2 + h) * HT8 + boff[ks] + nt * 2048);
+    };
+    auto mma = [&](int mh, int nh) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mh * 4 + mt][nh * 2 + nt] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nh][nt][ks], af[mt][ks], acc[mh * 4 + mt][nh * 2 + nt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define V8_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define V8_BAR() __builtin_amdgcn_s_barrier()
+
+    const int rounds = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    int bm = 0, bn = 0;
+    bool live = tile_id(0) < ntiles;               // the ids of one round are a permutation of it*grid .. it*grid + grid - 1
+    if (live) { coords(tile_id(0), bm, bn); sources(bm, bn); prologue(); }
+    for (int it = 0; it < rounds && live; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        V8_BAR();
+        if (wr == 1) V8_BAR();                     // waves 4-7 run one barrier behind
+        for (int t = 0; t < nk; ++t) {
+            const int d = t & 1;
+            const char* base = smem + d * BUF8;
+            const bool more = t + 2 < nk;
+            // phase 0
+            read_b(base, 0);
+            read_a(base, 0);
+            if (t + 1 < nk) stage(1, d ^ 1, t + 1);
+            V8_LGKM0();
+            V8_BAR();
+            mma(0, 0);
+            V8_BAR();
+            // phase 1
+            read_b(base, 1);
+            if (more) stage(0, d, t + 2);
+            V8_LGKM0();
+            V8_BAR();
+            mma(0, 1);
+            V8_BAR();
+            // phase 2
+            read_a(base, 1);
+            if (more) stage(2, d, t + 2);
+            V8_LGKM0();
+            V8_BAR();
+            mma(1, 1);
+            V8_BAR();
+            // phase 3
+            if (more) {
+                stage(3, d, t + 2);
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            V8_BAR();
+            mma(1, 0);
+            V8_BAR();
+        }
+        if (wr == 0) V8_BAR();                     // realign: every wave has finished reading the operand buffers
+
+        const int cbm = bm, cbn = bn;
+        live = tile_id(it + 1) < ntiles;
+        if (live) { coords(tile_id(it + 1), bm, bn); sources(bm, bn); prologue(); }
+
+        // epilogue of (cbm, cbn): acc[mi][ni][j] = C[cbm + wr*128 + mi*16 + (lane & 15)][cbn + wc*64 + ni*16 + (lane >> 4)*4 + j]
+        // -> private f32 image [16 rows][64 cols], 16-byte chunk c of row r at slot c ^ r -> rows of 256 B
+        TC* C = reinterpret_cast<TC*>(p.C);
+        char* img = smem + 2 * BUF8 + wave * 4096;
+        const bool vec = (p.ldc % 4 == 0) && ((reinterpret_cast<size_t>(p.C) & 15) == 0) &&
+                         (!p.addend || (reinterpret_cast<size_t>(p.addend) & 15) == 0) &&
+                         (!p.mask || (reinterpret_cast<size_t>(p.mask) & 7) == 0) && (!p.bias || (reinterpret_cast<size_t>(p.bias) & 15) == 0);
+        const int wrow = lane & 15, wq = lane >> 4;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                *reinterpret_cast<f32x4*>(img + wrow * 256 + (((ni * 4 + wq) ^ wrow) << 4)) = acc[mi][ni];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = q * 4 + (lane >> 4);                    // row of the 16-row slab
+                const int c = (lane & 15) ^ r;                        // logical 4-column chunk held by slot lane & 15
+                const f32x4 x = *reinterpret_cast<const f32x4*>(img + r * 256 + ((lane & 15) << 4));
+                const int m = cbm + wr * 128 + mi * 16 + r;
+                const int n0 = cbn + wc * 64 + c * 4;
+                if (m >= p.M || n0 >= p.N) continue;
+                const long ci = (long)m * p.ldc + n0;
+                float v[4] = {x[0], x[1], x[2], x[3]};
+                if (vec && n0 + 3 < p.N) {
+                    if (p.bias) {
+                        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0);   // n0 % 4 == 0; bias from hipMalloc/torch: 16-B aligned rows
+                        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                    }
+                    if (p.addend) {
+                        const float4 a = *reinterpret_cast<const float4*>(p.addend + ci);
+                        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                    }
+                    if (p.mask) {
+                        const uint2 mk = *reinterpret_cast<const uint2*>(p.mask + ci);
+                        const unsigned short ms[4] = {(unsigned short)(mk.x & 0xffff), (unsigned short)(mk.x >> 16),
+                                                      (unsigned short)(mk.y & 0xffff), (unsigned short)(mk.y >> 16)};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = bf16_to_f32(ms[j]) > 0.f ? v[j] * p.scale : 0.f;
+                    }
+                    if (p.drop.p > 0.f) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] *= drop_mult(p.drop, (unsigned long long)(ci + j));
+                    }
+                    if constexpr (sizeof(TC) == 4) {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(C) + ci) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        uint2 o;
+                        o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                        o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(C) + ci) = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (n0 + j >= p.N) continue;
+                        float y = v[j] + (p.bias ? p.bias[n0 + j] : 0.f);
+                        if (p.addend) y += p.addend[ci + j];
+                        if (p.relu) y = fmaxf(y, 0.f);
+                        if (p.mask) y = bf16_to_f32(p.mask[ci + j]) > 0.f ? y * p.scale : 0.f;
+                        y *= drop_mult(p.drop, (unsigned long long)(ci + j));
+                        if constexpr (sizeof(TC) == 4) reinterpret_cast<float*>(C)[ci + j] = y;
+                        else reinterpret_cast<bf16_t*>(C)[ci + j] = f32_to_bf16(y);
+                    }
+                }
+            }
+        }
+    }
+#undef V8_LGKM0
+#undef V8_BAR
+}
+
 template <typename K>
 int enable_lds(K kernel, int bytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -513,6 +762,7 @@ int enable_lds(K kernel, int bytes) {
 // Measured and dropped (same box, joint projection M=816000 N=4334 K=1024, v4 = 720 TFLOP/s): 256x128 3-stage ring with
 // counted vmcnt 621; persistent 256x256 with a 4-slice ring that never drains 668 (dgrad K=4352: 904 vs 938 for v6).
 int g_gemm_fast_version = 4;
+int g_num_cus = 0;
 int g_tn_target_blocks = 512;     // split-K aims at this many workgroups for small outputs (ttmi_set_option(4, n))
 
 
@@ -540,6 +790,26 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     TTMI_REQUIRE(nbatch >= 1 && nbatch <= 65535, "gemm_nt_bf16: bad batch count %d", nbatch);
     // 256x256 tiles pay off when the K loop is long enough to amortise the un-overlapped epilogue of a one-workgroup-per-CU
     // kernel and there are enough tiles to fill the chip (joint dgrad: K = 4352 -> 954 vs 880 TFLOP/s; short-K forward: worse)
+    if (g_gemm_fast_version == 8 && M >= 1024 && N >= 256 && nbatch == 1) {
+        if (g_num_cus == 0) {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+                g_num_cus = n / 8 * 8;        // the tile walk assumes a multiple of 8 (one share per XCD)
+            if (g_num_cus <= 0) g_num_cus = 256;
+        }
+        p.tiles_m = cdiv(M, T8); p.tiles_n = cdiv(N, T8);
+        const long nwg8 = (long)p.tiles_m * p.tiles_n;
+const int grid8 = (int)((std::min<long>(nwg8, g_num_cus) + 7) / 8 * 8);   // multiple of 8: one share of every round per XCD
+        if (c_dtype == 0) {
+            if (int rc = enable_lds(gemm_nt_bf16_v8_kernel<float>, LDS8)) return rc;
+            hipLaunchKernelGGL(gemm_nt_bf16_v8_kernel<float>, dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
+        } else {
+            if (int rc = enable_lds(gemm_nt_bf16_v8_kernel<bf16_t>, LDS8)) return rc;
+            hipLaunchKernelGGL(gemm_nt_bf16_v8_kernel<bf16_t>, dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
+        }
+        TTMI_LAUNCH_CHECK("gemm_nt_bf16_v8_kernel");
+        return TTMI_OK;
+    }
     const bool big = (g_gemm_fast_version == 6) || (g_gemm_fast_version == 4 && K >= 2048 && (long)cdiv(M, T6) * cdiv(N, T6) >= 1024);
     if (big && M >= 1024 && N >= 256 && nbatch == 1) {
         p.tiles_m = cdiv(M, T6); p.tiles_n = cdiv(N, T6);
