@@ -68,7 +68,7 @@ def test_both_kernel_generations_agree():
     A, B = _ints((4096, 512), g), _ints((640, 512), g)
     At, Bt = _ints((8192, 520), g), _ints((8192, 264), g)
     want_nt, want_tn = A.float() @ B.float().t(), At[:, :512].float().t() @ Bt[:, :260].float()
-    for v in (1, 3, 4, 6):
+    for v in (1, 3, 4, 5, 6, 8):
         ops.set_option(1, v)
         C = torch.zeros(4096, 640, device="cuda")
         ops.gemm_nt_bf16(A, B, C)
@@ -85,3 +85,25 @@ def test_both_kernel_generations_agree():
             ops.gemm_nt_bf16(A2, B2, C2, bias)
             assert torch.equal(C2, (A2.float() @ B2.float().t() + bias).to(cdt)), (M, N, K, cdt)
     ops.set_option(1, 4)
+
+
+@pytest.mark.parametrize("M,N,K,pad", [(1024, 256, 64, 0), (1024, 256, 128, 0), (1024, 256, 192, 0), (1030, 700, 72, 3),
+                                       (2048, 260, 320, 4), (5000, 4334, 1024, 18), (3000, 1024, 4352, 0), (1025, 257, 1000, 0),
+                                       (70000, 1100, 512, 0)])
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_persistent_256_kernel_exact(M, N, K, pad, cdt):
+    """v8 (persistent 256x256, staggered wave groups, counted vmcnt, LDS-transposed epilogue): exact on small integers for
+    1..68 K-tiles, K tails, ragged M/N, padded output pitch (pad columns untouched), several rounds of tiles per CU"""
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A, B = _ints((M, K), g), _ints((N, K), g)
+    bias = torch.randint(-3, 4, (N,), device="cuda", generator=g).float()
+    Cfull = torch.full((M, N + pad), 5.0, device="cuda", dtype=cdt)
+    ops.set_option(1, 8)
+    try:
+        ops.gemm_nt_bf16(A, B, Cfull[:, :N], bias)
+    finally:
+        ops.set_option(1, 4)
+    assert torch.equal(Cfull[:, :N], (A.float() @ B.float().t() + bias).to(cdt))
+    if pad:
+        assert bool((Cfull[:, N:] == 5.0).all())

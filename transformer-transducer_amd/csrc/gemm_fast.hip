@@ -504,22 +504,24 @@ __global__ __launch_bounds__(NTH6, 1) void gemm_nt_bf16_v6_kernel(const FP p) {
 // v8: persistent 256x256x64 kernel, one 512-thread workgroup per CU, 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 = 8 x 4
 // v_mfma_f32_16x16x32_bf16 tiles (128 accumulator registers), 2 x 64 KiB operand buffers + 32 KiB epilogue staging in LDS.
 // A K-tile is staged as four 16 KiB half-tiles (A rows with (row>>6)&1 = h, B columns with (col>>5)&1 = h) and consumed in
-// four phases, one 64x32 accumulator quadrant x K=64 (16 MFMAs) each:
-//     phase 0: read A(h0) B(h0) | mma (0,0)      phase 1: read B(h1) | mma (0,1)
-//     phase 2: read A(h1)       | mma (1,1)      phase 3:            | mma (1,0)
-// Every phase = [LDS reads + one half-tile of global_load_lds + s_waitcnt lgkmcnt(0)] s_barrier [16 MFMAs] s_barrier.  Waves
-// 4-7 (the SIMD partners of waves 0-3) run one barrier behind, so in every barrier interval one wave per SIMD issues MFMAs
-// while its partner reads LDS / issues the prefetch.  Loads are never drained inside the loop: each half-tile region is
-// re-staged one phase after its last read (A(h0) of tile t+2 in phase 1, B(h0) in 2, B(h1) in 3, A(h1) in phase 0 of t+1),
-// and one counted s_waitcnt vmcnt(6) per K-tile (phase 3: three half-tiles stay in flight) followed by a barrier orders the
-// LDS-DMA of tile t+1 before its first read in the next phase.  (Stores of the previous output tile may still be counted by
-// vmcnt: loads retire in order among themselves, so a counted wait can only be conservative.)
+// two phases of 32 MFMAs (half the wave tile's rows x K=64):
+//     phase A: read A(h0) B(h0) B(h1) | mma rows h0      phase B: read A(h1) | mma rows h1
+// Every phase = [LDS reads + global_load_lds prefetch + s_waitcnt lgkmcnt(0)] s_barrier [32 MFMAs] s_barrier.  Waves 4-7 (the
+// SIMD partners of waves 0-3) run one barrier behind, so in every barrier interval one wave per SIMD issues MFMAs while its
+// partner reads LDS / issues the prefetch.  Loads are never drained inside the loop: a half-tile region is re-staged in the
+// phase after its last read (A(h1) of K-tile t+1 in phase A, the other three of K-tile t+2 in phase B), and one counted
+// s_waitcnt vmcnt(6) per K-tile (phase B: three half-tiles stay in flight) followed by a barrier orders the LDS-DMA of tile
+// t+1 before its first read in the next phase.  (Stores of the previous output tile may still be counted by vmcnt: loads
+// retire in order among themselves, so a counted wait can only be conservative.)
+// Measured on MI355X (random operands): 8192^3 1505 TFLOP/s, joint dgrad (K=4352) 1264, joint forward (K=1024, 7 GB of bf16
+// output) 957; with four phases of 16 MFMAs (8 barriers per K-tile) 1314 / 1190 / 933; v4 128x128: 1052 / 939 / 736.
 // Output: the MFMA takes the B fragment as its row operand, so a lane holds 4 consecutive columns of one C row; each wave
 // passes its accumulators 16 rows at a time through a private 4 KiB f32 LDS image (XOR-swizzled) and writes whole 128-byte
 // (bf16) / 256-byte (f32) row segments.  The next output tile's first seven half-tiles are already in flight while the
 // epilogue runs, and its stores drain under the next tile's MFMAs.
 // =====================================================================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr int T8 = 256, NTH8 = 512, HT8 = 128 * 64 * 2, BUF8 = 4 * HT8;   // buffer: [A h0 | A h1 | B h0 | B h1]
 constexpr int LDS8 = 2 * BUF8 + 8 * 4096;
 
@@ -635,36 +637,27 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
             const int d = t & 1;
             const char* base = smem + d * BUF8;
             const bool more = t + 2 < nk;
-            // phase 0
-            read_b(base, 0);
+            // phase A: rows h0 of the wave tile x all 64 columns
             read_a(base, 0);
+            read_b(base, 0);
+            read_b(base, 1);
             if (t + 1 < nk) stage(1, d ^ 1, t + 1);
-            V8_LGKM0();
+            V8_LGKM0();                            // A(h0), B(h0), B(h1) are re-staged next phase: their reads must have retired
             V8_BAR();
             mma(0, 0);
-            V8_BAR();
-            // phase 1
-            read_b(base, 1);
-            if (more) stage(0, d, t + 2);
-            V8_LGKM0();
-            V8_BAR();
             mma(0, 1);
             V8_BAR();
-            // phase 2
+            // phase B: rows h1
             read_a(base, 1);
-            if (more) stage(2, d, t + 2);
-            V8_LGKM0();
-            V8_BAR();
-            mma(1, 1);
-            V8_BAR();
-            // phase 3
             if (more) {
-                stage(3, d, t + 2);
+                stage(0, d, t + 2); stage(2, d, t + 2); stage(3, d, t + 2);
                 asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            V8_LGKM0();
             V8_BAR();
+            mma(1, 1);
             mma(1, 0);
             V8_BAR();
         }
@@ -722,12 +715,13 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                         for (int j = 0; j < 4; ++j) v[j] *= drop_mult(p.drop, (unsigned long long)(ci + j));
                     }
                     if constexpr (sizeof(TC) == 4) {
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(C) + ci) = make_float4(v[0], v[1], v[2], v[3]);
+                        const f32x4 o = {v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + ci) = o;
                     } else {
-                        uint2 o;
+                        u32x2 o;
                         o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
                         o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(C) + ci) = o;
+                        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(C) + ci) = o;
                     }
                 } else {
 #pragma unroll
@@ -758,7 +752,8 @@ int enable_lds(K kernel, int bytes) {
 
 // ttmi_set_option(1, v) - A/B measurements: 1 = 128x128 double-buffered, 3 = 1 + software-pipelined fragment reads,
 // 4 (default) = single 32 KiB buffer, 4 workgroups per CU, one fragment set (stays under 128 VGPRs without spills; NT +15 % at
-// the joint shapes; TN +8 % once each XCD owns a K-range) with the 256x256 kernel for long-K shapes, 6 = 256x256 wherever it fits.
+// the joint shapes; TN +8 % once each XCD owns a K-range) with the persistent 256x256 kernel (v8) for outputs of >= 1024 tiles,
+// 5 = 4 without v8, 6 = the earlier double-buffered 256x256 kernel wherever it fits, 8 = v8 wherever it fits.
 // Measured and dropped (same box, joint projection M=816000 N=4334 K=1024, v4 = 720 TFLOP/s): 256x128 3-stage ring with
 // counted vmcnt 621; persistent 256x256 with a 4-slice ring that never drains 668 (dgrad K=4352: 904 vs 938 for v6).
 int g_gemm_fast_version = 4;
@@ -790,7 +785,10 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     TTMI_REQUIRE(nbatch >= 1 && nbatch <= 65535, "gemm_nt_bf16: bad batch count %d", nbatch);
     // 256x256 tiles pay off when the K loop is long enough to amortise the un-overlapped epilogue of a one-workgroup-per-CU
     // kernel and there are enough tiles to fill the chip (joint dgrad: K = 4352 -> 954 vs 880 TFLOP/s; short-K forward: worse)
-    if (g_gemm_fast_version == 8 && M >= 1024 && N >= 256 && nbatch == 1) {
+    // persistent 256x256 kernel: needs several rounds of tiles per CU to amortise its pipeline fill and tail
+    const bool v8 = (g_gemm_fast_version == 8 && M >= 1024 && N >= 256) ||
+                    (g_gemm_fast_version == 4 && (long)cdiv(M, T8) * cdiv(N, T8) >= 1024 && K >= 512);
+    if (v8 && nbatch == 1) {
         if (g_num_cus == 0) {
             int dev = 0, n = 0;
             if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
@@ -800,7 +798,7 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
         p.tiles_m = cdiv(M, T8); p.tiles_n = cdiv(N, T8);
         const long nwg8 = (long)p.tiles_m * p.tiles_n;
 const int grid8 = (int)((std::min<long>(nwg8, g_num_cus) + 7) / 8 * 8);   // multiple of 8: one share of every round per XCD
-        if (c_dtype == 0) {
+if (c_dtype == 0) {
             if (int rc = enable_lds(gemm_nt_bf16_v8_kernel<float>, LDS8)) return rc;
             hipLaunchKernelGGL(gemm_nt_bf16_v8_kernel<float>, dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
         } else {
@@ -810,7 +808,7 @@ const int grid8 = (int)((std::min<long>(nwg8, g_num_cus) + 7) / 8 * 8);   // mul
         TTMI_LAUNCH_CHECK("gemm_nt_bf16_v8_kernel");
         return TTMI_OK;
     }
-    const bool big = (g_gemm_fast_version == 6) || (g_gemm_fast_version == 4 && K >= 2048 && (long)cdiv(M, T6) * cdiv(N, T6) >= 1024);
+    const bool big = (g_gemm_fast_version == 6);
     if (big && M >= 1024 && N >= 256 && nbatch == 1) {
         p.tiles_m = cdiv(M, T6); p.tiles_n = cdiv(N, T6);
         const long nwg6 = (long)p.tiles_m * p.tiles_n;
