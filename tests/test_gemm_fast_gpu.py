@@ -107,3 +107,21 @@ def test_persistent_256_kernel_exact(M, N, K, pad, cdt):
     assert torch.equal(Cfull[:, :N], (A.float() @ B.float().t() + bias).to(cdt))
     if pad:
         assert bool((Cfull[:, N:] == 5.0).all())
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 1024, 32768), (1124, 1024, 40000), (2048, 1024, 33001), (4334, 1024, 65606)])
+def test_persistent_256_wgrad_kernel_exact(M, N, K):
+    """TN v8 (huge-reduction wgrad: persistent 256x256, transposed LDS reads, K-ranges per XCD, atomics, fused column sums via an
+    all-ones MFMA) + the 128x128 kernel on the M % 256 strip: exact on small integers, K tail, with and without column sums"""
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    lda = (M + 7) // 8 * 8 + 8
+    A, B = _ints((K, lda), g), _ints((K, N), g)
+    want, wcs = A[:, :M].float().t() @ B.float(), A[:, :M].float().sum(0)
+    C = torch.ones(M, N, device="cuda")
+    cs = torch.full((M,), 3.0, device="cuda")
+    ops.gemm_tn_bf16(A[:, :M], B, C, accumulate=True, colsum_a=cs)
+    assert torch.equal(C, want + 1) and torch.equal(cs, wcs + 3)
+    C.fill_(1.0)
+    ops.gemm_tn_bf16(A[:, :M], B, C, accumulate=True)
+    assert torch.equal(C, want + 1)

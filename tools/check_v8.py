@@ -41,6 +41,33 @@ def check():
     return bad
 
 
+def check_tn():
+    g = torch.Generator(device="cuda").manual_seed(7)
+    bad = 0
+    for (M, N, K) in [(1024, 1024, 32768), (1124, 1024, 40000), (2048, 1024, 33001), (4334, 1024, 65536 + 70)]:
+        lda = (M + 7) // 8 * 8 + 8
+        A, B = ints((K, lda), g), ints((K, N), g)
+        want = A[:, :M].float().t() @ B.float()
+        wcs = A[:, :M].float().sum(0)
+        for ver in (4, 5):
+            ops.set_option(1, ver)
+            C = torch.ones(M, N, device="cuda")
+            cs = torch.full((M,), 3.0, device="cuda")
+            ops.gemm_tn_bf16(A[:, :M], B, C, accumulate=True, colsum_a=cs)
+            C2 = torch.ones(M, N, device="cuda")
+            ops.gemm_tn_bf16(A[:, :M], B, C2, accumulate=True)
+            ops.set_option(1, 4)
+            ok = torch.equal(C, want + 1) and torch.equal(cs, wcs + 3) and torch.equal(C2, want + 1)
+            if not ok:
+                bad += 1
+                d = (C - want - 1).abs()
+                print("TN MISMATCH v%d" % ver, M, N, K, "C bad", int((d > 0).sum()), "first", (d > 0).nonzero()[:4].tolist(),
+                      "cs bad", int(((cs - wcs - 3).abs() > 0).sum()), "C2 bad", int(((C2 - want - 1).abs() > 0).sum()), flush=True)
+            else:
+                print("tn ok v%d" % ver, M, N, K, flush=True)
+    return bad
+
+
 def timeit(fn, n=5):
     fn()
     torch.cuda.synchronize()
@@ -77,11 +104,19 @@ def bench():
         ]:
             ms = timeit(fn)
             print("v%d %-40s %8.3f ms  %7.1f TFLOP/s" % (ver, name, ms, f / ms / 1e9), flush=True)
+    gW = torch.zeros(Vv, J, device="cuda")
+    gb = torch.zeros(Vv, device="cuda")
+    for ver in (5, 4):
+        ops.set_option(1, ver)
+        ms = timeit(lambda: ops.gemm_tn_bf16(Z[:, :Vv], H, gW, accumulate=True, colsum_a=gb))
+        print("v%d joint wgrad + colsum M=%d N=%d K=%d %8.3f ms  %7.1f TFLOP/s" % (ver, Vv, J, M, ms, 2.0 * M * Vv * J / ms / 1e9), flush=True)
+        ms = timeit(lambda: ops.gemm_tn_bf16(Z[:, :Vv], H, gW, accumulate=True))
+        print("v%d joint wgrad          %8.3f ms  %7.1f TFLOP/s" % (ver, ms, 2.0 * M * Vv * J / ms / 1e9), flush=True)
     ops.set_option(1, 4)
 
 
 if __name__ == "__main__":
-    bad = check()
+    bad = check() + check_tn()
     if bad:
         sys.exit(1)
     bench()

@@ -743,6 +743,216 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
 #undef V8_BAR
 }
 
+// =====================================================================================================================
+// v8 TN (wgrad with a huge reduction: C[M,N] += A[K,M]^T B[K,N], K >> M, N): the NT v8 schedule (256x256x64 tile, 8 waves as
+// 2 x 4, two phases of 32 v_mfma_f32_16x16x32_bf16 per K-tile, waves 4-7 one barrier behind, counted vmcnt) with both operands
+// reduction-major in LDS and every fragment read through ds_read_b64_tr_b16.
+// LDS regions (16 KiB each, 2 buffers): A(h) = [64 k][128 m], m = block rows h*128..+127; B(h) = [64 k][128 n] likewise; 256-byte
+// k-rows whose 16-byte chunks are XOR-swizzled by sw(k) = (k & 3) << 2 | ((k >> 3) & 1) << 1 through the glds SOURCE address, so
+// the 4 k-rows x 2 k-octets a half-wave's transposed read touches fall on 8 distinct 32-byte bank groups.
+// The wave tile is two 64-row strips (rows h*128 + wr*64 ..) x 64 columns: phase A needs only A(h0), phase B only A(h1).
+// Work: grid = one workgroup per CU; the reduction is cut into 8*S ranges, XCD x (workgroup ids equal mod 8) owns ranges
+// x*S..x*S+S-1 and its 32 workgroups walk the item list (range-major, then output tile), so the workgroups that run together
+// on an XCD stream the SAME rows of A and B through that XCD's L2.  Results are added to C with f32 atomics.
+// Fused bias gradient: colsum[m] += sum_k A[k][m] comes out of one extra MFMA per wave and K-tile against an all-ones fragment -
+// the 4 column tiles x 4 waves that read the same A rows each take one of the 16 (strip, 16-row tile, k-half) pieces.
+// =====================================================================================================================
+constexpr int LDS8T = 2 * BUF8;
+
+template <bool CS>
+__global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int S = p.splitk;                                // K-ranges per XCD
+    const int xcd = blockIdx.x & 7, cu = blockIdx.x >> 3, ncu = gridDim.x >> 3;
+    const int nitems = S * ntiles;
+    const int nkt = (p.K + TK - 1) / TK;                   // K-tiles in all
+    const int per = p.ksteps;                              // K-tiles per range
+    const void* zsrc = &g_zero16;
+
+    // staging: unit u = 2*wave + j covers k-rows 4u + (lane >> 4) of a region, 16-byte slot lane & 15 <- source chunk slot ^ sw(k)
+    int kst[2], cst[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        kst[j] = (wave * 2 + j) * 4 + (lane >> 4);
+        cst[j] = (lane & 15) ^ (((kst[j] & 3) << 2) | (((kst[j] >> 3) & 1) << 1));
+    }
+    const bf16_t* sA[2][2];
+    const bf16_t* sB[2][2];
+    long kbeg = 0;                                         // first reduction row of the current item
+    int nk = 0;
+    auto sources = [&](int bm, int bn, long k0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const long ca = min((long)bm + h * 128 + cst[j] * 8, p.lda - 8), cb = min((long)bn + h * 128 + cst[j] * 8, p.ldb - 8);
+                sA[h][j] = p.A + (k0 + kst[j]) * p.lda + ca;
+                sB[h][j] = p.B + (k0 + kst[j]) * p.ldb + cb;
+            }
+    };
+    auto stage = [&](int kind, int buf, int kt) {          // kind: 0 = A h0, 1 = A h1, 2 = B h0, 3 = B h1
+        char* dst = smem + buf * BUF8 + kind * HT8 + wave * 2048;
+        const long kb = kbeg + (long)kt * TK;
+        const bool tail = kb + TK > p.K;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bf16_t* s = kind == 0 ? sA[0][j] : kind == 1 ? sA[1][j] : kind == 2 ? sB[0][j] : sB[1][j];
+            const long ld = kind < 2 ? p.lda : p.ldb;
+            const bool zero = tail && (kb + kst[j] >= p.K);
+            glds16(zero ? zsrc : (const void*)(s + (long)kt * TK * ld), dst + j * 1024);
+        }
+    };
+    auto prologue = [&]() {
+        stage(0, 0, 0); stage(2, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
+        if (nk > 1) { stage(0, 1, 1); stage(2, 1, 1); stage(3, 1, 1); }
+    };
+    // item i of this XCD -> (range, tile); tiles in GROUP_M-grouped order so that co-resident tiles share A / B panels
+    auto item = [&](int i, int& bm, int& bn, int& tn) {
+        const int s = i / ntiles, t = i % ntiles;
+        const int per_group = GROUP_M * p.tiles_n;
+        const int group = t / per_group, in = t % per_group;
+        const int first = group * GROUP_M;
+        const int gsz = min(p.tiles_m - first, GROUP_M);
+        bm = (first + in % gsz) * T8;
+        tn = in / gsz;
+        bn = tn * T8;
+        const long r = (long)xcd * S + s;
+        kbeg = r * per * TK;
+        nk = (int)max(0L, min((long)per, (long)nkt - r * per));
+    };
+
+    // transposed fragment reads: group g = lane >> 4 (the k-octet), lane 4q + pp of the group addresses k-row q, columns 4pp..4pp+3
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int swz = (q << 2) | ((g & 1) << 1);
+    int aoff[4], boff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ca = wr * 64 + i * 16 + 4 * pp, cb = (wc & 1) * 64 + i * 16 + 4 * pp;
+        aoff[i] = (g * 8 + q) * 256 + (((ca >> 3) ^ swz) << 4) + (ca & 7) * 2;
+        boff[i] = (2 + (wc >> 1)) * HT8 + (g * 8 + q) * 256 + (((cb >> 3) ^ swz) << 4) + (cb & 7) * 2;
+    }
+    f32x4 acc[8][4];
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[4][2], bfr[4][2];
+    auto read_a = [&](const char* base, int h) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const char* a = base + h * HT8 + aoff[mt] + ks * 8192;
+                af[mt][ks] = __builtin_shufflevector(ds_read_tr16(a), ds_read_tr16(a + 1024), 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+    };
+    auto read_b = [&](const char* base) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const char* a = base + boff[nt] + ks * 8192;
+                bfr[nt][ks] = __builtin_shufflevector(ds_read_tr16(a), ds_read_tr16(a + 1024), 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+    };
+    auto mma = [&](int mh) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mh * 4 + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt][ks], af[mt][ks], acc[mh * 4 + mt][nt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+    int cs_unit = -1;                                      // (mh, mt, ks) piece of the column sums this wave owns for the current item
+    auto colsum_mma = [&](int mh) {
+        if (!CS) return;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                if (cs_unit == mh * 8 + mt * 2 + ks) cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[mt][ks], cs, 0, 0, 0);
+    };
+#define V8_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define V8_BAR() __builtin_amdgcn_s_barrier()
+
+    int bm = 0, bn = 0, tn = 0;
+    int it = cu;
+    bool live = it < nitems;
+    if (live) { item(it, bm, bn, tn); sources(bm, bn, kbeg); prologue(); }
+    while (live) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        cs = f32x4{0.f, 0.f, 0.f, 0.f};
+        cs_unit = CS ? __builtin_amdgcn_readfirstlane((tn & 3) * 4 + wc) : -1;
+        const int cnk = nk;
+        if (cnk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        V8_BAR();
+        if (wr == 1) V8_BAR();
+        for (int t = 0; t < cnk; ++t) {
+            const int d = t & 1;
+            const char* base = smem + d * BUF8;
+            const bool more = t + 2 < cnk;
+            read_a(base, 0);
+            read_b(base);
+            if (t + 1 < cnk) stage(1, d ^ 1, t + 1);
+            V8_LGKM0();
+            V8_BAR();
+            mma(0);
+            colsum_mma(0);
+            V8_BAR();
+            read_a(base, 1);
+            if (more) {
+                stage(0, d, t + 2); stage(2, d, t + 2); stage(3, d, t + 2);
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            V8_LGKM0();
+            V8_BAR();
+            mma(1);
+            colsum_mma(1);
+            V8_BAR();
+        }
+        if (wr == 0) V8_BAR();
+
+        const int cbm = bm, cbn = bn, cunit = cs_unit;
+        it += ncu;
+        live = it < nitems;
+        if (live) { item(it, bm, bn, tn); sources(bm, bn, kbeg); prologue(); }
+
+        if (cnk > 0) {
+            float* C = reinterpret_cast<float*>(p.C);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const int m = cbm + (mi >> 2) * 128 + wr * 64 + (mi & 3) * 16 + (lane & 15);
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int n0 = cbn + wc * 64 + ni * 16 + (lane >> 4) * 4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (n0 + j < p.N) atomicAdd(C + (long)m * p.ldc + n0 + j, acc[mi][ni][j]);
+                }
+            }
+            if (CS && lane < 16) {
+                const int m = cbm + (cunit >> 3) * 128 + wr * 64 + ((cunit >> 1) & 3) * 16 + lane;
+                if (m < p.M) atomicAdd(p.colsum + m, cs[0]);
+            }
+        }
+    }
+#undef V8_LGKM0
+#undef V8_BAR
+}
+
 template <typename K>
 int enable_lds(K kernel, int bytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -856,6 +1066,38 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
     fill_batch(p, batch);
     const int nbatch = batch.nz1 * batch.nz2;
     TTMI_REQUIRE(nbatch >= 1 && nbatch <= 65535, "gemm_tn_bf16: bad batch count %d", nbatch);
+    // huge-reduction wgrad (the joint projection: K = B*T*U1 rows): persistent 256x256 kernel on the 256-row tiles that are
+    // full, the 128x128 kernel below on the remaining M % 256 rows
+    const bool tn8 = (g_gemm_fast_version == 4 || g_gemm_fast_version == 8) && nbatch == 1 && accumulate && K >= 32768 &&
+                     M >= 1024 && N >= 256 && N % 256 == 0 && (N / 256) % 4 == 0;
+    if (tn8) {
+        if (g_num_cus == 0) {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+                g_num_cus = n / 8 * 8;
+            if (g_num_cus <= 0) g_num_cus = 256;
+        }
+        const int Mfull = M / T8 * T8;
+        p.M = Mfull; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+        p.tiles_m = Mfull / T8; p.tiles_n = N / T8;
+        const int ntile = p.tiles_m * p.tiles_n, ncu_x = g_num_cus / 8;
+        int S = 1;                                          // K-ranges per XCD: fill every CU of the XCD, then balance the rounds
+        while (S * ntile < ncu_x || ((S * ntile) % ncu_x != 0 && S * ntile < 8 * ncu_x)) ++S;
+        const int nkt = cdiv(K, TK);
+        p.splitk = S; p.ksteps = cdiv(nkt, 8 * S); p.atomic = 1; p.gm = GROUP_M;
+        if (colsum_a) {
+            if (int rc = enable_lds(gemm_tn_bf16_v8_kernel<true>, LDS8T)) return rc;
+            hipLaunchKernelGGL(gemm_tn_bf16_v8_kernel<true>, dim3((unsigned)g_num_cus), dim3(NTH8), LDS8T, st, p);
+        } else {
+            if (int rc = enable_lds(gemm_tn_bf16_v8_kernel<false>, LDS8T)) return rc;
+            hipLaunchKernelGGL(gemm_tn_bf16_v8_kernel<false>, dim3((unsigned)g_num_cus), dim3(NTH8), LDS8T, st, p);
+        }
+        TTMI_LAUNCH_CHECK("gemm_tn_bf16_v8_kernel");
+        if (Mfull == M) return TTMI_OK;
+        A += Mfull; C += (long)Mfull * ldc; M -= Mfull;     // the strip: same call, remaining rows of C
+        if (colsum_a) colsum_a += Mfull;
+        p.A = A; p.C = C; p.colsum = colsum_a;
+    }
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.tiles_m = cdiv(M, TM); p.tiles_n = cdiv(N, TN_);
     const long tiles = (long)p.tiles_m * p.tiles_n;
