@@ -49,7 +49,7 @@ def check_tn():
         A, B = ints((K, lda), g), ints((K, N), g)
         want = A[:, :M].float().t() @ B.float()
         wcs = A[:, :M].float().sum(0)
-        for ver in (4, 5):
+        for ver in (4, 5, 8):
             ops.set_option(1, ver)
             C = torch.ones(M, N, device="cuda")
             cs = torch.full((M,), 3.0, device="cuda")
@@ -106,7 +106,7 @@ def bench():
             print("v%d %-40s %8.3f ms  %7.1f TFLOP/s" % (ver, name, ms, f / ms / 1e9), flush=True)
     gW = torch.zeros(Vv, J, device="cuda")
     gb = torch.zeros(Vv, device="cuda")
-    for ver in (5, 4):
+    for ver in (5, 4, 8):
         ops.set_option(1, ver)
         ms = timeit(lambda: ops.gemm_tn_bf16(Z[:, :Vv], H, gW, accumulate=True, colsum_a=gb))
         print("v%d joint wgrad + colsum M=%d N=%d K=%d %8.3f ms  %7.1f TFLOP/s" % (ver, Vv, J, M, ms, 2.0 * M * Vv * J / ms / 1e9), flush=True)

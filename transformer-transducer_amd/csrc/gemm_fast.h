@@ -14,7 +14,8 @@ struct FastBatch {
 struct NtEpilogue {
     const float* bias = nullptr;
     const float* addend = nullptr;   // f32, same layout as C (residual add)
-    const bf16_t* mask = nullptr;    // bf16, same layout as C (ReLU backward)
+    const bf16_t* mask = nullptr;    // bf16, same layout as C: mask_mode 0 = ReLU backward (v = mask > 0 ? v * scale : 0), 1 = tanh backward (v *= 1 - mask^2)
+    int mask_mode = 0;
     int relu = 0;
     float scale = 1.f;               // applied to the masked result (1/(1-p) of a dropped ReLU in backward)
     DropSpec drop;                   // dropout on the result (after ReLU), element index m*ldc + n

@@ -35,6 +35,7 @@ struct FP {
     const float* bias;
     const float* addend;
     const bf16_t* mask;
+    int mask_mode;
     int relu;
     float scale;
     DropSpec drop;
@@ -83,7 +84,10 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], const FP& 
                 const long ci = (long)m * p.ldc + n;
                 if (p.addend) v += p.addend[ci];
                 if (p.relu) v = fmaxf(v, 0.f);
-                if (p.mask) v = bf16_to_f32(p.mask[ci]) > 0.f ? v * p.scale : 0.f;
+                if (p.mask) {
+                    const float mv = bf16_to_f32(p.mask[ci]);
+                    v = p.mask_mode ? v * (1.f - mv * mv) : (mv > 0.f ? v * p.scale : 0.f);
+                }
                 v *= drop_mult(p.drop, (unsigned long long)ci);
                 if constexpr (sizeof(TC) == 4) {
                     if (p.atomic) atomicAdd(reinterpret_cast<float*>(C) + ci, v);
@@ -492,7 +496,10 @@ __global__ __launch_bounds__(NTH6, 1) void gemm_nt_bf16_v6_kernel(const FP p) {
                 const long ci = (long)m * p.ldc + n;
                 if (p.addend) v += p.addend[ci];
                 if (p.relu) v = fmaxf(v, 0.f);
-                if (p.mask) v = bf16_to_f32(p.mask[ci]) > 0.f ? v * p.scale : 0.f;
+                if (p.mask) {
+                    const float mv = bf16_to_f32(p.mask[ci]);
+                    v = p.mask_mode ? v * (1.f - mv * mv) : (mv > 0.f ? v * p.scale : 0.f);
+                }
                 v *= drop_mult(p.drop, (unsigned long long)ci);
                 if constexpr (sizeof(TC) == 4) reinterpret_cast<float*>(C)[ci] = v;
                 else reinterpret_cast<bf16_t*>(C)[ci] = f32_to_bf16(v);
@@ -708,7 +715,10 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                         const unsigned short ms[4] = {(unsigned short)(mk.x & 0xffff), (unsigned short)(mk.x >> 16),
                                                       (unsigned short)(mk.y & 0xffff), (unsigned short)(mk.y >> 16)};
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = bf16_to_f32(ms[j]) > 0.f ? v[j] * p.scale : 0.f;
+                        for (int j = 0; j < 4; ++j) {
+                            const float mv = bf16_to_f32(ms[j]);
+                            v[j] = p.mask_mode ? v[j] * (1.f - mv * mv) : (mv > 0.f ? v[j] * p.scale : 0.f);
+                        }
                     }
                     if (p.drop.p > 0.f) {
 #pragma unroll
@@ -730,7 +740,10 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                         float y = v[j] + (p.bias ? p.bias[n0 + j] : 0.f);
                         if (p.addend) y += p.addend[ci + j];
                         if (p.relu) y = fmaxf(y, 0.f);
-                        if (p.mask) y = bf16_to_f32(p.mask[ci + j]) > 0.f ? y * p.scale : 0.f;
+                        if (p.mask) {
+                            const float mv = bf16_to_f32(p.mask[ci + j]);
+                            y = p.mask_mode ? y * (1.f - mv * mv) : (mv > 0.f ? y * p.scale : 0.f);
+                        }
                         y *= drop_mult(p.drop, (unsigned long long)(ci + j));
                         if constexpr (sizeof(TC) == 4) reinterpret_cast<float*>(C)[ci + j] = y;
                         else reinterpret_cast<bf16_t*>(C)[ci + j] = f32_to_bf16(y);
@@ -987,7 +1000,7 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     TTMI_REQUIRE(gemm_fast_nt_ok(A, B, C, M, N, K, lda, ldb), "gemm_nt_bf16: shape/alignment not supported (M=%d N=%d K=%d)", M,
                  N, K);
     FP p;
-    p.A = A; p.B = B; p.C = C; p.bias = epi.bias; p.addend = epi.addend; p.mask = epi.mask; p.relu = epi.relu; p.scale = epi.scale; p.drop = epi.drop;
+    p.A = A; p.B = B; p.C = C; p.bias = epi.bias; p.addend = epi.addend; p.mask = epi.mask; p.mask_mode = epi.mask_mode; p.relu = epi.relu; p.scale = epi.scale; p.drop = epi.drop;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.tiles_m = cdiv(M, TM); p.tiles_n = cdiv(N, TN_); p.splitk = 1; p.ksteps = cdiv(K, TK); p.atomic = 0; p.gm = GROUP_M; p.colsum = nullptr;
     fill_batch(p, batch);
@@ -1061,7 +1074,7 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
     TTMI_REQUIRE(gemm_fast_tn_ok(A, B, C, M, N, K, lda, ldb), "gemm_tn_bf16: shape/alignment not supported (M=%d N=%d K=%d)", M,
                  N, K);
     FP p;
-    p.A = A; p.B = B; p.C = C; p.bias = nullptr; p.addend = nullptr; p.mask = nullptr; p.relu = 0; p.scale = 1.f; p.drop = DropSpec();
+    p.A = A; p.B = B; p.C = C; p.bias = nullptr; p.addend = nullptr; p.mask = nullptr; p.mask_mode = 0; p.relu = 0; p.scale = 1.f; p.drop = DropSpec();
     p.colsum = colsum_a;
     fill_batch(p, batch);
     const int nbatch = batch.nz1 * batch.nz2;
@@ -1077,9 +1090,9 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
                 g_num_cus = n / 8 * 8;
             if (g_num_cus <= 0) g_num_cus = 256;
         }
-        const int Mfull = M / T8 * T8;
+        const int Mfull = g_gemm_fast_version == 8 ? M : M / T8 * T8;     // 8: ragged last tile row inside the kernel (A/B runs)
         p.M = Mfull; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-        p.tiles_m = Mfull / T8; p.tiles_n = N / T8;
+        p.tiles_m = cdiv(Mfull, T8); p.tiles_n = N / T8;
         const int ntile = p.tiles_m * p.tiles_n, ncu_x = g_num_cus / 8;
         int S = 1;                                          // K-ranges per XCD: fill every CU of the XCD, then balance the rounds
         while (S * ntile < ncu_x || ((S * ntile) % ncu_x != 0 && S * ntile < 8 * ncu_x)) ++S;

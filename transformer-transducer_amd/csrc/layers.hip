@@ -699,9 +699,12 @@ int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float*
         TTMI_REQUIRE((size_t)J * ldg <= 2 * al4((size_t)J * (((size_t)V + 63) / 64 * 64)), "joint_bwd: pitch %ld too large for the workspace", ldg);
         CK(gemm_tn_bf16(dZ, H16, g_wp, V, J, M, ldg, J, J, 1, st, g_bp));      // g_bp = column sums of dZ, fused
         CK(transpose_convert_bf16(wp, V, J, WpT16, ldg, st));
-        CK(gemm_nt_bf16(dZ, WpT16, dH16, 1, nullptr, M, J, (int)ldg, ldg, ldg, J, st));
+        NtEpilogue e;                                                           // dH * (1 - H^2) in the dgrad epilogue
+        e.mask = H16;
+        e.mask_mode = 1;
+        CK(gemm_nt_bf16(dZ, WpT16, dH16, 1, e, M, J, (int)ldg, ldg, ldg, J, st));
         CK(fill_zero(dPD, sizeof(float) * (size_t)B * U1 * J, st));
-        CK(joint_tanh_bwd(dH16, H16, 1, B, T, U1, J, dPE, dPD, st));
+        CK(joint_tanh_bwd(dH16, nullptr, 1, B, T, U1, J, dPE, dPD, st));
     }
     CK(colsum(dPE, J, (long)B * T, J, 1, 1, 0, 0, 0, 0, g_bf, st));
     CK(wgrad(dPE, enc, g_wf, J, de, B * T, J, de, din, prec, st));
