@@ -68,7 +68,7 @@ def test_both_kernel_generations_agree():
     A, B = _ints((4096, 512), g), _ints((640, 512), g)
     At, Bt = _ints((8192, 520), g), _ints((8192, 264), g)
     want_nt, want_tn = A.float() @ B.float().t(), At[:, :512].float().t() @ Bt[:, :260].float()
-    for v in (1, 3, 4, 5, 6, 8):
+    for v in (1, 3, 4, 5, 6, 8, 9):
         ops.set_option(1, v)
         C = torch.zeros(4096, 640, device="cuda")
         ops.gemm_nt_bf16(A, B, C)
@@ -109,7 +109,29 @@ def test_persistent_256_kernel_exact(M, N, K, pad, cdt):
         assert bool((Cfull[:, N:] == 5.0).all())
 
 
-@pytest.mark.parametrize("M,N,K", [(1024, 1024, 32768), (1124, 1024, 40000), (2048, 1024, 33001), (4334, 1024, 65606)])
+@pytest.mark.parametrize("M,N,K,pad", [(1024, 128, 64, 0), (1024, 256, 128, 0), (1024, 384, 192, 4), (16000, 512, 512, 0),
+                                       (16000, 1536, 512, 0), (3001, 700, 320, 3), (16000, 2048, 2048, 0), (1025, 129, 1024, 0),
+                                       (50000, 512, 256, 0), (3001, 700, 72, 3)])
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_persistent_256x128_kernel_exact(M, N, K, pad, cdt):
+    """v9 (persistent 256x128, three LDS stages, one phase per K-tile): exact on small integers for 1..32 K-tiles, ragged M/N,
+    padded pitch, 1..4 rounds of tiles per CU (K %% 64 != 0 falls back to the 128x128 kernel: same contract)"""
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A, B = _ints((M, K), g), _ints((N, K), g)
+    bias = torch.randint(-3, 4, (N,), device="cuda", generator=g).float()
+    Cfull = torch.full((M, N + pad), 5.0, device="cuda", dtype=cdt)
+    ops.set_option(1, 9)
+    try:
+        ops.gemm_nt_bf16(A, B, Cfull[:, :N], bias)
+    finally:
+        ops.set_option(1, 4)
+    assert torch.equal(Cfull[:, :N], (A.float() @ B.float().t() + bias).to(cdt))
+    if pad:
+        assert bool((Cfull[:, N:] == 5.0).all())
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 1024, 32768), (1124, 1024, 40000), (2048, 1024, 33001), (4334, 1024, 65600)])
 def test_persistent_256_wgrad_kernel_exact(M, N, K):
     """TN v8 (huge-reduction wgrad: persistent 256x256, transposed LDS reads, K-ranges per XCD, atomics, fused column sums via an
     all-ones MFMA) + the 128x128 kernel on the M % 256 strip: exact on small integers, K tail, with and without column sums"""

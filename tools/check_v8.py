@@ -41,10 +41,33 @@ def check():
     return bad
 
 
+def check_v9():
+    g = torch.Generator(device="cuda").manual_seed(11)
+    bad = 0
+    for (M, N, K, pad) in [(1024, 128, 64, 0), (1024, 256, 128, 0), (1024, 384, 192, 4), (16000, 512, 512, 0), (16000, 1536, 512, 0),
+                           (3001, 700, 72, 3), (16000, 2048, 2048, 0), (1025, 129, 1000, 0), (50000, 512, 256, 0)]:
+        A, B = ints((M, K), g), ints((N, K), g)
+        bias = torch.randint(-3, 4, (N,), device="cuda", generator=g).float()
+        for cdt in (torch.float32, torch.bfloat16):
+            Cfull = torch.full((M, N + pad), 5.0, device="cuda", dtype=cdt)
+            ops.set_option(1, 9)
+            ops.gemm_nt_bf16(A, B, Cfull[:, :N], bias)
+            ops.set_option(1, 4)
+            want = (A.float() @ B.float().t() + bias).to(cdt)
+            ok = torch.equal(Cfull[:, :N], want) and (pad == 0 or bool((Cfull[:, N:] == 5.0).all()))
+            if not ok:
+                bad += 1
+                idx = ((Cfull[:, :N].float() - want.float()).abs() > 0).nonzero()
+                print("V9 MISMATCH", M, N, K, pad, cdt, "n_bad", idx.shape[0], "first", idx[:4].tolist(), flush=True)
+            else:
+                print("v9 ok", M, N, K, pad, cdt, flush=True)
+    return bad
+
+
 def check_tn():
     g = torch.Generator(device="cuda").manual_seed(7)
     bad = 0
-    for (M, N, K) in [(1024, 1024, 32768), (1124, 1024, 40000), (2048, 1024, 33001), (4334, 1024, 65536 + 70)]:
+    for (M, N, K) in [(1024, 1024, 32768), (1124, 1024, 40000), (2048, 1024, 33001), (4334, 1024, 65536 + 64)]:
         lda = (M + 7) // 8 * 8 + 8
         A, B = ints((K, lda), g), ints((K, N), g)
         want = A[:, :M].float().t() @ B.float()
@@ -116,7 +139,7 @@ def bench():
 
 
 if __name__ == "__main__":
-    bad = check() + check_tn()
+    bad = check() + check_tn() + check_v9()
     if bad:
         sys.exit(1)
     bench()

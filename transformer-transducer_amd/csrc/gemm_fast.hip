@@ -507,6 +507,69 @@ __global__ __launch_bounds__(NTH6, 1) void gemm_nt_bf16_v6_kernel(const FP p) {
         }
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// epilogue of the 256-wide kernels for 4 consecutive columns n0..n0+3 of row m: bias, residual addend, ReLU, mask (ReLU' or tanh'),
+// dropout, then one 16-byte (f32) / 8-byte (bf16) store (scalar fallback on ragged or unaligned edges)
+template <typename TC>
+__device__ __forceinline__ void epi_store4(const FP& p, TC* C, int m, int n0, f32x4 x, bool vec) {
+    if (m >= p.M || n0 >= p.N) return;
+    const long ci = (long)m * p.ldc + n0;
+    float v[4] = {x[0], x[1], x[2], x[3]};
+    if (vec && n0 + 3 < p.N) {
+        if (p.bias) {
+            const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0);   // n0 % 4 == 0; bias from hipMalloc/torch: 16-B aligned rows
+            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+        }
+        if (p.addend) {
+            const float4 a = *reinterpret_cast<const float4*>(p.addend + ci);
+            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        if (p.mask) {
+            const uint2 mk = *reinterpret_cast<const uint2*>(p.mask + ci);
+            const unsigned short ms[4] = {(unsigned short)(mk.x & 0xffff), (unsigned short)(mk.x >> 16),
+                                          (unsigned short)(mk.y & 0xffff), (unsigned short)(mk.y >> 16)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float mv = bf16_to_f32(ms[j]);
+                v[j] = p.mask_mode ? v[j] * (1.f - mv * mv) : (mv > 0.f ? v[j] * p.scale : 0.f);
+            }
+        }
+        if (p.drop.p > 0.f) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= drop_mult(p.drop, (unsigned long long)(ci + j));
+        }
+        if constexpr (sizeof(TC) == 4) {
+            const f32x4 o = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + ci) = o;
+        } else {
+            u32x2 o;
+            o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+            o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(C) + ci) = o;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (n0 + j >= p.N) continue;
+            float y = v[j] + (p.bias ? p.bias[n0 + j] : 0.f);
+            if (p.addend) y += p.addend[ci + j];
+            if (p.relu) y = fmaxf(y, 0.f);
+            if (p.mask) {
+                const float mv = bf16_to_f32(p.mask[ci + j]);
+                y = p.mask_mode ? y * (1.f - mv * mv) : (mv > 0.f ? y * p.scale : 0.f);
+            }
+            y *= drop_mult(p.drop, (unsigned long long)(ci + j));
+            if constexpr (sizeof(TC) == 4) reinterpret_cast<float*>(C)[ci + j] = y;
+            else reinterpret_cast<bf16_t*>(C)[ci + j] = f32_to_bf16(y);
+        }
+    }
+}
+
 // =====================================================================================================================
 // v8: persistent 256x256x64 kernel, one 512-thread workgroup per CU, 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 = 8 x 4
 // v_mfma_f32_16x16x32_bf16 tiles (128 accumulator registers), 2 x 64 KiB operand buffers + 32 KiB epilogue staging in LDS.
@@ -527,8 +590,6 @@ __global__ __launch_bounds__(NTH6, 1) void gemm_nt_bf16_v6_kernel(const FP p) {
 // (bf16) / 256-byte (f32) row segments.  The next output tile's first seven half-tiles are already in flight while the
 // epilogue runs, and its stores drain under the next tile's MFMAs.
 // =====================================================================================================================
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr int T8 = 256, NTH8 = 512, HT8 = 128 * 64 * 2, BUF8 = 4 * HT8;   // buffer: [A h0 | A h1 | B h0 | B h1]
 constexpr int LDS8 = 2 * BUF8 + 8 * 4096;
 
@@ -539,7 +600,6 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
     const int wr = wave >> 2, wc = wave & 3;
     const int ntiles = p.tiles_m * p.tiles_n;
     const int nk = (p.K + TK - 1) / TK;
-    const void* zsrc = &g_zero16;
 
     // persistent tile walk: in every round the 32 workgroups of one XCD (ids equal mod 8) take 32 consecutive ids = an
     // 8-tall x 4-wide window of the GROUP_M-grouped order
@@ -554,33 +614,36 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
     };
     // staging: instruction j of wave w fills half-tile rows rho = (2w + j) * 8 + (lane >> 3), 16-byte slot lane & 7, which must
     // hold source chunk slot ^ ((rho >> 1) & 7)
-    const bf16_t* sA[2][2];
-    const bf16_t* sB[2][2];
+    // sources are a wave-uniform tile base (SGPRs) + a 32-bit per-lane byte offset: the saddr form of global_load_lds, no 64-bit VALU
+    unsigned oA[2][2], oB[2][2];
+    const char* baseA = nullptr;
+    const char* baseB = nullptr;
     int kch[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) kch[j] = (lane & 7) ^ ((((wave * 2 + j) * 8 + (lane >> 3)) >> 1) & 7);
     auto sources = [&](int bm, int bn) {
+        baseA = reinterpret_cast<const char*>(p.A + (long)bm * p.lda);
+        baseB = reinterpret_cast<const char*>(p.B + (long)bn * p.ldb);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int rho = (wave * 2 + j) * 8 + (lane >> 3);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int ra = bm + (rho >> 6) * 128 + h * 64 + (rho & 63);
-                const int rb = bn + (rho >> 5) * 64 + h * 32 + (rho & 31);
-                sA[h][j] = p.A + (long)min(ra, p.M - 1) * p.lda + kch[j] * 8;
-                sB[h][j] = p.B + (long)min(rb, p.N - 1) * p.ldb + kch[j] * 8;
+                const int ra = min((rho >> 6) * 128 + h * 64 + (rho & 63), p.M - 1 - bm);
+                const int rb = min((rho >> 5) * 64 + h * 32 + (rho & 31), p.N - 1 - bn);
+                oA[h][j] = (unsigned)(((long)ra * p.lda + kch[j] * 8) * 2);
+                oB[h][j] = (unsigned)(((long)rb * p.ldb + kch[j] * 8) * 2);
             }
         }
     };
     // kind: 0 = A h0, 1 = A h1, 2 = B h0, 3 = B h1 (also the region index inside a buffer)
     auto stage = [&](int kind, int buf, int kt) {
         char* dst = smem + buf * BUF8 + kind * HT8 + wave * 2048;
-        const bool tail = (kt + 1) * TK > p.K;
+        const char* base = (kind < 2 ? baseA : baseB) + (long)kt * (TK * 2);      // K % 64 == 0 (checked by the launcher): no tail
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const bf16_t* s = kind == 0 ? sA[0][j] : kind == 1 ? sA[1][j] : kind == 2 ? sB[0][j] : sB[1][j];
-            const bool zero = tail && (kt * TK + kch[j] * 8 >= p.K);
-            glds16(zero ? zsrc : (const void*)(s + (long)kt * TK), dst + j * 1024);
+            const unsigned o = kind == 0 ? oA[0][j] : kind == 1 ? oA[1][j] : kind == 2 ? oB[0][j] : oB[1][j];
+            glds16(base + o, dst + j * 1024);
         }
     };
     auto prologue = [&]() {                       // K-tile 0 complete + three half-tiles of K-tile 1
@@ -682,11 +745,13 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                          (!p.addend || (reinterpret_cast<size_t>(p.addend) & 15) == 0) &&
                          (!p.mask || (reinterpret_cast<size_t>(p.mask) & 7) == 0) && (!p.bias || (reinterpret_cast<size_t>(p.bias) & 15) == 0);
         const int wrow = lane & 15, wq = lane >> 4;
-#pragma unroll
+        // the slab loop stays rolled (one copy of the epilogue code); the accumulators are picked by a wave-uniform switch so that
+        // they are never indexed dynamically (which would put all 128 of them in scratch)
+#define V8_SLAB(I) case I: _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) \
+            *reinterpret_cast<f32x4*>(img + wrow * 256 + (((ni * 4 + wq) ^ wrow) << 4)) = acc[I][ni]; break;
+#pragma unroll 1
         for (int mi = 0; mi < 8; ++mi) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-                *reinterpret_cast<f32x4*>(img + wrow * 256 + (((ni * 4 + wq) ^ wrow) << 4)) = acc[mi][ni];
+            switch (mi) { V8_SLAB(0) V8_SLAB(1) V8_SLAB(2) V8_SLAB(3) V8_SLAB(4) V8_SLAB(5) V8_SLAB(6) V8_SLAB(7) }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = q * 4 + (lane >> 4);                    // row of the 16-row slab
@@ -694,66 +759,154 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                 const f32x4 x = *reinterpret_cast<const f32x4*>(img + r * 256 + ((lane & 15) << 4));
                 const int m = cbm + wr * 128 + mi * 16 + r;
                 const int n0 = cbn + wc * 64 + c * 4;
-                if (m >= p.M || n0 >= p.N) continue;
-                const long ci = (long)m * p.ldc + n0;
-                float v[4] = {x[0], x[1], x[2], x[3]};
-                if (vec && n0 + 3 < p.N) {
-                    if (p.bias) {
-                        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0);   // n0 % 4 == 0; bias from hipMalloc/torch: 16-B aligned rows
-                        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-                    }
-                    if (p.addend) {
-                        const float4 a = *reinterpret_cast<const float4*>(p.addend + ci);
-                        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
-                    }
-                    if (p.relu) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-                    }
-                    if (p.mask) {
-                        const uint2 mk = *reinterpret_cast<const uint2*>(p.mask + ci);
-                        const unsigned short ms[4] = {(unsigned short)(mk.x & 0xffff), (unsigned short)(mk.x >> 16),
-                                                      (unsigned short)(mk.y & 0xffff), (unsigned short)(mk.y >> 16)};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float mv = bf16_to_f32(ms[j]);
-                            v[j] = p.mask_mode ? v[j] * (1.f - mv * mv) : (mv > 0.f ? v[j] * p.scale : 0.f);
-                        }
-                    }
-                    if (p.drop.p > 0.f) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] *= drop_mult(p.drop, (unsigned long long)(ci + j));
-                    }
-                    if constexpr (sizeof(TC) == 4) {
-                        const f32x4 o = {v[0], v[1], v[2], v[3]};
-                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(C) + ci) = o;
-                    } else {
-                        u32x2 o;
-                        o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                        o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-                        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(C) + ci) = o;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (n0 + j >= p.N) continue;
-                        float y = v[j] + (p.bias ? p.bias[n0 + j] : 0.f);
-                        if (p.addend) y += p.addend[ci + j];
-                        if (p.relu) y = fmaxf(y, 0.f);
-                        if (p.mask) {
-                            const float mv = bf16_to_f32(p.mask[ci + j]);
-                            y = p.mask_mode ? y * (1.f - mv * mv) : (mv > 0.f ? y * p.scale : 0.f);
-                        }
-                        y *= drop_mult(p.drop, (unsigned long long)(ci + j));
-                        if constexpr (sizeof(TC) == 4) reinterpret_cast<float*>(C)[ci + j] = y;
-                        else reinterpret_cast<bf16_t*>(C)[ci + j] = f32_to_bf16(y);
-                    }
-                }
+                epi_store4<TC>(p, C, m, n0, x, vec);
             }
         }
     }
+#undef V8_SLAB
 #undef V8_LGKM0
 #undef V8_BAR
+}
+
+// =====================================================================================================================
+// v9: the v8 schedule for mid-sized outputs (the encoder GEMMs: 16000 rows x 512..2048 columns, K = 512..2048), where 256x256
+// tiles leave CUs idle.  Persistent, 256 (M) x 128 (N) x 64 tile, 8 waves as 4 x 2, wave tile 64 x 64 = 4 x 4 MFMA tiles (64
+// accumulator registers), THREE 48 KiB LDS stages and ONE phase per K-tile:
+//     [16 ds_read_b128 + prefetch of K-tile t+2 + lgkmcnt(0) + vmcnt(6)] s_barrier [32 MFMAs] s_barrier
+// waves 4-7 one barrier behind.  K-tile t+2 goes into the stage read in phase t-1 (retired before that phase's barrier), and the
+// counted wait at the end of phase t leaves exactly its six loads in flight, so K-tile t+1 has landed before phase t+1 reads it.
+// The epilogue images (4 KiB per wave, as in v8) live in stage 2, which the next output tile's prologue (K-tiles 0 and 1) does not
+// touch; the barrier that opens the next tile's loop orders them before K-tile 2 is staged there.
+// =====================================================================================================================
+constexpr int T9M = 256, T9N = 128, STG9 = (T9M + T9N) * 64 * 2, LDS9 = 3 * STG9;
+
+template <typename TC>
+__global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave & 3, wc = wave >> 2;               // waves w and w+4 (SIMD partners) differ in the column half
+    const int grp = wave >> 2;                             // 1: runs one barrier behind
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int nk = (p.K + TK - 1) / TK;
+
+    auto tile_id = [&](int it) { return (long)it * gridDim.x + (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3); };
+    auto coords = [&](long id, int& bm, int& bn) {
+        const int per_group = GROUP_M * p.tiles_n;
+        const int group = (int)(id / per_group), in = (int)(id % per_group);
+        const int first = group * GROUP_M;
+        const int gsz = min(p.tiles_m - first, GROUP_M);
+        bm = (first + in % gsz) * T9M;
+        bn = (in / gsz) * T9N;
+    };
+    // staging: A = 32 units of 8 rows (wave w: units 4w..4w+3), B = 16 units (wave w: 2w, 2w+1); slot lane & 7 <- chunk slot ^ ((row >> 1) & 7)
+    // (sources = wave-uniform tile base + 32-bit per-lane byte offsets: saddr form of global_load_lds; K % 64 == 0, no tail)
+    unsigned oA[4], oB[2];
+    const char* baseA = nullptr;
+    const char* baseB = nullptr;
+    auto sources = [&](int bm, int bn) {
+        baseA = reinterpret_cast<const char*>(p.A + (long)bm * p.lda);
+        baseB = reinterpret_cast<const char*>(p.B + (long)bn * p.ldb);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (wave * 4 + j) * 8 + (lane >> 3);
+            oA[j] = (unsigned)(((long)min(r, p.M - 1 - bm) * p.lda + ((lane & 7) ^ ((r >> 1) & 7)) * 8) * 2);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = (wave * 2 + j) * 8 + (lane >> 3);
+            oB[j] = (unsigned)(((long)min(r, p.N - 1 - bn) * p.ldb + ((lane & 7) ^ ((r >> 1) & 7)) * 8) * 2);
+        }
+    };
+    auto stage = [&](int stg, int kt) {
+        char* dst = smem + stg * STG9;
+        const char* ba = baseA + (long)kt * (TK * 2);
+        const char* bb = baseB + (long)kt * (TK * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(ba + oA[j], dst + (wave * 4 + j) * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(bb + oB[j], dst + T9M * 128 + (wave * 2 + j) * 1024);
+    };
+    const int sw = (lane >> 1) & 7;
+    int aoff[2], boff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int c = ((ks * 4 + (lane >> 4)) ^ sw) << 4;
+        aoff[ks] = (wr * 64 + (lane & 15)) * 128 + c;
+        boff[ks] = T9M * 128 + (wc * 64 + (lane & 15)) * 128 + c;
+    }
+    f32x4 acc[4][4];
+    bf16x8 af[4][2], bfr[4][2];
+#define V9_BAR() __builtin_amdgcn_s_barrier()
+
+    int bm = 0, bn = 0;
+    bool live = tile_id(0) < ntiles;
+    if (live) { coords(tile_id(0), bm, bn); sources(bm, bn); stage(0, 0); if (nk > 1) stage(1, 1); }
+    for (int it = 0; live; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        V9_BAR();
+        if (grp == 1) V9_BAR();
+        int stg = 0;                                       // t % 3
+        for (int t = 0; t < nk; ++t) {
+            const char* base = smem + stg * STG9;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i][ks] = *reinterpret_cast<const bf16x8*>(base + aoff[ks] + i * 2048);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bfr[i][ks] = *reinterpret_cast<const bf16x8*>(base + boff[ks] + i * 2048);
+            }
+            if (t + 2 < nk) {
+                stage(stg == 0 ? 2 : stg - 1, t + 2);      // (t + 2) % 3
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            V9_BAR();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt][ks], af[mt][ks], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            V9_BAR();
+            stg = stg == 2 ? 0 : stg + 1;
+        }
+        if (grp == 0) V9_BAR();
+
+        const int cbm = bm, cbn = bn;
+        live = tile_id(it + 1) < ntiles;
+        if (live) { coords(tile_id(it + 1), bm, bn); sources(bm, bn); stage(0, 0); if (nk > 1) stage(1, 1); }
+
+        TC* C = reinterpret_cast<TC*>(p.C);
+        char* img = smem + 2 * STG9 + wave * 4096;
+        const bool vec = (p.ldc % 4 == 0) && ((reinterpret_cast<size_t>(p.C) & 15) == 0) &&
+                         (!p.addend || (reinterpret_cast<size_t>(p.addend) & 15) == 0) &&
+                         (!p.mask || (reinterpret_cast<size_t>(p.mask) & 7) == 0) && (!p.bias || (reinterpret_cast<size_t>(p.bias) & 15) == 0);
+        const int wrow = lane & 15, wq = lane >> 4;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                *reinterpret_cast<f32x4*>(img + wrow * 256 + (((ni * 4 + wq) ^ wrow) << 4)) = acc[mi][ni];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = q * 4 + (lane >> 4);
+                const int c = (lane & 15) ^ r;
+                const f32x4 x = *reinterpret_cast<const f32x4*>(img + r * 256 + ((lane & 15) << 4));
+                epi_store4<TC>(p, C, cbm + wr * 64 + mi * 16 + r, cbn + wc * 64 + c * 4, x, vec);
+            }
+        }
+    }
+#undef V9_BAR
 }
 
 // =====================================================================================================================
@@ -783,7 +936,6 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
     const int nitems = S * ntiles;
     const int nkt = (p.K + TK - 1) / TK;                   // K-tiles in all
     const int per = p.ksteps;                              // K-tiles per range
-    const void* zsrc = &g_zero16;
 
     // staging: unit u = 2*wave + j covers k-rows 4u + (lane >> 4) of a region, 16-byte slot lane & 15 <- source chunk slot ^ sw(k)
     int kst[2], cst[2];
@@ -792,30 +944,31 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
         kst[j] = (wave * 2 + j) * 4 + (lane >> 4);
         cst[j] = (lane & 15) ^ (((kst[j] & 3) << 2) | (((kst[j] >> 3) & 1) << 1));
     }
-    const bf16_t* sA[2][2];
-    const bf16_t* sB[2][2];
+    // sources = wave-uniform (item, K-tile) base + 32-bit per-lane byte offsets (saddr form of global_load_lds); K % 64 == 0, no tail
+    unsigned oA[2][2], oB[2][2];
+    const char* baseA = nullptr;
+    const char* baseB = nullptr;
     long kbeg = 0;                                         // first reduction row of the current item
     int nk = 0;
     auto sources = [&](int bm, int bn, long k0) {
+        baseA = reinterpret_cast<const char*>(p.A + k0 * p.lda);
+        baseB = reinterpret_cast<const char*>(p.B + k0 * p.ldb);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const long ca = min((long)bm + h * 128 + cst[j] * 8, p.lda - 8), cb = min((long)bn + h * 128 + cst[j] * 8, p.ldb - 8);
-                sA[h][j] = p.A + (k0 + kst[j]) * p.lda + ca;
-                sB[h][j] = p.B + (k0 + kst[j]) * p.ldb + cb;
+                oA[h][j] = (unsigned)((kst[j] * p.lda + ca) * 2);
+                oB[h][j] = (unsigned)((kst[j] * p.ldb + cb) * 2);
             }
     };
     auto stage = [&](int kind, int buf, int kt) {          // kind: 0 = A h0, 1 = A h1, 2 = B h0, 3 = B h1
         char* dst = smem + buf * BUF8 + kind * HT8 + wave * 2048;
-        const long kb = kbeg + (long)kt * TK;
-        const bool tail = kb + TK > p.K;
+        const char* base = kind < 2 ? baseA + (long)kt * TK * p.lda * 2 : baseB + (long)kt * TK * p.ldb * 2;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const bf16_t* s = kind == 0 ? sA[0][j] : kind == 1 ? sA[1][j] : kind == 2 ? sB[0][j] : sB[1][j];
-            const long ld = kind < 2 ? p.lda : p.ldb;
-            const bool zero = tail && (kb + kst[j] >= p.K);
-            glds16(zero ? zsrc : (const void*)(s + (long)kt * TK * ld), dst + j * 1024);
+            const unsigned o = kind == 0 ? oA[0][j] : kind == 1 ? oA[1][j] : kind == 2 ? oB[0][j] : oB[1][j];
+            glds16(base + o, dst + j * 1024);
         }
     };
     auto prologue = [&]() {
@@ -1008,16 +1161,34 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     TTMI_REQUIRE(nbatch >= 1 && nbatch <= 65535, "gemm_nt_bf16: bad batch count %d", nbatch);
     // 256x256 tiles pay off when the K loop is long enough to amortise the un-overlapped epilogue of a one-workgroup-per-CU
     // kernel and there are enough tiles to fill the chip (joint dgrad: K = 4352 -> 954 vs 880 TFLOP/s; short-K forward: worse)
-    // persistent 256x256 kernel: needs several rounds of tiles per CU to amortise its pipeline fill and tail
-    const bool v8 = (g_gemm_fast_version == 8 && M >= 1024 && N >= 256) ||
-                    (g_gemm_fast_version == 4 && (long)cdiv(M, T8) * cdiv(N, T8) >= 1024 && K >= 512);
-    if (v8 && nbatch == 1) {
-        if (g_num_cus == 0) {
-            int dev = 0, n = 0;
-            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-                g_num_cus = n / 8 * 8;        // the tile walk assumes a multiple of 8 (one share per XCD)
-            if (g_num_cus <= 0) g_num_cus = 256;
+    if (g_num_cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            g_num_cus = n / 8 * 8;        // the persistent tile walks assume a multiple of 8 (one share per XCD)
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    // persistent kernels: 256x256 tiles (v8) are ~1.8x the cost of 256x128 tiles (v9); take whichever needs less time for its
+    // whole number of rounds over the CUs (joint: v8; encoder N = 512 / 1536: v9; N = 2048: v8), the 128x128 kernel for small outputs
+    const long t9 = (long)cdiv(M, T9M) * cdiv(N, T9N), t8 = (long)cdiv(M, T8) * cdiv(N, T8);
+    const bool pers = nbatch == 1 && M >= 1024 && N >= 128 && K >= 128 && K % TK == 0;
+    const double cost9 = (double)cdiv(t9, g_num_cus), cost8 = N >= 256 ? 1.8 * cdiv(t8, g_num_cus) : 1e30;
+    const bool v9 = pers && ((g_gemm_fast_version == 9) || (g_gemm_fast_version == 4 && t9 >= g_num_cus * 3 / 4 && cost9 <= cost8));
+    if (v9) {
+        p.tiles_m = cdiv(M, T9M); p.tiles_n = cdiv(N, T9N);
+        const int grid9 = (int)((std::min<long>(t9, g_num_cus) + 7) / 8 * 8);
+        if (c_dtype == 0) {
+            if (int rc = enable_lds(gemm_nt_bf16_v9_kernel<float>, LDS9)) return rc;
+            hipLaunchKernelGGL(gemm_nt_bf16_v9_kernel<float>, dim3((unsigned)grid9), dim3(NTH8), LDS9, st, p);
+        } else {
+            if (int rc = enable_lds(gemm_nt_bf16_v9_kernel<bf16_t>, LDS9)) return rc;
+            hipLaunchKernelGGL(gemm_nt_bf16_v9_kernel<bf16_t>, dim3((unsigned)grid9), dim3(NTH8), LDS9, st, p);
         }
+        TTMI_LAUNCH_CHECK("gemm_nt_bf16_v9_kernel");
+        return TTMI_OK;
+    }
+    // persistent 256x256 kernel: needs several rounds of tiles per CU to amortise its pipeline fill and tail
+    const bool v8 = pers && N >= 256 && ((g_gemm_fast_version == 8) || (g_gemm_fast_version == 4 && t9 >= g_num_cus * 3 / 4));
+    if (v8) {
         p.tiles_m = cdiv(M, T8); p.tiles_n = cdiv(N, T8);
         const long nwg8 = (long)p.tiles_m * p.tiles_n;
 const int grid8 = (int)((std::min<long>(nwg8, g_num_cus) + 7) / 8 * 8);   // multiple of 8: one share of every round per XCD
@@ -1081,7 +1252,7 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
     TTMI_REQUIRE(nbatch >= 1 && nbatch <= 65535, "gemm_tn_bf16: bad batch count %d", nbatch);
     // huge-reduction wgrad (the joint projection: K = B*T*U1 rows): persistent 256x256 kernel on the 256-row tiles that are
     // full, the 128x128 kernel below on the remaining M % 256 rows
-    const bool tn8 = (g_gemm_fast_version == 4 || g_gemm_fast_version == 8) && nbatch == 1 && accumulate && K >= 32768 &&
+    const bool tn8 = (g_gemm_fast_version == 4 || g_gemm_fast_version == 8) && nbatch == 1 && accumulate && K >= 32768 && K % TK == 0 &&
                      M >= 1024 && N >= 256 && N % 256 == 0 && (N / 256) % 4 == 0;
     if (tn8) {
         if (g_num_cus == 0) {
