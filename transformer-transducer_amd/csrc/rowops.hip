@@ -4,6 +4,7 @@
 // wave reductions by __shfl_xor; cross-row reductions finish with float atomics (agent scope).
 // Reference arithmetic: tt/transformer.py:52-58,148-175, tt/decoder.py:26,39, tt/model.py:33-37.
 #include "rowops.h"
+#include <algorithm>
 
 namespace {
 
@@ -144,6 +145,84 @@ __global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restr
     }
     atomicAdd(dgamma + c, ag);
     atomicAdd(dbeta + c, ab);
+}
+
+// dx, dgamma and dbeta in ONE pass over dy and s (d <= 512, d % 4 == 0): a wave keeps its row's dy*drop and x-hat in registers
+// between the row statistics and the dx formula, and carries per-column partial sums for gamma / beta over the rows it walks;
+// they are combined over the block's 4 waves in LDS and added with one atomic per column and block.
+template <int KV>
+__global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ s,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ g, const float* __restrict__ dadd, long rows,
+                                                           int d, float* __restrict__ dx, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, DropSpec ddrop) {
+    __shared__ float red[2][4][KV * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float gam[KV][4], ag[KV][4], ab[KV][4];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+        const int c0 = k * 256 + lane * 4;
+        const float4 gv = c0 < d ? *reinterpret_cast<const float4*>(g + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        gam[k][0] = gv.x; gam[k][1] = gv.y; gam[k][2] = gv.z; gam[k][3] = gv.w;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ag[k][c] = ab[k][c] = 0.f;
+    }
+    const float invd = 1.f / d;
+    for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+        const float mu = mean[r], rs = rstd[r];
+        const unsigned long long base = (unsigned long long)r * d;
+        float v[KV][4], xh[KV][4];
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const int c0 = k * 256 + lane * 4;
+            if (c0 < d) {
+                const float4 a = *reinterpret_cast<const float4*>(dy + base + c0), b = *reinterpret_cast<const float4*>(s + base + c0);
+                const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    v[k][c] = av[c] * drop_mult(ddrop, base + c0 + c);
+                    xh[k][c] = (bv[c] - mu) * rs;
+                    const float dxh = v[k][c] * gam[k][c];
+                    m1 += dxh;
+                    m2 += dxh * xh[k][c];
+                    ag[k][c] += v[k][c] * xh[k][c];
+                    ab[k][c] += v[k][c];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[k][c] = xh[k][c] = 0.f;
+            }
+        }
+        m1 = wave_sum(m1) * invd;
+        m2 = wave_sum(m2) * invd;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const int c0 = k * 256 + lane * 4;
+            if (c0 < d) {
+                float o[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = rs * (v[k][c] * gam[k][c] - m1 - xh[k][c] * m2);
+                if (dadd) {
+                    const float4 e = *reinterpret_cast<const float4*>(dadd + base + c0);
+                    o[0] += e.x; o[1] += e.y; o[2] += e.z; o[3] += e.w;
+                }
+                *reinterpret_cast<float4*>(dx + base + c0) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            red[0][wave][k * 256 + lane * 4 + c] = ag[k][c];
+            red[1][wave][k * 256 + lane * 4 + c] = ab[k][c];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) {
+        atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    }
 }
 
 // ------------------------------------------------------------------ masked softmax on the score view
@@ -546,6 +625,15 @@ int ln_fwd(const float* x, const float* res, const float* g, const float* b, lon
 int ln_bwd(const float* dy, const float* s, const float* mean, const float* rstd, const float* g, const float* dadd, long rows,
            int d, float* dx, float* dgamma, float* dbeta, hipStream_t st, DropSpec dy_drop) {
     TTMI_REQUIRE(dy && s && mean && rstd && g && dx && dgamma && dbeta && rows > 0 && d > 0, "ln_bwd: bad arguments");
+    if (d % 4 == 0 && d <= 512 && aligned16(dy) && aligned16(s) && aligned16(g) && aligned16(dx) && (!dadd || aligned16(dadd))) {
+        const int grid = (int)std::min<long>(cdiv(rows, 4), 512);         // ~2 blocks per CU; rows are walked grid-stride
+        if (d <= 256)
+            hipLaunchKernelGGL(ln_bwd_fused_kernel<1>, dim3(grid), dim3(256), 0, st, dy, s, mean, rstd, g, dadd, rows, d, dx, dgamma, dbeta, dy_drop);
+        else
+            hipLaunchKernelGGL(ln_bwd_fused_kernel<2>, dim3(grid), dim3(256), 0, st, dy, s, mean, rstd, g, dadd, rows, d, dx, dgamma, dbeta, dy_drop);
+        TTMI_LAUNCH_CHECK("ln_bwd_fused_kernel");
+        return TTMI_OK;
+    }
     hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3(cdiv(rows, WPB)), dim3(WPB * 64), 0, st, dy, s, mean, rstd, g, dadd, rows, d, dx,
                        dy_drop);
     TTMI_LAUNCH_CHECK("ln_bwd_dx_kernel");
