@@ -58,3 +58,26 @@ def test_layer_fused_vs_oracle_and_unfused(Dh, H, L, K, mk, monkeypatch):
     print("fused: out %.2e worst grad %.2e | unfused: out %.2e worst grad %.2e" % (e_f, worst_f, e_u, worst_u))
     assert e_f < 3e-2 and worst_f < 8e-2
     assert e_f < 2.5 * e_u + 1e-3 and worst_f < 2.5 * worst_u + 1e-3     # the fused kernels are as accurate as the unfused chain
+
+
+@pytest.mark.parametrize("Dh,H,L,K", [(64, 2, 70, 128), (32, 4, 33, 16), (64, 8, 500, 512), (64, 1, 129, 40)])
+def test_position_slab_kernel_matches_the_gemm_path(Dh, H, L, K, monkeypatch):
+    """relpos_slab_kernel (whole slab rows streamed from LDS) vs the batched-GEMM + memset construction of the same slab:
+    same bf16 operands, f32 accumulation over Dh -> the layer outputs agree to f32 rounding"""
+    from tt.encoder import BaseEncoder
+    from ttmi import ops
+    from ttmi.ops import MaskSpec
+    monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    d, B = H * Dh, 3
+    torch.manual_seed(L)
+    layer = BaseEncoder(k_len=K, n_head=H, d_model=d, d_head=Dh, d_inner=64, dropout=0.0).cuda().eval()
+    x = torch.randn(B, L, d, device="cuda")
+    cot = torch.randn(B, L, d, device="cuda")
+    y1, dx1, g1 = _run(layer, x, cot, MaskSpec(0))
+    ops.set_option(5, 1)
+    try:
+        y0, dx0, g0 = _run(layer, x, cot, MaskSpec(0))
+    finally:
+        ops.set_option(5, 0)
+    assert rel_err(y1.cpu().numpy(), y0.cpu().numpy()) < 2e-3       # bf16 activations downstream of an f32-rounding-level change
+    assert rel_err(dx1.cpu().numpy(), dx0.cpu().numpy()) < 5e-3

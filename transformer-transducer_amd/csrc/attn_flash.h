@@ -37,3 +37,8 @@ struct FlashParams {
 bool flash_supported(int Dh, long ld_qu, long ld_kv, long ld_o);
 int flash_attn_fwd(const FlashParams& p, hipStream_t st);
 int flash_attn_bwd(const FlashParams& p, hipStream_t st);
+// G slab of the position term (q E^T + c, column 0 zero, row pitch L+1, f32) for all (b, h): q rows (b, i) at q[(b*L+i)*ld_q + h*Dh],
+// E rows p at E[p*ld_e + h*Dh], c[h][p]
+int relpos_slab(const bf16_t* q, long ld_q, const bf16_t* E, long ld_e, const float* c, int B, int L, int H, int Dh, float* G,
+                hipStream_t st);
+void relpos_slab_set_debug(int bits);   // timing experiments only: 1 = skip the MFMA part, 2 = skip the stores

@@ -386,6 +386,134 @@ bool flash_supported(int Dh, long ld_qu, long ld_kv, long ld_o) {
     return (Dh == 32 || Dh == 64) && ld_qu % 8 == 0 && ld_kv % 8 == 0 && ld_o % 8 == 0;
 }
 
+// ------------------------------------------------------------------ position-term slab
+// G[z][i][1 + p] = q_i . E[p] + c[h][p], G[z][i][0] = 0, written as the pitch-(L+1) f32 slab whose pitch-L view is _rel_shift
+// (see layers.hip).  This is a write-bound op (L*(L+1)*4 bytes per (b, h), K = Dh): one workgroup builds 16 complete rows in LDS
+// and streams them out as ONE contiguous run of 16-byte stores (rows of the slab are back to back; the LDS image is shifted by the
+// run's misalignment so that LDS and global float4s coincide).  Replaces a batched GEMM whose 128x128 tiles wrote 512-byte row
+// pieces (1.5 TB/s) plus a strided memset for column 0.
+int g_slab_dbg = 0;
+constexpr int SLAB_RB = 4;        // 16-row blocks per workgroup: E_h (L x Dh, read by every block) stays in registers across them
+// SINGLE: L <= 512, one pass of 8 column tiles per wave covers a row and the E fragments are loaded once per workgroup (otherwise
+// they are re-read per row block and pass).  Kept under 128 VGPRs (4 workgroups per CU): at 244 the kernel was latency-bound.
+template <int DH, bool SINGLE>
+__global__ __launch_bounds__(256, 4) void relpos_slab_kernel(const bf16_t* __restrict__ q, long ld_q, const bf16_t* __restrict__ E,
+                                                             long ld_e, const float* __restrict__ c, int L, int H,
+                                                             float* __restrict__ G, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) float img[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int z = blockIdx.y, b = z / H, h = z % H;
+    const int fr = lane & 15, fq = lane >> 4;
+    constexpr int KS = DH / 32;
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    const int ntile = (L + 15) / 16;
+    const float* cr = c + (long)h * L;
+    bf16x8_t ef[8][KS];
+    // 8 column tiles per wave and pass, all E fragments in flight before the first MFMA
+    auto load_tiles = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bf16_t* er = E + (long)min((c0 + 4 * u) * 16 + fr, L - 1) * ld_e + h * DH + fq * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) ef[u][ks] = *reinterpret_cast<const bf16x8_t*>(er + ks * 32);
+        }
+    };
+    auto load_bias = [&](int ct, float (&cb)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cb[j] = cr[min(ct * 16 + fq * 4 + j, L - 1)];
+    };
+    if (SINGLE) load_tiles(wave);
+    bf16x8_t qn[KS];
+    auto load_q = [&](int r0) {
+        const bf16_t* qr = q + ((long)b * L + min(r0 + fr, L - 1)) * ld_q + h * DH + fq * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qn[ks] = *reinterpret_cast<const bf16x8_t*>(qr + ks * 32);
+    };
+    load_q(blockIdx.x * SLAB_RB * 16);
+    for (int rbi = 0; rbi < SLAB_RB; ++rbi) {
+        const int r0 = (blockIdx.x * SLAB_RB + rbi) * 16;
+        if (r0 >= L) break;
+        const int nrows = min(16, L - r0);
+        const long g0 = (long)z * L * (L + 1) + (long)r0 * (L + 1);   // first float of this block's run
+        const int sh = (int)(g0 & 3);
+        bf16x8_t qf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
+        load_q(r0 + 16);                                              // next block's rows fly under this block's work
+        if (tid < 16) img[sh + tid * (L + 1)] = 0.f;
+        for (int c0 = wave; c0 < ntile && !(dbg & 1); c0 += 32) {
+            if (!SINGLE) load_tiles(c0);
+            float cbA[4], cbB[4];                          // bias values one tile ahead (a load per tile after its MFMA would serialise)
+            load_bias(c0, cbA);
+            auto tile = [&](int u, const float (&cb)[4]) {
+                const int ct = c0 + 4 * u;
+                if (ct >= ntile) return;
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef[u][ks], qf[ks], acc, 0, 0, 0);
+                // acc[j] = G[r0 + fr][p = ct*16 + fq*4 + j]
+                const int p0 = ct * 16 + fq * 4;
+                float* dst = img + sh + fr * (L + 1) + 1 + p0;
+                if (ct * 16 + 16 <= L) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dst[j] = acc[j] + cb[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (p0 + j < L) dst[j] = acc[j] + cb[j];
+                }
+            };
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                load_bias(c0 + 4 * (u + 1), cbB);
+                tile(u, cbA);
+                if (u + 2 < 8) load_bias(c0 + 4 * (u + 2), cbA);
+                tile(u + 1, cbB);
+            }
+        }
+        __syncthreads();
+        const int n = nrows * (L + 1);                       // floats in the run; LDS index sh + e <-> global g0 + e
+        float* gal = G + (g0 - sh);                          // 16-byte aligned (G itself is)
+        for (int i4 = tid * 4; i4 < sh + n && !(dbg & 2); i4 += 1024) {
+            if (i4 >= sh && i4 + 3 < sh + n) {
+                *reinterpret_cast<float4*>(gal + i4) = *reinterpret_cast<const float4*>(img + i4);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (i4 + e >= sh && i4 + e < sh + n) gal[i4 + e] = img[i4 + e];
+            }
+        }
+        // the image is rebuilt for the next row block: its LDS reads must have retired, the global stores need not (a
+        // __syncthreads() here would drain them - vmcnt(0) - once per row block)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+void relpos_slab_set_debug(int bits) { g_slab_dbg = bits; }
+
+int relpos_slab(const bf16_t* q, long ld_q, const bf16_t* E, long ld_e, const float* c, int B, int L, int H, int Dh, float* G,
+                hipStream_t st) {
+    TTMI_REQUIRE(q && E && c && G && B > 0 && L > 0 && H > 0 && (Dh == 32 || Dh == 64), "relpos_slab: bad arguments");
+    TTMI_REQUIRE(aligned16(q) && aligned16(E) && aligned16(G) && ld_q % 8 == 0 && ld_e % 8 == 0, "relpos_slab: alignment");
+    const size_t lds = ((size_t)16 * (L + 1) + 8) * sizeof(float);
+    TTMI_REQUIRE(lds <= 160 * 1024 && (long)B * H <= 65535, "relpos_slab: L = %d too long for one LDS image (or B*H too large)", L);
+    dim3 grid(cdiv(L, 16 * SLAB_RB), B * H);
+    const bool single = L <= 512;
+#define SLAB_LAUNCH(DHV, SV) do { \
+        if (lds > 64 * 1024) { \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(relpos_slab_kernel<DHV, SV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) { ttmi_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; } \
+        } \
+        hipLaunchKernelGGL((relpos_slab_kernel<DHV, SV>), grid, dim3(256), lds, st, q, ld_q, E, ld_e, c, L, H, G, g_slab_dbg); } while (0)
+    if (Dh == 64) { if (single) SLAB_LAUNCH(64, true); else SLAB_LAUNCH(64, false); }
+    else { if (single) SLAB_LAUNCH(32, true); else SLAB_LAUNCH(32, false); }
+#undef SLAB_LAUNCH
+    TTMI_LAUNCH_CHECK("relpos_slab_kernel");
+    return TTMI_OK;
+}
+
 int flash_attn_fwd(const FlashParams& p, hipStream_t st) {
     TTMI_REQUIRE(p.qu && p.k && p.v && p.bd && p.o && p.lse, "flash_attn_fwd: null pointer");
     TTMI_REQUIRE(flash_supported(p.Dh, p.ld_qu, p.ld_kv, p.ld_o), "flash_attn_fwd: unsupported head dim %d / pitches", p.Dh);

@@ -1252,8 +1252,8 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
     TTMI_REQUIRE(nbatch >= 1 && nbatch <= 65535, "gemm_tn_bf16: bad batch count %d", nbatch);
     // huge-reduction wgrad (the joint projection: K = B*T*U1 rows): persistent 256x256 kernel on the 256-row tiles that are
     // full, the 128x128 kernel below on the remaining M % 256 rows
-    const bool tn8 = (g_gemm_fast_version == 4 || g_gemm_fast_version == 8) && nbatch == 1 && accumulate && K >= 32768 && K % TK == 0 &&
-                     M >= 1024 && N >= 256 && N % 256 == 0 && (N / 256) % 4 == 0;
+    const bool tn8 = nbatch == 1 && accumulate && K % TK == 0 && N >= 256 && N % 256 == 0 && (!colsum_a || (N / 256) % 4 == 0) &&
+                     ((g_gemm_fast_version == 4 && K >= 32768 && M >= 1024) || (g_gemm_fast_version == 8 && K >= 2048 && M >= 256));
     if (tn8) {
         if (g_num_cus == 0) {
             int dev = 0, n = 0;

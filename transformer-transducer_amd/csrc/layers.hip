@@ -59,6 +59,7 @@ int wgrad(const float* dY, const float* X, float* gW, int M, int N, int K, long 
 // library-owned side stream (one per caller stream) and joined before the call returns (scratch buffers they read are reused by
 // the next call).  ttmi_set_option(3, 0) disables it.
 int g_fork_wgrad = 1;
+int g_gemm_slab = 0;            // ttmi_set_option(5, 1): position-term slab by the batched GEMM (A/B measurements)
 struct SideCtx {
     hipStream_t main = nullptr, side = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -279,8 +280,12 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
     // 3. effective tables for this length (clamped rows when L > K)
     CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st));
     // 4. G = q E^T + c into the pitch-(L+1) slab, column 0 zero
-    CK(memset2d(c.P, (size_t)(L + 1) * 4, 4, (size_t)B * H * L, st));
-    if (attn_fused(fast, a) && Dh % 8 == 0) {
+    if (attn_fused(fast, a) && g_gemm_slab == 0 && (size_t)16 * (L + 1) * 4 + 32 <= 160 * 1024) {
+        // write-bound: dedicated kernel that streams whole slab rows (column 0 included) instead of a batched GEMM + strided memset
+        CK(convert_bf16(w.E, w.E16, (long)L * a.HD, st));
+        CK(relpos_slab(static_cast<const bf16_t*>(c.qkv), a.W3, w.E16, a.HD, w.cT, B, L, H, Dh, c.P, st));
+    } else if (attn_fused(fast, a) && Dh % 8 == 0) {
+        CK(memset2d(c.P, (size_t)(L + 1) * 4, 4, (size_t)B * H * L, st));
         // on the glds kernel: q (bf16, in place in qkv) x E16^T, batched over (b, h), bias c, pitch-(L+1) f32 output
         CK(convert_bf16(w.E, w.E16, (long)L * a.HD, st));
         FastBatch fb;
@@ -290,6 +295,7 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
         e.bias = w.cT;
         CK(gemm_nt_bf16(static_cast<const bf16_t*>(c.qkv), w.E16, c.P + 1, 0, e, L, L, Dh, a.W3, a.HD, L + 1, st, fb));
     } else {
+        CK(memset2d(c.P, (size_t)(L + 1) * 4, 4, (size_t)B * H * L, st));
         GemmDesc g = mkx(c.qkv, adt, w.E, DT_F32, c.P + 1, DT_F32, L, L, Dh, a.W3, a.HD, L + 1, NT_ | GEMM_BIAS, prec);
         batch_bh(g, a, L * a.W3, Dh, 0, Dh, H * a.slab, a.slab);
         g.bias = w.cT; g.sBias1 = 0; g.sBias2 = L;
@@ -717,8 +723,9 @@ int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float*
 // process-wide switches for A/B measurements.  key 0: 1 = disable the fused attention kernels (bf16 pipeline only);
 // key 1: throughput-GEMM generation (see gemm_fast.hip); key 2: flash-kernel timing switches; key 3: 0 = no wgrad fork
 int ttmi_set_option(int key, int value) {
-    TTMI_REQUIRE(key >= 0 && key <= 4, "set_option: unknown key %d", key);
+    TTMI_REQUIRE(key >= 0 && key <= 5, "set_option: unknown key %d", key);
     if (key == 4) { gemm_fast_set_tn_target(value); return TTMI_OK; }
+    if (key == 5) { g_gemm_slab = value & 1; relpos_slab_set_debug(value >> 1); return TTMI_OK; }
     if (key == 0) g_disable_fused_attention = value;
     else if (key == 1) gemm_fast_set_version(value);
     else if (key == 2) g_flash_debug = value;
