@@ -201,7 +201,7 @@ def main():
                                    ", T=%d U=%d, batch %d/GPU, dropout 0.1, SGD momentum + clip 200" % (T, U, B),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
             "model_tflops": round(flops_per_utt(cfg, T, U1) * utt_s / 1e12, 2),
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel (joint vocabulary projection, M=%d N=%d K=%d)" % (B * T * U1, V, J),
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_v8_kernel (joint vocabulary projection, M=%d N=%d K=%d)" % (B * T * U1, V, J),
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "traffic": traffic, "kernel_ms": round(k_ms, 4)},
             "final_loss": round(float(last), 4),
