@@ -115,7 +115,8 @@ int ttmi_adam_step(float* p, const float* g, float* m, float* v, long n, float l
 
 /* ---- bring-up / measurement helpers ------------------------------------------------------------------------------
  * generic MFMA GEMM (every layout / dtype / epilogue; flags = GemmFlags of csrc/gemm.h) and the two throughput
- * kernels; HIP-event probes recorded on the launch stream around one kernel (slot 0 = joint vocabulary projection). */
+ * kernels; HIP-event probes recorded on the launch stream around the joint vocabulary projection: ttmi_probe_arm(i), 0 <= i < 64,
+ * makes the NEXT such launch record into event pair i; ttmi_probe_read_ms(i) waits for pair i and returns its duration. */
 int ttmi_gemm(const void* A, const void* B, void* C, const float* bias, const float* aux, int a_dtype, int b_dtype,
               int c_dtype, int M, int N, int K, long lda, long ldb, long ldc, int nz1, int nz2, long sA1, long sA2,
               long sB1, long sB2, long sC1, long sC2, float alpha, float beta, int flags, int splitk, void* stream);
