@@ -25,6 +25,7 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(0)
     vers = [int(v) for v in os.environ.get("GEMM_VERSIONS", "4").split(",")]
     rows = 16000
+    ops.set_option(4, int(os.environ.get("TTMI_TN_TARGET", "512")))
     for ver in vers:
         ops.set_option(1, ver)
         tot = 0.0
