@@ -353,17 +353,17 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
     AttnWs w(bw, a, fast);
     const float scale = 1.0f / sqrtf((float)Dh);
     // 1. dres = LN'(dy) -> dx (doubles as the residual gradient)
-    CK(ln_bwd(dy, c.s1, c.mean, c.rstd, ln_g, nullptr, a.BL, d, dx, g_ln_g, g_ln_b, st));
-    // 2. gWo += da^T O ; 3. dO = da Wo, with da = dres * dropout mask of the forward (dres itself stays the residual grad)
+    // 2. gWo += da^T O ; 3. dO = da Wo, with da = dres * dropout mask of the forward (dres itself stays the residual grad);
+    //    the bf16 pipeline gets da from the same pass
     DropSpec rd;
     rd.p = p_drop; rd.seed = seed ^ 0xA1u;
+    CK(ln_bwd(dy, c.s1, c.mean, c.rstd, ln_g, nullptr, a.BL, d, dx, g_ln_g, g_ln_b, st, DropSpec(), fast ? w.dres16 : nullptr, rd, nullptr));
     const float* da = dx;
     if (!fast && p_drop > 0.f) {
         CK(dropout_apply(dx, a.BL * d, rd, w.a, nullptr, st));
         da = w.a;
     }
     if (fast) {
-        CK(dropout_apply(dx, a.BL * d, rd, nullptr, w.dres16, st));
         CK(gemm_tn_bf16(w.dres16, static_cast<bf16_t*>(c.O), g_o_w, d, (int)a.HD, (int)a.BL, d, a.HD, a.HD, 1, fork_stream(st)));
         CK(transpose_convert_bf16(o_w, d, (int)a.HD, w.wo16, d, st));                          // Wo^T [HD, d]
         CK(gemm_nt_bf16(w.dres16, w.wo16, w.dO, 1, nullptr, (int)a.BL, (int)a.HD, d, d, d, a.HD, st));
@@ -583,14 +583,18 @@ int ttmi_ffn_bwd(const float* dz, const float* y, const float* w1, const float* 
     d_out.p = p_drop; d_out.seed = seed ^ 0xC3u;
     d_layer.p = p_layer; d_layer.seed = seed ^ 0xD4u;
     const float inv_keep = 1.f / (1.f - p_drop);
-    CK(ln_bwd(dz, c.s2, c.mean2, c.rstd2, ln_g, nullptr, rows, d, w.dres, g_ln_g, g_ln_b, st, d_layer));
-    // df = dres * mask(CoreNet.4); dres itself remains the residual-branch gradient
+    // df = dres * mask(CoreNet.4); dres itself remains the residual-branch gradient.  bf16 pipeline: df (bf16) and g_b2 = its
+    // column sums come out of the LayerNorm-backward pass itself
+    CK(ln_bwd(dz, c.s2, c.mean2, c.rstd2, ln_g, nullptr, rows, d, w.dres, g_ln_g, g_ln_b, st, d_layer, fast ? w.dres16 : nullptr, d_out,
+              fast ? g_b2 : nullptr));
     const float* df = w.dres;
-    if (p_drop > 0.f || fast) {
-        CK(dropout_apply(w.dres, rows * d, d_out, p_drop > 0.f ? w.f : nullptr, fast ? w.dres16 : nullptr, st));
-        if (p_drop > 0.f) df = w.f;
+    if (!fast) {
+        if (p_drop > 0.f) {
+            CK(dropout_apply(w.dres, rows * d, d_out, w.f, nullptr, st));
+            df = w.f;
+        }
+        CK(colsum(df, d, rows, d, 1, 1, 0, 0, 0, 0, g_b2, st));
     }
-    CK(colsum(df, d, rows, d, 1, 1, 0, 0, 0, 0, g_b2, st));
     if (fast) {
         bf16_t* a1 = static_cast<bf16_t*>(c.a1);
         bf16_t* h = static_cast<bf16_t*>(c.h);

@@ -19,8 +19,11 @@ int ln_fwd(const float* x, const float* res, const float* g, const float* b, lon
            DropSpec out_drop = DropSpec());
 // dx = dadd + LN'(dy) ; dgamma/dbeta accumulated atomically (caller zeroes them once per step)
 // dy_drop: the forward applied dropout to the LN output, so dy is masked/scaled identically on the way in
+// dx16 (optional, bf16 pipeline): bf16(dx * dropout(dx16_drop)) - the masked gradient the following GEMMs consume - and, with
+// dx16_colsum, its column sums accumulated atomically (the bias gradient of the Linear in front of that dropout)
 int ln_bwd(const float* dy, const float* s, const float* mean, const float* rstd, const float* g, const float* dadd, long rows,
-           int d, float* dx, float* dgamma, float* dbeta, hipStream_t st, DropSpec dy_drop = DropSpec());
+           int d, float* dx, float* dgamma, float* dbeta, hipStream_t st, DropSpec dy_drop = DropSpec(), bf16_t* dx16 = nullptr,
+           DropSpec dx16_drop = DropSpec(), float* dx16_colsum = nullptr);
 // out[i] = in[i] * dropout_multiplier(i)  (out f32 and/or bf16); with p = 0 this is the plain f32 -> bf16 conversion
 int dropout_apply(const float* in, long n, DropSpec ds, float* out32, bf16_t* out16, hipStream_t st);
 // in-place P = softmax_j(scale * S) over the batched score view (nb slabs, L rows of ld floats each)

@@ -155,17 +155,20 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restri
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ g, const float* __restrict__ dadd, long rows,
                                                            int d, float* __restrict__ dx, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, DropSpec ddrop) {
-    __shared__ float red[2][4][KV * 256];
+                                                           float* __restrict__ dbeta, DropSpec ddrop, bf16_t* __restrict__ dx16,
+                                                           DropSpec xdrop, float* __restrict__ dx16_colsum) {
+    // optional second output for the bf16 pipeline: dx16 = bf16(dx * dropout(xdrop)) (the masked gradient the following
+    // GEMMs consume) and its column sums (the bias gradient of the Linear in front of the dropout)
+    __shared__ float red[3][4][KV * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float gam[KV][4], ag[KV][4], ab[KV][4];
+    float gam[KV][4], ag[KV][4], ab[KV][4], ac[KV][4];
 #pragma unroll
     for (int k = 0; k < KV; ++k) {
         const int c0 = k * 256 + lane * 4;
         const float4 gv = c0 < d ? *reinterpret_cast<const float4*>(g + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
         gam[k][0] = gv.x; gam[k][1] = gv.y; gam[k][2] = gv.z; gam[k][3] = gv.w;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) ag[k][c] = ab[k][c] = 0.f;
+        for (int c = 0; c < 4; ++c) ag[k][c] = ab[k][c] = ac[k][c] = 0.f;
     }
     const float invd = 1.f / d;
     for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
@@ -208,6 +211,18 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restri
                     o[0] += e.x; o[1] += e.y; o[2] += e.z; o[3] += e.w;
                 }
                 *reinterpret_cast<float4*>(dx + base + c0) = make_float4(o[0], o[1], o[2], o[3]);
+                if (dx16) {
+                    float m[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        m[c] = o[c] * drop_mult(xdrop, base + c0 + c);
+                        ac[k][c] += m[c];
+                    }
+                    uint2 w;
+                    w.x = pack_bf16x2(m[0], m[1]);
+                    w.y = pack_bf16x2(m[2], m[3]);
+                    *reinterpret_cast<uint2*>(dx16 + base + c0) = w;
+                }
             }
         }
     }
@@ -217,11 +232,13 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restri
         for (int c = 0; c < 4; ++c) {
             red[0][wave][k * 256 + lane * 4 + c] = ag[k][c];
             red[1][wave][k * 256 + lane * 4 + c] = ab[k][c];
+            red[2][wave][k * 256 + lane * 4 + c] = ac[k][c];
         }
     __syncthreads();
     for (int c = threadIdx.x; c < d; c += 256) {
         atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
         atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        if (dx16_colsum) atomicAdd(dx16_colsum + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
     }
 }
 
@@ -308,6 +325,32 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
     float a = 0.f;
     for (long r = r0; r < r1; ++r) a += p[r * ld + c];
     atomicAdd(out + z1 * so1 + z2 * so2 + c, a);
+}
+
+// vector form (cols % 4 == 0, 16-byte aligned rows): thread = 4 columns x every 4th row of a 64-row slab, four loads in flight,
+// the block's 4 row-lanes combined in LDS, one atomic per column and block (the scalar kernel above ran at 0.85 TB/s)
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict__ in, long ld, long rows, int cols,
+                                                         float* __restrict__ out) {
+    __shared__ float red[4][256];
+    const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 256 + cg * 4;
+    const long r0 = (long)blockIdx.y * 64;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < cols) {
+#pragma unroll 4
+        for (int k = 0; k < 16; ++k) {
+            const long r = r0 + rl + 4 * k;
+            if (r < rows) {
+                const float4 v = *reinterpret_cast<const float4*>(in + r * ld + c0);
+                a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[rl][cg * 4 + c] = a[c];
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < cols) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 __global__ void relpos_gather_kernel(const float* __restrict__ r_emb, const float* __restrict__ r_bias, int K, int L, int H,
@@ -623,14 +666,17 @@ int ln_fwd(const float* x, const float* res, const float* g, const float* b, lon
 }
 
 int ln_bwd(const float* dy, const float* s, const float* mean, const float* rstd, const float* g, const float* dadd, long rows,
-           int d, float* dx, float* dgamma, float* dbeta, hipStream_t st, DropSpec dy_drop) {
+           int d, float* dx, float* dgamma, float* dbeta, hipStream_t st, DropSpec dy_drop, bf16_t* dx16, DropSpec dx16_drop,
+           float* dx16_colsum) {
     TTMI_REQUIRE(dy && s && mean && rstd && g && dx && dgamma && dbeta && rows > 0 && d > 0, "ln_bwd: bad arguments");
-    if (d % 4 == 0 && d <= 512 && aligned16(dy) && aligned16(s) && aligned16(g) && aligned16(dx) && (!dadd || aligned16(dadd))) {
+    const bool fused = d % 4 == 0 && d <= 512 && aligned16(dy) && aligned16(s) && aligned16(g) && aligned16(dx) && (!dadd || aligned16(dadd)) &&
+                       (!dx16 || (reinterpret_cast<uintptr_t>(dx16) & 7) == 0);
+    if (fused) {
         const int grid = (int)std::min<long>(cdiv(rows, 4), 512);         // ~2 blocks per CU; rows are walked grid-stride
         if (d <= 256)
-            hipLaunchKernelGGL(ln_bwd_fused_kernel<1>, dim3(grid), dim3(256), 0, st, dy, s, mean, rstd, g, dadd, rows, d, dx, dgamma, dbeta, dy_drop);
+            hipLaunchKernelGGL(ln_bwd_fused_kernel<1>, dim3(grid), dim3(256), 0, st, dy, s, mean, rstd, g, dadd, rows, d, dx, dgamma, dbeta, dy_drop, dx16, dx16_drop, dx16_colsum);
         else
-            hipLaunchKernelGGL(ln_bwd_fused_kernel<2>, dim3(grid), dim3(256), 0, st, dy, s, mean, rstd, g, dadd, rows, d, dx, dgamma, dbeta, dy_drop);
+            hipLaunchKernelGGL(ln_bwd_fused_kernel<2>, dim3(grid), dim3(256), 0, st, dy, s, mean, rstd, g, dadd, rows, d, dx, dgamma, dbeta, dy_drop, dx16, dx16_drop, dx16_colsum);
         TTMI_LAUNCH_CHECK("ln_bwd_fused_kernel");
         return TTMI_OK;
     }
@@ -640,6 +686,10 @@ int ln_bwd(const float* dy, const float* s, const float* mean, const float* rstd
     hipLaunchKernelGGL(ln_bwd_params_kernel, dim3(cdiv(d, 256), cdiv(rows, LNP_ROWS)), dim3(256), 0, st, dy, s, mean, rstd, rows,
                        d, dgamma, dbeta, dy_drop);
     TTMI_LAUNCH_CHECK("ln_bwd_params_kernel");
+    if (dx16) {                                             // shapes the fused kernel does not take: same results by separate passes
+        if (int rc = dropout_apply(dx, rows * d, dx16_drop, nullptr, dx16, st)) return rc;
+        if (dx16_colsum) return colsum_bf16(dx16, d, rows, d, dx16_colsum, st, 1, 1, 0, 0, 0);
+    }
     return TTMI_OK;
 }
 
@@ -670,6 +720,11 @@ int add_row_bias(const float* in, long ldi, const float* bias, long rows, int co
 int colsum(const float* in, long ld, long rows, int cols, int nz1, int nz2, long si1, long si2, long so1, long so2, float* out,
            hipStream_t st) {
     TTMI_REQUIRE(in && out && rows > 0 && cols > 0 && nz1 > 0 && nz2 > 0, "colsum: bad arguments");
+    if (nz1 * nz2 == 1 && cols % 4 == 0 && ld % 4 == 0 && aligned16(in) && cdiv(rows, 64) <= 65535) {
+        hipLaunchKernelGGL(colsum_vec_kernel, dim3(cdiv(cols, 256), cdiv(rows, 64)), dim3(256), 0, st, in, ld, rows, cols, out);
+        TTMI_LAUNCH_CHECK("colsum_vec_kernel");
+        return TTMI_OK;
+    }
     dim3 grid(cdiv(cols, 256), cdiv(rows, CS_ROWS), nz1 * nz2);
     TTMI_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "colsum: grid too large");
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, in, ld, rows, cols, nz2, si1, si2, so1, so2, out);
