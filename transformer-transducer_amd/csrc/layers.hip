@@ -146,6 +146,7 @@ GemmDesc mkx(const void* A, int adt, const void* B, int bdt, void* C, int cdt, i
 struct AttnCtx {   // saved for backward.  act = f32 (parity) or bf16 (fast)
     void *qkv, *qu, *O;
     float *P, *s1, *mean, *rstd, *lse;     // P: probabilities (unfused path) or the G slab (fused path)
+    bf16_t* x16 = nullptr;                 // bf16 copy of the input (fast): the qkv wgrad reads it again in backward
     AttnCtx(Bump& b, const AttnDims& a, bool fast) {
         const size_t es = fast ? 2 : 4;
         qkv = b.take<char>(a.BL * a.W3 * es);
@@ -156,13 +157,14 @@ struct AttnCtx {   // saved for backward.  act = f32 (parity) or bf16 (fast)
         mean = b.take<float>(a.BL);
         rstd = b.take<float>(a.BL);
         lse = b.take<float>((size_t)a.B * a.H * a.L);
+        if (fast) x16 = b.take<bf16_t>(a.BL * a.d);
     }
 };
 
 struct AttnWs {   // scratch (union of forward and backward needs)
     float *E, *cT, *dE, *dcT, *a, *dS, *dqkv, *delta;
     void* dO;
-    bf16_t *x16, *wqkv16, *wo16, *dqkv16, *dres16, *dS16, *dG16, *E16, *kT16, *ET16;
+    bf16_t *wqkv16, *wo16, *dqkv16, *dres16, *dS16, *dG16, *E16, *kT16, *ET16;
     long ldp, slab16;
     AttnWs(Bump& b, const AttnDims& a, bool fast) {
         E = b.take<float>((size_t)a.L * a.HD);
@@ -174,7 +176,7 @@ struct AttnWs {   // scratch (union of forward and backward needs)
         dqkv = b.take<float>(a.BL * a.W3);
         delta = b.take<float>((size_t)a.B * a.H * a.L);
         dO = b.take<char>(a.BL * a.HD * (fast ? 2 : 4));
-        x16 = wqkv16 = wo16 = dqkv16 = dres16 = dS16 = dG16 = E16 = kT16 = ET16 = nullptr;
+        wqkv16 = wo16 = dqkv16 = dres16 = dS16 = dG16 = E16 = kT16 = ET16 = nullptr;
         ldp = (a.L + 7) / 8 * 8;
         slab16 = (long)a.L * ldp;
         if (fast) {
@@ -183,7 +185,6 @@ struct AttnWs {   // scratch (union of forward and backward needs)
             E16 = b.take<bf16_t>((size_t)a.L * a.HD);
             kT16 = b.take<bf16_t>((size_t)a.B * a.H * a.Dh * ldp);
             ET16 = b.take<bf16_t>((size_t)a.H * a.Dh * ldp);
-            x16 = b.take<bf16_t>(a.BL * a.d);
             wqkv16 = b.take<bf16_t>(a.W3 * a.d);
             wo16 = b.take<bf16_t>(a.HD * a.d);
             dqkv16 = b.take<bf16_t>(a.BL * a.W3);
@@ -269,9 +270,9 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
     const float scale = 1.0f / sqrtf((float)Dh);
     // 1. qkv = x Wqkv^T ; 2. qu = q + r_w_bias
     if (fast) {
-        CK(convert_bf16(x, w.x16, a.BL * d, st));
+        CK(convert_bf16(x, c.x16, a.BL * d, st));
         CK(convert_bf16(qkv_w, w.wqkv16, a.W3 * d, st));
-        CK(gemm_nt_bf16(w.x16, w.wqkv16, c.qkv, 1, nullptr, (int)a.BL, (int)a.W3, d, d, d, a.W3, st));
+        CK(gemm_nt_bf16(c.x16, w.wqkv16, c.qkv, 1, nullptr, (int)a.BL, (int)a.W3, d, d, d, a.W3, st));
         CK(add_row_bias_bf16(static_cast<bf16_t*>(c.qkv), a.W3, r_w_bias, a.BL, (int)a.HD, static_cast<bf16_t*>(c.qu), a.HD, st));
     } else {
         CK(ttmi_launch_gemm(mk(x, qkv_w, static_cast<float*>(c.qkv), (int)a.BL, (int)a.W3, d, d, d, a.W3, NT_, prec), st));
@@ -381,6 +382,7 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
         f.delta = w.delta;
         f.dS16 = w.dS16; f.dG16 = w.dG16; f.ldp = w.ldp; f.slab16 = w.slab16;
         f.dK = w.dqkv + a.HD; f.dV = w.dqkv + 2 * a.HD; f.ld_dkv = a.W3;
+        f.dK16 = w.dqkv16 + a.HD; f.dV16 = w.dqkv16 + 2 * a.HD;
         CK(flash_attn_bwd(f, st));
     } else {
         // first L floats of each dS slab lie outside the pitch-L view but inside dG's row 0: zero them
@@ -440,8 +442,8 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
         fb.nz1 = B; fb.nz2 = H; fb.sA1 = H * w.slab16; fb.sA2 = w.slab16; fb.sB1 = 0; fb.sB2 = (long)Dh * w.ldp;
         fb.sC1 = L * a.W3; fb.sC2 = Dh;
         NtEpilogue e;
-        e.addend = w.dqkv;
-        CK(gemm_nt_bf16(w.dG16, w.ET16, w.dqkv, 0, e, L, Dh, (int)w.ldp, w.ldp, w.ldp, a.W3, st, fb));
+        e.addend = w.dqkv;                          // content part (f32); the sum leaves in bf16, the form the qkv GEMMs read
+        CK(gemm_nt_bf16(w.dG16, w.ET16, w.dqkv16, 1, e, L, Dh, (int)w.ldp, w.ldp, w.ldp, a.W3, st, fb));
         FastBatch tb;
         tb.nz1 = B; tb.nz2 = H; tb.sA1 = H * w.slab16; tb.sA2 = w.slab16; tb.sB1 = L * a.W3; tb.sB2 = Dh; tb.sC1 = 0; tb.sC2 = Dh;
         tb.sV1 = 0; tb.sV2 = L;
@@ -468,9 +470,8 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
     CK(relpos_scatter(w.dE, w.dcT, K, L, H, Dh, g_r_emb, g_r_bias, st));
     // 14. gWqkv += dqkv^T x ; 15. dx += dqkv Wqkv
     if (fast) {
-        CK(convert_bf16(w.dqkv, w.dqkv16, a.BL * a.W3, st));
-        CK(convert_bf16(x, w.x16, a.BL * d, st));
-        CK(gemm_tn_bf16(w.dqkv16, w.x16, g_qkv_w, (int)a.W3, d, (int)a.BL, a.W3, d, d, 1, fork_stream(st)));
+        if (!fastpos) CK(convert_bf16(w.dqkv, w.dqkv16, a.BL * a.W3, st));      // fastpos: dq / dK / dV were written in bf16 by their producers
+        CK(gemm_tn_bf16(w.dqkv16, c.x16, g_qkv_w, (int)a.W3, d, (int)a.BL, a.W3, d, d, 1, fork_stream(st)));
         CK(transpose_convert_bf16(qkv_w, (int)a.W3, d, w.wqkv16, a.W3, st));                   // Wqkv^T [d, W3]
         NtEpilogue e;
         e.addend = dx;
