@@ -8,7 +8,7 @@ struct FlashParams {
     const bf16_t* k = nullptr;
     const bf16_t* v = nullptr;
     long ld_qu = 0, ld_kv = 0, ld_o = 0;
-    const float* bd = nullptr;    // shifted position scores: element (z, i, j) at bd[z*slab + i*L + j]  (z = b*H + h)
+    const bf16_t* bd = nullptr;   // shifted position scores (bf16): element (z, i, j) at bd[z*slab + i*L + j]  (z = b*H + h)
     long slab = 0;
     bf16_t* o = nullptr;          // attention output (fwd: written, bwd: read)
     float* lse = nullptr;         // [B*H, L] log-sum-exp of the scaled, masked scores
@@ -39,8 +39,8 @@ struct FlashParams {
 bool flash_supported(int Dh, long ld_qu, long ld_kv, long ld_o);
 int flash_attn_fwd(const FlashParams& p, hipStream_t st);
 int flash_attn_bwd(const FlashParams& p, hipStream_t st);
-// G slab of the position term (q E^T + c, column 0 zero, row pitch L+1, f32) for all (b, h): q rows (b, i) at q[(b*L+i)*ld_q + h*Dh],
+// G slab of the position term (q E^T + c, column 0 zero, row pitch L+1, bf16) for all (b, h): q rows (b, i) at q[(b*L+i)*ld_q + h*Dh],
 // E rows p at E[p*ld_e + h*Dh], c[h][p]
-int relpos_slab(const bf16_t* q, long ld_q, const bf16_t* E, long ld_e, const float* c, int B, int L, int H, int Dh, float* G,
+int relpos_slab(const bf16_t* q, long ld_q, const bf16_t* E, long ld_e, const float* c, int B, int L, int H, int Dh, bf16_t* G,
                 hipStream_t st);
 void relpos_slab_set_debug(int bits);   // timing experiments only: 1 = skip the MFMA part, 2 = skip the stores

@@ -125,12 +125,12 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m = NEGBIG, l = 0.f;
-    const float* bd_row = p.bd + (long)z * p.slab + (long)ic * L;
+    const bf16_t* bd_row = p.bd + (long)z * p.slab + (long)ic * L;
     const bf16_t* kbase = p.k + (long)b * L * p.ld_kv + h * DH;
     const bf16_t* vbase = p.v + (long)b * L * p.ld_kv + h * DH;
 
-    // bias of one 32-key sub-tile for this lane's query: keys jb + 4 hh + 8 g + (0..3), g = 0..3  ->  4 float4 when aligned
-    const bool bvec = (L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.bd) & 15) == 0) && (p.slab % 4 == 0);
+    // bias of one 32-key sub-tile for this lane's query: keys jb + 4 hh + 8 g + (0..3), g = 0..3  ->  4 x 8-byte loads when aligned
+    const bool bvec = (L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.bd) & 7) == 0) && (p.slab % 4 == 0);
     auto load_bias = [&](int jb, float (&bv)[16]) {
         if (p.debug & 1) {
 #pragma unroll
@@ -140,12 +140,13 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashParams p) {
         if (bvec && jb + 32 <= L) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const float4 t = *reinterpret_cast<const float4*>(bd_row + jb + 4 * hh + 8 * g4);
-                bv[4 * g4] = t.x; bv[4 * g4 + 1] = t.y; bv[4 * g4 + 2] = t.z; bv[4 * g4 + 3] = t.w;
+                const uint2 t = *reinterpret_cast<const uint2*>(bd_row + jb + 4 * hh + 8 * g4);
+                bv[4 * g4] = __uint_as_float(t.x << 16); bv[4 * g4 + 1] = __uint_as_float(t.x & 0xffff0000u);
+                bv[4 * g4 + 2] = __uint_as_float(t.y << 16); bv[4 * g4 + 3] = __uint_as_float(t.y & 0xffff0000u);
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) bv[r] = bd_row[min(jb + (r & 3) + 8 * (r >> 2) + 4 * hh, L - 1)];
+            for (int r = 0; r < 16; ++r) bv[r] = bf16_to_f32(bd_row[min(jb + (r & 3) + 8 * (r >> 2) + 4 * hh, L - 1)]);
         }
     };
     auto sub_step = [&](int jb, int sub, float (&bcur)[16], float (&bnxt)[16]) {
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) 
         for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
     const bf16_t* qbase = p.qu + (long)b * L * p.ld_qu + h * DH;
     const bf16_t* dobase = p.dO + (long)b * L * p.ld_o + h * DH;
-    const float* bd = p.bd + (long)z * p.slab;
+    const bf16_t* bd = p.bd + (long)z * p.slab;
     bf16_t* ds16 = p.dS16 + (long)z * p.slab16;
     bf16_t* dg16 = p.dG16 + (long)z * p.slab16;
 
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = min(i0 + (r & 3) + 8 * (r >> 2) + 4 * hh, L - 1);
-            bv[r] = (p.debug & 1) ? 0.f : bd[(long)i * L + jc];
+            bv[r] = (p.debug & 1) ? 0.f : bf16_to_f32(bd[(long)i * L + jc]);
         }
     };
     RowStage<DH, 32> stQ, stO;
@@ -407,8 +408,8 @@ constexpr int SLAB_RB = 4;        // 16-row blocks per workgroup: E_h (L x Dh, r
 template <int DH, bool SINGLE>
 __global__ __launch_bounds__(256, 4) void relpos_slab_kernel(const bf16_t* __restrict__ q, long ld_q, const bf16_t* __restrict__ E,
                                                              long ld_e, const float* __restrict__ c, int L, int H,
-                                                             float* __restrict__ G, int dbg) {
-    extern __shared__ __attribute__((aligned(16))) float img[];
+                                                             bf16_t* __restrict__ G, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t img[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int z = blockIdx.y, b = z / H, h = z % H;
     const int fr = lane & 15, fq = lane >> 4;
@@ -443,13 +444,13 @@ __global__ __launch_bounds__(256, 4) void relpos_slab_kernel(const bf16_t* __res
         const int r0 = (blockIdx.x * SLAB_RB + rbi) * 16;
         if (r0 >= L) break;
         const int nrows = min(16, L - r0);
-        const long g0 = (long)z * L * (L + 1) + (long)r0 * (L + 1);   // first float of this block's run
-        const int sh = (int)(g0 & 3);
+        const long g0 = (long)z * L * (L + 1) + (long)r0 * (L + 1);   // first element of this block's run
+        const int sh = (int)(g0 & 7);
         bf16x8_t qf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
         load_q(r0 + 16);                                              // next block's rows fly under this block's work
-        if (tid < 16) img[sh + tid * (L + 1)] = 0.f;
+        if (tid < 16) img[sh + tid * (L + 1)] = 0;
         for (int c0 = wave; c0 < ntile && !(dbg & 1); c0 += 32) {
             if (!SINGLE) load_tiles(c0);
             float cbA[4], cbB[4];                          // bias values one tile ahead (a load per tile after its MFMA would serialise)
@@ -462,14 +463,14 @@ __global__ __launch_bounds__(256, 4) void relpos_slab_kernel(const bf16_t* __res
                 for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ef[u][ks], qf[ks], acc, 0, 0, 0);
                 // acc[j] = G[r0 + fr][p = ct*16 + fq*4 + j]
                 const int p0 = ct * 16 + fq * 4;
-                float* dst = img + sh + fr * (L + 1) + 1 + p0;
+                bf16_t* dst = img + sh + fr * (L + 1) + 1 + p0;
                 if (ct * 16 + 16 <= L) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) dst[j] = acc[j] + cb[j];
+                    for (int j = 0; j < 4; ++j) dst[j] = f32_to_bf16(acc[j] + cb[j]);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (p0 + j < L) dst[j] = acc[j] + cb[j];
+                        if (p0 + j < L) dst[j] = f32_to_bf16(acc[j] + cb[j]);
                 }
             };
 #pragma unroll
@@ -481,15 +482,15 @@ __global__ __launch_bounds__(256, 4) void relpos_slab_kernel(const bf16_t* __res
             }
         }
         __syncthreads();
-        const int n = nrows * (L + 1);                       // floats in the run; LDS index sh + e <-> global g0 + e
-        float* gal = G + (g0 - sh);                          // 16-byte aligned (G itself is)
-        for (int i4 = tid * 4; i4 < sh + n && !(dbg & 2); i4 += 1024) {
-            if (i4 >= sh && i4 + 3 < sh + n) {
-                *reinterpret_cast<float4*>(gal + i4) = *reinterpret_cast<const float4*>(img + i4);
+        const int n = nrows * (L + 1);                       // elements in the run; LDS index sh + e <-> global g0 + e
+        bf16_t* gal = G + (g0 - sh);                         // 16-byte aligned (G itself is)
+        for (int i8 = tid * 8; i8 < sh + n && !(dbg & 2); i8 += 2048) {
+            if (i8 >= sh && i8 + 7 < sh + n) {
+                *reinterpret_cast<uint4*>(gal + i8) = *reinterpret_cast<const uint4*>(img + i8);
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (i4 + e >= sh && i4 + e < sh + n) gal[i4 + e] = img[i4 + e];
+                for (int e = 0; e < 8; ++e)
+                    if (i8 + e >= sh && i8 + e < sh + n) gal[i8 + e] = img[i8 + e];
             }
         }
         // the image is rebuilt for the next row block: its LDS reads must have retired, the global stores need not (a
@@ -501,11 +502,11 @@ __global__ __launch_bounds__(256, 4) void relpos_slab_kernel(const bf16_t* __res
 
 void relpos_slab_set_debug(int bits) { g_slab_dbg = bits; }
 
-int relpos_slab(const bf16_t* q, long ld_q, const bf16_t* E, long ld_e, const float* c, int B, int L, int H, int Dh, float* G,
+int relpos_slab(const bf16_t* q, long ld_q, const bf16_t* E, long ld_e, const float* c, int B, int L, int H, int Dh, bf16_t* G,
                 hipStream_t st) {
     TTMI_REQUIRE(q && E && c && G && B > 0 && L > 0 && H > 0 && (Dh == 32 || Dh == 64), "relpos_slab: bad arguments");
     TTMI_REQUIRE(aligned16(q) && aligned16(E) && aligned16(G) && ld_q % 8 == 0 && ld_e % 8 == 0, "relpos_slab: alignment");
-    const size_t lds = ((size_t)16 * (L + 1) + 8) * sizeof(float);
+    const size_t lds = ((size_t)16 * (L + 1) + 16) * sizeof(bf16_t);
     TTMI_REQUIRE(lds <= 160 * 1024 && (long)B * H <= 65535, "relpos_slab: L = %d too long for one LDS image (or B*H too large)", L);
     dim3 grid(cdiv(L, 16 * SLAB_RB), B * H);
     const bool single = L <= 512;

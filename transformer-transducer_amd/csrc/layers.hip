@@ -145,7 +145,7 @@ GemmDesc mkx(const void* A, int adt, const void* B, int bdt, void* C, int cdt, i
 
 struct AttnCtx {   // saved for backward.  act = f32 (parity) or bf16 (fast)
     void *qkv, *qu, *O;
-    float *P, *s1, *mean, *rstd, *lse;     // P: probabilities (unfused path) or the G slab (fused path)
+    float *P, *s1, *mean, *rstd, *lse;     // P: f32 probabilities (unfused path) or the bf16 position-term slab (fused path, first half)
     bf16_t* x16 = nullptr;                 // bf16 copy of the input (fast): the qkv wgrad reads it again in backward
     AttnCtx(Bump& b, const AttnDims& a, bool fast) {
         const size_t es = fast ? 2 : 4;
@@ -207,7 +207,7 @@ FlashParams flash_params(const AttnDims& a, const AttnCtx& c, float scale, int m
     f.k = static_cast<const bf16_t*>(c.qkv) + a.HD;
     f.v = static_cast<const bf16_t*>(c.qkv) + 2 * a.HD;
     f.ld_qu = a.HD; f.ld_kv = a.W3; f.ld_o = a.HD;
-    f.bd = c.P + a.L; f.slab = a.slab;
+    f.bd = reinterpret_cast<const bf16_t*>(c.P) + a.L; f.slab = a.slab;      // fused path: the slab is bf16 (in the same arena)
     f.o = static_cast<bf16_t*>(c.O);
     f.lse = c.lse;
     f.B = a.B; f.L = a.L; f.H = a.H; f.Dh = a.Dh; f.scale = scale;
@@ -284,17 +284,18 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
     if (attn_fused(fast, a) && g_gemm_slab == 0 && (size_t)16 * (L + 1) * 4 + 32 <= 160 * 1024) {
         // write-bound: dedicated kernel that streams whole slab rows (column 0 included) instead of a batched GEMM + strided memset
         CK(convert_bf16(w.E, w.E16, (long)L * a.HD, st));
-        CK(relpos_slab(static_cast<const bf16_t*>(c.qkv), a.W3, w.E16, a.HD, w.cT, B, L, H, Dh, c.P, st));
+        CK(relpos_slab(static_cast<const bf16_t*>(c.qkv), a.W3, w.E16, a.HD, w.cT, B, L, H, Dh, reinterpret_cast<bf16_t*>(c.P), st));
     } else if (attn_fused(fast, a) && Dh % 8 == 0) {
-        CK(memset2d(c.P, (size_t)(L + 1) * 4, 4, (size_t)B * H * L, st));
-        // on the glds kernel: q (bf16, in place in qkv) x E16^T, batched over (b, h), bias c, pitch-(L+1) f32 output
+        bf16_t* P16 = reinterpret_cast<bf16_t*>(c.P);
+        CK(memset2d(P16, (size_t)(L + 1) * 2, 2, (size_t)B * H * L, st));
+        // on the glds kernel: q (bf16, in place in qkv) x E16^T, batched over (b, h), bias c, pitch-(L+1) bf16 output
         CK(convert_bf16(w.E, w.E16, (long)L * a.HD, st));
         FastBatch fb;
         fb.nz1 = B; fb.nz2 = H; fb.sA1 = L * a.W3; fb.sA2 = Dh; fb.sB1 = 0; fb.sB2 = Dh; fb.sC1 = H * a.slab; fb.sC2 = a.slab;
         fb.sV1 = 0; fb.sV2 = L;
         NtEpilogue e;
         e.bias = w.cT;
-        CK(gemm_nt_bf16(static_cast<const bf16_t*>(c.qkv), w.E16, c.P + 1, 0, e, L, L, Dh, a.W3, a.HD, L + 1, st, fb));
+        CK(gemm_nt_bf16(static_cast<const bf16_t*>(c.qkv), w.E16, P16 + 1, 1, e, L, L, Dh, a.W3, a.HD, L + 1, st, fb));
     } else {
         CK(memset2d(c.P, (size_t)(L + 1) * 4, 4, (size_t)B * H * L, st));
         GemmDesc g = mkx(c.qkv, adt, w.E, DT_F32, c.P + 1, DT_F32, L, L, Dh, a.W3, a.HD, L + 1, NT_ | GEMM_BIAS, prec);
