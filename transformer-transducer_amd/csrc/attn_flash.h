@@ -26,7 +26,7 @@ struct FlashParams {
     float* dK = nullptr;          // f32 [B*L, ld_dkv] (+ h*Dh)
     float* dV = nullptr;
     long ld_dkv = 0;
-    bf16_t* dK16 = nullptr;       // optional bf16 copies of dK / dV, same pitch ld_dkv (+ h*Dh)
+    bf16_t* dK16 = nullptr;       // if set, dK / dV are written here in bf16 (same pitch ld_dkv, + h*Dh) INSTEAD of the f32 buffers
     bf16_t* dV16 = nullptr;
     int B = 0, L = 0, H = 0, Dh = 0;
     float scale = 1.f;

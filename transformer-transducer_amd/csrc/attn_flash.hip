@@ -350,15 +350,16 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) 
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int d = 32 * dt + 8 * g4 + 4 * hh;
-                *reinterpret_cast<float4*>(dkrow + d) = make_float4(dk[dt][4 * g4], dk[dt][4 * g4 + 1], dk[dt][4 * g4 + 2], dk[dt][4 * g4 + 3]);
-                *reinterpret_cast<float4*>(dvrow + d) = make_float4(dv[dt][4 * g4], dv[dt][4 * g4 + 1], dv[dt][4 * g4 + 2], dv[dt][4 * g4 + 3]);
-                if (p.dK16) {      // bf16 copies in the layout the qkv dgrad / wgrad GEMMs read (saves a conversion pass over dqkv)
+                if (p.dK16) {      // bf16, the form the qkv dgrad / wgrad GEMMs read (no f32 copy, no conversion pass over dqkv)
                     const long o16 = ((long)b * L + j) * p.ld_dkv + h * DH + d;
                     uint2 wk, wv;
                     wk.x = pack_bf16x2(dk[dt][4 * g4], dk[dt][4 * g4 + 1]); wk.y = pack_bf16x2(dk[dt][4 * g4 + 2], dk[dt][4 * g4 + 3]);
                     wv.x = pack_bf16x2(dv[dt][4 * g4], dv[dt][4 * g4 + 1]); wv.y = pack_bf16x2(dv[dt][4 * g4 + 2], dv[dt][4 * g4 + 3]);
                     *reinterpret_cast<uint2*>(p.dK16 + o16) = wk;
                     *reinterpret_cast<uint2*>(p.dV16 + o16) = wv;
+                } else {
+                    *reinterpret_cast<float4*>(dkrow + d) = make_float4(dk[dt][4 * g4], dk[dt][4 * g4 + 1], dk[dt][4 * g4 + 2], dk[dt][4 * g4 + 3]);
+                    *reinterpret_cast<float4*>(dvrow + d) = make_float4(dv[dt][4 * g4], dv[dt][4 * g4 + 1], dv[dt][4 * g4 + 2], dv[dt][4 * g4 + 3]);
                 }
             }
     }

@@ -1293,7 +1293,7 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
     if (tiles * nbatch < 1024) {
         // every split adds a tile of contended f32 atomics: a 512x512 output (16 tiles) pays more for 32 adds per element than it
         // gains from 512 workgroups (measured 37 -> 29 us at 256)
-        const long target = tiles * nbatch <= 16 ? std::min(g_tn_target_blocks, 256) : g_tn_target_blocks;
+        const long target = tiles * nbatch <= 16 && ksteps_total < 1024 ? std::min(g_tn_target_blocks, 256) : g_tn_target_blocks;
         splitk = (int)((target + tiles * nbatch - 1) / (tiles * nbatch));
         if (ksteps_total >= 1024 && splitk < 8) splitk = 8;
         if (splitk > ksteps_total / 4) splitk = ksteps_total / 4;
