@@ -30,13 +30,14 @@ __device__ __forceinline__ bf16x4 tr16(const char* lds_addr) {
     return __builtin_bit_cast(bf16x4, v);
 }
 
+// MK = mask kind, a template parameter of the kernels: with a run-time switch the compiler kept ~30 scalar instructions of control
+// flow per score element in the inner loops (the forward's instruction stream was mostly s_mov/s_and/s_cbranch)
+template <int MK>
 __device__ __forceinline__ bool is_masked(const FlashParams& p, int b, int i, int j) {
-    switch (p.mask_kind) {
-        case 1: return j > i;
-        case 2: return (j > i + p.mask_right) || (j < i - p.mask_left);
-        case 3: return p.mask[(long)b * p.mask_sb + (long)i * p.mask_si + j] != 0;
-        default: return false;
-    }
+    if constexpr (MK == 1) return j > i;
+    else if constexpr (MK == 2) return (j > i + p.mask_right) || (j < i - p.mask_left);
+    else if constexpr (MK == 3) return p.mask[(long)b * p.mask_sb + (long)i * p.mask_si + j] != 0;
+    else return false;
 }
 
 template <int DH>
@@ -60,24 +61,25 @@ __device__ __forceinline__ void stage_rows(char* lds, const bf16_t* g, long ld, 
 
 // register-staged variant: issue the global loads of the NEXT tile early, write them to LDS after the barrier that
 // retires the current tile (T14 split).  NPT = 16-byte chunks per thread.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <int DH, int NROWS>
 struct RowStage {
     using T = Tile<DH>;
     static constexpr int NPT = (NROWS * T::NCH + 255) / 256;
-    uint4 v[NPT];
+    u32x4_t v[NPT];   // native vector type: with HIP's uint4 struct the array stayed in scratch (load -> wait -> scratch)
     __device__ __forceinline__ void load(const bf16_t* g, long ld, int r0, int rmax, int tid) {
 #pragma unroll
         for (int k = 0; k < NPT; ++k) {
             const int c = tid + 256 * k;
             const int row = min(c / T::NCH, NROWS - 1), ch = c % T::NCH;
-            v[k] = *reinterpret_cast<const uint4*>(g + (long)min(r0 + row, rmax) * ld + ch * 8);
+            v[k] = *reinterpret_cast<const u32x4_t*>(g + (long)min(r0 + row, rmax) * ld + ch * 8);
         }
     }
     __device__ __forceinline__ void store(char* lds, int tid) const {
 #pragma unroll
         for (int k = 0; k < NPT; ++k) {
             const int c = tid + 256 * k;
-            if (c < NROWS * T::NCH) *reinterpret_cast<uint4*>(lds + T::off(c / T::NCH, c % T::NCH)) = v[k];
+            if (c < NROWS * T::NCH) *reinterpret_cast<u32x4_t*>(lds + T::off(c / T::NCH, c % T::NCH)) = v[k];
         }
     }
 };
@@ -103,8 +105,11 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rbase, int c0, i
 }
 
 // ------------------------------------------------------------------ forward
-template <int DH>
-__global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashParams p) {
+#ifndef FWD_MINB
+#define FWD_MINB 2
+#endif
+template <int DH, int MK>
+__global__ __launch_bounds__(256, FWD_MINB) void flash_fwd_kernel(const FlashParams p) {
     using T = Tile<DH>;
     constexpr int KS = DH / 16, DT = DH / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashParams p) {
         for (int r = 0; r < 16; ++r) {
             const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * hh;
             float v = NEGBIG;
-            if (j < L && !is_masked(p, b, ic, j)) v = (s[r] + bcur[r]) * p.scale;
+            if (j < L && !is_masked<MK>(p, b, ic, j)) v = (s[r] + bcur[r]) * p.scale;
             s[r] = v;
             pmax = fmaxf(pmax, v);
         }
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashParams p) {
 }
 
 // ------------------------------------------------------------------ backward (dK, dV, dS)
-template <int DH>
+template <int DH, int MK>
 __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) {
     using T = Tile<DH>;
     constexpr int KS = DH / 16, DT = DH / 32;
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) 
             const bool inb = (i < L) && kvalid;
             float pr = 0.f, ds = 0.f;
             if (inb) {
-                if (!is_masked(p, b, i, j)) {
+                if (!is_masked<MK>(p, b, i, j)) {
                     const float sc = (s[r] + bcur[r]) * p.scale;
                     pr = __expf(sc - lse_s[q]);
                     ds = pr * (dp[r] - del_s[q]) * p.scale;
@@ -530,8 +535,15 @@ int flash_attn_fwd(const FlashParams& p, hipStream_t st) {
     TTMI_REQUIRE(aligned16(p.qu) && aligned16(p.k) && aligned16(p.v) && (reinterpret_cast<uintptr_t>(p.o) & 7) == 0, "flash_attn_fwd: alignment");
     dim3 grid(cdiv(p.L, 128), p.B * p.H);
     TTMI_REQUIRE(grid.y <= 65535, "flash_attn_fwd: B*H too large");
-    if (p.Dh == 64) hipLaunchKernelGGL(flash_fwd_kernel<64>, grid, dim3(256), 2 * 64 * 128, st, p);
-    else hipLaunchKernelGGL(flash_fwd_kernel<32>, grid, dim3(256), 2 * 64 * 64, st, p);
+#define FWD_LAUNCH(MKV) do { if (p.Dh == 64) hipLaunchKernelGGL((flash_fwd_kernel<64, MKV>), grid, dim3(256), 2 * 64 * 128, st, p); \
+                             else hipLaunchKernelGGL((flash_fwd_kernel<32, MKV>), grid, dim3(256), 2 * 64 * 64, st, p); } while (0)
+    switch (p.mask_kind) {
+        case 1: FWD_LAUNCH(1); break;
+        case 2: FWD_LAUNCH(2); break;
+        case 3: FWD_LAUNCH(3); break;
+        default: FWD_LAUNCH(0); break;
+    }
+#undef FWD_LAUNCH
     TTMI_LAUNCH_CHECK("flash_fwd_kernel");
     return TTMI_OK;
 }
@@ -543,13 +555,17 @@ int flash_attn_bwd(const FlashParams& p, hipStream_t st) {
     TTMI_REQUIRE(aligned16(p.qu) && aligned16(p.k) && aligned16(p.v) && aligned16(p.dO) && aligned16(p.dK) && aligned16(p.dV), "flash_attn_bwd: alignment");
     const long n = (long)p.B * p.L * p.H;
     dim3 grid(cdiv(p.L, 128), p.B * p.H);
-    if (p.Dh == 64) {
-        hipLaunchKernelGGL(flash_delta_kernel<64>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta);
-        hipLaunchKernelGGL(flash_bwd_kernel<64>, grid, dim3(256), 64 * 128 + 256, st, p);
-    } else {
-        hipLaunchKernelGGL(flash_delta_kernel<32>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta);
-        hipLaunchKernelGGL(flash_bwd_kernel<32>, grid, dim3(256), 64 * 64 + 256, st, p);
+    if (p.Dh == 64) hipLaunchKernelGGL(flash_delta_kernel<64>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta);
+    else hipLaunchKernelGGL(flash_delta_kernel<32>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta);
+#define BWD_LAUNCH(MKV) do { if (p.Dh == 64) hipLaunchKernelGGL((flash_bwd_kernel<64, MKV>), grid, dim3(256), 64 * 128 + 256, st, p); \
+                             else hipLaunchKernelGGL((flash_bwd_kernel<32, MKV>), grid, dim3(256), 64 * 64 + 256, st, p); } while (0)
+    switch (p.mask_kind) {
+        case 1: BWD_LAUNCH(1); break;
+        case 2: BWD_LAUNCH(2); break;
+        case 3: BWD_LAUNCH(3); break;
+        default: BWD_LAUNCH(0); break;
     }
+#undef BWD_LAUNCH
     TTMI_LAUNCH_CHECK("flash_bwd_kernel");
     return TTMI_OK;
 }
