@@ -270,11 +270,15 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) 
     bf16_t* dg16 = p.dG16 + (long)z * p.slab16;
 
     // bias of one 32-query tile for this lane's key: rows i0 + q_r, column jc (coalesced across the lanes)
+    // (32-bit element offsets from the per-(b,h) slab bases: the 64-bit products per element were a third of the loop's VALU work)
+    const int ldp = (int)p.ldp;
+    const int bias_lim = (L - 1) * L + jc;
     auto load_bias = [&](int i0, float (&bv)[16]) {
+        const int b0 = (i0 + 4 * hh) * L + jc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int i = min(i0 + (r & 3) + 8 * (r >> 2) + 4 * hh, L - 1);
-            bv[r] = (p.debug & 1) ? 0.f : bf16_to_f32(bd[(long)i * L + jc]);
+            const unsigned off = (unsigned)min(b0 + ((r & 3) + 8 * (r >> 2)) * L, bias_lim);      // row clamped to L-1
+            bv[r] = (p.debug & 1) ? 0.f : bf16_to_f32(bd[off]);
         }
     };
     RowStage<DH, 32> stQ, stO;
@@ -307,9 +311,14 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) 
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
         }
+        // dS16[i][j] at i*ldp + j;  dG16[r][c-1], (r, c) = divmod((i+1) L + j, L+1): j <= i -> (i, L-i+j), j > i -> (i+1, j-i-1), i.e.
+        // element i*(ldp-1) + (j <= i ? L-1+j : ldp+j-2), nothing for j == i+1 (c = 0)
+        const int ds0 = (i0 + 4 * hh) * ldp + j, dg0 = (i0 + 4 * hh) * (ldp - 1);
+        const int gsel_lo = L - 1 + j, gsel_hi = ldp + j - 2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int q = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const int cq = (r & 3) + 8 * (r >> 2);
+            const int q = cq + 4 * hh;
             const int i = i0 + q;
             const bool inb = (i < L) && kvalid;
             float pr = 0.f, ds = 0.f;
@@ -321,10 +330,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) 
                 }
                 if (!(p.debug & 2)) {
                     const bf16_t d16 = f32_to_bf16(ds);
-                    ds16[(long)i * p.ldp + j] = d16;
-                    // (r, c) = divmod((i+1) L + j, L+1) without the division: j <= i -> (i, L-i+j); j > i -> (i+1, j-i-1)
-                    const int rr = j <= i ? i : i + 1, cc = j <= i ? L - i + j : j - i - 1;
-                    if (cc > 0) dg16[(long)rr * p.ldp + cc - 1] = d16;
+                    ds16[(unsigned)(ds0 + cq * ldp)] = d16;
+                    if (j != i + 1) dg16[(unsigned)(dg0 + cq * (ldp - 1) + (j <= i ? gsel_lo : gsel_hi))] = d16;
                 }
             }
             s[r] = pr;
