@@ -272,24 +272,52 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) 
     // bias of one 32-query tile for this lane's key: rows i0 + q_r, column jc (coalesced across the lanes)
     // (32-bit element offsets from the per-(b,h) slab bases: the 64-bit products per element were a third of the loop's VALU work)
     const int ldp = (int)p.ldp;
+    // bias of a 32-query tile x the workgroup's 128 keys = 32 rows of 256 contiguous bytes: fetched one tile ahead with 8-byte
+    // loads (4 per thread), parked in LDS, read back per lane (row i0 + q, column = own key).  The per-element global 2-byte
+    // loads this replaces were 42 % of the kernel's time.
+    bf16_t* btile = reinterpret_cast<bf16_t*>(del_s + 32);                   // [32][128] bf16
+    const int jw0 = blockIdx.x * 128;
+    const bool bstage = (L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.bd) & 7) == 0) && (p.slab % 4 == 0) && L >= 4;
+    uint2 bpre[4];
     const int bias_lim = (L - 1) * L + jc;
-    auto load_bias = [&](int i0, float (&bv)[16]) {
-        const int b0 = (i0 + 4 * hh) * L + jc;
+    auto fetch_bias = [&](int i0) {
+        if (!bstage || (p.debug & 1)) return;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned off = (unsigned)min(b0 + ((r & 3) + 8 * (r >> 2)) * L, bias_lim);      // row clamped to L-1
-            bv[r] = (p.debug & 1) ? 0.f : bf16_to_f32(bd[off]);
+        for (int k = 0; k < 4; ++k) {
+            const int c = tid + 256 * k;                                     // chunk of 4 columns: row c >> 5, columns 4 (c & 31)
+            const int row = min(i0 + (c >> 5), L - 1), col = min(jw0 + 4 * (c & 31), L - 4);
+            bpre[k] = *reinterpret_cast<const uint2*>(bd + (unsigned)(row * L + col));
+        }
+    };
+    auto park_bias = [&]() {
+        if (!bstage || (p.debug & 1)) return;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<uint2*>(btile + 4 * (tid + 256 * k)) = bpre[k];
+    };
+    auto read_bias = [&](int i0, float (&bv)[16]) {
+        if (p.debug & 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bv[r] = 0.f;
+        } else if (bstage) {
+            // columns beyond L - 1 were fetched from a clamped chunk: those lanes' keys do not exist (kvalid false), any value does
+            const bf16_t* col = btile + wave * 32 + (lane & 31) + 4 * hh * 128;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bv[r] = bf16_to_f32(col[((r & 3) + 8 * (r >> 2)) * 128]);
+        } else {
+            const int b0 = (i0 + 4 * hh) * L + jc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bv[r] = bf16_to_f32(bd[(unsigned)min(b0 + ((r & 3) + 8 * (r >> 2)) * L, bias_lim)]);
         }
     };
     RowStage<DH, 32> stQ, stO;
     stQ.load(qbase, p.ld_qu, 0, L - 1, tid);
     stO.load(dobase, p.ld_o, 0, L - 1, tid);
-    float biasA[16], biasB[16];
-    load_bias(0, biasA);
-    auto step = [&](int i0, float (&bcur)[16], float (&bnext)[16]) {
+    fetch_bias(0);
+    auto step = [&](int i0) {
         __syncthreads();
         stQ.store(qtile, tid);
         stO.store(dotile, tid);
+        park_bias();
         if (tid < 32) {
             const int ii = min(i0 + tid, L - 1);
             lse_s[tid] = p.lse[(long)z * L + ii];
@@ -299,8 +327,10 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) 
         if (i0 + 32 < L) {                                          // next tile's operands and bias fly under this tile's MFMAs
             stQ.load(qbase, p.ld_qu, i0 + 32, L - 1, tid);
             stO.load(dobase, p.ld_o, i0 + 32, L - 1, tid);
-            load_bias(i0 + 32, bnext);
+            fetch_bias(i0 + 32);
         }
+        float bcur[16];
+        read_bias(i0, bcur);
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -315,27 +345,57 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) 
         // element i*(ldp-1) + (j <= i ? L-1+j : ldp+j-2), nothing for j == i+1 (c = 0)
         const int ds0 = (i0 + 4 * hh) * ldp + j, dg0 = (i0 + 4 * hh) * (ldp - 1);
         const int gsel_lo = L - 1 + j, gsel_hi = ldp + j - 2;
+        // interior tiles (all 32 queries and all 128 keys of the workgroup in range, the j == i+1 diagonal not crossing the tile) take a
+        // branch-free element loop; edge and diagonal tiles the general one
+        const bool interior = (i0 + 32 <= L) && (jw0 > i0 + 32 || jw0 + 127 < i0 + 1) && !(p.debug & 2);
+        if (interior) {
+            // all 32 queries in range, the whole tile on one side of the j == i+1 diagonal: branch-free score loop, then ONE predicated
+            // region for the lanes whose key exists
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int cq = (r & 3) + 8 * (r >> 2);
-            const int q = cq + 4 * hh;
-            const int i = i0 + q;
-            const bool inb = (i < L) && kvalid;
-            float pr = 0.f, ds = 0.f;
-            if (inb) {
-                if (!is_masked<MK>(p, b, i, j)) {
+            for (int r = 0; r < 16; ++r) {
+                const int q = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float pr = 0.f, ds = 0.f;
+                if (!is_masked<MK>(p, b, i0 + q, j)) {
                     const float sc = (s[r] + bcur[r]) * p.scale;
                     pr = __expf(sc - lse_s[q]);
                     ds = pr * (dp[r] - del_s[q]) * p.scale;
                 }
-                if (!(p.debug & 2)) {
-                    const bf16_t d16 = f32_to_bf16(ds);
+                s[r] = kvalid ? pr : 0.f;
+                dp[r] = kvalid ? ds : 0.f;
+            }
+            if (kvalid) {
+                const int gsel = dg0 + (jw0 < i0 ? gsel_lo : gsel_hi);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cq = (r & 3) + 8 * (r >> 2);
+                    const bf16_t d16 = f32_to_bf16(dp[r]);
                     ds16[(unsigned)(ds0 + cq * ldp)] = d16;
-                    if (j != i + 1) dg16[(unsigned)(dg0 + cq * (ldp - 1) + (j <= i ? gsel_lo : gsel_hi))] = d16;
+                    dg16[(unsigned)(gsel + cq * (ldp - 1))] = d16;
                 }
             }
-            s[r] = pr;
-            dp[r] = ds;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cq = (r & 3) + 8 * (r >> 2);
+                const int q = cq + 4 * hh;
+                const int i = i0 + q;
+                const bool inb = (i < L) && kvalid;
+                float pr = 0.f, ds = 0.f;
+                if (inb) {
+                    if (!is_masked<MK>(p, b, i, j)) {
+                        const float sc = (s[r] + bcur[r]) * p.scale;
+                        pr = __expf(sc - lse_s[q]);
+                        ds = pr * (dp[r] - del_s[q]) * p.scale;
+                    }
+                    if (!(p.debug & 2)) {
+                        const bf16_t d16 = f32_to_bf16(ds);
+                        ds16[(unsigned)(ds0 + cq * ldp)] = d16;
+                        if (j != i + 1) dg16[(unsigned)(dg0 + cq * (ldp - 1) + (j <= i ? gsel_lo : gsel_hi))] = d16;
+                    }
+                }
+                s[r] = pr;
+                dp[r] = ds;
+            }
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -351,8 +411,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) 
         }
     };
     for (int i0 = 0; i0 < L; i0 += 64) {
-        step(i0, biasA, biasB);
-        if (i0 + 32 < L) step(i0 + 32, biasB, biasA);
+        step(i0);
+        if (i0 + 32 < L) step(i0 + 32);
     }
     if (kvalid) {
         float* dkrow = p.dK + ((long)b * L + j) * p.ld_dkv + h * DH;
@@ -564,8 +624,8 @@ int flash_attn_bwd(const FlashParams& p, hipStream_t st) {
     dim3 grid(cdiv(p.L, 128), p.B * p.H);
     if (p.Dh == 64) hipLaunchKernelGGL(flash_delta_kernel<64>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta);
     else hipLaunchKernelGGL(flash_delta_kernel<32>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta);
-#define BWD_LAUNCH(MKV) do { if (p.Dh == 64) hipLaunchKernelGGL((flash_bwd_kernel<64, MKV>), grid, dim3(256), 64 * 128 + 256, st, p); \
-                             else hipLaunchKernelGGL((flash_bwd_kernel<32, MKV>), grid, dim3(256), 64 * 64 + 256, st, p); } while (0)
+#define BWD_LAUNCH(MKV) do { if (p.Dh == 64) hipLaunchKernelGGL((flash_bwd_kernel<64, MKV>), grid, dim3(256), 64 * 128 + 256 + 8192, st, p); \
+                             else hipLaunchKernelGGL((flash_bwd_kernel<32, MKV>), grid, dim3(256), 64 * 64 + 256 + 8192, st, p); } while (0)
     switch (p.mask_kind) {
         case 1: BWD_LAUNCH(1); break;
         case 2: BWD_LAUNCH(2); break;
