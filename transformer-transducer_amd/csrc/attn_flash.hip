@@ -134,18 +134,40 @@ __global__ __launch_bounds__(256, FWD_MINB) void flash_fwd_kernel(const FlashPar
     const bf16_t* kbase = p.k + (long)b * L * p.ld_kv + h * DH;
     const bf16_t* vbase = p.v + (long)b * L * p.ld_kv + h * DH;
 
-    // bias of one 32-key sub-tile for this lane's query: keys jb + 4 hh + 8 g + (0..3), g = 0..3  ->  4 x 8-byte loads when aligned
-    const bool bvec = (L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.bd) & 7) == 0) && (p.slab % 4 == 0);
-    auto load_bias = [&](int jb, float (&bv)[16]) {
+    // bias of a 64-key tile x the workgroup's 128 queries = 128 rows of 128 contiguous bytes: fetched one tile ahead with 8-byte loads
+    // (8 per thread), parked in LDS behind the K / V tiles, read back per lane (own query row; keys jb + 4 hh + 8 g + (0..3)) with four
+    // ds_read_b64.  (Per-lane row-strided global loads touched 64 cache lines per instruction.)
+    constexpr int BP = 68;                                                       // row pitch (bf16): 136 B, so 32 query rows hit 32 distinct bank pairs
+    bf16_t* btile = reinterpret_cast<bf16_t*>(smem + 2 * 64 * T::ROWB);          // [128][BP] bf16
+    const bf16_t* bdz = p.bd + (long)z * p.slab;
+    const bool bstage = (L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.bd) & 7) == 0) && (p.slab % 4 == 0) && L >= 4 && !(p.debug & 1);
+    uint2 bpre[8];
+    auto fetch_bias = [&](int j0) {
+        if (!bstage) return;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = tid + 256 * k;                                         // row c >> 4, columns 4 (c & 15)
+            const int row = min((int)blockIdx.x * 128 + (c >> 4), L - 1), col = min(j0 + 4 * (c & 15), L - 4);
+            bpre[k] = *reinterpret_cast<const uint2*>(bdz + (unsigned)(row * L + col));
+        }
+    };
+    auto park_bias = [&]() {
+        if (!bstage) return;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = tid + 256 * k;
+            *reinterpret_cast<uint2*>(btile + (c >> 4) * BP + 4 * (c & 15)) = bpre[k];
+        }
+    };
+    auto read_bias = [&](int jb, int sub, float (&bv)[16]) {
         if (p.debug & 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) bv[r] = 0.f;
-            return;
-        }
-        if (bvec && jb + 32 <= L) {
+        } else if (bstage) {
+            const bf16_t* rowp = btile + (wave * 32 + (lane & 31)) * BP + sub * 32 + 4 * hh;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const uint2 t = *reinterpret_cast<const uint2*>(bd_row + jb + 4 * hh + 8 * g4);
+                const uint2 t = *reinterpret_cast<const uint2*>(rowp + 8 * g4);
                 bv[4 * g4] = __uint_as_float(t.x << 16); bv[4 * g4 + 1] = __uint_as_float(t.x & 0xffff0000u);
                 bv[4 * g4 + 2] = __uint_as_float(t.y << 16); bv[4 * g4 + 3] = __uint_as_float(t.y & 0xffff0000u);
             }
@@ -154,8 +176,9 @@ __global__ __launch_bounds__(256, FWD_MINB) void flash_fwd_kernel(const FlashPar
             for (int r = 0; r < 16; ++r) bv[r] = bf16_to_f32(bd_row[min(jb + (r & 3) + 8 * (r >> 2) + 4 * hh, L - 1)]);
         }
     };
-    auto sub_step = [&](int jb, int sub, float (&bcur)[16], float (&bnxt)[16]) {
-        if (jb + 32 < L) load_bias(jb + 32, bnxt);            // prefetch the next sub-tile's bias
+    auto sub_step = [&](int jb, int sub) {
+        float bcur[16];
+        read_bias(jb, sub, bcur);
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -202,19 +225,20 @@ __global__ __launch_bounds__(256, FWD_MINB) void flash_fwd_kernel(const FlashPar
     RowStage<DH, 64> stK, stV;
     stK.load(kbase, p.ld_kv, 0, L - 1, tid);
     stV.load(vbase, p.ld_kv, 0, L - 1, tid);
-    float bias0[16], bias1[16];
-    load_bias(0, bias0);
+    fetch_bias(0);
     for (int j0 = 0; j0 < L; j0 += 64) {
         __syncthreads();                                            // everyone is done reading the previous tile
         stK.store(ktile, tid);
         stV.store(vtile, tid);
+        park_bias();
         __syncthreads();
         if (j0 + 64 < L) {                                          // next tile's loads fly under this tile's MFMAs
             stK.load(kbase, p.ld_kv, j0 + 64, L - 1, tid);
             stV.load(vbase, p.ld_kv, j0 + 64, L - 1, tid);
+            fetch_bias(j0 + 64);
         }
-        sub_step(j0, 0, bias0, bias1);
-        if (j0 + 32 < L) sub_step(j0 + 32, 1, bias1, bias0);
+        sub_step(j0, 0);
+        if (j0 + 32 < L) sub_step(j0 + 32, 1);
     }
     l += __shfl_xor(l, 32, 64);
     if (i < L) {
@@ -602,8 +626,8 @@ int flash_attn_fwd(const FlashParams& p, hipStream_t st) {
     TTMI_REQUIRE(aligned16(p.qu) && aligned16(p.k) && aligned16(p.v) && (reinterpret_cast<uintptr_t>(p.o) & 7) == 0, "flash_attn_fwd: alignment");
     dim3 grid(cdiv(p.L, 128), p.B * p.H);
     TTMI_REQUIRE(grid.y <= 65535, "flash_attn_fwd: B*H too large");
-#define FWD_LAUNCH(MKV) do { if (p.Dh == 64) hipLaunchKernelGGL((flash_fwd_kernel<64, MKV>), grid, dim3(256), 2 * 64 * 128, st, p); \
-                             else hipLaunchKernelGGL((flash_fwd_kernel<32, MKV>), grid, dim3(256), 2 * 64 * 64, st, p); } while (0)
+#define FWD_LAUNCH(MKV) do { if (p.Dh == 64) hipLaunchKernelGGL((flash_fwd_kernel<64, MKV>), grid, dim3(256), 2 * 64 * 128 + 128 * 68 * 2, st, p); \
+                             else hipLaunchKernelGGL((flash_fwd_kernel<32, MKV>), grid, dim3(256), 2 * 64 * 64 + 128 * 68 * 2, st, p); } while (0)
     switch (p.mask_kind) {
         case 1: FWD_LAUNCH(1); break;
         case 2: FWD_LAUNCH(2); break;
