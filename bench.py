@@ -141,6 +141,9 @@ def main():
     loss_sum = torch.zeros(1, device=dev)
     probe_ms = []
 
+    if world > 1:
+        ops.set_option(6, 32)      # gradient all-reduce kernels run beside backward: the persistent encoder GEMMs leave them 4 CUs per XCD
+
     def step(timed, i=0):
         # harness front-end: fixed 80 -> d_model projection (the reference encoder has no input layer)
         ops.gemm(feats, proj, inputs, B * T, d, 80, 80, d, d, gflags)

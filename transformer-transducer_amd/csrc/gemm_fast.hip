@@ -69,6 +69,31 @@ __device__ __forceinline__ void tile_of(int bid, int nwg, int tiles_m, int tiles
 template <typename TC>
 __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], const FP& p, TC* C, int bm, int bn, int wm, int wn,
                                            int lane, bool add_bias) {
+    // plain epilogue (every wgrad, most forward GEMMs): decided once per workgroup, not per element
+    if (!add_bias && !p.addend && !p.relu && !p.mask && p.drop.p <= 0.f) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = bn + wn * 64 + j * 32 + (lane & 31);
+                if (n >= p.N) continue;
+                const int m0 = bm + wm * 64 + i * 32 + 4 * (lane >> 5);
+                TC* c0 = C + (long)m0 * p.ldc + n;
+                const bool full = m0 + 28 < p.M;             // rows m0 + {0..3} + 8 {0..3}
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dm = (r & 3) + 8 * (r >> 2);
+                    if (!full && m0 + dm >= p.M) continue;
+                    if constexpr (sizeof(TC) == 4) {
+                        if (p.atomic) atomicAdd(reinterpret_cast<float*>(c0) + (long)dm * p.ldc, acc[i][j][r]);
+                        else reinterpret_cast<float*>(c0)[(long)dm * p.ldc] = acc[i][j][r];
+                    } else {
+                        reinterpret_cast<bf16_t*>(c0)[(long)dm * p.ldc] = f32_to_bf16(acc[i][j][r]);
+                    }
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1134,6 +1159,7 @@ int enable_lds(K kernel, int bytes) {
 // counted vmcnt 621; persistent 256x256 with a 4-slice ring that never drains 668 (dgrad K=4352: 904 vs 938 for v6).
 int g_gemm_fast_version = 4;
 int g_num_cus = 0;
+int g_reserved_cus = 0;           // ttmi_set_option(6, n): CUs the mid-sized persistent GEMMs leave to concurrently running communication kernels
 int g_tn_target_blocks = 512;     // split-K aims at this many workgroups for small outputs (ttmi_set_option(4, n))
 
 
@@ -1171,11 +1197,15 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     // whole number of rounds over the CUs (joint: v8; encoder N = 512 / 1536: v9; N = 2048: v8), the 128x128 kernel for small outputs
     const long t9 = (long)cdiv(M, T9M) * cdiv(N, T9N), t8 = (long)cdiv(M, T8) * cdiv(N, T8);
     const bool pers = nbatch == 1 && M >= 1024 && N >= 128 && K >= 128 && K % TK == 0;
-    const double cost9 = (double)cdiv(t9, g_num_cus), cost8 = N >= 256 ? 1.8 * cdiv(t8, g_num_cus) : 1e30;
+    const int cus_avail = std::max(8, (g_num_cus - g_reserved_cus) / 8 * 8);
+    const double cost9 = (double)cdiv(t9, cus_avail), cost8 = N >= 256 ? 1.8 * cdiv(t8, t8 < 1024 ? cus_avail : g_num_cus) : 1e30;
     const bool v9 = pers && ((g_gemm_fast_version == 9) || (g_gemm_fast_version == 4 && t9 >= g_num_cus * 3 / 4 && cost9 <= cost8));
     if (v9) {
         p.tiles_m = cdiv(M, T9M); p.tiles_n = cdiv(N, T9N);
-        const int grid9 = (int)((std::min<long>(t9, g_num_cus) + 7) / 8 * 8);
+        // a persistent grid larger than the CUs that are actually free runs its surplus workgroups AFTER the others (twice the time):
+        // with gradient all-reduce kernels resident during backward, leave them room (multi-GPU runs set option 6)
+        const int cus9 = std::max(8, (g_num_cus - g_reserved_cus) / 8 * 8);
+        const int grid9 = (int)((std::min<long>(t9, cus9) + 7) / 8 * 8);
         if (c_dtype == 0) {
             if (int rc = enable_lds(gemm_nt_bf16_v9_kernel<float>, LDS9)) return rc;
             hipLaunchKernelGGL(gemm_nt_bf16_v9_kernel<float>, dim3((unsigned)grid9), dim3(NTH8), LDS9, st, p);
@@ -1191,7 +1221,8 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     if (v8) {
         p.tiles_m = cdiv(M, T8); p.tiles_n = cdiv(N, T8);
         const long nwg8 = (long)p.tiles_m * p.tiles_n;
-const int grid8 = (int)((std::min<long>(nwg8, g_num_cus) + 7) / 8 * 8);   // multiple of 8: one share of every round per XCD
+const int cus8 = nwg8 < 1024 ? std::max(8, (g_num_cus - g_reserved_cus) / 8 * 8) : g_num_cus;   // encoder-sized problems only (see v9)
+        const int grid8 = (int)((std::min<long>(nwg8, cus8) + 7) / 8 * 8);   // multiple of 8: one share of every round per XCD
 if (c_dtype == 0) {
             if (int rc = enable_lds(gemm_nt_bf16_v8_kernel<float>, LDS8)) return rc;
             hipLaunchKernelGGL(gemm_nt_bf16_v8_kernel<float>, dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
@@ -1320,6 +1351,7 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
 
 void gemm_fast_set_version(int v) { g_gemm_fast_version = v; }
 void gemm_fast_set_tn_target(int n) { g_tn_target_blocks = n; }
+void gemm_fast_set_reserved_cus(int n) { g_reserved_cus = n < 0 ? 0 : n; }
 
 extern "C" {
 // bring-up / test entry points (dtype codes 0 = f32, 1 = bf16)
