@@ -240,3 +240,29 @@ def test_blocked_greedy_decode_matches_frame_by_frame():
             got = [model.decode(enc[b], lens[b], block=block) for b in range(2)]
             assert got == want, block
         assert model.recognize(x, torch.tensor(lens)) == want
+
+
+@pytest.mark.parametrize("J,V", [(512, 200), (1024, 130), (80, 48)])
+def test_bf16_joint_wide_inner_dims_vs_torch(J, V, monkeypatch):
+    """the 8-column tanh / (t,u)-reduction kernels (J = 512, 1024) and the 4-column ones (other J) of the bf16 joint: logits
+    and every gradient against an fp32 torch evaluation of JointNet.forward (tt/model.py:20-39 of the reference)"""
+    from tt.model import JointNet
+    monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    torch.manual_seed(J)
+    B, T, U1, de = 2, 37, 9, 64
+    joint = JointNet(2 * de, J, V).cuda()
+    enc = torch.randn(B, T, de, device="cuda", requires_grad=True)
+    dec = torch.randn(B, U1, de, device="cuda", requires_grad=True)
+    cot = torch.randn(B, T, U1, V, device="cuda")
+    out = joint(enc, dec)
+    (out.float() * cot).sum().backward()
+    got = [out.detach().float(), enc.grad.clone(), dec.grad.clone()] + [p.grad.clone() for p in joint.parameters()]
+    enc.grad = dec.grad = None
+    joint.zero_grad()
+    Wf, bf, Wp, bp = joint.forward_layer.weight, joint.forward_layer.bias, joint.project_layer.weight, joint.project_layer.bias
+    cat = torch.cat([enc[:, :, None, :].expand(B, T, U1, de), dec[:, None, :, :].expand(B, T, U1, de)], dim=-1)
+    ref = torch.tanh(cat @ Wf.t() + bf) @ Wp.t() + bp
+    (ref * cot).sum().backward()
+    want = [ref.detach(), enc.grad, dec.grad] + [p.grad for p in joint.parameters()]
+    for g, w in zip(got, want):
+        assert rel_err(g.cpu().numpy(), w.cpu().numpy()) < 2e-2

@@ -451,6 +451,35 @@ __global__ __launch_bounds__(256) void joint_tanh_fwd_bf16x4_kernel(const float*
     }
 }
 
+// J in {256, 512, 1024, 2048}: 8 columns per thread (16-byte stores), the block's 256 / (J/8) thread groups take every groups-th u
+__global__ __launch_bounds__(256) void joint_tanh_fwd_bf16x8_kernel(const float* __restrict__ PE, const float* __restrict__ PD,
+                                                                    const float* __restrict__ bias, int T, int U1, int J,
+                                                                    bf16_t* __restrict__ H) {
+    const long bt = blockIdx.x;
+    const int b = (int)(bt / T);
+    const int tpr = J >> 3, grp = threadIdx.x / tpr, ngrp = 256 / tpr;
+    const int j = (threadIdx.x - grp * tpr) * 8;
+    float e[8];
+    {
+        const float4 p0 = *reinterpret_cast<const float4*>(PE + bt * J + j), p1 = *reinterpret_cast<const float4*>(PE + bt * J + j + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + j), b1 = *reinterpret_cast<const float4*>(bias + j + 4);
+        e[0] = p0.x + b0.x; e[1] = p0.y + b0.y; e[2] = p0.z + b0.z; e[3] = p0.w + b0.w;
+        e[4] = p1.x + b1.x; e[5] = p1.y + b1.y; e[6] = p1.z + b1.z; e[7] = p1.w + b1.w;
+    }
+    const float* pd = PD + (long)b * U1 * J + j;
+    bf16_t* h = H + bt * U1 * J + j;
+#pragma unroll 4
+    for (int u = grp; u < U1; u += ngrp) {
+        const float4 d0 = *reinterpret_cast<const float4*>(pd + (long)u * J), d1 = *reinterpret_cast<const float4*>(pd + (long)u * J + 4);
+        uint4 w;
+        w.x = pack_bf16x2(fast_tanh(e[0] + d0.x), fast_tanh(e[1] + d0.y));
+        w.y = pack_bf16x2(fast_tanh(e[2] + d0.z), fast_tanh(e[3] + d0.w));
+        w.z = pack_bf16x2(fast_tanh(e[4] + d1.x), fast_tanh(e[5] + d1.y));
+        w.w = pack_bf16x2(fast_tanh(e[6] + d1.z), fast_tanh(e[7] + d1.w));
+        *reinterpret_cast<uint4*>(h + (long)u * J) = w;
+    }
+}
+
 constexpr int JT_TC = 16;
 template <typename TH>
 __global__ __launch_bounds__(256) void joint_tanh_bwd_kernel(const TH* __restrict__ dH, const TH* __restrict__ H, int T, int U1,
@@ -769,6 +798,8 @@ int joint_tanh_fwd(const float* PE, const float* PD, const float* bias, int B, i
     if (h_dtype == 0)
         hipLaunchKernelGGL(joint_tanh_fwd_kernel<float>, dim3(B * T), dim3(256), 0, st, PE, PD, bias, T, U1, J,
                            static_cast<float*>(H));
+    else if ((J == 256 || J == 512 || J == 1024 || J == 2048) && aligned16(PE) && aligned16(PD) && aligned16(bias) && aligned16(H))
+        hipLaunchKernelGGL(joint_tanh_fwd_bf16x8_kernel, dim3(B * T), dim3(256), 0, st, PE, PD, bias, T, U1, J, static_cast<bf16_t*>(H));
     else if (J % 4 == 0 && aligned16(PE) && aligned16(PD) && aligned16(bias) && (reinterpret_cast<uintptr_t>(H) & 7) == 0)
         hipLaunchKernelGGL(joint_tanh_fwd_bf16x4_kernel, dim3(B * T), dim3(256), 0, st, PE, PD, bias, T, U1, J, static_cast<bf16_t*>(H));
     else
@@ -785,7 +816,7 @@ int joint_tanh_bwd(const void* dH, const void* H, int h_dtype, int B, int T, int
         TTMI_REQUIRE(h_dtype == 1 && J % 4 == 0 && aligned16(dPE) && (reinterpret_cast<uintptr_t>(dH) & 7) == 0, "joint_tanh_bwd: pre-multiplied input needs bf16, J %% 4 == 0");
         hipLaunchKernelGGL(joint_sum_bwd_bf16x4_kernel, dim3(cdiv(J, 1024), cdiv(T, JT_TC), B), dim3(256), 0, st,
                            static_cast<const bf16_t*>(dH), T, U1, J, dPE, dPD);
-        TTMI_LAUNCH_CHECK("joint_sum_bwd_bf16x4_kernel");
+        TTMI_LAUNCH_CHECK("joint_sum_bwd_bf16 kernel");
         return TTMI_OK;
     }
     dim3 grid(cdiv(J, 256), cdiv(T, JT_TC), B);
