@@ -19,6 +19,13 @@ struct NtEpilogue {
     int relu = 0;
     float scale = 1.f;               // applied to the masked result (1/(1-p) of a dropped ReLU in backward)
     DropSpec drop;                   // dropout on the result (after ReLU), element index m*ldc + n
+    // optional second operand pair accumulated into the same tile (128x128 kernel only): C = epi(A.B^T + A2.B2^T); A2 is batched with
+    // A's strides, B2 with (sB1b, sB2b); colsum_mid (nullable, f32, batch strides sV1/sV2): += column sums of A.B^T alone
+    const bf16_t* A2 = nullptr;
+    const bf16_t* B2 = nullptr;
+    int K2 = 0;
+    long lda2 = 0, ldb2 = 0, sB1b = 0, sB2b = 0;
+    float* colsum_mid = nullptr;
 };
 // C[M,N] = epilogue(A[M,K] . B[N,K]^T); c_dtype 0 = f32, 1 = bf16
 int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const NtEpilogue& epi, int M, int N, int K, long lda,

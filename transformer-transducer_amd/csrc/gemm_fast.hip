@@ -47,6 +47,12 @@ struct FP {
     float* colsum;                          // TN: if set, colsum[m] += sum_k A[k][m] (taken from the LDS tiles by the tn == 0 blocks)
     int nz2;                                // batch z = blockIdx.y = z1 * nz2 + z2
     long sA1, sA2, sB1, sB2, sC1, sC2, sV1, sV2;
+    // NT only: optional second operand pair accumulated into the same tile, C = A.B^T + A2.B2^T (A2 has A's batch strides)
+    const bf16_t* A2;
+    const bf16_t* B2;
+    int K2;
+    long lda2, ldb2, sB1b, sB2b;
+    float* colsum_mid;                      // column sums of the FIRST product (rows < M), atomically added; batch strides sV1 / sV2
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
@@ -125,7 +131,7 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[2][2], const FP& 
 }
 
 // ------------------------------------------------------------------ NT: A[M,K], B[N,K], K contiguous in both
-template <typename TC, int NBUF, bool PIPE>
+template <typename TC, int NBUF, bool PIPE, bool DUAL = false>
 __global__ __launch_bounds__(NTH, NBUF == 1 ? 4 : 2) void gemm_nt_bf16_kernel(const FP p_) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [NBUF buffers][A 16K | B 16K]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -143,6 +149,11 @@ __global__ __launch_bounds__(NTH, NBUF == 1 ? 4 : 2) void gemm_nt_bf16_kernel(co
         if (p.addend) p.addend += co;
         if (p.mask) p.mask += co;
         if (p.bias) p.bias += z1 * p.sV1 + z2 * p.sV2;
+        if (DUAL) {
+            p.A2 += z1 * p.sA1 + z2 * p.sA2;
+            p.B2 += z1 * p.sB1b + z2 * p.sB2b;
+            if (p.colsum_mid) p.colsum_mid += z1 * p.sV1 + z2 * p.sV2;
+        }
     }
 
     // staging: wave w, instruction j covers tile rows R = (4w + j) * 8 + (lane >> 3), LDS slot = lane & 7,
@@ -244,6 +255,39 @@ __global__ __launch_bounds__(NTH, NBUF == 1 ? 4 : 2) void gemm_nt_bf16_kernel(co
             __syncthreads();
             compute(smem, smem + TILE_B);
             __syncthreads();
+        }
+        if constexpr (DUAL) {
+            // column sums of the first product over the tile's valid rows (attention backward: d r_w_bias = sum_i dq_content[i])
+            if (p.colsum_mid) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float cs = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) < p.M) cs += acc[i][j][r];
+                    cs += __shfl_xor(cs, 32, 64);
+                    const int n = bn + wn * 64 + j * 32 + (lane & 31);
+                    if (lane < 32 && n < p.N) atomicAdd(p.colsum_mid + n, cs);
+                }
+            }
+            // second operand pair into the same accumulators
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int R = (wave * 4 + j) * 8 + (lane >> 3);
+                const int chunk = (lane & 7) ^ ((R >> 1) & 7);
+                asrc[j] = p.A2 + (long)min(bm + R, p.M - 1) * p.lda2 + chunk * 8;
+                bsrc[j] = p.B2 + (long)min(bn + R, p.N - 1) * p.ldb2 + chunk * 8;
+            }
+            p.K = p.K2;
+            const int nk2 = (p.K2 + TK - 1) / TK;
+            for (int kt = 0; kt < nk2; ++kt) {
+                issue(0, kt);
+                __syncthreads();
+                compute(smem, smem + TILE_B);
+                __syncthreads();
+            }
         }
     }
     store_tile<TC>(acc, p, reinterpret_cast<TC*>(p.C), bm, bn, wm, wn, lane, p.bias != nullptr);
@@ -1189,6 +1233,10 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     p.A = A; p.B = B; p.C = C; p.bias = epi.bias; p.addend = epi.addend; p.mask = epi.mask; p.mask_mode = epi.mask_mode; p.relu = epi.relu; p.scale = epi.scale; p.drop = epi.drop;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.tiles_m = cdiv(M, TM); p.tiles_n = cdiv(N, TN_); p.splitk = 1; p.ksteps = cdiv(K, TK); p.atomic = 0; p.gm = GROUP_M; p.colsum = nullptr;
+    p.A2 = epi.A2; p.B2 = epi.B2; p.K2 = epi.K2; p.lda2 = epi.lda2; p.ldb2 = epi.ldb2; p.sB1b = epi.sB1b; p.sB2b = epi.sB2b; p.colsum_mid = epi.colsum_mid;
+    const bool dual = epi.A2 != nullptr;
+    if (dual) TTMI_REQUIRE(epi.B2 && epi.K2 >= 8 && epi.K2 % 8 == 0 && aligned16(epi.A2) && aligned16(epi.B2) && epi.lda2 % 8 == 0 && epi.ldb2 % 8 == 0 &&
+                           c_dtype == 1, "gemm_nt_bf16: bad second operand pair");
     fill_batch(p, batch);
     const int nbatch = batch.nz1 * batch.nz2;
     TTMI_REQUIRE(nbatch >= 1 && nbatch <= 65535, "gemm_nt_bf16: bad batch count %d", nbatch);
@@ -1203,7 +1251,7 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     // persistent kernels: 256x256 tiles (v8) are ~1.8x the cost of 256x128 tiles (v9); take whichever needs less time for its
     // whole number of rounds over the CUs (joint: v8; encoder N = 512 / 1536: v9; N = 2048: v8), the 128x128 kernel for small outputs
     const long t9 = (long)cdiv(M, T9M) * cdiv(N, T9N), t8 = (long)cdiv(M, T8) * cdiv(N, T8);
-    const bool pers = nbatch == 1 && M >= 1024 && N >= 128 && K >= 128 && K % TK == 0;
+    const bool pers = nbatch == 1 && M >= 1024 && N >= 128 && K >= 128 && K % TK == 0 && !dual;
     const int cus_avail = std::max(8, (g_num_cus - g_reserved_cus) / 8 * 8);
     const double cost9 = (double)cdiv(t9, cus_avail), cost8 = N >= 256 ? 1.8 * cdiv(t8, t8 < 1024 ? cus_avail : g_num_cus) : 1e30;
     const bool v9 = pers && ((g_gemm_fast_version == 9) || (g_gemm_fast_version == 4 && t9 >= g_num_cus * 3 / 4 && cost9 <= cost8));
@@ -1240,7 +1288,7 @@ if (c_dtype == 0) {
         TTMI_LAUNCH_CHECK("gemm_nt_bf16_v8_kernel");
         return TTMI_OK;
     }
-    const bool big = (g_gemm_fast_version == 6);
+    const bool big = (g_gemm_fast_version == 6) && !dual;
     if (big && M >= 1024 && N >= 256 && nbatch == 1) {
         p.tiles_m = cdiv(M, T6); p.tiles_n = cdiv(N, T6);
         const long nwg6 = (long)p.tiles_m * p.tiles_n;
@@ -1258,7 +1306,9 @@ if (c_dtype == 0) {
     TTMI_REQUIRE(nwg < (1L << 31), "gemm_nt_bf16: too many tiles");
     const int ver = g_gemm_fast_version;
 #define NT_LAUNCH(TCT, NB, PP) hipLaunchKernelGGL((gemm_nt_bf16_kernel<TCT, NB, PP>), dim3((unsigned)nwg, nbatch), dim3(NTH), 2 * NB * TILE_B, st, p)
-    if (c_dtype == 0) {
+    if (dual) {
+        hipLaunchKernelGGL((gemm_nt_bf16_kernel<bf16_t, 1, false, true>), dim3((unsigned)nwg, nbatch), dim3(NTH), 2 * TILE_B, st, p);
+    } else if (c_dtype == 0) {
         if (ver >= 4) NT_LAUNCH(float, 1, false);
         else if (ver == 3) NT_LAUNCH(float, 2, true);
         else NT_LAUNCH(float, 2, false);

@@ -411,10 +411,7 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
             CK(memset2d(w.dG16 + L, (size_t)w.ldp * 2, (size_t)(w.ldp - L) * 2, (size_t)B * H * L, st));
         }
         CK(transpose_bf16_batched(static_cast<const bf16_t*>(c.qkv) + a.HD, 1, a.W3, B, H, L * a.W3, Dh, L, Dh, w.kT16, w.ldp, st));
-        FastBatch fb;
-        fb.nz1 = B; fb.nz2 = H; fb.sA1 = H * w.slab16; fb.sA2 = w.slab16; fb.sB1 = (long)H * Dh * w.ldp; fb.sB2 = (long)Dh * w.ldp;
-        fb.sC1 = L * a.W3; fb.sC2 = Dh;
-        CK(gemm_nt_bf16(w.dS16, w.kT16, w.dqkv, 0, NtEpilogue(), L, Dh, (int)w.ldp, w.ldp, w.ldp, a.W3, st, fb));
+        // (the product itself is issued together with the position part below: one launch, no f32 intermediate)
     } else {
         {
             GemmDesc g = fused ? mkx(w.dS16, DT_BF16, eoff(c.qkv, adt, a.HD), adt, w.dqkv, DT_F32, L, Dh, L, w.ldp, a.W3, a.W3, NN_, prec)
@@ -424,8 +421,8 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
             CK(ttmi_launch_gemm(g, st));
         }
     }
-    // 8. g r_w_bias += column sums of dq(content)
-    CK(colsum(w.dqkv, a.W3, a.BL, (int)a.HD, 1, 1, 0, 0, 0, 0, g_r_w_bias, st));
+    // 8. g r_w_bias += column sums of dq(content)  (fastpos: taken from the accumulators of the fused launch below)
+    if (!fastpos) CK(colsum(w.dqkv, a.W3, a.BL, (int)a.HD, 1, 1, 0, 0, 0, 0, g_r_w_bias, st));
     if (!fused) {
         // 9. dK = dS^T (q + u)
         {
@@ -439,12 +436,15 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
     CK(fill_zero(w.dE, sizeof(float) * ((size_t)L * a.HD + (size_t)H * L), st));
     if (fastpos) {
         CK(transpose_bf16_batched(w.E, 0, a.HD, 1, H, 0, Dh, L, Dh, w.ET16, w.ldp, st));
+        // dq = dS k + dG E in ONE launch: both products accumulate into the same tile, the column sums of the first (d r_w_bias) are taken
+        // in between, and the sum leaves in bf16 - the form the qkv GEMMs read
         FastBatch fb;
-        fb.nz1 = B; fb.nz2 = H; fb.sA1 = H * w.slab16; fb.sA2 = w.slab16; fb.sB1 = 0; fb.sB2 = (long)Dh * w.ldp;
-        fb.sC1 = L * a.W3; fb.sC2 = Dh;
+        fb.nz1 = B; fb.nz2 = H; fb.sA1 = H * w.slab16; fb.sA2 = w.slab16; fb.sB1 = (long)H * Dh * w.ldp; fb.sB2 = (long)Dh * w.ldp;
+        fb.sC1 = L * a.W3; fb.sC2 = Dh; fb.sV1 = 0; fb.sV2 = Dh;
         NtEpilogue e;
-        e.addend = w.dqkv;                          // content part (f32); the sum leaves in bf16, the form the qkv GEMMs read
-        CK(gemm_nt_bf16(w.dG16, w.ET16, w.dqkv16, 1, e, L, Dh, (int)w.ldp, w.ldp, w.ldp, a.W3, st, fb));
+        e.A2 = w.dG16; e.B2 = w.ET16; e.K2 = (int)w.ldp; e.lda2 = w.ldp; e.ldb2 = w.ldp; e.sB1b = 0; e.sB2b = (long)Dh * w.ldp;
+        e.colsum_mid = g_r_w_bias;
+        CK(gemm_nt_bf16(w.dS16, w.kT16, w.dqkv16, 1, e, L, Dh, (int)w.ldp, w.ldp, w.ldp, a.W3, st, fb));
         FastBatch tb;
         tb.nz1 = B; tb.nz2 = H; tb.sA1 = H * w.slab16; tb.sA2 = w.slab16; tb.sB1 = L * a.W3; tb.sB2 = Dh; tb.sC1 = 0; tb.sC2 = Dh;
         tb.sV1 = 0; tb.sV2 = L;
