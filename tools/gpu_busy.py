@@ -25,13 +25,14 @@ for a, b in zip(marks[:-1], marks[1:]):
             cur_e = max(cur_e, e)
     busy += cur_e - cur_s
     gaps = []
-    cur_e = None
+    cur_e, prev_n = None, ""
     for s, e, n in seg:
         if cur_e is not None and s > cur_e:
-            gaps.append((s - cur_e, n))
-        cur_e = e if cur_e is None else max(cur_e, e)
+            gaps.append((s - cur_e, prev_n[:28] + " -> " + n))
+        if cur_e is None or e > cur_e:
+            cur_e, prev_n = e, n
     gaps.sort(reverse=True)
     print("step: %d kernels, span %.2f ms, busy (union) %.2f ms, idle %.2f ms, sum of durations %.2f ms" %
           (len(seg), span / 1e6, busy / 1e6, (span - busy) / 1e6, tot / 1e6))
     print("   idle gaps: n=%d, >20us: %d (%.2f ms), largest: %s" % (len(gaps), sum(1 for g, _ in gaps if g > 20000),
-          sum(g for g, _ in gaps if g > 20000) / 1e6, ", ".join("%.0fus before %s" % (g / 1e3, n[:40]) for g, n in gaps[:6])))
+          sum(g for g, _ in gaps if g > 20000) / 1e6, "; ".join("%.0fus %s" % (g / 1e3, n[:75]) for g, n in gaps[:8])))
