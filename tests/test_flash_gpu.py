@@ -60,7 +60,7 @@ def test_layer_fused_vs_oracle_and_unfused(Dh, H, L, K, mk, monkeypatch):
     assert e_f < 2.5 * e_u + 1e-3 and worst_f < 2.5 * worst_u + 1e-3     # the fused kernels are as accurate as the unfused chain
 
 
-@pytest.mark.parametrize("Dh,H,L,K", [(64, 2, 70, 128), (32, 4, 33, 16), (64, 8, 500, 512), (64, 1, 129, 40)])
+@pytest.mark.parametrize("Dh,H,L,K", [(64, 2, 70, 128), (32, 4, 33, 16), (64, 8, 500, 512), (64, 1, 129, 40), (64, 1, 600, 64), (32, 2, 520, 700)])
 def test_position_slab_kernel_matches_the_gemm_path(Dh, H, L, K, monkeypatch):
     """relpos_slab_kernel (whole slab rows streamed from LDS) vs the batched-GEMM + memset construction of the same slab:
     same bf16 operands, f32 accumulation over Dh -> the layer outputs agree to f32 rounding"""
