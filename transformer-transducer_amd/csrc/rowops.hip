@@ -4,6 +4,9 @@
 // wave reductions by __shfl_xor; cross-row reductions finish with float atomics (agent scope).
 // Reference arithmetic: tt/transformer.py:52-58,148-175, tt/decoder.py:26,39, tt/model.py:33-37.
 #include "rowops.h"
+#ifndef LN_BWD_GRID
+#define LN_BWD_GRID 512
+#endif
 #include <algorithm>
 
 namespace {
@@ -694,6 +697,7 @@ int ln_fwd(const float* x, const float* res, const float* g, const float* b, lon
     return TTMI_OK;
 }
 
+int g_ln_bwd_grid = LN_BWD_GRID;
 int ln_bwd(const float* dy, const float* s, const float* mean, const float* rstd, const float* g, const float* dadd, long rows,
            int d, float* dx, float* dgamma, float* dbeta, hipStream_t st, DropSpec dy_drop, bf16_t* dx16, DropSpec dx16_drop,
            float* dx16_colsum) {
@@ -701,7 +705,7 @@ int ln_bwd(const float* dy, const float* s, const float* mean, const float* rstd
     const bool fused = d % 4 == 0 && d <= 512 && aligned16(dy) && aligned16(s) && aligned16(g) && aligned16(dx) && (!dadd || aligned16(dadd)) &&
                        (!dx16 || (reinterpret_cast<uintptr_t>(dx16) & 7) == 0);
     if (fused) {
-        const int grid = (int)std::min<long>(cdiv(rows, 4), 512);         // ~2 blocks per CU; rows are walked grid-stride
+        const int grid = (int)std::min<long>(cdiv(rows, 4), g_ln_bwd_grid);   // rows are walked grid-stride
         if (d <= 256)
             hipLaunchKernelGGL(ln_bwd_fused_kernel<1>, dim3(grid), dim3(256), 0, st, dy, s, mean, rstd, g, dadd, rows, d, dx, dgamma, dbeta, dy_drop, dx16, dx16_drop, dx16_colsum);
         else
