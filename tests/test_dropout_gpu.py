@@ -64,3 +64,42 @@ def test_eval_mode_is_deterministic_and_dropout_free():
     layer.train()
     a, b = layer.forward_bm(x, MaskSpec(0)), layer.forward_bm(x, MaskSpec(0))
     assert not torch.equal(a, b)                               # fresh seeds per call in training mode
+
+
+def test_full_size_layer_on_the_persistent_kernels_matches_oracle(monkeypatch):
+    """one audio-encoder layer at the C2 shapes (16384 rows, d = 512, Di = 2048, H = 8 x 64, dropout 0.1): the sizes at which the
+    persistent 256x256 / 256x128 GEMMs, their ReLU + dropout / ReLU'-mask / residual epilogues, the slab kernel and the LDS-staged
+    flash kernels are the ones that run.  Forward, dx and every parameter gradient against the float64 oracle with the same masks."""
+    from tt.encoder import BaseEncoder
+    from ttmi import ops
+    from ttmi.ops import MaskSpec
+    monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    p, B, L, d, Di, H, Dh = 0.1, 32, 512, 512, 2048, 8, 64
+    torch.manual_seed(5)
+    layer = BaseEncoder(k_len=512, n_head=H, d_model=d, d_head=Dh, d_inner=Di, dropout=p).cuda().train()
+    x = torch.randn(B, L, d, generator=torch.Generator().manual_seed(3))
+    cot = torch.randn(B, L, d, generator=torch.Generator().manual_seed(4))
+    torch.manual_seed(78)
+    s_attn = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    s_ffn = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    torch.manual_seed(78)
+    xg = x.cuda().requires_grad_(True)
+    y = layer.forward_bm(xg, MaskSpec(0))
+    (y * cot.cuda()).sum().backward()
+
+    def mult(n, seed, shape):
+        return ops.dropout_multipliers(n, p, seed, "cuda").cpu().numpy().astype(np.float32).reshape(shape)
+
+    sd = {"encoder.layers.0." + k: v.detach().cpu().numpy().astype(np.float64) for k, v in layer.state_dict().items()}
+    prm = O.layer_params(sd, "encoder.", 0)
+    prm["drop_attn"] = mult(B * L * d, s_attn ^ 0xA1, (B, L, d))
+    prm["drop_ff_in"] = mult(B * L * Di, s_ffn ^ 0xB2, (B, L, Di))
+    prm["drop_ff_out"] = mult(B * L * d, s_ffn ^ 0xC3, (B, L, d))
+    prm["drop_layer"] = mult(B * L * d, s_ffn ^ 0xD4, (B, L, d))
+    want, cache = O.layer_fwd(x.numpy().astype(np.float64), prm, None)
+    dx, g = O.layer_bwd(cot.numpy().astype(np.float64), cache, prm)
+    assert rel_err(y.detach().cpu().numpy(), want) < 2e-2
+    assert rel_err(xg.grad.cpu().numpy(), dx) < 6e-2
+    names = {v: k for k, v in O._LAYER_KEYS.items()}
+    for n, prm_t in layer.named_parameters():
+        assert rel_err(prm_t.grad.cpu().numpy(), g[names[n]]) < 6e-2, n

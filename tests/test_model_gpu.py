@@ -242,15 +242,15 @@ def test_blocked_greedy_decode_matches_frame_by_frame():
         assert model.recognize(x, torch.tensor(lens)) == want
 
 
-@pytest.mark.parametrize("J,V", [(512, 200), (1024, 130), (80, 48)])
-def test_bf16_joint_wide_inner_dims_vs_torch(J, V, monkeypatch):
+@pytest.mark.parametrize("J,V,B,T,U1", [(512, 200, 2, 37, 9), (1024, 130, 2, 37, 9), (80, 48, 2, 37, 9), (1024, 1500, 4, 400, 21)])
+def test_bf16_joint_wide_inner_dims_vs_torch(J, V, B, T, U1, monkeypatch):
     """the 8-column tanh / (t,u)-reduction kernels (J = 512, 1024) and the 4-column ones (other J) of the bf16 joint: logits
     and every gradient against an fp32 torch evaluation of JointNet.forward (tt/model.py:20-39 of the reference)"""
     from tt.model import JointNet
     monkeypatch.setenv("TTMI_PRECISION", "bf16")
     torch.manual_seed(J)
-    B, T, U1, de = 2, 37, 9, 64
-    joint = JointNet(2 * de, J, V).cuda()
+    de = 64                 # the last case (33600 lattice rows) runs on the persistent kernels: v8 forward / dgrad with the tanh' epilogue,
+    joint = JointNet(2 * de, J, V).cuda()     # TN v8 wgrad with its all-ones column sums and the M % 256 strip
     enc = torch.randn(B, T, de, device="cuda", requires_grad=True)
     dec = torch.randn(B, U1, de, device="cuda", requires_grad=True)
     cot = torch.randn(B, T, U1, V, device="cuda")
