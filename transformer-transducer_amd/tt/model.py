@@ -80,10 +80,12 @@ class Transducer(nn.Module):
             # the label encoder (tiny, launch-latency-bound kernels) is independent of the audio encoder until the joint:
             # run it on a side stream so both fill the chip together; autograd replays the same streams in backward
             main, side = torch.cuda.current_stream(inputs.device), ops.side_stream(inputs.device)
-            side.wait_stream(main)
+            side.wait_stream(main)                                          # the side stream needs `targets`, nothing else
+            # host order: the audio encoder's long kernels are queued FIRST, the label encoder's ~400 tiny launches are issued while the
+            # GPU is busy with them (issued first, they left the chip nearly idle for the ~1 ms the host needs to enqueue them)
+            enc_state = self.encoder(inputs, audio_mask)
             with torch.cuda.stream(side):
                 dec_state = self.decoder(targets, MaskSpec(1))
-            enc_state = self.encoder(inputs, audio_mask)
             main.wait_stream(side)
             dec_state.record_stream(main)
         else:
