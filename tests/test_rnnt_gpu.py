@@ -157,3 +157,24 @@ def test_bf16_row_padded_logits(B, T, U, V):
     assert rel_err(g.float().cpu().numpy(), want[2]) < 6e-3  # gradient rounded to bf16 (2^-9 relative)
     full = torch.as_strided(g, (B, T, U + 1, Vp), g.stride())
     assert float(full[..., V:].float().abs().max()) == 0
+
+
+def test_length_check_cache_follows_tensor_identity_and_version():
+    """the max-length validation (a host sync in warp-transducer's certify_inputs) is cached per lengths tensor OBJECT and version
+    counter: an in-place change or a different tensor is validated again"""
+    from warprnnt_pytorch import RNNTLoss
+    B, T, U, V = 2, 5, 3, 7
+    acts = torch.randn(B, T, U + 1, V, device="cuda")
+    labels = torch.randint(1, V, (B, U), device="cuda", dtype=torch.int32)
+    alen = torch.full((B,), T, device="cuda", dtype=torch.int32)
+    llen = torch.full((B,), U, device="cuda", dtype=torch.int32)
+    crit = RNNTLoss()
+    a = crit(acts, labels, alen, llen)
+    b = crit(acts, labels, alen, llen)                   # cached path
+    assert torch.equal(a, b)
+    alen[0] = T - 1
+    alen[1] = T - 1                                      # in place: version changes, max is now T-1 != T
+    with pytest.raises(ValueError):
+        crit(acts, labels, alen, llen)
+    with pytest.raises(ValueError):
+        crit(acts, labels, torch.full((B,), T + 1, device="cuda", dtype=torch.int32), llen)
