@@ -1009,7 +1009,10 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
     const int ntiles = p.tiles_m * p.tiles_n;
     const int S = p.splitk;                                // K-ranges per XCD
     const int xcd = blockIdx.x & 7, cu = blockIdx.x >> 3, ncu = gridDim.x >> 3;
-    const int nitems = S * ntiles;
+    // p.gm = Q > 0: the M % 256 rows form one more tile row whose p.tiles_n tiles are cut into Q pieces along the XCD's whole K share and
+    // appended to the item list, one piece per workgroup (tiles_n * Q = workgroups per XCD): every CU gets the same extra 1/Q tile
+    const int nmain = S * ntiles;
+    const int nitems = nmain + (p.gm > 0 ? p.tiles_n * p.gm : 0);
     const int nkt = (p.K + TK - 1) / TK;                   // K-tiles in all
     const int per = p.ksteps;                              // K-tiles per range
 
@@ -1053,6 +1056,18 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
     };
     // item i of this XCD -> (range, tile); tiles in GROUP_M-grouped order so that co-resident tiles share A / B panels
     auto item = [&](int i, int& bm, int& bn, int& tn) {
+        if (i >= nmain) {                                  // a piece of a strip tile
+            const int si = i - nmain;
+            tn = si % p.tiles_n;
+            const int piece = si / p.tiles_n;
+            bm = p.tiles_m * T8;
+            bn = tn * T8;
+            const long share = (long)S * per, pp = (share + p.gm - 1) / p.gm;       // K-tiles of this XCD, per piece
+            const long k0t = (long)xcd * share + piece * pp;
+            kbeg = k0t * TK;
+            nk = (int)max(0L, min(min(pp, share - piece * pp), (long)nkt - k0t));
+            return;
+        }
         const int s = i / ntiles, t = i % ntiles;
         const int per_group = GROUP_M * p.tiles_n;
         const int group = t / per_group, in = t % per_group;
@@ -1349,14 +1364,18 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
                 g_num_cus = n / 8 * 8;
             if (g_num_cus <= 0) g_num_cus = 256;
         }
-        const int Mfull = g_gemm_fast_version == 8 ? M : M / T8 * T8;     // 8: ragged last tile row inside the kernel (A/B runs)
-        p.M = Mfull; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-        p.tiles_m = cdiv(Mfull, T8); p.tiles_n = N / T8;
-        const int ntile = p.tiles_m * p.tiles_n, ncu_x = g_num_cus / 8;
+        const int ncu_x = g_num_cus / 8;
+        p.tiles_m = M / T8; p.tiles_n = N / T8;             // full tile rows; the M % 256 strip: see below
+        const int ntile = p.tiles_m * p.tiles_n;
         int S = 1;                                          // K-ranges per XCD: fill every CU of the XCD, then balance the rounds
         while (S * ntile < ncu_x || ((S * ntile) % ncu_x != 0 && S * ntile < 8 * ncu_x)) ++S;
         const int nkt = cdiv(K, TK);
-        p.splitk = S; p.ksteps = cdiv(nkt, 8 * S); p.atomic = 1; p.gm = GROUP_M;
+        // the strip rides along inside the kernel when its pieces deal out evenly (one per workgroup of the XCD) behind balanced main items;
+        // otherwise it goes to the 128x128 kernel below
+        const bool strip_in = M % T8 != 0 && ncu_x % p.tiles_n == 0 && (S * ntile) % ncu_x == 0 && g_gemm_fast_version != 8;
+        const int Mfull = strip_in ? M : M / T8 * T8;
+        p.M = Mfull; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+        p.splitk = S; p.ksteps = cdiv(nkt, 8 * S); p.atomic = 1; p.gm = strip_in ? ncu_x / p.tiles_n : 0;
         if (colsum_a) {
             if (int rc = enable_lds(gemm_tn_bf16_v8_kernel<true>, LDS8T)) return rc;
             hipLaunchKernelGGL(gemm_tn_bf16_v8_kernel<true>, dim3((unsigned)g_num_cus), dim3(NTH8), LDS8T, st, p);
