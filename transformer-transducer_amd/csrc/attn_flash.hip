@@ -368,6 +368,18 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) 
         // dS16[i][j] at i*ldp + j;  dG16[r][c-1], (r, c) = divmod((i+1) L + j, L+1): j <= i -> (i, L-i+j), j > i -> (i+1, j-i-1), i.e.
         // element i*(ldp-1) + (j <= i ? L-1+j : ldp+j-2), nothing for j == i+1 (c = 0)
         const int ds0 = (i0 + 4 * hh) * ldp + j, dg0 = (i0 + 4 * hh) * (ldp - 1);
+        // pad columns [L, ldp) of both bf16 slabs feed the K loop of the dq / dE products and must be zero: the lanes whose key index falls
+        // there write the zeros (no separate strided memsets over B*H*L rows)
+        if (!kvalid && j < ldp && !(p.debug & 2)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cq = (r & 3) + 8 * (r >> 2);
+                if (i0 + cq + 4 * hh < L) {
+                    ds16[(unsigned)(ds0 + cq * ldp)] = 0;
+                    dg16[(unsigned)(ds0 + cq * ldp)] = 0;
+                }
+            }
+        }
         const int gsel_lo = L - 1 + j, gsel_hi = ldp + j - 2;
         // interior tiles (all 32 queries and all 128 keys of the workgroup in range, the j == i+1 diagonal not crossing the tile) take a
         // branch-free element loop; edge and diagonal tiles the general one

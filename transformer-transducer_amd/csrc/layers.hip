@@ -406,10 +406,7 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
     // 7. dq(content) = dS K -> dqkv[q]
     const bool fastpos = fused && Dh % 8 == 0;      // position/content products on the glds kernels (K-major transposed k, E)
     if (fastpos) {
-        if (w.ldp > L) {                             // K runs over the padded pitch: pad columns of dS16 / dG16 must be zero
-            CK(memset2d(w.dS16 + L, (size_t)w.ldp * 2, (size_t)(w.ldp - L) * 2, (size_t)B * H * L, st));
-            CK(memset2d(w.dG16 + L, (size_t)w.ldp * 2, (size_t)(w.ldp - L) * 2, (size_t)B * H * L, st));
-        }
+        // (K runs over the padded pitch ldp: the pad columns of dS16 / dG16 were zeroed by the flash backward kernel itself)
         CK(transpose_bf16_batched(static_cast<const bf16_t*>(c.qkv) + a.HD, 1, a.W3, B, H, L * a.W3, Dh, L, Dh, w.kT16, w.ldp, st));
         // (the product itself is issued together with the position part below: one launch, no f32 intermediate)
     } else {
