@@ -45,7 +45,8 @@ const char* ttmi_last_error(void);   /* thread-local, valid until the next faili
  * r_w_bias [H,Dh]; r_bias [K,H].  mask_kind 0 none | 1 causal (tt/utils.py:233-239) | 2 band: masked iff
  * j > i+right or j < i-left (tt/utils.py:242-251) | 3 uint8 tensor, element (b,i,j) at
  * mask[b*mask_sb + i*mask_si + j], nonzero = masked (any [L,L,1] / [L,L,B] / (klen,bsz) mask of
- * tt/transformer.py:154-159 after a permute). */
+ * tt/transformer.py:154-159 after a permute) | 4 per-row key intervals: `mask` points at int32 pairs, (lo, hi) of query i of batch b at
+ * ((const int*)mask)[b*mask_sb + 2*i], key j masked iff j < lo or j > hi (what chunk / band masks are; mask_sb = 0 shares one table). */
 size_t ttmi_attn_ctx_floats(int B, int L, int d, int H, int Dh, int prec);
 size_t ttmi_attn_ws_floats(int B, int L, int d, int H, int Dh, int prec);
 int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const float* ln_g, const float* ln_b,

@@ -81,3 +81,34 @@ def test_position_slab_kernel_matches_the_gemm_path(Dh, H, L, K, monkeypatch):
         ops.set_option(5, 0)
     assert rel_err(y1.cpu().numpy(), y0.cpu().numpy()) < 2e-3       # bf16 activations downstream of an f32-rounding-level change
     assert rel_err(dx1.cpu().numpy(), dx0.cpu().numpy()) < 5e-3
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_interval_structured_masks_take_the_row_range_path(prec, monkeypatch):
+    """as_mask_spec turns a mask whose rows are single key intervals (chunk / band masks) into per-row (lo, hi) ranges (mask kind 4); the
+    result is identical to the byte-mask path (kind 3) in the fused kernels (bf16) and in the softmax chain (fp32).  A mask with holes
+    stays a byte mask."""
+    from tt.encoder import BaseEncoder
+    from tt.transformer import as_mask_spec
+    from ttmi.ops import MaskSpec
+    monkeypatch.setenv("TTMI_PRECISION", prec)
+    Dh, H, L, K, B = 64, 2, 96, 128, 2
+    torch.manual_seed(3)
+    layer = BaseEncoder(k_len=K, n_head=H, d_model=H * Dh, d_head=Dh, d_inner=64, dropout=0.0).cuda().eval()
+    x = torch.randn(B, L, H * Dh, device="cuda")
+    cot = torch.randn(B, L, H * Dh, device="cuda")
+    m = torch.tensor(O.chunk_mask(L, 16, 32)).cuda()                 # [L, L] bool-like, True = masked
+    ref_style = (m != 0)[:, :, None]                                 # (qlen, klen, 1) as the reference passes it
+    spec = as_mask_spec(ref_style, B, L)
+    assert spec.kind == 4 and spec.tensor.shape == (1, L, 2)
+    assert as_mask_spec(ref_style, B, L) is spec                     # cached per mask tensor
+    y4, dx4, g4 = _run(layer, x, cot, spec)
+    y3, dx3, g3 = _run(layer, x, cot, MaskSpec(3, tensor=(m != 0)[None].to(torch.uint8).contiguous()))
+    assert torch.equal(y4, y3) and torch.equal(dx4, dx3)
+    for n in g4:      # parameter gradients are summed by f32 atomics (split-K, column sums): same values, not the same bits
+        assert rel_err(g4[n].cpu().numpy(), g3[n].cpu().numpy()) < 1e-5, n
+    holes = ref_style.clone()
+    holes[5, 3, 0] = True
+    holes[5, 1, 0] = False
+    holes[5, 5, 0] = False
+    assert as_mask_spec(holes, B, L).kind == 3

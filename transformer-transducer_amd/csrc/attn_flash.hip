@@ -37,7 +37,10 @@ __device__ __forceinline__ bool is_masked(const FlashParams& p, int b, int i, in
     if constexpr (MK == 1) return j > i;
     else if constexpr (MK == 2) return (j > i + p.mask_right) || (j < i - p.mask_left);
     else if constexpr (MK == 3) return p.mask[(long)b * p.mask_sb + (long)i * p.mask_si + j] != 0;
-    else return false;
+    else if constexpr (MK == 4) {                  // per-row key interval (the kernels keep lo / hi in registers or LDS instead)
+        const int* r = reinterpret_cast<const int*>(p.mask) + (long)b * p.mask_sb + 2 * i;
+        return j < r[0] || j > r[1];
+    } else return false;
 }
 
 template <int DH>
@@ -130,6 +133,12 @@ __global__ __launch_bounds__(256, FWD_MINB) void flash_fwd_kernel(const FlashPar
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m = NEGBIG, l = 0.f;
+    int mlo = 0, mhi = 0x7fffffff;                 // MK == 4: this lane's query row allows keys mlo..mhi
+    if constexpr (MK == 4) {
+        const int* r = reinterpret_cast<const int*>(p.mask) + (long)b * p.mask_sb + 2 * ic;
+        mlo = r[0];
+        mhi = r[1];
+    }
     const bf16_t* bd_row = p.bd + (long)z * p.slab + (long)ic * L;
     const bf16_t* kbase = p.k + (long)b * L * p.ld_kv + h * DH;
     const bf16_t* vbase = p.v + (long)b * L * p.ld_kv + h * DH;
@@ -192,7 +201,8 @@ __global__ __launch_bounds__(256, FWD_MINB) void flash_fwd_kernel(const FlashPar
         for (int r = 0; r < 16; ++r) {
             const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * hh;
             float v = NEGBIG;
-            if (j < L && !is_masked<MK>(p, b, ic, j)) v = (s[r] + bcur[r]) * p.scale;
+            const bool msk = MK == 4 ? (j < mlo || j > mhi) : is_masked<MK>(p, b, ic, j);
+            if (j < L && !msk) v = (s[r] + bcur[r]) * p.scale;
             s[r] = v;
             pmax = fmaxf(pmax, v);
         }
@@ -300,6 +310,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) 
     // loads (4 per thread), parked in LDS, read back per lane (row i0 + q, column = own key).  The per-element global 2-byte
     // loads this replaces were 42 % of the kernel's time.
     bf16_t* btile = reinterpret_cast<bf16_t*>(del_s + 32);                   // [32][128] bf16
+    int* lo_s = reinterpret_cast<int*>(btile + 32 * 128);                    // MK == 4: the tile's 32 (lo, hi) pairs
+    int* hi_s = lo_s + 32;
     const int jw0 = blockIdx.x * 128;
     const bool bstage = (L % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.bd) & 7) == 0) && (p.slab % 4 == 0) && L >= 4;
     uint2 bpre[4];
@@ -346,6 +358,11 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) 
             const int ii = min(i0 + tid, L - 1);
             lse_s[tid] = p.lse[(long)z * L + ii];
             del_s[tid] = p.delta[(long)z * L + ii];
+            if constexpr (MK == 4) {
+                const int* r = reinterpret_cast<const int*>(p.mask) + (long)b * p.mask_sb + 2 * ii;
+                lo_s[tid] = r[0];
+                hi_s[tid] = r[1];
+            }
         }
         __syncthreads();
         if (i0 + 32 < L) {                                          // next tile's operands and bias fly under this tile's MFMAs
@@ -391,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) 
             for (int r = 0; r < 16; ++r) {
                 const int q = (r & 3) + 8 * (r >> 2) + 4 * hh;
                 float pr = 0.f, ds = 0.f;
-                if (!is_masked<MK>(p, b, i0 + q, j)) {
+                if (!(MK == 4 ? (j < lo_s[q] || j > hi_s[q]) : is_masked<MK>(p, b, i0 + q, j))) {
                     const float sc = (s[r] + bcur[r]) * p.scale;
                     pr = __expf(sc - lse_s[q]);
                     ds = pr * (dp[r] - del_s[q]) * p.scale;
@@ -418,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) 
                 const bool inb = (i < L) && kvalid;
                 float pr = 0.f, ds = 0.f;
                 if (inb) {
-                    if (!is_masked<MK>(p, b, i, j)) {
+                    if (!(MK == 4 ? (j < lo_s[q] || j > hi_s[q]) : is_masked<MK>(p, b, i, j))) {
                         const float sc = (s[r] + bcur[r]) * p.scale;
                         pr = __expf(sc - lse_s[q]);
                         ds = pr * (dp[r] - del_s[q]) * p.scale;
@@ -644,6 +661,7 @@ int flash_attn_fwd(const FlashParams& p, hipStream_t st) {
         case 1: FWD_LAUNCH(1); break;
         case 2: FWD_LAUNCH(2); break;
         case 3: FWD_LAUNCH(3); break;
+        case 4: FWD_LAUNCH(4); break;
         default: FWD_LAUNCH(0); break;
     }
 #undef FWD_LAUNCH
@@ -660,12 +678,13 @@ int flash_attn_bwd(const FlashParams& p, hipStream_t st) {
     dim3 grid(cdiv(p.L, 128), p.B * p.H);
     if (p.Dh == 64) hipLaunchKernelGGL(flash_delta_kernel<64>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta);
     else hipLaunchKernelGGL(flash_delta_kernel<32>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta);
-#define BWD_LAUNCH(MKV) do { if (p.Dh == 64) hipLaunchKernelGGL((flash_bwd_kernel<64, MKV>), grid, dim3(256), 64 * 128 + 256 + 8192, st, p); \
-                             else hipLaunchKernelGGL((flash_bwd_kernel<32, MKV>), grid, dim3(256), 64 * 64 + 256 + 8192, st, p); } while (0)
+#define BWD_LAUNCH(MKV) do { if (p.Dh == 64) hipLaunchKernelGGL((flash_bwd_kernel<64, MKV>), grid, dim3(256), 64 * 128 + 256 + 8192 + 256, st, p); \
+                             else hipLaunchKernelGGL((flash_bwd_kernel<32, MKV>), grid, dim3(256), 64 * 64 + 256 + 8192 + 256, st, p); } while (0)
     switch (p.mask_kind) {
         case 1: BWD_LAUNCH(1); break;
         case 2: BWD_LAUNCH(2); break;
         case 3: BWD_LAUNCH(3); break;
+        case 4: BWD_LAUNCH(4); break;
         default: BWD_LAUNCH(0); break;
     }
 #undef BWD_LAUNCH

@@ -258,7 +258,7 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
     TTMI_REQUIRE(x && qkv_w && o_w && ln_g && ln_b && r_emb && r_w_bias && r_bias && ctx && ws && y, "attn_fwd: null pointer");
     TTMI_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "attn_fwd: dropout probability %f outside [0,1)", p_drop);
     TTMI_REQUIRE(B > 0 && L > 0 && d > 0 && H > 0 && Dh > 0 && K > 0, "attn_fwd: bad dims");
-    TTMI_REQUIRE(mask_kind >= 0 && mask_kind <= 3, "attn_fwd: bad mask kind %d", mask_kind);
+    TTMI_REQUIRE(mask_kind >= 0 && mask_kind <= 4, "attn_fwd: bad mask kind %d", mask_kind);
     TTMI_REQUIRE(((reinterpret_cast<uintptr_t>(ctx) | reinterpret_cast<uintptr_t>(ws)) & 255) == 0, "attn_fwd: ctx/ws must be 256-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const AttnDims a(B, L, d, H, Dh, K);

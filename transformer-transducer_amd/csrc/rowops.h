@@ -2,12 +2,13 @@
 #pragma once
 #include "common.h"
 
-enum MaskKind { MASK_NONE = 0, MASK_CAUSAL = 1, MASK_BAND = 2, MASK_TENSOR = 3 };
+enum MaskKind { MASK_NONE = 0, MASK_CAUSAL = 1, MASK_BAND = 2, MASK_TENSOR = 3, MASK_INTERVAL = 4 };
 
 struct MaskDesc {
     int kind = MASK_NONE;
     int left = 0, right = 0;            // MASK_BAND: masked iff j > i + right or j < i - left
     const uint8_t* ptr = nullptr;       // MASK_TENSOR: nonzero = masked, element (b,i,j) at ptr[b*sb + i*si + j]
+                                        // MASK_INTERVAL: int32 pairs (lo, hi) at ((const int*)ptr)[b*sb + 2*i]: masked iff j < lo || j > hi
     long sb = 0, si = 0;
 };
 

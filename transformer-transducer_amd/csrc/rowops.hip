@@ -251,6 +251,10 @@ __device__ __forceinline__ bool masked_at(const MaskDesc& m, int b, int i, int j
         case MASK_CAUSAL: return j > i;
         case MASK_BAND: return (j > i + m.right) || (j < i - m.left);
         case MASK_TENSOR: return m.ptr[(long)b * m.sb + (long)i * m.si + j] != 0;
+        case MASK_INTERVAL: {
+            const int* r = reinterpret_cast<const int*>(m.ptr) + (long)b * m.sb + 2 * i;
+            return j < r[0] || j > r[1];
+        }
         default: return false;
     }
 }
@@ -728,7 +732,7 @@ int ln_bwd(const float* dy, const float* s, const float* mean, const float* rstd
 
 int softmax_fwd(float* S, int nb, int nh, int L, long ld, long slab, float scale, const MaskDesc& m, hipStream_t st) {
     TTMI_REQUIRE(S && nb > 0 && nh > 0 && L > 0, "softmax_fwd: bad arguments");
-    TTMI_REQUIRE(m.kind != MASK_TENSOR || m.ptr, "softmax_fwd: tensor mask without pointer");
+    TTMI_REQUIRE((m.kind != MASK_TENSOR && m.kind != MASK_INTERVAL) || m.ptr, "softmax_fwd: tensor mask without pointer");
     const long nrows = (long)nb * nh * L;
     hipLaunchKernelGGL(softmax_fwd_kernel, dim3(cdiv(nrows, WPB)), dim3(WPB * 64), 0, st, S, nrows, nh, L, ld, slab, scale, m);
     TTMI_LAUNCH_CHECK("softmax_fwd_kernel");

@@ -20,13 +20,21 @@ def default_precision():
     return 1 if os.environ.get("TTMI_PRECISION", "fp32").lower() in ("bf16", "1") else 0
 
 
+_mask_cache = {}     # id(mask tensor) -> (weakref, version, MaskSpec): every layer of a stack gets the same mask tensor
+
+
 def as_mask_spec(mask, B, L):
     """Reference mask conventions (tt/transformer.py:154-159): None; 2-D = (klen, bsz) key mask broadcast over
-    queries; 3-D = (qlen, klen, bsz|1).  Nonzero / True = masked.  Returns a MaskSpec for the kernels."""
+    queries; 3-D = (qlen, klen, bsz|1).  Nonzero / True = masked.  Returns a MaskSpec for the kernels.  The conversion (and the
+    check whether every row's unmasked keys form one interval - chunk / band / causal masks do - in which case the kernels get
+    per-row [lo, hi] ranges instead of L x L bytes) is done once per mask tensor object and version."""
     if mask is None:
         return MaskSpec(0)
     if isinstance(mask, MaskSpec):
         return mask
+    ent = _mask_cache.get(id(mask))
+    if ent is not None and ent[0]() is mask and ent[1] == mask._version:
+        return ent[2]
     m = mask != 0
     if m.dim() == 2:
         t = m.t().unsqueeze(1)                    # [b, 1, j]
@@ -34,7 +42,19 @@ def as_mask_spec(mask, B, L):
         t = m.permute(2, 0, 1)                    # [b|1, i, j]
     else:
         raise ValueError("attn_mask must be 2-D (klen, bsz) or 3-D (qlen, klen, bsz)")
-    return MaskSpec(3, tensor=t.to(torch.uint8).contiguous())
+    spec = MaskSpec(3, tensor=t.to(torch.uint8).contiguous())
+    if t.is_cuda and t.shape[1] > 1:
+        keep = ~t                                                   # [b|1, i, j], True = attend
+        n = keep.sum(-1)
+        lo = keep.int().argmax(-1)
+        hi = t.shape[-1] - 1 - keep.flip(-1).int().argmax(-1)
+        if bool(((n > 0) & (n == hi - lo + 1)).all()):             # one host sync per distinct mask tensor
+            spec = MaskSpec(4, tensor=torch.stack([lo, hi], -1).to(torch.int32).contiguous())
+    if len(_mask_cache) > 32:
+        _mask_cache.clear()
+    import weakref
+    _mask_cache[id(mask)] = (weakref.ref(mask), mask._version, spec)
+    return spec
 
 
 def grad_targets(params, names):

@@ -112,7 +112,8 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, flags, bias=None, aux=None, alpha=1.0,
 # ----------------------------------------------------------------------------- sub-layers
 class MaskSpec:
     """Attention mask handed to the kernels as parameters: kind 0 none, 1 causal
-    (look_ahead_mask), 2 band (context_mask left/right), 3 arbitrary uint8 tensor [B|1, L, L]."""
+    (look_ahead_mask), 2 band (context_mask left/right), 3 arbitrary uint8 tensor [B|1, L, L], 4 per-row key intervals: int32 tensor
+    [B|1, L, 2] of (lo, hi), key j of query i is masked iff j < lo or j > hi."""
     __slots__ = ("kind", "left", "right", "tensor")
 
     def __init__(self, kind=0, left=0, right=0, tensor=None):
@@ -120,6 +121,8 @@ class MaskSpec:
 
     def args(self):
         t = self.tensor
+        if self.kind == 4:
+            return c_int(4), c_int(0), c_int(0), _p(t), c_long(t.stride(0) if t.shape[0] > 1 else 0), c_long(2)
         if self.kind != 3:
             return c_int(self.kind), c_int(self.left), c_int(self.right), c_void_p(0), c_long(0), c_long(0)
         sb = t.stride(0) if t.shape[0] > 1 else 0
