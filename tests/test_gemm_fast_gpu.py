@@ -147,3 +147,27 @@ def test_persistent_256_wgrad_kernel_exact(M, N, K):
     C.fill_(1.0)
     ops.gemm_tn_bf16(A[:, :M], B, C, accumulate=True)
     assert torch.equal(C, want + 1)
+
+
+@pytest.mark.parametrize("M,N,K,cs", [(512, 512, 16000, False), (1536, 512, 16000, False), (2048, 512, 16000, True), (512, 2048, 16000, False),
+                                      (256, 1024, 4096, False), (1024, 512, 8192, True)])
+def test_persistent_256x128_wgrad_kernel_exact(M, N, K, cs):
+    """TN v9 (encoder wgrads: persistent 256x128, transposed LDS reads, three stages, K-range items per XCD, atomics, all-ones-MFMA column
+    sums when there are exactly 4 column tiles): exact on small integers, accumulating into a non-zero C"""
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    A, B = _ints((K, M), g), _ints((K, N), g)
+    want, wcs = A.float().t() @ B.float(), A.float().sum(0)
+    C = torch.ones(M, N, device="cuda")
+    csum = torch.full((M,), 3.0, device="cuda")
+    ops.gemm_tn_bf16(A, B, C, accumulate=True, colsum_a=csum if cs else None)
+    assert torch.equal(C, want + 1)
+    if cs:
+        assert torch.equal(csum, wcs + 3)
+    ops.set_option(1, 5)                               # the 128x128 kernel gives the same numbers
+    try:
+        C2 = torch.ones(M, N, device="cuda")
+        ops.gemm_tn_bf16(A, B, C2, accumulate=True)
+    finally:
+        ops.set_option(1, 4)
+    assert torch.equal(C2, want + 1)

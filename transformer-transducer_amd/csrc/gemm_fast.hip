@@ -999,7 +999,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p) {
 // Fused bias gradient: colsum[m] += sum_k A[k][m] comes out of one extra MFMA per wave and K-tile against an all-ones fragment -
 // the 4 column tiles x 4 waves that read the same A rows each take one of the 16 (strip, 16-row tile, k-half) pieces.
 // =====================================================================================================================
-constexpr int LDS8T = 2 * BUF8;
+constexpr int LDS8T = 2 * BUF8 + 8 * 4096;      // operand buffers + the epilogue's per-wave images
 
 template <bool CS>
 __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
@@ -1187,19 +1187,24 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
         if (live) { item(it, bm, bn, tn); sources(bm, bn, kbeg); prologue(); }
 
         if (cnk > 0) {
+            // memory-side atomics want whole contiguous segments per wave-instruction: 16 rows at a time through a private LDS image
+            // (behind the operand buffers), one 256-byte row per instruction (see TN v9)
             float* C = reinterpret_cast<float*>(p.C);
-#pragma unroll
+            float* img = reinterpret_cast<float*>(smem + 2 * BUF8 + wave * 4096);
+            const int n = cbn + wc * 64 + lane;
+#define TN8_SLAB(I) case I: _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) \
+            *reinterpret_cast<f32x4*>(img + (lane & 15) * 64 + ((ni * 4 + (lane >> 4)) ^ (lane & 15)) * 4) = acc[I][ni]; break;
+#pragma unroll 1
             for (int mi = 0; mi < 8; ++mi) {
-                const int m = cbm + (mi >> 2) * 128 + wr * 64 + (mi & 3) * 16 + (lane & 15);
-                if (m >= p.M) continue;
+                switch (mi) { TN8_SLAB(0) TN8_SLAB(1) TN8_SLAB(2) TN8_SLAB(3) TN8_SLAB(4) TN8_SLAB(5) TN8_SLAB(6) TN8_SLAB(7) }
+                const int m0 = cbm + (mi >> 2) * 128 + wr * 64 + (mi & 3) * 16;
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    const int n0 = cbn + wc * 64 + ni * 16 + (lane >> 4) * 4;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (n0 + j < p.N) atomicAdd(C + (long)m * p.ldc + n0 + j, acc[mi][ni][j]);
+                for (int r = 0; r < 16; ++r) {
+                    const float v = img[r * 64 + (((lane >> 2) ^ r) << 2) + (lane & 3)];
+                    if (m0 + r < p.M && n < p.N) atomicAdd(C + (long)(m0 + r) * p.ldc + n, v);
                 }
             }
+#undef TN8_SLAB
             if (CS && lane < 16) {
                 const int m = cbm + (cunit >> 3) * 128 + wr * 64 + ((cunit >> 1) & 3) * 16 + lane;
                 if (m < p.M) atomicAdd(p.colsum + m, cs[0]);
@@ -1208,6 +1213,186 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
     }
 #undef V8_LGKM0
 #undef V8_BAR
+}
+
+// =====================================================================================================================
+// v9 TN: the encoder wgrads (C[M,N] += A[K,M]^T B[K,N], M, N = 512..2048, K = B*T = 16000): TN v8's operand handling (both
+// operands reduction-major in LDS, every fragment by ds_read_b64_tr_b16, same sw(k) swizzle) on v9's schedule (256 x 128 tile,
+// 8 waves as 4 x 2, wave tile 64 x 64, three 48 KiB stages, one phase per K-tile, waves 4-7 one barrier behind, counted
+// vmcnt(6)).  A stage = A [64 k][256 m] (512-byte k-rows, 32 staging units of 2 k-rows) | B [64 k][128 n] (256-byte k-rows, 16
+// units of 4 k-rows).  Work = TN v8's item list: the reduction is cut into 8*S ranges, XCD x owns S of them, its workgroups
+// walk (range, tile) items; f32 atomics into C; optional column sums of A from one extra all-ones MFMA per wave and K-tile
+// (needs tiles_n == 4: the 4 column tiles x 2 wave columns that read the same A rows share its 8 (16-row tile, k-half) pieces).
+// The 128x128 kernel this replaces spent 150 of its 221 us per layer in the main loops (4 workgroups per CU, single-buffered).
+// =====================================================================================================================
+template <bool CS>
+__global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v9_kernel(const FP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave & 3, wc = wave >> 2;               // waves w and w+4 (SIMD partners) differ in the column half
+    const int grp = wave >> 2;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int S = p.splitk;
+    const int xcd = blockIdx.x & 7, cu = blockIdx.x >> 3, ncu = gridDim.x >> 3;
+    const int nitems = S * ntiles;
+    const int nkt = (p.K + TK - 1) / TK;
+    const int per = p.ksteps;
+
+    // staging: A unit u = 4*wave + j: k-rows 2u + (lane >> 5), 16-byte slot lane & 31; B unit u = 2*wave + j: k-rows 4u + (lane >> 4), slot lane & 15
+    unsigned oA[4], oB[2];
+    const char* baseA = nullptr;
+    const char* baseB = nullptr;
+    long kbeg = 0;
+    int nk = 0;
+    auto sources = [&](int bm, int bn, long k0) {
+        baseA = reinterpret_cast<const char*>(p.A + k0 * p.lda);
+        baseB = reinterpret_cast<const char*>(p.B + k0 * p.ldb);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = (wave * 4 + j) * 2 + (lane >> 5);
+            const int c = (lane & 31) ^ (((k & 3) << 2) | (((k >> 3) & 1) << 1));
+            oA[j] = (unsigned)((k * p.lda + min((long)bm + c * 8, p.lda - 8)) * 2);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = (wave * 2 + j) * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ (((k & 3) << 2) | (((k >> 3) & 1) << 1));
+            oB[j] = (unsigned)((k * p.ldb + min((long)bn + c * 8, p.ldb - 8)) * 2);
+        }
+    };
+    auto stage = [&](int stg, int kt) {
+        char* dst = smem + stg * STG9;
+        const char* ba = baseA + (long)kt * TK * p.lda * 2;
+        const char* bb = baseB + (long)kt * TK * p.ldb * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(ba + oA[j], dst + (wave * 4 + j) * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(bb + oB[j], dst + T9M * 128 + (wave * 2 + j) * 1024);
+    };
+    auto item = [&](int i, int& bm, int& bn, int& tn) {
+        const int s = i / ntiles, t = i % ntiles;
+        const int per_group = GROUP_M * p.tiles_n;
+        const int group = t / per_group, in = t % per_group;
+        const int first = group * GROUP_M;
+        const int gsz = min(p.tiles_m - first, GROUP_M);
+        bm = (first + in % gsz) * T9M;
+        tn = in / gsz;
+        bn = tn * T9N;
+        const long r = (long)xcd * S + s;
+        kbeg = r * per * TK;
+        nk = (int)max(0L, min((long)per, (long)nkt - r * per));
+    };
+
+    // transposed fragment reads: group g = lane >> 4 (the k-octet), lane 4q + pp of the group addresses k-row q, columns 4pp..4pp+3
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int swz = (q << 2) | ((g & 1) << 1);
+    int aoff[4], boff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ca = wr * 64 + i * 16 + 4 * pp, cb = wc * 64 + i * 16 + 4 * pp;
+        aoff[i] = (g * 8 + q) * 512 + (((ca >> 3) ^ swz) << 4) + (ca & 7) * 2;
+        boff[i] = T9M * 128 + (g * 8 + q) * 256 + (((cb >> 3) ^ swz) << 4) + (cb & 7) * 2;
+    }
+    f32x4 acc[4][4];
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[4][2], bfr[4][2];
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+#define V9_BAR() __builtin_amdgcn_s_barrier()
+
+    int bm = 0, bn = 0, tn = 0;
+    int it = cu;
+    bool live = it < nitems;
+    if (live) { item(it, bm, bn, tn); sources(bm, bn, kbeg); stage(0, 0); if (nk > 1) stage(1, 1); }
+    while (live) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        cs = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int cs_unit = CS ? __builtin_amdgcn_readfirstlane((tn & 3) * 2 + wc) : -1;     // (mt, ks) = (unit >> 1, unit & 1)
+        const int cnk = nk;
+        if (cnk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        V9_BAR();
+        if (grp == 1) V9_BAR();
+        int stg = 0;
+        for (int t = 0; t < cnk; ++t) {
+            const char* base = smem + stg * STG9;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const char* a = base + aoff[i] + ks * (32 * 512);
+                    af[i][ks] = __builtin_shufflevector(ds_read_tr16(a), ds_read_tr16(a + 4 * 512), 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const char* bq = base + boff[i] + ks * (32 * 256);
+                    bfr[i][ks] = __builtin_shufflevector(ds_read_tr16(bq), ds_read_tr16(bq + 4 * 256), 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            }
+            if (t + 2 < cnk) {
+                stage(stg == 0 ? 2 : stg - 1, t + 2);
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            V9_BAR();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt][ks], af[mt][ks], acc[mt][nt], 0, 0, 0);
+            if (CS) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+                        if (cs_unit == mt * 2 + ks) cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[mt][ks], cs, 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            V9_BAR();
+            stg = stg == 2 ? 0 : stg + 1;
+        }
+        if (grp == 0) V9_BAR();
+
+        const int cbm = bm, cbn = bn, cunit = cs_unit;
+        it += ncu;
+        live = it < nitems;
+        if (live) { item(it, bm, bn, tn); sources(bm, bn, kbeg); stage(0, 0); if (nk > 1) stage(1, 1); }
+
+        if (cnk > 0) {
+            // atomics run at the memory side and want whole contiguous segments per wave-instruction: the accumulators (a lane holds 4
+            // columns of one row) go 16 rows at a time through a private LDS image in stage 2 (free until the next loop's K-tile 2) and
+            // leave as one 256-byte row per instruction - straight from the registers the same adds were 4-byte pieces in 16 rows
+            float* C = reinterpret_cast<float*>(p.C);
+            float* img = reinterpret_cast<float*>(smem + 2 * STG9 + wave * 4096);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    *reinterpret_cast<f32x4*>(img + (lane & 15) * 64 + ((ni * 4 + (lane >> 4)) ^ (lane & 15)) * 4) = acc[mi][ni];
+                const int n = cbn + wc * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = cbm + wr * 64 + mi * 16 + r;
+                    const float v = img[r * 64 + (((lane >> 2) ^ r) << 2) + (lane & 3)];
+                    if (m < p.M && n < p.N) atomicAdd(C + (long)m * p.ldc + n, v);
+                }
+            }
+            if (CS && lane < 16) {
+                const int m = cbm + wr * 64 + (cunit >> 1) * 16 + lane;
+                if (m < p.M) atomicAdd(p.colsum + m, cs[0]);
+            }
+        }
+    }
+#undef V9_BAR
 }
 
 template <typename K>
@@ -1353,9 +1538,38 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
     fill_batch(p, batch);
     const int nbatch = batch.nz1 * batch.nz2;
     TTMI_REQUIRE(nbatch >= 1 && nbatch <= 65535, "gemm_tn_bf16: bad batch count %d", nbatch);
+    if (g_num_cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            g_num_cus = n / 8 * 8;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    // encoder-sized wgrad: persistent 256x128 kernel when its tiles fill the output exactly and the reduction is long enough
+    const bool tn9 = (g_gemm_fast_version == 4 || g_gemm_fast_version == 9) && nbatch == 1 && accumulate && K % TK == 0 && K >= 4096 && K < 32768 &&
+                     M % T9M == 0 && N % T9N == 0 && (!colsum_a || N / T9N == 4) && (long)(M / T9M) * (N / T9N) >= 8;
+    if (tn9) {
+        p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+        p.tiles_m = M / T9M; p.tiles_n = N / T9N;
+        const int cus = std::max(8, (g_num_cus - g_reserved_cus) / 8 * 8), ncu_x = cus / 8, ntile = p.tiles_m * p.tiles_n;
+        // ranges per XCD: keep every item >= ~16 K-tiles long (atomics per output element grow with the number of ranges) and fill the XCD's
+        // workgroups as evenly as the tile count allows
+        const int nkt = cdiv(K, TK);
+        int S = std::max(1, ncu_x / ntile);
+        while (S > 1 && nkt / (8 * S) < 12) --S;
+        p.splitk = S; p.ksteps = cdiv(nkt, 8 * S); p.atomic = 1; p.gm = 0;
+        if (colsum_a) {
+            if (int rc = enable_lds(gemm_tn_bf16_v9_kernel<true>, LDS9)) return rc;
+            hipLaunchKernelGGL(gemm_tn_bf16_v9_kernel<true>, dim3((unsigned)cus), dim3(NTH8), LDS9, st, p);
+        } else {
+            if (int rc = enable_lds(gemm_tn_bf16_v9_kernel<false>, LDS9)) return rc;
+            hipLaunchKernelGGL(gemm_tn_bf16_v9_kernel<false>, dim3((unsigned)cus), dim3(NTH8), LDS9, st, p);
+        }
+        TTMI_LAUNCH_CHECK("gemm_tn_bf16_v9_kernel");
+        return TTMI_OK;
+    }
     // huge-reduction wgrad (the joint projection: K = B*T*U1 rows): persistent 256x256 kernel on the 256-row tiles that are
     // full, the 128x128 kernel below on the remaining M % 256 rows
-    const bool tn8 = nbatch == 1 && accumulate && K % TK == 0 && N >= 256 && N % 256 == 0 && (!colsum_a || (N / 256) % 4 == 0) &&
+    const bool tn8 = nbatch == 1 && accumulate && K % TK == 0 && N >= 256 && N % 256 == 0 && (!colsum_a || N / 256 == 4) &&
                      ((g_gemm_fast_version == 4 && K >= 32768 && M >= 1024) || (g_gemm_fast_version == 8 && K >= 2048 && M >= 256));
     if (tn8) {
         if (g_num_cus == 0) {
