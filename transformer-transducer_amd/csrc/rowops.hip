@@ -524,8 +524,9 @@ __global__ __launch_bounds__(256) void joint_tanh_bwd_kernel(const TH* __restric
 // dPE[b,t,:] = sum_u dP[b,t,u,:], dPD[b,u,:] += sum_t dP[b,t,u,:].  4 columns per thread, 8-byte loads.
 __global__ __launch_bounds__(256) void joint_sum_bwd_bf16x4_kernel(const bf16_t* __restrict__ dP, int T, int U1, int J,
                                                                    float* __restrict__ dPE, float* __restrict__ dPD) {
+    __shared__ float xch[4 * 256];                     // per wave: 256 column sums on their way to lane-contiguous atomics
     const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (j >= J) return;
+    const bool act = j < J;                            // (whole waves stay alive: the exchange is per wave)
     const int t0 = blockIdx.y * JT_TC;
     const int b = blockIdx.z;
     float accE[JT_TC][4];
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(256) void joint_sum_bwd_bf16x4_kernel(const bf16_t*
 #pragma unroll
         for (int tt = 0; tt < JT_TC; ++tt) {
             const int t = t0 + tt;
-            if (t < T) {
+            if (t < T && act) {
                 const uint2 w = *reinterpret_cast<const uint2*>(dP + (((long)b * T + t) * U1 + u) * J + j);
                 const float v[4] = {__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
                                     __uint_as_float(w.y & 0xffff0000u)};
@@ -546,13 +547,20 @@ __global__ __launch_bounds__(256) void joint_sum_bwd_bf16x4_kernel(const bf16_t*
                 for (int c = 0; c < 4; ++c) { accE[tt][c] += v[c]; accD[c] += v[c]; }
             }
         }
-        float* d = dPD + ((long)b * U1 + u) * J + j;
+        // memory-side atomics want contiguous segments per wave-instruction: the wave's 256 column sums (4 consecutive per lane) are
+        // re-dealt through LDS so that lane l adds column 64c + l (one 256-byte segment per instruction instead of 4-byte pieces)
+        float* xw = xch + (threadIdx.x >> 6) * 256;
+        *reinterpret_cast<float4*>(xw + (threadIdx.x & 63) * 4) = make_float4(accD[0], accD[1], accD[2], accD[3]);
+        float* d = dPD + ((long)b * U1 + u) * J + (blockIdx.x * 256 + (threadIdx.x & ~63)) * 4;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) atomicAdd(d + c, accD[c]);
+        for (int c = 0; c < 4; ++c) {
+            const int col = 64 * c + (threadIdx.x & 63);
+            if ((blockIdx.x * 256 + (threadIdx.x & ~63)) * 4 + col < J) atomicAdd(d + col, xw[col]);
+        }
     }
 #pragma unroll
     for (int tt = 0; tt < JT_TC; ++tt)
-        if (t0 + tt < T)
+        if (t0 + tt < T && act)
             *reinterpret_cast<float4*>(dPE + ((long)b * T + t0 + tt) * J + j) = make_float4(accE[tt][0], accE[tt][1], accE[tt][2], accE[tt][3]);
 }
 
