@@ -162,12 +162,11 @@ struct AttnCtx {   // saved for backward.  act = f32 (parity) or bf16 (fast)
 };
 
 struct AttnWs {   // scratch (union of forward and backward needs)
-    float *E, *cT, *dE, *dcT, *a, *dS, *dqkv, *delta, *lnpart;
+    float *E, *cT, *dE, *dcT, *a, *dS, *dqkv, *delta;
     void* dO;
     bf16_t *wqkv16, *wo16, *dqkv16, *dres16, *dS16, *dG16, *E16, *kT16, *ET16;
     long ldp, slab16;
     AttnWs(Bump& b, const AttnDims& a, bool fast) {
-        lnpart = b.take<float>(ln_bwd_part_floats(a.d));
         E = b.take<float>((size_t)a.L * a.HD);
         cT = b.take<float>((size_t)a.H * a.L);
         dE = b.take<float>((size_t)a.L * a.HD + (size_t)a.H * a.L + 64);   // dE and dcT zeroed together
@@ -360,7 +359,7 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
     //    the bf16 pipeline gets da from the same pass
     DropSpec rd;
     rd.p = p_drop; rd.seed = seed ^ 0xA1u;
-    CK(ln_bwd(dy, c.s1, c.mean, c.rstd, ln_g, nullptr, a.BL, d, dx, g_ln_g, g_ln_b, st, DropSpec(), fast ? w.dres16 : nullptr, rd, nullptr, w.lnpart));
+    CK(ln_bwd(dy, c.s1, c.mean, c.rstd, ln_g, nullptr, a.BL, d, dx, g_ln_g, g_ln_b, st, DropSpec(), fast ? w.dres16 : nullptr, rd, nullptr));
     const float* da = dx;
     if (!fast && p_drop > 0.f) {
         CK(dropout_apply(dx, a.BL * d, rd, w.a, nullptr, st));
@@ -500,11 +499,10 @@ struct FfnCtx {
     }
 };
 struct FfnWs {
-    float *f, *dres, *dh, *lnpart;
+    float *f, *dres, *dh;
     void* da1;
     bf16_t *w1_16, *w2_16, *dres16;
     FfnWs(Bump& b, long rows, int d, int Di, bool fast) {
-        lnpart = b.take<float>(ln_bwd_part_floats(d));
         f = b.take<float>(rows * d);
         dres = b.take<float>(rows * d);
         dh = b.take<float>(rows * d);
@@ -587,7 +585,7 @@ int ttmi_ffn_bwd(const float* dz, const float* y, const float* w1, const float* 
     // df = dres * mask(CoreNet.4); dres itself remains the residual-branch gradient.  bf16 pipeline: df (bf16) and g_b2 = its
     // column sums come out of the LayerNorm-backward pass itself
     CK(ln_bwd(dz, c.s2, c.mean2, c.rstd2, ln_g, nullptr, rows, d, w.dres, g_ln_g, g_ln_b, st, d_layer, fast ? w.dres16 : nullptr, d_out,
-              fast ? g_b2 : nullptr, w.lnpart));
+              fast ? g_b2 : nullptr));
     const float* df = w.dres;
     if (!fast) {
         if (p_drop > 0.f) {
@@ -620,7 +618,7 @@ int ttmi_ffn_bwd(const float* dz, const float* y, const float* w1, const float* 
         CK(wgrad(da1, h, g_w1, Di, d, (int)rows, Di, d, d, prec, st));
         CK(ttmi_launch_gemm(mk(da1, w1, w.dh, (int)rows, d, Di, Di, d, d, NN_, prec), st));
     }
-    CK(ln_bwd(w.dh, y, c.mean1, c.rstd1, ln_g, w.dres, rows, d, dy, g_ln_g, g_ln_b, st, DropSpec(), nullptr, DropSpec(), nullptr, w.lnpart));
+    CK(ln_bwd(w.dh, y, c.mean1, c.rstd1, ln_g, w.dres, rows, d, dy, g_ln_g, g_ln_b, st));
     join_stream(st);
     return TTMI_OK;
 }

@@ -2,7 +2,6 @@
 #pragma once
 #include "common.h"
 
-constexpr int LN_BWD_MAX_GRID = 512;
 enum MaskKind { MASK_NONE = 0, MASK_CAUSAL = 1, MASK_BAND = 2, MASK_TENSOR = 3, MASK_INTERVAL = 4 };
 
 struct MaskDesc {
@@ -25,10 +24,7 @@ int ln_fwd(const float* x, const float* res, const float* g, const float* b, lon
 // dx16_colsum, its column sums accumulated atomically (the bias gradient of the Linear in front of that dropout)
 int ln_bwd(const float* dy, const float* s, const float* mean, const float* rstd, const float* g, const float* dadd, long rows,
            int d, float* dx, float* dgamma, float* dbeta, hipStream_t st, DropSpec dy_drop = DropSpec(), bf16_t* dx16 = nullptr,
-           DropSpec dx16_drop = DropSpec(), float* dx16_colsum = nullptr, float* part_ws = nullptr);
-// part_ws (optional scratch, ln_bwd_part_floats(d) floats): per-block partial sums for dgamma / dbeta / colsum instead of every block's atomics
-// on the same d addresses
-inline size_t ln_bwd_part_floats(int d) { return (size_t)LN_BWD_MAX_GRID * 3 * d; }
+           DropSpec dx16_drop = DropSpec(), float* dx16_colsum = nullptr);
 // out[i] = in[i] * dropout_multiplier(i)  (out f32 and/or bf16); with p = 0 this is the plain f32 -> bf16 conversion
 int dropout_apply(const float* in, long n, DropSpec ds, float* out32, bf16_t* out16, hipStream_t st);
 // in-place P = softmax_j(scale * S) over the batched score view (nb slabs, L rows of ld floats each)

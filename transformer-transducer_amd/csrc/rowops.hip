@@ -4,7 +4,9 @@
 // wave reductions by __shfl_xor; cross-row reductions finish with float atomics (agent scope).
 // Reference arithmetic: tt/transformer.py:52-58,148-175, tt/decoder.py:26,39, tt/model.py:33-37.
 #include "rowops.h"
-#define LN_BWD_GRID LN_BWD_MAX_GRID
+#ifndef LN_BWD_GRID
+#define LN_BWD_GRID 512
+#endif
 #include <algorithm>
 
 namespace {
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restri
                                                            const float* __restrict__ g, const float* __restrict__ dadd, long rows,
                                                            int d, float* __restrict__ dx, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, DropSpec ddrop, bf16_t* __restrict__ dx16,
-                                                           DropSpec xdrop, float* __restrict__ dx16_colsum, float* __restrict__ part) {
+                                                           DropSpec xdrop, float* __restrict__ dx16_colsum) {
     // optional second output for the bf16 pipeline: dx16 = bf16(dx * dropout(xdrop)) (the masked gradient the following
     // GEMMs consume) and its column sums (the bias gradient of the Linear in front of the dropout)
     __shared__ float red[3][4][KV * 256];
@@ -237,31 +239,10 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restri
         }
     __syncthreads();
     for (int c = threadIdx.x; c < d; c += 256) {
-        const float sg = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c], sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
-        const float sc = red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c];
-        if (part) {
-            // every block adding into the same d addresses is the memory-side atomics' worst case (14x slower than spread adds, and all blocks
-            // finish together): plain partial rows here, summed by ln_bwd_reduce_kernel with a handful of adds per address
-            float* pr = part + (long)blockIdx.x * 3 * d;
-            pr[c] = sg; pr[d + c] = sb; pr[2 * d + c] = sc;
-        } else {
-            atomicAdd(dgamma + c, sg);
-            atomicAdd(dbeta + c, sb);
-            if (dx16_colsum) atomicAdd(dx16_colsum + c, sc);
-        }
+        atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        if (dx16_colsum) atomicAdd(dx16_colsum + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
     }
-}
-
-// column sums of the per-block partial rows [nblk][3][d] of ln_bwd_fused_kernel: block (x, y) sums partial rows y, y + gridDim.y, ... for
-// 256 of the 3*d columns and adds the result to dgamma | dbeta | colsum (gridDim.y adds per address)
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblk, int d, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, float* __restrict__ colsum) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= 3 * d) return;
-    float a = 0.f;
-    for (int b = blockIdx.y; b < nblk; b += gridDim.y) a += part[(long)b * 3 * d + c];
-    float* dst = c < d ? dgamma + c : c < 2 * d ? dbeta + (c - d) : (colsum ? colsum + (c - 2 * d) : nullptr);
-    if (dst) atomicAdd(dst, a);
 }
 
 // ------------------------------------------------------------------ masked softmax on the score view
@@ -731,22 +712,17 @@ int ln_fwd(const float* x, const float* res, const float* g, const float* b, lon
 int g_ln_bwd_grid = LN_BWD_GRID;
 int ln_bwd(const float* dy, const float* s, const float* mean, const float* rstd, const float* g, const float* dadd, long rows,
            int d, float* dx, float* dgamma, float* dbeta, hipStream_t st, DropSpec dy_drop, bf16_t* dx16, DropSpec dx16_drop,
-           float* dx16_colsum, float* part_ws) {
+           float* dx16_colsum) {
     TTMI_REQUIRE(dy && s && mean && rstd && g && dx && dgamma && dbeta && rows > 0 && d > 0, "ln_bwd: bad arguments");
     const bool fused = d % 4 == 0 && d <= 512 && aligned16(dy) && aligned16(s) && aligned16(g) && aligned16(dx) && (!dadd || aligned16(dadd)) &&
                        (!dx16 || (reinterpret_cast<uintptr_t>(dx16) & 7) == 0);
     if (fused) {
         const int grid = (int)std::min<long>(cdiv(rows, 4), g_ln_bwd_grid);   // rows are walked grid-stride
-        float* part = grid >= 64 ? part_ws : nullptr;       // few blocks: direct atomics are fine
         if (d <= 256)
-            hipLaunchKernelGGL(ln_bwd_fused_kernel<1>, dim3(grid), dim3(256), 0, st, dy, s, mean, rstd, g, dadd, rows, d, dx, dgamma, dbeta, dy_drop, dx16, dx16_drop, dx16_colsum, part);
+            hipLaunchKernelGGL(ln_bwd_fused_kernel<1>, dim3(grid), dim3(256), 0, st, dy, s, mean, rstd, g, dadd, rows, d, dx, dgamma, dbeta, dy_drop, dx16, dx16_drop, dx16_colsum);
         else
-            hipLaunchKernelGGL(ln_bwd_fused_kernel<2>, dim3(grid), dim3(256), 0, st, dy, s, mean, rstd, g, dadd, rows, d, dx, dgamma, dbeta, dy_drop, dx16, dx16_drop, dx16_colsum, part);
+            hipLaunchKernelGGL(ln_bwd_fused_kernel<2>, dim3(grid), dim3(256), 0, st, dy, s, mean, rstd, g, dadd, rows, d, dx, dgamma, dbeta, dy_drop, dx16, dx16_drop, dx16_colsum);
         TTMI_LAUNCH_CHECK("ln_bwd_fused_kernel");
-        if (part) {
-            hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(cdiv(3 * d, 256), 8), dim3(256), 0, st, part, grid, d, dgamma, dbeta, dx16_colsum);
-            TTMI_LAUNCH_CHECK("ln_bwd_reduce_kernel");
-        }
         return TTMI_OK;
     }
     hipLaunchKernelGGL(ln_bwd_dx_kernel, dim3(cdiv(rows, WPB)), dim3(WPB * 64), 0, st, dy, s, mean, rstd, g, dadd, rows, d, dx,
