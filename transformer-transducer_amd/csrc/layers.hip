@@ -147,6 +147,7 @@ struct AttnCtx {   // saved for backward.  act = f32 (parity) or bf16 (fast)
     void *qkv, *qu, *O;
     float *P, *s1, *mean, *rstd, *lse;     // P: f32 probabilities (unfused path) or the bf16 position-term slab (fused path, first half)
     bf16_t* x16 = nullptr;                 // bf16 copy of the input (fast): the qkv wgrad reads it again in backward
+    bf16_t *wqkvT16 = nullptr, *woT16 = nullptr;   // transposed bf16 weights for the dgrads, made in forward from the same read as the plain copies
     AttnCtx(Bump& b, const AttnDims& a, bool fast) {
         const size_t es = fast ? 2 : 4;
         qkv = b.take<char>(a.BL * a.W3 * es);
@@ -157,7 +158,11 @@ struct AttnCtx {   // saved for backward.  act = f32 (parity) or bf16 (fast)
         mean = b.take<float>(a.BL);
         rstd = b.take<float>(a.BL);
         lse = b.take<float>((size_t)a.B * a.H * a.L);
-        if (fast) x16 = b.take<bf16_t>(a.BL * a.d);
+        if (fast) {
+            x16 = b.take<bf16_t>(a.BL * a.d);
+            wqkvT16 = b.take<bf16_t>(a.W3 * a.d);
+            woT16 = b.take<bf16_t>(a.HD * a.d);
+        }
     }
 };
 
@@ -271,7 +276,7 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
     // 1. qkv = x Wqkv^T ; 2. qu = q + r_w_bias
     if (fast) {
         CK(convert_bf16(x, c.x16, a.BL * d, st));
-        CK(convert_bf16(qkv_w, w.wqkv16, a.W3 * d, st));
+        CK(transpose_convert_bf16(qkv_w, (int)a.W3, d, c.wqkvT16, a.W3, st, w.wqkv16));        // Wqkv (bf16) and Wqkv^T [d, W3] for backward
         CK(gemm_nt_bf16(c.x16, w.wqkv16, c.qkv, 1, nullptr, (int)a.BL, (int)a.W3, d, d, d, a.W3, st));
         CK(add_row_bias_bf16(static_cast<bf16_t*>(c.qkv), a.W3, r_w_bias, a.BL, (int)a.HD, static_cast<bf16_t*>(c.qu), a.HD, st));
     } else {
@@ -327,7 +332,7 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
     }
     // 8. a = O Wo^T ; 9. y = LN(x + a)
     if (fast) {
-        CK(convert_bf16(o_w, w.wo16, (long)d * a.HD, st));
+        CK(transpose_convert_bf16(o_w, d, (int)a.HD, c.woT16, d, st, w.wo16));                   // Wo (bf16) and Wo^T [HD, d] for backward
         CK(gemm_nt_bf16(static_cast<bf16_t*>(c.O), w.wo16, w.a, 0, nullptr, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, st));
     } else {
         CK(ttmi_launch_gemm(mk(static_cast<float*>(c.O), o_w, w.a, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, NT_, prec), st));
@@ -367,8 +372,7 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
     }
     if (fast) {
         CK(gemm_tn_bf16(w.dres16, static_cast<bf16_t*>(c.O), g_o_w, d, (int)a.HD, (int)a.BL, d, a.HD, a.HD, 1, fork_stream(st)));
-        CK(transpose_convert_bf16(o_w, d, (int)a.HD, w.wo16, d, st));                          // Wo^T [HD, d]
-        CK(gemm_nt_bf16(w.dres16, w.wo16, w.dO, 1, nullptr, (int)a.BL, (int)a.HD, d, d, d, a.HD, st));
+        CK(gemm_nt_bf16(w.dres16, c.woT16, w.dO, 1, nullptr, (int)a.BL, (int)a.HD, d, d, d, a.HD, st));
     } else {
         CK(wgrad(da, static_cast<float*>(c.O), g_o_w, d, (int)a.HD, (int)a.BL, d, a.HD, a.HD, prec, st));
         CK(ttmi_launch_gemm(mk(da, o_w, static_cast<float*>(w.dO), (int)a.BL, (int)a.HD, d, d, a.HD, a.HD, NN_, prec), st));
@@ -470,10 +474,9 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
     if (fast) {
         if (!fastpos) CK(convert_bf16(w.dqkv, w.dqkv16, a.BL * a.W3, st));      // fastpos: dq / dK / dV were written in bf16 by their producers
         CK(gemm_tn_bf16(w.dqkv16, c.x16, g_qkv_w, (int)a.W3, d, (int)a.BL, a.W3, d, d, 1, fork_stream(st)));
-        CK(transpose_convert_bf16(qkv_w, (int)a.W3, d, w.wqkv16, a.W3, st));                   // Wqkv^T [d, W3]
         NtEpilogue e;
         e.addend = dx;
-        CK(gemm_nt_bf16(w.dqkv16, w.wqkv16, dx, 0, e, (int)a.BL, d, (int)a.W3, a.W3, a.W3, d, st));
+        CK(gemm_nt_bf16(w.dqkv16, c.wqkvT16, dx, 0, e, (int)a.BL, d, (int)a.W3, a.W3, a.W3, d, st));
     } else {
         CK(wgrad(w.dqkv, x, g_qkv_w, (int)a.W3, d, (int)a.BL, a.W3, d, d, prec, st));
         GemmDesc g = mk(w.dqkv, qkv_w, dx, (int)a.BL, d, (int)a.W3, a.W3, d, d, NN_, prec);
@@ -489,6 +492,7 @@ namespace {
 struct FfnCtx {
     void *h, *a1;      // f32 (parity) or bf16 (fast)
     float *s2, *mean1, *rstd1, *mean2, *rstd2;
+    bf16_t *w1T16 = nullptr, *w2T16 = nullptr;     // W1^T [d, Di], W2^T [Di, d] (fast): made in forward for the backward dgrads
     FfnCtx(Bump& b, long rows, int d, int Di, bool fast) {
         const size_t es = fast ? 2 : 4;
         h = b.take<char>(rows * d * es);
@@ -496,6 +500,10 @@ struct FfnCtx {
         s2 = b.take<float>(rows * d);
         mean1 = b.take<float>(rows); rstd1 = b.take<float>(rows);
         mean2 = b.take<float>(rows); rstd2 = b.take<float>(rows);
+        if (fast) {
+            w1T16 = b.take<bf16_t>((size_t)Di * d);
+            w2T16 = b.take<bf16_t>((size_t)Di * d);
+        }
     }
 };
 struct FfnWs {
@@ -547,8 +555,8 @@ int ttmi_ffn_fwd(const float* y, const float* w1, const float* b1, const float* 
     FfnWs w(bw, rows, d, Di, fast);
     if (fast) {
         CK(ln_fwd(y, nullptr, ln_g, ln_b, rows, d, 1e-5f, nullptr, nullptr, c.mean1, c.rstd1, st, static_cast<bf16_t*>(c.h)));
-        CK(convert_bf16(w1, w.w1_16, (long)Di * d, st));
-        CK(convert_bf16(w2, w.w2_16, (long)Di * d, st));
+        CK(transpose_convert_bf16(w1, Di, d, c.w1T16, Di, st, w.w1_16));                        // W1 (bf16) and W1^T [d, Di]
+        CK(transpose_convert_bf16(w2, d, Di, c.w2T16, d, st, w.w2_16));                         // W2 (bf16) and W2^T [Di, d]
         NtEpilogue e1;
         e1.bias = b1; e1.relu = 1; e1.drop = d_in;
         CK(gemm_nt_bf16(static_cast<bf16_t*>(c.h), w.w1_16, c.a1, 1, e1, (int)rows, Di, d, d, d, Di, st));
@@ -599,13 +607,11 @@ int ttmi_ffn_bwd(const float* dz, const float* y, const float* w1, const float* 
         bf16_t* h = static_cast<bf16_t*>(c.h);
         bf16_t* da1 = static_cast<bf16_t*>(w.da1);
         CK(gemm_tn_bf16(w.dres16, a1, g_w2, d, Di, (int)rows, d, Di, Di, 1, fork_stream(st)));
-        CK(transpose_convert_bf16(w2, d, Di, w.w2_16, d, st));                                 // W2^T [Di, d]
         NtEpilogue e;
         e.mask = a1; e.scale = inv_keep;                   // a1 is stored post-dropout: a1 > 0 <=> ReLU active AND kept
-        CK(gemm_nt_bf16(w.dres16, w.w2_16, da1, 1, e, (int)rows, Di, d, d, d, Di, st));
+        CK(gemm_nt_bf16(w.dres16, c.w2T16, da1, 1, e, (int)rows, Di, d, d, d, Di, st));
         CK(gemm_tn_bf16(da1, h, g_w1, Di, d, (int)rows, Di, d, d, 1, fork_stream(st), g_b1));   // g_b1 = column sums of da1, fused
-        CK(transpose_convert_bf16(w1, Di, d, w.w1_16, Di, st));                                // W1^T [d, Di]
-        CK(gemm_nt_bf16(da1, w.w1_16, w.dh, 0, nullptr, (int)rows, d, Di, Di, Di, d, st));
+        CK(gemm_nt_bf16(da1, c.w1T16, w.dh, 0, nullptr, (int)rows, d, Di, Di, Di, d, st));
     } else {
         const float* a1 = static_cast<const float*>(c.a1);
         const float* h = static_cast<const float*>(c.h);

@@ -588,13 +588,15 @@ __global__ void dropout_apply_kernel(const float* __restrict__ in, long n, DropS
 
 // 32x32 tile transpose through LDS
 __global__ __launch_bounds__(256) void transpose_convert_kernel(const float* __restrict__ src, int R, int C,
-                                                                bf16_t* __restrict__ dst, long ldd) {
+                                                                bf16_t* __restrict__ dst, long ldd, bf16_t* __restrict__ plain) {
     __shared__ float tile[32][33];
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int i = ty; i < 32; i += 8) {
         const int r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < R && c < C) ? src[(long)r * C + c] : 0.f;
+        const float v = (r < R && c < C) ? src[(long)r * C + c] : 0.f;
+        tile[i][tx] = v;
+        if (plain && r < R && c < C) plain[(long)r * C + c] = f32_to_bf16(v);      // the untransposed bf16 copy from the same read
     }
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
@@ -862,9 +864,9 @@ int convert_bf16(const float* src, bf16_t* dst, long n, hipStream_t st) {
     return TTMI_OK;
 }
 
-int transpose_convert_bf16(const float* src, int R, int C, bf16_t* dst, long ldd, hipStream_t st) {
+int transpose_convert_bf16(const float* src, int R, int C, bf16_t* dst, long ldd, hipStream_t st, bf16_t* plain) {
     TTMI_REQUIRE(src && dst && R > 0 && C > 0 && ldd >= R, "transpose_convert_bf16: bad arguments");
-    hipLaunchKernelGGL(transpose_convert_kernel, dim3(cdiv(C, 32), cdiv(ldd, 32)), dim3(256), 0, st, src, R, C, dst, ldd);
+    hipLaunchKernelGGL(transpose_convert_kernel, dim3(cdiv(C, 32), cdiv(ldd, 32)), dim3(256), 0, st, src, R, C, dst, ldd, plain);
     TTMI_LAUNCH_CHECK("transpose_convert_kernel");
     return TTMI_OK;
 }
