@@ -821,6 +821,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                          (!p.addend || (reinterpret_cast<size_t>(p.addend) & 15) == 0) &&
                          (!p.mask || (reinterpret_cast<size_t>(p.mask) & 7) == 0) && (!p.bias || (reinterpret_cast<size_t>(p.bias) & 15) == 0);
         const int wrow = lane & 15, wq = lane >> 4;
+        const bool plain8 = vec && p.ldc % 8 == 0 && !p.addend && !p.relu && !p.mask && p.drop.p <= 0.f;
         // the slab loop stays rolled (one copy of the epilogue code); the accumulators are picked by a wave-uniform switch so that
         // they are never indexed dynamically (which would put all 128 of them in scratch)
 #define V8_SLAB(I) case I: _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) \
@@ -828,6 +829,32 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
 #pragma unroll 1
         for (int mi = 0; mi < 8; ++mi) {
             switch (mi) { V8_SLAB(0) V8_SLAB(1) V8_SLAB(2) V8_SLAB(3) V8_SLAB(4) V8_SLAB(5) V8_SLAB(6) V8_SLAB(7) }
+            if (sizeof(TC) == 2 && plain8) {
+                // bf16 output with the plain (bias-only) epilogue: 8 columns per lane, one 16-byte store - 8 rows x 128 B per instruction
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int r = q * 8 + (lane >> 3);
+                    const int c8 = lane & 7;
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(img + r * 256 + (((2 * c8) ^ r) << 4));
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(img + r * 256 + (((2 * c8 + 1) ^ r) << 4));
+                    const int m = cbm + wr * 128 + mi * 16 + r;
+                    const int n0 = cbn + wc * 64 + c8 * 8;
+                    if (m < p.M && n0 + 7 < p.N) {
+                        float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        if (p.bias) {
+                            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n0), b1 = *reinterpret_cast<const float4*>(p.bias + n0 + 4);
+                            bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+                        }
+                        uint4 o;
+                        o.x = pack_bf16x2(x0[0] + bv[0], x0[1] + bv[1]); o.y = pack_bf16x2(x0[2] + bv[2], x0[3] + bv[3]);
+                        o.z = pack_bf16x2(x1[0] + bv[4], x1[1] + bv[5]); o.w = pack_bf16x2(x1[2] + bv[6], x1[3] + bv[7]);
+                        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(C) + (long)m * p.ldc + n0) = o;
+                    } else {
+                        epi_store4<TC>(p, C, m, n0, x0, vec);
+                        epi_store4<TC>(p, C, m, n0 + 4, x1, vec);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = q * 4 + (lane >> 4);                    // row of the 16-row slab
@@ -836,6 +863,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                 const int m = cbm + wr * 128 + mi * 16 + r;
                 const int n0 = cbn + wc * 64 + c * 4;
                 epi_store4<TC>(p, C, m, n0, x, vec);
+            }
             }
         }
     }
@@ -967,18 +995,46 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p) {
         const bool vec = (p.ldc % 4 == 0) && ((reinterpret_cast<size_t>(p.C) & 15) == 0) &&
                          (!p.addend || (reinterpret_cast<size_t>(p.addend) & 15) == 0) &&
                          (!p.mask || (reinterpret_cast<size_t>(p.mask) & 7) == 0) && (!p.bias || (reinterpret_cast<size_t>(p.bias) & 15) == 0);
+        const bool plain8 = vec && p.ldc % 8 == 0 && !p.addend && !p.relu && !p.mask && p.drop.p <= 0.f;
         const int wrow = lane & 15, wq = lane >> 4;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
                 *reinterpret_cast<f32x4*>(img + wrow * 256 + (((ni * 4 + wq) ^ wrow) << 4)) = acc[mi][ni];
+            if (sizeof(TC) == 2 && plain8) {
+                // bf16 output, bias-only epilogue: 8 columns per lane, one 16-byte store (8 rows x 128 B per instruction)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int r = q * 8 + (lane >> 3);
+                    const int c8 = lane & 7;
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(img + r * 256 + (((2 * c8) ^ r) << 4));
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(img + r * 256 + (((2 * c8 + 1) ^ r) << 4));
+                    const int m = cbm + wr * 64 + mi * 16 + r;
+                    const int n0 = cbn + wc * 64 + c8 * 8;
+                    if (m < p.M && n0 + 7 < p.N) {
+                        float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        if (p.bias) {
+                            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n0), b1 = *reinterpret_cast<const float4*>(p.bias + n0 + 4);
+                            bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+                        }
+                        uint4 o;
+                        o.x = pack_bf16x2(x0[0] + bv[0], x0[1] + bv[1]); o.y = pack_bf16x2(x0[2] + bv[2], x0[3] + bv[3]);
+                        o.z = pack_bf16x2(x1[0] + bv[4], x1[1] + bv[5]); o.w = pack_bf16x2(x1[2] + bv[6], x1[3] + bv[7]);
+                        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(C) + (long)m * p.ldc + n0) = o;
+                    } else {
+                        epi_store4<TC>(p, C, m, n0, x0, vec);
+                        epi_store4<TC>(p, C, m, n0 + 4, x1, vec);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = q * 4 + (lane >> 4);
                 const int c = (lane & 15) ^ r;
                 const f32x4 x = *reinterpret_cast<const f32x4*>(img + r * 256 + ((lane & 15) << 4));
                 epi_store4<TC>(p, C, cbm + wr * 64 + mi * 16 + r, cbn + wc * 64 + c * 4, x, vec);
+            }
             }
         }
     }
