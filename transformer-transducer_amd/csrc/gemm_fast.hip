@@ -639,6 +639,54 @@ __device__ __forceinline__ void epi_store4(const FP& p, TC* C, int m, int n0, f3
     }
 }
 
+// the vector path of epi_store4 without the store: bias, residual, ReLU, mask, dropout on 4 consecutive columns (caller guarantees the
+// alignment conditions of `vec`, m < M and n0 + 3 < N)
+__device__ __forceinline__ void epi_math4(const FP& p, int m, int n0, f32x4 x, float (&v)[4]) {
+    const long ci = (long)m * p.ldc + n0;
+    v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+    if (p.bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+    }
+    if (p.addend) {
+        const float4 a = *reinterpret_cast<const float4*>(p.addend + ci);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+    }
+    if (p.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    if (p.mask) {
+        const uint2 mk = *reinterpret_cast<const uint2*>(p.mask + ci);
+        const unsigned short ms[4] = {(unsigned short)(mk.x & 0xffff), (unsigned short)(mk.x >> 16),
+                                      (unsigned short)(mk.y & 0xffff), (unsigned short)(mk.y >> 16)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float mv = bf16_to_f32(ms[j]);
+            v[j] = p.mask_mode ? v[j] * (1.f - mv * mv) : (mv > 0.f ? v[j] * p.scale : 0.f);
+        }
+    }
+    if (p.drop.p > 0.f) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= drop_mult(p.drop, (unsigned long long)(ci + j));
+    }
+}
+
+// bf16 output, 8 consecutive columns of row m from two image chunks: one 16-byte store on the aligned interior, epi_store4 twice otherwise
+__device__ __forceinline__ void epi_store8_bf16(const FP& p, bf16_t* C, int m, int n0, f32x4 x0, f32x4 x1, bool vec) {
+    if (m < p.M && n0 + 7 < p.N) {
+        float a[4], b[4];
+        epi_math4(p, m, n0, x0, a);
+        epi_math4(p, m, n0 + 4, x1, b);
+        uint4 o;
+        o.x = pack_bf16x2(a[0], a[1]); o.y = pack_bf16x2(a[2], a[3]); o.z = pack_bf16x2(b[0], b[1]); o.w = pack_bf16x2(b[2], b[3]);
+        *reinterpret_cast<uint4*>(C + (long)m * p.ldc + n0) = o;
+    } else {
+        epi_store4<bf16_t>(p, C, m, n0, x0, vec);
+        epi_store4<bf16_t>(p, C, m, n0 + 4, x1, vec);
+    }
+}
+
 // =====================================================================================================================
 // v8: persistent 256x256x64 kernel, one 512-thread workgroup per CU, 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 = 8 x 4
 // v_mfma_f32_16x16x32_bf16 tiles (128 accumulator registers), 2 x 64 KiB operand buffers + 32 KiB epilogue staging in LDS.
@@ -821,7 +869,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                          (!p.addend || (reinterpret_cast<size_t>(p.addend) & 15) == 0) &&
                          (!p.mask || (reinterpret_cast<size_t>(p.mask) & 7) == 0) && (!p.bias || (reinterpret_cast<size_t>(p.bias) & 15) == 0);
         const int wrow = lane & 15, wq = lane >> 4;
-        const bool plain8 = vec && p.ldc % 8 == 0 && !p.addend && !p.relu && !p.mask && p.drop.p <= 0.f;
+        const bool plain8 = vec && p.ldc % 8 == 0;       // bf16 rows in 16-byte pieces (any epilogue)
         // the slab loop stays rolled (one copy of the epilogue code); the accumulators are picked by a wave-uniform switch so that
         // they are never indexed dynamically (which would put all 128 of them in scratch)
 #define V8_SLAB(I) case I: _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) \
@@ -830,29 +878,15 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
         for (int mi = 0; mi < 8; ++mi) {
             switch (mi) { V8_SLAB(0) V8_SLAB(1) V8_SLAB(2) V8_SLAB(3) V8_SLAB(4) V8_SLAB(5) V8_SLAB(6) V8_SLAB(7) }
             if (sizeof(TC) == 2 && plain8) {
-                // bf16 output with the plain (bias-only) epilogue: 8 columns per lane, one 16-byte store - 8 rows x 128 B per instruction
+                // bf16 output: 8 columns per lane, one 16-byte store - 8 rows x 128 B per instruction
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int r = q * 8 + (lane >> 3);
                     const int c8 = lane & 7;
                     const f32x4 x0 = *reinterpret_cast<const f32x4*>(img + r * 256 + (((2 * c8) ^ r) << 4));
                     const f32x4 x1 = *reinterpret_cast<const f32x4*>(img + r * 256 + (((2 * c8 + 1) ^ r) << 4));
-                    const int m = cbm + wr * 128 + mi * 16 + r;
-                    const int n0 = cbn + wc * 64 + c8 * 8;
-                    if (m < p.M && n0 + 7 < p.N) {
-                        float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        if (p.bias) {
-                            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n0), b1 = *reinterpret_cast<const float4*>(p.bias + n0 + 4);
-                            bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
-                        }
-                        uint4 o;
-                        o.x = pack_bf16x2(x0[0] + bv[0], x0[1] + bv[1]); o.y = pack_bf16x2(x0[2] + bv[2], x0[3] + bv[3]);
-                        o.z = pack_bf16x2(x1[0] + bv[4], x1[1] + bv[5]); o.w = pack_bf16x2(x1[2] + bv[6], x1[3] + bv[7]);
-                        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(C) + (long)m * p.ldc + n0) = o;
-                    } else {
-                        epi_store4<TC>(p, C, m, n0, x0, vec);
-                        epi_store4<TC>(p, C, m, n0 + 4, x1, vec);
-                    }
+                    if constexpr (sizeof(TC) == 2)
+                        epi_store8_bf16(p, reinterpret_cast<bf16_t*>(C), cbm + wr * 128 + mi * 16 + r, cbn + wc * 64 + c8 * 8, x0, x1, vec);
                 }
             } else {
 #pragma unroll
@@ -995,37 +1029,24 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p) {
         const bool vec = (p.ldc % 4 == 0) && ((reinterpret_cast<size_t>(p.C) & 15) == 0) &&
                          (!p.addend || (reinterpret_cast<size_t>(p.addend) & 15) == 0) &&
                          (!p.mask || (reinterpret_cast<size_t>(p.mask) & 7) == 0) && (!p.bias || (reinterpret_cast<size_t>(p.bias) & 15) == 0);
-        const bool plain8 = vec && p.ldc % 8 == 0 && !p.addend && !p.relu && !p.mask && p.drop.p <= 0.f;
+        const bool plain8 = vec && p.ldc % 8 == 0;       // bf16 rows in 16-byte pieces (any epilogue)
         const int wrow = lane & 15, wq = lane >> 4;
-#pragma unroll
+        // rolled slab loop with a wave-uniform switch over the accumulators (one copy of the epilogue code, no dynamic register indexing)
+#define V9_SLAB(I) case I: _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) \
+            *reinterpret_cast<f32x4*>(img + wrow * 256 + (((ni * 4 + wq) ^ wrow) << 4)) = acc[I][ni]; break;
+#pragma unroll 1
         for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-                *reinterpret_cast<f32x4*>(img + wrow * 256 + (((ni * 4 + wq) ^ wrow) << 4)) = acc[mi][ni];
+            switch (mi) { V9_SLAB(0) V9_SLAB(1) V9_SLAB(2) V9_SLAB(3) }
             if (sizeof(TC) == 2 && plain8) {
-                // bf16 output, bias-only epilogue: 8 columns per lane, one 16-byte store (8 rows x 128 B per instruction)
+                // bf16 output: 8 columns per lane, one 16-byte store (8 rows x 128 B per instruction)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int r = q * 8 + (lane >> 3);
                     const int c8 = lane & 7;
                     const f32x4 x0 = *reinterpret_cast<const f32x4*>(img + r * 256 + (((2 * c8) ^ r) << 4));
                     const f32x4 x1 = *reinterpret_cast<const f32x4*>(img + r * 256 + (((2 * c8 + 1) ^ r) << 4));
-                    const int m = cbm + wr * 64 + mi * 16 + r;
-                    const int n0 = cbn + wc * 64 + c8 * 8;
-                    if (m < p.M && n0 + 7 < p.N) {
-                        float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        if (p.bias) {
-                            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n0), b1 = *reinterpret_cast<const float4*>(p.bias + n0 + 4);
-                            bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
-                        }
-                        uint4 o;
-                        o.x = pack_bf16x2(x0[0] + bv[0], x0[1] + bv[1]); o.y = pack_bf16x2(x0[2] + bv[2], x0[3] + bv[3]);
-                        o.z = pack_bf16x2(x1[0] + bv[4], x1[1] + bv[5]); o.w = pack_bf16x2(x1[2] + bv[6], x1[3] + bv[7]);
-                        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(C) + (long)m * p.ldc + n0) = o;
-                    } else {
-                        epi_store4<TC>(p, C, m, n0, x0, vec);
-                        epi_store4<TC>(p, C, m, n0 + 4, x1, vec);
-                    }
+                    if constexpr (sizeof(TC) == 2)
+                        epi_store8_bf16(p, reinterpret_cast<bf16_t*>(C), cbm + wr * 64 + mi * 16 + r, cbn + wc * 64 + c8 * 8, x0, x1, vec);
                 }
             } else {
 #pragma unroll
@@ -1038,6 +1059,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p) {
             }
         }
     }
+#undef V9_SLAB
 #undef V9_BAR
 }
 
