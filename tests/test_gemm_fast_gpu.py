@@ -131,7 +131,8 @@ def test_persistent_256x128_kernel_exact(M, N, K, pad, cdt):
         assert bool((Cfull[:, N:] == 5.0).all())
 
 
-@pytest.mark.parametrize("M,N,K", [(1024, 1024, 32768), (1124, 1024, 40000), (2048, 1024, 33001), (4334, 1024, 65600)])
+@pytest.mark.parametrize("M,N,K", [(1024, 1024, 32768), (1124, 1024, 40000), (2048, 1024, 33001), (4334, 1024, 65600),
+                                   (1349, 2048, 34048), (1024, 1536, 32768)])
 def test_persistent_256_wgrad_kernel_exact(M, N, K):
     """TN v8 (huge-reduction wgrad: persistent 256x256, transposed LDS reads, K-ranges per XCD, atomics, fused column sums via an
     all-ones MFMA) + the 128x128 kernel on the M % 256 strip: exact on small integers, K tail, with and without column sums"""
@@ -150,10 +151,10 @@ def test_persistent_256_wgrad_kernel_exact(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,cs", [(512, 512, 16000, False), (1536, 512, 16000, False), (2048, 512, 16000, True), (512, 2048, 16000, False),
-                                      (256, 1024, 4096, False), (1024, 512, 8192, True)])
+                                      (256, 1024, 4096, False), (1024, 512, 8192, True), (512, 1024, 8192, True), (768, 2048, 6400, True)])
 def test_persistent_256x128_wgrad_kernel_exact(M, N, K, cs):
     """TN v9 (encoder wgrads: persistent 256x128, transposed LDS reads, three stages, K-range items per XCD, atomics, all-ones-MFMA column
-    sums when there are exactly 4 column tiles): exact on small integers, accumulating into a non-zero C"""
+    sums from column tiles 0..3 when there are at least 4): exact on small integers, accumulating into a non-zero C"""
     from ttmi import ops
     g = torch.Generator(device="cuda").manual_seed(M + N)
     A, B = _ints((K, M), g), _ints((K, N), g)

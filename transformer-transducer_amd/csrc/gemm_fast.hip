@@ -1226,7 +1226,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         cs = f32x4{0.f, 0.f, 0.f, 0.f};
-        cs_unit = CS ? __builtin_amdgcn_readfirstlane((tn & 3) * 4 + wc) : -1;
+        cs_unit = CS && tn < 4 ? __builtin_amdgcn_readfirstlane(tn * 4 + wc) : -1;     // column tiles 0..3 share the 16 pieces
         const int cnk = nk;
         if (cnk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1283,7 +1283,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
                 }
             }
 #undef TN8_SLAB
-            if (CS && lane < 16) {
+            if (CS && cunit >= 0 && lane < 16) {
                 const int m = cbm + (cunit >> 3) * 128 + wr * 64 + ((cunit >> 1) & 3) * 16 + lane;
                 if (m < p.M) atomicAdd(p.colsum + m, cs[0]);
             }
@@ -1300,7 +1300,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
 // vmcnt(6)).  A stage = A [64 k][256 m] (512-byte k-rows, 32 staging units of 2 k-rows) | B [64 k][128 n] (256-byte k-rows, 16
 // units of 4 k-rows).  Work = TN v8's item list: the reduction is cut into 8*S ranges, XCD x owns S of them, its workgroups
 // walk (range, tile) items; f32 atomics into C; optional column sums of A from one extra all-ones MFMA per wave and K-tile
-// (needs tiles_n == 4: the 4 column tiles x 2 wave columns that read the same A rows share its 8 (16-row tile, k-half) pieces).
+// (needs tiles_n >= 4: column tiles 0..3 x 2 wave columns that read the same A rows share its 8 (16-row tile, k-half) pieces).
 // The 128x128 kernel this replaces spent 150 of its 221 us per layer in the main loops (4 workgroups per CU, single-buffered).
 // =====================================================================================================================
 template <bool CS>
@@ -1389,7 +1389,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v9_kernel(const FP p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         cs = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int cs_unit = CS ? __builtin_amdgcn_readfirstlane((tn & 3) * 2 + wc) : -1;     // (mt, ks) = (unit >> 1, unit & 1)
+        const int cs_unit = CS && tn < 4 ? __builtin_amdgcn_readfirstlane(tn * 2 + wc) : -1;     // (mt, ks) = (unit >> 1, unit & 1); column tiles 0..3 share the 8 pieces
         const int cnk = nk;
         if (cnk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1464,7 +1464,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v9_kernel(const FP p) {
                     if (m < p.M && n < p.N) atomicAdd(C + (long)m * p.ldc + n, v);
                 }
             }
-            if (CS && lane < 16) {
+            if (CS && cunit >= 0 && lane < 16) {
                 const int m = cbm + wr * 64 + (cunit >> 1) * 16 + lane;
                 if (m < p.M) atomicAdd(p.colsum + m, cs[0]);
             }
@@ -1624,7 +1624,7 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
     }
     // encoder-sized wgrad: persistent 256x128 kernel when its tiles fill the output exactly and the reduction is long enough
     const bool tn9 = (g_gemm_fast_version == 4 || g_gemm_fast_version == 9) && nbatch == 1 && accumulate && K % TK == 0 && K >= 4096 && K < 32768 &&
-                     M % T9M == 0 && N % T9N == 0 && (!colsum_a || N / T9N == 4) && (long)(M / T9M) * (N / T9N) >= 8;
+                     M % T9M == 0 && N % T9N == 0 && (!colsum_a || N / T9N >= 4) && (long)(M / T9M) * (N / T9N) >= 8;
     if (tn9) {
         p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
         p.tiles_m = M / T9M; p.tiles_n = N / T9N;
@@ -1647,7 +1647,7 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
     }
     // huge-reduction wgrad (the joint projection: K = B*T*U1 rows): persistent 256x256 kernel on the 256-row tiles that are
     // full, the 128x128 kernel below on the remaining M % 256 rows
-    const bool tn8 = nbatch == 1 && accumulate && K % TK == 0 && N >= 256 && N % 256 == 0 && (!colsum_a || N / 256 == 4) &&
+    const bool tn8 = nbatch == 1 && accumulate && K % TK == 0 && N >= 256 && N % 256 == 0 && (!colsum_a || N / 256 >= 4) &&
                      ((g_gemm_fast_version == 4 && K >= 32768 && M >= 1024) || (g_gemm_fast_version == 8 && K >= 2048 && M >= 256));
     if (tn8) {
         if (g_num_cus == 0) {
