@@ -27,6 +27,7 @@ import torch.distributed as dist
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 MFMA_F32_PEAK_TFLOPS = 157.3
+HBM_PEAK_GBS = 8000.0               # HBM3E, MI355X_MICROARCH.md
 
 
 def c2_config(n_enc=12, n_dec=6):
@@ -82,6 +83,27 @@ def cpu_baseline(model, feats, proj, targets, T, U, n_utt, gpu_costs):
     return n_utt / dt, dt, rel
 
 
+def decode_mode(args):
+    """single GPU: tools/bench_decode.run (product path) + the oracle's frame-by-frame greedy loop on the host as checker and CPU baseline"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_decode
+    prec = "fp32" if "--precision" not in sys.argv else args.precision      # token parity is an fp32 claim
+    out, model, inputs, lens, hyps = bench_decode.run(8, args.T, args.emit_rate, prec)
+    if not args.no_cpu_baseline:
+        from oracle import tt_oracle as O
+        n = args.cpu_utts
+        sd = {k: v.detach().float().cpu().numpy() for k, v in model.state_dict().items()}
+        x = inputs[:n].float().cpu().numpy()
+        t0 = time.perf_counter()
+        ref = O.recognize(x, lens[:n], sd)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(n / dt, 4), "unit": "utt/s", "cores": _blas_threads(), "kind": "port",
+                               "sample": "%d utterance(s), oracle/tt_oracle.py recognize (frame-by-frame loop), %.1f s" % (n, dt)}
+        out["tokens_identical_to_oracle"] = [r == h for r, h in zip(ref, hyps)]
+        out["oracle_symbols"] = [len(r) for r in ref]
+    print(json.dumps(out), flush=True)
+
+
 def _blas_threads():
     """threads the oracle's BLAS calls actually use (threadpoolctl), else the CPUs this process may run on"""
     try:
@@ -112,7 +134,12 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c2", "c4-band", "c4-chunk", "c5"],
                     help="c2 = BASELINE configs[1] (headline, default); c4-* = streaming model configs[3]; c5 = configs[4] "
                          "long-utterance stress (T=2000 U=200 batch 8)")
+    ap.add_argument("--mode", default="train", choices=["train", "decode"],
+                    help="train = the metric (default); decode = greedy decode of the C2 model (SURVEY §8 A10) with the oracle's loop beside it")
+    ap.add_argument("--emit-rate", type=float, default=0.1, help="decode mode: fraction of frames that emit a symbol (blank bias is set for it)")
     args = ap.parse_args()
+    if args.mode == "decode":
+        return decode_mode(args)
     os.environ["TTMI_PRECISION"] = args.precision
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -189,7 +216,9 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if rank == 0:                                     # the probes are read after the timed region: no host sync inside it
-        probe_ms = [ops.probe_read_ms(i % 64) for i in range(max(0, args.steps - 64), args.steps)]
+        slots = [i % 64 for i in range(max(0, args.steps - 64), args.steps)]
+        probe_ms = [ops.probe_read_ms(i) for i in slots]
+        loss_ms = [(ops.probe_read_ms(i, 1), ops.probe_read_ms(i, 2)) for i in slots]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -208,6 +237,20 @@ def main():
         if os.path.exists(pmc) and args.workload == "c2" and (B, T, U) == (32, 500, 50) and args.precision == "bf16":
             j = json.load(open(pmc))
             traffic = (2.0 * j["fetch_size_kb"] + j["write_size_kb"]) * 1024.0
+        # the RNN-T loss op at the API boundary: logits read once, gradient written once, alpha / beta / lp_blank / lp_label in f32
+        es = 2 if args.precision == "bf16" else 4
+        loss_bytes = B * (2.0 * es * T * U1 * V + 16.0 * T * U1)
+        lf = float(np.mean([a for a, b in loss_ms if a > 0 and b > 0])) if loss_ms else float("nan")
+        lb = float(np.mean([b for a, b in loss_ms if a > 0 and b > 0])) if loss_ms else float("nan")
+        loss_gbs = loss_bytes / ((lf + lb) * 1e-3) / 1e9
+        roof_joint = {"bound": "mfma", "kernel": "gemm_nt_bf16_v8_kernel (joint vocabulary projection, M=%d N=%d K=%d)" % (B * T * U1, V, J),
+                      "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                      "traffic": traffic, "kernel_ms": round(k_ms, 4)}
+        roof_loss = {"bound": "hbm", "kernel": "RNN-T loss op: rnnt_lse_kernel + rnnt_alphabeta_kernel (%.3f ms) + rnnt_grad_kernel (%.3f ms), "
+                                               "logits [%d,%d,%d,%d] %s" % (lf, lb, B, T, U1, V, "bf16" if es == 2 else "f32"),
+                     "achieved": round(loss_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(loss_gbs / HBM_PEAK_GBS, 4),
+                     "traffic": None, "kernel_ms": round(lf + lb, 4)}
+        lattice_run = args.workload == "c5"             # BASELINE configs[4] is the lattice's HBM-roofline run: the loss op is its dominant-kernel line
         out = {
             "metric": "utterances/sec (fwd+bwd) on 80-d fbank T=%d U=%d" % (T, U), "value": round(utt_s, 3), "unit": "utt/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
@@ -220,9 +263,8 @@ def main():
                                    ", T=%d U=%d, batch %d/GPU, dropout 0.1, SGD momentum + clip 200" % (T, U, B),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
             "host_enqueue_ms_per_step": round(1e3 * enqueue / args.steps, 3), "model_tflops": round(flops_per_utt(cfg, T, U1) * utt_s / 1e12, 2),
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_v8_kernel (joint vocabulary projection, M=%d N=%d K=%d)" % (B * T * U1, V, J),
-                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                         "traffic": traffic, "kernel_ms": round(k_ms, 4)},
+            "roofline": roof_loss if lattice_run else roof_joint,
+            "roofline_joint" if lattice_run else "roofline_loss": roof_joint if lattice_run else roof_loss,
             "final_loss": round(float(last), 4),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -116,8 +116,10 @@ int ttmi_adam_step(float* p, const float* g, float* m, float* v, long n, float l
 
 /* ---- bring-up / measurement helpers ------------------------------------------------------------------------------
  * generic MFMA GEMM (every layout / dtype / epilogue; flags = GemmFlags of csrc/gemm.h) and the two throughput
- * kernels; HIP-event probes recorded on the launch stream around the joint vocabulary projection: ttmi_probe_arm(i), 0 <= i < 64,
- * makes the NEXT such launch record into event pair i; ttmi_probe_read_ms(i) waits for pair i and returns its duration. */
+ * kernels; HIP-event probes recorded on the launch stream at three points (0 = joint vocabulary projection, 1 = ttmi_rnnt_loss_fwd's
+ * kernels, 2 = ttmi_rnnt_loss_bwd's kernel): ttmi_probe_arm(i), 0 <= i < 64, makes the NEXT launch at every point record into its event
+ * pair i; ttmi_probe_point_read_ms(point, i) waits for that pair and returns its duration in ms (< 0: never fired);
+ * ttmi_probe_read_ms(i) = point 0. */
 int ttmi_gemm(const void* A, const void* B, void* C, const float* bias, const float* aux, int a_dtype, int b_dtype,
               int c_dtype, int M, int N, int K, long lda, long ldb, long ldc, int nz1, int nz2, long sA1, long sA2,
               long sB1, long sB2, long sC1, long sC2, float alpha, float beta, int flags, int splitk, void* stream);
@@ -127,11 +129,13 @@ int ttmi_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int 
                       float* colsum_a /* nullable: colsum_a[m] += sum_k A[k][m] */, void* stream);
 /* process-wide A/B switches for measurements: key 0: 1 = no fused attention kernels; 1: throughput-GEMM generation (csrc/gemm_fast.hip);
  * 2: flash-kernel timing bits; 3: 0 = no side-stream wgrad fork; 4: split-K workgroup target; 5: 1 = position-term slab by batched GEMM;
- * 6: n = CUs the encoder-sized persistent GEMMs leave free for communication kernels that run beside backward (data-parallel runs) */
+ * 6: n = CUs the encoder-sized persistent GEMMs leave free for communication kernels that run beside backward (data-parallel runs);
+ * 7: exact-f32 products with at most n rows use the skinny 32x32 split-reduction kernel (default 128, 0 = never: greedy decode A/B) */
 int ttmi_set_option(int key, int value);
 int ttmi_dropout_apply(const float* in, long n, float p, unsigned seed, float* out, void* stream);
 int ttmi_probe_arm(int slot);
 float ttmi_probe_read_ms(int slot);
+float ttmi_probe_point_read_ms(int point, int slot);
 
 #ifdef __cplusplus
 }

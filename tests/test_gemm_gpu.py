@@ -111,3 +111,33 @@ def test_linearity_large():
     assert float(err) < 1e-5
     ref = A1.double() @ W.double().t()      # torch fp64 matmul as an independent check of one product
     assert float((out[0].double() - ref).norm() / ref.norm()) < 2e-6
+
+
+@pytest.mark.parametrize("b_k", [True, False])
+@pytest.mark.parametrize("M,N,K", [(1, 1536, 512), (64, 4334, 1024), (7, 33, 9), (128, 512, 1030), (33, 64, 64), (50, 42, 3)])
+def test_skinny_f32_exact_integers(M, N, K, b_k):
+    """the decoder-sized exact-f32 kernel (M <= 128, 32x32 tile, reduction split over 4 waves, operands straight from global memory):
+    integer operands are exact, so any lane-map / k-pairing / tail error shows bit-for-bit; same numbers with the kernel switched off"""
+    from ttmi import ops
+    got, want = _run(M, N, K, True, b_k, False, seed=99)
+    assert np.array_equal(got, want.astype(np.float32))
+    ops.set_option(7, 0)
+    try:
+        got2, _ = _run(M, N, K, True, b_k, False, seed=99)
+    finally:
+        ops.set_option(7, 128)
+    assert np.array_equal(got2, got)
+
+
+def test_skinny_f32_epilogues_and_batches():
+    from ttmi import ops
+    got, want = _run(100, 70, 40, True, True, False, flags_extra=ops.GEMM_BIAS | ops.GEMM_RELU, seed=11)
+    assert rel_err(got, want) < 2e-6
+    got, want = _run(100, 70, 41, True, False, False, flags_extra=ops.GEMM_MASK_AUX, seed=12)
+    assert rel_err(got, want) < 2e-6
+    got, want = _run(65, 70, 40, True, True, False, beta=1.0, alpha=0.5, seed=13)
+    assert rel_err(got, want) < 2e-6
+    got, want = _run(51, 51, 64, True, True, False, nz=(2, 8), seed=14)           # per-head score products of a 51-token history
+    assert rel_err(got, want) < 2e-6
+    got, want = _run(51, 64, 51, True, False, False, nz=(1, 8), seed=15)          # per-head P.V (B stored [K, N])
+    assert rel_err(got, want) < 2e-6

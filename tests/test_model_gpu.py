@@ -242,6 +242,30 @@ def test_blocked_greedy_decode_matches_frame_by_frame():
         assert model.recognize(x, torch.tensor(lens)) == want
 
 
+def test_full_size_greedy_decode_tokens_vs_oracle():
+    """BASELINE configs[1] model (12 / 6 layers, d_model 512, V = 4334, random init under seed 1) with a blank bias that lets about
+    15 % of the frames emit: `recognize` gives the oracle's frame-by-frame token lists (tt/model.py:70-108) exactly, including
+    histories longer than the label encoder's table (L > K = 42 needs > 41 symbols: the second utterance runs 400 frames)"""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bench_decode
+    prev = os.environ.get("TTMI_PRECISION")
+    try:
+        out, model, inputs, lens, _ = bench_decode.run(utts=2, T=400, emit_rate=0.15, precision="fp32")
+    finally:
+        if prev is None:
+            os.environ.pop("TTMI_PRECISION", None)
+        else:
+            os.environ["TTMI_PRECISION"] = prev
+    lens = [150, 400]
+    with torch.no_grad():
+        hyp = model.recognize(inputs, torch.tensor(lens))
+    sd = {k: v.detach().float().cpu().numpy() for k, v in model.state_dict().items()}
+    ref = O.recognize(inputs.float().cpu().numpy(), lens, sd)
+    assert len(ref[1]) > 42 and len(ref[0]) < 150
+    assert hyp == ref
+
+
 @pytest.mark.parametrize("J,V,B,T,U1", [(512, 200, 2, 37, 9), (1024, 130, 2, 37, 9), (80, 48, 2, 37, 9), (1024, 1500, 4, 400, 21)])
 def test_bf16_joint_wide_inner_dims_vs_torch(J, V, B, T, U1, monkeypatch):
     """the 8-column tanh / (t,u)-reduction kernels (J = 512, 1024) and the 4-column ones (other J) of the bf16 joint: logits

@@ -33,3 +33,5 @@ struct GemmDesc {
 
 // returns 0 / <0 invalid / >0 hipError_t
 int ttmi_launch_gemm(const GemmDesc& d, hipStream_t st);
+// f32 products (A K-major, f32 C, no atomics) with at most `rows` rows use the 32x32-tile split-reduction kernel (default 128; 0 = never)
+void ttmi_gemm_set_skinny_rows(int rows);

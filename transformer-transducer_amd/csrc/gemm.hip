@@ -280,6 +280,92 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const KParams p) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Skinny exact-f32 GEMM (M <= 128 rows, A K-major): the greedy decoder runs the label encoder on ONE history of L tokens and
+// the joint on a block of <= 64 frames, so every product has a handful of rows.  The 128x128 kernel above spends its whole
+// K loop (K/16 barrier-separated steps of one workgroup per 128 columns) on a mostly empty tile: 67 us per launch, 88 % of a
+// decode step.  Here a workgroup owns a 32 x 32 output tile and its 4 waves split the reduction: wave w takes the 8-wide
+// k-chunks w, w+4, ...; operands go straight from global memory (L2-resident at these sizes) into the MFMA registers - lane
+// (r = lane & 31, g = lane >> 5) loads 4 consecutive k of row r at chunk offset 4g, MFMA c of the chunk consumes component c
+// of both operands (any pairing of k indices is a valid reduction order as long as A and B agree) - then the four partial
+// tiles meet in LDS in a fixed order (deterministic) and all 256 threads run the epilogue with row-contiguous stores.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int SK_T = 32, SK_PITCH = 33;
+
+template <bool BKM>
+__global__ __launch_bounds__(NT) void gemm_skinny_f32_kernel(const KParams p) {
+    __shared__ float red[4][SK_T][SK_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, g = lane >> 5;
+    const int bm = blockIdx.y * SK_T, bn = blockIdx.x * SK_T;
+    const int z = blockIdx.z, z1 = z / p.nz2, z2 = z % p.nz2;
+    const float* A = reinterpret_cast<const float*>(p.A) + z1 * p.sA1 + z2 * p.sA2;
+    const float* B = reinterpret_cast<const float*>(p.B) + z1 * p.sB1 + z2 * p.sB2;
+    float* Cp = reinterpret_cast<float*>(p.C) + z1 * p.sC1 + z2 * p.sC2;
+    // rows / columns beyond the matrix are clamped for the loads and never stored
+    const float* arow = A + (long)min(bm + r, p.M - 1) * p.lda;
+    const int ncol = min(bn + r, p.N - 1);
+    const float* brow = BKM ? B + (long)ncol * p.ldb : B + ncol;
+    const int nchunk = (p.K + 7) >> 3;
+
+    auto load_a = [&](int k) { return load4<float>(arow + k, p.K - k, p.vecA); };
+    auto load_b = [&](int k) {
+        if constexpr (BKM) {
+            return load4<float>(brow + k, p.K - k, p.vecB);
+        } else {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < p.K) v.x = brow[(long)k * p.ldb];
+            if (k + 1 < p.K) v.y = brow[(long)(k + 1) * p.ldb];
+            if (k + 2 < p.K) v.z = brow[(long)(k + 2) * p.ldb];
+            if (k + 3 < p.K) v.w = brow[(long)(k + 3) * p.ldb];
+            return v;
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    constexpr int UN = 4;                                  // chunks in flight per wave: 8 float4 loads, then 16 MFMAs
+    for (int c0 = wave; c0 < nchunk; c0 += 4 * UN) {
+        float4 av[UN], bv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int k = (c0 + 4 * u) * 8 + 4 * g;        // chunks past the end load zeros (nvalid <= 0)
+            av[u] = load_a(k);
+            bv[u] = load_b(k);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, bv[u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].w, bv[u].w, acc, 0, 0, 0);
+        }
+    }
+    // C/D map of the 32x32 MFMA: col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave][(i & 3) + 8 * (i >> 2) + 4 * g][r] = acc[i];
+    __syncthreads();
+
+    const float* bias = (p.flags & GEMM_BIAS) ? p.bias + z1 * p.sBias1 + z2 * p.sBias2 : nullptr;
+    const float* aux = (p.flags & GEMM_MASK_AUX) ? p.aux + z1 * p.sC1 + z2 * p.sC2 : nullptr;
+#pragma unroll
+    for (int i = 0; i < SK_T * SK_T / NT; ++i) {
+        const int idx = tid + NT * i, row = idx >> 5, col = idx & 31;
+        const int m = bm + row, n = bn + col;
+        if (m >= p.M || n >= p.N) continue;
+        const long ci = (long)m * p.ldc + n;
+        float v = p.alpha * (((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col]);
+        if (bias) v += bias[n];
+        if (p.beta != 0.f) v += p.beta * Cp[ci];
+        if (p.flags & GEMM_RELU) v = fmaxf(v, 0.f);
+        if (aux) v = aux[ci] > 0.f ? v : 0.f;
+        v *= drop_mult(p.drop, (unsigned long long)ci);
+        Cp[ci] = v;
+    }
+}
+
+
 template <typename SA, typename SB, typename TC, bool AK, bool BKM, bool BF16C>
 int launch_t(const KParams& p, dim3 grid, hipStream_t st) {
     const size_t lds = 4 * Cfg<BF16C>::TILE_BYTES;
@@ -298,6 +384,9 @@ int launch_layout(const KParams& p, dim3 grid, hipStream_t st) {
 }
 
 }  // namespace
+
+static int g_skinny_rows = 128;     // f32 products with at most this many rows go to gemm_skinny_f32_kernel (0 = never)
+void ttmi_gemm_set_skinny_rows(int rows) { g_skinny_rows = rows < 0 ? 0 : rows; }
 
 int ttmi_launch_gemm(const GemmDesc& d, hipStream_t st) {
     TTMI_REQUIRE(d.A && d.B && d.C, "gemm: null operand");
@@ -327,6 +416,14 @@ int ttmi_launch_gemm(const GemmDesc& d, hipStream_t st) {
     };
     p.vecA = vec_ok(d.A, ea, d.lda, d.sA1, d.sA2);
     p.vecB = vec_ok(d.B, eb, d.ldb, d.sB1, d.sB2);
+    if (!bf16c && g_skinny_rows > 0 && d.M <= g_skinny_rows && (d.flags & GEMM_A_KMAJOR) && !(d.flags & GEMM_ATOMIC) && d.splitk == 1 &&
+        d.c_dtype == DT_F32 && d.K > 0 && (long)d.nz1 * d.nz2 <= 65535) {
+        dim3 sgrid(cdiv(d.N, SK_T), cdiv(d.M, SK_T), d.nz1 * d.nz2);
+        if (d.flags & GEMM_B_KMAJOR) hipLaunchKernelGGL(gemm_skinny_f32_kernel<true>, sgrid, dim3(NT), 0, st, p);
+        else hipLaunchKernelGGL(gemm_skinny_f32_kernel<false>, sgrid, dim3(NT), 0, st, p);
+        TTMI_LAUNCH_CHECK("gemm_skinny_f32_kernel");
+        return TTMI_OK;
+    }
     dim3 grid(cdiv(d.N, BN), cdiv(d.M, BM), d.nz1 * d.nz2 * d.splitk);
     TTMI_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large (M tiles %u, batch %u)", grid.y, grid.z);
     const int key = (bf16c ? 8 : 0) | (d.a_dtype << 2) | (d.b_dtype << 1) | d.c_dtype;

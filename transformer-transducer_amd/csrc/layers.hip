@@ -732,8 +732,9 @@ int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float*
 // process-wide switches for A/B measurements.  key 0: 1 = disable the fused attention kernels (bf16 pipeline only);
 // key 1: throughput-GEMM generation (see gemm_fast.hip); key 2: flash-kernel timing switches; key 3: 0 = no wgrad fork
 int ttmi_set_option(int key, int value) {
-    TTMI_REQUIRE(key >= 0 && key <= 6, "set_option: unknown key %d", key);
+    TTMI_REQUIRE(key >= 0 && key <= 7, "set_option: unknown key %d", key);
     if (key == 6) { gemm_fast_set_reserved_cus(value); return TTMI_OK; }
+    if (key == 7) { ttmi_gemm_set_skinny_rows(value); return TTMI_OK; }
     if (key == 4) { gemm_fast_set_tn_target(value); return TTMI_OK; }
     if (key == 5) { g_gemm_slab = value & 1; relpos_slab_set_debug(value >> 1); return TTMI_OK; }
     if (key == 0) g_disable_fused_attention = value;

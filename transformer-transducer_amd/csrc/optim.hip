@@ -114,43 +114,46 @@ int ttmi_adam_step(float* p, const float* g, float* m, float* v, long n, float l
     return TTMI_OK;
 }
 
-// ---- timing probes: HIP events recorded on the launch stream around one named kernel launch ----------------
-// slot 0 = joint vocabulary projection GEMM (forward).  Events are owned by the library.
-// The probe point (slot argument of begin/end; only 0 = joint vocabulary projection exists) records into whichever of the 64
-// event pairs was armed last, so a timing loop can arm pair i in step i and read them all after its final fence - no host
-// synchronisation inside the timed region.
-constexpr int NPROBE = 64;
-static hipEvent_t g_probe[NPROBE][2];
-static int g_probe_state[NPROBE];     // 0 idle, 1 armed, 2 recorded
+// ---- timing probes: HIP events recorded on the launch stream around named launches --------------------------
+// Probe points: 0 = joint vocabulary projection GEMM (forward), 1 = RNN-T loss forward (log-sum-exp pass + lattice), 2 = RNN-T loss
+// backward (gradient pass).  Events are owned by the library.  Every point records into whichever of the 64 event pairs was armed
+// last, so a timing loop can arm pair i in step i and read them all after its final fence - no host synchronisation inside the
+// timed region.
+constexpr int NPROBE = 64, NPOINT = 3;
+static hipEvent_t g_probe[NPOINT][NPROBE][2];
+static int g_probe_state[NPOINT][NPROBE];     // 0 idle, 1 armed, 2 recorded
 static int g_probe_cur = -1;
 
 int ttmi_probe_arm(int slot) {
     TTMI_REQUIRE(slot >= 0 && slot < NPROBE, "probe: bad slot");
-    if (!g_probe[slot][0]) {
-        (void)hipEventCreate(&g_probe[slot][0]);
-        (void)hipEventCreate(&g_probe[slot][1]);
+    for (int pt = 0; pt < NPOINT; ++pt) {
+        if (!g_probe[pt][slot][0]) {
+            (void)hipEventCreate(&g_probe[pt][slot][0]);
+            (void)hipEventCreate(&g_probe[pt][slot][1]);
+        }
+        g_probe_state[pt][slot] = 1;
     }
-    g_probe_state[slot] = 1;
     g_probe_cur = slot;
     return TTMI_OK;
 }
 // blocks until the stop event has completed; returns elapsed milliseconds (or <0 if the probe never fired)
-float ttmi_probe_read_ms(int slot) {
-    if (slot < 0 || slot >= NPROBE || !g_probe[slot][0] || g_probe_state[slot] != 2) return -1.f;
+float ttmi_probe_point_read_ms(int point, int slot) {
+    if (point < 0 || point >= NPOINT || slot < 0 || slot >= NPROBE || !g_probe[point][slot][0] || g_probe_state[point][slot] != 2) return -1.f;
     float ms = -1.f;
-    (void)hipEventSynchronize(g_probe[slot][1]);
-    (void)hipEventElapsedTime(&ms, g_probe[slot][0], g_probe[slot][1]);
-    g_probe_state[slot] = 0;
+    (void)hipEventSynchronize(g_probe[point][slot][1]);
+    (void)hipEventElapsedTime(&ms, g_probe[point][slot][0], g_probe[point][slot][1]);
+    g_probe_state[point][slot] = 0;
     return ms;
 }
+float ttmi_probe_read_ms(int slot) { return ttmi_probe_point_read_ms(0, slot); }
 }
 
-void ttmi_probe_begin(int, hipStream_t st) {
-    if (g_probe_cur >= 0 && g_probe_state[g_probe_cur] == 1) (void)hipEventRecord(g_probe[g_probe_cur][0], st);
+void ttmi_probe_begin(int pt, hipStream_t st) {
+    if (g_probe_cur >= 0 && g_probe_state[pt][g_probe_cur] == 1) (void)hipEventRecord(g_probe[pt][g_probe_cur][0], st);
 }
-void ttmi_probe_end(int, hipStream_t st) {
-    if (g_probe_cur >= 0 && g_probe_state[g_probe_cur] == 1) {
-        (void)hipEventRecord(g_probe[g_probe_cur][1], st);
-        g_probe_state[g_probe_cur] = 2;
+void ttmi_probe_end(int pt, hipStream_t st) {
+    if (g_probe_cur >= 0 && g_probe_state[pt][g_probe_cur] == 1) {
+        (void)hipEventRecord(g_probe[pt][g_probe_cur][1], st);
+        g_probe_state[pt][g_probe_cur] = 2;
     }
 }

@@ -395,6 +395,9 @@ Ws carve(void* ws, int B, int T, int U1) {
 
 }  // namespace
 
+void ttmi_probe_begin(int point, hipStream_t st);      // optim.hip: HIP-event timing probes (point 1 = loss forward, 2 = loss backward)
+void ttmi_probe_end(int point, hipStream_t st);
+
 extern "C" {
 
 // bytes of caller-provided workspace shared by ttmi_rnnt_loss_fwd / _bwd
@@ -419,6 +422,7 @@ int ttmi_rnnt_loss_fwd(const void* logits, int dtype, long ldv, const int* label
     const long rows = (long)B * T * U1;
     const size_t es = dtype == 0 ? 4 : 2;
     const int vec_ok = ((reinterpret_cast<uintptr_t>(logits) % es) == 0) ? 1 : 0;
+    ttmi_probe_begin(1, st);
     if (dtype == 0)
         hipLaunchKernelGGL(rnnt_lse_kernel<float>, dim3(cdiv(rows, LSE_WAVES)), dim3(LSE_WAVES * 64), 0, st,
                            static_cast<const float*>(logits), ldv, labels, act_lens, label_lens, B, T, U1, V, blank, vec_ok,
@@ -433,6 +437,7 @@ int ttmi_rnnt_loss_fwd(const void* logits, int dtype, long ldv, const int* label
     else if (U1 <= 256) launch_alphabeta<4, 4>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
     else if (U1 <= 512) launch_alphabeta<8, 2>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
     else launch_alphabeta<16, 1>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
+    ttmi_probe_end(1, st);
     TTMI_LAUNCH_CHECK("rnnt_alphabeta_kernel");
     return TTMI_OK;
 }
@@ -455,6 +460,7 @@ int ttmi_rnnt_loss_bwd(const void* logits, int dtype, long ldv, const int* label
     // vector path needs logits and grad rows to share their 16-byte phase
     const int vec_ok = ((reinterpret_cast<uintptr_t>(logits) % 16) == (reinterpret_cast<uintptr_t>(grad) % 16) &&
                         ((ldv - ldg) * (long)es) % 16 == 0 && (reinterpret_cast<uintptr_t>(logits) % es) == 0) ? 1 : 0;
+    ttmi_probe_begin(2, st);
     if (dtype == 0)
         hipLaunchKernelGGL(rnnt_grad_kernel<float>, dim3(cdiv(rows, LSE_WAVES)), dim3(LSE_WAVES * 64), 0, st,
                            static_cast<const float*>(logits), ldv, labels, act_lens, label_lens, B, T, U1, V, blank, vec_ok,
@@ -463,6 +469,7 @@ int ttmi_rnnt_loss_bwd(const void* logits, int dtype, long ldv, const int* label
         hipLaunchKernelGGL(rnnt_grad_kernel<bf16_t>, dim3(cdiv(rows, LSE_WAVES)), dim3(LSE_WAVES * 64), 0, st,
                            static_cast<const bf16_t*>(logits), ldv, labels, act_lens, label_lens, B, T, U1, V, blank, vec_ok,
                            w.lse, w.alpha, w.beta, w.ll, grad_out, grad_out_stride, scale, static_cast<bf16_t*>(grad), ldg);
+    ttmi_probe_end(2, st);
     TTMI_LAUNCH_CHECK("rnnt_grad_kernel");
     return TTMI_OK;
 }

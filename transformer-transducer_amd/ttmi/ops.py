@@ -302,10 +302,11 @@ def probe_arm(slot=0):
     check(lib().ttmi_probe_arm(c_int(slot)), "ttmi_probe_arm")
 
 
-def probe_read_ms(slot=0):
-    f = lib().ttmi_probe_read_ms
+def probe_read_ms(slot=0, point=0):
+    """duration of probe `point` (0 joint projection, 1 RNN-T loss forward, 2 RNN-T loss backward) armed in `slot`; < 0 = never fired"""
+    f = lib().ttmi_probe_point_read_ms
     f.restype = ctypes.c_float
-    return float(f(c_int(slot)))
+    return float(f(c_int(point), c_int(slot)))
 
 
 # ----------------------------------------------------------------------------- throughput bf16 GEMMs (tests / tools)
