@@ -638,6 +638,15 @@ int ttmi_ffn_bwd(const float* dz, const float* y, const float* w1, const float* 
 // the vocabulary projection / its dgrad / its wgrad run on the glds-staged kernels of gemm_fast.hip; logits rows
 // have pitch ldv >= V (callers use a multiple of 64) and dlogits must be zero in columns [V, ldv).
 static inline bool joint_fast(int prec, int J) { return prec == 1 && J % 8 == 0; }
+static inline size_t al8(size_t n) { return (n + 7) & ~(size_t)7; }
+// forward_layer (the 2d -> J input layer) on the throughput kernels: training-sized batches whose bf16 operand copies fit in the
+// free part of the first workspace region (see ttmi_joint_fwd / _bwd); everything else keeps the generic kernel
+static inline bool joint_input_fast(int prec, int B, int T, int U1, int de, int dd, int J) {
+    if (!joint_fast(prec, J) || de % 8 || dd % 8 || (long)B * T < 1024) return false;
+    const size_t M = (size_t)B * T * U1, din = (size_t)de + dd;
+    const size_t need = al8((size_t)B * T * de) + al8((size_t)B * U1 * dd) + al8((size_t)B * T * J) + al8((size_t)B * U1 * J) + al8(din * J) + 8;
+    return need <= (size_t)M * J;                           // bf16 elements behind dH16 (backward); the forward pass needs less
+}
 // dtype of the logits this configuration produces / expects: 0 = f32, 1 = bf16
 int ttmi_joint_logits_dtype(int prec, int J) { return joint_fast(prec, J) ? 1 : 0; }
 
@@ -659,8 +668,21 @@ int ttmi_joint_fwd(const float* enc, const float* dec, const float* wf, const fl
     float* PD = PE + al4((size_t)B * T * J);
     const int din = de + dd;
     const int M = B * T * U1;
-    CK(ttmi_launch_gemm(mk(enc, wf, PE, B * T, J, de, de, din, J, NT_, prec), st));
-    CK(ttmi_launch_gemm(mk(dec, wf + de, PD, B * U1, J, dd, dd, din, J, NT_, prec), st));
+    if (joint_input_fast(prec, B, T, U1, de, dd, J)) {
+        // forward_layer on the throughput kernels: bf16 copies of the encoder states and of [We | Wd] live in the first workspace
+        // region (dH's, unused in the forward pass); same operand rounding as the generic kernel's convert-while-staging
+        bf16_t* enc16 = reinterpret_cast<bf16_t*>(ws);
+        bf16_t* dec16 = enc16 + al8((size_t)B * T * de);
+        bf16_t* Wf16 = dec16 + al8((size_t)B * U1 * dd);
+        CK(convert_bf16(enc, enc16, (long)B * T * de, st));
+        CK(convert_bf16(dec, dec16, (long)B * U1 * dd, st));
+        CK(convert_bf16(wf, Wf16, (long)J * din, st));
+        CK(gemm_nt_bf16(enc16, Wf16, PE, 0, nullptr, B * T, J, de, de, din, J, st));
+        CK(gemm_nt_bf16(dec16, Wf16 + de, PD, 0, nullptr, B * U1, J, dd, dd, din, J, st));
+    } else {
+        CK(ttmi_launch_gemm(mk(enc, wf, PE, B * T, J, de, de, din, J, NT_, prec), st));
+        CK(ttmi_launch_gemm(mk(dec, wf + de, PD, B * U1, J, dd, dd, din, J, NT_, prec), st));
+    }
     if (!fast) {
         float* Hh = ctx;
         CK(joint_tanh_fwd(PE, PD, bf, B, T, U1, J, Hh, 0, st));
@@ -720,6 +742,26 @@ int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float*
         CK(gemm_nt_bf16(dZ, WpT16, dH16, 1, e, M, J, (int)ldg, ldg, ldg, J, st));
         CK(fill_zero(dPD, sizeof(float) * (size_t)B * U1 * J, st));
         CK(joint_tanh_bwd(dH16, nullptr, 1, B, T, U1, J, dPE, dPD, st));
+    }
+    if (joint_input_fast(prec, B, T, U1, de, dd, J)) {
+        // forward_layer's backward on the throughput kernels; the bf16 operands sit behind dH16 in the first workspace region
+        // (M*J floats hold M*J bf16 of dH16 + as many again); g_bf = column sums of dPE come out of the enc wgrad launch
+        bf16_t* enc16 = reinterpret_cast<bf16_t*>(ws) + al8((size_t)M * J);
+        bf16_t* dec16 = enc16 + al8((size_t)B * T * de);
+        bf16_t* dPE16 = dec16 + al8((size_t)B * U1 * dd);
+        bf16_t* dPD16 = dPE16 + al8((size_t)B * T * J);
+        bf16_t* WfT16 = dPD16 + al8((size_t)B * U1 * J);                       // [din, J] = [We | Wd]^T
+        CK(convert_bf16(enc, enc16, (long)B * T * de, st));
+        CK(convert_bf16(dec, dec16, (long)B * U1 * dd, st));
+        CK(convert_bf16(dPE, dPE16, (long)B * T * J, st));
+        CK(convert_bf16(dPD, dPD16, (long)B * U1 * J, st));
+        CK(transpose_convert_bf16(wf, J, din, WfT16, J, st));
+        CK(gemm_tn_bf16(dPE16, enc16, g_wf, J, de, B * T, J, de, din, 1, fork_stream(st), g_bf));
+        CK(gemm_tn_bf16(dPD16, dec16, g_wf + de, J, dd, B * U1, J, dd, din, 1, fork_stream(st)));
+        CK(gemm_nt_bf16(dPE16, WfT16, denc, 0, nullptr, B * T, de, J, J, J, de, st));
+        CK(gemm_nt_bf16(dPD16, WfT16 + (size_t)de * J, ddec, 0, nullptr, B * U1, dd, J, J, J, dd, st));
+        join_stream(st);
+        return TTMI_OK;
     }
     CK(colsum(dPE, J, (long)B * T, J, 1, 1, 0, 0, 0, 0, g_bf, st));
     CK(wgrad(dPE, enc, g_wf, J, de, B * T, J, de, din, prec, st));
