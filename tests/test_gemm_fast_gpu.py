@@ -109,6 +109,27 @@ def test_persistent_256_kernel_exact(M, N, K, pad, cdt):
         assert bool((Cfull[:, N:] == 5.0).all())
 
 
+@pytest.mark.parametrize("M,N,K,pad", [(1024, 256, 128, 0), (1024, 256, 192, 0), (2048, 260, 320, 4), (5000, 4334, 1024, 18), (3000, 1024, 4352, 0),
+                                       (70000, 1100, 512, 0)])
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_four_wave_256_kernel_exact(M, N, K, pad, cdt):
+    """v10 (the measured alternative to v8, selectable with option 1 = 10: 4 waves x 128x128 wave tiles, accumulators pinned to AGPRs,
+    five 32-deep LDS stages, hand-laid step): exact on small integers for 4..136 K-steps, ragged M/N, padded pitch"""
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + 1)
+    A, B = _ints((M, K), g), _ints((N, K), g)
+    bias = torch.randint(-3, 4, (N,), device="cuda", generator=g).float()
+    Cfull = torch.full((M, N + pad), 5.0, device="cuda", dtype=cdt)
+    ops.set_option(1, 10)
+    try:
+        ops.gemm_nt_bf16(A, B, Cfull[:, :N], bias)
+    finally:
+        ops.set_option(1, 4)
+    assert torch.equal(Cfull[:, :N], (A.float() @ B.float().t() + bias).to(cdt))
+    if pad:
+        assert bool((Cfull[:, N:] == 5.0).all())
+
+
 @pytest.mark.parametrize("M,N,K,pad", [(1024, 128, 64, 0), (1024, 256, 128, 0), (1024, 384, 192, 4), (16000, 512, 512, 0),
                                        (16000, 1536, 512, 0), (3001, 700, 320, 3), (16000, 2048, 2048, 0), (1025, 129, 1024, 0),
                                        (50000, 512, 256, 0), (3001, 700, 72, 3)])

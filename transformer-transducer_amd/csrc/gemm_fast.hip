@@ -21,6 +21,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+#ifndef V10_SCHED
+#define V10_SCHED 1
+#endif
 constexpr int TM = 128, TN_ = 128, TK = 64, NTH = 256;
 constexpr int TILE_B = 128 * 64 * 2;        // 16 KiB per operand tile
 constexpr int GROUP_M = 8;
@@ -907,6 +910,204 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
 }
 
 // =====================================================================================================================
+// v10: the v8 problem (persistent 256x256 output tiles, joint-sized GEMMs) on FOUR waves (2 x 2) with 128 x 128 wave tiles:
+// 8 x 8 v_mfma_f32_16x16x32_bf16 tiles = 256 accumulator registers per lane (AGPRs; one wave per SIMD).  v8's 128 x 64 wave
+// tiles read (128 + 64) x 64 x 2 B of fragments per wave and K-tile: 8 waves x 24 KiB + 64 KiB of staging = 256 KiB through
+// a 128 B/cycle LDS port = 2048 cycles, exactly the 2048 cycles the MFMAs of the same K-tile need - v8 is LDS-bound.  Here
+// 4 waves x 32 KiB + 64 KiB = 192 KiB = 1536 cycles.  The vendor library's assembly kernel for these shapes has the same
+// macro tile / wave tile (MT256x256x64, 4 waves) and runs the joint forward 8 % faster than v8.
+// K-step = 32 (one MFMA depth): five 32 KiB LDS stages (A 256 rows x 64 B | B 256 rows x 64 B, 16-byte slot q of row r holds
+// source chunk q ^ (-(r >> 2) & 3): a fragment = 16 rows x 64 B, conflict-free for ds_read_b128's four 16-lane groups
+// {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... - the plain (r >> 2) & 3 swizzle is 2-way conflicted on them), staged by global_load_lds four steps ahead.
+// Step s, every wave:  [8 global_load_lds of step s+4] [16 ds_read_b128 = fragments of step s+1 into the other register set]
+// [64 MFMAs on step s]  s_waitcnt lgkmcnt(0); every second step: vmcnt(8), s_barrier.   One barrier per 128 MFMAs; with a single wave per SIMD the
+// overlap of LDS reads / DMA issue with the MFMAs is the in-order issue of independent instructions between MFMAs.
+// =====================================================================================================================
+constexpr int T10 = 256, NTH10 = 256, KS10 = 32, HALF10 = 256 * KS10 * 2, STG10 = 2 * HALF10;
+constexpr int NST10 = 5, LDS10 = NST10 * STG10;      // the epilogue's images live in stage 4 (free between tiles)
+
+template <typename TC, int DBG = 0>
+__global__ __launch_bounds__(NTH10, 1) void gemm_nt_bf16_v10_kernel(const FP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int ns = p.K / KS10;                                  // K % 64 == 0 (launcher): even, >= 4
+
+    auto tile_id = [&](int it) { return (long)it * gridDim.x + (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3); };
+    auto coords = [&](long id, int& bm, int& bn) {
+        const int per_group = GROUP_M * p.tiles_n;
+        const int group = (int)(id / per_group), in = (int)(id % per_group);
+        const int first = group * GROUP_M;
+        const int gsz = min(p.tiles_m - first, GROUP_M);
+        bm = (first + in % gsz) * T10;
+        bn = (in / gsz) * T10;
+    };
+    // staging: wave w fills rows w*64 .. w*64+63 of both operands, instruction j rows rho = w*64 + j*16 + (lane >> 2), slot lane & 3,
+    // which must hold source chunk (lane & 3) ^ (-(rho >> 2) & 3) = (lane & 3) ^ (-(lane >> 4) & 3)
+    unsigned oA[4], oB[4];
+    const char* baseA = nullptr;
+    const char* baseB = nullptr;
+    const int kc = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
+    auto sources = [&](int bm, int bn) {
+        baseA = reinterpret_cast<const char*>(p.A + (long)bm * p.lda);
+        baseB = reinterpret_cast<const char*>(p.B + (long)bn * p.ldb);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rho = wave * 64 + j * 16 + (lane >> 2);
+            const int ra = min(rho, p.M - 1 - bm), rb = min(rho, p.N - 1 - bn);
+            oA[j] = (unsigned)(((long)ra * p.lda + kc * 8) * 2);
+            oB[j] = (unsigned)(((long)rb * p.ldb + kc * 8) * 2);
+        }
+    };
+    auto stage = [&](int s) {
+        char* dst = smem + (s % NST10) * STG10 + wave * 4096;
+        const char* ba = baseA + (long)s * (KS10 * 2);
+        const char* bb = baseB + (long)s * (KS10 * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(ba + oA[j], dst + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(bb + oB[j], dst + HALF10 + j * 1024);
+    };
+    auto prologue = [&]() { stage(0); stage(1); stage(2); stage(3); };
+
+    // fragment t of A: rows wr*128 + t*16 + (lane & 15), chunk lane >> 4 at slot (lane >> 4) ^ (-(lane >> 2) & 3)
+    const int fsw = ((lane >> 4) ^ ((0 - (lane >> 2)) & 3)) << 4;
+    const int aoff = (wr * 128 + (lane & 15)) * 64 + fsw;
+    const int boff = HALF10 + (wc * 128 + (lane & 15)) * 64 + fsw;
+    // The accumulators are pinned to AGPRs and the step is laid out by hand (inline asm): left to the register allocator the 256
+    // accumulators and 128 fragment registers get mixed across both files and every MFMA drags v_accvgpr moves along (1.04 PFLOP/s
+    // at 8192^3 against v8's 1.49).  Order inside a step: 16 groups of [DMA issue (every other group) | one ds_read_b128 of the
+    // next step's fragments | 4 MFMAs of this step].
+    f32x4 acc[8][8];
+    bf16x8 af[2][8], bfr[2][8];
+    const unsigned lds0 = (unsigned)(size_t)smem;              // LDS byte offset = low half of the flat shared address
+#define V10_DSREAD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define V10_MFMA(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
+    auto step = [&](int s, int cur, auto full) {
+        constexpr bool FULL = decltype(full)::value;
+        const bool st = !(DBG & 2) && (FULL || s + 4 < ns), rd = !(DBG & 1) && (FULL || s + 1 < ns);
+        const unsigned fa = lds0 + ((s + 1) % NST10) * STG10 + aoff, fb = lds0 + ((s + 1) % NST10) * STG10 + boff;
+        char* dst = smem + ((s + 4) % NST10) * STG10 + wave * 4096;
+        const char* ba = baseA + (long)(s + 4) * (KS10 * 2);
+        const char* bb = baseB + (long)(s + 4) * (KS10 * 2);
+        const int nx = cur ^ 1;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            if (st && (g & 1) == 0) {
+                const int j = g >> 1;
+                if (j < 4) glds16(ba + oA[j], dst + j * 1024);
+                else glds16(bb + oB[j - 4], dst + HALF10 + (j - 4) * 1024);
+            }
+            if (rd && g < 8) {                                  // both operands' fragment g: all reads are out by mid-step
+                switch (g) {
+                    case 0: V10_DSREAD(af[nx][0], fa, 0); V10_DSREAD(bfr[nx][0], fb, 0); break;
+                    case 1: V10_DSREAD(af[nx][1], fa, 1024); V10_DSREAD(bfr[nx][1], fb, 1024); break;
+                    case 2: V10_DSREAD(af[nx][2], fa, 2048); V10_DSREAD(bfr[nx][2], fb, 2048); break;
+                    case 3: V10_DSREAD(af[nx][3], fa, 3072); V10_DSREAD(bfr[nx][3], fb, 3072); break;
+                    case 4: V10_DSREAD(af[nx][4], fa, 4096); V10_DSREAD(bfr[nx][4], fb, 4096); break;
+                    case 5: V10_DSREAD(af[nx][5], fa, 5120); V10_DSREAD(bfr[nx][5], fb, 5120); break;
+                    case 6: V10_DSREAD(af[nx][6], fa, 6144); V10_DSREAD(bfr[nx][6], fb, 6144); break;
+                    default: V10_DSREAD(af[nx][7], fa, 7168); V10_DSREAD(bfr[nx][7], fb, 7168); break;
+                }
+            }
+#pragma unroll
+            for (int q = g * 4; q < g * 4 + 4; ++q) V10_MFMA(acc[q >> 3][q & 7], bfr[cur][q & 7], af[cur][q >> 3]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (cur == 1) {
+            // one barrier per TWO steps (128 MFMAs): with five stages the region a step overwrites was last read two steps earlier, i.e.
+            // before the previous barrier; the barrier publishes the DMA data of the next two steps (s+2, s+3 - only s+4 stays in flight)
+            if (st) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+    auto read0 = [&]() {                                       // fragments of step 0 into set 0 (tile start)
+        const unsigned fa = lds0 + aoff, fb = lds0 + boff;
+        V10_DSREAD(af[0][0], fa, 0); V10_DSREAD(af[0][1], fa, 1024); V10_DSREAD(af[0][2], fa, 2048); V10_DSREAD(af[0][3], fa, 3072);
+        V10_DSREAD(af[0][4], fa, 4096); V10_DSREAD(af[0][5], fa, 5120); V10_DSREAD(af[0][6], fa, 6144); V10_DSREAD(af[0][7], fa, 7168);
+        V10_DSREAD(bfr[0][0], fb, 0); V10_DSREAD(bfr[0][1], fb, 1024); V10_DSREAD(bfr[0][2], fb, 2048); V10_DSREAD(bfr[0][3], fb, 3072);
+        V10_DSREAD(bfr[0][4], fb, 4096); V10_DSREAD(bfr[0][5], fb, 5120); V10_DSREAD(bfr[0][6], fb, 6144); V10_DSREAD(bfr[0][7], fb, 7168);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+
+    const int rounds = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (rounds > 8) {                                   // per-XCD start stagger (see v8)
+        const int n = (ns >> 1) * (blockIdx.x & 7) * 5;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+    int bm = 0, bn = 0;
+    bool live = tile_id(0) < ntiles;
+    if (live) { coords(tile_id(0), bm, bn); sources(bm, bn); prologue(); }
+    for (int it = 0; it < rounds && live; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                 // steps 0, 1, 2 have landed (3 may be in flight)
+        __builtin_amdgcn_s_barrier();
+        read0();
+        int s = 0;
+        for (; s + 5 < ns; s += 2) {
+            step(s, 0, std::true_type());
+            step(s + 1, 1, std::true_type());
+        }
+        for (; s < ns; s += 2) {
+            step(s, 0, std::false_type());
+            step(s + 1, 1, std::false_type());
+        }
+
+        const int cbm = bm, cbn = bn;
+        live = tile_id(it + 1) < ntiles;
+        if (live) { coords(tile_id(it + 1), bm, bn); sources(bm, bn); prologue(); }
+
+        // epilogue: acc[mi][ni][j] = C[cbm + wr*128 + mi*16 + (lane & 15)][cbn + wc*128 + ni*16 + (lane >> 4)*4 + j]; 16 rows x 64 columns at a
+        // time through the wave's private f32 image (v8's layout: chunk c of row r at slot c ^ r)
+        TC* C = reinterpret_cast<TC*>(p.C);
+        char* img = smem + 4 * STG10 + wave * 8192;          // stage 4: not touched by the next tile's prologue (stages 0..3)
+        const bool vec = (p.ldc % 4 == 0) && ((reinterpret_cast<size_t>(p.C) & 15) == 0) &&
+                         (!p.addend || (reinterpret_cast<size_t>(p.addend) & 15) == 0) &&
+                         (!p.mask || (reinterpret_cast<size_t>(p.mask) & 7) == 0) && (!p.bias || (reinterpret_cast<size_t>(p.bias) & 15) == 0);
+        const int wrow = lane & 15, wq = lane >> 4;
+        const bool plain8 = vec && p.ldc % 8 == 0;
+#define V10_SLAB(I) case I: _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) \
+            *reinterpret_cast<f32x4*>(img + hf * 4096 + wrow * 256 + (((ni * 4 + wq) ^ wrow) << 4)) = acc[I][hf * 4 + ni]; break;
+#pragma unroll 1
+        for (int mi = 0; mi < 8; ++mi) {
+            switch (mi) { V10_SLAB(0) V10_SLAB(1) V10_SLAB(2) V10_SLAB(3) V10_SLAB(4) V10_SLAB(5) V10_SLAB(6) V10_SLAB(7) }
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const char* im = img + hf * 4096;
+                const int nb = cbn + wc * 128 + hf * 64;
+                if (sizeof(TC) == 2 && plain8) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int r = q * 8 + (lane >> 3);
+                        const int c8 = lane & 7;
+                        const f32x4 x0 = *reinterpret_cast<const f32x4*>(im + r * 256 + (((2 * c8) ^ r) << 4));
+                        const f32x4 x1 = *reinterpret_cast<const f32x4*>(im + r * 256 + (((2 * c8 + 1) ^ r) << 4));
+                        if constexpr (sizeof(TC) == 2)
+                            epi_store8_bf16(p, reinterpret_cast<bf16_t*>(C), cbm + wr * 128 + mi * 16 + r, nb + c8 * 8, x0, x1, vec);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = q * 4 + (lane >> 4);
+                        const int c = (lane & 15) ^ r;
+                        const f32x4 x = *reinterpret_cast<const f32x4*>(im + r * 256 + ((lane & 15) << 4));
+                        epi_store4<TC>(p, C, cbm + wr * 128 + mi * 16 + r, nb + c * 4, x, vec);
+                    }
+                }
+            }
+        }
+#undef V10_SLAB
+    }
+#undef V10_DSREAD
+#undef V10_MFMA
+}
+
+// =====================================================================================================================
 // v9: the v8 schedule for mid-sized outputs (the encoder GEMMs: 16000 rows x 512..2048 columns, K = 512..2048), where 256x256
 // tiles leave CUs idle.  Persistent, 256 (M) x 128 (N) x 64 tile, 8 waves as 4 x 2, wave tile 64 x 64 = 4 x 4 MFMA tiles (64
 // accumulator registers), THREE 48 KiB LDS stages and ONE phase per K-tile:
@@ -1547,6 +1748,32 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
             hipLaunchKernelGGL(gemm_nt_bf16_v9_kernel<bf16_t>, dim3((unsigned)grid9), dim3(NTH8), LDS9, st, p);
         }
         TTMI_LAUNCH_CHECK("gemm_nt_bf16_v9_kernel");
+        return TTMI_OK;
+    }
+    if (pers && N >= 256 && g_gemm_fast_version >= 10 && g_gemm_fast_version <= 13) {
+        p.tiles_m = cdiv(M, T10); p.tiles_n = cdiv(N, T10);
+        const long nwg10 = (long)p.tiles_m * p.tiles_n;
+        const int cus10 = nwg10 < 1024 ? std::max(8, (g_num_cus - g_reserved_cus) / 8 * 8) : g_num_cus;
+        const int grid10 = (int)((std::min<long>(nwg10, cus10) + 7) / 8 * 8);
+        if (c_dtype == 0) {
+            if (int rc = enable_lds(gemm_nt_bf16_v10_kernel<float>, LDS10)) return rc;
+            hipLaunchKernelGGL(gemm_nt_bf16_v10_kernel<float>, dim3((unsigned)grid10), dim3(NTH10), LDS10, st, p);
+        } else {
+            if (g_gemm_fast_version == 11) {
+                if (int rc = enable_lds(gemm_nt_bf16_v10_kernel<bf16_t, 1>, LDS10)) return rc;
+                hipLaunchKernelGGL((gemm_nt_bf16_v10_kernel<bf16_t, 1>), dim3((unsigned)grid10), dim3(NTH10), LDS10, st, p);
+            } else if (g_gemm_fast_version == 12) {
+                if (int rc = enable_lds(gemm_nt_bf16_v10_kernel<bf16_t, 2>, LDS10)) return rc;
+                hipLaunchKernelGGL((gemm_nt_bf16_v10_kernel<bf16_t, 2>), dim3((unsigned)grid10), dim3(NTH10), LDS10, st, p);
+            } else if (g_gemm_fast_version == 13) {
+                if (int rc = enable_lds(gemm_nt_bf16_v10_kernel<bf16_t, 3>, LDS10)) return rc;
+                hipLaunchKernelGGL((gemm_nt_bf16_v10_kernel<bf16_t, 3>), dim3((unsigned)grid10), dim3(NTH10), LDS10, st, p);
+            } else {
+            if (int rc = enable_lds(gemm_nt_bf16_v10_kernel<bf16_t>, LDS10)) return rc;
+            hipLaunchKernelGGL(gemm_nt_bf16_v10_kernel<bf16_t>, dim3((unsigned)grid10), dim3(NTH10), LDS10, st, p);
+            }
+        }
+        TTMI_LAUNCH_CHECK("gemm_nt_bf16_v10_kernel");
         return TTMI_OK;
     }
     // persistent 256x256 kernel: needs several rounds of tiles per CU to amortise its pipeline fill and tail
