@@ -265,7 +265,7 @@ def main():
             "host_enqueue_ms_per_step": round(1e3 * enqueue / args.steps, 3), "model_tflops": round(flops_per_utt(cfg, T, U1) * utt_s / 1e12, 2),
             "roofline": roof_loss if lattice_run else roof_joint,
             "roofline_joint" if lattice_run else "roofline_loss": roof_joint if lattice_run else roof_loss,
-            "final_loss": round(float(last), 4),
+            "final_loss": round(float(last.detach()), 4),
         }
         if world == 1 and not args.no_cpu_baseline:
             model.eval()
