@@ -174,8 +174,32 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restri
         for (int c = 0; c < 4; ++c) ag[k][c] = ab[k][c] = ac[k][c] = 0.f;
     }
     const float invd = 1.f / d;
-    for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
-        const float mu = mean[r], rs = rstd[r];
+    // the row loop is software-pipelined by hand: the loads of the wave's NEXT row are in flight while the current row goes through
+    // its two wave reductions and its stores (8 waves per CU at this grid cannot hide a row's latency chain on their own)
+    struct RowIn {
+        float4 a[KV], b[KV], e[KV];
+        float mu, rs;
+    };
+    const long stride = (long)gridDim.x * 4;
+    auto fetch = [&](long r, RowIn& in) {
+        const unsigned long long base = (unsigned long long)r * d;
+        in.mu = mean[r]; in.rs = rstd[r];
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const int c0 = k * 256 + lane * 4;
+            if (c0 < d) {
+                in.a[k] = *reinterpret_cast<const float4*>(dy + base + c0);
+                in.b[k] = *reinterpret_cast<const float4*>(s + base + c0);
+                if (dadd) in.e[k] = *reinterpret_cast<const float4*>(dadd + base + c0);
+            }
+        }
+    };
+    long r = (long)blockIdx.x * 4 + wave;
+    RowIn cur, nxt;
+    if (r < rows) fetch(r, cur);
+    for (; r < rows; r += stride) {
+        if (r + stride < rows) fetch(r + stride, nxt);
+        const float mu = cur.mu, rs = cur.rs;
         const unsigned long long base = (unsigned long long)r * d;
         float v[KV][4], xh[KV][4];
         float m1 = 0.f, m2 = 0.f;
@@ -183,7 +207,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restri
         for (int k = 0; k < KV; ++k) {
             const int c0 = k * 256 + lane * 4;
             if (c0 < d) {
-                const float4 a = *reinterpret_cast<const float4*>(dy + base + c0), b = *reinterpret_cast<const float4*>(s + base + c0);
+                const float4 a = cur.a[k], b = cur.b[k];
                 const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -210,7 +234,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restri
 #pragma unroll
                 for (int c = 0; c < 4; ++c) o[c] = rs * (v[k][c] * gam[k][c] - m1 - xh[k][c] * m2);
                 if (dadd) {
-                    const float4 e = *reinterpret_cast<const float4*>(dadd + base + c0);
+                    const float4 e = cur.e[k];
                     o[0] += e.x; o[1] += e.y; o[2] += e.z; o[3] += e.w;
                 }
                 *reinterpret_cast<float4*>(dx + base + c0) = make_float4(o[0], o[1], o[2], o[3]);
@@ -228,6 +252,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restri
                 }
             }
         }
+        cur = nxt;
     }
 #pragma unroll
     for (int k = 0; k < KV; ++k)
