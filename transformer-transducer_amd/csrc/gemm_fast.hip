@@ -39,6 +39,7 @@ struct FP {
     const float* addend;
     const bf16_t* mask;
     int mask_mode;
+    int nt;                                 // persistent kernels: 1 = streaming (nontemporal) 16-byte bf16 output stores
     int relu;
     float scale;
     DropSpec drop;
@@ -581,6 +582,7 @@ __global__ __launch_bounds__(NTH6, 1) void gemm_nt_bf16_v6_kernel(const FP p) {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // epilogue of the 256-wide kernels for 4 consecutive columns n0..n0+3 of row m: bias, residual addend, ReLU, mask (ReLU' or tanh'),
 // dropout, then one 16-byte (f32) / 8-byte (bf16) store (scalar fallback on ragged or unaligned edges)
 template <typename TC>
@@ -683,7 +685,11 @@ __device__ __forceinline__ void epi_store8_bf16(const FP& p, bf16_t* C, int m, i
         epi_math4(p, m, n0 + 4, x1, b);
         uint4 o;
         o.x = pack_bf16x2(a[0], a[1]); o.y = pack_bf16x2(a[2], a[3]); o.z = pack_bf16x2(b[0], b[1]); o.w = pack_bf16x2(b[2], b[3]);
-        *reinterpret_cast<uint4*>(C + (long)m * p.ldc + n0) = o;
+        // outputs far larger than the L2 (the joint's logits, 7 GB) leave as streaming stores: they would only evict the operand panels
+        // (joint forward 7.47 -> 7.2 ms)
+        // (the scope bits only hurt: sc1 / sc0 sc1 / sc1 nt / sc0 sc1 nt 7.8-7.9 ms against 7.65 plain and 7.3 nt on the same box)
+        if (p.nt) __builtin_nontemporal_store(u32x4{o.x, o.y, o.z, o.w}, reinterpret_cast<u32x4*>(C + (long)m * p.ldc + n0));
+        else *reinterpret_cast<uint4*>(C + (long)m * p.ldc + n0) = o;
     } else {
         epi_store4<bf16_t>(p, C, m, n0, x0, vec);
         epi_store4<bf16_t>(p, C, m, n0 + 4, x1, vec);
@@ -1688,6 +1694,7 @@ int enable_lds(K kernel, int bytes) {
 // Measured and dropped (same box, joint projection M=816000 N=4334 K=1024, v4 = 720 TFLOP/s): 256x128 3-stage ring with
 // counted vmcnt 621; persistent 256x256 with a 4-slice ring that never drains 668 (dgrad K=4352: 904 vs 938 for v6).
 int g_gemm_fast_version = 4;
+int g_nt_stores = 1;             // streaming stores for bf16 outputs >= 256 MB (set_version(14 / 15) = off / on, generation unchanged)
 int g_num_cus = 0;
 int g_reserved_cus = 0;           // ttmi_set_option(6, n): CUs the mid-sized persistent GEMMs leave to concurrently running communication kernels
 int g_tn_target_blocks = 512;     // split-K aims at this many workgroups for small outputs (ttmi_set_option(4, n))
@@ -1709,7 +1716,7 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     TTMI_REQUIRE(gemm_fast_nt_ok(A, B, C, M, N, K, lda, ldb), "gemm_nt_bf16: shape/alignment not supported (M=%d N=%d K=%d)", M,
                  N, K);
     FP p;
-    p.A = A; p.B = B; p.C = C; p.bias = epi.bias; p.addend = epi.addend; p.mask = epi.mask; p.mask_mode = epi.mask_mode; p.relu = epi.relu; p.scale = epi.scale; p.drop = epi.drop;
+    p.A = A; p.B = B; p.C = C; p.bias = epi.bias; p.addend = epi.addend; p.mask = epi.mask; p.mask_mode = epi.mask_mode; p.nt = (g_nt_stores && c_dtype == 1 && (long)M * ldc * 2 >= (256L << 20)) ? 1 : 0; p.relu = epi.relu; p.scale = epi.scale; p.drop = epi.drop;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.tiles_m = cdiv(M, TM); p.tiles_n = cdiv(N, TN_); p.splitk = 1; p.ksteps = cdiv(K, TK); p.atomic = 0; p.gm = GROUP_M; p.colsum = nullptr;
     p.A2 = epi.A2; p.B2 = epi.B2; p.K2 = epi.K2; p.lda2 = epi.lda2; p.ldb2 = epi.ldb2; p.sB1b = epi.sB1b; p.sB2b = epi.sB2b; p.colsum_mid = epi.colsum_mid;
@@ -1838,7 +1845,7 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
     TTMI_REQUIRE(gemm_fast_tn_ok(A, B, C, M, N, K, lda, ldb), "gemm_tn_bf16: shape/alignment not supported (M=%d N=%d K=%d)", M,
                  N, K);
     FP p;
-    p.A = A; p.B = B; p.C = C; p.bias = nullptr; p.addend = nullptr; p.mask = nullptr; p.mask_mode = 0; p.relu = 0; p.scale = 1.f; p.drop = DropSpec();
+    p.A = A; p.B = B; p.C = C; p.bias = nullptr; p.addend = nullptr; p.mask = nullptr; p.mask_mode = 0; p.nt = 0; p.relu = 0; p.scale = 1.f; p.drop = DropSpec();
     p.colsum = colsum_a;
     fill_batch(p, batch);
     const int nbatch = batch.nz1 * batch.nz2;
@@ -1944,7 +1951,10 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
     return TTMI_OK;
 }
 
-void gemm_fast_set_version(int v) { g_gemm_fast_version = v; }
+void gemm_fast_set_version(int v) {
+    if (v == 14 || v == 15) { g_nt_stores = v == 15; return; }
+    g_gemm_fast_version = v;
+}
 void gemm_fast_set_tn_target(int n) { g_tn_target_blocks = n; }
 void gemm_fast_set_reserved_cus(int n) { g_reserved_cus = n < 0 ? 0 : n; }
 

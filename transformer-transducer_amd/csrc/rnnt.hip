@@ -50,12 +50,15 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 __host__ __device__ __forceinline__ long diag_stride(int T, int U1) { return (long)(T + U1 - 1) * U1; }
 
 // ------------------------------------------------------------------ row access helpers (f32 or bf16 logits)
+typedef unsigned u32x4n __attribute__((ext_vector_type(4)));
 template <typename TL>
 struct Vec16 {                                   // one 16-byte access = NV elements
     static constexpr int NV = 16 / sizeof(TL);
     float f[NV];
     __device__ __forceinline__ void load(const TL* p) {
-        const uint4 w = *reinterpret_cast<const uint4*>(p);
+        // the logits / gradient stream through once per pass (7 - 56 GB): streaming accesses, nothing worth keeping in the L2
+        const u32x4n wn = __builtin_nontemporal_load(reinterpret_cast<const u32x4n*>(p));
+        const uint4 w = make_uint4(wn.x, wn.y, wn.z, wn.w);
         if constexpr (sizeof(TL) == 4) {
             f[0] = __uint_as_float(w.x); f[1] = __uint_as_float(w.y); f[2] = __uint_as_float(w.z); f[3] = __uint_as_float(w.w);
         } else {
@@ -75,7 +78,7 @@ struct Vec16 {                                   // one 16-byte access = NV elem
             w.x = pack_bf16x2(f[0], f[1]); w.y = pack_bf16x2(f[2], f[3]);
             w.z = pack_bf16x2(f[4], f[5]); w.w = pack_bf16x2(f[6], f[7]);
         }
-        *reinterpret_cast<uint4*>(p) = w;
+        __builtin_nontemporal_store(u32x4n{w.x, w.y, w.z, w.w}, reinterpret_cast<u32x4n*>(p));
     }
 };
 template <typename TL>
