@@ -719,7 +719,9 @@ __device__ __forceinline__ void epi_store8_bf16(const FP& p, bf16_t* C, int m, i
 constexpr int T8 = 256, NTH8 = 512, HT8 = 128 * 64 * 2, BUF8 = 4 * HT8;   // buffer: [A h0 | A h1 | B h0 | B h1]
 constexpr int LDS8 = 2 * BUF8 + 8 * 4096;
 
-template <typename TC>
+// LEAN: the instance for bias-only bf16 outputs (the joint forward): its epilogue carries no residual / mask / ReLU / dropout code, which
+// costs the main loop registers in the general instance
+template <typename TC, bool LEAN = false>
 __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -886,7 +888,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
 #pragma unroll 1
         for (int mi = 0; mi < 8; ++mi) {
             switch (mi) { V8_SLAB(0) V8_SLAB(1) V8_SLAB(2) V8_SLAB(3) V8_SLAB(4) V8_SLAB(5) V8_SLAB(6) V8_SLAB(7) }
-            if (sizeof(TC) == 2 && plain8) {
+            if (LEAN || (sizeof(TC) == 2 && plain8)) {
                 // bf16 output: 8 columns per lane, one 16-byte store - 8 rows x 128 B per instruction
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
@@ -894,10 +896,26 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                     const int c8 = lane & 7;
                     const f32x4 x0 = *reinterpret_cast<const f32x4*>(img + r * 256 + (((2 * c8) ^ r) << 4));
                     const f32x4 x1 = *reinterpret_cast<const f32x4*>(img + r * 256 + (((2 * c8 + 1) ^ r) << 4));
-                    if constexpr (sizeof(TC) == 2)
+                    if constexpr (LEAN) {
+                        const int m = cbm + wr * 128 + mi * 16 + r, n0 = cbn + wc * 64 + c8 * 8;
+                        if (m < p.M && n0 + 7 < p.N) {
+                            float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+                            if (p.bias) { b0 = *reinterpret_cast<const float4*>(p.bias + n0); b1 = *reinterpret_cast<const float4*>(p.bias + n0 + 4); }
+                            const u32x4 o = {pack_bf16x2(x0[0] + b0.x, x0[1] + b0.y), pack_bf16x2(x0[2] + b0.z, x0[3] + b0.w),
+                                             pack_bf16x2(x1[0] + b1.x, x1[1] + b1.y), pack_bf16x2(x1[2] + b1.z, x1[3] + b1.w)};
+                            bf16_t* dst = reinterpret_cast<bf16_t*>(C) + (long)m * p.ldc + n0;
+                            if (p.nt) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(dst));
+                            else *reinterpret_cast<u32x4*>(dst) = o;
+                        } else if (m < p.M) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (n0 + j < p.N)
+                                    reinterpret_cast<bf16_t*>(C)[(long)m * p.ldc + n0 + j] = f32_to_bf16((j < 4 ? x0[j] : x1[j - 4]) + (p.bias ? p.bias[n0 + j] : 0.f));
+                        }
+                    } else if constexpr (sizeof(TC) == 2)
                         epi_store8_bf16(p, reinterpret_cast<bf16_t*>(C), cbm + wr * 128 + mi * 16 + r, cbn + wc * 64 + c8 * 8, x0, x1, vec);
                 }
-            } else {
+            } else if constexpr (!LEAN) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = q * 4 + (lane >> 4);                    // row of the 16-row slab
@@ -1793,6 +1811,9 @@ const int cus8 = nwg8 < 1024 ? std::max(8, (g_num_cus - g_reserved_cus) / 8 * 8)
 if (c_dtype == 0) {
             if (int rc = enable_lds(gemm_nt_bf16_v8_kernel<float>, LDS8)) return rc;
             hipLaunchKernelGGL(gemm_nt_bf16_v8_kernel<float>, dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
+        } else if (!p.addend && !p.mask && !p.relu && p.drop.p <= 0.f && ldc % 8 == 0 && aligned16(C) && (!p.bias || aligned16(p.bias))) {
+            if (int rc = enable_lds((gemm_nt_bf16_v8_kernel<bf16_t, true>), LDS8)) return rc;
+            hipLaunchKernelGGL((gemm_nt_bf16_v8_kernel<bf16_t, true>), dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
         } else {
             if (int rc = enable_lds(gemm_nt_bf16_v8_kernel<bf16_t>, LDS8)) return rc;
             hipLaunchKernelGGL(gemm_nt_bf16_v8_kernel<bf16_t>, dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
