@@ -885,6 +885,17 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
         // they are never indexed dynamically (which would put all 128 of them in scratch)
 #define V8_SLAB(I) case I: _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) \
             *reinterpret_cast<f32x4*>(img + wrow * 256 + (((ni * 4 + wq) ^ wrow) << 4)) = acc[I][ni]; break;
+        // LEAN: everything that does not depend on the slab is formed once per tile - the lane's 8 bias values, its column test and its row-0
+        // output address
+        const int ln0 = cbn + wc * 64 + (lane & 7) * 8;
+        const bool lfull = ln0 + 7 < p.N;
+        float lb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (LEAN && p.bias && lfull) {
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + ln0), b1 = *reinterpret_cast<const float4*>(p.bias + ln0 + 4);
+            lb[0] = b0.x; lb[1] = b0.y; lb[2] = b0.z; lb[3] = b0.w; lb[4] = b1.x; lb[5] = b1.y; lb[6] = b1.z; lb[7] = b1.w;
+        }
+        const int lm0 = cbm + wr * 128 + (lane >> 3);
+        bf16_t* lrow0 = reinterpret_cast<bf16_t*>(p.C) + (long)lm0 * p.ldc + ln0;
 #pragma unroll 1
         for (int mi = 0; mi < 8; ++mi) {
             switch (mi) { V8_SLAB(0) V8_SLAB(1) V8_SLAB(2) V8_SLAB(3) V8_SLAB(4) V8_SLAB(5) V8_SLAB(6) V8_SLAB(7) }
@@ -897,20 +908,20 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                     const f32x4 x0 = *reinterpret_cast<const f32x4*>(img + r * 256 + (((2 * c8) ^ r) << 4));
                     const f32x4 x1 = *reinterpret_cast<const f32x4*>(img + r * 256 + (((2 * c8 + 1) ^ r) << 4));
                     if constexpr (LEAN) {
-                        const int m = cbm + wr * 128 + mi * 16 + r, n0 = cbn + wc * 64 + c8 * 8;
-                        if (m < p.M && n0 + 7 < p.N) {
-                            float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-                            if (p.bias) { b0 = *reinterpret_cast<const float4*>(p.bias + n0); b1 = *reinterpret_cast<const float4*>(p.bias + n0 + 4); }
-                            const u32x4 o = {pack_bf16x2(x0[0] + b0.x, x0[1] + b0.y), pack_bf16x2(x0[2] + b0.z, x0[3] + b0.w),
-                                             pack_bf16x2(x1[0] + b1.x, x1[1] + b1.y), pack_bf16x2(x1[2] + b1.z, x1[3] + b1.w)};
-                            bf16_t* dst = reinterpret_cast<bf16_t*>(C) + (long)m * p.ldc + n0;
-                            if (p.nt) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(dst));
-                            else *reinterpret_cast<u32x4*>(dst) = o;
-                        } else if (m < p.M) {
+                        const int m = lm0 + mi * 16 + q * 8;
+                        if (lfull) {
+                            if (m < p.M) {
+                                const u32x4 o = {pack_bf16x2(x0[0] + lb[0], x0[1] + lb[1]), pack_bf16x2(x0[2] + lb[2], x0[3] + lb[3]),
+                                                 pack_bf16x2(x1[0] + lb[4], x1[1] + lb[5]), pack_bf16x2(x1[2] + lb[6], x1[3] + lb[7])};
+                                bf16_t* dst = lrow0 + (long)(mi * 16 + q * 8) * p.ldc;
+                                if (p.nt) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(dst));
+                                else *reinterpret_cast<u32x4*>(dst) = o;
+                            }
+                        } else if (m < p.M) {            // the ragged last 8-column group of the matrix
 #pragma unroll
                             for (int j = 0; j < 8; ++j)
-                                if (n0 + j < p.N)
-                                    reinterpret_cast<bf16_t*>(C)[(long)m * p.ldc + n0 + j] = f32_to_bf16((j < 4 ? x0[j] : x1[j - 4]) + (p.bias ? p.bias[n0 + j] : 0.f));
+                                if (ln0 + j < p.N)
+                                    reinterpret_cast<bf16_t*>(C)[(long)m * p.ldc + ln0 + j] = f32_to_bf16((j < 4 ? x0[j] : x1[j - 4]) + (p.bias ? p.bias[ln0 + j] : 0.f));
                         }
                     } else if constexpr (sizeof(TC) == 2)
                         epi_store8_bf16(p, reinterpret_cast<bf16_t*>(C), cbm + wr * 128 + mi * 16 + r, cbn + wc * 64 + c8 * 8, x0, x1, vec);
