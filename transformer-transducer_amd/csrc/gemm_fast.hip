@@ -719,9 +719,10 @@ __device__ __forceinline__ void epi_store8_bf16(const FP& p, bf16_t* C, int m, i
 constexpr int T8 = 256, NTH8 = 512, HT8 = 128 * 64 * 2, BUF8 = 4 * HT8;   // buffer: [A h0 | A h1 | B h0 | B h1]
 constexpr int LDS8 = 2 * BUF8 + 8 * 4096;
 
-// LEAN: the instance for bias-only bf16 outputs (the joint forward): its epilogue carries no residual / mask / ReLU / dropout code, which
+// LEAN: 1 = the instance for bias-only bf16 outputs (the joint forward), 2 = for mask-only ones (the joint dgrad's tanh', ReLU'): their epilogues
+// carry no residual / ReLU / dropout code and test nothing per store, which
 // costs the main loop registers in the general instance
-template <typename TC, bool LEAN = false>
+template <typename TC, int LEAN = 0>
 __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -890,7 +891,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
         const int ln0 = cbn + wc * 64 + (lane & 7) * 8;
         const bool lfull = ln0 + 7 < p.N;
         float lb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (LEAN && p.bias && lfull) {
+        if (LEAN == 1 && p.bias && lfull) {
             const float4 b0 = *reinterpret_cast<const float4*>(p.bias + ln0), b1 = *reinterpret_cast<const float4*>(p.bias + ln0 + 4);
             lb[0] = b0.x; lb[1] = b0.y; lb[2] = b0.z; lb[3] = b0.w; lb[4] = b1.x; lb[5] = b1.y; lb[6] = b1.z; lb[7] = b1.w;
         }
@@ -911,8 +912,17 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                         const int m = lm0 + mi * 16 + q * 8;
                         if (lfull) {
                             if (m < p.M) {
-                                const u32x4 o = {pack_bf16x2(x0[0] + lb[0], x0[1] + lb[1]), pack_bf16x2(x0[2] + lb[2], x0[3] + lb[3]),
-                                                 pack_bf16x2(x1[0] + lb[4], x1[1] + lb[5]), pack_bf16x2(x1[2] + lb[6], x1[3] + lb[7])};
+                                float v[8] = {x0[0] + lb[0], x0[1] + lb[1], x0[2] + lb[2], x0[3] + lb[3], x1[0] + lb[4], x1[1] + lb[5], x1[2] + lb[6], x1[3] + lb[7]};
+                                if constexpr (LEAN == 2) {         // one 16-byte read of the mask operand (same layout as the output)
+                                    const u32x4 mk = *reinterpret_cast<const u32x4*>(p.mask + (long)m * p.ldc + ln0);
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) {
+                                        const float lo = __uint_as_float(mk[j] << 16), hi = __uint_as_float(mk[j] & 0xffff0000u);
+                                        v[2 * j] = p.mask_mode ? v[2 * j] * (1.f - lo * lo) : (lo > 0.f ? v[2 * j] * p.scale : 0.f);
+                                        v[2 * j + 1] = p.mask_mode ? v[2 * j + 1] * (1.f - hi * hi) : (hi > 0.f ? v[2 * j + 1] * p.scale : 0.f);
+                                    }
+                                }
+                                const u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
                                 bf16_t* dst = lrow0 + (long)(mi * 16 + q * 8) * p.ldc;
                                 if (p.nt) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(dst));
                                 else *reinterpret_cast<u32x4*>(dst) = o;
@@ -921,7 +931,14 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
 #pragma unroll
                             for (int j = 0; j < 8; ++j)
                                 if (ln0 + j < p.N)
-                                    reinterpret_cast<bf16_t*>(C)[(long)m * p.ldc + ln0 + j] = f32_to_bf16((j < 4 ? x0[j] : x1[j - 4]) + (p.bias ? p.bias[ln0 + j] : 0.f));
+                                {
+                                    float y = (j < 4 ? x0[j] : x1[j - 4]) + (LEAN == 1 && p.bias ? p.bias[ln0 + j] : 0.f);
+                                    if constexpr (LEAN == 2) {
+                                        const float mv = bf16_to_f32(p.mask[(long)m * p.ldc + ln0 + j]);
+                                        y = p.mask_mode ? y * (1.f - mv * mv) : (mv > 0.f ? y * p.scale : 0.f);
+                                    }
+                                    reinterpret_cast<bf16_t*>(C)[(long)m * p.ldc + ln0 + j] = f32_to_bf16(y);
+                                }
                         }
                     } else if constexpr (sizeof(TC) == 2)
                         epi_store8_bf16(p, reinterpret_cast<bf16_t*>(C), cbm + wr * 128 + mi * 16 + r, cbn + wc * 64 + c8 * 8, x0, x1, vec);
@@ -1823,8 +1840,11 @@ if (c_dtype == 0) {
             if (int rc = enable_lds(gemm_nt_bf16_v8_kernel<float>, LDS8)) return rc;
             hipLaunchKernelGGL(gemm_nt_bf16_v8_kernel<float>, dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
         } else if (!p.addend && !p.mask && !p.relu && p.drop.p <= 0.f && ldc % 8 == 0 && aligned16(C) && (!p.bias || aligned16(p.bias))) {
-            if (int rc = enable_lds((gemm_nt_bf16_v8_kernel<bf16_t, true>), LDS8)) return rc;
-            hipLaunchKernelGGL((gemm_nt_bf16_v8_kernel<bf16_t, true>), dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
+            if (int rc = enable_lds((gemm_nt_bf16_v8_kernel<bf16_t, 1>), LDS8)) return rc;
+            hipLaunchKernelGGL((gemm_nt_bf16_v8_kernel<bf16_t, 1>), dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
+        } else if (!p.addend && p.mask && !p.bias && !p.relu && p.drop.p <= 0.f && ldc % 8 == 0 && aligned16(C) && aligned16(p.mask)) {
+            if (int rc = enable_lds((gemm_nt_bf16_v8_kernel<bf16_t, 2>), LDS8)) return rc;
+            hipLaunchKernelGGL((gemm_nt_bf16_v8_kernel<bf16_t, 2>), dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
         } else {
             if (int rc = enable_lds(gemm_nt_bf16_v8_kernel<bf16_t>, LDS8)) return rc;
             hipLaunchKernelGGL(gemm_nt_bf16_v8_kernel<bf16_t>, dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
