@@ -1171,7 +1171,8 @@ __global__ __launch_bounds__(NTH10, 1) void gemm_nt_bf16_v10_kernel(const FP p) 
 // =====================================================================================================================
 constexpr int T9M = 256, T9N = 128, STG9 = (T9M + T9N) * 64 * 2, LDS9 = 3 * STG9;
 
-template <typename TC>
+// LEAN (as in v8): 1 = plain or bias-only epilogue (either output type), 2 = mask-only (bf16 output); launcher-checked alignment
+template <typename TC, int LEAN = 0>
 __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1287,6 +1288,74 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p) {
         // rolled slab loop with a wave-uniform switch over the accumulators (one copy of the epilogue code, no dynamic register indexing)
 #define V9_SLAB(I) case I: _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) \
             *reinterpret_cast<f32x4*>(img + wrow * 256 + (((ni * 4 + wq) ^ wrow) << 4)) = acc[I][ni]; break;
+        if constexpr (LEAN != 0) {
+            // per-tile constants: the lane's columns (8 for bf16, 4 for f32 output), their bias, the column test, the row-0 address
+            constexpr int NC = sizeof(TC) == 2 ? 8 : 4;
+            const int ln0 = cbn + wc * 64 + (sizeof(TC) == 2 ? (lane & 7) * 8 : (lane & 15) * 4);
+            const bool lfull = ln0 + NC - 1 < p.N;
+            float lb[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) lb[j] = 0.f;
+            if (LEAN == 1 && p.bias && lfull) {
+#pragma unroll
+                for (int j = 0; j < NC; j += 4) {
+                    const float4 b = *reinterpret_cast<const float4*>(p.bias + ln0 + j);
+                    lb[j] = b.x; lb[j + 1] = b.y; lb[j + 2] = b.z; lb[j + 3] = b.w;
+                }
+            }
+            const int lm0 = cbm + wr * 64 + (sizeof(TC) == 2 ? (lane >> 3) : (lane >> 4));
+            TC* lrow0 = C + (long)lm0 * p.ldc + ln0;
+#pragma unroll 1
+            for (int mi = 0; mi < 4; ++mi) {
+                switch (mi) { V9_SLAB(0) V9_SLAB(1) V9_SLAB(2) V9_SLAB(3) }
+                if constexpr (sizeof(TC) == 2) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int r = q * 8 + (lane >> 3);
+                        const int c8 = lane & 7;
+                        const f32x4 x0 = *reinterpret_cast<const f32x4*>(img + r * 256 + (((2 * c8) ^ r) << 4));
+                        const f32x4 x1 = *reinterpret_cast<const f32x4*>(img + r * 256 + (((2 * c8 + 1) ^ r) << 4));
+                        const int m = lm0 + mi * 16 + q * 8;
+                        if (lfull) {
+                            if (m < p.M) {
+                                float v[8] = {x0[0] + lb[0], x0[1] + lb[1], x0[2] + lb[2], x0[3] + lb[3], x1[0] + lb[4], x1[1] + lb[5], x1[2] + lb[6], x1[3] + lb[7]};
+                                if constexpr (LEAN == 2) {
+                                    const u32x4 mk = *reinterpret_cast<const u32x4*>(p.mask + (long)m * p.ldc + ln0);
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) {
+                                        const float lo = __uint_as_float(mk[j] << 16), hi = __uint_as_float(mk[j] & 0xffff0000u);
+                                        v[2 * j] = p.mask_mode ? v[2 * j] * (1.f - lo * lo) : (lo > 0.f ? v[2 * j] * p.scale : 0.f);
+                                        v[2 * j + 1] = p.mask_mode ? v[2 * j + 1] * (1.f - hi * hi) : (hi > 0.f ? v[2 * j + 1] * p.scale : 0.f);
+                                    }
+                                }
+                                const u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                                bf16_t* dst = reinterpret_cast<bf16_t*>(lrow0) + (long)(mi * 16 + q * 8) * p.ldc;
+                                if (p.nt) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(dst));
+                                else *reinterpret_cast<u32x4*>(dst) = o;
+                            }
+                        } else {                       // the ragged last column group: the general element-wise path
+                            epi_store4<bf16_t>(p, reinterpret_cast<bf16_t*>(C), m, ln0, x0, vec);
+                            epi_store4<bf16_t>(p, reinterpret_cast<bf16_t*>(C), m, ln0 + 4, x1, vec);
+                        }
+                    }
+                } else {
+                    // f32 output: the lane keeps ONE 4-column chunk (c = lane & 15) for every row, read from slot c ^ r
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = q * 4 + (lane >> 4);
+                        const f32x4 x = *reinterpret_cast<const f32x4*>(img + r * 256 + (((lane & 15) ^ r) << 4));
+                        const int m = lm0 + mi * 16 + q * 4;
+                        if (lfull) {
+                            if (m < p.M)
+                                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(lrow0) + (long)(mi * 16 + q * 4) * p.ldc) =
+                                    f32x4{x[0] + lb[0], x[1] + lb[1], x[2] + lb[2], x[3] + lb[3]};
+                        } else {
+                            epi_store4<TC>(p, C, m, ln0, x, vec);
+                        }
+                    }
+                }
+            }
+        } else {
 #pragma unroll 1
         for (int mi = 0; mi < 4; ++mi) {
             switch (mi) { V9_SLAB(0) V9_SLAB(1) V9_SLAB(2) V9_SLAB(3) }
@@ -1312,6 +1381,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p) {
             }
         }
     }
+        }
 #undef V9_SLAB
 #undef V9_BAR
 }
@@ -1793,13 +1863,21 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
         // with gradient all-reduce kernels resident during backward, leave them room (multi-GPU runs set option 6)
         const int cus9 = std::max(8, (g_num_cus - g_reserved_cus) / 8 * 8);
         const int grid9 = (int)((std::min<long>(t9, cus9) + 7) / 8 * 8);
+        // lean epilogue instances (nothing tested per store): plain / bias-only for both output types, mask-only for bf16
+        const bool base_ok = !p.addend && !p.relu && p.drop.p <= 0.f && aligned16(C) && (!p.bias || aligned16(p.bias));
+        const bool lean1 = base_ok && !p.mask && ldc % (c_dtype == 0 ? 4 : 8) == 0;
+        const bool lean2 = base_ok && p.mask && !p.bias && c_dtype == 1 && ldc % 8 == 0 && aligned16(p.mask);
+#define V9_LAUNCH(...) do { if (int rc = enable_lds((gemm_nt_bf16_v9_kernel<__VA_ARGS__>), LDS9)) return rc; \
+            hipLaunchKernelGGL((gemm_nt_bf16_v9_kernel<__VA_ARGS__>), dim3((unsigned)grid9), dim3(NTH8), LDS9, st, p); } while (0)
         if (c_dtype == 0) {
-            if (int rc = enable_lds(gemm_nt_bf16_v9_kernel<float>, LDS9)) return rc;
-            hipLaunchKernelGGL(gemm_nt_bf16_v9_kernel<float>, dim3((unsigned)grid9), dim3(NTH8), LDS9, st, p);
+            if (lean1) V9_LAUNCH(float, 1);
+            else V9_LAUNCH(float, 0);
         } else {
-            if (int rc = enable_lds(gemm_nt_bf16_v9_kernel<bf16_t>, LDS9)) return rc;
-            hipLaunchKernelGGL(gemm_nt_bf16_v9_kernel<bf16_t>, dim3((unsigned)grid9), dim3(NTH8), LDS9, st, p);
+            if (lean1) V9_LAUNCH(bf16_t, 1);
+            else if (lean2) V9_LAUNCH(bf16_t, 2);
+            else V9_LAUNCH(bf16_t, 0);
         }
+#undef V9_LAUNCH
         TTMI_LAUNCH_CHECK("gemm_nt_bf16_v9_kernel");
         return TTMI_OK;
     }
