@@ -1171,7 +1171,8 @@ __global__ __launch_bounds__(NTH10, 1) void gemm_nt_bf16_v10_kernel(const FP p) 
 // =====================================================================================================================
 constexpr int T9M = 256, T9N = 128, STG9 = (T9M + T9N) * 64 * 2, LDS9 = 3 * STG9;
 
-// LEAN (as in v8): 1 = plain or bias-only epilogue (either output type), 2 = mask-only (bf16 output); launcher-checked alignment
+// LEAN (as in v8): 1 = plain or bias-only epilogue (either output type), 2 = mask-only (bf16 output), 3 = f32 output + residual addend
+// (+ bias); launcher-checked alignment
 template <typename TC, int LEAN = 0>
 __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1296,7 +1297,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p) {
             float lb[NC];
 #pragma unroll
             for (int j = 0; j < NC; ++j) lb[j] = 0.f;
-            if (LEAN == 1 && p.bias && lfull) {
+            if ((LEAN == 1 || LEAN == 3) && p.bias && lfull) {
 #pragma unroll
                 for (int j = 0; j < NC; j += 4) {
                     const float4 b = *reinterpret_cast<const float4*>(p.bias + ln0 + j);
@@ -1346,9 +1347,12 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p) {
                         const f32x4 x = *reinterpret_cast<const f32x4*>(img + r * 256 + (((lane & 15) ^ r) << 4));
                         const int m = lm0 + mi * 16 + q * 4;
                         if (lfull) {
-                            if (m < p.M)
-                                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(lrow0) + (long)(mi * 16 + q * 4) * p.ldc) =
-                                    f32x4{x[0] + lb[0], x[1] + lb[1], x[2] + lb[2], x[3] + lb[3]};
+                            if (m < p.M) {
+                                f32x4 o = {x[0] + lb[0], x[1] + lb[1], x[2] + lb[2], x[3] + lb[3]};
+                                const long off = (long)(mi * 16 + q * 4) * p.ldc;
+                                if constexpr (LEAN == 3) o += *reinterpret_cast<const f32x4*>(p.addend + (long)lm0 * p.ldc + ln0 + off);
+                                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(lrow0) + off) = o;
+                            }
                         } else {
                             epi_store4<TC>(p, C, m, ln0, x, vec);
                         }
@@ -1871,6 +1875,7 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
             hipLaunchKernelGGL((gemm_nt_bf16_v9_kernel<__VA_ARGS__>), dim3((unsigned)grid9), dim3(NTH8), LDS9, st, p); } while (0)
         if (c_dtype == 0) {
             if (lean1) V9_LAUNCH(float, 1);
+            else if (p.addend && !p.mask && !p.relu && p.drop.p <= 0.f && ldc % 4 == 0 && aligned16(C) && aligned16(p.addend) && (!p.bias || aligned16(p.bias))) V9_LAUNCH(float, 3);
             else V9_LAUNCH(float, 0);
         } else {
             if (lean1) V9_LAUNCH(bf16_t, 1);
