@@ -897,8 +897,18 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
         }
         const int lm0 = cbm + wr * 128 + (lane >> 3);
         bf16_t* lrow0 = reinterpret_cast<bf16_t*>(p.C) + (long)lm0 * p.ldc + ln0;
+        // LEAN 2: the mask vectors of slab mi + 1 are requested before slab mi goes through its LDS transposes and stores
+        u32x4 mkc[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}}, mkn[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+        const bf16_t* lmask0 = p.mask + (long)lm0 * p.ldc + ln0;
+        auto mask_fetch = [&](int mi, u32x4 (&dst)[2]) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (lfull && lm0 + mi * 16 + q * 8 < p.M) dst[q] = *reinterpret_cast<const u32x4*>(lmask0 + (long)(mi * 16 + q * 8) * p.ldc);
+        };
+        if constexpr (LEAN == 2) mask_fetch(0, mkc);
 #pragma unroll 1
         for (int mi = 0; mi < 8; ++mi) {
+            if constexpr (LEAN == 2) { if (mi + 1 < 8) mask_fetch(mi + 1, mkn); }
             switch (mi) { V8_SLAB(0) V8_SLAB(1) V8_SLAB(2) V8_SLAB(3) V8_SLAB(4) V8_SLAB(5) V8_SLAB(6) V8_SLAB(7) }
             if (LEAN || (sizeof(TC) == 2 && plain8)) {
                 // bf16 output: 8 columns per lane, one 16-byte store - 8 rows x 128 B per instruction
@@ -914,7 +924,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                             if (m < p.M) {
                                 float v[8] = {x0[0] + lb[0], x0[1] + lb[1], x0[2] + lb[2], x0[3] + lb[3], x1[0] + lb[4], x1[1] + lb[5], x1[2] + lb[6], x1[3] + lb[7]};
                                 if constexpr (LEAN == 2) {         // one 16-byte read of the mask operand (same layout as the output)
-                                    const u32x4 mk = *reinterpret_cast<const u32x4*>(p.mask + (long)m * p.ldc + ln0);
+                                    const u32x4 mk = mkc[q];
 #pragma unroll
                                     for (int j = 0; j < 4; ++j) {
                                         const float lo = __uint_as_float(mk[j] << 16), hi = __uint_as_float(mk[j] & 0xffff0000u);
@@ -943,6 +953,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                     } else if constexpr (sizeof(TC) == 2)
                         epi_store8_bf16(p, reinterpret_cast<bf16_t*>(C), cbm + wr * 128 + mi * 16 + r, cbn + wc * 64 + c8 * 8, x0, x1, vec);
                 }
+                if constexpr (LEAN == 2) { mkc[0] = mkn[0]; mkc[1] = mkn[1]; }
             } else if constexpr (!LEAN) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
