@@ -183,6 +183,9 @@ def main():
     loss_sum = torch.zeros(1, device=dev)
     probe_ms = []
 
+    for kv in os.environ.get("TTMI_OPTIONS", "").split(","):          # measurement switches, e.g. TTMI_OPTIONS=3:0 (no wgrad fork); see include/ttmi.h
+        if kv:
+            ops.set_option(int(kv.split(":")[0]), int(kv.split(":")[1]))
     if world > 1:
         ops.set_option(6, 32)      # gradient all-reduce kernels run beside backward: the persistent encoder GEMMs leave them 4 CUs per XCD
 
