@@ -242,6 +242,39 @@ def test_blocked_greedy_decode_matches_frame_by_frame():
         assert model.recognize(x, torch.tensor(lens)) == want
 
 
+def test_decode_graphs_match_eager_and_follow_weight_updates():
+    """decode replays one captured graph per history length for the label-encoder re-runs: same tokens as the eager launches
+    (config.decode_graphs = False), on first use, on reuse for the next utterance, and after an in-place weight update (graphs hold
+    pointers, not values)"""
+    from tt.model import Transducer
+    from tt.utils import AttrDict
+    side = dict(n_layer=2, d_model=64, n_head=2, d_head=32, d_inner=96)
+    cfg = AttrDict(dict(enc=dict(side, max_input_length=16), dec=dict(side, max_target_length=8),
+                        joint=dict(input_size=128, inner_size=48), vocab_size=29, dropout=0.0))
+    torch.manual_seed(9)
+    model = Transducer(cfg).cuda().eval()
+    with torch.no_grad():
+        model.joint.project_layer.bias[0] += 0.4             # some blank frames between the emissions
+    x = torch.randn(3, 70, 64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(10))
+    lens = torch.tensor([70, 55, 70])
+
+    def both():
+        model.config["decode_graphs"] = False
+        eager = model.recognize(x, lens)
+        model.config["decode_graphs"] = True
+        return eager, model.recognize(x, lens)
+
+    eager, graphed = both()
+    assert len(eager[0]) > 8 and graphed == eager          # histories longer than the label encoder's table (K = 8) included
+    assert model.__dict__["_decode_graphs"].graphs                      # graphs were captured and are reused below
+    assert model.recognize(x, lens) == eager
+    with torch.no_grad():
+        for p_ in model.decoder.parameters():
+            p_.mul_(1.25)
+    eager2, graphed2 = both()
+    assert graphed2 == eager2 and eager2 != eager
+
+
 def test_full_size_greedy_decode_tokens_vs_oracle():
     """BASELINE configs[1] model (12 / 6 layers, d_model 512, V = 4334, random init under seed 1) with a blank bias that lets about
     15 % of the frames emit: `recognize` gives the oracle's frame-by-frame token lists (tt/model.py:70-108) exactly, including

@@ -61,6 +61,50 @@ class JointNet(nn.Module):
         return out if squeeze is None else out.reshape(*squeeze, out.shape[-1])
 
 
+class _LabelStateGraphs:
+    """Greedy decoding re-runs the label encoder on the whole token history after every emitted symbol (tt/model.py:75,88 of the
+    reference): ~100 tiny launches whose cost is the host issuing them.  One captured graph per history length L replays them with a
+    single launch; the token history lives on the device (`master`), each graph reads its own static copy and writes a static output.
+    Graphs are captured lazily, share one memory pool and are dropped when the label encoder's parameter storage or the precision
+    mode changes."""
+    MAX_L = 128
+
+    def __init__(self, model, device):
+        self.decoder, self.device = model.decoder, device
+        self.master = torch.zeros(1, self.MAX_L, dtype=torch.long, device=device)
+        self.stream = torch.cuda.Stream(device)
+        self.pool = torch.cuda.graph_pool_handle()
+        self.graphs = {}
+        self.key = self.weights_key(model)
+
+    @staticmethod
+    def weights_key(model):
+        return tuple(p.data_ptr() for p in model.decoder.parameters()) + (default_precision(),)
+
+    def set_token(self, pos, tok):
+        self.master[0, pos] = tok                                   # a device fill, no synchronisation
+
+    def state(self, L):
+        """label-encoder output at the last position of master[:, :L] -> [1, 1, d] (static buffer of graph L)"""
+        entry = self.graphs.get(L)
+        if entry is None:
+            tok = self.master[:, :L].clone()
+            cur = torch.cuda.current_stream(self.device)
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                for _ in range(2):                                  # warm-up outside the capture: scratch arenas, kernel attributes
+                    self.decoder(tok)
+            cur.wait_stream(self.stream)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, pool=self.pool, stream=self.stream):
+                out = self.decoder(tok)[:, -1:, :]
+            entry = self.graphs[L] = (graph, tok, out)
+        graph, tok, out = entry
+        tok.copy_(self.master[:, :L])
+        graph.replay()
+        return out
+
+
 class Transducer(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -109,11 +153,22 @@ class Transducer(nn.Module):
         """Greedy: <= 1 symbol per frame, label encoder re-run on the whole history WITHOUT look-ahead mask (tt/model.py:70-90).
         Same token sequence as the reference's per-frame loop, but frames are scored `block` at a time against the current
         label state and the first non-blank frame is found on the device (ttmi_greedy_scan): one host sync per emitted
-        symbol instead of one per frame."""
+        symbol instead of one per frame.  The label-encoder re-runs replay captured graphs (one per history length, see
+        _LabelStateGraphs)."""
         token_list = [0]
         dev = enc_state.device
         T = int(lengths)
-        dec_state = self.decoder(torch.tensor([token_list], dtype=torch.long, device=dev))[:, -1:, :]      # [1, 1, d]
+        graphs = self._label_state_graphs(dev)
+
+        def label_state():
+            """label-encoder output for the current history -> [1, 1, d]"""
+            L = len(token_list)
+            if graphs is not None and L <= graphs.MAX_L:
+                graphs.set_token(L - 1, token_list[-1])
+                return graphs.state(L)
+            return self.decoder(torch.tensor([token_list], dtype=torch.long, device=dev))[:, -1:, :]
+
+        dec_state = label_state()
         t = 0
         while t < T:
             n = min(block, T - t)
@@ -123,9 +178,18 @@ class Transducer(nn.Module):
                 t += n
                 continue
             token_list.append(tok)
-            dec_state = self.decoder(torch.tensor([token_list], dtype=torch.long, device=dev))[:, -1:, :]
+            dec_state = label_state()
             t += row + 1                                                    # the emitting frame is consumed
         return token_list[1:]
+
+    def _label_state_graphs(self, dev):
+        """the per-model graph cache of `decode` (None: CPU tensors, or switched off with config.decode_graphs = False)"""
+        if dev.type != "cuda" or self.config.decode_graphs is False:
+            return None
+        g = self.__dict__.get("_decode_graphs")
+        if g is None or g.device != dev or g.key != _LabelStateGraphs.weights_key(self):
+            g = self.__dict__["_decode_graphs"] = _LabelStateGraphs(self, dev)
+        return g
 
     @torch.no_grad()
     def recognize(self, inputs, inputs_length=None, audio_mask=None):
