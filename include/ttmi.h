@@ -46,7 +46,10 @@ const char* ttmi_last_error(void);   /* thread-local, valid until the next faili
  * j > i+right or j < i-left (tt/utils.py:242-251) | 3 uint8 tensor, element (b,i,j) at
  * mask[b*mask_sb + i*mask_si + j], nonzero = masked (any [L,L,1] / [L,L,B] / (klen,bsz) mask of
  * tt/transformer.py:154-159 after a permute) | 4 per-row key intervals: `mask` points at int32 pairs, (lo, hi) of query i of batch b at
- * ((const int*)mask)[b*mask_sb + 2*i], key j masked iff j < lo or j > hi (what chunk / band masks are; mask_sb = 0 shares one table). */
+ * ((const int*)mask)[b*mask_sb + 2*i], key j masked iff j < lo or j > hi (what chunk / band masks are; mask_sb = 0 shares one table);
+ * with kind 4, mask_left / mask_right may carry bounds on the intervals' reach from the diagonal (lo_i >= i - left, hi_i <= i + right,
+ * -1 / -1 or 0 / 0 = not known).  The fused attention kernels skip key tiles that are masked for a whole query block (kinds 1, 2, 4),
+ * and for narrow bands (kind 2, or kind 4 with bounds) the backward also skips the query tiles a key block never meets. */
 size_t ttmi_attn_ctx_floats(int B, int L, int d, int H, int Dh, int prec);
 size_t ttmi_attn_ws_floats(int B, int L, int d, int H, int Dh, int prec);
 int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const float* ln_g, const float* ln_b,

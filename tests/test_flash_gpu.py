@@ -112,3 +112,34 @@ def test_interval_structured_masks_take_the_row_range_path(prec, monkeypatch):
     holes[5, 1, 0] = False
     holes[5, 5, 0] = False
     assert as_mask_spec(holes, B, L).kind == 3
+
+
+@pytest.mark.parametrize("L,kind", [(500, "band"), (500, "chunk"), (1100, "band"), (1100, "chunk"), (700, "causal")])
+def test_masked_tile_skipping_changes_nothing(L, kind, monkeypatch):
+    """structured masks let the fused kernels skip key tiles that are masked for a whole query block (forward) and, for narrow bands on
+    long sequences, the query tiles a key block never meets (backward, slabs pre-zeroed): skipped tiles contribute exact zeros, so the
+    layer's output and input gradient equal the byte-mask path (kind 3, nothing skipped) bit for bit"""
+    from tt.encoder import BaseEncoder
+    from tt.transformer import as_mask_spec
+    from ttmi.ops import MaskSpec
+    monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    Dh, H, K, B = 64, 2, 64, 1
+    torch.manual_seed(L)
+    layer = BaseEncoder(k_len=K, n_head=H, d_model=H * Dh, d_head=Dh, d_inner=64, dropout=0.0).cuda().eval()
+    x = torch.randn(B, L, H * Dh, device="cuda")
+    cot = torch.randn(B, L, H * Dh, device="cuda")
+    if kind == "band":
+        m = torch.tensor(O.context_mask(L, 64, 0) != 0).cuda()
+        spec = MaskSpec(2, left=64, right=0)
+    elif kind == "chunk":
+        m = torch.tensor(O.chunk_mask(L, 16, 64) != 0).cuda()
+        spec = as_mask_spec(m[:, :, None], B, L)
+        assert spec.kind == 4 and spec.left == 64 + 15 and spec.right == 15
+    else:
+        m = torch.tensor(O.look_ahead_mask(L) != 0).cuda()
+        spec = MaskSpec(1)
+    y, dx, g = _run(layer, x, cot, spec)
+    y3, dx3, g3 = _run(layer, x, cot, MaskSpec(3, tensor=m[None].to(torch.uint8).contiguous()))
+    assert torch.equal(y, y3) and torch.equal(dx, dx3)
+    for n in g:
+        assert rel_err(g[n].cpu().numpy(), g3[n].cpu().numpy()) < 1e-5, n

@@ -30,9 +30,10 @@ struct FlashParams {
     bf16_t* dV16 = nullptr;
     int B = 0, L = 0, H = 0, Dh = 0;
     float scale = 1.f;
-    int mask_kind = 0, mask_left = 0, mask_right = 0;
+    int mask_kind = 0, mask_left = 0, mask_right = 0;   // kind 2: the band; kind 4: bounds on the intervals' reach from the diagonal (-1 = unknown)
     const unsigned char* mask = nullptr;
     long mask_sb = 0, mask_si = 0;
+    int bwd_skip = 0;             // set by flash_attn_bwd: dS16 / dG16 are pre-zeroed, the kernel walks only the query tiles its key block can meet
     int debug = 0;                // measurement only (ttmi_set_option(2, bits)): 1 = skip the bias read, 2 = skip the dS write
 };
 

@@ -232,23 +232,46 @@ __global__ __launch_bounds__(256, FWD_MINB) void flash_fwd_kernel(const FlashPar
             }
         }
     };
+    // structured masks: key tiles that are masked for all 128 queries of the workgroup contribute exact zeros (p = 0, the running maximum
+    // and sum unchanged) and are skipped - a band of left + right + 1 keys touches (left + right + 128) / 64 + 1 tiles instead of L / 64
+    int jbeg = 0, jend = L;
+    {
+        const int i0w = blockIdx.x * 128, i1w = min(i0w + 127, L - 1);
+        if constexpr (MK == 1) jend = i1w + 1;
+        if constexpr (MK == 2) {
+            jbeg = max(0, i0w - p.mask_left);
+            jend = (int)min((long)L, (long)i1w + p.mask_right + 1);
+        }
+        if constexpr (MK == 4) {
+            __shared__ int rng[2];
+            if (tid == 0) { rng[0] = 0x7fffffff; rng[1] = -1; }
+            __syncthreads();
+            atomicMin(&rng[0], mlo);
+            atomicMax(&rng[1], mhi);
+            __syncthreads();
+            jbeg = max(0, rng[0]);
+            jend = (int)min((long)L, (long)rng[1] + 1);
+        }
+        if (jend <= jbeg) { jbeg = 0; jend = L; }                   // nothing visible at all: keep the unskipped behaviour
+        jbeg &= ~63;
+    }
     RowStage<DH, 64> stK, stV;
-    stK.load(kbase, p.ld_kv, 0, L - 1, tid);
-    stV.load(vbase, p.ld_kv, 0, L - 1, tid);
-    fetch_bias(0);
-    for (int j0 = 0; j0 < L; j0 += 64) {
+    stK.load(kbase, p.ld_kv, jbeg, L - 1, tid);
+    stV.load(vbase, p.ld_kv, jbeg, L - 1, tid);
+    fetch_bias(jbeg);
+    for (int j0 = jbeg; j0 < jend; j0 += 64) {
         __syncthreads();                                            // everyone is done reading the previous tile
         stK.store(ktile, tid);
         stV.store(vtile, tid);
         park_bias();
         __syncthreads();
-        if (j0 + 64 < L) {                                          // next tile's loads fly under this tile's MFMAs
+        if (j0 + 64 < jend) {                                       // next tile's loads fly under this tile's MFMAs
             stK.load(kbase, p.ld_kv, j0 + 64, L - 1, tid);
             stV.load(vbase, p.ld_kv, j0 + 64, L - 1, tid);
             fetch_bias(j0 + 64);
         }
         sub_step(j0, 0);
-        if (j0 + 32 < L) sub_step(j0 + 32, 1);
+        if (j0 + 32 < jend) sub_step(j0 + 32, 1);
     }
     l += __shfl_xor(l, 32, 64);
     if (i < L) {
@@ -345,10 +368,18 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) 
             for (int r = 0; r < 16; ++r) bv[r] = bf16_to_f32(bd[(unsigned)min(b0 + ((r & 3) + 8 * (r >> 2)) * L, bias_lim)]);
         }
     };
+    // narrow structured masks (launcher's choice, p.bwd_skip): both bf16 slabs were zeroed up front and only the query tiles that can see
+    // one of this workgroup's 128 keys are walked: query i meets key j iff i - left <= j <= i + right
+    int ibeg = 0, iend = L;
+    if (p.bwd_skip) {
+        ibeg = max(0, jw0 - p.mask_right) & ~63;
+        iend = (int)min((long)L, (long)jw0 + 127 + p.mask_left + 1);
+        if (iend <= ibeg) { ibeg = 0; iend = 0; }
+    }
     RowStage<DH, 32> stQ, stO;
-    stQ.load(qbase, p.ld_qu, 0, L - 1, tid);
-    stO.load(dobase, p.ld_o, 0, L - 1, tid);
-    fetch_bias(0);
+    stQ.load(qbase, p.ld_qu, ibeg, L - 1, tid);
+    stO.load(dobase, p.ld_o, ibeg, L - 1, tid);
+    fetch_bias(ibeg);
     auto step = [&](int i0) {
         __syncthreads();
         stQ.store(qtile, tid);
@@ -365,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) 
             }
         }
         __syncthreads();
-        if (i0 + 32 < L) {                                          // next tile's operands and bias fly under this tile's MFMAs
+        if (i0 + 32 < iend) {                                       // next tile's operands and bias fly under this tile's MFMAs
             stQ.load(qbase, p.ld_qu, i0 + 32, L - 1, tid);
             stO.load(dobase, p.ld_o, i0 + 32, L - 1, tid);
             fetch_bias(i0 + 32);
@@ -463,9 +494,9 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) 
             }
         }
     };
-    for (int i0 = 0; i0 < L; i0 += 64) {
+    for (int i0 = ibeg; i0 < iend; i0 += 64) {
         step(i0);
-        if (i0 + 32 < L) step(i0 + 32);
+        if (i0 + 32 < iend) step(i0 + 32);
     }
     if (kvalid) {
         float* dkrow = p.dK + ((long)b * L + j) * p.ld_dkv + h * DH;
@@ -676,10 +707,23 @@ int flash_attn_bwd(const FlashParams& p, hipStream_t st) {
     TTMI_REQUIRE(aligned16(p.qu) && aligned16(p.k) && aligned16(p.v) && aligned16(p.dO) && aligned16(p.dK) && aligned16(p.dV), "flash_attn_bwd: alignment");
     const long n = (long)p.B * p.L * p.H;
     dim3 grid(cdiv(p.L, 128), p.B * p.H);
+    FlashParams q = p;
+    // band / interval masks that leave at most half of the query tiles to a key block: zero the two bf16 slabs once (they must hold zeros
+    // wherever the mask cuts) and let the kernel skip the rest - 256 MB of memset against 3/4 of the kernel's loads, MFMAs and 2-byte stores
+    // (kind 4: callers that know nothing pass -1 / -1; 0 / 0 from callers written before the bounds existed is treated the same way)
+    const bool reach_known = p.mask_kind == 2 || (p.mask_kind == 4 && p.mask_left >= 0 && p.mask_right >= 0 && p.mask_left + p.mask_right > 0);
+    if (reach_known && ((long)p.mask_left + p.mask_right + 1 + 128 + 64) * 2 <= p.L && !(p.debug & 4)) {
+        const size_t bytes = (size_t)p.B * p.H * p.slab16 * sizeof(bf16_t);
+        if (hipMemsetAsync(p.dS16, 0, bytes, st) != hipSuccess || hipMemsetAsync(p.dG16, 0, bytes, st) != hipSuccess) {
+            ttmi_set_error("flash_attn_bwd: hipMemsetAsync failed");
+            return TTMI_EINVAL;
+        }
+        q.bwd_skip = 1;
+    }
     if (p.Dh == 64) hipLaunchKernelGGL(flash_delta_kernel<64>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta);
     else hipLaunchKernelGGL(flash_delta_kernel<32>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta);
-#define BWD_LAUNCH(MKV) do { if (p.Dh == 64) hipLaunchKernelGGL((flash_bwd_kernel<64, MKV>), grid, dim3(256), 64 * 128 + 256 + 8192 + 256, st, p); \
-                             else hipLaunchKernelGGL((flash_bwd_kernel<32, MKV>), grid, dim3(256), 64 * 64 + 256 + 8192 + 256, st, p); } while (0)
+#define BWD_LAUNCH(MKV) do { if (p.Dh == 64) hipLaunchKernelGGL((flash_bwd_kernel<64, MKV>), grid, dim3(256), 64 * 128 + 256 + 8192 + 256, st, q); \
+                             else hipLaunchKernelGGL((flash_bwd_kernel<32, MKV>), grid, dim3(256), 64 * 64 + 256 + 8192 + 256, st, q); } while (0)
     switch (p.mask_kind) {
         case 1: BWD_LAUNCH(1); break;
         case 2: BWD_LAUNCH(2); break;

@@ -49,7 +49,11 @@ def as_mask_spec(mask, B, L):
         lo = keep.int().argmax(-1)
         hi = t.shape[-1] - 1 - keep.flip(-1).int().argmax(-1)
         if bool(((n > 0) & (n == hi - lo + 1)).all()):             # one host sync per distinct mask tensor
-            spec = MaskSpec(4, tensor=torch.stack([lo, hi], -1).to(torch.int32).contiguous())
+            # how far the intervals reach from the diagonal (lo_i >= i - left, hi_i <= i + right): lets the backward kernel skip the
+            # query tiles a key block never meets (same host sync as the interval test)
+            rows = torch.arange(t.shape[1], device=t.device)
+            reach = torch.stack([(rows - lo).max(), (hi - rows).max()]).clamp_(min=0).tolist()
+            spec = MaskSpec(4, left=int(reach[0]), right=int(reach[1]), tensor=torch.stack([lo, hi], -1).to(torch.int32).contiguous())
     if len(_mask_cache) > 32:
         _mask_cache.clear()
     import weakref

@@ -116,13 +116,17 @@ class MaskSpec:
     [B|1, L, 2] of (lo, hi), key j of query i is masked iff j < lo or j > hi."""
     __slots__ = ("kind", "left", "right", "tensor")
 
-    def __init__(self, kind=0, left=0, right=0, tensor=None):
-        self.kind, self.left, self.right, self.tensor = kind, left, right, tensor
+    def __init__(self, kind=0, left=None, right=None, tensor=None):
+        unknown = -1 if kind == 4 else 0
+        self.kind, self.tensor = kind, tensor
+        self.left = unknown if left is None else left
+        self.right = unknown if right is None else right
 
     def args(self):
         t = self.tensor
         if self.kind == 4:
-            return c_int(4), c_int(0), c_int(0), _p(t), c_long(t.stride(0) if t.shape[0] > 1 else 0), c_long(2)
+            # left / right: bounds on how far the intervals reach from the diagonal (-1 = not known)
+            return c_int(4), c_int(self.left), c_int(self.right), _p(t), c_long(t.stride(0) if t.shape[0] > 1 else 0), c_long(2)
         if self.kind != 3:
             return c_int(self.kind), c_int(self.left), c_int(self.right), c_void_p(0), c_long(0), c_long(0)
         sb = t.stride(0) if t.shape[0] > 1 else 0
