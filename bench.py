@@ -186,8 +186,6 @@ def main():
     for kv in os.environ.get("TTMI_OPTIONS", "").split(","):          # measurement switches, e.g. TTMI_OPTIONS=3:0 (no wgrad fork); see include/ttmi.h
         if kv:
             ops.set_option(int(kv.split(":")[0]), int(kv.split(":")[1]))
-    if world > 1:
-        ops.set_option(6, 32)      # gradient all-reduce kernels run beside backward: the persistent encoder GEMMs leave them 4 CUs per XCD
 
     def step(timed, i=0):
         # harness front-end: fixed 80 -> d_model projection (the reference encoder has no input layer)
@@ -198,8 +196,12 @@ def main():
             ops.probe_arm(i % 64)                     # this step's joint-projection launch records into event pair i
         logits = model(inputs, targets)
         loss = criterion(logits, targets.int(), ilen, tlen)
+        if world > 1:
+            ops.set_option(6, 32)                     # gradient all-reduce kernels run beside backward: the persistent encoder GEMMs leave them 4 CUs per XCD
         loss.backward()
         sync.finish()
+        if world > 1:
+            ops.set_option(6, 0)                      # the next forward pass gets the whole chip (the option is read at launch time)
         opt.step()
         loss_sum.add_(loss.detach())
         return loss
