@@ -238,10 +238,12 @@ def main():
         peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
         ach = flop_launch / (k_ms * 1e-3) / 1e12
         traffic = None          # HBM-side bytes of one launch from the committed PMC passes (only valid for the default workload)
+        mfma_busy = None
         pmc = os.path.join(ROOT, "profiles", "pmc_joint_projection.json")
         if os.path.exists(pmc) and args.workload == "c2" and (B, T, U) == (32, 500, 50) and args.precision == "bf16":
             j = json.load(open(pmc))
             traffic = (2.0 * j["fetch_size_kb"] + j["write_size_kb"]) * 1024.0
+            mfma_busy = j.get("mfma_busy")           # SQ_VALU_MFMA_BUSY_CYCLES / elapsed SIMD cycles of the same launch (committed PMC pass)
         # the RNN-T loss op at the API boundary: logits read once, gradient written once, alpha / beta / lp_blank / lp_label in f32
         es = 2 if args.precision == "bf16" else 4
         loss_bytes = B * (2.0 * es * T * U1 * V + 16.0 * T * U1)
@@ -250,7 +252,7 @@ def main():
         loss_gbs = loss_bytes / ((lf + lb) * 1e-3) / 1e9
         roof_joint = {"bound": "mfma", "kernel": "gemm_nt_bf16_v8_kernel (joint vocabulary projection, M=%d N=%d K=%d)" % (B * T * U1, V, J),
                       "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                      "traffic": traffic, "kernel_ms": round(k_ms, 4)}
+                      "traffic": traffic, "mfma_busy": mfma_busy, "kernel_ms": round(k_ms, 4)}
         roof_loss = {"bound": "hbm", "kernel": "RNN-T loss op: rnnt_lse_kernel + rnnt_alphabeta_kernel (%.3f ms) + rnnt_grad_kernel (%.3f ms), "
                                                "logits [%d,%d,%d,%d] %s" % (lf, lb, B, T, U1, V, "bf16" if es == 2 else "f32"),
                      "achieved": round(loss_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(loss_gbs / HBM_PEAK_GBS, 4),
