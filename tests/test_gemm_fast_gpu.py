@@ -193,3 +193,24 @@ def test_persistent_256x128_wgrad_kernel_exact(M, N, K, cs):
     finally:
         ops.set_option(1, 4)
     assert torch.equal(C2, want + 1)
+
+
+@pytest.mark.parametrize("M,N,K", [(300000, 512, 128), (350000, 384, 128)])
+def test_streaming_store_path_exact(M, N, K):
+    """bf16 outputs of 256 MB and more leave the persistent kernels (v8 / v9, lean bias epilogue) as streaming stores: exact on small
+    integers, and the same bits with the streaming stores switched off (option 1 = 14)"""
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    A, B = _ints((M, K), g), _ints((N, K), g)
+    bias = torch.randint(-3, 4, (N,), device="cuda", generator=g).float()
+    C = torch.full((M, N), 5.0, device="cuda", dtype=torch.bfloat16)
+    ops.gemm_nt_bf16(A, B, C, bias)
+    want = (A[:50000].float() @ B.float().t() + bias).to(torch.bfloat16)
+    assert torch.equal(C[:50000], want) and torch.equal(C[-50000:], (A[-50000:].float() @ B.float().t() + bias).to(torch.bfloat16))
+    ops.set_option(1, 14)
+    try:
+        C2 = torch.full((M, N), 5.0, device="cuda", dtype=torch.bfloat16)
+        ops.gemm_nt_bf16(A, B, C2, bias)
+    finally:
+        ops.set_option(1, 15)
+    assert torch.equal(C2, C)

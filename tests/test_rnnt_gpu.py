@@ -178,3 +178,22 @@ def test_length_check_cache_follows_tensor_identity_and_version():
         crit(acts, labels, alen, llen)
     with pytest.raises(ValueError):
         crit(acts, labels, torch.full((B,), T + 1, device="cuda", dtype=torch.int32), llen)
+
+
+def test_timing_probes_fire_around_the_loss_kernels():
+    """ttmi_probe_arm(i) makes the next RNN-T loss forward (point 1) and backward (point 2) record HIP events into pair i; an unarmed
+    pair reads < 0"""
+    from ttmi import ops
+    from warprnnt_pytorch import RNNTLoss
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B, T, U, V = 2, 30, 5, 40
+    logits = torch.randn(B, T, U + 1, V, device="cuda", generator=g, requires_grad=True)
+    labels = torch.randint(1, V, (B, U), device="cuda", generator=g).int()
+    tl = torch.full((B,), T, dtype=torch.int32, device="cuda")
+    ul = torch.full((B,), U, dtype=torch.int32, device="cuda")
+    ops.probe_arm(7)
+    RNNTLoss()(logits, labels, tl, ul).backward()
+    torch.cuda.synchronize()
+    assert ops.probe_read_ms(7, 1) > 0 and ops.probe_read_ms(7, 2) > 0
+    assert ops.probe_read_ms(7, 1) < 0                   # consumed
+    assert ops.probe_read_ms(9, 1) < 0                   # never armed
