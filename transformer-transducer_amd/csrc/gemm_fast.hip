@@ -820,13 +820,8 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
 #define V8_BAR() __builtin_amdgcn_s_barrier()
 
     const int rounds = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    if (rounds > 8) {
-        // De-phase the XCDs.  In lockstep all 256 CUs write their output tile at the same moment and share the ~5.5 TB/s the HBM
-        // takes (6 us per 128 KiB tile); up to 64 CUs writing alone get 70 GB/s each (1.85 us).  Workgroups of one XCD re-synchronise
-        // by themselves (they draft behind each other's A/B panel fetches), so the stagger is per XCD: XCD x starts x/8 of a tile late.
-        const int n = nk * (blockIdx.x & 7) * 5;              // x/8 of ~40 64-cycle units per K-tile (measured: 7.49 -> 7.27 ms on the joint forward)
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
-    }
+    // (a per-XCD start stagger lived here: with the lean epilogue and streaming stores it measures as a 0.05 ms loss - phase offsets do not
+    // persist, see DESIGN.md - and is gone)
     int bm = 0, bn = 0;
     bool live = tile_id(0) < ntiles;               // the ids of one round are a permutation of it*grid .. it*grid + grid - 1
     if (live) { coords(tile_id(0), bm, bn); sources(bm, bn); prologue(); }
@@ -1096,10 +1091,6 @@ __global__ __launch_bounds__(NTH10, 1) void gemm_nt_bf16_v10_kernel(const FP p) 
     };
 
     const int rounds = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    if (rounds > 8) {                                   // per-XCD start stagger (see v8)
-        const int n = (ns >> 1) * (blockIdx.x & 7) * 5;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
-    }
     int bm = 0, bn = 0;
     bool live = tile_id(0) < ntiles;
     if (live) { coords(tile_id(0), bm, bn); sources(bm, bn); prologue(); }
