@@ -197,11 +197,11 @@ def main():
         logits = model(inputs, targets)
         loss = criterion(logits, targets.int(), ilen, tlen)
         if world > 1:
-            ops.set_option(6, 32)                     # gradient all-reduce kernels run beside backward: the persistent encoder GEMMs leave them 4 CUs per XCD
+            ops.reserve_cus(32)                       # gradient all-reduce kernels run beside backward: the persistent encoder GEMMs leave them 4 CUs per XCD (per-stream state)
         loss.backward()
         sync.finish()
         if world > 1:
-            ops.set_option(6, 0)                      # the next forward pass gets the whole chip (the option is read at launch time)
+            ops.reserve_cus(0)                        # the next forward pass gets the whole chip (read at launch time)
         opt.step()
         loss_sum.add_(loss.detach())
         return loss

@@ -130,9 +130,13 @@ int ttmi_gemm_nt_bf16(const void* A, const void* B, void* C, int c_dtype, const 
                       long ldb, long ldc, void* stream);
 int ttmi_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
                       float* colsum_a /* nullable: colsum_a[m] += sum_k A[k][m] */, void* stream);
-/* process-wide A/B switches for measurements: key 0: 1 = no fused attention kernels; 1: throughput-GEMM generation (csrc/gemm_fast.hip; 14 / 15 = streaming output stores off / on);
+/* data-parallel runs (train.py:55-56,214-219 replaced by one process per GPU + RCCL): the gradient all-reduce kernels run beside the
+ * backward pass; the encoder-sized persistent GEMMs launched on `stream` (and on the library's fork streams serving it) leave n CUs to
+ * them.  Per-stream state read at launch time; 0 = whole chip (default). */
+int ttmi_stream_reserve_cus(void* stream, int n);
+/* process-wide A/B switches for MEASUREMENTS ONLY (not thread-safe against concurrent launches, no product path depends on them): key 0: 1 = no fused attention kernels; 1: throughput-GEMM generation (csrc/gemm_fast.hip; 14 / 15 = streaming output stores off / on);
  * 2: flash-kernel timing bits; 3: 0 = no side-stream wgrad fork; 4: split-K workgroup target; 5: 1 = position-term slab by batched GEMM;
- * 6: n = CUs the encoder-sized persistent GEMMs leave free for communication kernels that run beside backward (data-parallel runs);
+ * 6: process-wide default of ttmi_stream_reserve_cus for streams that never set one;
  * 7: exact-f32 products with at most n rows use the skinny 32x32 split-reduction kernel (default 128, 0 = never: greedy decode A/B) */
 int ttmi_set_option(int key, int value);
 int ttmi_dropout_apply(const float* in, long n, float p, unsigned seed, float* out, void* stream);

@@ -43,6 +43,8 @@ int rnnt_oracle_f32(const float* logits, const int* labels, const int* act_lens,
         if (Tb < 1 || Tb > T || Ub < 0 || Ub > U) return 2;
         const float* x = logits + (size_t)b * T * U1 * V;
         const int* y = labels + (size_t)b * U;
+        /* rows are independent: threads over t (the GPU box's host cores; results do not depend on the thread count) */
+        #pragma omp parallel for schedule(static)
         for (int t = 0; t < Tb; ++t)
             for (int u = 0; u <= Ub; ++u) {
                 const float* r = x + ((size_t)t * U1 + u) * V;
@@ -73,6 +75,7 @@ int rnnt_oracle_f32(const float* logits, const int* labels, const int* act_lens,
         costs[b] = (float)(-ll);
         if (!grad) continue;
         float* g = grad + (size_t)b * T * U1 * V;
+        #pragma omp parallel for schedule(static)
         for (int t = 0; t < Tb; ++t)
             for (int u = 0; u <= Ub; ++u) {
                 const float* r = x + ((size_t)t * U1 + u) * V;

@@ -214,13 +214,19 @@ def rel_attn_bwd(dy, cache, p):
 # ----------------------------------------------------------------------------
 def ffn_fwd(x, p):
     h, c1 = layer_norm_fwd(x, p["ff_ln_g"], p["ff_ln_b"])
-    a = np.maximum(h @ p["ff_w1"].T + p["ff_b1"], 0)
+    z1 = h @ p["ff_w1"].T + p["ff_b1"]
+    # ReLU is discontinuous in its derivative: a unit whose pre-activation is within rounding noise of 0 may be on in one arithmetic and
+    # off in another, which changes gradients by a whole rank-1 term.  Like the dropout multipliers below, a test may therefore feed the
+    # ON/OFF decisions the checked implementation actually took ("relu_active", bool [B,L,Di]); absent = decide here (tt/transformer.py:45).
+    active = p.get("relu_active")
+    a = np.maximum(z1, 0) if active is None else np.where(active, z1, 0)
+    relu_on = (a > 0) if active is None else active
     one = np.ones((), dtype=x.dtype)                          # optional dropout multipliers: CoreNet.2, CoreNet.4, layer (:47,49,196)
     m_in, m_out, m_layer = (p.get(k, one) if p.get(k) is not None else one for k in ("drop_ff_in", "drop_ff_out", "drop_layer"))
     a = a * m_in
     f = (a @ p["ff_w2"].T + p["ff_b2"]) * m_out
     y, c2 = layer_norm_fwd(x + f, p["ff_ln_g"], p["ff_ln_b"])
-    return y * m_layer, dict(x=x, h=h, a=a, c1=c1, c2=c2, m_in=m_in, m_out=m_out, m_layer=m_layer)
+    return y * m_layer, dict(x=x, h=h, a=a, c1=c1, c2=c2, m_in=m_in, m_out=m_out, m_layer=m_layer, relu_on=relu_on, z1_abs_min=float(np.abs(z1).min()))
 
 
 def ffn_bwd(dy, cache, p):
@@ -232,7 +238,7 @@ def ffn_bwd(dy, cache, p):
     df = dres * cache["m_out"]
     g["ff_b2"] = df.reshape(-1, d).sum(0)
     g["ff_w2"] = df.reshape(-1, d).T @ a.reshape(-1, a.shape[-1])
-    da = (df @ p["ff_w2"]) * cache["m_in"] * (a > 0)
+    da = (df @ p["ff_w2"]) * cache["m_in"] * cache["relu_on"]
     g["ff_b1"] = da.reshape(-1, a.shape[-1]).sum(0)
     g["ff_w1"] = da.reshape(-1, a.shape[-1]).T @ h.reshape(-1, d)
     dh = da @ p["ff_w1"]
@@ -274,8 +280,16 @@ _LAYER_KEYS = {
 }
 
 
+_LAYER_EXTRAS = ("relu_active", "drop_attn", "drop_ff_in", "drop_ff_out", "drop_layer")     # optional per-layer test inputs, same key scheme
+
+
 def layer_params(sd, prefix, i):
-    return {k: sd["%slayers.%d.%s" % (prefix, i, v)] for k, v in _LAYER_KEYS.items()}
+    p = {k: sd["%slayers.%d.%s" % (prefix, i, v)] for k, v in _LAYER_KEYS.items()}
+    for k in _LAYER_EXTRAS:
+        v = sd.get("%slayers.%d.%s" % (prefix, i, k))
+        if v is not None:
+            p[k] = v
+    return p
 
 
 def n_layers(sd, prefix):

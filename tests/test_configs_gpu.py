@@ -1,0 +1,245 @@
+"""Parity at the sizes BASELINE.json's configs name, through the C ABI:
+
+* C5 (configs[4]): the lattice at B=8, T=2000, U=200, V=4334 in bf16 (properties at full size + C-oracle spot checks of a full and a
+  ragged utterance), an f32 lattice of the same T x U, and one audio-encoder layer at L=2000 (> K=410: the clamped-table branch of
+  tt/transformer.py:128-132) against the float64 oracle, unmasked and under a band mask.
+* C4 (configs[3], config/joint_streaming.yaml:24-45): the joint at J=2048, V=6485 over 33 600 lattice rows (8 column tiles in the
+  wgrad's fused bias sums) against fp32 torch, and an 18-layer-shape encoder layer (Di=2048) under context_mask(64, 0) and the
+  chunk(16, 64) mask against the float64 oracle.
+* C2 (configs[1]) end to end: the full 12 / 6 model in fp32 at B=2, T=500, U=50: logits, loss and every parameter gradient against
+  oracle.transducer_loss_and_grads, 1e-4 rel (north_star's fp32 tolerance).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import tt_oracle as O
+from oracle.rnnt_c import rnnt_loss_c
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+# ----------------------------------------------------------------------------------------------- C5: long-utterance lattice
+def test_c5_lattice_bf16_full_size():
+    """B=8, T=2000, U=200, V=4334, bf16 logits in the joint's row-padded layout (pitch 4352): every gradient row sums to zero
+    (softmax shift invariance), nothing outside a ragged utterance's lattice, pad columns zero; costs and gradients of one full and
+    one ragged utterance against the C oracle evaluated on the same bf16 values."""
+    from warprnnt_pytorch import RNNTLoss
+    B, T, U, V = 8, 2000, 200, 4334
+    Vp = (V + 63) // 64 * 64
+    g = torch.Generator(device="cuda").manual_seed(11)
+    buf = torch.empty(B, T, U + 1, Vp, device="cuda", dtype=torch.bfloat16)
+    for b in range(B):                                   # one utterance at a time: no 56 GB f32 temporary
+        buf[b] = (torch.randn(T, U + 1, Vp, device="cuda", generator=g) * 1.5).to(torch.bfloat16)
+    acts = buf[..., :V].detach().requires_grad_(True)
+    lab = torch.randint(1, V, (B, U), device="cuda", generator=g, dtype=torch.int32)
+    tl = torch.full((B,), T, dtype=torch.int32, device="cuda")
+    ul = torch.full((B,), U, dtype=torch.int32, device="cuda")
+    tl[3], ul[3] = 1500, 150
+    tl[5], ul[5] = 1999, 200
+    raw = []
+    acts.register_hook(raw.append)
+    costs = RNNTLoss(reduction="none")(acts, lab, tl, ul)
+    costs.sum().backward()
+    gr = raw[0]
+    assert gr.dtype is torch.bfloat16 and gr.stride(-2) == Vp
+    full = torch.as_strided(gr, (B, T, U + 1, Vp), gr.stride())
+    for b in range(B):
+        gb = full[b].float()
+        assert float(gb[..., V:].abs().max()) == 0
+        assert float(gb[..., :V].sum(-1).abs().max()) < 4e-3            # bf16-rounded rows of magnitude <= 1
+    assert float(gr[3, 1500:].float().abs().max()) == 0 and float(gr[3, :, 151:].float().abs().max()) == 0
+    assert float(gr[5, 1999:].float().abs().max()) == 0
+    for b in (0, 3):
+        xb = acts[b:b + 1].detach().float().cpu().numpy()
+        _, cb, gb = rnnt_loss_c(xb, lab[b:b + 1].cpu().numpy(), tl[b:b + 1].cpu().numpy(), ul[b:b + 1].cpu().numpy(), reduction="sum")
+        assert abs(float(costs[b]) - cb[0]) / cb[0] < 1e-5
+        assert rel_err(gr[b].float().cpu().numpy(), gb[0]) < 6e-3       # gradient rounded to bf16 once
+        del xb, gb
+
+
+def test_c5_lattice_f32_long():
+    """the same T x U in f32 (B=2, one ragged): costs and gradients against the C oracle at 1e-4"""
+    from warprnnt_pytorch import RNNTLoss
+    B, T, U, V = 2, 2000, 200, 4334
+    g = torch.Generator(device="cuda").manual_seed(12)
+    acts = torch.randn(B, T, U + 1, V, device="cuda", generator=g).requires_grad_(True)
+    lab = torch.randint(1, V, (B, U), device="cuda", generator=g, dtype=torch.int32)
+    tl = torch.tensor([T, 1777], dtype=torch.int32, device="cuda")
+    ul = torch.tensor([U, 93], dtype=torch.int32, device="cuda")
+    costs = RNNTLoss(reduction="none")(acts, lab, tl, ul)
+    costs.sum().backward()
+    assert float(acts.grad.sum(-1).abs().max()) < 2e-5
+    _, cb, gb = rnnt_loss_c(acts.detach().cpu().numpy(), lab.cpu().numpy(), tl.cpu().numpy(), ul.cpu().numpy(), reduction="sum")
+    assert float(np.abs(costs.detach().cpu().numpy() - cb).max() / np.abs(cb).max()) < TOL
+    assert rel_err(acts.grad.cpu().numpy(), gb) < TOL
+
+
+def _layer_vs_oracle(prec, B, L, K, Di, omask, mask, monkeypatch, H=8, Dh=64, seed=0):
+    from tt.encoder import BaseEncoder
+    monkeypatch.setenv("TTMI_PRECISION", prec)
+    d = H * Dh
+    torch.manual_seed(seed + L)
+    layer = BaseEncoder(k_len=K, n_head=H, d_model=d, d_head=Dh, d_inner=Di, dropout=0.0).cuda().eval()
+    gen = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(B, L, d, generator=gen)
+    cot = torch.randn(B, L, d, generator=gen)
+    xg = x.cuda().requires_grad_(True)
+    y = layer.forward_bm(xg, mask)
+    (y * cot.cuda()).sum().backward()
+    sd = {"encoder.layers.0." + k: v.detach().cpu().numpy().astype(np.float64) for k, v in layer.state_dict().items()}
+    prm = O.layer_params(sd, "encoder.", 0)
+    want, cache = O.layer_fwd(x.numpy().astype(np.float64), prm, omask)
+    dxo, go = O.layer_bwd(cot.numpy().astype(np.float64), cache, prm)
+    names = {v: k for k, v in O._LAYER_KEYS.items()}
+    e_out = rel_err(y.detach().cpu().numpy(), want)
+    e_dx = rel_err(xg.grad.cpu().numpy(), dxo)
+    e_g = {n: rel_err(p.grad.cpu().numpy(), go[names[n]]) for n, p in layer.named_parameters()}
+    print("%s L=%d: out %.2e dx %.2e worst grad %.2e (%s)" % (prec, L, e_out, e_dx, max(e_g.values()), max(e_g, key=e_g.get)))
+    return e_out, e_dx, e_g
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("mk", ["none", "band"])
+def test_c5_encoder_layer_L2000(prec, mk, monkeypatch):
+    """one C2-shape audio layer (d=512, 8 x 64 heads, Di=1024, K=410) at L=2000: the table is shorter than the sequence, so relative
+    positions beyond K-1 clamp onto row 0 and their gradients fold back onto it (tt/transformer.py:128-132)"""
+    from ttmi.ops import MaskSpec
+    L = 2000
+    mask, omask = (MaskSpec(0), None) if mk == "none" else (MaskSpec(2, left=64, right=0), O.context_mask(L, 64, 0)[:, :, None])
+    e_out, e_dx, e_g = _layer_vs_oracle(prec, 2, L, 410, 1024, omask, mask, monkeypatch)
+    if prec == "fp32":
+        assert e_out < TOL and e_dx < TOL and max(e_g.values()) < TOL
+    else:
+        assert e_out < 3e-2 and e_dx < 8e-2 and max(e_g.values()) < 8e-2
+
+
+# ----------------------------------------------------------------------------------------------- C4: joint_streaming.yaml dims
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("mk", ["band_64_0", "chunk_16_64"])
+def test_c4_encoder_layer_under_streaming_masks(prec, mk, monkeypatch):
+    """config/joint_streaming.yaml:27-31 layer (d=512, 8 x 64, Di=2048, K=410) at T=500 under BASELINE configs[3]'s two masks:
+    context_mask(left=64, right=0) handed over parametrically and the chunk mask (16-frame blocks + 64 left) handed over as the
+    reference would, a [T, T, 1] tensor"""
+    from tt.transformer import as_mask_spec
+    from ttmi.ops import MaskSpec
+    B, L = 4, 500
+    if mk == "band_64_0":
+        mask, om = MaskSpec(2, left=64, right=0), O.context_mask(L, 64, 0)
+    else:
+        om = O.chunk_mask(L, 16, 64)
+        mask = as_mask_spec(torch.tensor(om != 0).cuda()[:, :, None], B, L)
+        assert mask.kind == 4
+    e_out, e_dx, e_g = _layer_vs_oracle(prec, B, L, 410, 2048, om[:, :, None], mask, monkeypatch, seed=7)
+    if prec == "fp32":
+        assert e_out < TOL and e_dx < TOL and max(e_g.values()) < TOL
+    else:
+        assert e_out < 3e-2 and e_dx < 8e-2 and max(e_g.values()) < 8e-2
+
+
+def test_c4_joint_dims_vs_torch(monkeypatch):
+    """the joint at config/joint_streaming.yaml:43-45 sizes (inner 2048, V=6485) over 33 600 lattice rows in the bf16 pipeline:
+    v8 forward (26 column tiles), v8 dgrad with the tanh' epilogue (K = 6528), TN v8 wgrad whose fused bias column sums span 8 column
+    tiles of J (the case a first version got wrong, profiles/r01_bench_c4-band_before_colsum_fix_kernel_stats.csv)"""
+    from tt.model import JointNet
+    monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    J, V, B, T, U1, de = 2048, 6485, 4, 400, 21, 512
+    torch.manual_seed(J)
+    joint = JointNet(2 * de, J, V).cuda()
+    enc = torch.randn(B, T, de, device="cuda", requires_grad=True)
+    dec = torch.randn(B, U1, de, device="cuda", requires_grad=True)
+    cot = torch.randn(B, T, U1, V, device="cuda")
+    out = joint(enc, dec)
+    assert out.dtype is torch.bfloat16 and out.stride(-2) == 6528
+    (out.float() * cot).sum().backward()
+    got = [out.detach().float(), enc.grad.clone(), dec.grad.clone()] + [p.grad.clone() for p in joint.parameters()]
+    enc.grad = dec.grad = None
+    joint.zero_grad()
+    Wf, bf, Wp, bp = joint.forward_layer.weight, joint.forward_layer.bias, joint.project_layer.weight, joint.project_layer.bias
+    h = torch.tanh((enc @ Wf[:, :de].t())[:, :, None, :] + (dec @ Wf[:, de:].t())[:, None, :, :] + bf)
+    ref = h @ Wp.t() + bp
+    (ref * cot).sum().backward()
+    want = [ref.detach(), enc.grad, dec.grad] + [p.grad for p in joint.parameters()]
+    names = ["logits", "denc", "ddec", "g_wf", "g_bf", "g_wp", "g_bp"]
+    for n, g, w in zip(names, got, want):
+        e = rel_err(g.cpu().numpy(), w.cpu().numpy())
+        print(n, "%.2e" % e)
+        assert e < 2e-2, n
+    # the bias gradient is a plain column sum of the cotangent (rounded to bf16 by the pipeline): tight check on every one of its 6485 entries
+    assert rel_err(got[6].cpu().numpy(), cot.to(torch.bfloat16).float().sum((0, 1, 2)).cpu().numpy()) < 1e-4
+
+
+# ----------------------------------------------------------------------------------------------- C2 end to end
+def test_c2_full_model_fp32_end_to_end(monkeypatch):
+    """BASELINE configs[1] model (12 audio / 6 label layers, d_model=512, Di=1024, J=1024, V=4334, K=410/42; 48.2 M parameters, random
+    init) at B=2, T=500, U=50 in fp32: logits, loss, input gradient and EVERY parameter gradient against the float64 oracle.
+
+    ReLU decisions: among the 12.6 M FFN hidden units of this run a handful have pre-activations within f32 rounding noise of zero
+    (smallest |z| here: 7e-8); whether such a unit counts as active is decided by the last bit, and a single flipped unit changes the
+    gradients upstream of it by ~3e-4 relative (1 / sqrt(#units)) - in ANY fp32 implementation, the reference's included.  As with the
+    dropout masks, the oracle is therefore fed the ON/OFF decisions the HIP path actually took (read from the saved activations of
+    ttmi_ffn_fwd); that they differ from the oracle's own decisions only on near-zero units is asserted."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from tt.model import Transducer
+    from ttmi import ops
+    from warprnnt_pytorch import RNNTLoss
+    monkeypatch.setenv("TTMI_PRECISION", "fp32")
+    cfg = bench.c2_config()
+    cfg["dropout"] = 0.0
+    torch.manual_seed(1)
+    model = Transducer(cfg).cuda().eval()
+    assert sum(p.numel() for p in model.parameters()) == 48222862
+    B, T, U, V = 2, 500, 50, 4334
+    gen = torch.Generator().manual_seed(1234)
+    inp = torch.randn(B, T, 512, generator=gen)
+    tgt = torch.randint(1, V, (B, U), generator=gen)
+    tl, ul = np.array([T, 431], dtype=np.int32), np.array([U, 37], dtype=np.int32)
+    saved = []                                               # (ctx, rows, d, Di) of every FFN forward, in host issue order
+    real_ffn_fwd = ops.ffn_fwd
+
+    def spy(y, p, prec, *a, **k):
+        z, ctx = real_ffn_fwd(y, p, prec, *a, **k)
+        saved.append((ctx, y.numel() // y.shape[-1], y.shape[-1], p["ff_w1"].shape[0], tuple(y.shape[:-1])))
+        return z, ctx
+
+    monkeypatch.setattr(ops, "ffn_fwd", spy)
+    x = inp.cuda().requires_grad_(True)
+    logits = model(x, tgt.cuda())
+    loss = RNNTLoss()(logits, tgt.int().cuda(), torch.tensor(tl).cuda(), torch.tensor(ul).cuda())
+    loss.backward()
+    ops.join_side_streams()
+    torch.cuda.synchronize()
+    sd64 = {k: (v.detach().cpu().numpy().astype(np.float64) if v.dtype == torch.float32 else v.detach().cpu().numpy())
+            for k, v in model.state_dict().items()}
+    assert len(saved) == 18                                  # 12 audio layers (queued first), then 6 label layers
+    for n, (ctx, rows, d, Di, lead) in enumerate(saved):
+        off = (rows * d * 4 + 255) // 256 * 256 // 4        # FfnCtx (csrc/layers.hip): h [rows, d] f32, then a1 [rows, Di] f32, 256-byte aligned
+        a1 = ctx[off:off + rows * Di].view(*lead, Di)
+        key = ("encoder.layers.%d" % n) if n < 12 else ("decoder.layers.%d" % (n - 12))
+        sd64[key + ".relu_active"] = (a1 > 0).cpu().numpy()
+    own = O.transducer_fwd(inp.numpy().astype(np.float64), tgt.numpy(), {k: v for k, v in sd64.items() if not k.endswith("relu_active")})[1]
+    flips = 0
+    for i, (ca, cf) in enumerate(own[0]):                    # the oracle's own decisions differ from the HIP path's only on near-zero units
+        diff = cf["relu_on"] != sd64["encoder.layers.%d.relu_active" % i]
+        flips += int(diff.sum())
+        if diff.any():
+            z1 = np.abs((cf["h"] @ sd64["encoder.layers.%d.MultiHeadAttention.pos_ff.CoreNet.0.weight" % i].T +
+                         sd64["encoder.layers.%d.MultiHeadAttention.pos_ff.CoreNet.0.bias" % i])[diff])
+            assert z1.max() < 1e-5, (i, z1.max())
+    want = O.transducer_loss_and_grads(inp.numpy().astype(np.float64), tgt.numpy(), tl, ul, sd64)
+    assert rel_err(logits.detach().cpu().numpy(), want["logits"]) < TOL
+    assert abs(float(loss.detach()) - want["loss"]) / want["loss"] < TOL
+    assert rel_err(x.grad.cpu().numpy(), want["dinputs"]) < TOL
+    worst = ("", 0.0)
+    for name, p in model.named_parameters():
+        e = rel_err(p.grad.cpu().numpy(), want["grads"][name])
+        if e > worst[1]:
+            worst = (name, e)
+        assert e < TOL, (name, e)
+    print("C2 end to end fp32: loss rel %.2e, dinputs %.2e, worst gradient %s %.2e, ReLU units decided differently from float64: %d"
+          % (abs(float(loss.detach()) - want["loss"]) / want["loss"], rel_err(x.grad.cpu().numpy(), want["dinputs"]), worst[0], worst[1], flips))

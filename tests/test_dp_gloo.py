@@ -36,7 +36,10 @@ def _worker(rank, world, port, q):
         loss = ((model(xs) - ys) ** 2).sum() / 4            # 'mean' over the LOCAL batch, like RNNTLoss(reduction='mean')
         loss.backward()
         sync.finish()
-    q.put((rank, flat.grad.clone() / world, [p.data_ptr() == flat.flat[o:o + 1].data_ptr() for p, o in zip(flat.params, flat.offsets)]))
+    from tt import transformer as tr
+    torch.manual_seed(9)                                    # every rank seeds torch alike (identical init) ...
+    seed = tr._new_seed(0.1)                                # ... and still draws its own dropout masks
+    q.put((rank, flat.grad.clone() / world, [p.data_ptr() == flat.flat[o:o + 1].data_ptr() for p, o in zip(flat.params, flat.offsets)], seed))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -59,7 +62,8 @@ def test_bucketed_allreduce_matches_full_batch():
     y = torch.randn(8, 5, generator=g)
     (((model(x) - y) ** 2).sum() / 8).backward()
     want = torch.cat([torch.nn.functional.pad(p.grad.reshape(-1), (0, (-p.numel()) % 4)) for p in model.parameters()])
-    for rank, got, views in res:
+    assert res[0][3] != res[1][3] and all(0 <= r[3] < 2 ** 31 for r in res)      # rank-mixed dropout seeds
+    for rank, got, views, _ in res:
         assert all(views)                                    # parameters really are views of the flat buffer
         assert torch.allclose(got, want, rtol=1e-5, atol=1e-7), rank
     assert torch.equal(res[0][1], res[1][1])                 # identical reduced gradients on every rank

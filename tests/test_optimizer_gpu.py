@@ -1,0 +1,165 @@
+"""Training-step tail and checkpointing: the fused clip + SGD / Adam kernels on the flat buffers against
+torch.optim over several steps (so the momentum / moment recurrences are exercised, not just their first step), epoch decay
+(tt/optim.py:30-33), and save -> reload -> continue in the reference's `.chkpt` layout (tt/utils.py:80-91, train.py:196-212,234-241)
+bit-identical to an uninterrupted run."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(dropout=0.0):
+    from tt.utils import AttrDict
+    side = dict(n_layer=1, d_model=64, n_head=2, d_head=32, d_inner=96)
+    return AttrDict(dict(enc=dict(side, max_input_length=16), dec=dict(side, max_target_length=8),
+                         joint=dict(input_size=128, inner_size=48), vocab_size=29, dropout=dropout))
+
+
+def _batch(step):
+    g = torch.Generator().manual_seed(100 + step)
+    return torch.randn(3, 20, 64, generator=g).cuda(), torch.randint(1, 29, (3, 6), generator=g).cuda()
+
+
+def _loss(model, x, y):
+    from warprnnt_pytorch import RNNTLoss
+    B = x.shape[0]
+    return RNNTLoss()(model(x, y), y.int(), torch.full((B,), 20, dtype=torch.int32).cuda(), torch.full((B,), 6, dtype=torch.int32).cuda())
+
+
+@pytest.mark.parametrize("kind,clip", [("sgd", 5.0), ("sgd", 0.0), ("adam", 5.0), ("adam", 0.0)])
+def test_fused_update_matches_torch_over_five_steps(kind, clip):
+    """same gradients fed to both optimizers for five steps: torch.nn.utils.clip_grad_norm_ + torch.optim.{SGD(momentum .9),
+    Adam(betas (.9, .98), eps 1e-8)} (tt/optim.py:57-73) against ttmi_sumsq + ttmi_sgd_step / ttmi_adam_step"""
+    from ttmi.train import FlatModel, FusedOptimizer
+    torch.manual_seed(3)
+    ref = torch.nn.Sequential(torch.nn.Linear(37, 50), torch.nn.Linear(50, 11)).cuda()
+    mine = copy.deepcopy(ref)
+    flat = FlatModel(mine)
+    lr = 0.05 if kind == "sgd" else 0.01
+    opt = FusedOptimizer(flat, kind=kind, lr=lr, momentum=0.9, weight_decay=1e-3, max_grad_norm=clip)
+    topt = (torch.optim.SGD(ref.parameters(), lr=lr, momentum=0.9, weight_decay=1e-3) if kind == "sgd" else
+            torch.optim.Adam(ref.parameters(), lr=lr, betas=(0.9, 0.98), eps=1e-8, weight_decay=1e-3))
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for step in range(5):
+        for pr, pm in zip(ref.parameters(), mine.parameters()):
+            gr = torch.randn(pr.shape, device="cuda", generator=g) * (3.0 if step % 2 else 0.3)     # some steps clip, some do not
+            pr.grad = gr.clone()
+            pm.grad.copy_(gr)
+        if clip:
+            norm = torch.nn.utils.clip_grad_norm_(ref.parameters(), clip)
+        topt.step()
+        opt.step()
+        if clip:
+            assert abs(float(opt.grad_norm()) - float(norm)) / float(norm) < 1e-5
+        for pr, pm in zip(ref.parameters(), mine.parameters()):
+            assert rel_err(pm.detach().cpu().numpy(), pr.detach().cpu().numpy()) < 2e-6, (kind, step)
+    # and the states agree, in torch's own layout
+    sd, tsd = opt.state_dict(), topt.state_dict()
+    for i in tsd["state"]:
+        for k, v in tsd["state"][i].items():
+            if k == "step":
+                assert float(sd["state"][i][k]) == float(v)
+            else:
+                assert rel_err(sd["state"][i][k].cpu().numpy(), v.cpu().numpy()) < 2e-6, k
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adam"])
+def test_checkpoint_resume_is_bit_identical(kind, tmp_path):
+    """3 steps, save in the reference's checkpoint layout, 3 more steps; a fresh model + optimizer restored from the file and run for
+    the same 3 steps ends with the same bits in every parameter and optimizer state (the HIP model, dropout off: gradients are
+    deterministic functions of the weights apart from atomic-order noise, so the batch is fixed and the comparison is on the update)"""
+    from tt.model import Transducer
+    from ttmi.train import FlatModel, FusedOptimizer, load_checkpoint, save_checkpoint
+
+    def make():
+        torch.manual_seed(1)
+        model = Transducer(_cfg()).cuda().train()
+        flat = FlatModel(model)
+        return model, flat, FusedOptimizer(flat, kind=kind, lr=0.01, momentum=0.9, max_grad_norm=5.0, decay_ratio=0.5)
+
+    grads = []                                              # gradients are recorded once and replayed, so both runs see the same bits
+
+    def run(model, flat, opt, steps, record):
+        for s in steps:
+            flat.zero_grad()
+            if record:
+                _loss(model, *_batch(s)).backward()
+                grads.append(flat.grad.clone())
+            else:
+                flat.grad.copy_(grads[s])
+            opt.step()
+            if s == 3:
+                opt.epoch()
+                opt.decay_lr()
+
+    model, flat, opt = make()
+    run(model, flat, opt, range(3), True)
+    path = str(tmp_path / "tt.epoch0.chkpt")
+    save_checkpoint(model, opt, path)
+    run(model, flat, opt, range(3, 6), True)
+    ck = torch.load(path)
+    assert set(ck) == {"encoder", "decoder", "joint", "optimizer", "epoch", "step"} and ck["step"] == 4 and ck["epoch"] == 0
+    assert "layers.0.MultiHeadAttention.dec_attn.qkv_net.weight" in ck["encoder"] and "dec_embedding.weight" in ck["decoder"]
+
+    model2, flat2, opt2 = make()
+    with torch.no_grad():
+        flat2.flat.add_(1.0)                                # prove the weights come from the file
+    load_checkpoint(model2, opt2, path, mode="continue")
+    assert opt2.global_step == 4 and opt2.current_epoch == 0
+    assert all(p.data_ptr() == flat2.flat.data_ptr() + 4 * o for p, o in zip(flat2.params, flat2.offsets))     # still views
+    run(model2, flat2, opt2, range(3, 6), False)
+    assert opt2.lr == opt.lr == 0.005 and opt2.global_step == opt.global_step == 7 and opt2.current_epoch == 1
+    assert torch.equal(flat2.flat, flat.flat)
+    for a, b in zip(opt2.state, opt.state):
+        assert torch.equal(a, b)
+
+
+def test_reference_shaped_optimizer_wrapper():
+    """tt.optim.Optimizer(model.parameters(), config.optim) with the reference's surface and YAML keys (config/aishell.yaml optim
+    section): used the way train.py uses it - zero_grad, backward, clip_grad_norm_, step, epoch, decay_lr - against torch.optim.SGD"""
+    from tt.model import Transducer
+    from tt.optim import Optimizer
+    from tt.utils import AttrDict
+    ocfg = AttrDict(dict(type="sgd", lr=0.01, momentum=0.9, decay_ratio=0.5, weight_decay=0, begin_to_adjust_lr=60, nesterov=None))
+    torch.manual_seed(1)
+    model = Transducer(_cfg()).cuda().train()
+    ref = Transducer(_cfg()).cuda().train()
+    ref.load_state_dict(model.state_dict())
+    opt = Optimizer(model.parameters(), ocfg)
+    topt = torch.optim.SGD(ref.parameters(), lr=0.01, momentum=0.9)
+    assert opt.global_step == 1 and opt.current_epoch == 0 and opt.lr == 0.01
+    for s in range(3):
+        for m, o in ((model, opt), (ref, topt)):
+            o.zero_grad()
+            _loss(m, *_batch(s)).backward()
+            torch.nn.utils.clip_grad_norm_(m.parameters(), 200.0)           # train.py:62-63
+            o.step()
+    assert opt.global_step == 4
+    for (n, a), b in zip(model.named_parameters(), ref.parameters()):
+        assert rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy()) < 1e-5, n
+    opt.epoch()
+    opt.decay_lr()
+    assert opt.current_epoch == 1 and opt.lr == 0.005 and opt.param_groups[0]["lr"] == 0.005
+    topt.load_state_dict(opt.state_dict())                  # torch.optim accepts our state_dict as it stands
+    with pytest.raises(NotImplementedError):
+        Optimizer(model.parameters(), AttrDict(dict(type="adadelta", lr=1.0)))
+
+
+def test_embedding_index_contract():
+    """nn.Embedding (tt/decoder.py:26) takes int32 or int64 ids; anything else raises, and an id outside [0, V) does not pass as
+    some other row"""
+    from ttmi import ops
+    W = torch.randn(11, 8, device="cuda")
+    ids = torch.tensor([[1, 5, 10]], device="cuda")
+    a = ops.embed_fwd(ids, W)
+    assert torch.equal(a, W[ids]) and torch.equal(ops.embed_fwd(ids.int(), W), a)
+    with pytest.raises(TypeError):
+        ops.embed_fwd(ids.float(), W)
+    bad = ops.embed_fwd(torch.tensor([[1, 11, -1]], device="cuda"), W)
+    assert torch.isnan(bad[0, 1]).all() and torch.isnan(bad[0, 2]).all() and torch.equal(bad[0, 0], W[1])

@@ -43,4 +43,7 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
                  hipStream_t st, float* colsum_a = nullptr, const FastBatch& batch = FastBatch());
 void gemm_fast_set_version(int v);   // kernel generation for A/B runs, see gemm_fast.hip (default 4)
 void gemm_fast_set_tn_target(int n);
-void gemm_fast_set_reserved_cus(int n);   // CUs left free by the mid-sized persistent GEMMs (for concurrent RCCL kernels)
+void gemm_fast_set_reserved_cus(int n);   // process-wide default (measurement switch)
+void gemm_fast_stream_reserve_cus(hipStream_t st, int n);   // per-stream state: launches on `st` (and on fork streams aliased to it) leave n CUs free
+void gemm_fast_alias_stream(hipStream_t child, hipStream_t parent);
+//   // CUs left free by the mid-sized persistent GEMMs (for concurrent RCCL kernels)

@@ -13,6 +13,7 @@
 // Workgroups are renumbered so the 8 that share an XCD (ids equal mod 8) walk a compact 8x8-tile window
 // (A and B panels of ~2 MB each stay in that XCD's 4 MB L2).
 #include "gemm_fast.h"
+#include <mutex>
 
 namespace {
 
@@ -1818,7 +1819,32 @@ int enable_lds(K kernel, int bytes) {
 int g_gemm_fast_version = 4;
 int g_nt_stores = 1;             // streaming stores for bf16 outputs >= 256 MB (set_version(14 / 15) = off / on, generation unchanged)
 int g_num_cus = 0;
-int g_reserved_cus = 0;           // ttmi_set_option(6, n): CUs the mid-sized persistent GEMMs leave to concurrently running communication kernels
+int g_reserved_cus = 0;           // ttmi_set_option(6, n): process-wide default of the per-stream reservation below (measurement switch)
+// CUs the mid-sized persistent GEMMs leave to concurrently running communication kernels: PER-STREAM state (ttmi_stream_reserve_cus), so a
+// data-parallel backward pass on one stream does not change what another stream or thread launches.  Library-owned fork streams answer
+// for the caller stream they serve (gemm_fast_alias_stream).
+struct StreamRes { int dev; hipStream_t st, parent; int n; bool has_n; };
+constexpr int MAX_RES = 64;
+StreamRes g_res[MAX_RES];
+int g_nres = 0;
+std::mutex g_res_mu;
+
+StreamRes* res_entry(int dev, hipStream_t st, bool create) {
+    for (int i = 0; i < g_nres; ++i)
+        if (g_res[i].dev == dev && g_res[i].st == st) return &g_res[i];
+    if (!create || g_nres == MAX_RES) return nullptr;
+    g_res[g_nres] = StreamRes{dev, st, st, 0, false};
+    return &g_res[g_nres++];
+}
+
+int reserved_cus(hipStream_t st) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_res_mu);
+    StreamRes* e = res_entry(dev, st, false);
+    if (e && e->parent != st) e = res_entry(dev, e->parent, false);
+    return e && e->has_n ? e->n : g_reserved_cus;
+}
 int g_tn_target_blocks = 512;     // split-K aims at this many workgroups for small outputs (ttmi_set_option(4, n))
 
 
@@ -1860,14 +1886,15 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     // whole number of rounds over the CUs (joint: v8; encoder N = 512 / 1536: v9; N = 2048: v8), the 128x128 kernel for small outputs
     const long t9 = (long)cdiv(M, T9M) * cdiv(N, T9N), t8 = (long)cdiv(M, T8) * cdiv(N, T8);
     const bool pers = nbatch == 1 && M >= 1024 && N >= 128 && K >= 128 && K % TK == 0 && !dual;
-    const int cus_avail = std::max(8, (g_num_cus - g_reserved_cus) / 8 * 8);
+    const int reserved = reserved_cus(st);
+    const int cus_avail = std::max(8, (g_num_cus - reserved) / 8 * 8);
     const double cost9 = (double)cdiv(t9, cus_avail), cost8 = N >= 256 ? 1.8 * cdiv(t8, t8 < 1024 ? cus_avail : g_num_cus) : 1e30;
     const bool v9 = pers && ((g_gemm_fast_version == 9) || (g_gemm_fast_version == 4 && t9 >= g_num_cus * 3 / 4 && cost9 <= cost8));
     if (v9) {
         p.tiles_m = cdiv(M, T9M); p.tiles_n = cdiv(N, T9N);
         // a persistent grid larger than the CUs that are actually free runs its surplus workgroups AFTER the others (twice the time):
         // with gradient all-reduce kernels resident during backward, leave them room (multi-GPU runs set option 6)
-        const int cus9 = std::max(8, (g_num_cus - g_reserved_cus) / 8 * 8);
+        const int cus9 = std::max(8, (g_num_cus - reserved) / 8 * 8);
         const int grid9 = (int)((std::min<long>(t9, cus9) + 7) / 8 * 8);
         // lean epilogue instances (nothing tested per store): plain / bias-only for both output types, mask-only for bf16
         const bool base_ok = !p.addend && !p.relu && p.drop.p <= 0.f && aligned16(C) && (!p.bias || aligned16(p.bias));
@@ -1891,7 +1918,7 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     if (pers && N >= 256 && g_gemm_fast_version >= 10 && g_gemm_fast_version <= 13) {
         p.tiles_m = cdiv(M, T10); p.tiles_n = cdiv(N, T10);
         const long nwg10 = (long)p.tiles_m * p.tiles_n;
-        const int cus10 = nwg10 < 1024 ? std::max(8, (g_num_cus - g_reserved_cus) / 8 * 8) : g_num_cus;
+        const int cus10 = nwg10 < 1024 ? std::max(8, (g_num_cus - reserved) / 8 * 8) : g_num_cus;
         const int grid10 = (int)((std::min<long>(nwg10, cus10) + 7) / 8 * 8);
         if (c_dtype == 0) {
             if (int rc = enable_lds(gemm_nt_bf16_v10_kernel<float>, LDS10)) return rc;
@@ -1919,7 +1946,7 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     if (v8) {
         p.tiles_m = cdiv(M, T8); p.tiles_n = cdiv(N, T8);
         const long nwg8 = (long)p.tiles_m * p.tiles_n;
-const int cus8 = nwg8 < 1024 ? std::max(8, (g_num_cus - g_reserved_cus) / 8 * 8) : g_num_cus;   // encoder-sized problems only (see v9)
+const int cus8 = nwg8 < 1024 ? std::max(8, (g_num_cus - reserved) / 8 * 8) : g_num_cus;   // encoder-sized problems only (see v9)
         const int grid8 = (int)((std::min<long>(nwg8, cus8) + 7) / 8 * 8);   // multiple of 8: one share of every round per XCD
 if (c_dtype == 0) {
             if (int rc = enable_lds(gemm_nt_bf16_v8_kernel<float>, LDS8)) return rc;
@@ -1999,7 +2026,7 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
     if (tn9) {
         p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
         p.tiles_m = M / T9M; p.tiles_n = N / T9N;
-        const int cus = std::max(8, (g_num_cus - g_reserved_cus) / 8 * 8), ncu_x = cus / 8, ntile = p.tiles_m * p.tiles_n;
+        const int cus = std::max(8, (g_num_cus - reserved_cus(st)) / 8 * 8), ncu_x = cus / 8, ntile = p.tiles_m * p.tiles_n;
         // ranges per XCD: keep every item >= ~16 K-tiles long (atomics per output element grow with the number of ranges) and fill the XCD's
         // workgroups as evenly as the tile count allows
         const int nkt = cdiv(K, TK);
@@ -2094,6 +2121,18 @@ void gemm_fast_set_version(int v) {
 }
 void gemm_fast_set_tn_target(int n) { g_tn_target_blocks = n; }
 void gemm_fast_set_reserved_cus(int n) { g_reserved_cus = n < 0 ? 0 : n; }
+void gemm_fast_stream_reserve_cus(hipStream_t st, int n) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_res_mu);
+    if (StreamRes* e = res_entry(dev, st, true)) { e->n = n < 0 ? 0 : n; e->has_n = true; }
+}
+void gemm_fast_alias_stream(hipStream_t child, hipStream_t parent) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_res_mu);
+    if (StreamRes* e = res_entry(dev, child, true)) e->parent = parent;
+}
 
 extern "C" {
 // bring-up / test entry points (dtype codes 0 = f32, 1 = bf16)

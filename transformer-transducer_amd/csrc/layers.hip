@@ -13,6 +13,7 @@
 #include "rowops.h"
 #include "gemm_fast.h"
 #include "attn_flash.h"
+#include <mutex>
 
 void ttmi_probe_begin(int slot, hipStream_t st);
 void ttmi_probe_end(int slot, hipStream_t st);
@@ -61,23 +62,34 @@ int wgrad(const float* dY, const float* X, float* gW, int M, int N, int K, long 
 int g_fork_wgrad = 1;
 int g_gemm_slab = 0;            // ttmi_set_option(5, 1): position-term slab by the batched GEMM (A/B measurements)
 struct SideCtx {
+    int device = -1;
     hipStream_t main = nullptr, side = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     int next = 0;
     bool used = false;
 };
-SideCtx g_side[8];
+// One fork context per (device, caller stream): the default stream is nullptr on EVERY device, and autograd runs one backward thread
+// per device, so the table is keyed by both and guarded by a mutex (creation is rare; a lookup is a short scan).  A context itself is
+// only ever used by the thread that owns its caller stream's work.
+constexpr int MAX_SIDE = 64;
+SideCtx g_side[MAX_SIDE];
 int g_nside = 0;
+std::mutex g_side_mu;
 
 SideCtx* side_for(hipStream_t main) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(g_side_mu);
     for (int i = 0; i < g_nside; ++i)
-        if (g_side[i].main == main) return &g_side[i];
-    if (g_nside == 8) return nullptr;
+        if (g_side[i].main == main && g_side[i].device == dev) return &g_side[i];
+    if (g_nside == MAX_SIDE) return nullptr;
     SideCtx& c = g_side[g_nside];
     if (hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
     for (auto& e : c.ev)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
     c.main = main;
+    c.device = dev;
+    gemm_fast_alias_stream(c.side, main);       // the fork stream answers for its caller stream's CU reservation
     ++g_nside;
     return &c;
 }
@@ -768,6 +780,14 @@ int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float*
     CK(wgrad(dPD, dec, g_wf + de, J, dd, B * U1, J, dd, din, prec, st));
     CK(ttmi_launch_gemm(mk(dPE, wf, denc, B * T, de, J, J, din, de, NN_, prec), st));
     CK(ttmi_launch_gemm(mk(dPD, wf + de, ddec, B * U1, dd, J, J, din, dd, NN_, prec), st));
+    return TTMI_OK;
+}
+
+// CUs that the encoder-sized persistent GEMMs launched on `stream` leave free (for RCCL's kernels running beside a data-parallel
+// backward pass): per-stream state, read at launch time.
+int ttmi_stream_reserve_cus(void* stream, int n) {
+    TTMI_REQUIRE(n >= 0 && n <= 128, "stream_reserve_cus: n = %d outside [0, 128]", n);
+    gemm_fast_stream_reserve_cus(static_cast<hipStream_t>(stream), n);
     return TTMI_OK;
 }
 

@@ -422,9 +422,9 @@ __global__ void embed_fwd_kernel(const long* __restrict__ tok, const float* __re
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * d) return;
     const long r = idx / d;
-    long t = tok[r];
-    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
-    out[idx] = W[t * d + idx % d];
+    const long t = tok[r];
+    // an id outside [0, V) is a caller error (nn.Embedding raises): it must not pass silently as some other row, so it reads as NaN
+    out[idx] = (t < 0 || t >= V) ? __builtin_nanf("") : W[t * d + idx % d];
 }
 
 __global__ void embed_bwd_kernel(const long* __restrict__ tok, const float* __restrict__ dout, long n, int d, int V, int pad,

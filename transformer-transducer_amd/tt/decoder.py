@@ -10,6 +10,10 @@ from tt.transformer import RelLearnableDecoderLayer, as_mask_spec, grad_targets
 class _EmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tokens, weight, padding_idx):
+        if tokens.dtype is not torch.long:      # nn.Embedding accepts int32 ids too; the kernels read int64
+            if tokens.dtype is not torch.int32:
+                raise TypeError("embedding indices must be int64 or int32, got %s" % tokens.dtype)
+            tokens = tokens.long()
         tokens = tokens.contiguous()
         ctx.save_for_backward(tokens)
         ctx.shape, ctx.padding_idx, ctx.params = weight.shape, padding_idx, (weight,)

@@ -76,6 +76,14 @@ class _LabelStateGraphs:
         self.pool = torch.cuda.graph_pool_handle()
         self.graphs = {}
         self.key = self.weights_key(model)
+        # every captured graph bakes in the address of this stream's scratch arena (ttmi.ops.scratch), which is re-allocated when a
+        # longer history needs more: size it for MAX_L before the first capture, and drop the graphs should it ever move all the same
+        cur = torch.cuda.current_stream(device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.decoder(torch.zeros(1, self.MAX_L, dtype=torch.long, device=device))
+        cur.wait_stream(self.stream)
+        self.arena = ops.scratch_generation(device, self.stream)
 
     @staticmethod
     def weights_key(model):
@@ -86,6 +94,9 @@ class _LabelStateGraphs:
 
     def state(self, L):
         """label-encoder output at the last position of master[:, :L] -> [1, 1, d] (static buffer of graph L)"""
+        if ops.scratch_generation(self.device, self.stream) != self.arena:      # the arena moved: every graph points at freed memory
+            self.graphs.clear()
+            self.arena = ops.scratch_generation(self.device, self.stream)
         entry = self.graphs.get(L)
         if entry is None:
             tok = self.master[:, :L].clone()
@@ -98,6 +109,7 @@ class _LabelStateGraphs:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, pool=self.pool, stream=self.stream):
                 out = self.decoder(tok)[:, -1:, :]
+            assert ops.scratch_generation(self.device, self.stream) == self.arena, "scratch arena grew during a capture"
             entry = self.graphs[L] = (graph, tok, out)
         graph, tok, out = entry
         tok.copy_(self.master[:, :L])
@@ -177,6 +189,8 @@ class Transducer(nn.Module):
             if tok is None:
                 t += n
                 continue
+            if tok >= self.config.vocab_size:   # NaN logits (bad weights / inputs) come back as an impossible symbol: fail here, not later
+                raise RuntimeError("greedy decode: the joint produced no finite maximum at frame %d (NaN logits?)" % (t + row))
             token_list.append(tok)
             dec_state = label_state()
             t += row + 1                                                    # the emitting frame is consumed

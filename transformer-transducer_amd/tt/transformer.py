@@ -133,10 +133,20 @@ def _drop_p(module, p):
     return float(p) if (module.training and p) else 0.0
 
 
+_seed_salt = 0
+
+
+def set_seed_salt(rank):
+    """data-parallel ranks share one torch seed (identical initial weights, config/aishell.yaml:55) but must not share dropout masks:
+    `ttmi.train.GradSync` mixes the rank into every seed drawn below"""
+    global _seed_salt
+    _seed_salt = (int(rank) * 0x9E3779B1) & 0x7FFFFFFF
+
+
 def _new_seed(*ps):
-    """one 31-bit seed per sub-layer call from torch's CPU generator (reproducible under torch.manual_seed); the HIP
-    kernels derive their counter-based masks from it and regenerate them in backward"""
-    return int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if any(ps) else 0
+    """one 31-bit seed per sub-layer call from torch's CPU generator (reproducible under torch.manual_seed), mixed with the
+    data-parallel rank; the HIP kernels derive their counter-based masks from it and regenerate them in backward"""
+    return (int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) ^ _seed_salt) if any(ps) else 0
 
 
 class PositionwiseFF(nn.Module):

@@ -49,8 +49,9 @@ def padded_empty(shape, dtype, device, multiple=64):
     return buf, buf[..., :V]
 
 
-# gradients written by rnnt_loss_bwd carry exact zeros in their pad columns; the joint's fast dgrad relies on that
-_zero_padded = {}
+# gradients written by rnnt_loss_bwd carry exact zeros in their pad columns; the joint's fast dgrad relies on that.  The guarantee is
+# attached to the gradient's TENSOR OBJECT (attribute `_ttmi_zero_pad` = its pitch), never to a raw address: a foreign gradient that the
+# caching allocator happens to place where an earlier one lived must not inherit it.
 
 
 # ----------------------------------------------------------------------------- RNN-T loss
@@ -87,9 +88,7 @@ def rnnt_loss_bwd(logits, labels, act_lens, label_lens, blank, workspace, grad_o
                                    c_int(grad_out_stride), c_float(scale), _p(grad), c_long(ldg), _stream()),
           "ttmi_rnnt_loss_bwd")
     if ldg != V:
-        if len(_zero_padded) > 64:
-            _zero_padded.clear()
-        _zero_padded[grad.data_ptr()] = ldg
+        grad._ttmi_zero_pad = ldg
     return grad
 
 
@@ -150,6 +149,13 @@ def scratch(n, device):
     if t is None or t.numel() < n:
         t = _ws_cache[key] = _f32(max(int(n), 1 << 20), device)
     return t
+
+
+def scratch_generation(device, stream):
+    """identity of `stream`'s scratch arena (its base address, None before first use): captured graphs hold this pointer, so whoever
+    replays them must notice a re-allocation (the arena only ever grows)"""
+    t = _ws_cache.get((device.type, device.index, stream.cuda_stream))
+    return None if t is None else t.data_ptr()
 
 
 def attn_fwd(x, p, mask, prec, p_drop=0.0, seed=0):
@@ -253,7 +259,7 @@ def joint_bwd(dlogits, enc, dec, wf, wp, ctx, prec, grads):
     ldg = row_pitch(dlogits)
     if dt is torch.bfloat16:
         ok = (dlogits.dtype is dt and ldg is not None and ldg % 8 == 0 and dlogits.data_ptr() % 16 == 0 and
-              (ldg == V or _zero_padded.pop(dlogits.data_ptr(), None) == ldg))
+              (ldg == V or getattr(dlogits, "_ttmi_zero_pad", None) == ldg))
         if not ok:                                  # foreign gradient: repack into a zero-padded bf16 buffer
             buf, view = padded_empty((B, T, U1, V), dt, enc.device)
             buf.zero_()
@@ -272,6 +278,11 @@ def joint_bwd(dlogits, enc, dec, wf, wp, ctx, prec, grads):
 
 def embed_fwd(tokens, W):
     _need_cuda(tokens, W)
+    if tokens.dtype is not torch.long:          # the kernel reads int64 ids; nn.Embedding (tt/decoder.py:26) also takes int32
+        if tokens.dtype is not torch.int32:
+            raise TypeError("embedding indices must be int64 or int32, got %s" % tokens.dtype)
+        tokens = tokens.long()
+    tokens = tokens.contiguous()
     n, (V, d) = tokens.numel(), W.shape
     out = torch.empty(*tokens.shape, d, dtype=torch.float32, device=W.device)
     check(lib().ttmi_embed_fwd(_p(tokens), _p(W), c_long(n), c_int(d), c_int(V), _p(out), _stream()), "ttmi_embed_fwd")
@@ -343,6 +354,16 @@ def dropout_multipliers(n, p, seed, device):
 def set_option(key, value):
     """process-wide A/B switches (key 0: 1 disables the fused attention kernels of the bf16 pipeline)"""
     check(lib().ttmi_set_option(c_int(key), c_int(value)), "ttmi_set_option")
+
+
+def reserve_cus(n, device=None):
+    """CUs the encoder-sized persistent GEMMs leave free on the CURRENT stream and on the label encoder's side stream (data-parallel
+    backward: RCCL's kernels run beside it).  Per-stream state in the library, read at launch time; 0 = whole chip."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    check(lib().ttmi_stream_reserve_cus(c_void_p(torch.cuda.current_stream(device).cuda_stream), c_int(n)), "ttmi_stream_reserve_cus")
+    st = _side_streams.get((device.type, device.index))
+    if st is not None:
+        check(lib().ttmi_stream_reserve_cus(c_void_p(st.cuda_stream), c_int(n)), "ttmi_stream_reserve_cus")
 
 
 def side_stream(device):

@@ -63,7 +63,12 @@ class GradSync:
                 start, members = end, []
         self.pending = [0] * len(self.buckets)
         self.seen = [False] * len(flat.params)
+        self.writers = [set() for _ in self.buckets]
         self.works = []
+        self.cuda = flat.flat.is_cuda
+        # every rank starts from the same torch seed (identical initial weights); its dropout masks must still differ
+        from tt import transformer as _tr
+        _tr.set_seed_salt(dist.get_rank(group) if self.world > 1 else 0)
         if self.world > 1:
             for i, p in enumerate(flat.params):
                 hook = self._make_hook(i)
@@ -77,14 +82,30 @@ class GradSync:
             self.seen[i] = True
             b = self.bucket_of[i]
             self.pending[b] += 1
+            if self.cuda:
+                # the kernels that wrote this gradient were queued on the CURRENT stream (main stream, or the label encoder's side
+                # stream): remember every stream that wrote into the bucket
+                self.writers[b].add(torch.cuda.current_stream(self.flat.flat.device))
             if self.pending[b] == self.buckets[b][2]:
-                s, e, _ = self.buckets[b]
-                self.works.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._reduce(b)
         return hook
+
+    def _reduce(self, b):
+        """queue bucket b's all-reduce behind EVERY stream that wrote into it.  The collective orders itself only after the stream
+        that is current when it is issued; a bucket can hold gradients written on the side stream (label encoder) and on the main
+        stream (audio encoder), and the hook that completes it fires on just one of them."""
+        s, e, _ = self.buckets[b]
+        if self.cuda:
+            cur = torch.cuda.current_stream(self.flat.flat.device)
+            for st in self.writers[b]:
+                if st != cur:
+                    cur.wait_stream(st)
+        self.works.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def start_step(self):
         self.pending = [0] * len(self.buckets)
         self.seen = [False] * len(self.flat.params)
+        self.writers = [set() for _ in self.buckets]
         self.works = []
 
     def finish(self):
@@ -95,36 +116,135 @@ class GradSync:
             return
         for b, (s, e, n) in enumerate(self.buckets):
             if self.pending[b] != n:
-                self.works.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._reduce(b)                # (join_side_streams above already ordered the current stream behind the side stream)
         for w in self.works:
             w.wait()
         self.works = []
 
 
 class FusedOptimizer:
-    """SGD(momentum)/Adam on the flat buffers with clip_grad_norm_ folded in (tt/optim.py:57-73, train.py:62-65)."""
+    """SGD(momentum)/Adam on the flat buffers with clip_grad_norm_ folded in (tt/optim.py:57-73, train.py:62-65), plus the
+    bookkeeping of the reference's `Optimizer` wrapper (tt/optim.py:4-33): `global_step` (starts at 1), `current_epoch`,
+    `decay_lr()` (lr *= decay_ratio) and a `state_dict()` in torch.optim's own layout, so the 'optimizer' entry of a reference
+    checkpoint (tt/utils.py:80-91) loads here and ours loads into torch.optim.SGD / Adam."""
 
     def __init__(self, flat, kind="sgd", lr=0.00025, momentum=0.9, nesterov=False, weight_decay=0.0, betas=(0.9, 0.98),
-                 eps=1e-8, max_grad_norm=200.0, world=1):
+                 eps=1e-8, max_grad_norm=200.0, world=1, decay_ratio=0.5):
+        if kind not in ("sgd", "adam"):
+            raise NotImplementedError("FusedOptimizer: optimizer type %r (sgd and adam are on the MI355X path)" % (kind,))
         self.flat, self.kind, self.lr, self.momentum, self.nesterov = flat, kind, lr, momentum, nesterov
         self.weight_decay, self.betas, self.eps, self.max_grad_norm, self.world = weight_decay, betas, eps, max_grad_norm, world
+        self.decay_ratio = decay_ratio
         self.state = [torch.zeros_like(flat.flat) for _ in range(2 if kind == "adam" else 1)]
         self.normsq = torch.zeros(1, dtype=torch.float32, device=flat.flat.device)
-        self.global_step = 0
+        self.global_step = 1                # tt/optim.py:8
+        self.current_epoch = 0
+        self.steps_taken = 0                # Adam's bias-correction exponent (torch keeps it per parameter in state['step'])
 
     def step(self):
         """gradients in flat.grad are SUMS over ranks; the 1/world averaging is folded into the update."""
+        flat = self.flat
+        for p, o in zip(flat.params, flat.offsets):       # the kernels read flat.grad: a .grad that was re-pointed (zero_grad(set_to_none),
+            if p.grad is None or p.grad.data_ptr() != flat.grad.data_ptr() + 4 * o:       # p.grad = ...) would be silently ignored
+                raise RuntimeError("FusedOptimizer.step: a parameter's .grad no longer aliases the flat gradient buffer "
+                                   "(use FlatModel.zero_grad(), not zero_grad(set_to_none=True))")
         self.global_step += 1
+        self.steps_taken += 1
         ops.join_side_streams()
         scale = 1.0 / self.world
+        max_norm = self.max_grad_norm or 0.0
         self.normsq.zero_()
-        ops.sumsq(self.flat.grad, self.normsq)
+        if max_norm > 0:
+            ops.sumsq(flat.grad, self.normsq)
         if self.kind == "adam":
-            ops.adam_step(self.flat.flat, self.flat.grad, self.state[0], self.state[1], self.lr, self.betas, self.eps,
-                          self.weight_decay, self.global_step, self.max_grad_norm, self.normsq, scale)
+            ops.adam_step(flat.flat, flat.grad, self.state[0], self.state[1], self.lr, self.betas, self.eps,
+                          self.weight_decay, self.steps_taken, max_norm, self.normsq, scale)
         else:
-            ops.sgd_step(self.flat.flat, self.flat.grad, self.state[0], self.lr, self.momentum, self.weight_decay,
-                         self.nesterov, self.max_grad_norm, self.normsq, scale)
+            ops.sgd_step(flat.flat, flat.grad, self.state[0], self.lr, self.momentum, self.weight_decay,
+                         self.nesterov, max_norm, self.normsq, scale)
 
     def grad_norm(self):
         return self.normsq.sqrt() / self.world
+
+    # ---- tt/optim.py:17-33
+    def epoch(self):
+        self.current_epoch += 1
+
+    def zero_grad(self):
+        self.flat.zero_grad()
+
+    def decay_lr(self):
+        self.lr *= self.decay_ratio
+
+    # ---- checkpointing in torch.optim's layout (train.py:196-212 restores it with optimizer.load_state_dict)
+    def _views(self, buf):
+        f = self.flat
+        return [buf[o:o + p.numel()].view_as(p) for p, o in zip(f.params, f.offsets)]
+
+    def state_dict(self):
+        n = len(self.flat.params)
+        if self.kind == "sgd":
+            group = dict(lr=self.lr, momentum=self.momentum, dampening=0, weight_decay=self.weight_decay, nesterov=self.nesterov)
+            state = {}
+            if self.steps_taken > 0 and self.momentum != 0:
+                state = {i: {"momentum_buffer": v.clone()} for i, v in enumerate(self._views(self.state[0]))}
+        else:
+            group = dict(lr=self.lr, betas=tuple(self.betas), eps=self.eps, weight_decay=self.weight_decay, amsgrad=False)
+            state = {}
+            if self.steps_taken > 0:
+                m, v = self._views(self.state[0]), self._views(self.state[1])
+                state = {i: {"step": torch.tensor(float(self.steps_taken)), "exp_avg": m[i].clone(), "exp_avg_sq": v[i].clone()}
+                         for i in range(n)}
+        group["params"] = list(range(n))
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.flat.params):
+            raise ValueError("FusedOptimizer.load_state_dict: expected one parameter group with %d parameters" % len(self.flat.params))
+        g = groups[0]
+        self.lr = g["lr"]
+        self.weight_decay = g.get("weight_decay", self.weight_decay)
+        if self.kind == "sgd":
+            self.momentum, self.nesterov = g.get("momentum", self.momentum), g.get("nesterov", self.nesterov)
+        else:
+            self.betas, self.eps = tuple(g.get("betas", self.betas)), g.get("eps", self.eps)
+        for b in self.state:
+            b.zero_()
+        self.steps_taken = 0
+        ids = g["params"]
+        st = sd["state"]
+        names = ("momentum_buffer",) if self.kind == "sgd" else ("exp_avg", "exp_avg_sq")
+        for k, name in enumerate(names):
+            for pos, view in enumerate(self._views(self.state[k])):
+                ent = st.get(ids[pos], st.get(str(ids[pos])))
+                if ent is not None and ent.get(name) is not None:
+                    view.copy_(ent[name])
+        steps = [int(e["step"]) for e in st.values() if "step" in e]
+        if steps:
+            if min(steps) != max(steps):
+                raise ValueError("FusedOptimizer.load_state_dict: per-parameter Adam step counts differ; one flat update needs one count")
+            self.steps_taken = steps[0]
+        elif st:
+            self.steps_taken = 1            # SGD: torch seeds the momentum buffer with the first gradient; ours has the same value after step 1
+
+
+def save_checkpoint(model, optimizer, path, multi_gpu=False):
+    """the reference's `.chkpt` layout (tt/utils.py:80-91): per-module state_dicts (un-prefixed keys), the optimizer's state_dict,
+    'epoch' and 'step'.  Rank 0 writes it in data-parallel runs."""
+    m = model.module if multi_gpu else model
+    torch.save({"encoder": m.encoder.state_dict(), "decoder": m.decoder.state_dict(), "joint": m.joint.state_dict(),
+                "optimizer": optimizer.state_dict(), "epoch": optimizer.current_epoch, "step": optimizer.global_step}, path)
+
+
+def load_checkpoint(model, optimizer, path, mode="continue", map_location=None):
+    """train.py:196-212 + 234-241: weights always; optimizer state, epoch and step only in 'continue' mode.  Parameters stay views of
+    the flat buffer (load_state_dict copies in place)."""
+    ck = torch.load(path, map_location=map_location)
+    model.encoder.load_state_dict(ck["encoder"])
+    model.decoder.load_state_dict(ck["decoder"])
+    model.joint.load_state_dict(ck["joint"])
+    if optimizer is not None and mode == "continue":
+        optimizer.load_state_dict(ck["optimizer"])
+        optimizer.global_step, optimizer.current_epoch = ck["step"], ck["epoch"]
+    return ck
