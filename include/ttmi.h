@@ -108,6 +108,23 @@ int ttmi_rnnt_loss_bwd(const void* logits, int dtype, long ldv, const int* label
  * state; *out (device u64) = (first row whose argmax != blank) << 32 | symbol, or n << 32 if all rows are blank. */
 int ttmi_greedy_scan(const void* logits, int dtype, long ld, int n, int V, int blank, unsigned long long* out, void* stream);
 
+/* ---- feature front-end on the GPU: replaces the data loader's per-utterance numpy code.
+ * ttmi_logmel: get_feature / get_feature2 (tt/utils.py:182-207: librosa.feature.melspectrogram(y, sr, n_fft=512, hop_length=160, n_mels), then
+ * log) for a batch.  wave i16 [B, pitch >= nmax] zero padded, n_samples i32 [B] (device) -> out f32 [B, Fmax, n_mels], Fmax = 1 + nmax / hop,
+ * frames beyond 1 + n_b / hop zero.  The STFT is a GEMM with `dft` [2*(n_fft/2+1), n_fft] (rows 2k / 2k+1 = w[n] cos(2 pi k n / n_fft) /
+ * -w[n] sin(...), analysis window w folded in), the filterbank a GEMM with mel_w [n_mels, n_fft/2+1]; log_mode 0 = np.ma.log(..).filled(0),
+ * 1 = log10 with zeros -> float64 eps, 2 = none.  ws: ttmi_logmel_ws_floats floats, 256-byte aligned.
+ * ttmi_stack_subsample: concat_frame + subsampling + Dataset.pad (tt/utils.py:120-151, tt/dataset.py:40-57) in one pass: feat f32 [B, Tin, F],
+ * n_frames i32 [B] (device, nullable) -> out f32 [B, Tout, F*(1+left+right)], rows >= ceil(n_b / subsample) zero; out_lens nullable.
+ * ttmi_spec_mask: frequency_mask_augment + time_mask_augment (tt/utils.py:297-329, train.py:41-44) in place on x f32 [B, T, F]; the (start,
+ * width) pairs are HOST arrays (<= 32 per axis), drawn by the caller with the reference's RNG protocol. */
+size_t ttmi_logmel_ws_floats(int B, int nmax, int n_fft, int hop);
+int ttmi_logmel(const short* wave, long pitch, const int* n_samples, int B, int nmax, int n_fft, int hop, int n_mels, const float* dft,
+                const float* mel_w, int log_mode, float* ws, float* out, void* stream);
+int ttmi_stack_subsample(const float* feat, const int* n_frames, int B, int Tin, int F, int left, int right, int subsample, int Tout,
+                         float* out, int* out_lens, void* stream);
+int ttmi_spec_mask(float* x, int B, int T, int F, const int* time_spans, int n_time, const int* freq_spans, int n_freq, void* stream);
+
 /* ---- training-step tail on flat f32 buffers: clip_grad_norm_ + optimizer.step (train.py:62-65, tt/optim.py:57-73)
  * normsq: device scalar holding sum(g^2) over ALL gradients (ttmi_sumsq accumulates into it); NULL = no clipping.
  * The effective gradient is g * grad_scale (1/world_size after a SUM all-reduce) clipped to max_norm. */

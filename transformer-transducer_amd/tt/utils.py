@@ -1,6 +1,6 @@
-"""Hot-path subset of the reference's tt/utils.py: AttrDict (tt/utils.py:11-27) and the two mask
-builders (tt/utils.py:233-251).  Feature extraction / logging / checkpoint helpers of that file are
-outside the accelerated path."""
+"""The reference's tt/utils.py names that belong to the accelerated path: AttrDict (tt/utils.py:11-27), the mask builders
+(:233-251), the feature front-end (:120-151,182-214,297-329, on the GPU: ttmi.frontend) and save_model (:80-91).  Logging, scoring and
+file helpers of that file are outside it and resolve to the reference's own module when it is on sys.path."""
 import importlib.util
 import os
 import sys
@@ -80,6 +80,78 @@ def chunk_mask(audio, chunk=16, left_context=64):
     lo = (i // chunk) * chunk - left_context
     hi = (i // chunk + 1) * chunk - 1
     return ((j < lo) | (j > hi)).to(audio.dtype)
+
+
+# ---- feature front-end with the reference's names (tt/utils.py:120-151,182-214,297-329), computed by the HIP kernels of ttmi.frontend.
+# numpy in -> numpy out (so tt/dataset.py keeps working), device tensor in -> device tensor out.  There is no CPU arithmetic here.
+def _dev(x, dtype):
+    if isinstance(x, torch.Tensor):
+        return x.to(device="cuda", dtype=dtype) if not x.is_cuda else x.to(dtype), False
+    import numpy as np
+    return torch.as_tensor(np.ascontiguousarray(x)).to(device="cuda", dtype=dtype), True
+
+
+def concat_frame(features, left_context_width, right_context_width):
+    """[T, F] -> [T, F * (1 + left + right)]: `left` past frames | frame | future frames (placed as the reference places them)"""
+    from ttmi import frontend
+    x, was_np = _dev(features, torch.float32)
+    out = frontend.stack_subsample(x[None], None, left_context_width, right_context_width, 1)[0][0]
+    return out.cpu().numpy() if was_np else out
+
+
+def subsampling(features, subsample=3):
+    """every `subsample`-th row from row 0 (a strided copy; the fused path is ttmi.frontend.stack_subsample)"""
+    if isinstance(features, torch.Tensor):
+        return features[::subsample].contiguous()
+    return features[::subsample].copy()
+
+
+def _log_mel(wave_data, framerate, feature_dim, mode):
+    from ttmi import frontend
+    w, was_np = _dev(wave_data, torch.int16)
+    n = torch.tensor([w.numel()], dtype=torch.int32, device=w.device)
+    out = frontend.log_mel(w.reshape(1, -1), n, framerate, feature_dim, mode)[0]
+    return out.cpu().numpy() if was_np else out
+
+
+def get_feature(wave_data, framerate, feature_dim=128):
+    """int16 samples -> natural-log mel spectrogram [1 + n // 160, feature_dim] (zeros where the power is 0)"""
+    return _log_mel(wave_data, framerate, feature_dim, "ln")
+
+
+def get_feature2(wave_data, framerate, feature_dim=128):
+    """int16 samples -> log10 mel spectrogram (zero power -> log10 of the float64 epsilon)"""
+    return _log_mel(wave_data, framerate, feature_dim, "log10")
+
+
+def get_final_feature(samples, sample_rate=16000, feature_dim=128, left=3, right=0, subsample=3):
+    from ttmi import frontend
+    w, was_np = _dev(samples, torch.int16)
+    n = torch.tensor([w.numel()], dtype=torch.int32, device=w.device)
+    mel = frontend.log_mel(w.reshape(1, -1), n, sample_rate, feature_dim, "ln")
+    out = frontend.stack_subsample(mel, None, left, right, subsample)[0][0]
+    return out.cpu().numpy() if was_np else out
+
+
+def time_mask_augment(inputs, max_mask_time=5, mask_num=10):
+    """in place on [B, T, F]: `mask_num` row spans zeroed for the whole batch; widths / starts drawn exactly as the reference draws them"""
+    from ttmi import frontend
+    if not (isinstance(inputs, torch.Tensor) and inputs.is_cuda):
+        raise ValueError("time_mask_augment: the MI355X path masks device tensors (train.py:37-44 moves the batch to the GPU first)")
+    return frontend.spec_mask_(inputs, time_spans=frontend.draw_spans(inputs.shape[1], max_mask_time, mask_num))
+
+
+def frequency_mask_augment(inputs, max_mask_frequency=5, mask_num=10):
+    from ttmi import frontend
+    if not (isinstance(inputs, torch.Tensor) and inputs.is_cuda):
+        raise ValueError("frequency_mask_augment: the MI355X path masks device tensors (train.py:37-44 moves the batch to the GPU first)")
+    return frontend.spec_mask_(inputs, freq_spans=frontend.draw_spans(inputs.shape[2], max_mask_frequency, mask_num))
+
+
+def save_model(model, optimizer, config, save_name):
+    """the reference's checkpoint layout (tt/utils.py:80-91)"""
+    from ttmi.train import save_checkpoint
+    save_checkpoint(model, optimizer, save_name, multi_gpu=config.training.num_gpu > 1)
 
 
 def count_parameters(model):
