@@ -136,6 +136,9 @@ def main():
                          "long-utterance stress (T=2000 U=200 batch 8)")
     ap.add_argument("--mode", default="train", choices=["train", "decode"],
                     help="train = the metric (default); decode = greedy decode of the C2 model (SURVEY §8 A10) with the oracle's loop beside it")
+    ap.add_argument("--fused-loss", action="store_true",
+                    help="Transducer.loss(...) (joint + RNN-T loss in chunks, logits never materialised; SURVEY 8f-1) instead of model() + RNNTLoss()")
+    ap.add_argument("--loss-chunk", type=int, default=0, help="utterances per chunk of the fused loss (0 = default: logits chunk <= 2 GB)")
     ap.add_argument("--emit-rate", type=float, default=0.1, help="decode mode: fraction of frames that emit a symbol (blank bias is set for it)")
     args = ap.parse_args()
     if args.mode == "decode":
@@ -194,8 +197,11 @@ def main():
         sync.start_step()
         if timed and rank == 0:
             ops.probe_arm(i % 64)                     # this step's joint-projection launch records into event pair i
-        logits = model(inputs, targets)
-        loss = criterion(logits, targets.int(), ilen, tlen)
+        if args.fused_loss:
+            loss = model.loss(inputs, ilen, targets, tlen, chunk=args.loss_chunk or None)
+        else:
+            logits = model(inputs, targets)
+            loss = criterion(logits, targets.int(), ilen, tlen)
         if world > 1:
             ops.reserve_cus(32)                       # gradient all-reduce kernels run beside backward: the persistent encoder GEMMs leave them 4 CUs per XCD (per-stream state)
         loss.backward()
@@ -274,6 +280,8 @@ def main():
             "roofline_joint" if lattice_run else "roofline_loss": roof_joint if lattice_run else roof_loss,
             "final_loss": round(float(last.detach()), 4),
         }
+        if args.fused_loss:
+            out["config"]["loss"] = "fused joint + loss (Transducer.loss), chunk %s" % (args.loss_chunk or "default")
         if world == 1 and not args.no_cpu_baseline:
             model.eval()
             with torch.no_grad():

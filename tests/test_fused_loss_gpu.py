@@ -1,0 +1,118 @@
+"""Fused joint + RNN-T loss, `Transducer.loss(inputs, inputs_length, targets, targets_length)`: the same numbers as
+`model(inputs, targets)` + `RNNTLoss()` (train.py:51-53) without ever holding the [B, T, U+1, V] logits - against the reference-run
+fixtures, the oracle, and the two-call form."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from test_model_gpu import build
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(params=["tiny_klong", "tiny_kshort"])
+def gm(request):
+    z, sd = load_golden(request.param)
+    return z, sd, build(sd)
+
+
+@pytest.mark.parametrize("tag", ["full", "ragged"])
+@pytest.mark.parametrize("chunk", [1, 2])
+def test_loss_and_every_gradient_vs_reference_fixtures(gm, tag, chunk):
+    z, sd, model = gm
+    model.zero_grad()
+    inp = torch.tensor(z["inputs"], device="cuda", requires_grad=True)
+    tgt = torch.tensor(z["targets"], device="cuda")
+    loss = model.loss(inp, torch.tensor(z[tag + "/act_lens"], device="cuda"), tgt, torch.tensor(z[tag + "/label_lens"], device="cuda"),
+                      chunk=chunk, check_lengths=False)
+    assert loss.shape == (1,) and abs(float(loss) - float(z[tag + "/loss"])) / float(z[tag + "/loss"]) < TOL
+    loss.backward()
+    assert rel_err(inp.grad.cpu().numpy(), z[tag + "/dinputs"]) < TOL
+    for name, p in model.named_parameters():
+        assert rel_err(p.grad.cpu().numpy(), z["%s/grad/%s" % (tag, name)]) < TOL, name
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_same_numbers_as_the_two_call_form(gm, prec, monkeypatch):
+    """identical kernels on identical inputs: the loss agrees to the last bit, the gradients up to the order of f32 atomic sums; an
+    upstream factor (loss * 3) scales everything"""
+    z, sd, model = gm
+    from warprnnt_pytorch import RNNTLoss
+    monkeypatch.setenv("TTMI_PRECISION", prec)
+    tgt = torch.tensor(z["targets"], device="cuda")
+    al, ll = torch.tensor(z["ragged/act_lens"], device="cuda"), torch.tensor(z["ragged/label_lens"], device="cuda")
+    res = []
+    for fused in (False, True):
+        model.zero_grad()
+        inp = torch.tensor(z["inputs"], device="cuda", requires_grad=True)
+        if fused:
+            loss = model.loss(inp, al, tgt, ll, chunk=1, check_lengths=False)
+        else:
+            loss = RNNTLoss(check_lengths=False)(model(inp, tgt), tgt.int(), al, ll)
+        (loss * 3.0).backward()
+        res.append((loss.detach().clone(), inp.grad.clone(), {n: p.grad.clone() for n, p in model.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0])
+    tol = 1e-5 if prec == "fp32" else 2e-3
+    assert rel_err(res[1][1].cpu().numpy(), res[0][1].cpu().numpy()) < tol
+    for n in res[0][2]:
+        assert rel_err(res[1][2][n].cpu().numpy(), res[0][2][n].cpu().numpy()) < tol, n
+    none = model.loss(torch.tensor(z["inputs"], device="cuda"), al, tgt, ll, reduction="none", check_lengths=False)
+    assert none.shape == (2,) and abs(float(none.sum() / 2) - float(res[0][0])) < 1e-4 * float(res[0][0])
+
+
+def test_length_contract(gm):
+    z, sd, model = gm
+    tgt = torch.tensor(z["targets"], device="cuda")
+    inp = torch.tensor(z["inputs"], device="cuda")
+    al, ll = torch.tensor(z["full/act_lens"], device="cuda"), torch.tensor(z["full/label_lens"], device="cuda")
+    model.loss(inp, al, tgt, ll)                                            # full lengths pass warp-transducer's checks
+    with pytest.raises(ValueError):
+        model.loss(inp, al - 1, tgt, ll)                                    # T != max(act_lens)
+    with pytest.raises(ValueError):
+        model.loss(inp, al, tgt, ll - 1)                                    # U + 1 != max(label_lens) + 1
+    with pytest.raises(ValueError):
+        model.loss(inp, al[:1], tgt, ll)
+
+
+def test_flat_model_gradients_and_memory(monkeypatch):
+    """bf16 pipeline at a size where the persistent GEMMs run (B=8, T=200, U=20, J=1024, V=4334): gradients land in FlatModel's flat
+    buffer and match the two-call form; the peak memory of the step drops by about the size of the logits + their gradient"""
+    from tt.model import Transducer
+    from tt.utils import AttrDict
+    from ttmi.train import FlatModel
+    from warprnnt_pytorch import RNNTLoss
+    monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    side = dict(n_layer=1, d_model=512, n_head=8, d_head=64, d_inner=256)
+    cfg = AttrDict(dict(enc=dict(side, max_input_length=64), dec=dict(side, max_target_length=16),
+                        joint=dict(input_size=1024, inner_size=1024), vocab_size=4334, dropout=0.0))
+    torch.manual_seed(2)
+    model = Transducer(cfg).cuda().train()
+    flat = FlatModel(model)
+    B, T, U = 8, 200, 20
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(B, T, 512, device="cuda", generator=g)
+    y = torch.randint(1, 4334, (B, U), device="cuda", generator=g)
+    al = torch.full((B,), T, dtype=torch.int32, device="cuda")
+    ll = torch.full((B,), U, dtype=torch.int32, device="cuda")
+    al[2], ll[2] = 150, 11
+    out = []
+    for fused in (False, True):
+        flat.zero_grad()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        if fused:
+            loss = model.loss(x, al, y, ll, chunk=2, check_lengths=False)
+        else:
+            loss = RNNTLoss(check_lengths=False)(model(x, y), y.int(), al, ll)
+        loss.backward()
+        torch.cuda.synchronize()
+        out.append((float(loss.detach()), flat.grad.clone(), torch.cuda.max_memory_allocated() - base))
+        del loss
+    assert out[0][0] == out[1][0]
+    assert rel_err(out[1][1].cpu().numpy(), out[0][1].cpu().numpy()) < 3e-3
+    logits_bytes = B * T * (U + 1) * 4352 * 2
+    print("peak above baseline: two-call %.0f MB, fused %.0f MB (logits %.0f MB)" % (out[0][2] / 2 ** 20, out[1][2] / 2 ** 20, logits_bytes / 2 ** 20))
+    assert out[0][2] - out[1][2] > 1.2 * logits_bytes        # logits + gradient gone, a chunk's worth (1/4) of one buffer remains

@@ -38,6 +38,65 @@ class _JointFn(torch.autograd.Function):
         return (denc, ddec, *rets, None)
 
 
+class _JointLossFn(torch.autograd.Function):
+    """joint network + RNN-T loss as ONE op that never holds the [B, T, U+1, V] logits: the batch is cut into chunks
+    of utterances; per chunk the logits are produced (ttmi_joint_fwd), reduced to the lattice (ttmi_rnnt_loss_fwd), overwritten IN PLACE
+    by their own gradient (ttmi_rnnt_loss_bwd, the same kernels as RNNTLoss) and consumed by the joint's backward (ttmi_joint_bwd) - in
+    the forward pass, as warp-transducer itself forms its gradients - so one chunk's buffer is the whole footprint (C2: 14.2 GB of
+    logits + gradient -> 0.44 GB per chunk of 2 utterances; C5: 55.8 GB -> 3.5 GB per utterance).  backward() only scales by the
+    incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, enc, dec, wf, bf, wp, bp, labels, act_lens, label_lens, prec, chunk, reduction):
+        enc, dec = enc.contiguous(), dec.contiguous()
+        params = (wf, bf, wp, bp)
+        wf_, bf_, wp_, bp_ = (t.detach() for t in params)
+        B, T = enc.shape[0], enc.shape[1]
+        U1 = dec.shape[1]
+        need = any(ctx.needs_input_grad[:6])
+        costs = torch.empty(B, dtype=torch.float32, device=enc.device)
+        one = torch.ones(1, dtype=torch.float32, device=enc.device)
+        scale = 1.0 / B if reduction == "mean" else 1.0
+        if need:
+            denc, ddec = torch.empty_like(enc), torch.empty_like(dec)
+            g = {n: torch.zeros_like(t) for n, t in zip(("wf", "bf", "wp", "bp"), params)}
+        for c0 in range(0, B, chunk):
+            c1 = min(B, c0 + chunk)
+            logits, saved = ops.joint_fwd(enc[c0:c1], dec[c0:c1], wf_, bf_, wp_, bp_, prec)
+            ws = ops.rnnt_workspace(c1 - c0, T, U1, enc.device)
+            lab, al, ll = labels[c0:c1], act_lens[c0:c1], label_lens[c0:c1]
+            costs[c0:c1] = ops.rnnt_loss_fwd(logits, lab, al, ll, 0, ws)
+            if need:
+                grad = ops.rnnt_loss_bwd(logits, lab, al, ll, 0, ws, one, 0, scale, inplace=True)
+                ops.joint_bwd(grad, enc[c0:c1], dec[c0:c1], wf_, wp_, saved, prec, g, out=(denc[c0:c1], ddec[c0:c1]))
+            del logits, saved
+        if need:
+            ctx.save_for_backward(denc, ddec, *g.values())
+        ctx.params = params
+        if reduction == "none":
+            return costs
+        return costs.sum().reshape(1) * scale
+
+    @staticmethod
+    def backward(ctx, gout):
+        denc, ddec, *gs = ctx.saved_tensors
+        gout = gout.float()
+        if gout.numel() != 1:
+            raise NotImplementedError("fused joint + loss: per-utterance upstream gradients (reduction='none') are not supported; "
+                                      "use model(inputs, targets) + RNNTLoss(reduction='none')")
+        rets = []
+        for prm, gp in zip(ctx.params, gs):
+            if getattr(prm, "_ttmi_direct", False) and prm.grad is not None:       # FlatModel: accumulate into the flat gradient buffer
+                prm.grad.addcmul_(gp, gout)
+                rets.append(None)
+                cb = getattr(prm, "_ttmi_on_grad", None)
+                if cb is not None:
+                    cb()
+            else:
+                rets.append(gp * gout)
+        return (denc * gout, ddec * gout, *rets, None, None, None, None, None, None)
+
+
 class JointNet(nn.Module):
     """logits = project_layer(tanh(forward_layer(cat(enc, dec)))) evaluated in split-weight form
     (forward_layer.weight = [W_enc | W_dec]); accepts [B,T,de]/[B,U,dd] (lattice) or two 1-D vectors (decode)."""
@@ -130,6 +189,29 @@ class Transducer(nn.Module):
             raise AttributeError("'BuildDecoder' object has no attribute 'embedding' (share_embedding is broken upstream)")
 
     def forward(self, inputs, targets):
+        return self.joint(*self._encode(inputs, targets))
+
+    def loss(self, inputs, inputs_length, targets, targets_length, reduction="mean", chunk=None, check_lengths=True):
+        """Opt-in fused form of train.py:51-53 (`logits = model(inputs, targets); loss = criterion(logits, targets.int(),
+        inputs_length.int(), targets_length.int())`) that never materialises the logits (API precedent: tt_espnet/model.py:35-81 returns
+        the loss from forward).  Same numbers as the two-call form: the same kernels run, one chunk of `chunk` utterances at a time
+        (default: as many as keep a chunk's logits under ~2 GB), and the chunk's buffer is overwritten by its gradient and consumed by the
+        joint's backward before the next chunk starts.  Returns the loss ([1] for 'mean' / 'sum', [B] for 'none')."""
+        from warprnnt_pytorch import check_lengths as certify
+        enc_state, dec_state = self._encode(inputs, targets)
+        B, T, U1 = enc_state.shape[0], enc_state.shape[1], dec_state.shape[1]
+        labels, al, ll = (t.to(device=enc_state.device, dtype=torch.int32).contiguous() for t in (targets, inputs_length, targets_length))
+        certify(labels, al, ll, B, T, U1, check_lengths)
+        prec = default_precision()
+        if chunk is None:
+            es = 2 if ops.joint_logits_dtype(prec, self.joint.forward_layer.out_features) is torch.bfloat16 else 4
+            chunk = max(1, min(B, int((2 << 30) // (es * T * U1 * self.config.vocab_size))))
+        j = self.joint
+        return _JointLossFn.apply(enc_state, dec_state, j.forward_layer.weight, j.forward_layer.bias, j.project_layer.weight,
+                                  j.project_layer.bias, labels, al, ll, prec, int(chunk), reduction)
+
+    def _encode(self, inputs, targets):
+        """both encoders of forward() (tt/model.py:58-65): -> (enc_state [B,T,d], dec_state [B,U+1,d])"""
         targets = F.pad(targets, pad=[1, 0, 0, 0], value=0)                 # leading blank / SOS
         audio_mask = self._audio_mask(inputs)
         if self.config.overlap_label_encoder and inputs.is_cuda:
@@ -147,7 +229,7 @@ class Transducer(nn.Module):
         else:
             enc_state = self.encoder(inputs, audio_mask)
             dec_state = self.decoder(targets, MaskSpec(1))                  # == look_ahead_mask(targets)[:, :, None]
-        return self.joint(enc_state, dec_state)
+        return enc_state, dec_state
 
     def _audio_mask(self, inputs):
         """Reference behaviour is audio_mask=None (tt/model.py:60-61).  Opt-in `config.streaming` (absent in the

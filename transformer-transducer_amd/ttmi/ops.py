@@ -73,11 +73,15 @@ def rnnt_loss_fwd(logits, labels, act_lens, label_lens, blank, workspace):
     return costs
 
 
-def rnnt_loss_bwd(logits, labels, act_lens, label_lens, blank, workspace, grad_out, grad_out_stride, scale):
+def rnnt_loss_bwd(logits, labels, act_lens, label_lens, blank, workspace, grad_out, grad_out_stride, scale, inplace=False):
+    """inplace: the gradient overwrites the logits (same dtype and pitch; the fused joint + loss path needs them only once)"""
     _need_cuda(logits, labels, act_lens, label_lens, workspace, grad_out)
     B, T, U1, V = logits.shape
     ld = row_pitch(logits)
-    if ld == V:
+    if inplace:
+        buf = grad = logits
+        ldg = ld
+    elif ld == V:
         buf = grad = torch.empty_like(logits)
         ldg = V
     else:
@@ -248,7 +252,8 @@ def joint_fwd(enc, dec, wf, bf, wp, bp, prec):
     return logits, ctx
 
 
-def joint_bwd(dlogits, enc, dec, wf, wp, ctx, prec, grads):
+def joint_bwd(dlogits, enc, dec, wf, wp, ctx, prec, grads, out=None):
+    """out: optional (denc, ddec) buffers to write the input gradients into"""
     B, T, de = enc.shape
     U1, dd = dec.shape[1], dec.shape[2]
     J, V = wf.shape[0], wp.shape[0]
@@ -269,7 +274,8 @@ def joint_bwd(dlogits, enc, dec, wf, wp, ctx, prec, grads):
         if dlogits.dtype is not dt or ldg is None:
             dlogits = dlogits.to(dt).contiguous()
             ldg = V
-    denc, ddec = torch.empty_like(enc), torch.empty_like(dec)
+    denc, ddec = (torch.empty_like(enc), torch.empty_like(dec)) if out is None else out
+    assert denc.is_contiguous() and ddec.is_contiguous() and denc.shape == enc.shape and ddec.shape == dec.shape
     check(L_.ttmi_joint_bwd(_p(dlogits), c_long(ldg), _p(enc), _p(dec), _p(wf), _p(wp), c_int(B), c_int(T), c_int(U1), c_int(de),
                             c_int(dd), c_int(J), c_int(V), c_int(prec), _p(ctx), _p(ws), _p(denc), _p(ddec), _p(grads["wf"]),
                             _p(grads["bf"]), _p(grads["wp"]), _p(grads["bp"]), _stream()), "ttmi_joint_bwd")

@@ -16,7 +16,7 @@ import torch
 
 from ttmi import ops
 
-__all__ = ["RNNTLoss", "rnnt_loss"]
+__all__ = ["RNNTLoss", "rnnt_loss", "check_lengths"]
 
 
 _max_cache = {}     # id(tensor) -> (weakref, tensor._version, max): the length check costs a device-to-host sync; a lengths tensor that
@@ -54,6 +54,26 @@ def _certify(acts, labels, act_lens, label_lens, check_lengths):
         if _cached_max(act_lens) != acts.shape[1]:
             raise ValueError("Input length mismatch")
         if _cached_max(label_lens) + 1 != acts.shape[2]:
+            raise ValueError("Output length mismatch")
+
+
+def check_lengths(labels, act_lens, label_lens, B, T, U1, check_max):
+    """the label / length part of warp-transducer's certify_inputs for callers that never hold an `acts` tensor (the fused joint + loss)"""
+    for name, t in (("labels", labels), ("label_lengths", label_lens), ("lengths", act_lens)):
+        if t.dtype is not torch.int32:
+            raise TypeError("%s must be int32" % name)
+        if not t.is_contiguous():
+            raise ValueError("%s must be contiguous" % name)
+    if labels.dim() != 2 or act_lens.dim() != 1 or label_lens.dim() != 1:
+        raise ValueError("labels must be 2-D, lengths 1-D")
+    if act_lens.shape[0] != B or label_lens.shape[0] != B:
+        raise ValueError("must have a length per example")
+    if labels.shape[0] != B or labels.shape[1] != U1 - 1:
+        raise ValueError("labels must be [batch, U] with U+1 == acts.shape[2]")
+    if check_max:
+        if _cached_max(act_lens) != T:
+            raise ValueError("Input length mismatch")
+        if _cached_max(label_lens) + 1 != U1:
             raise ValueError("Output length mismatch")
 
 
