@@ -64,8 +64,8 @@ def flops_per_utt(cfg, T, U1):
     return 3 * fwd
 
 
-def cpu_baseline(model, feats, proj, targets, T, U, n_utt, gpu_costs):
-    """Time the oracle (numpy model + C lattice) on `n_utt` utterances of the same workload; also returns the
+def cpu_baseline(model, feats, proj, targets, T, U, n_utt, gpu_costs, reps):
+    """Time the oracle (numpy model + C lattice) on `n_utt` utterances of the same workload, `reps` times (median); also returns the
     relative error of the GPU's per-utterance costs against it."""
     from oracle import tt_oracle as O
     from oracle.rnnt_c import rnnt_loss_c
@@ -74,13 +74,22 @@ def cpu_baseline(model, feats, proj, targets, T, U, n_utt, gpu_costs):
     y = targets[:n_utt].cpu().numpy()
     tl = np.full(n_utt, T, dtype=np.int32)
     ul = np.full(n_utt, U, dtype=np.int32)
-    t0 = time.perf_counter()
-    z, cache = O.transducer_fwd(x, y, sd)
-    loss, costs, dz = rnnt_loss_c(z, y, tl, ul)
-    O.transducer_bwd(dz, cache, sd)
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        z, cache = O.transducer_fwd(x, y, sd)
+        loss, costs, dz = rnnt_loss_c(z, y, tl, ul)
+        O.transducer_bwd(dz, cache, sd)
+        times.append(time.perf_counter() - t0)
+        del z, cache, dz
+    dt = float(np.median(times))
     rel = float(np.abs(gpu_costs[:n_utt] - costs).max() / np.abs(costs).max())
-    return n_utt / dt, dt, rel
+    return n_utt / dt, dt, rel, times
+
+
+def _sha16(path):
+    import hashlib
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
 def decode_mode(args):
@@ -129,13 +138,15 @@ def main():
     ap.add_argument("--U", type=int, default=50)
     ap.add_argument("--precision", default=os.environ.get("TTMI_PRECISION", "bf16"), choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-utts", type=int, default=1)
+    ap.add_argument("--cpu-utts", type=int, default=2, help="utterances of the CPU-baseline sample (BASELINE.md §3: B=2)")
+    ap.add_argument("--cpu-reps", type=int, default=3, help="repetitions of the CPU-baseline sample (median reported)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI)")
     ap.add_argument("--workload", default="c2", choices=["c2", "c4-band", "c4-chunk", "c5"],
                     help="c2 = BASELINE configs[1] (headline, default); c4-* = streaming model configs[3]; c5 = configs[4] "
                          "long-utterance stress (T=2000 U=200 batch 8)")
     ap.add_argument("--mode", default="train", choices=["train", "decode"],
                     help="train = the metric (default); decode = greedy decode of the C2 model (SURVEY §8 A10) with the oracle's loop beside it")
+    ap.add_argument("--no-weight-shadows", action="store_true", help="convert the f32 master weights to bf16 in every call (round-1 behaviour; A/B)")
     ap.add_argument("--fused-loss", action="store_true",
                     help="Transducer.loss(...) (joint + RNN-T loss in chunks, logits never materialised; SURVEY 8f-1) instead of model() + RNNTLoss()")
     ap.add_argument("--loss-chunk", type=int, default=0, help="utterances per chunk of the fused loss (0 = default: logits chunk <= 2 GB)")
@@ -170,6 +181,8 @@ def main():
     torch.manual_seed(1)                                   # config/aishell.yaml:55 - same init on every rank
     model = Transducer(cfg).to(dev).train()
     flat = FlatModel(model)
+    if args.precision == "bf16" and not args.no_weight_shadows:
+        flat.enable_shadows()                              # bf16 weight copies rebuilt once per optimiser step (one launch) instead of per call
     sync = GradSync(flat)
     opt = FusedOptimizer(flat, kind="sgd", lr=0.00025, momentum=0.9, max_grad_norm=200.0, world=world)
     criterion = RNNTLoss()
@@ -230,6 +243,8 @@ def main():
         slots = [i % 64 for i in range(max(0, args.steps - 64), args.steps)]
         probe_ms = [ops.probe_read_ms(i) for i in slots]
         loss_ms = [(ops.probe_read_ms(i, 1), ops.probe_read_ms(i, 2)) for i in slots]
+        attn_ms = [ops.probe_read_ms(i, 3) for i in slots]
+        wgrad_ms = [ops.probe_read_ms(i, 4) for i in slots]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -246,10 +261,17 @@ def main():
         traffic = None          # HBM-side bytes of one launch from the committed PMC passes (only valid for the default workload)
         mfma_busy = None
         pmc = os.path.join(ROOT, "profiles", "pmc_joint_projection.json")
-        if os.path.exists(pmc) and args.workload == "c2" and (B, T, U) == (32, 500, 50) and args.precision == "bf16":
+        pmc_build = None
+        if os.path.exists(pmc) and args.workload == "c2" and (B, T, U) == (32, 500, 50) and args.precision == "bf16" and not args.fused_loss:
             j = json.load(open(pmc))
-            traffic = (2.0 * j["fetch_size_kb"] + j["write_size_kb"]) * 1024.0
-            mfma_busy = j.get("mfma_busy")           # SQ_VALU_MFMA_BUSY_CYCLES / elapsed SIMD cycles of the same launch (committed PMC pass)
+            # the counters come from separate rocprofv3 --pmc passes (profiles/): valid only for the kernel source they were measured on
+            src = os.path.join(ROOT, "transformer-transducer_amd", "csrc", "gemm_fast.hip")
+            pmc_build = {"measured_at_commit": j.get("commit"), "gemm_fast_sha16": j.get("gemm_fast_sha16"), "source": j.get("source")}
+            if j.get("gemm_fast_sha16") == _sha16(src):
+                traffic = (2.0 * j["fetch_size_kb"] + j["write_size_kb"]) * 1024.0
+                mfma_busy = j.get("mfma_busy")       # SQ_VALU_MFMA_BUSY_CYCLES / elapsed SIMD cycles of the same launch
+            else:
+                pmc_build["stale"] = "csrc/gemm_fast.hip changed since the PMC passes: traffic / mfma_busy withheld"
         # the RNN-T loss op at the API boundary: logits read once, gradient written once, alpha / beta / lp_blank / lp_label in f32
         es = 2 if args.precision == "bf16" else 4
         loss_bytes = B * (2.0 * es * T * U1 * V + 16.0 * T * U1)
@@ -258,7 +280,24 @@ def main():
         loss_gbs = loss_bytes / ((lf + lb) * 1e-3) / 1e9
         roof_joint = {"bound": "mfma", "kernel": "gemm_nt_bf16_v8_kernel (joint vocabulary projection, M=%d N=%d K=%d)" % (B * T * U1, V, J),
                       "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                      "traffic": traffic, "mfma_busy": mfma_busy, "kernel_ms": round(k_ms, 4)}
+                      "traffic": traffic, "mfma_busy": mfma_busy, "kernel_ms": round(k_ms, 4), "pmc": pmc_build}
+        # the two weakest kernels of the step, on the record every round
+        enc = cfg["enc"]
+        H, Dh, dm = enc["n_head"], enc["d_head"], enc["d_model"]
+        a_ms = float(np.mean([m for m in attn_ms if m > 0])) if any(m > 0 for m in attn_ms) else float("nan")
+        attn_bytes = B * T * H * Dh * 2.0 * 6 + B * H * T * 8.0       # (q+u), k, v, dO in; dK, dV out (bf16); lse + delta (f32)
+        attn_flops = 10.0 * B * H * T * T * Dh                         # S, dP, dV, dK and (in the following launch) dq products
+        roof_attn = {"bound": "hbm", "kernel": "flash_bwd_kernel, one audio layer (B=%d L=%d H=%d Dh=%d): recomputes P, writes dK / dV and the dS / dG slabs"
+                                               % (B, T, H, Dh),
+                     "achieved": round(attn_bytes / (a_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(attn_bytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(a_ms, 4),
+                     "mfma_tflops": round(0.8 * attn_flops / (a_ms * 1e-3) / 1e12, 1),
+                     "note": "algorithmic bytes only; the bias slab read (B*H*L*L*2) and the dS / dG slabs written (2x) are design traffic on top"}
+        w_ms = float(np.mean([m for m in wgrad_ms if m > 0])) if any(m > 0 for m in wgrad_ms) else float("nan")
+        wg_flops = 2.0 * (3 * H * Dh) * dm * (B * T)
+        roof_wgrad = {"bound": "mfma", "kernel": "qkv_net weight gradient, one audio layer (M=%d N=%d K=%d, f32 atomics across K ranges)" % (3 * H * Dh, dm, B * T),
+                      "achieved": round(wg_flops / (w_ms * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                      "frac": round(wg_flops / (w_ms * 1e-3) / 1e12 / peak, 4), "traffic": None, "kernel_ms": round(w_ms, 4)}
         roof_loss = {"bound": "hbm", "kernel": "RNN-T loss op: rnnt_lse_kernel + rnnt_alphabeta_kernel (%.3f ms) + rnnt_grad_kernel (%.3f ms), "
                                                "logits [%d,%d,%d,%d] %s" % (lf, lb, B, T, U1, V, "bf16" if es == 2 else "f32"),
                      "achieved": round(loss_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(loss_gbs / HBM_PEAK_GBS, 4),
@@ -278,6 +317,7 @@ def main():
             "host_enqueue_ms_per_step": round(1e3 * enqueue / args.steps, 3), "model_tflops": round(flops_per_utt(cfg, T, U1) * utt_s / 1e12, 2),
             "roofline": roof_loss if lattice_run else roof_joint,
             "roofline_joint" if lattice_run else "roofline_loss": roof_joint if lattice_run else roof_loss,
+            "roofline_attn": roof_attn, "roofline_wgrad": roof_wgrad,
             "final_loss": round(float(last.detach()), 4),
         }
         if args.fused_loss:
@@ -287,10 +327,13 @@ def main():
             with torch.no_grad():
                 lg = model(inputs[:args.cpu_utts], targets[:args.cpu_utts])
                 costs = RNNTLoss(reduction="none")(lg, targets[:args.cpu_utts].int(), ilen[:args.cpu_utts], tlen[:args.cpu_utts])
-            v, dt, rel = cpu_baseline(model, feats, proj, targets, T, U, args.cpu_utts, costs.float().cpu().numpy())
+            v, dt, rel, times = cpu_baseline(model, feats, proj, targets, T, U, args.cpu_utts, costs.float().cpu().numpy(), args.cpu_reps)
             out["cpu_baseline"] = {"value": round(v, 4), "unit": "utt/s", "cores": _blas_threads(), "kind": "port",
-                                   "sample": "%d utterance(s) of the same workload, fwd+loss+bwd through oracle/tt_oracle.py "
-                                             "(numpy, multithreaded BLAS) + oracle/rnnt_lattice.c, %.1f s" % (args.cpu_utts, dt)}
+                                   "sample": "%d utterance(s) of the same workload (B=%d as in BASELINE.md §3), fwd+loss+bwd through "
+                                             "oracle/tt_oracle.py (numpy, multithreaded BLAS) + oracle/rnnt_lattice.c, median of %d runs "
+                                             "(%s s)" % (args.cpu_utts, args.cpu_utts, len(times), ", ".join("%.1f" % t for t in times)),
+                                   # the reference's OWN PyTorch CPU path, timed once in the survey container (it cannot travel to the GPU box):
+                                   "reference_cpu_probe": {"value": 0.33, "unit": "utt/s", "cores": 8, "source": "BASELINE.md §2 (fwd+bwd, lattice excluded, B=2)"}}
             out["loss_rel_err_vs_oracle"] = float("%.3e" % rel)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -136,8 +136,9 @@ int ttmi_adam_step(float* p, const float* g, float* m, float* v, long n, float l
 
 /* ---- bring-up / measurement helpers ------------------------------------------------------------------------------
  * generic MFMA GEMM (every layout / dtype / epilogue; flags = GemmFlags of csrc/gemm.h) and the two throughput
- * kernels; HIP-event probes recorded on the launch stream at three points (0 = joint vocabulary projection, 1 = ttmi_rnnt_loss_fwd's
- * kernels, 2 = ttmi_rnnt_loss_bwd's kernel): ttmi_probe_arm(i), 0 <= i < 64, makes the NEXT launch at every point record into its event
+ * kernels; HIP-event probes recorded on the launch stream at five points (0 = joint vocabulary projection, 1 = ttmi_rnnt_loss_fwd's
+ * kernels, 2 = ttmi_rnnt_loss_bwd's kernel, 3 = the fused attention backward kernel of a layer with L >= 256, 4 = the qkv_net weight-gradient GEMM of
+ * a layer with B*L >= 4096): ttmi_probe_arm(i), 0 <= i < 64, makes the NEXT launch at every point record into its event
  * pair i; ttmi_probe_point_read_ms(point, i) waits for that pair and returns its duration in ms (< 0: never fired);
  * ttmi_probe_read_ms(i) = point 0. */
 int ttmi_gemm(const void* A, const void* B, void* C, const float* bias, const float* aux, int a_dtype, int b_dtype,
@@ -147,6 +148,16 @@ int ttmi_gemm_nt_bf16(const void* A, const void* B, void* C, int c_dtype, const 
                       long ldb, long ldc, void* stream);
 int ttmi_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
                       float* colsum_a /* nullable: colsum_a[m] += sum_k A[k][m] */, void* stream);
+/* bf16 shadows of GEMM weights.  Every forward call otherwise converts its f32 master weights to bf16 (plain + transposed copies: 118
+ * launches per step at C2 for weights that change once per optimiser step).  A training loop registers, per weight w [R, C], a plain bf16
+ * copy w16 [R, C] and a transposed one wT16 [C, ldT] (ldT >= R, columns [R, ldT) zero) and rebuilds ALL of them with one launch after each
+ * update (ttmi_weight_shadow_refresh: `table` = device array of n rows of 8 longs (w, R, C, wT16, ldT, w16, first 32x32 tile, tiles along C),
+ * sorted by first tile; total_tiles = their sum).  The sub-layer calls look a shadow up by the f32 pointer and use it when its geometry
+ * matches, else convert as before.  The caller owns the memory and the freshness (ttmi.train.FlatModel). */
+int ttmi_weight_shadow_register(const float* w, int R, int C, const void* w16, const void* wT16, long ldT);
+int ttmi_weight_shadow_clear(const float* w /* NULL = all */);
+int ttmi_weight_shadow_refresh(const long* table, int n, long total_tiles, void* stream);
+
 /* data-parallel runs (train.py:55-56,214-219 replaced by one process per GPU + RCCL): the gradient all-reduce kernels run beside the
  * backward pass; the encoder-sized persistent GEMMs launched on `stream` (and on the library's fork streams serving it) leave n CUs to
  * them.  Per-stream state read at launch time; 0 = whole chip (default). */

@@ -165,3 +165,63 @@ def test_embedding_index_contract():
         ops.embed_fwd(ids.float(), W)
     bad = ops.embed_fwd(torch.tensor([[1, 11, -1]], device="cuda"), W)
     assert torch.isnan(bad[0, 1]).all() and torch.isnan(bad[0, 2]).all() and torch.equal(bad[0, 0], W[1])
+
+
+def test_bf16_weight_shadows_are_transparent(monkeypatch):
+    """FlatModel.enable_shadows(): the library takes its bf16 weight copies from buffers rebuilt once per optimiser step instead of
+    converting in every call.  Same bits as the converting path: on the first step, after fused updates, after an in-place change made
+    through torch (caught by the version check), after an explicit refresh_shadows() following a write through .data, and back to the
+    converting path once disabled."""
+    from tt.model import Transducer
+    from tt.utils import AttrDict
+    from ttmi.train import FlatModel, FusedOptimizer
+    monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    side = dict(n_layer=2, d_model=64, n_head=2, d_head=32, d_inner=96)
+    cfg = AttrDict(dict(enc=dict(side, max_input_length=16), dec=dict(side, max_target_length=8),
+                        joint=dict(input_size=128, inner_size=72), vocab_size=301, dropout=0.0))     # V = 301: the joint's transposed shadow is padded
+
+    def make(shadows):
+        torch.manual_seed(4)
+        model = Transducer(cfg).cuda().train()
+        flat = FlatModel(model)
+        if shadows:
+            flat.enable_shadows()
+            assert flat.shadow["n"] >= 2 * 4 + 2 * 4 + 2        # qkv / o / W1 / W2 of every layer + the joint's two matrices
+        return model, flat, FusedOptimizer(flat, kind="sgd", lr=0.05, momentum=0.9, max_grad_norm=5.0)
+
+    def step(model, flat, opt, s, update=True):
+        flat.zero_grad()
+        loss = _loss_v(model, s)
+        loss.backward()
+        g = flat.grad.clone()
+        if update:
+            opt.step()
+        return loss.detach().clone(), g
+
+    def _loss_v(model, s):
+        from warprnnt_pytorch import RNNTLoss
+        g = torch.Generator().manual_seed(100 + s)
+        x, y = torch.randn(3, 20, 64, generator=g).cuda(), torch.randint(1, 301, (3, 6), generator=g).cuda()
+        return RNNTLoss()(model(x, y), y.int(), torch.full((3,), 20, dtype=torch.int32).cuda(), torch.full((3,), 6, dtype=torch.int32).cuda())
+
+    a, b = make(False), make(True)
+    for s in range(3):
+        la, ga = step(*a, s)
+        lb, gb = step(*b, s)
+        assert torch.equal(la, lb), s
+        assert rel_err(gb.cpu().numpy(), ga.cpu().numpy()) < 1e-5, s                 # (f32 atomic order is the only difference)
+    with torch.no_grad():
+        for m in (a[0], b[0]):
+            m.encoder.layers[0].MultiHeadAttention.pos_ff.CoreNet[0].weight.mul_(1.5)  # through torch: version counter moves
+    la, _ = step(*a, 7, update=False)
+    lb, _ = step(*b, 7, update=False)
+    assert torch.equal(la, lb)
+    for m in (a[0], b[0]):
+        m.joint.project_layer.weight.data.mul_(0.5)                                     # through .data: invisible to the version check
+    b[1].refresh_shadows()
+    la, _ = step(*a, 8, update=False)
+    lb, _ = step(*b, 8, update=False)
+    assert torch.equal(la, lb)
+    b[1].disable_shadows()
+    lb2, _ = step(*b, 8, update=False)
+    assert torch.equal(lb2, lb)

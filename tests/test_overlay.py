@@ -17,14 +17,16 @@ def test_non_hot_path_modules_resolve_to_the_reference():
 import sys
 sys.dont_write_bytecode = True
 import tt, tt.model, tt.encoder, tt.transformer, tt.utils
-import tt.optim                                   # not part of the overlay -> the reference's own file
+import tt.optim                                   # the overlay's (round 2): the reference's wrapper surface on the flat-buffer optimiser
+import tt.kaldi_io                                # not part of the overlay -> the reference's own file
 assert tt.model.__file__.startswith(%r), tt.model.__file__
+assert tt.kaldi_io.__file__.startswith(%r), tt.kaldi_io.__file__
 assert tt.optim.__file__.startswith(%r), tt.optim.__file__
 from tt.utils import AttrDict, look_ahead_mask, context_mask       # hot-path names: ours
 assert AttrDict.__module__ == "tt.utils" and tt.utils.__file__.startswith(%r)
 cfg = AttrDict(dict(type="sgd", lr=0.1, momentum=0.9, weight_decay=0.0, decay_ratio=0.5))
 import torch
-opt = tt.optim.Optimizer([torch.nn.Parameter(torch.zeros(3))], cfg)   # the reference's wrapper drives our AttrDict
+opt = tt.optim.Optimizer([torch.nn.Parameter(torch.zeros(3))], cfg)   # same constructor and counters as the reference's wrapper
 opt.epoch(); opt.decay_lr()
 assert abs(opt.lr - 0.05) < 1e-12 and opt.global_step == 1
 try:
@@ -34,7 +36,7 @@ except AttributeError as e:
     assert "not part of the accelerated path" in str(e)
     print("reference utils unavailable (missing third-party deps), error is explicit")
 print("overlay ok")
-""" % (PKG, REF, PKG)
+""" % (PKG, REF, PKG, PKG)
     env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + REF, PYTHONDONTWRITEBYTECODE="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]

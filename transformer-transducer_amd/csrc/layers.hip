@@ -14,6 +14,7 @@
 #include "gemm_fast.h"
 #include "attn_flash.h"
 #include <mutex>
+#include <unordered_map>
 
 void ttmi_probe_begin(int slot, hipStream_t st);
 void ttmi_probe_end(int slot, hipStream_t st);
@@ -113,6 +114,24 @@ void join_stream(hipStream_t main) {
     if (!c || !c->used) return;
     if (hipEventRecord(c->ev[2], c->side) == hipSuccess) (void)hipStreamWaitEvent(main, c->ev[2], 0);
     c->used = false;
+}
+
+// ---- bf16 shadows of GEMM weights (ttmi_weight_shadow_*): a training loop keeps a plain and a transposed bf16 copy of every weight,
+// rebuilt once per optimiser step (one launch), instead of converting every weight in every forward call (118 launches per step at C2).
+// Registered by the caller, looked up by the f32 weight pointer; a shadow is used only if its geometry is the one the call needs.
+struct Shadow { int R, C; const bf16_t* w16; const bf16_t* wT16; long ldT; };
+std::unordered_map<const void*, Shadow> g_shadows;
+std::mutex g_shadow_mu;
+
+bool shadow_of(const float* w, int R, int C, long ldT, Shadow& out) {
+    std::lock_guard<std::mutex> lock(g_shadow_mu);
+    if (g_shadows.empty()) return false;
+    auto it = g_shadows.find(w);
+    if (it == g_shadows.end()) return false;
+    const Shadow& s = it->second;
+    if (s.R != R || s.C != C || !s.w16 || !s.wT16 || s.ldT != ldT) return false;
+    out = s;
+    return true;
 }
 
 struct AttnDims {
@@ -288,8 +307,11 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
     // 1. qkv = x Wqkv^T ; 2. qu = q + r_w_bias
     if (fast) {
         CK(convert_bf16(x, c.x16, a.BL * d, st));
-        CK(transpose_convert_bf16(qkv_w, (int)a.W3, d, c.wqkvT16, a.W3, st, w.wqkv16));        // Wqkv (bf16) and Wqkv^T [d, W3] for backward
-        CK(gemm_nt_bf16(c.x16, w.wqkv16, c.qkv, 1, nullptr, (int)a.BL, (int)a.W3, d, d, d, a.W3, st));
+        Shadow sh;
+        const bf16_t* wqkv16 = w.wqkv16;
+        if (shadow_of(qkv_w, (int)a.W3, d, a.W3, sh)) wqkv16 = sh.w16;                          // kept current by the optimiser step
+        else CK(transpose_convert_bf16(qkv_w, (int)a.W3, d, c.wqkvT16, a.W3, st, w.wqkv16));   // Wqkv (bf16) and Wqkv^T [d, W3] for backward
+        CK(gemm_nt_bf16(c.x16, wqkv16, c.qkv, 1, nullptr, (int)a.BL, (int)a.W3, d, d, d, a.W3, st));
         CK(add_row_bias_bf16(static_cast<bf16_t*>(c.qkv), a.W3, r_w_bias, a.BL, (int)a.HD, static_cast<bf16_t*>(c.qu), a.HD, st));
     } else {
         CK(ttmi_launch_gemm(mk(x, qkv_w, static_cast<float*>(c.qkv), (int)a.BL, (int)a.W3, d, d, d, a.W3, NT_, prec), st));
@@ -344,8 +366,11 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
     }
     // 8. a = O Wo^T ; 9. y = LN(x + a)
     if (fast) {
-        CK(transpose_convert_bf16(o_w, d, (int)a.HD, c.woT16, d, st, w.wo16));                   // Wo (bf16) and Wo^T [HD, d] for backward
-        CK(gemm_nt_bf16(static_cast<bf16_t*>(c.O), w.wo16, w.a, 0, nullptr, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, st));
+        Shadow sh;
+        const bf16_t* wo16 = w.wo16;
+        if (shadow_of(o_w, d, (int)a.HD, d, sh)) wo16 = sh.w16;
+        else CK(transpose_convert_bf16(o_w, d, (int)a.HD, c.woT16, d, st, w.wo16));              // Wo (bf16) and Wo^T [HD, d] for backward
+        CK(gemm_nt_bf16(static_cast<bf16_t*>(c.O), wo16, w.a, 0, nullptr, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, st));
     } else {
         CK(ttmi_launch_gemm(mk(static_cast<float*>(c.O), o_w, w.a, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, NT_, prec), st));
     }
@@ -383,8 +408,10 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
         da = w.a;
     }
     if (fast) {
+        Shadow sh;
+        const bf16_t* woT16 = shadow_of(o_w, d, (int)a.HD, d, sh) ? sh.wT16 : c.woT16;
         CK(gemm_tn_bf16(w.dres16, static_cast<bf16_t*>(c.O), g_o_w, d, (int)a.HD, (int)a.BL, d, a.HD, a.HD, 1, fork_stream(st)));
-        CK(gemm_nt_bf16(w.dres16, c.woT16, w.dO, 1, nullptr, (int)a.BL, (int)a.HD, d, d, d, a.HD, st));
+        CK(gemm_nt_bf16(w.dres16, woT16, w.dO, 1, nullptr, (int)a.BL, (int)a.HD, d, d, d, a.HD, st));
     } else {
         CK(wgrad(da, static_cast<float*>(c.O), g_o_w, d, (int)a.HD, (int)a.BL, d, a.HD, a.HD, prec, st));
         CK(ttmi_launch_gemm(mk(da, o_w, static_cast<float*>(w.dO), (int)a.BL, (int)a.HD, d, d, a.HD, a.HD, NN_, prec), st));
@@ -485,10 +512,19 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
     // 14. gWqkv += dqkv^T x ; 15. dx += dqkv Wqkv
     if (fast) {
         if (!fastpos) CK(convert_bf16(w.dqkv, w.dqkv16, a.BL * a.W3, st));      // fastpos: dq / dK / dV were written in bf16 by their producers
-        CK(gemm_tn_bf16(w.dqkv16, c.x16, g_qkv_w, (int)a.W3, d, (int)a.BL, a.W3, d, d, 1, fork_stream(st)));
+        {
+            hipStream_t fs = fork_stream(st);
+            const bool probe = a.BL >= 4096;        // timing probe 4: an audio-sized qkv_net weight gradient, on the stream it is launched on
+            if (probe) ttmi_probe_begin(4, fs);
+            const int rc = gemm_tn_bf16(w.dqkv16, c.x16, g_qkv_w, (int)a.W3, d, (int)a.BL, a.W3, d, d, 1, fs);
+            if (probe) ttmi_probe_end(4, fs);
+            CK(rc);
+        }
         NtEpilogue e;
         e.addend = dx;
-        CK(gemm_nt_bf16(w.dqkv16, c.wqkvT16, dx, 0, e, (int)a.BL, d, (int)a.W3, a.W3, a.W3, d, st));
+        Shadow sh;
+        const bf16_t* wqkvT16 = shadow_of(qkv_w, (int)a.W3, d, a.W3, sh) ? sh.wT16 : c.wqkvT16;
+        CK(gemm_nt_bf16(w.dqkv16, wqkvT16, dx, 0, e, (int)a.BL, d, (int)a.W3, a.W3, a.W3, d, st));
     } else {
         CK(wgrad(w.dqkv, x, g_qkv_w, (int)a.W3, d, (int)a.BL, a.W3, d, d, prec, st));
         GemmDesc g = mk(w.dqkv, qkv_w, dx, (int)a.BL, d, (int)a.W3, a.W3, d, d, NN_, prec);
@@ -567,12 +603,16 @@ int ttmi_ffn_fwd(const float* y, const float* w1, const float* b1, const float* 
     FfnWs w(bw, rows, d, Di, fast);
     if (fast) {
         CK(ln_fwd(y, nullptr, ln_g, ln_b, rows, d, 1e-5f, nullptr, nullptr, c.mean1, c.rstd1, st, static_cast<bf16_t*>(c.h)));
-        CK(transpose_convert_bf16(w1, Di, d, c.w1T16, Di, st, w.w1_16));                        // W1 (bf16) and W1^T [d, Di]
-        CK(transpose_convert_bf16(w2, d, Di, c.w2T16, d, st, w.w2_16));                         // W2 (bf16) and W2^T [Di, d]
+        Shadow s1, s2;
+        const bf16_t *w1_16 = w.w1_16, *w2_16 = w.w2_16;
+        if (shadow_of(w1, Di, d, Di, s1)) w1_16 = s1.w16;
+        else CK(transpose_convert_bf16(w1, Di, d, c.w1T16, Di, st, w.w1_16));                   // W1 (bf16) and W1^T [d, Di]
+        if (shadow_of(w2, d, Di, d, s2)) w2_16 = s2.w16;
+        else CK(transpose_convert_bf16(w2, d, Di, c.w2T16, d, st, w.w2_16));                    // W2 (bf16) and W2^T [Di, d]
         NtEpilogue e1;
         e1.bias = b1; e1.relu = 1; e1.drop = d_in;
-        CK(gemm_nt_bf16(static_cast<bf16_t*>(c.h), w.w1_16, c.a1, 1, e1, (int)rows, Di, d, d, d, Di, st));
-        CK(gemm_nt_bf16(static_cast<bf16_t*>(c.a1), w.w2_16, w.f, 0, b2, (int)rows, d, Di, Di, Di, d, st));
+        CK(gemm_nt_bf16(static_cast<bf16_t*>(c.h), w1_16, c.a1, 1, e1, (int)rows, Di, d, d, d, Di, st));
+        CK(gemm_nt_bf16(static_cast<bf16_t*>(c.a1), w2_16, w.f, 0, b2, (int)rows, d, Di, Di, Di, d, st));
     } else {
         float* h = static_cast<float*>(c.h);
         float* a1 = static_cast<float*>(c.a1);
@@ -618,12 +658,15 @@ int ttmi_ffn_bwd(const float* dz, const float* y, const float* w1, const float* 
         bf16_t* a1 = static_cast<bf16_t*>(c.a1);
         bf16_t* h = static_cast<bf16_t*>(c.h);
         bf16_t* da1 = static_cast<bf16_t*>(w.da1);
+        Shadow s1, s2;
+        const bf16_t* w1T16 = shadow_of(w1, Di, d, Di, s1) ? s1.wT16 : c.w1T16;
+        const bf16_t* w2T16 = shadow_of(w2, d, Di, d, s2) ? s2.wT16 : c.w2T16;
         CK(gemm_tn_bf16(w.dres16, a1, g_w2, d, Di, (int)rows, d, Di, Di, 1, fork_stream(st)));
         NtEpilogue e;
         e.mask = a1; e.scale = inv_keep;                   // a1 is stored post-dropout: a1 > 0 <=> ReLU active AND kept
-        CK(gemm_nt_bf16(w.dres16, c.w2T16, da1, 1, e, (int)rows, Di, d, d, d, Di, st));
+        CK(gemm_nt_bf16(w.dres16, w2T16, da1, 1, e, (int)rows, Di, d, d, d, Di, st));
         CK(gemm_tn_bf16(da1, h, g_w1, Di, d, (int)rows, Di, d, d, 1, fork_stream(st), g_b1));   // g_b1 = column sums of da1, fused
-        CK(gemm_nt_bf16(da1, c.w1T16, w.dh, 0, nullptr, (int)rows, d, Di, Di, Di, d, st));
+        CK(gemm_nt_bf16(da1, w1T16, w.dh, 0, nullptr, (int)rows, d, Di, Di, Di, d, st));
     } else {
         const float* a1 = static_cast<const float*>(c.a1);
         const float* h = static_cast<const float*>(c.h);
@@ -688,9 +731,12 @@ int ttmi_joint_fwd(const float* enc, const float* dec, const float* wf, const fl
         bf16_t* Wf16 = dec16 + al8((size_t)B * U1 * dd);
         CK(convert_bf16(enc, enc16, (long)B * T * de, st));
         CK(convert_bf16(dec, dec16, (long)B * U1 * dd, st));
-        CK(convert_bf16(wf, Wf16, (long)J * din, st));
-        CK(gemm_nt_bf16(enc16, Wf16, PE, 0, nullptr, B * T, J, de, de, din, J, st));
-        CK(gemm_nt_bf16(dec16, Wf16 + de, PD, 0, nullptr, B * U1, J, dd, dd, din, J, st));
+        Shadow sh;
+        const bf16_t* wf16 = Wf16;
+        if (shadow_of(wf, J, din, J, sh)) wf16 = sh.w16;
+        else CK(convert_bf16(wf, Wf16, (long)J * din, st));
+        CK(gemm_nt_bf16(enc16, wf16, PE, 0, nullptr, B * T, J, de, de, din, J, st));
+        CK(gemm_nt_bf16(dec16, wf16 + de, PD, 0, nullptr, B * U1, J, dd, dd, din, J, st));
     } else {
         CK(ttmi_launch_gemm(mk(enc, wf, PE, B * T, J, de, de, din, J, NT_, prec), st));
         CK(ttmi_launch_gemm(mk(dec, wf + de, PD, B * U1, J, dd, dd, din, J, NT_, prec), st));
@@ -710,9 +756,12 @@ int ttmi_joint_fwd(const float* enc, const float* dec, const float* wf, const fl
     bf16_t* H16 = reinterpret_cast<bf16_t*>(ctx);
     bf16_t* Wp16 = reinterpret_cast<bf16_t*>(PD + 2 * al4((size_t)B * U1 * J));
     CK(joint_tanh_fwd(PE, PD, bf, B, T, U1, J, H16, 1, st));
-    CK(convert_bf16(wp, Wp16, (long)V * J, st));
+    Shadow shp;
+    const bf16_t* wp16 = Wp16;
+    if (shadow_of(wp, V, J, (V + 63) / 64 * 64, shp)) wp16 = shp.w16;
+    else CK(convert_bf16(wp, Wp16, (long)V * J, st));
     ttmi_probe_begin(0, st);
-    const int rc = gemm_nt_bf16(H16, Wp16, logits, 1, bp, M, V, J, J, J, ldv, st);
+    const int rc = gemm_nt_bf16(H16, wp16, logits, 1, bp, M, V, J, J, J, ldv, st);
     ttmi_probe_end(0, st);
     CK(rc);
     return TTMI_OK;
@@ -747,11 +796,14 @@ int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float*
         bf16_t* WpT16 = reinterpret_cast<bf16_t*>(dPD + 2 * al4((size_t)B * U1 * J));    // [J, ldg], zero beyond V
         TTMI_REQUIRE((size_t)J * ldg <= 2 * al4((size_t)J * (((size_t)V + 63) / 64 * 64)), "joint_bwd: pitch %ld too large for the workspace", ldg);
         CK(gemm_tn_bf16(dZ, H16, g_wp, V, J, M, ldg, J, J, 1, st, g_bp));      // g_bp = column sums of dZ, fused
-        CK(transpose_convert_bf16(wp, V, J, WpT16, ldg, st));
+        Shadow shp;
+        const bf16_t* wpT16 = WpT16;
+        if (shadow_of(wp, V, J, ldg, shp)) wpT16 = shp.wT16;                    // [J, ldg], zero beyond V (kept so by the refresh kernel)
+        else CK(transpose_convert_bf16(wp, V, J, WpT16, ldg, st));
         NtEpilogue e;                                                           // dH * (1 - H^2) in the dgrad epilogue
         e.mask = H16;
         e.mask_mode = 1;
-        CK(gemm_nt_bf16(dZ, WpT16, dH16, 1, e, M, J, (int)ldg, ldg, ldg, J, st));
+        CK(gemm_nt_bf16(dZ, wpT16, dH16, 1, e, M, J, (int)ldg, ldg, ldg, J, st));
         CK(fill_zero(dPD, sizeof(float) * (size_t)B * U1 * J, st));
         CK(joint_tanh_bwd(dH16, nullptr, 1, B, T, U1, J, dPE, dPD, st));
     }
@@ -767,11 +819,14 @@ int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float*
         CK(convert_bf16(dec, dec16, (long)B * U1 * dd, st));
         CK(convert_bf16(dPE, dPE16, (long)B * T * J, st));
         CK(convert_bf16(dPD, dPD16, (long)B * U1 * J, st));
-        CK(transpose_convert_bf16(wf, J, din, WfT16, J, st));
+        Shadow shf;
+        const bf16_t* wfT16 = WfT16;
+        if (shadow_of(wf, J, din, J, shf)) wfT16 = shf.wT16;
+        else CK(transpose_convert_bf16(wf, J, din, WfT16, J, st));
         CK(gemm_tn_bf16(dPE16, enc16, g_wf, J, de, B * T, J, de, din, 1, fork_stream(st), g_bf));
         CK(gemm_tn_bf16(dPD16, dec16, g_wf + de, J, dd, B * U1, J, dd, din, 1, fork_stream(st)));
-        CK(gemm_nt_bf16(dPE16, WfT16, denc, 0, nullptr, B * T, de, J, J, J, de, st));
-        CK(gemm_nt_bf16(dPD16, WfT16 + (size_t)de * J, ddec, 0, nullptr, B * U1, dd, J, J, J, dd, st));
+        CK(gemm_nt_bf16(dPE16, wfT16, denc, 0, nullptr, B * T, de, J, J, J, de, st));
+        CK(gemm_nt_bf16(dPD16, wfT16 + (size_t)de * J, ddec, 0, nullptr, B * U1, dd, J, J, J, dd, st));
         join_stream(st);
         return TTMI_OK;
     }
@@ -781,6 +836,24 @@ int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float*
     CK(ttmi_launch_gemm(mk(dPE, wf, denc, B * T, de, J, J, din, de, NN_, prec), st));
     CK(ttmi_launch_gemm(mk(dPD, wf + de, ddec, B * U1, dd, J, J, din, dd, NN_, prec), st));
     return TTMI_OK;
+}
+
+// ---- bf16 weight shadows
+int ttmi_weight_shadow_register(const float* w, int R, int C, const void* w16, const void* wT16, long ldT) {
+    TTMI_REQUIRE(w && w16 && wT16 && R > 0 && C > 0 && ldT >= R, "weight_shadow_register: bad arguments");
+    TTMI_REQUIRE(aligned16(w16) && aligned16(wT16) && C % 8 == 0 && ldT % 8 == 0, "weight_shadow_register: shadows must be 16-byte aligned with row pitches %% 8 == 0");
+    std::lock_guard<std::mutex> lock(g_shadow_mu);
+    g_shadows[w] = Shadow{R, C, static_cast<const bf16_t*>(w16), static_cast<const bf16_t*>(wT16), ldT};
+    return TTMI_OK;
+}
+int ttmi_weight_shadow_clear(const float* w) {
+    std::lock_guard<std::mutex> lock(g_shadow_mu);
+    if (w) g_shadows.erase(w);
+    else g_shadows.clear();
+    return TTMI_OK;
+}
+int ttmi_weight_shadow_refresh(const long* table, int n, long total_tiles, void* stream) {
+    return shadow_refresh(table, n, total_tiles, static_cast<hipStream_t>(stream));
 }
 
 // CUs that the encoder-sized persistent GEMMs launched on `stream` leave free (for RCCL's kernels running beside a data-parallel

@@ -116,10 +116,11 @@ int ttmi_adam_step(float* p, const float* g, float* m, float* v, long n, float l
 
 // ---- timing probes: HIP events recorded on the launch stream around named launches --------------------------
 // Probe points: 0 = joint vocabulary projection GEMM (forward), 1 = RNN-T loss forward (log-sum-exp pass + lattice), 2 = RNN-T loss
-// backward (gradient pass).  Events are owned by the library.  Every point records into whichever of the 64 event pairs was armed
+// backward (gradient pass), 3 = fused attention backward kernel of an audio-sized layer (L >= 256), 4 = the qkv_net weight-gradient GEMM of
+// an audio-sized layer (rows >= 4096).  Events are owned by the library.  Every point records into whichever of the 64 event pairs was armed
 // last, so a timing loop can arm pair i in step i and read them all after its final fence - no host synchronisation inside the
 // timed region.
-constexpr int NPROBE = 64, NPOINT = 3;
+constexpr int NPROBE = 64, NPOINT = 5;
 static hipEvent_t g_probe[NPOINT][NPROBE][2];
 static int g_probe_state[NPOINT][NPROBE];     // 0 idle, 1 armed, 2 recorded
 static int g_probe_cur = -1;

@@ -57,6 +57,8 @@ int convert_bf16(const float* src, bf16_t* dst, long n, hipStream_t st);
 // dst[c, r] (bf16, pitch ldd >= R, columns [R, ldd) zero) = src[r, c] (f32, [R, C] dense)
 // plain (optional): also the untransposed bf16 copy [R, C] (forward passes get both from one read of the weight)
 int transpose_convert_bf16(const float* src, int R, int C, bf16_t* dst, long ldd, hipStream_t st, bf16_t* plain = nullptr);
+// one launch rebuilding the plain + transposed bf16 copies of every weight in `table` (device, n rows of 8 longs, see rowops.hip)
+int shadow_refresh(const long* table, int n, long total_tiles, hipStream_t st);
 // out[c] += sum_r in[r*ld + c] for a bf16 matrix (atomic; caller zeroes / accumulates)
 int colsum_bf16(const bf16_t* in, long ld, long rows, int cols, float* out, hipStream_t st, int nz1 = 1, int nz2 = 1, long si1 = 0,
                 long si2 = 0, long so2 = 0);   // batch z = z1*nz2+z2 reads in + z1*si1 + z2*si2, adds into out + z2*so2

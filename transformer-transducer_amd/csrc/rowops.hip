@@ -630,6 +630,42 @@ __global__ __launch_bounds__(256) void transpose_convert_kernel(const float* __r
     }
 }
 
+// the same tile transpose for MANY weights in one launch (the bf16 shadows of ttmi.train.FlatModel, refreshed once per optimiser step):
+// table row = (src f32*, R, C, dstT bf16*, ldd, plain bf16*, first tile, tiles along C); block b serves the weight whose tile range holds b
+__global__ __launch_bounds__(256) void shadow_refresh_kernel(const long* __restrict__ table, int n) {
+    __shared__ float tile[32][33];
+    __shared__ long ent[8];
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {                                   // last entry whose first tile <= blockIdx.x
+            const int mid = (lo + hi + 1) >> 1;
+            if (table[mid * 8 + 6] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        for (int k = 0; k < 8; ++k) ent[k] = table[lo * 8 + k];
+    }
+    __syncthreads();
+    const float* src = reinterpret_cast<const float*>(ent[0]);
+    const int R = (int)ent[1], C = (int)ent[2];
+    bf16_t* dst = reinterpret_cast<bf16_t*>(ent[3]);
+    const long ldd = ent[4];
+    bf16_t* plain = reinterpret_cast<bf16_t*>(ent[5]);
+    const int t = (int)((long)blockIdx.x - ent[6]), tx_n = (int)ent[7];
+    const int r0 = (t / tx_n) * 32, c0 = (t % tx_n) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        const float v = (r < R && c < C) ? src[(long)r * C + c] : 0.f;
+        tile[i][tx] = v;
+        if (plain && r < R && c < C) plain[(long)r * C + c] = f32_to_bf16(v);
+    }
+    __syncthreads();
+    if (dst)
+        for (int i = ty; i < 32; i += 8) {
+            const int c = c0 + i, r = r0 + tx;
+            if (c < C && r < ldd) dst[(long)c * ldd + r] = f32_to_bf16(tile[tx][i]);     // rows [R, ldd) of the pitch receive zeros
+        }
+}
+
 constexpr int CSB_ROWS = 128;
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ in_, long ld, long rows, int cols,
                                                           float* __restrict__ out_, int nz2, long si1, long si2, long so2) {
@@ -893,6 +929,13 @@ int transpose_convert_bf16(const float* src, int R, int C, bf16_t* dst, long ldd
     TTMI_REQUIRE(src && dst && R > 0 && C > 0 && ldd >= R, "transpose_convert_bf16: bad arguments");
     hipLaunchKernelGGL(transpose_convert_kernel, dim3(cdiv(C, 32), cdiv(ldd, 32)), dim3(256), 0, st, src, R, C, dst, ldd, plain);
     TTMI_LAUNCH_CHECK("transpose_convert_kernel");
+    return TTMI_OK;
+}
+
+int shadow_refresh(const long* table, int n, long total_tiles, hipStream_t st) {
+    TTMI_REQUIRE(table && n > 0 && total_tiles > 0 && total_tiles < (1L << 31), "shadow_refresh: bad arguments");
+    hipLaunchKernelGGL(shadow_refresh_kernel, dim3((unsigned)total_tiles), dim3(256), 0, st, table, n);
+    TTMI_LAUNCH_CHECK("shadow_refresh_kernel");
     return TTMI_OK;
 }
 

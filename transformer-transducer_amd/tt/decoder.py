@@ -55,6 +55,7 @@ class BuildDecoder(nn.Module):
             for _ in range(config.dec.n_layer)])
 
     def forward(self, inputs, mask=None):
+        ops.weights_fresh()
         spec = as_mask_spec(mask, inputs.size(0), inputs.size(1))
         x = _EmbedFn.apply(inputs, self.dec_embedding.weight, self.dec_embedding.padding_idx)
         for layer in self.layers:

@@ -4,6 +4,7 @@ r_w_bias[H,Dh], r_bias[K,H] (randn init, :18-20) + one RelLearnableDecoderLayer 
 import torch
 import torch.nn as nn
 
+from ttmi import ops
 from tt.transformer import RelLearnableDecoderLayer, as_mask_spec
 
 
@@ -32,6 +33,7 @@ class BuildEncoder(nn.Module):
             for _ in range(config.enc.n_layer)])
 
     def forward(self, inputs, mask=None):
+        ops.weights_fresh()
         spec = as_mask_spec(mask, inputs.size(0), inputs.size(1))     # converted once, shared by every layer
         x = inputs
         for layer in self.layers:

@@ -108,6 +108,7 @@ class JointNet(nn.Module):
         self.project_layer = nn.Linear(inner_dim, vocab_size, bias=True)
 
     def forward(self, enc_state, dec_state):
+        ops.weights_fresh()
         if enc_state.dim() == 3 and dec_state.dim() == 3:
             squeeze = None
         else:
@@ -202,6 +203,7 @@ class Transducer(nn.Module):
         B, T, U1 = enc_state.shape[0], enc_state.shape[1], dec_state.shape[1]
         labels, al, ll = (t.to(device=enc_state.device, dtype=torch.int32).contiguous() for t in (targets, inputs_length, targets_length))
         certify(labels, al, ll, B, T, U1, check_lengths)
+        ops.weights_fresh()
         prec = default_precision()
         if chunk is None:
             es = 2 if ops.joint_logits_dtype(prec, self.joint.forward_layer.out_features) is torch.bfloat16 else 4

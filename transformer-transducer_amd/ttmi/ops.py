@@ -20,6 +20,16 @@ def _stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def weights_fresh():
+    """called at the module-level entry points (BuildEncoder / BuildDecoder / JointNet forward, Transducer.loss) before weights are handed
+    to the library: if a ttmi.train.FlatModel keeps bf16 weight shadows and a parameter was changed through torch since their last
+    refresh, they are rebuilt first.  Free when no shadows exist."""
+    import sys
+    tr = sys.modules.get("ttmi.train")
+    if tr is not None and tr._shadowed:
+        tr.ensure_fresh()
+
+
 def _need_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:

@@ -34,9 +34,80 @@ class FlatModel:
             p.grad = self.grad[o:o + p.numel()].view_as(p)
             p._ttmi_direct = True           # the HIP backward kernels accumulate straight into p.grad (tt.transformer.grad_targets)
         self.numel = n
+        self.shadow = None
 
     def zero_grad(self):
         self.grad.zero_()
+
+    # ---- bf16 shadows of the GEMM weights (include/ttmi.h: ttmi_weight_shadow_*)
+    def enable_shadows(self):
+        """Keep a plain and a transposed bf16 copy of every 2-D GEMM weight, rebuilt by ONE launch after each optimiser step, and
+        register them with the library: the bf16 pipeline's forward / backward calls then skip their per-call weight conversions
+        (118 launches per step at C2).  Freshness: FusedOptimizer.step refreshes after its update; in-place changes made through the
+        parameter itself (load_state_dict, `with torch.no_grad(): p.mul_(..)`) bump its version counter and are caught by `ensure_fresh()`
+        at the next encoder / decoder / joint call; after writing through `p.data` or the flat buffer directly, call refresh_shadows()."""
+        import weakref
+        dev = self.flat.device
+        if dev.type != "cuda":
+            raise ValueError("bf16 weight shadows need the parameters on the GPU")
+        ents = [(p, o) for p, o in zip(self.params, self.offsets) if p.dim() == 2 and p.shape[1] % 8 == 0 and p.shape[0] >= 64]
+        plain = torch.zeros(sum((p.numel() + 7) // 8 * 8 for p, _ in ents), dtype=torch.bfloat16, device=dev)
+        ldts = [(p.shape[0] + 63) // 64 * 64 if p.shape[0] % 8 else p.shape[0] for p, _ in ents]
+        trans = torch.zeros(sum((p.shape[1] * ld + 7) // 8 * 8 for (p, _), ld in zip(ents, ldts)), dtype=torch.bfloat16, device=dev)
+        rows, po, to, tile0 = [], 0, 0, 0
+        L = ops.lib()
+        for (p, o), ld in zip(ents, ldts):
+            R, C = p.shape
+            w16, wT16 = plain[po:po + R * C], trans[to:to + C * ld]
+            tx, ty = (C + 31) // 32, (ld + 31) // 32
+            rows.append([p.data_ptr(), R, C, wT16.data_ptr(), ld, w16.data_ptr(), tile0, tx])
+            ops.check(L.ttmi_weight_shadow_register(ops.c_void_p(p.data_ptr()), ops.c_int(R), ops.c_int(C), ops.c_void_p(w16.data_ptr()),
+                                                    ops.c_void_p(wT16.data_ptr()), ops.c_long(ld)), "ttmi_weight_shadow_register")
+            po += (R * C + 7) // 8 * 8
+            to += (C * ld + 7) // 8 * 8
+            tile0 += tx * ty
+        self.shadow = dict(plain=plain, trans=trans, table=torch.tensor(rows, dtype=torch.int64, device=dev), n=len(rows), tiles=tile0,
+                           version=-1, ptrs=[r[0] for r in rows])
+        _shadowed.append(weakref.ref(self))
+        self.refresh_shadows()
+        return self
+
+    def refresh_shadows(self):
+        sh = self.shadow
+        if sh is None:
+            return
+        ops.check(ops.lib().ttmi_weight_shadow_refresh(ops.c_void_p(sh["table"].data_ptr()), ops.c_int(sh["n"]), ops.c_long(sh["tiles"]),
+                                                       ops._stream()), "ttmi_weight_shadow_refresh")
+        sh["version"] = self._versions()
+
+    def _versions(self):
+        return sum(p._version for p in self.params)
+
+    def disable_shadows(self):
+        if self.shadow is not None:
+            for ptr in self.shadow["ptrs"]:
+                ops.lib().ttmi_weight_shadow_clear(ops.c_void_p(ptr))
+            self.shadow = None
+
+    def __del__(self):
+        try:
+            self.disable_shadows()
+        except Exception:
+            pass
+
+
+_shadowed = []      # weak references to FlatModels with live shadows
+
+
+def ensure_fresh():
+    """called by the sub-layer autograd functions before they hand weights to the library: a parameter changed through torch since the
+    last refresh (the flat buffer's version counter moved) gets its shadows rebuilt first"""
+    for ref in _shadowed[:]:
+        fm = ref()
+        if fm is None or fm.shadow is None:
+            _shadowed.remove(ref)
+        elif fm._versions() != fm.shadow["version"]:
+            fm.refresh_shadows()
 
 
 class GradSync:
@@ -162,6 +233,7 @@ class FusedOptimizer:
         else:
             ops.sgd_step(flat.flat, flat.grad, self.state[0], self.lr, self.momentum, self.weight_decay,
                          self.nesterov, max_norm, self.normsq, scale)
+        flat.refresh_shadows()              # the kernels above changed the weights behind torch's back: rebuild the bf16 copies (one launch)
 
     def grad_norm(self):
         return self.normsq.sqrt() / self.world
