@@ -165,7 +165,8 @@ int ttmi_stream_reserve_cus(void* stream, int n);
 /* process-wide A/B switches for MEASUREMENTS ONLY (not thread-safe against concurrent launches, no product path depends on them): key 0: 1 = no fused attention kernels; 1: throughput-GEMM generation (csrc/gemm_fast.hip; 14 / 15 = streaming output stores off / on);
  * 2: flash-kernel timing bits; 3: 0 = no side-stream wgrad fork; 4: split-K workgroup target; 5: 1 = position-term slab by batched GEMM;
  * 6: process-wide default of ttmi_stream_reserve_cus for streams that never set one;
- * 7: exact-f32 products with at most n rows use the skinny 32x32 split-reduction kernel (default 128, 0 = never: greedy decode A/B) */
+ * 7: exact-f32 products with at most n rows use the skinny 32x32 split-reduction kernel (default 128, 0 = never: greedy decode A/B);
+ * 8: 0 = the fused attention kernels read the position term from a [B,H,L,L+1] bf16 slab (round-1 design) instead of forming it themselves */
 int ttmi_set_option(int key, int value);
 int ttmi_dropout_apply(const float* in, long n, float p, unsigned seed, float* out, void* stream);
 int ttmi_probe_arm(int slot);

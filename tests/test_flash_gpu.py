@@ -73,12 +73,14 @@ def test_position_slab_kernel_matches_the_gemm_path(Dh, H, L, K, monkeypatch):
     layer = BaseEncoder(k_len=K, n_head=H, d_model=d, d_head=Dh, d_inner=64, dropout=0.0).cuda().eval()
     x = torch.randn(B, L, d, device="cuda")
     cot = torch.randn(B, L, d, device="cuda")
-    y1, dx1, g1 = _run(layer, x, cot, MaskSpec(0))
-    ops.set_option(5, 1)
+    ops.set_option(8, 0)                     # the slab design (round 1): position term through HBM
     try:
+        y1, dx1, g1 = _run(layer, x, cot, MaskSpec(0))
+        ops.set_option(5, 1)
         y0, dx0, g0 = _run(layer, x, cot, MaskSpec(0))
     finally:
         ops.set_option(5, 0)
+        ops.set_option(8, 1)
     assert rel_err(y1.cpu().numpy(), y0.cpu().numpy()) < 2e-3       # bf16 activations downstream of an f32-rounding-level change
     assert rel_err(dx1.cpu().numpy(), dx0.cpu().numpy()) < 5e-3
 
@@ -143,3 +145,53 @@ def test_masked_tile_skipping_changes_nothing(L, kind, monkeypatch):
     assert torch.equal(y, y3) and torch.equal(dx, dx3)
     for n in g:
         assert rel_err(g[n].cpu().numpy(), g3[n].cpu().numpy()) < 1e-5, n
+
+
+@pytest.mark.parametrize("Dh,H,L,K,mk", [(64, 2, 70, 128, "none"), (64, 2, 150, 40, "none"), (32, 4, 33, 64, "causal"), (64, 1, 129, 16, "band"),
+                                          (32, 2, 96, 200, "chunk"), (64, 8, 500, 410, "none"), (64, 2, 1000, 410, "band"), (64, 1, 257, 300, "causal"),
+                                          (64, 1, 1, 8, "none"), (64, 1, 2, 8, "none"), (32, 1, 640, 64, "none")])
+def test_position_term_inside_the_kernels_vs_the_slab_design(Dh, H, L, K, mk, monkeypatch):
+    """the fused kernels form BD = _rel_shift(q E^T + c) themselves (table window in LDS, MFMA blocks, skew through a private LDS image:
+    tt/transformer.py:82-89,143-149) - against the round-1 design that read it from a [B, H, L, L+1] slab: same bf16 operands, f32
+    accumulation in a different order, so outputs agree to bf16 rounding; and against the float64 oracle with the same bounds as the slab
+    path.  Lengths on and off the tile grid, both table branches (L <= K, L > K), every structured mask, L = 1 and 2 (no upper part)."""
+    from tt.encoder import BaseEncoder
+    from tt.transformer import as_mask_spec
+    from ttmi import ops
+    from ttmi.ops import MaskSpec
+    monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    d, B = H * Dh, 2
+    torch.manual_seed(L + Dh)
+    layer = BaseEncoder(k_len=K, n_head=H, d_model=d, d_head=Dh, d_inner=64, dropout=0.0).cuda().eval()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, L, d, generator=g).cuda()
+    cot = torch.randn(B, L, d, generator=g).cuda()
+    omask = None
+    if mk == "none":
+        mask = MaskSpec(0)
+    elif mk == "causal":
+        mask, omask = MaskSpec(1), O.look_ahead_mask(L)[:, :, None]
+    elif mk == "band":
+        mask, omask = MaskSpec(2, left=20, right=3), O.context_mask(L, 20, 3)[:, :, None]
+    else:
+        m = O.chunk_mask(L, 16, 32)
+        mask, omask = as_mask_spec(torch.tensor(m != 0).cuda()[:, :, None], B, L), m[:, :, None]
+        assert mask.kind == 4
+    y1, dx1, g1 = _run(layer, x, cot, mask)
+    ops.set_option(8, 0)
+    try:
+        y0, dx0, g0 = _run(layer, x, cot, mask)
+    finally:
+        ops.set_option(8, 1)
+    e_y, e_dx = rel_err(y1.cpu().numpy(), y0.cpu().numpy()), rel_err(dx1.cpu().numpy(), dx0.cpu().numpy())
+    e_g = max(rel_err(g1[n].cpu().numpy(), g0[n].cpu().numpy()) for n in g1)
+    sd = {"encoder.layers.0." + k: v.detach().cpu().numpy().astype(np.float64) for k, v in layer.state_dict().items()}
+    prm = O.layer_params(sd, "encoder.", 0)
+    want, cache = O.layer_fwd(x.cpu().numpy().astype(np.float64), prm, omask)
+    dxo, go = O.layer_bwd(cot.cpu().numpy().astype(np.float64), cache, prm)
+    names = {v: k for k, v in O._LAYER_KEYS.items()}
+    o_y, o_dx = rel_err(y1.cpu().numpy(), want), rel_err(dx1.cpu().numpy(), dxo)
+    o_g = max(rel_err(g1[n].cpu().numpy(), go[names[n]]) for n in g1)
+    print("in-kernel vs slab: out %.2e dx %.2e grads %.2e | vs oracle: out %.2e dx %.2e grads %.2e" % (e_y, e_dx, e_g, o_y, o_dx, o_g))
+    assert e_y < 5e-3 and e_dx < 2e-2 and e_g < 2e-2
+    assert o_y < 3e-2 and o_dx < 8e-2 and o_g < 8e-2

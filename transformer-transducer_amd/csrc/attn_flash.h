@@ -10,6 +10,13 @@ struct FlashParams {
     long ld_qu = 0, ld_kv = 0, ld_o = 0;
     const bf16_t* bd = nullptr;   // shifted position scores (bf16): element (z, i, j) at bd[z*slab + i*L + j]  (z = b*H + h)
     long slab = 0;
+    // position term formed inside the kernels (no slab): plain q rows (same row indexing as qu), the effective table E16 [L, ld_e] (row p =
+    // r_emb[max(0, p + K - L)], head h at column h*Dh) and its bias cT [H][L]; used when e16 != nullptr
+    const bf16_t* qp = nullptr;
+    long ld_qp = 0;
+    const bf16_t* e16 = nullptr;
+    long ld_e = 0;
+    const float* cT = nullptr;
     bf16_t* o = nullptr;          // attention output (fwd: written, bwd: read)
     float* lse = nullptr;         // [B*H, L] log-sum-exp of the scaled, masked scores
     // backward only

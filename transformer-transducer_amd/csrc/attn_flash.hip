@@ -294,6 +294,594 @@ __global__ __launch_bounds__(256, FWD_MINB) void flash_fwd_kernel(const FlashPar
     }
 }
 
+// ------------------------------------------------------------------ forward with the position term formed in the kernel
+// BD[i][j] (tt/transformer.py:143-149 incl. _rel_shift) depends on (i, j) only through p' = L-1-i+j and on WHICH query row multiplies the
+// table: with the extended table Eext[p'] = E[p'] (p' <= L-1), 0 (p' = L), E[p'-L-1] (p' >= L+1) and cext likewise,
+//     BD[i][j] = (p' <= L-1 ? q_i : q_{i+1}) . Eext[p'] + cext[p'],        p' = L-1-i+j
+// (lower triangle incl. diagonal / forced zero at j = i+1 / the shift's wrap-around above it).  For a wave's 32
+// queries and a 64-key tile the p' values form ONE window of 95 table rows: G^T = Eext_window . q^T is three 32x32 MFMA blocks (rows = p',
+// columns = queries; blocks entirely below L use q_i, entirely above L use q_{i+1}, the one block that straddles L takes both products with
+// the other side's table rows zeroed), and the skew p' -> j is a read of the block through a private LDS image at [query][31 - ii + jj].
+// No [B, H, L, L] slab exists: the table window (192 rows for the workgroup's 128 queries) is staged in LDS next to the K / V tiles.
+template <int DH, int MK>
+__global__ __launch_bounds__(256, 2) void flash_fwd_rel_kernel(const FlashParams p) {
+    using T = Tile<DH>;
+    constexpr int KS = DH / 16, DT = DH / 32;
+    constexpr int EROWS = 256, GP = 100;                       // table ring of 256 rows (slot = p' & 255): a tile's window is 192 rows, each key tile adds 64
+                                                               // Gs row pitch in bf16 (96 window columns + 4): 200 bytes
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ktile = smem;
+    char* vtile = smem + 64 * T::ROWB;
+    char* etile = smem + 128 * T::ROWB;                        // [192][DH] swizzled like the K tile
+    float* ctile = reinterpret_cast<float*>(smem + (128 + EROWS) * T::ROWB);        // cext of the window
+    bf16_t* gs_all = reinterpret_cast<bf16_t*>(ctile + EROWS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, ii = lane & 31;
+    bf16_t* gs = gs_all + wave * 32 * GP + ii * GP;            // this lane's query row of the wave's private image
+    const int z = blockIdx.y, b = z / p.H, h = z % p.H;
+    const int L = p.L;
+    const int i0w = blockIdx.x * 128;
+    const int i = i0w + wave * 32 + ii;
+    const int ic = min(i, L - 1);
+    const bf16_t* qrow = p.qu + ((long)b * L + ic) * p.ld_qu + h * DH;
+    const bf16_t* prow = p.qp + ((long)b * L + ic) * p.ld_qp + h * DH;
+    const bf16_t* prow1 = p.qp + ((long)b * L + min(ic + 1, L - 1)) * p.ld_qp + h * DH;
+    bf16x8 qf[KS], qp[KS], qp1[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks + 8 * hh);
+        qp[ks] = *reinterpret_cast<const bf16x8*>(prow + 16 * ks + 8 * hh);
+        qp1[ks] = *reinterpret_cast<const bf16x8*>(prow1 + 16 * ks + 8 * hh);
+    }
+    f32x16 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m = NEGBIG, l = 0.f;
+    int mlo = 0, mhi = 0x7fffffff;
+    if constexpr (MK == 4) {
+        const int* r = reinterpret_cast<const int*>(p.mask) + (long)b * p.mask_sb + 2 * ic;
+        mlo = r[0];
+        mhi = r[1];
+    }
+    const bf16_t* kbase = p.k + (long)b * L * p.ld_kv + h * DH;
+    const bf16_t* vbase = p.v + (long)b * L * p.ld_kv + h * DH;
+    const bf16_t* ebase = p.e16 + h * DH;
+    const float* cbase = p.cT + (long)h * L;
+
+    // table window of a key tile: rows p' = wbase .. wbase + 191, wbase = L - 128 - i0w + j0 (wave w reads rows 96 - 32 w .. + 95 of it),
+    // kept in a ring: row p' lives in slot (p' - L) & 255; the first tile stages all 192 rows, every later tile only its 64 new ones
+    u32x4_t epre[2];                                           // the 64 new rows of the next tile (DH = 64: 512 chunks, 2 per thread)
+    float cpre = 0.f;
+    auto ext_row = [&](int pe, int& src) -> bool {             // extended-table row p' -> source row of E / c, false = zero row
+        src = pe < L ? pe : pe - L - 1;
+        const bool ok = pe >= 0 && pe != L && src < L;
+        src = min(max(src, 0), L - 1);
+        return ok;
+    };
+    auto load_chunk = [&](int pe, int ch) -> u32x4_t {
+        int src;
+        const bool ok = ext_row(pe, src);
+        u32x4_t v = *reinterpret_cast<const u32x4_t*>(ebase + (long)src * p.ld_e + ch * 8);
+        if (!ok) v = u32x4_t{0u, 0u, 0u, 0u};
+        return v;
+    };
+    auto load_c = [&](int pe) -> float {
+        int src;
+        const bool ok = ext_row(pe, src);
+        const float cv = cbase[src];
+        return ok ? cv : 0.f;
+    };
+    auto stage_window = [&](int j0) {                          // prologue: the whole first window, straight to LDS
+        const int wbase = L - 128 - i0w + j0;
+        for (int c = tid; c < 192 * T::NCH; c += 256) {
+            const int pe = wbase + c / T::NCH, ch = c % T::NCH;
+            *reinterpret_cast<u32x4_t*>(etile + T::off((pe - L) & 255, ch)) = load_chunk(pe, ch);
+        }
+        if (tid < 192) ctile[(wbase + tid - L) & 255] = load_c(wbase + tid);
+    };
+    auto fetch_e = [&](int j0) {                               // rows wbase(j0) + 128 .. + 191: the part of tile j0's window the previous tile did not have
+        const int wnew = L - 128 - i0w + j0 + 128;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int c = tid + 256 * k;
+            if (c < 64 * T::NCH) epre[k] = load_chunk(wnew + c / T::NCH, c % T::NCH);
+        }
+        if (tid < 64) cpre = load_c(wnew + tid);
+    };
+    auto park_e = [&](int j0) {
+        const int wnew = L - 128 - i0w + j0 + 128;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int c = tid + 256 * k;
+            if (c < 64 * T::NCH) *reinterpret_cast<u32x4_t*>(etile + T::off((wnew + c / T::NCH - L) & 255, c % T::NCH)) = epre[k];
+        }
+        if (tid < 64) ctile[(wnew + tid - L) & 255] = cpre;
+    };
+    const int eoff = 96 - 32 * wave;                           // this wave's first row inside the window
+    // G^T blocks of the tile -> the wave's private image gs[query][window column]
+    auto position = [&](int j0) {
+        if (p.debug & 1) return;
+        asm volatile("" ::: "memory");                         // (the image is written as uint2 and read as bf16: keep the compiler from reordering across)
+        const int pe_w = L - 128 - i0w + j0 + eoff;            // p' of the wave's window row 0
+#pragma unroll
+        for (int blk = 0; blk < 3; ++blk) {
+            const int pe0 = pe_w + 32 * blk;
+            f32x16 g;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[r] = 0.f;
+            const int erow = (pe0 + ii - L) & 255;             // ring slot of this lane's table row
+            if (pe0 + 31 <= L - 1) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 ef = *reinterpret_cast<const bf16x8*>(etile + T::off(erow, 2 * ks + hh));
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ef, qp[ks], g, 0, 0, 0);
+                }
+            } else if (pe0 >= L + 1) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 ef = *reinterpret_cast<const bf16x8*>(etile + T::off(erow, 2 * ks + hh));
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ef, qp1[ks], g, 0, 0, 0);
+                }
+            } else {                                           // the block that holds p' = L: rows below it take q_i, rows above it q_{i+1}
+                const bool lower = pe0 + ii <= L - 1;
+                bf16x8 zero;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) zero[e] = (__bf16)0.0f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 ef = *reinterpret_cast<const bf16x8*>(etile + T::off(erow, 2 * ks + hh));
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lower ? ef : zero, qp[ks], g, 0, 0, 0);
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lower ? zero : ef, qp1[ks], g, 0, 0, 0);
+                }
+            }
+            // lane (query ii, half hh) holds window rows 32 blk + 8 g4 + 4 hh + (0..3): + cext, to bf16, 8 bytes per group into its image row
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int col = 32 * blk + 8 * g4 + 4 * hh;
+                const float4 cv = *reinterpret_cast<const float4*>(ctile + ((pe_w + col - L) & 255));     // slots count from p' - L: a multiple of 4 here
+                uint2 w;
+                w.x = pack_bf16x2(g[4 * g4] + cv.x, g[4 * g4 + 1] + cv.y);
+                w.y = pack_bf16x2(g[4 * g4 + 2] + cv.z, g[4 * g4 + 3] + cv.w);
+                *reinterpret_cast<uint2*>(gs + col) = w;
+            }
+        }
+        asm volatile("" ::: "memory");                         // DS operations of one wave execute in order: the reads below see these writes
+    };
+    auto sub_step = [&](int jb, int sub) {
+        float bcur[16];
+        if (p.debug & 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bcur[r] = 0.f;
+        } else {
+            const bf16_t* gr = gs + 31 - ii + 32 * sub + 4 * hh;          // key jj of the tile sits at window column 31 - ii + jj
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bcur[r] = bf16_to_f32(gr[(r & 3) + 8 * (r >> 2)]);
+        }
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ktile + T::off(32 * sub + (lane & 31), 2 * ks + hh));
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+        }
+        float pmax = NEGBIG;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            float v = NEGBIG;
+            const bool msk = MK == 4 ? (j < mlo || j > mhi) : is_masked<MK>(p, b, ic, j);
+            if (j < L && !msk) v = (s[r] + bcur[r]) * p.scale;
+            s[r] = v;
+            pmax = fmaxf(pmax, v);
+        }
+        pmax = fmaxf(pmax, __shfl_xor(pmax, 32, 64));
+        const float mn = fmaxf(m, pmax);
+        const float alpha = __expf(m - mn);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pr = s[r] > 0.5f * NEGBIG ? __expf(s[r] - mn) : 0.f;
+            s[r] = pr;
+            psum += pr;
+        }
+        l = l * alpha + psum;
+        m = mn;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pb = pack8(s, 8 * s2);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16x8 vf = tr_frag<DH>(vtile, 32 * sub + 16 * s2, 32 * dt, lane);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o[dt], 0, 0, 0);
+            }
+        }
+    };
+    int jbeg = 0, jend = L;
+    {
+        const int i1w = min(i0w + 127, L - 1);
+        if constexpr (MK == 1) jend = i1w + 1;
+        if constexpr (MK == 2) {
+            jbeg = max(0, i0w - p.mask_left);
+            jend = (int)min((long)L, (long)i1w + p.mask_right + 1);
+        }
+        if constexpr (MK == 4) {
+            __shared__ int rng[2];
+            if (tid == 0) { rng[0] = 0x7fffffff; rng[1] = -1; }
+            __syncthreads();
+            atomicMin(&rng[0], mlo);
+            atomicMax(&rng[1], mhi);
+            __syncthreads();
+            jbeg = max(0, rng[0]);
+            jend = (int)min((long)L, (long)rng[1] + 1);
+        }
+        if (jend <= jbeg) { jbeg = 0; jend = L; }
+        jbeg &= ~63;
+    }
+    RowStage<DH, 64> stK, stV;
+    stK.load(kbase, p.ld_kv, jbeg, L - 1, tid);
+    stV.load(vbase, p.ld_kv, jbeg, L - 1, tid);
+    stage_window(jbeg - 64);                                   // rows wbase(jbeg) - 64 .. + 127; the loop's first park adds + 128 .. + 191
+    fetch_e(jbeg);
+    for (int j0 = jbeg; j0 < jend; j0 += 64) {
+        __syncthreads();
+        stK.store(ktile, tid);
+        stV.store(vtile, tid);
+        park_e(j0);
+        __syncthreads();
+        if (j0 + 64 < jend) {
+            stK.load(kbase, p.ld_kv, j0 + 64, L - 1, tid);
+            stV.load(vbase, p.ld_kv, j0 + 64, L - 1, tid);
+            fetch_e(j0 + 64);
+        }
+        position(j0);
+        sub_step(j0, 0);
+        if (j0 + 32 < jend) sub_step(j0 + 32, 1);
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (i < L) {
+        const float inv = 1.f / l;
+        bf16_t* orow = p.o + ((long)b * L + i) * p.ld_o + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = 32 * dt + 8 * g4 + 4 * hh;
+                uint2 w;
+                w.x = pack_bf16x2(o[dt][4 * g4] * inv, o[dt][4 * g4 + 1] * inv);
+                w.y = pack_bf16x2(o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
+                *reinterpret_cast<uint2*>(orow + d) = w;
+            }
+        if (hh == 0) p.lse[(long)z * L + i] = m + __logf(l);
+    }
+}
+
+// ------------------------------------------------------------------ backward (dK, dV, dS), position term recomputed in the kernel
+// Same structure as flash_bwd_kernel below (key on the lane, dS leaves twice in bf16 for the dq / dE products); the bias tile is not read
+// from a slab but recomputed like in flash_fwd_rel_kernel: for a wave's 32 keys and a 32-query tile the p' = L-1-i+j values form one
+// window of 63 table rows; G = Qsel . Eext_window^T is two 32x32 MFMA blocks (rows = queries, columns = p'; q_i below L, q_{i+1} above,
+// both with the other side's table rows zeroed in the block that holds p' = L), skewed through a private LDS image [p'][query].
+template <int DH, int MK>
+__global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams p) {
+    using T = Tile<DH>;
+    constexpr int KS = DH / 16, DT = DH / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* qtile = smem;                          // (q+u) rows of the current query tile
+    char* dotile = smem + 32 * T::ROWB;          // dO rows
+    char* ptile = smem + 64 * T::ROWB;           // plain q rows, ring of 64 (slot = row & 63): rows i0 .. i0 + 32 are read (the upper part multiplies
+                                                 // q_{i+1}), rows i0 + 32 .. i0 + 63 arrive one step ahead
+    char* etile = smem + (64 + 64) * T::ROWB;    // ring of 256 table rows (the workgroup's 128 keys x 32 queries need 159)
+    float* ctile = reinterpret_cast<float*>(smem + (64 + 64 + 256) * T::ROWB);
+    float* lse_s = ctile + 256;
+    float* del_s = lse_s + 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int z = blockIdx.y, b = z / p.H, h = z % p.H;
+    const int L = p.L;
+    const int j = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const int jc = min(j, L - 1);
+    const bool kvalid = j < L;
+    const bf16_t* krow = p.k + ((long)b * L + jc) * p.ld_kv + h * DH;
+    const bf16_t* vrow = p.v + ((long)b * L + jc) * p.ld_kv + h * DH;
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = *reinterpret_cast<const bf16x8*>(krow + 16 * ks + 8 * hh);
+        vf[ks] = *reinterpret_cast<const bf16x8*>(vrow + 16 * ks + 8 * hh);
+    }
+    f32x16 dk[DT], dv[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+    const bf16_t* qbase = p.qu + (long)b * L * p.ld_qu + h * DH;
+    const bf16_t* dobase = p.dO + (long)b * L * p.ld_o + h * DH;
+    bf16_t* ds16 = p.dS16 + (long)z * p.slab16;
+    bf16_t* dg16 = p.dG16 + (long)z * p.slab16;
+
+    const int ldp = (int)p.ldp;
+    int* lo_s = reinterpret_cast<int*>(del_s + 32);                          // MK == 4: the tile's 32 (lo, hi) pairs
+    int* hi_s = lo_s + 32;
+    constexpr int GPB = 36;                                                  // image row pitch in bf16 (32 queries + 4): 72 bytes
+    bf16_t* gs = reinterpret_cast<bf16_t*>(hi_s + 32) + wave * 64 * GPB;     // the wave's private image [64 window columns][GPB]
+    const int jw0 = blockIdx.x * 128;
+    const bf16_t* pbase = p.qp + (long)b * L * p.ld_qp + h * DH;
+    const bf16_t* ebase = p.e16 + h * DH;
+    const float* cbase = p.cT + (long)h * L;
+    u32x4_t epre, ppre;                                  // the 32 new table rows of the next query tile + the plain q rows i0 + 64 .. i0 + 95 (one chunk each)
+    float cpre = 0.f;
+    auto ext_row = [&](int pe, int& src) -> bool {
+        src = pe < L ? pe : pe - L - 1;
+        const bool ok = pe >= 0 && pe != L && src < L;
+        src = min(max(src, 0), L - 1);
+        return ok;
+    };
+    auto load_chunk = [&](int pe, int ch) -> u32x4_t {
+        int src;
+        const bool ok = ext_row(pe, src);
+        u32x4_t v = *reinterpret_cast<const u32x4_t*>(ebase + (long)src * p.ld_e + ch * 8);
+        if (!ok) v = u32x4_t{0u, 0u, 0u, 0u};
+        return v;
+    };
+    auto load_c = [&](int pe) -> float {
+        int src;
+        const bool ok = ext_row(pe, src);
+        const float cv = cbase[src];
+        return ok ? cv : 0.f;
+    };
+    // table window of a query tile: rows p' = wbase .. wbase + 159, wbase = L - 32 - i0 + jw0, in a ring (slot = (p' - L) & 255); every step
+    // moves the window down by 32 rows, so only those 32 are fetched per step; the prologue stages the 160 rows above the first window
+    auto stage_window = [&](int i0) {                    // (i0 = first tile - 32) also: the first tile's own plain q rows
+        for (int c = tid; c < 32 * T::NCH; c += 256)
+            *reinterpret_cast<u32x4_t*>(ptile + T::off((i0 + 32 + c / T::NCH) & 63, c % T::NCH)) =
+                *reinterpret_cast<const u32x4_t*>(pbase + (long)min(i0 + 32 + c / T::NCH, L - 1) * p.ld_qp + (c % T::NCH) * 8);
+        const int wbase = L - 32 - i0 + jw0;
+        for (int c = tid; c < 160 * T::NCH; c += 256) {
+            const int pe = wbase + c / T::NCH, ch = c % T::NCH;
+            *reinterpret_cast<u32x4_t*>(etile + T::off((pe - L) & 255, ch)) = load_chunk(pe, ch);
+        }
+        if (tid < 160) ctile[(wbase + tid - L) & 255] = load_c(wbase + tid);
+    };
+    auto fetch_bias = [&](int i0) {
+        if (p.debug & 1) return;
+        const int wbase = L - 32 - i0 + jw0;
+        if (tid < 32 * T::NCH) {
+            epre = load_chunk(wbase + tid / T::NCH, tid % T::NCH);
+            ppre = *reinterpret_cast<const u32x4_t*>(pbase + (long)min(i0 + 32 + tid / T::NCH, L - 1) * p.ld_qp + (tid % T::NCH) * 8);
+        }
+        if (tid < 32) cpre = load_c(wbase + tid);
+    };
+    int parked_i0 = 0;
+    auto park_bias = [&]() {
+        if (p.debug & 1) return;
+        const int wbase = L - 32 - parked_i0 + jw0;
+        if (tid < 32 * T::NCH) {
+            *reinterpret_cast<u32x4_t*>(etile + T::off((wbase + tid / T::NCH - L) & 255, tid % T::NCH)) = epre;
+            *reinterpret_cast<u32x4_t*>(ptile + T::off((parked_i0 + 32 + tid / T::NCH) & 63, tid % T::NCH)) = ppre;
+        }
+        if (tid < 32) ctile[(wbase + tid - L) & 255] = cpre;
+    };
+    auto read_bias = [&](int i0, float (&bv)[16]) {
+        if (p.debug & 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bv[r] = 0.f;
+            return;
+        }
+        const int pe_w = L - 32 - i0 + jw0 + 32 * wave;           // p' of the wave's window column 0
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int pe0 = pe_w + 32 * blk;
+            f32x16 g;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[r] = 0.f;
+            const int erow = (pe0 + (lane & 31) - L) & 255;          // ring slot of this lane's table row
+            if (pe0 + 31 <= L - 1) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 qa = *reinterpret_cast<const bf16x8*>(ptile + T::off((i0 + (lane & 31)) & 63, 2 * ks + hh));
+                    const bf16x8 ef = *reinterpret_cast<const bf16x8*>(etile + T::off(erow, 2 * ks + hh));
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, ef, g, 0, 0, 0);
+                }
+            } else if (pe0 >= L + 1) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 qa = *reinterpret_cast<const bf16x8*>(ptile + T::off((i0 + (lane & 31) + 1) & 63, 2 * ks + hh));
+                    const bf16x8 ef = *reinterpret_cast<const bf16x8*>(etile + T::off(erow, 2 * ks + hh));
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, ef, g, 0, 0, 0);
+                }
+            } else {
+                const bool lower = pe0 + (lane & 31) <= L - 1;
+                bf16x8 zero;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) zero[e] = (__bf16)0.0f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 qa = *reinterpret_cast<const bf16x8*>(ptile + T::off((i0 + (lane & 31)) & 63, 2 * ks + hh));
+                    const bf16x8 qb = *reinterpret_cast<const bf16x8*>(ptile + T::off((i0 + (lane & 31) + 1) & 63, 2 * ks + hh));
+                    const bf16x8 ef = *reinterpret_cast<const bf16x8*>(etile + T::off(erow, 2 * ks + hh));
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, lower ? ef : zero, g, 0, 0, 0);
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qb, lower ? zero : ef, g, 0, 0, 0);
+                }
+            }
+            // lane (window column pp = lane & 31 of this block, half hh) holds queries 8 g4 + 4 hh + (0..3): + cext[column], to bf16
+            const float cv = ctile[(pe0 + (lane & 31) - L) & 255];
+            bf16_t* col = gs + (32 * blk + (lane & 31)) * GPB;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                uint2 w;
+                w.x = pack_bf16x2(g[4 * g4] + cv, g[4 * g4 + 1] + cv);
+                w.y = pack_bf16x2(g[4 * g4 + 2] + cv, g[4 * g4 + 3] + cv);
+                *reinterpret_cast<uint2*>(col + 8 * g4 + 4 * hh) = w;
+            }
+        }
+        asm volatile("" ::: "memory");                            // DS operations of one wave execute in order
+        // score (query qi, own key jj = lane & 31) sits at window column 31 - qi + jj
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qi = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            bv[r] = bf16_to_f32(gs[(31 - qi + (lane & 31)) * GPB + qi]);
+        }
+    };
+    // narrow structured masks (launcher's choice, p.bwd_skip): both bf16 slabs were zeroed up front and only the query tiles that can see
+    // one of this workgroup's 128 keys are walked: query i meets key j iff i - left <= j <= i + right
+    int ibeg = 0, iend = L;
+    if (p.bwd_skip) {
+        ibeg = max(0, jw0 - p.mask_right) & ~63;
+        iend = (int)min((long)L, (long)jw0 + 127 + p.mask_left + 1);
+        if (iend <= ibeg) { ibeg = 0; iend = 0; }
+    }
+    RowStage<DH, 32> stQ, stO;
+    stQ.load(qbase, p.ld_qu, ibeg, L - 1, tid);
+    stO.load(dobase, p.ld_o, ibeg, L - 1, tid);
+    if (!(p.debug & 1) && ibeg < iend) stage_window(ibeg - 32);        // rows wbase(ibeg) + 32 .. + 191: step(ibeg) parks the 32 below them
+    fetch_bias(ibeg);
+    auto step = [&](int i0) {
+        __syncthreads();
+        stQ.store(qtile, tid);
+        stO.store(dotile, tid);
+        parked_i0 = i0;
+        park_bias();
+        if (tid < 32) {
+            const int ii = min(i0 + tid, L - 1);
+            lse_s[tid] = p.lse[(long)z * L + ii];
+            del_s[tid] = p.delta[(long)z * L + ii];
+            if constexpr (MK == 4) {
+                const int* r = reinterpret_cast<const int*>(p.mask) + (long)b * p.mask_sb + 2 * ii;
+                lo_s[tid] = r[0];
+                hi_s[tid] = r[1];
+            }
+        }
+        __syncthreads();
+        if (i0 + 32 < iend) {                                       // next tile's operands and bias fly under this tile's MFMAs
+            stQ.load(qbase, p.ld_qu, i0 + 32, L - 1, tid);
+            stO.load(dobase, p.ld_o, i0 + 32, L - 1, tid);
+            fetch_bias(i0 + 32);
+        }
+        float bcur[16];
+        read_bias(i0, bcur);
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 qa = *reinterpret_cast<const bf16x8*>(qtile + T::off(lane & 31, 2 * ks + hh));
+            const bf16x8 da = *reinterpret_cast<const bf16x8*>(dotile + T::off(lane & 31, 2 * ks + hh));
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
+        }
+        // dS16[i][j] at i*ldp + j;  dG16[r][c-1], (r, c) = divmod((i+1) L + j, L+1): j <= i -> (i, L-i+j), j > i -> (i+1, j-i-1), i.e.
+        // element i*(ldp-1) + (j <= i ? L-1+j : ldp+j-2), nothing for j == i+1 (c = 0)
+        const int ds0 = (i0 + 4 * hh) * ldp + j, dg0 = (i0 + 4 * hh) * (ldp - 1);
+        // pad columns [L, ldp) of both bf16 slabs feed the K loop of the dq / dE products and must be zero: the lanes whose key index falls
+        // there write the zeros (no separate strided memsets over B*H*L rows)
+        if (!kvalid && j < ldp && !(p.debug & 2)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cq = (r & 3) + 8 * (r >> 2);
+                if (i0 + cq + 4 * hh < L) {
+                    ds16[(unsigned)(ds0 + cq * ldp)] = 0;
+                    dg16[(unsigned)(ds0 + cq * ldp)] = 0;
+                }
+            }
+        }
+        const int gsel_lo = L - 1 + j, gsel_hi = ldp + j - 2;
+        // interior tiles (all 32 queries and all 128 keys of the workgroup in range, the j == i+1 diagonal not crossing the tile) take a
+        // branch-free element loop; edge and diagonal tiles the general one
+        const bool interior = (i0 + 32 <= L) && (jw0 > i0 + 32 || jw0 + 127 < i0 + 1) && !(p.debug & 2);
+        if (interior) {
+            // all 32 queries in range, the whole tile on one side of the j == i+1 diagonal: branch-free score loop, then ONE predicated
+            // region for the lanes whose key exists
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float pr = 0.f, ds = 0.f;
+                if (!(MK == 4 ? (j < lo_s[q] || j > hi_s[q]) : is_masked<MK>(p, b, i0 + q, j))) {
+                    const float sc = (s[r] + bcur[r]) * p.scale;
+                    pr = __expf(sc - lse_s[q]);
+                    ds = pr * (dp[r] - del_s[q]) * p.scale;
+                }
+                s[r] = kvalid ? pr : 0.f;
+                dp[r] = kvalid ? ds : 0.f;
+            }
+            if (kvalid) {
+                const int gsel = dg0 + (jw0 < i0 ? gsel_lo : gsel_hi);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cq = (r & 3) + 8 * (r >> 2);
+                    const bf16_t d16 = f32_to_bf16(dp[r]);
+                    ds16[(unsigned)(ds0 + cq * ldp)] = d16;
+                    dg16[(unsigned)(gsel + cq * (ldp - 1))] = d16;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cq = (r & 3) + 8 * (r >> 2);
+                const int q = cq + 4 * hh;
+                const int i = i0 + q;
+                const bool inb = (i < L) && kvalid;
+                float pr = 0.f, ds = 0.f;
+                if (inb) {
+                    if (!(MK == 4 ? (j < lo_s[q] || j > hi_s[q]) : is_masked<MK>(p, b, i, j))) {
+                        const float sc = (s[r] + bcur[r]) * p.scale;
+                        pr = __expf(sc - lse_s[q]);
+                        ds = pr * (dp[r] - del_s[q]) * p.scale;
+                    }
+                    if (!(p.debug & 2)) {
+                        const bf16_t d16 = f32_to_bf16(ds);
+                        ds16[(unsigned)(ds0 + cq * ldp)] = d16;
+                        if (j != i + 1) dg16[(unsigned)(dg0 + cq * (ldp - 1) + (j <= i ? gsel_lo : gsel_hi))] = d16;
+                    }
+                }
+                s[r] = pr;
+                dp[r] = ds;
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pb = pack8(s, 8 * s2);
+            const bf16x8 dsb = pack8(dp, 8 * s2);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16x8 a_do = tr_frag<DH>(dotile, 16 * s2, 32 * dt, lane);
+                const bf16x8 a_qu = tr_frag<DH>(qtile, 16 * s2, 32 * dt, lane);
+                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_do, pb, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_qu, dsb, dk[dt], 0, 0, 0);
+            }
+        }
+    };
+    for (int i0 = ibeg; i0 < iend; i0 += 64) {
+        step(i0);
+        if (i0 + 32 < iend) step(i0 + 32);
+    }
+    if (kvalid) {
+        float* dkrow = p.dK + ((long)b * L + j) * p.ld_dkv + h * DH;
+        float* dvrow = p.dV + ((long)b * L + j) * p.ld_dkv + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = 32 * dt + 8 * g4 + 4 * hh;
+                if (p.dK16) {      // bf16, the form the qkv dgrad / wgrad GEMMs read (no f32 copy, no conversion pass over dqkv)
+                    const long o16 = ((long)b * L + j) * p.ld_dkv + h * DH + d;
+                    uint2 wk, wv;
+                    wk.x = pack_bf16x2(dk[dt][4 * g4], dk[dt][4 * g4 + 1]); wk.y = pack_bf16x2(dk[dt][4 * g4 + 2], dk[dt][4 * g4 + 3]);
+                    wv.x = pack_bf16x2(dv[dt][4 * g4], dv[dt][4 * g4 + 1]); wv.y = pack_bf16x2(dv[dt][4 * g4 + 2], dv[dt][4 * g4 + 3]);
+                    *reinterpret_cast<uint2*>(p.dK16 + o16) = wk;
+                    *reinterpret_cast<uint2*>(p.dV16 + o16) = wv;
+                } else {
+                    *reinterpret_cast<float4*>(dkrow + d) = make_float4(dk[dt][4 * g4], dk[dt][4 * g4 + 1], dk[dt][4 * g4 + 2], dk[dt][4 * g4 + 3]);
+                    *reinterpret_cast<float4*>(dvrow + d) = make_float4(dv[dt][4 * g4], dv[dt][4 * g4 + 1], dv[dt][4 * g4 + 2], dv[dt][4 * g4 + 3]);
+                }
+            }
+    }
+}
+
 // ------------------------------------------------------------------ backward (dK, dV, dS)
 template <int DH, int MK>
 __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) {
@@ -684,7 +1272,30 @@ int relpos_slab(const bf16_t* q, long ld_q, const bf16_t* E, long ld_e, const fl
 }
 
 int flash_attn_fwd(const FlashParams& p, hipStream_t st) {
-    TTMI_REQUIRE(p.qu && p.k && p.v && p.bd && p.o && p.lse, "flash_attn_fwd: null pointer");
+    TTMI_REQUIRE(p.qu && p.k && p.v && (p.bd || p.e16) && p.o && p.lse, "flash_attn_fwd: null pointer");
+    if (p.e16) {                                    // position term formed in the kernel (no slab)
+        TTMI_REQUIRE(p.qp && p.cT && flash_supported(p.Dh, p.ld_qu, p.ld_kv, p.ld_o) && p.ld_qp % 8 == 0 && p.ld_e % 8 == 0 && aligned16(p.qp) &&
+                     aligned16(p.e16) && aligned16(p.qu) && aligned16(p.k) && aligned16(p.v) && (reinterpret_cast<uintptr_t>(p.o) & 7) == 0,
+                     "flash_attn_fwd: in-kernel position term needs 16-byte aligned q / E with pitches %% 8 == 0");
+        dim3 grid(cdiv(p.L, 128), p.B * p.H);
+        TTMI_REQUIRE(grid.y <= 65535, "flash_attn_fwd: B*H too large");
+#define FWDR_LAUNCH(MKV) do { \
+        if (p.Dh == 64) { const int lds = (128 + 256) * 128 + 256 * 4 + 4 * 32 * 100 * 2; \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_fwd_rel_kernel<64, MKV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) { ttmi_set_error("flash_attn_fwd: LDS attribute"); return TTMI_EINVAL; } \
+            hipLaunchKernelGGL((flash_fwd_rel_kernel<64, MKV>), grid, dim3(256), lds, st, p); } \
+        else { const int lds = (128 + 256) * 64 + 256 * 4 + 4 * 32 * 100 * 2; \
+            hipLaunchKernelGGL((flash_fwd_rel_kernel<32, MKV>), grid, dim3(256), lds, st, p); } } while (0)
+        switch (p.mask_kind) {
+            case 1: FWDR_LAUNCH(1); break;
+            case 2: FWDR_LAUNCH(2); break;
+            case 3: FWDR_LAUNCH(3); break;
+            case 4: FWDR_LAUNCH(4); break;
+            default: FWDR_LAUNCH(0); break;
+        }
+#undef FWDR_LAUNCH
+        TTMI_LAUNCH_CHECK("flash_fwd_rel_kernel");
+        return TTMI_OK;
+    }
     TTMI_REQUIRE(flash_supported(p.Dh, p.ld_qu, p.ld_kv, p.ld_o), "flash_attn_fwd: unsupported head dim %d / pitches", p.Dh);
     TTMI_REQUIRE(aligned16(p.qu) && aligned16(p.k) && aligned16(p.v) && (reinterpret_cast<uintptr_t>(p.o) & 7) == 0, "flash_attn_fwd: alignment");
     dim3 grid(cdiv(p.L, 128), p.B * p.H);
@@ -704,7 +1315,9 @@ int flash_attn_fwd(const FlashParams& p, hipStream_t st) {
 }
 
 int flash_attn_bwd(const FlashParams& p, hipStream_t st) {
-    TTMI_REQUIRE(p.qu && p.k && p.v && p.bd && p.o && p.lse && p.dO && p.delta && p.dS16 && p.dG16 && p.dK && p.dV, "flash_attn_bwd: null pointer");
+    TTMI_REQUIRE(p.qu && p.k && p.v && (p.bd || p.e16) && p.o && p.lse && p.dO && p.delta && p.dS16 && p.dG16 && p.dK && p.dV, "flash_attn_bwd: null pointer");
+    TTMI_REQUIRE(!p.e16 || (p.qp && p.cT && p.ld_qp % 8 == 0 && p.ld_e % 8 == 0 && aligned16(p.qp) && aligned16(p.e16)),
+                 "flash_attn_bwd: in-kernel position term needs 16-byte aligned q / E with pitches %% 8 == 0");
     TTMI_REQUIRE(p.ldp >= p.L && p.ldp % 8 == 0 && (long)p.L * (p.L + 1) < (1L << 31), "flash_attn_bwd: bad dS pitch / L too large");
     TTMI_REQUIRE(flash_supported(p.Dh, p.ld_qu, p.ld_kv, p.ld_o) && p.ld_dkv % 4 == 0, "flash_attn_bwd: unsupported head dim %d / pitches", p.Dh);
     TTMI_REQUIRE(aligned16(p.qu) && aligned16(p.k) && aligned16(p.v) && aligned16(p.dO) && aligned16(p.dK) && aligned16(p.dV), "flash_attn_bwd: alignment");
@@ -725,8 +1338,15 @@ int flash_attn_bwd(const FlashParams& p, hipStream_t st) {
     }
     if (p.Dh == 64) hipLaunchKernelGGL(flash_delta_kernel<64>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta);
     else hipLaunchKernelGGL(flash_delta_kernel<32>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta);
-#define BWD_LAUNCH(MKV) do { if (p.Dh == 64) hipLaunchKernelGGL((flash_bwd_kernel<64, MKV>), grid, dim3(256), 64 * 128 + 256 + 8192 + 256, st, q); \
-                             else hipLaunchKernelGGL((flash_bwd_kernel<32, MKV>), grid, dim3(256), 64 * 64 + 256 + 8192 + 256, st, q); } while (0)
+    // in-kernel position term: (64 + 64 + 256) tile rows + cext ring + lse / delta + lo / hi + 4 private images of [64][36] bf16
+#define BWD_LAUNCH(MKV) do { \
+        if (p.e16) { \
+            if (p.Dh == 64) { const int lds = 384 * 128 + 256 * 4 + 256 + 256 + 4 * 64 * 36 * 2; \
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_bwd_rel_kernel<64, MKV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) { ttmi_set_error("flash_attn_bwd: LDS attribute"); return TTMI_EINVAL; } \
+                hipLaunchKernelGGL((flash_bwd_rel_kernel<64, MKV>), grid, dim3(256), lds, st, q); } \
+            else hipLaunchKernelGGL((flash_bwd_rel_kernel<32, MKV>), grid, dim3(256), 384 * 64 + 256 * 4 + 256 + 256 + 4 * 64 * 36 * 2, st, q); \
+        } else if (p.Dh == 64) hipLaunchKernelGGL((flash_bwd_kernel<64, MKV>), grid, dim3(256), 64 * 128 + 256 + 8192 + 256, st, q); \
+        else hipLaunchKernelGGL((flash_bwd_kernel<32, MKV>), grid, dim3(256), 64 * 64 + 256 + 8192 + 256, st, q); } while (0)
     const bool probe = p.L >= 256;                   // timing probe 3: the audio encoder's backward kernel (the label encoder's is tiny)
     if (probe) ttmi_probe_begin(3, st);
     switch (p.mask_kind) {

@@ -174,6 +174,17 @@ GemmDesc mkx(const void* A, int adt, const void* B, int bdt, void* C, int cdt, i
     return d;
 }
 
+// fused (flash-style) attention core: bf16 pipeline, head dim 32/64
+int g_flash_debug = 0;
+int g_inkernel_pos = 1;                 // ttmi_set_option(8, 0): position term from the [B,H,L,L+1] slab instead of inside the attention kernels (A/B;
+                                        // changes the ctx layout: set it between complete forward + backward passes only)
+int g_disable_fused_attention = 0;      // ttmi_set_option(0, 1): A/B switch back to the unfused GEMM + softmax chain
+inline bool attn_fused(bool fast, const AttnDims& a) {
+    return fast && !g_disable_fused_attention && flash_supported(a.Dh, a.HD, a.W3, a.HD);
+}
+// the [B, H, L, L+1] score / position slab in the saved context: not needed when the fused kernels form the position term themselves
+inline bool attn_inkernel(bool fast, const AttnDims& a) { return attn_fused(fast, a) && g_inkernel_pos && a.Dh % 8 == 0; }
+
 struct AttnCtx {   // saved for backward.  act = f32 (parity) or bf16 (fast)
     void *qkv, *qu, *O;
     float *P, *s1, *mean, *rstd, *lse;     // P: f32 probabilities (unfused path) or the bf16 position-term slab (fused path, first half)
@@ -184,7 +195,7 @@ struct AttnCtx {   // saved for backward.  act = f32 (parity) or bf16 (fast)
         qkv = b.take<char>(a.BL * a.W3 * es);
         qu = b.take<char>(a.BL * a.HD * es);
         O = b.take<char>(a.BL * a.HD * es);
-        P = b.take<float>((size_t)a.B * a.H * a.slab);
+        P = b.take<float>(attn_inkernel(fast, a) ? 64 : (size_t)a.B * a.H * a.slab);
         s1 = b.take<float>(a.BL * a.d);
         mean = b.take<float>(a.BL);
         rstd = b.take<float>(a.BL);
@@ -229,12 +240,6 @@ struct AttnWs {   // scratch (union of forward and backward needs)
     }
 };
 
-// fused (flash-style) attention core: bf16 pipeline, head dim 32/64
-int g_flash_debug = 0;
-int g_disable_fused_attention = 0;      // ttmi_set_option(0, 1): A/B switch back to the unfused GEMM + softmax chain
-inline bool attn_fused(bool fast, const AttnDims& a) {
-    return fast && !g_disable_fused_attention && flash_supported(a.Dh, a.HD, a.W3, a.HD);
-}
 
 FlashParams flash_params(const AttnDims& a, const AttnCtx& c, float scale, int mask_kind, int mask_left, int mask_right,
                          const unsigned char* mask, long mask_sb, long mask_si) {
@@ -251,6 +256,16 @@ FlashParams flash_params(const AttnDims& a, const AttnCtx& c, float scale, int m
     f.mask = mask; f.mask_sb = mask_sb; f.mask_si = mask_si;
     f.debug = g_flash_debug;
     return f;
+}
+
+// position term formed inside the attention kernels: plain q (first third of the qkv rows), the effective table in bf16 and its bias
+void flash_inkernel(FlashParams& f, const AttnDims& a, const AttnCtx& c, const AttnWs& w) {
+    f.bd = nullptr;
+    f.qp = static_cast<const bf16_t*>(c.qkv);
+    f.ld_qp = a.W3;
+    f.e16 = w.E16;
+    f.ld_e = a.HD;
+    f.cT = w.cT;
 }
 
 int memset2d(void* p, size_t pitch, size_t width, size_t height, hipStream_t st) {
@@ -319,8 +334,11 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
     }
     // 3. effective tables for this length (clamped rows when L > K)
     CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st));
-    // 4. G = q E^T + c into the pitch-(L+1) slab, column 0 zero
-    if (attn_fused(fast, a) && g_gemm_slab == 0 && (size_t)16 * (L + 1) * 4 + 32 <= 160 * 1024) {
+    // 4. G = q E^T + c into the pitch-(L+1) slab, column 0 zero - unless the fused kernels form the position term themselves
+    const bool inkernel = attn_inkernel(fast, a);
+    if (inkernel) {
+        CK(convert_bf16(w.E, w.E16, (long)L * a.HD, st));
+    } else if (attn_fused(fast, a) && g_gemm_slab == 0 && (size_t)16 * (L + 1) * 4 + 32 <= 160 * 1024) {
         // write-bound: dedicated kernel that streams whole slab rows (column 0 included) instead of a batched GEMM + strided memset
         CK(convert_bf16(w.E, w.E16, (long)L * a.HD, st));
         CK(relpos_slab(static_cast<const bf16_t*>(c.qkv), a.W3, w.E16, a.HD, w.cT, B, L, H, Dh, reinterpret_cast<bf16_t*>(c.P), st));
@@ -344,7 +362,9 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
     }
     if (attn_fused(fast, a)) {
         // 5-7 fused: softmax((q+u) k^T + shifted(G)) V without materialising the probabilities
-        CK(flash_attn_fwd(flash_params(a, c, scale, mask_kind, mask_left, mask_right, mask, mask_sb, mask_si), st));
+        FlashParams f = flash_params(a, c, scale, mask_kind, mask_left, mask_right, mask, mask_sb, mask_si);
+        if (inkernel) flash_inkernel(f, a, c, w);
+        CK(flash_attn_fwd(f, st));
     } else {
         // 5. S = shifted(G) + (q+u) k^T, accumulated through the pitch-L view
         {
@@ -422,6 +442,11 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
         // bf16 with aligned rows: [i][j] for the content dgrad and the shifted [r][c-1] form (= dG) for the position grads.
         CK(memset2d(w.dG16, (size_t)w.slab16 * 2, (size_t)w.ldp * 2, (size_t)B * H, st));       // dG row 0 is (almost) never written
         FlashParams f = flash_params(a, c, scale, mask_kind, mask_left, mask_right, mask, mask_sb, mask_si);
+        if (attn_inkernel(fast, a)) {                // the kernel recomputes the position term: effective table + bias for this length, as in forward
+            CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st));
+            CK(convert_bf16(w.E, w.E16, (long)L * a.HD, st));
+            flash_inkernel(f, a, c, w);
+        }
         f.dO = static_cast<const bf16_t*>(w.dO);
         f.delta = w.delta;
         f.dS16 = w.dS16; f.dG16 = w.dG16; f.ldp = w.ldp; f.slab16 = w.slab16;
@@ -867,7 +892,8 @@ int ttmi_stream_reserve_cus(void* stream, int n) {
 // process-wide switches for A/B measurements.  key 0: 1 = disable the fused attention kernels (bf16 pipeline only);
 // key 1: throughput-GEMM generation (see gemm_fast.hip); key 2: flash-kernel timing switches; key 3: 0 = no wgrad fork
 int ttmi_set_option(int key, int value) {
-    TTMI_REQUIRE(key >= 0 && key <= 7, "set_option: unknown key %d", key);
+    TTMI_REQUIRE(key >= 0 && key <= 8, "set_option: unknown key %d", key);
+    if (key == 8) { g_inkernel_pos = value; return TTMI_OK; }
     if (key == 6) { gemm_fast_set_reserved_cus(value); return TTMI_OK; }
     if (key == 7) { ttmi_gemm_set_skinny_rows(value); return TTMI_OK; }
     if (key == 4) { gemm_fast_set_tn_target(value); return TTMI_OK; }
