@@ -665,15 +665,16 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
         }
         if (tid < 32) ctile[(wbase + tid - L) & 255] = cpre;
     };
-    auto read_bias = [&](int i0, float (&bv)[16]) {
+    // result: bf16 pairs, bvp[k] = (bias of accumulator element 2k) | (element 2k + 1) << 16 - eight registers instead of sixteen floats
+    auto read_bias = [&](int i0, unsigned (&bvp)[8]) {
         if (p.debug & 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) bv[r] = 0.f;
+            for (int k2 = 0; k2 < 8; ++k2) bvp[k2] = 0u;
             return;
         }
         const int pe_w = L - 32 - i0 + jw0 + 32 * wave;           // p' of the wave's window column 0
         asm volatile("" ::: "memory");
-#pragma unroll
+#pragma unroll 1
         for (int blk = 0; blk < 2; ++blk) {
             const int pe0 = pe_w + 32 * blk;
             f32x16 g;
@@ -722,9 +723,9 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
         asm volatile("" ::: "memory");                            // DS operations of one wave execute in order
         // score (query qi, own key jj = lane & 31) sits at window column 31 - qi + jj
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qi = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            bv[r] = bf16_to_f32(gs[(31 - qi + (lane & 31)) * GPB + qi]);
+        for (int k2 = 0; k2 < 8; ++k2) {
+            const int q0 = ((2 * k2) & 3) + 8 * ((2 * k2) >> 2) + 4 * hh, q1 = q0 + 1;
+            bvp[k2] = (unsigned)gs[(31 - q0 + (lane & 31)) * GPB + q0] | ((unsigned)gs[(31 - q1 + (lane & 31)) * GPB + q1] << 16);
         }
     };
     // narrow structured masks (launcher's choice, p.bwd_skip): both bf16 slabs were zeroed up front and only the query tiles that can see
@@ -762,8 +763,9 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
             stO.load(dobase, p.ld_o, i0 + 32, L - 1, tid);
             fetch_bias(i0 + 32);
         }
-        float bcur[16];
-        read_bias(i0, bcur);
+        unsigned bvp[8];
+        read_bias(i0, bvp);
+#define BCUR(r) __uint_as_float(((r) & 1) ? (bvp[(r) >> 1] & 0xffff0000u) : (bvp[(r) >> 1] << 16))
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -801,7 +803,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
                 const int q = (r & 3) + 8 * (r >> 2) + 4 * hh;
                 float pr = 0.f, ds = 0.f;
                 if (!(MK == 4 ? (j < lo_s[q] || j > hi_s[q]) : is_masked<MK>(p, b, i0 + q, j))) {
-                    const float sc = (s[r] + bcur[r]) * p.scale;
+                    const float sc = (s[r] + BCUR(r)) * p.scale;
                     pr = __expf(sc - lse_s[q]);
                     ds = pr * (dp[r] - del_s[q]) * p.scale;
                 }
@@ -828,7 +830,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
                 float pr = 0.f, ds = 0.f;
                 if (inb) {
                     if (!(MK == 4 ? (j < lo_s[q] || j > hi_s[q]) : is_masked<MK>(p, b, i, j))) {
-                        const float sc = (s[r] + bcur[r]) * p.scale;
+                        const float sc = (s[r] + BCUR(r)) * p.scale;
                         pr = __expf(sc - lse_s[q]);
                         ds = pr * (dp[r] - del_s[q]) * p.scale;
                     }
@@ -882,6 +884,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
     }
 }
 
+#undef BCUR
 // ------------------------------------------------------------------ backward (dK, dV, dS)
 template <int DH, int MK>
 __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) {

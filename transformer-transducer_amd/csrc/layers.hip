@@ -497,7 +497,7 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
         }
     }
     // 10. dq += dG E ; 11. dE[p,h,:] = sum_b dG^T q ; 12. dc[h][p] = sum_b colsum(dG) ; 13. fold onto the K-row tables
-    CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st));
+    if (!(fused && attn_inkernel(fast, a))) CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st));     // (already gathered for the kernel above)
     CK(fill_zero(w.dE, sizeof(float) * ((size_t)L * a.HD + (size_t)H * L), st));
     if (fastpos) {
         CK(transpose_bf16_batched(w.E, 0, a.HD, 1, H, 0, Dh, L, Dh, w.ET16, w.ldp, st));
