@@ -195,3 +195,23 @@ def test_position_term_inside_the_kernels_vs_the_slab_design(Dh, H, L, K, mk, mo
     print("in-kernel vs slab: out %.2e dx %.2e grads %.2e | vs oracle: out %.2e dx %.2e grads %.2e" % (e_y, e_dx, e_g, o_y, o_dx, o_g))
     assert e_y < 5e-3 and e_dx < 2e-2 and e_g < 2e-2
     assert o_y < 3e-2 and o_dx < 8e-2 and o_g < 8e-2
+
+
+def test_streaming_config_chunk_mask_is_cached_and_equals_the_tensor_mask(monkeypatch):
+    """config.streaming = {chunk, left}: the model hands the kernels per-row key intervals built once per (T, chunk, left) - the same
+    MaskSpec object on every forward, no [T, T] mask tensor - and the encoder output equals the one under tt.utils.chunk_mask given as
+    the reference would give it (a [T, T, 1] tensor)"""
+    from tt.model import Transducer
+    from tt.utils import AttrDict, chunk_mask
+    monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    side = dict(n_layer=2, d_model=128, n_head=2, d_head=64, d_inner=96)
+    cfg = AttrDict(dict(enc=dict(side, max_input_length=64), dec=dict(side, max_target_length=8), joint=dict(input_size=256, inner_size=48),
+                        vocab_size=29, dropout=0.0, streaming=dict(chunk=16, left=64)))
+    torch.manual_seed(0)
+    model = Transducer(cfg).cuda().eval()
+    x = torch.randn(2, 300, 128, device="cuda")
+    a = model._audio_mask(x)
+    assert a.kind == 4 and a.left == 79 and a.right == 15 and model._audio_mask(x) is a
+    y1 = model.encoder(x, a)
+    y2 = model.encoder(x, chunk_mask(x, 16, 64)[:, :, None])
+    assert torch.equal(y1, y2)

@@ -245,8 +245,19 @@ class Transducer(nn.Module):
         if not s:
             return None
         if "chunk" in s:
-            from tt.utils import chunk_mask
-            return chunk_mask(inputs, s["chunk"], s.get("left", 0))[:, :, None]
+            # per-row key intervals of the block mask (tt.utils.chunk_mask), built once per (T, chunk, left, device) and handed to the kernels
+            # as they are: no [T, T] tensor per forward and none of as_mask_spec's host synchronisations (they made the C4-chunk run host-bound)
+            chunk, left, T = int(s["chunk"]), int(s.get("left", 0)), inputs.size(1)
+            key = (T, chunk, left, str(inputs.device))
+            cache = self.__dict__.setdefault("_chunk_specs", {})
+            spec = cache.get(key)
+            if spec is None:
+                i = torch.arange(T, device=inputs.device)
+                lo = ((i // chunk) * chunk - left).clamp_(min=0)
+                hi = ((i // chunk + 1) * chunk - 1).clamp_(max=T - 1)
+                spec = cache[key] = MaskSpec(4, left=left + chunk - 1, right=chunk - 1,
+                                             tensor=torch.stack([lo, hi], -1).to(torch.int32)[None].contiguous())
+            return spec
         return MaskSpec(2, left=int(s.get("left", 0)), right=int(s.get("right", 0)))
 
     @torch.no_grad()
