@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Rebuild profiles/pmc_joint_projection.json from the three rocprofv3 --pmc passes of tools/profile_round.sh (GPU box).
+usage: update_pmc_json.py <fetch dir> <write dir> <sq dir> <commit> <round tag>"""
+import csv
+import glob
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL = "gemm_nt_bf16_v8_kernel<unsigned short, 1>"
+
+
+def values(d, counter):
+    out = []
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                out.append(float(r["Counter_Value"]))
+    return out
+
+
+fetch, write = values(sys.argv[1], "FETCH_SIZE"), values(sys.argv[2], "WRITE_SIZE")
+busy, gui = values(sys.argv[3], "SQ_VALU_MFMA_BUSY_CYCLES"), values(sys.argv[3], "GRBM_GUI_ACTIVE")
+src = os.path.join(ROOT, "transformer-transducer_amd", "csrc", "gemm_fast.hip")
+mean = lambda v: sum(v) / len(v)
+j = {
+    "kernel": KERNEL + " joint vocabulary projection, M=816000 N=4334 K=1024 (one launch per step, persistent 256x256 tiles)",
+    "source": "profiles/%s_pmc_joint_kernels.txt: rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE and the SQ / GRBM counters in three separate passes of "
+              "the same bench.py command (tools/profile_round.sh); means over %d / %d launches" % (sys.argv[5], len(fetch), len(write)),
+    "commit": sys.argv[4],
+    "gemm_fast_sha16": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16],
+    "fetch_size_kb": mean(fetch), "write_size_kb": mean(write),
+    "correction": "gfx950 FETCH_SIZE reads 1/2 of wide (16 B/lane) streaming reads incl. global_load ... lds (MI355X_MICROARCH.md, HBM): traffic = "
+                  "2*FETCH + WRITE; FETCH counts L2 misses served by the Infinity Cache too (re-read A panels)",
+    "algorithmic_bytes": 816000.0 * 1024 * 2 + 4334.0 * 1024 * 2 + 816000.0 * 4352 * 2,
+    "mfma_busy": round(mean(busy) / (mean(gui) / 8.0 * 1024.0), 3),
+    "mfma_busy_source": "SQ_VALU_MFMA_BUSY_CYCLES %.4e / (GRBM_GUI_ACTIVE %.4e / 8 XCDs * 1024 SIMDs)" % (mean(busy), mean(gui)),
+}
+json.dump(j, open(os.path.join(ROOT, "profiles", "pmc_joint_projection.json"), "w"), indent=1)
+print(json.dumps(j, indent=1))

@@ -332,12 +332,11 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
         CK(ttmi_launch_gemm(mk(x, qkv_w, static_cast<float*>(c.qkv), (int)a.BL, (int)a.W3, d, d, d, a.W3, NT_, prec), st));
         CK(add_row_bias(static_cast<float*>(c.qkv), a.W3, r_w_bias, a.BL, (int)a.HD, static_cast<float*>(c.qu), a.HD, st));
     }
-    // 3. effective tables for this length (clamped rows when L > K)
-    CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st));
-    // 4. G = q E^T + c into the pitch-(L+1) slab, column 0 zero - unless the fused kernels form the position term themselves
+    // 3. effective tables for this length (clamped rows when L > K); the fused kernels' bf16 copy comes out of the same launch
     const bool inkernel = attn_inkernel(fast, a);
+    CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st, inkernel ? w.E16 : nullptr));
+    // 4. G = q E^T + c into the pitch-(L+1) slab, column 0 zero - unless the fused kernels form the position term themselves
     if (inkernel) {
-        CK(convert_bf16(w.E, w.E16, (long)L * a.HD, st));
     } else if (attn_fused(fast, a) && g_gemm_slab == 0 && (size_t)16 * (L + 1) * 4 + 32 <= 160 * 1024) {
         // write-bound: dedicated kernel that streams whole slab rows (column 0 included) instead of a batched GEMM + strided memset
         CK(convert_bf16(w.E, w.E16, (long)L * a.HD, st));
@@ -443,8 +442,7 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
         CK(memset2d(w.dG16, (size_t)w.slab16 * 2, (size_t)w.ldp * 2, (size_t)B * H, st));       // dG row 0 is (almost) never written
         FlashParams f = flash_params(a, c, scale, mask_kind, mask_left, mask_right, mask, mask_sb, mask_si);
         if (attn_inkernel(fast, a)) {                // the kernel recomputes the position term: effective table + bias for this length, as in forward
-            CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st));
-            CK(convert_bf16(w.E, w.E16, (long)L * a.HD, st));
+            CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st, w.E16));
             flash_inkernel(f, a, c, w);
         }
         f.dO = static_cast<const bf16_t*>(w.dO);

@@ -39,7 +39,8 @@ int add_row_bias_bf16(const bf16_t* in, long ldi, const float* bias, long rows, 
 int colsum(const float* in, long ld, long rows, int cols, int nz1, int nz2, long si1, long si2, long so1, long so2, float* out,
            hipStream_t st);
 // E[p,h,:] = r_emb[e(p),h,:], cT[h][p] = r_bias[e(p),h], e(p) = max(0, p + K - L)
-int relpos_gather(const float* r_emb, const float* r_bias, int K, int L, int H, int Dh, float* E, float* cT, hipStream_t st);
+int relpos_gather(const float* r_emb, const float* r_bias, int K, int L, int H, int Dh, float* E, float* cT, hipStream_t st,
+                  bf16_t* E16 = nullptr);   // E16 (optional): bf16 copy of E from the same pass
 // g_r_emb[e(p),h,:] += dE[p,h,:], g_r_bias[e(p),h] += dcT[h][p]
 int relpos_scatter(const float* dE, const float* dcT, int K, int L, int H, int Dh, float* g_r_emb, float* g_r_bias,
                    hipStream_t st);

@@ -386,13 +386,15 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict
 }
 
 __global__ void relpos_gather_kernel(const float* __restrict__ r_emb, const float* __restrict__ r_bias, int K, int L, int H,
-                                     int Dh, float* __restrict__ E, float* __restrict__ cT) {
+                                     int Dh, float* __restrict__ E, float* __restrict__ cT, bf16_t* __restrict__ E16) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long n = (long)L * H * Dh;
     if (idx < n) {
         const int p = (int)(idx / (H * Dh));
         const int e = max(0, p + K - L);
-        E[idx] = r_emb[(long)e * H * Dh + idx % (H * Dh)];
+        const float v = r_emb[(long)e * H * Dh + idx % (H * Dh)];
+        E[idx] = v;
+        if (E16) E16[idx] = f32_to_bf16(v);                    // the bf16 copy the fused attention kernels read, from the same pass
     }
     if (idx < (long)L * H) {
         const int h = (int)(idx / L), p = (int)(idx % L);
@@ -840,10 +842,10 @@ int colsum(const float* in, long ld, long rows, int cols, int nz1, int nz2, long
     return TTMI_OK;
 }
 
-int relpos_gather(const float* r_emb, const float* r_bias, int K, int L, int H, int Dh, float* E, float* cT, hipStream_t st) {
+int relpos_gather(const float* r_emb, const float* r_bias, int K, int L, int H, int Dh, float* E, float* cT, hipStream_t st, bf16_t* E16) {
     TTMI_REQUIRE(r_emb && r_bias && E && cT && K > 0 && L > 0, "relpos_gather: bad arguments");
     hipLaunchKernelGGL(relpos_gather_kernel, dim3(cdiv((long)L * H * Dh, 256)), dim3(256), 0, st, r_emb, r_bias, K, L, H, Dh, E,
-                       cT);
+                       cT, E16);
     TTMI_LAUNCH_CHECK("relpos_gather_kernel");
     return TTMI_OK;
 }
