@@ -323,3 +323,21 @@ def test_bf16_joint_wide_inner_dims_vs_torch(J, V, B, T, U1, monkeypatch):
     want = [ref.detach(), enc.grad, dec.grad] + [p.grad for p in joint.parameters()]
     for g, w in zip(got, want):
         assert rel_err(g.cpu().numpy(), w.cpu().numpy()) < 2e-2
+
+
+@pytest.mark.parametrize("name", ["tiny_klong", "tiny_kshort"])
+@pytest.mark.parametrize("graphs", [True, False])
+def test_sparse_greedy_decode_identical_tokens(name, graphs):
+    """the reference's own recognize() with the blank logit raised (tests/golden/greedy_sparse.npz): most frames are blank, histories outgrow
+    the label encoder's table; blocked on-device scan + captured label-encoder graphs give the identical token lists"""
+    import os
+    from conftest import GOLDEN
+    z, sd = load_golden(name)
+    g = np.load(os.path.join(GOLDEN, "greedy_sparse.npz"))
+    model = build(sd)
+    with torch.no_grad():
+        model.joint.project_layer.bias[0] += float(g[name + "/blank_bias"])
+    model.config["decode_graphs"] = graphs
+    hyp = model.recognize(torch.tensor(g[name + "/inputs"], device="cuda"), torch.tensor(g[name + "/lens"]))
+    for b, h in enumerate(hyp):
+        assert h == g["%s/tokens%d" % (name, b)].tolist(), b

@@ -88,3 +88,20 @@ def test_flat_view_shift_equals_index_form():
         dG = np.zeros_like(G)
         np.add.at(dG, (slice(None), slice(None), row, col), dBD * valid)
         assert np.allclose(O.rel_shift_flat_bwd(dBD), dG, atol=0, rtol=0)
+
+
+def test_sparse_greedy_tokens(golden, request):
+    """the reference's recognize() on the same nets with the blank logit raised (tools/gen_golden_r2.py): 5-20 % of the frames emit, so the
+    blank branch of tt/model.py:76-83 carries most frames and the label histories outgrow both table lengths"""
+    import os
+    from conftest import GOLDEN
+    z, sd = golden
+    name = request.node.callspec.params["golden"]
+    g = np.load(os.path.join(GOLDEN, "greedy_sparse.npz"))
+    sd = dict(sd)
+    sd["joint.project_layer.bias"] = sd["joint.project_layer.bias"].copy()
+    sd["joint.project_layer.bias"][0] += float(g[name + "/blank_bias"])
+    hyp = O.recognize(g[name + "/inputs"], g[name + "/lens"], sd)
+    for b, h in enumerate(hyp):
+        assert h == g["%s/tokens%d" % (name, b)].tolist()
+    assert 0 < sum(len(h) for h in hyp) < 0.25 * int(g[name + "/lens"].sum())

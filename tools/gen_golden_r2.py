@@ -162,7 +162,40 @@ def streaming_fixture():
         len(feats), len(enc_calls), [c[0] for c in enc_calls], len(tokens), tokens, os.path.getsize(os.path.join(OUT, "streaming.npz")) / 1024))
 
 
+def sparse_greedy_fixture():
+    """the reference's own Transducer.recognize (tt/model.py:92-108) on the tiny fixture nets with the blank logit raised, so that most frames
+    do NOT emit (round 1's greedy fixtures emitted on nearly every frame and barely exercised the blank branch): weights = the committed
+    tiny_klong / tiny_kshort state_dicts + a blank bias, inputs = fresh seeded features of 120 frames (histories beyond both table lengths)"""
+    out = {}
+    for name, k_enc, k_dec in (("tiny_klong", 64, 12), ("tiny_kshort", 16, 4)):
+        z = np.load(os.path.join(OUT, name + ".npz"))
+        cfg = yaml.load(open(os.path.join(REF, "config", "aishell.yaml")), Loader=yaml.FullLoader)
+        m = cfg["model"]
+        for side, k in (("enc", k_enc), ("dec", k_dec)):
+            m[side].update(n_layer=2, d_model=96, n_head=4, d_head=24, d_inner=160)
+        m["enc"]["max_input_length"], m["dec"]["max_target_length"] = k_enc, k_dec
+        m["joint"].update(input_size=192, inner_size=80)
+        m["vocab_size"], m["dropout"] = 48, 0.0
+        model = Transducer(AttrDict(m)).eval()
+        for pre, mod in (("encoder.", model.encoder), ("decoder.", model.decoder), ("joint.", model.joint)):
+            mod.load_state_dict({k[len("sd/" + pre):]: torch.tensor(z[k]) for k in z.files if k.startswith("sd/" + pre)})
+        bias = 0.75
+        with torch.no_grad():
+            model.joint.project_layer.bias[0] += bias
+        gen = torch.Generator().manual_seed(99)
+        x = torch.randn(3, 120, 96, generator=gen)
+        lens = torch.tensor([120, 77, 120])
+        with torch.no_grad():
+            hyp = model.recognize(x, lens)
+        out[name + "/inputs"], out[name + "/lens"], out[name + "/blank_bias"] = x.numpy(), lens.numpy(), np.array(bias, dtype=np.float32)
+        for b, h in enumerate(hyp):
+            out["%s/tokens%d" % (name, b)] = np.array(h, dtype=np.int64)
+        print(name, "sparse greedy:", [len(h) for h in hyp], "symbols for", lens.tolist(), "frames")
+    np.savez_compressed(os.path.join(OUT, "greedy_sparse.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     frontend_fixture()
     streaming_fixture()
+    sparse_greedy_fixture()

@@ -118,15 +118,19 @@ class GradSync:
     reduced asynchronously the moment all of its parameters have accumulated.  xGMI is a point-to-point mesh,
     so few large messages beat many small ones: default 32 MB buckets -> ~6 calls for the 193 MB payload."""
 
-    def __init__(self, flat, bucket_mb=32, group=None):
+    def __init__(self, flat, bucket_mb=32, group=None, tail_mb=None, tail_buckets=2):
+        """tail_mb: size of the first `tail_buckets` buckets (the parameters whose gradients arrive LAST - audio-encoder layer 0 first in
+        parameter order): the all-reduce of the bucket that completes last cannot overlap anything, so it is kept small (default
+        bucket_mb / 4)"""
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.buckets, self.bucket_of = [], {}
-        limit = int(bucket_mb * (1 << 20) / 4)
+        tail_mb = bucket_mb / 4.0 if tail_mb is None else tail_mb
         start, members = 0, []
         for i, p in enumerate(flat.params):
             members.append(i)
             end = flat.offsets[i + 1]
+            limit = int((tail_mb if len(self.buckets) < tail_buckets else bucket_mb) * (1 << 20) / 4)
             if end - start >= limit or i == len(flat.params) - 1:
                 for m in members:
                     self.bucket_of[m] = len(self.buckets)
