@@ -104,3 +104,68 @@ def test_two_ranks_over_rccl():
     assert np.array_equal(res[0][1], res[1][1])             # identical reduced gradients ...
     assert np.array_equal(res[0][2], res[1][2])             # ... and identical parameters after three updates
     assert res[0][3] != res[1][3]                           # but different dropout masks
+
+
+def _solo(port, q):
+    for p in (ROOT, os.path.join(ROOT, "transformer-transducer_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", TTMI_PRECISION="bf16")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from tt.model import Transducer
+    from ttmi import ops
+    from ttmi.train import FlatModel, FusedOptimizer, GradSync
+    torch.manual_seed(1)
+    model = Transducer(_cfg()).to(dev).train()
+    flat = FlatModel(model).enable_shadows()
+    sync = GradSync(flat, bucket_mb=0.05, always_reduce=True)          # a one-rank group still launches every bucket's collective
+    opt = FusedOptimizer(flat, kind="sgd", lr=0.01, momentum=0.9, max_grad_norm=5.0, world=1)
+    n_works = 0
+    for step in range(2):
+        x, y = _data(step)
+        flat.zero_grad()
+        sync.start_step()
+        loss = _loss(model, x, y, dev)
+        ops.reserve_cus(32)
+        loss.backward()
+        n_works = max(n_works, len(sync.works))
+        sync.finish()
+        ops.reserve_cus(0)
+        if step == 0:
+            torch.cuda.synchronize()
+            first = flat.grad.cpu().numpy()
+        opt.step()
+    dist.barrier()
+    t = torch.tensor([1.5], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    torch.cuda.synchronize()
+    q.put((first, n_works, len(sync.buckets), float(t)))
+    dist.destroy_process_group()
+
+
+def test_single_rank_rccl_path_on_one_gpu(monkeypatch):
+    """what a one-GPU box can execute of the RCCL path: a one-rank `nccl` group, every bucket's all-reduce issued from the gradient
+    hooks during backward (async handles, stream ordering against the side stream, the barrier and MAX reduction bench.py uses); the
+    'reduced' gradients must equal the plain ones"""
+    monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    port = 29700 + os.getpid() % 200
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_solo, args=(port, q))
+    p.start()
+    first, n_works, n_buckets, t = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    assert n_buckets > 3 and n_works >= n_buckets - 1 and t == 1.5            # collectives were launched from the hooks, during backward
+    from tt.model import Transducer
+    from ttmi import ops
+    from ttmi.train import FlatModel
+    torch.manual_seed(1)
+    model = Transducer(_cfg()).cuda().train()
+    flat = FlatModel(model)
+    x, y = _data(0)
+    _loss(model, x, y, torch.device("cuda", 0)).backward()
+    ops.join_side_streams()
+    torch.cuda.synchronize()
+    assert rel_err(first, flat.grad.cpu().numpy()) < 1e-5

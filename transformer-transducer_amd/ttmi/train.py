@@ -118,7 +118,7 @@ class GradSync:
     reduced asynchronously the moment all of its parameters have accumulated.  xGMI is a point-to-point mesh,
     so few large messages beat many small ones: default 32 MB buckets -> ~6 calls for the 193 MB payload."""
 
-    def __init__(self, flat, bucket_mb=32, group=None, tail_mb=None, tail_buckets=2):
+    def __init__(self, flat, bucket_mb=32, group=None, tail_mb=None, tail_buckets=2, always_reduce=False):
         """tail_mb: size of the first `tail_buckets` buckets (the parameters whose gradients arrive LAST - audio-encoder layer 0 first in
         parameter order): the all-reduce of the bucket that completes last cannot overlap anything, so it is kept small (default
         bucket_mb / 4)"""
@@ -144,7 +144,8 @@ class GradSync:
         # every rank starts from the same torch seed (identical initial weights); its dropout masks must still differ
         from tt import transformer as _tr
         _tr.set_seed_salt(dist.get_rank(group) if self.world > 1 else 0)
-        if self.world > 1:
+        self.active = self.world > 1 or (always_reduce and dist.is_available() and dist.is_initialized())   # always_reduce: a one-rank group still
+        if self.active:                                                                                          # issues its collectives (tests)
             for i, p in enumerate(flat.params):
                 hook = self._make_hook(i)
                 p.register_post_accumulate_grad_hook(hook)      # gradients that arrive through autograd
@@ -187,7 +188,7 @@ class GradSync:
         """Wait for outstanding bucket reductions (stream-level wait, no host block on the GPU work);
         reduces any bucket whose hooks did not all fire (parameters unused in this step)."""
         ops.join_side_streams()             # label-encoder gradients are written in place on the side stream
-        if self.world == 1:
+        if not self.active:
             return
         for b, (s, e, n) in enumerate(self.buckets):
             if self.pending[b] != n:
