@@ -57,7 +57,7 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
                   int mask_kind, int mask_left, int mask_right, const unsigned char* mask, long mask_sb, long mask_si,
                   int prec, float p_drop, unsigned seed, float* ctx, float* ws, float* y, void* stream);
 int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const float* o_w, const float* ln_g,
-                  const float* r_emb, const float* r_bias, int B, int L, int d, int H, int Dh, int K, int mask_kind,
+                  const float* r_emb, const float* r_w_bias, const float* r_bias, int B, int L, int d, int H, int Dh, int K, int mask_kind,
                   int mask_left, int mask_right, const unsigned char* mask, long mask_sb, long mask_si, int prec,
                   float p_drop, unsigned seed, const float* ctx, float* ws, float* dx, float* g_qkv_w, float* g_o_w,
                   float* g_ln_g, float* g_ln_b, float* g_r_emb, float* g_r_w_bias, float* g_r_bias, void* stream);

@@ -17,6 +17,7 @@ struct FlashParams {
     const bf16_t* e16 = nullptr;
     long ld_e = 0;
     const float* cT = nullptr;
+    const float* u = nullptr;     // r_w_bias [H*Dh] (f32): the in-kernel variants form q + u themselves (no qu tensor)
     bf16_t* o = nullptr;          // attention output (fwd: written, bwd: read)
     float* lse = nullptr;         // [B*H, L] log-sum-exp of the scaled, masked scores
     // backward only

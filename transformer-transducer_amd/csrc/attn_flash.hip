@@ -322,15 +322,18 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_rel_kernel(const FlashParams
     const int i0w = blockIdx.x * 128;
     const int i = i0w + wave * 32 + ii;
     const int ic = min(i, L - 1);
-    const bf16_t* qrow = p.qu + ((long)b * L + ic) * p.ld_qu + h * DH;
     const bf16_t* prow = p.qp + ((long)b * L + ic) * p.ld_qp + h * DH;
     const bf16_t* prow1 = p.qp + ((long)b * L + min(ic + 1, L - 1)) * p.ld_qp + h * DH;
     bf16x8 qf[KS], qp[KS], qp1[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks + 8 * hh);
         qp[ks] = *reinterpret_cast<const bf16x8*>(prow + 16 * ks + 8 * hh);
         qp1[ks] = *reinterpret_cast<const bf16x8*>(prow1 + 16 * ks + 8 * hh);
+        // q + r_w_bias (the content term's query, tt/transformer.py:140) formed here: f32 add of the bf16 q, rounded to bf16 once - the values
+        // a separate add_row_bias pass used to store as a [B*L, H*Dh] tensor
+        const float* uh = p.u + h * DH + 16 * ks + 8 * hh;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[ks][e] = (__bf16)((float)qp[ks][e] + uh[e]);
     }
     f32x16 o[DT];
 #pragma unroll
@@ -449,18 +452,15 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_rel_kernel(const FlashParams
         asm volatile("" ::: "memory");                         // DS operations of one wave execute in order: the reads below see these writes
     };
     auto sub_step = [&](int jb, int sub) {
-        float bcur[16];
+        f32x16 s;                                                         // the position term initialises the score accumulator
         if (p.debug & 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) bcur[r] = 0.f;
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
         } else {
             const bf16_t* gr = gs + 31 - ii + 32 * sub + 4 * hh;          // key jj of the tile sits at window column 31 - ii + jj
 #pragma unroll
-            for (int r = 0; r < 16; ++r) bcur[r] = bf16_to_f32(gr[(r & 3) + 8 * (r >> 2)]);
+            for (int r = 0; r < 16; ++r) s[r] = bf16_to_f32(gr[(r & 3) + 8 * (r >> 2)]);
         }
-        f32x16 s;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ktile + T::off(32 * sub + (lane & 31), 2 * ks + hh));
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_rel_kernel(const FlashParams
             const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * hh;
             float v = NEGBIG;
             const bool msk = MK == 4 ? (j < mlo || j > mhi) : is_masked<MK>(p, b, ic, j);
-            if (j < L && !msk) v = (s[r] + bcur[r]) * p.scale;
+            if (j < L && !msk) v = s[r] * p.scale;
             s[r] = v;
             pmax = fmaxf(pmax, v);
         }
@@ -571,12 +571,12 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
     using T = Tile<DH>;
     constexpr int KS = DH / 16, DT = DH / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* qtile = smem;                          // (q+u) rows of the current query tile
-    char* dotile = smem + 32 * T::ROWB;          // dO rows
-    char* ptile = smem + 64 * T::ROWB;           // plain q rows, ring of 64 (slot = row & 63): rows i0 .. i0 + 32 are read (the upper part multiplies
+    char* qtile = smem;                          // (q+u) rows, ring of 64 like ptile: formed from the plain q rows when they are parked
+    char* dotile = smem + 64 * T::ROWB;          // dO rows of the current query tile
+    char* ptile = smem + 96 * T::ROWB;           // plain q rows, ring of 64 (slot = row & 63): rows i0 .. i0 + 32 are read (the upper part multiplies
                                                  // q_{i+1}), rows i0 + 32 .. i0 + 63 arrive one step ahead
-    char* etile = smem + (64 + 64) * T::ROWB;    // ring of 256 table rows (the workgroup's 128 keys x 32 queries need 159)
-    float* ctile = reinterpret_cast<float*>(smem + (64 + 64 + 256) * T::ROWB);
+    char* etile = smem + (96 + 64) * T::ROWB;    // ring of 256 table rows (the workgroup's 128 keys x 32 queries need 159)
+    float* ctile = reinterpret_cast<float*>(smem + (96 + 64 + 256) * T::ROWB);
     float* lse_s = ctile + 256;
     float* del_s = lse_s + 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
@@ -598,7 +598,19 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
-    const bf16_t* qbase = p.qu + (long)b * L * p.ld_qu + h * DH;
+    // r_w_bias of this head sits in LDS (q + u is formed while plain q rows are parked; eight registers per thread were eight too many)
+    float* u_s = reinterpret_cast<float*>(smem + (96 + 64 + 256) * T::ROWB + 256 * 4 + 128 * 4 + 4 * 64 * 36 * 2);     // behind ctile, lse / delta / lo / hi and the four images
+    if (tid < DH) u_s[tid] = p.u[h * DH + tid];
+    __syncthreads();
+    auto add_u = [&](u32x4_t v) -> u32x4_t {
+        const float4 ua = *reinterpret_cast<const float4*>(u_s + (tid % T::NCH) * 8), ub = *reinterpret_cast<const float4*>(u_s + (tid % T::NCH) * 8 + 4);
+        u32x4_t o;
+        o[0] = pack_bf16x2(__uint_as_float(v[0] << 16) + ua.x, __uint_as_float(v[0] & 0xffff0000u) + ua.y);
+        o[1] = pack_bf16x2(__uint_as_float(v[1] << 16) + ua.z, __uint_as_float(v[1] & 0xffff0000u) + ua.w);
+        o[2] = pack_bf16x2(__uint_as_float(v[2] << 16) + ub.x, __uint_as_float(v[2] & 0xffff0000u) + ub.y);
+        o[3] = pack_bf16x2(__uint_as_float(v[3] << 16) + ub.z, __uint_as_float(v[3] & 0xffff0000u) + ub.w);
+        return o;
+    };
     const bf16_t* dobase = p.dO + (long)b * L * p.ld_o + h * DH;
     bf16_t* ds16 = p.dS16 + (long)z * p.slab16;
     bf16_t* dg16 = p.dG16 + (long)z * p.slab16;
@@ -636,9 +648,11 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
     // table window of a query tile: rows p' = wbase .. wbase + 159, wbase = L - 32 - i0 + jw0, in a ring (slot = (p' - L) & 255); every step
     // moves the window down by 32 rows, so only those 32 are fetched per step; the prologue stages the 160 rows above the first window
     auto stage_window = [&](int i0) {                    // (i0 = first tile - 32) also: the first tile's own plain q rows
-        for (int c = tid; c < 32 * T::NCH; c += 256)
-            *reinterpret_cast<u32x4_t*>(ptile + T::off((i0 + 32 + c / T::NCH) & 63, c % T::NCH)) =
-                *reinterpret_cast<const u32x4_t*>(pbase + (long)min(i0 + 32 + c / T::NCH, L - 1) * p.ld_qp + (c % T::NCH) * 8);
+        for (int c = tid; c < 32 * T::NCH; c += 256) {           // (c % NCH == tid % NCH: 256 is a multiple of NCH, so uc is this chunk's bias)
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(pbase + (long)min(i0 + 32 + c / T::NCH, L - 1) * p.ld_qp + (c % T::NCH) * 8);
+            *reinterpret_cast<u32x4_t*>(ptile + T::off((i0 + 32 + c / T::NCH) & 63, c % T::NCH)) = v;
+            *reinterpret_cast<u32x4_t*>(qtile + T::off((i0 + 32 + c / T::NCH) & 63, c % T::NCH)) = add_u(v);
+        }
         const int wbase = L - 32 - i0 + jw0;
         for (int c = tid; c < 160 * T::NCH; c += 256) {
             const int pe = wbase + c / T::NCH, ch = c % T::NCH;
@@ -662,14 +676,16 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
         if (tid < 32 * T::NCH) {
             *reinterpret_cast<u32x4_t*>(etile + T::off((wbase + tid / T::NCH - L) & 255, tid % T::NCH)) = epre;
             *reinterpret_cast<u32x4_t*>(ptile + T::off((parked_i0 + 32 + tid / T::NCH) & 63, tid % T::NCH)) = ppre;
+            *reinterpret_cast<u32x4_t*>(qtile + T::off((parked_i0 + 32 + tid / T::NCH) & 63, tid % T::NCH)) = add_u(ppre);
         }
         if (tid < 32) ctile[(wbase + tid - L) & 255] = cpre;
     };
-    // result: bf16 pairs, bvp[k] = (bias of accumulator element 2k) | (element 2k + 1) << 16 - eight registers instead of sixteen floats
-    auto read_bias = [&](int i0, unsigned (&bvp)[8]) {
+    // result: the bias in the layout of the score accumulator, which it initialises (S = bias + (q+u).k comes out of the MFMA chain itself: no
+    // separate registers for the bias, no add per element)
+    auto read_bias = [&](int i0, f32x16& bv) {
         if (p.debug & 1) {
 #pragma unroll
-            for (int k2 = 0; k2 < 8; ++k2) bvp[k2] = 0u;
+            for (int r = 0; r < 16; ++r) bv[r] = 0.f;
             return;
         }
         const int pe_w = L - 32 - i0 + jw0 + 32 * wave;           // p' of the wave's window column 0
@@ -723,9 +739,9 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
         asm volatile("" ::: "memory");                            // DS operations of one wave execute in order
         // score (query qi, own key jj = lane & 31) sits at window column 31 - qi + jj
 #pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2) {
-            const int q0 = ((2 * k2) & 3) + 8 * ((2 * k2) >> 2) + 4 * hh, q1 = q0 + 1;
-            bvp[k2] = (unsigned)gs[(31 - q0 + (lane & 31)) * GPB + q0] | ((unsigned)gs[(31 - q1 + (lane & 31)) * GPB + q1] << 16);
+        for (int r = 0; r < 16; ++r) {
+            const int qi = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            bv[r] = bf16_to_f32(gs[(31 - qi + (lane & 31)) * GPB + qi]);
         }
     };
     // narrow structured masks (launcher's choice, p.bwd_skip): both bf16 slabs were zeroed up front and only the query tiles that can see
@@ -736,16 +752,15 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
         iend = (int)min((long)L, (long)jw0 + 127 + p.mask_left + 1);
         if (iend <= ibeg) { ibeg = 0; iend = 0; }
     }
-    RowStage<DH, 32> stQ, stO;
-    stQ.load(qbase, p.ld_qu, ibeg, L - 1, tid);
+    RowStage<DH, 32> stO;
     stO.load(dobase, p.ld_o, ibeg, L - 1, tid);
     if (!(p.debug & 1) && ibeg < iend) stage_window(ibeg - 32);        // rows wbase(ibeg) + 32 .. + 191: step(ibeg) parks the 32 below them
     fetch_bias(ibeg);
     auto step = [&](int i0) {
         __syncthreads();
-        stQ.store(qtile, tid);
         stO.store(dotile, tid);
         parked_i0 = i0;
+        const char* qcur = qtile + (i0 & 32) * T::ROWB;     // this tile's 32 (q+u) rows inside the ring (same swizzle phase: 32 rows = 4 periods)
         park_bias();
         if (tid < 32) {
             const int ii = min(i0 + tid, L - 1);
@@ -759,19 +774,16 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
         }
         __syncthreads();
         if (i0 + 32 < iend) {                                       // next tile's operands and bias fly under this tile's MFMAs
-            stQ.load(qbase, p.ld_qu, i0 + 32, L - 1, tid);
             stO.load(dobase, p.ld_o, i0 + 32, L - 1, tid);
             fetch_bias(i0 + 32);
         }
-        unsigned bvp[8];
-        read_bias(i0, bvp);
-#define BCUR(r) __uint_as_float(((r) & 1) ? (bvp[(r) >> 1] & 0xffff0000u) : (bvp[(r) >> 1] << 16))
         f32x16 s, dp;
+        read_bias(i0, s);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) dp[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 qa = *reinterpret_cast<const bf16x8*>(qtile + T::off(lane & 31, 2 * ks + hh));
+            const bf16x8 qa = *reinterpret_cast<const bf16x8*>(qcur + T::off(lane & 31, 2 * ks + hh));
             const bf16x8 da = *reinterpret_cast<const bf16x8*>(dotile + T::off(lane & 31, 2 * ks + hh));
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
@@ -803,7 +815,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
                 const int q = (r & 3) + 8 * (r >> 2) + 4 * hh;
                 float pr = 0.f, ds = 0.f;
                 if (!(MK == 4 ? (j < lo_s[q] || j > hi_s[q]) : is_masked<MK>(p, b, i0 + q, j))) {
-                    const float sc = (s[r] + BCUR(r)) * p.scale;
+                    const float sc = s[r] * p.scale;
                     pr = __expf(sc - lse_s[q]);
                     ds = pr * (dp[r] - del_s[q]) * p.scale;
                 }
@@ -830,7 +842,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
                 float pr = 0.f, ds = 0.f;
                 if (inb) {
                     if (!(MK == 4 ? (j < lo_s[q] || j > hi_s[q]) : is_masked<MK>(p, b, i, j))) {
-                        const float sc = (s[r] + BCUR(r)) * p.scale;
+                        const float sc = s[r] * p.scale;
                         pr = __expf(sc - lse_s[q]);
                         ds = pr * (dp[r] - del_s[q]) * p.scale;
                     }
@@ -851,7 +863,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const bf16x8 a_do = tr_frag<DH>(dotile, 16 * s2, 32 * dt, lane);
-                const bf16x8 a_qu = tr_frag<DH>(qtile, 16 * s2, 32 * dt, lane);
+                const bf16x8 a_qu = tr_frag<DH>(qcur, 16 * s2, 32 * dt, lane);
                 dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_do, pb, dv[dt], 0, 0, 0);
                 dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_qu, dsb, dk[dt], 0, 0, 0);
             }
@@ -884,7 +896,6 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
     }
 }
 
-#undef BCUR
 // ------------------------------------------------------------------ backward (dK, dV, dS)
 template <int DH, int MK>
 __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) {
@@ -1275,10 +1286,10 @@ int relpos_slab(const bf16_t* q, long ld_q, const bf16_t* E, long ld_e, const fl
 }
 
 int flash_attn_fwd(const FlashParams& p, hipStream_t st) {
-    TTMI_REQUIRE(p.qu && p.k && p.v && (p.bd || p.e16) && p.o && p.lse, "flash_attn_fwd: null pointer");
-    if (p.e16) {                                    // position term formed in the kernel (no slab)
-        TTMI_REQUIRE(p.qp && p.cT && flash_supported(p.Dh, p.ld_qu, p.ld_kv, p.ld_o) && p.ld_qp % 8 == 0 && p.ld_e % 8 == 0 && aligned16(p.qp) &&
-                     aligned16(p.e16) && aligned16(p.qu) && aligned16(p.k) && aligned16(p.v) && (reinterpret_cast<uintptr_t>(p.o) & 7) == 0,
+    TTMI_REQUIRE((p.qu || p.e16) && p.k && p.v && (p.bd || p.e16) && p.o && p.lse, "flash_attn_fwd: null pointer");
+    if (p.e16) {                                    // position term (and q + u) formed in the kernel: no slab, no q+u tensor
+        TTMI_REQUIRE(p.qp && p.cT && p.u && flash_supported(p.Dh, p.ld_qp, p.ld_kv, p.ld_o) && p.ld_qp % 8 == 0 && p.ld_e % 8 == 0 && aligned16(p.qp) &&
+                     aligned16(p.e16) && aligned16(p.k) && aligned16(p.v) && (reinterpret_cast<uintptr_t>(p.o) & 7) == 0,
                      "flash_attn_fwd: in-kernel position term needs 16-byte aligned q / E with pitches %% 8 == 0");
         dim3 grid(cdiv(p.L, 128), p.B * p.H);
         TTMI_REQUIRE(grid.y <= 65535, "flash_attn_fwd: B*H too large");
@@ -1318,12 +1329,12 @@ int flash_attn_fwd(const FlashParams& p, hipStream_t st) {
 }
 
 int flash_attn_bwd(const FlashParams& p, hipStream_t st) {
-    TTMI_REQUIRE(p.qu && p.k && p.v && (p.bd || p.e16) && p.o && p.lse && p.dO && p.delta && p.dS16 && p.dG16 && p.dK && p.dV, "flash_attn_bwd: null pointer");
-    TTMI_REQUIRE(!p.e16 || (p.qp && p.cT && p.ld_qp % 8 == 0 && p.ld_e % 8 == 0 && aligned16(p.qp) && aligned16(p.e16)),
+    TTMI_REQUIRE((p.qu || p.e16) && p.k && p.v && (p.bd || p.e16) && p.o && p.lse && p.dO && p.delta && p.dS16 && p.dG16 && p.dK && p.dV, "flash_attn_bwd: null pointer");
+    TTMI_REQUIRE(!p.e16 || (p.qp && p.cT && p.u && p.ld_qp % 8 == 0 && p.ld_e % 8 == 0 && aligned16(p.qp) && aligned16(p.e16)),
                  "flash_attn_bwd: in-kernel position term needs 16-byte aligned q / E with pitches %% 8 == 0");
     TTMI_REQUIRE(p.ldp >= p.L && p.ldp % 8 == 0 && (long)p.L * (p.L + 1) < (1L << 31), "flash_attn_bwd: bad dS pitch / L too large");
-    TTMI_REQUIRE(flash_supported(p.Dh, p.ld_qu, p.ld_kv, p.ld_o) && p.ld_dkv % 4 == 0, "flash_attn_bwd: unsupported head dim %d / pitches", p.Dh);
-    TTMI_REQUIRE(aligned16(p.qu) && aligned16(p.k) && aligned16(p.v) && aligned16(p.dO) && aligned16(p.dK) && aligned16(p.dV), "flash_attn_bwd: alignment");
+    TTMI_REQUIRE(flash_supported(p.Dh, p.e16 ? p.ld_qp : p.ld_qu, p.ld_kv, p.ld_o) && p.ld_dkv % 4 == 0, "flash_attn_bwd: unsupported head dim %d / pitches", p.Dh);
+    TTMI_REQUIRE((p.e16 || aligned16(p.qu)) && aligned16(p.k) && aligned16(p.v) && aligned16(p.dO) && aligned16(p.dK) && aligned16(p.dV), "flash_attn_bwd: alignment");
     const long n = (long)p.B * p.L * p.H;
     dim3 grid(cdiv(p.L, 128), p.B * p.H);
     FlashParams q = p;
@@ -1341,13 +1352,13 @@ int flash_attn_bwd(const FlashParams& p, hipStream_t st) {
     }
     if (p.Dh == 64) hipLaunchKernelGGL(flash_delta_kernel<64>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta);
     else hipLaunchKernelGGL(flash_delta_kernel<32>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta);
-    // in-kernel position term: (64 + 64 + 256) tile rows + cext ring + lse / delta + lo / hi + 4 private images of [64][36] bf16
+    // in-kernel position term: (64 + 32 + 64 + 256) tile rows + cext ring + lse / delta + lo / hi + 4 private images of [64][36] bf16
 #define BWD_LAUNCH(MKV) do { \
         if (p.e16) { \
-            if (p.Dh == 64) { const int lds = 384 * 128 + 256 * 4 + 256 + 256 + 4 * 64 * 36 * 2; \
+            if (p.Dh == 64) { const int lds = 416 * 128 + 256 * 4 + 256 + 256 + 4 * 64 * 36 * 2 + 256; \
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_bwd_rel_kernel<64, MKV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) { ttmi_set_error("flash_attn_bwd: LDS attribute"); return TTMI_EINVAL; } \
                 hipLaunchKernelGGL((flash_bwd_rel_kernel<64, MKV>), grid, dim3(256), lds, st, q); } \
-            else hipLaunchKernelGGL((flash_bwd_rel_kernel<32, MKV>), grid, dim3(256), 384 * 64 + 256 * 4 + 256 + 256 + 4 * 64 * 36 * 2, st, q); \
+            else hipLaunchKernelGGL((flash_bwd_rel_kernel<32, MKV>), grid, dim3(256), 416 * 64 + 256 * 4 + 256 + 256 + 4 * 64 * 36 * 2 + 256, st, q); \
         } else if (p.Dh == 64) hipLaunchKernelGGL((flash_bwd_kernel<64, MKV>), grid, dim3(256), 64 * 128 + 256 + 8192 + 256, st, q); \
         else hipLaunchKernelGGL((flash_bwd_kernel<32, MKV>), grid, dim3(256), 64 * 64 + 256 + 8192 + 256, st, q); } while (0)
     const bool probe = p.L >= 256;                   // timing probe 3: the audio encoder's backward kernel (the label encoder's is tiny)

@@ -193,7 +193,7 @@ struct AttnCtx {   // saved for backward.  act = f32 (parity) or bf16 (fast)
     AttnCtx(Bump& b, const AttnDims& a, bool fast) {
         const size_t es = fast ? 2 : 4;
         qkv = b.take<char>(a.BL * a.W3 * es);
-        qu = b.take<char>(a.BL * a.HD * es);
+        qu = b.take<char>(attn_inkernel(fast, a) ? 64 : a.BL * a.HD * es);    // in-kernel variants form q + u themselves
         O = b.take<char>(a.BL * a.HD * es);
         P = b.take<float>(attn_inkernel(fast, a) ? 64 : (size_t)a.B * a.H * a.slab);
         s1 = b.take<float>(a.BL * a.d);
@@ -259,8 +259,10 @@ FlashParams flash_params(const AttnDims& a, const AttnCtx& c, float scale, int m
 }
 
 // position term formed inside the attention kernels: plain q (first third of the qkv rows), the effective table in bf16 and its bias
-void flash_inkernel(FlashParams& f, const AttnDims& a, const AttnCtx& c, const AttnWs& w) {
+void flash_inkernel(FlashParams& f, const AttnDims& a, const AttnCtx& c, const AttnWs& w, const float* r_w_bias) {
     f.bd = nullptr;
+    f.qu = nullptr;
+    f.u = r_w_bias;
     f.qp = static_cast<const bf16_t*>(c.qkv);
     f.ld_qp = a.W3;
     f.e16 = w.E16;
@@ -327,7 +329,8 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
         if (shadow_of(qkv_w, (int)a.W3, d, a.W3, sh)) wqkv16 = sh.w16;                          // kept current by the optimiser step
         else CK(transpose_convert_bf16(qkv_w, (int)a.W3, d, c.wqkvT16, a.W3, st, w.wqkv16));   // Wqkv (bf16) and Wqkv^T [d, W3] for backward
         CK(gemm_nt_bf16(c.x16, wqkv16, c.qkv, 1, nullptr, (int)a.BL, (int)a.W3, d, d, d, a.W3, st));
-        CK(add_row_bias_bf16(static_cast<bf16_t*>(c.qkv), a.W3, r_w_bias, a.BL, (int)a.HD, static_cast<bf16_t*>(c.qu), a.HD, st));
+        if (!attn_inkernel(fast, a))
+            CK(add_row_bias_bf16(static_cast<bf16_t*>(c.qkv), a.W3, r_w_bias, a.BL, (int)a.HD, static_cast<bf16_t*>(c.qu), a.HD, st));
     } else {
         CK(ttmi_launch_gemm(mk(x, qkv_w, static_cast<float*>(c.qkv), (int)a.BL, (int)a.W3, d, d, d, a.W3, NT_, prec), st));
         CK(add_row_bias(static_cast<float*>(c.qkv), a.W3, r_w_bias, a.BL, (int)a.HD, static_cast<float*>(c.qu), a.HD, st));
@@ -362,7 +365,7 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
     if (attn_fused(fast, a)) {
         // 5-7 fused: softmax((q+u) k^T + shifted(G)) V without materialising the probabilities
         FlashParams f = flash_params(a, c, scale, mask_kind, mask_left, mask_right, mask, mask_sb, mask_si);
-        if (inkernel) flash_inkernel(f, a, c, w);
+        if (inkernel) flash_inkernel(f, a, c, w, r_w_bias);
         CK(flash_attn_fwd(f, st));
     } else {
         // 5. S = shifted(G) + (q+u) k^T, accumulated through the pitch-L view
@@ -401,7 +404,7 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
 
 // Backward of ttmi_attn_fwd.  dx is written; every g_* buffer is ACCUMULATED into (zero them per step).
 int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const float* o_w, const float* ln_g,
-                  const float* r_emb, const float* r_bias, int B, int L, int d, int H, int Dh, int K, int mask_kind,
+                  const float* r_emb, const float* r_w_bias, const float* r_bias, int B, int L, int d, int H, int Dh, int K, int mask_kind,
                   int mask_left, int mask_right, const unsigned char* mask, long mask_sb, long mask_si, int prec,
                   float p_drop, unsigned seed, const float* ctx, float* ws, float* dx, float* g_qkv_w, float* g_o_w,
                   float* g_ln_g, float* g_ln_b, float* g_r_emb, float* g_r_w_bias, float* g_r_bias, void* stream) {
@@ -443,7 +446,8 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
         FlashParams f = flash_params(a, c, scale, mask_kind, mask_left, mask_right, mask, mask_sb, mask_si);
         if (attn_inkernel(fast, a)) {                // the kernel recomputes the position term: effective table + bias for this length, as in forward
             CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st, w.E16));
-            flash_inkernel(f, a, c, w);
+            TTMI_REQUIRE(r_w_bias, "attn_bwd: r_w_bias is required (the attention kernels form q + r_w_bias themselves)");
+            flash_inkernel(f, a, c, w, r_w_bias);
         }
         f.dO = static_cast<const bf16_t*>(w.dO);
         f.delta = w.delta;

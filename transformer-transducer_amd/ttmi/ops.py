@@ -198,7 +198,7 @@ def attn_bwd(dy, x, p, ctx, prec, grads, p_drop=0.0, seed=0, mask=None):
     L_.ttmi_attn_ws_floats.restype = ctypes.c_size_t
     ws = scratch(L_.ttmi_attn_ws_floats(c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh), c_int(prec)), x.device)
     dx = torch.empty_like(x)
-    check(L_.ttmi_attn_bwd(_p(dy), _p(x), _p(p["qkv_w"]), _p(p["o_w"]), _p(p["ln_g"]), _p(p["r_emb"]), _p(p["r_bias"]),
+    check(L_.ttmi_attn_bwd(_p(dy), _p(x), _p(p["qkv_w"]), _p(p["o_w"]), _p(p["ln_g"]), _p(p["r_emb"]), _p(p["r_w_bias"]), _p(p["r_bias"]),
                            c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh), c_int(K), *(mask or MaskSpec()).args(), c_int(prec),
                            c_float(p_drop), ctypes.c_uint(seed), _p(ctx), _p(ws), _p(dx),
                            _p(grads["qkv_w"]), _p(grads["o_w"]), _p(grads["ln_g"]), _p(grads["ln_b"]), _p(grads["r_emb"]),
