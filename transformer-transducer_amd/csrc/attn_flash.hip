@@ -407,7 +407,40 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_rel_kernel(const FlashParams
         if (p.debug & 1) return;
         asm volatile("" ::: "memory");                         // (the image is written as uint2 and read as bf16: keep the compiler from reordering across)
         const int pe_w = L - 128 - i0w + j0 + eoff;            // p' of the wave's window row 0
+        auto emit = [&](int blk, const f32x16& g) {            // + cext, to bf16, into this lane's image row: window columns 32 blk + 8 g4 + 4 hh + (0..3)
 #pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int col = 32 * blk + 8 * g4 + 4 * hh;
+                const float4 cv = *reinterpret_cast<const float4*>(ctile + ((pe_w + col - L) & 255));     // slots count from p' - L: a multiple of 4 here
+                uint2 w;
+                w.x = pack_bf16x2(g[4 * g4] + cv.x, g[4 * g4 + 1] + cv.y);
+                w.y = pack_bf16x2(g[4 * g4 + 2] + cv.z, g[4 * g4 + 3] + cv.w);
+                *reinterpret_cast<uint2*>(gs + col) = w;
+            }
+        };
+        const bool all_low = pe_w + 95 <= L - 1, all_up = pe_w >= L + 1;
+        if (all_low || all_up) {
+            // the common case (the tile is wholly below or wholly above the j = i + 1 diagonal): three independent accumulator chains, their
+            // MFMAs interleaved - a block's four dependent MFMAs alone leave the pipe idle for the accumulator latency
+            f32x16 g0, g1, g2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; g2[r] = 0.f; }
+            const int e0 = (pe_w + ii - L) & 255, e1 = (pe_w + 32 + ii - L) & 255, e2 = (pe_w + 64 + ii - L) & 255;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 qs = all_low ? qp[ks] : qp1[ks];
+                const bf16x8 f0 = *reinterpret_cast<const bf16x8*>(etile + T::off(e0, 2 * ks + hh));
+                const bf16x8 f1 = *reinterpret_cast<const bf16x8*>(etile + T::off(e1, 2 * ks + hh));
+                const bf16x8 f2 = *reinterpret_cast<const bf16x8*>(etile + T::off(e2, 2 * ks + hh));
+                g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, qs, g0, 0, 0, 0);
+                g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, qs, g1, 0, 0, 0);
+                g2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2, qs, g2, 0, 0, 0);
+            }
+            emit(0, g0);
+            emit(1, g1);
+            emit(2, g2);
+        } else {
+#pragma unroll 1
         for (int blk = 0; blk < 3; ++blk) {
             const int pe0 = pe_w + 32 * blk;
             f32x16 g;
@@ -438,16 +471,8 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_rel_kernel(const FlashParams
                     g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lower ? zero : ef, qp1[ks], g, 0, 0, 0);
                 }
             }
-            // lane (query ii, half hh) holds window rows 32 blk + 8 g4 + 4 hh + (0..3): + cext, to bf16, 8 bytes per group into its image row
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int col = 32 * blk + 8 * g4 + 4 * hh;
-                const float4 cv = *reinterpret_cast<const float4*>(ctile + ((pe_w + col - L) & 255));     // slots count from p' - L: a multiple of 4 here
-                uint2 w;
-                w.x = pack_bf16x2(g[4 * g4] + cv.x, g[4 * g4 + 1] + cv.y);
-                w.y = pack_bf16x2(g[4 * g4 + 2] + cv.z, g[4 * g4 + 3] + cv.w);
-                *reinterpret_cast<uint2*>(gs + col) = w;
-            }
+            emit(blk, g);
+        }
         }
         asm volatile("" ::: "memory");                         // DS operations of one wave execute in order: the reads below see these writes
     };
@@ -690,6 +715,35 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
         }
         const int pe_w = L - 32 - i0 + jw0 + 32 * wave;           // p' of the wave's window column 0
         asm volatile("" ::: "memory");
+        auto emit = [&](int blk, const f32x16& g) {               // lane = window column of the block; queries 8 g4 + 4 hh + (0..3): + cext[column], to bf16
+            const float cv = ctile[(pe_w + 32 * blk + (lane & 31) - L) & 255];
+            bf16_t* col = gs + (32 * blk + (lane & 31)) * GPB;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                uint2 w;
+                w.x = pack_bf16x2(g[4 * g4] + cv, g[4 * g4 + 1] + cv);
+                w.y = pack_bf16x2(g[4 * g4 + 2] + cv, g[4 * g4 + 3] + cv);
+                *reinterpret_cast<uint2*>(col + 8 * g4 + 4 * hh) = w;
+            }
+        };
+        const bool all_low = pe_w + 63 <= L - 1, all_up = pe_w >= L + 1;
+        if (all_low || all_up) {                                  // both blocks on one side of p' = L: two independent MFMA chains, interleaved
+            f32x16 g0, g1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; }
+            const int qrow = (i0 + (lane & 31) + (all_low ? 0 : 1)) & 63;
+            const int e0 = (pe_w + (lane & 31) - L) & 255, e1 = (pe_w + 32 + (lane & 31) - L) & 255;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 qa = *reinterpret_cast<const bf16x8*>(ptile + T::off(qrow, 2 * ks + hh));
+                const bf16x8 f0 = *reinterpret_cast<const bf16x8*>(etile + T::off(e0, 2 * ks + hh));
+                const bf16x8 f1 = *reinterpret_cast<const bf16x8*>(etile + T::off(e1, 2 * ks + hh));
+                g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, f0, g0, 0, 0, 0);
+                g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, f1, g1, 0, 0, 0);
+            }
+            emit(0, g0);
+            emit(1, g1);
+        } else {
 #pragma unroll 1
         for (int blk = 0; blk < 2; ++blk) {
             const int pe0 = pe_w + 32 * blk;
@@ -725,16 +779,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
                     g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qb, lower ? zero : ef, g, 0, 0, 0);
                 }
             }
-            // lane (window column pp = lane & 31 of this block, half hh) holds queries 8 g4 + 4 hh + (0..3): + cext[column], to bf16
-            const float cv = ctile[(pe0 + (lane & 31) - L) & 255];
-            bf16_t* col = gs + (32 * blk + (lane & 31)) * GPB;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                uint2 w;
-                w.x = pack_bf16x2(g[4 * g4] + cv, g[4 * g4 + 1] + cv);
-                w.y = pack_bf16x2(g[4 * g4 + 2] + cv, g[4 * g4 + 3] + cv);
-                *reinterpret_cast<uint2*>(col + 8 * g4 + 4 * hh) = w;
-            }
+            emit(blk, g);
+        }
         }
         asm volatile("" ::: "memory");                            // DS operations of one wave execute in order
         // score (query qi, own key jj = lane & 31) sits at window column 31 - qi + jj
