@@ -254,7 +254,8 @@ def main():
         ms_step = 1e3 * elapsed / args.steps
         utt_s = world * B * args.steps / elapsed
         U1, J = U + 1, cfg["joint"]["inner_size"]
-        flop_launch = 2.0 * B * T * U1 * J * V                                   # one joint-projection launch
+        B_launch = B if not args.fused_loss else (args.loss_chunk or model.default_loss_chunk(B, T, U1))      # utterances per joint-projection launch
+        flop_launch = 2.0 * B_launch * T * U1 * J * V                            # one joint-projection launch
         k_ms = float(np.mean([m for m in probe_ms if m > 0])) if probe_ms else float("nan")
         peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
         ach = flop_launch / (k_ms * 1e-3) / 1e12
@@ -278,7 +279,7 @@ def main():
         lf = float(np.mean([a for a, b in loss_ms if a > 0 and b > 0])) if loss_ms else float("nan")
         lb = float(np.mean([b for a, b in loss_ms if a > 0 and b > 0])) if loss_ms else float("nan")
         loss_gbs = loss_bytes / ((lf + lb) * 1e-3) / 1e9
-        roof_joint = {"bound": "mfma", "kernel": "gemm_nt_bf16_v8_kernel (joint vocabulary projection, M=%d N=%d K=%d)" % (B * T * U1, V, J),
+        roof_joint = {"bound": "mfma", "kernel": "gemm_nt_bf16_v8_kernel (joint vocabulary projection, M=%d N=%d K=%d)" % (B_launch * T * U1, V, J),
                       "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                       "traffic": traffic, "mfma_busy": mfma_busy, "kernel_ms": round(k_ms, 4), "pmc": pmc_build}
         # the two weakest kernels of the step, on the record every round
@@ -287,12 +288,13 @@ def main():
         a_ms = float(np.mean([m for m in attn_ms if m > 0])) if any(m > 0 for m in attn_ms) else float("nan")
         attn_bytes = B * T * H * Dh * 2.0 * 6 + B * H * T * 8.0       # (q+u), k, v, dO in; dK, dV out (bf16); lse + delta (f32)
         attn_flops = 10.0 * B * H * T * T * Dh                         # S, dP, dV, dK and (in the following launch) dq products
-        roof_attn = {"bound": "hbm", "kernel": "flash_bwd_kernel, one audio layer (B=%d L=%d H=%d Dh=%d): recomputes P, writes dK / dV and the dS / dG slabs"
-                                               % (B, T, H, Dh),
+        roof_attn = {"bound": "hbm", "kernel": "attention backward kernel (flash_bwd_rel_kernel), one audio layer (B=%d L=%d H=%d Dh=%d): recomputes P incl. the "
+                                               "position term, writes dK / dV and dS twice (bf16) for the dq / dE products" % (B, T, H, Dh),
                      "achieved": round(attn_bytes / (a_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(attn_bytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(a_ms, 4),
                      "mfma_tflops": round(0.8 * attn_flops / (a_ms * 1e-3) / 1e12, 1),
-                     "note": "algorithmic bytes only; the bias slab read (B*H*L*L*2) and the dS / dG slabs written (2x) are design traffic on top"}
+                     "note": "algorithmic bytes only (q, k, v, dO in; dK, dV out); the dS / dG slabs written (2 x B*H*L*L*2 bytes) are design traffic on top; "
+                             "kernel_ms is the first audio layer's launch between two events on its stream"}
         w_ms = float(np.mean([m for m in wgrad_ms if m > 0])) if any(m > 0 for m in wgrad_ms) else float("nan")
         wg_flops = 2.0 * (3 * H * Dh) * dm * (B * T)
         roof_wgrad = {"bound": "mfma", "kernel": "qkv_net weight gradient, one audio layer (M=%d N=%d K=%d, f32 atomics across K ranges)" % (3 * H * Dh, dm, B * T),

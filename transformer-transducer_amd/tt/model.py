@@ -206,16 +206,21 @@ class Transducer(nn.Module):
         ops.weights_fresh()
         prec = default_precision()
         if chunk is None:
-            es = 2 if ops.joint_logits_dtype(prec, self.joint.forward_layer.out_features) is torch.bfloat16 else 4
-            chunk = max(1, min(B, int((2 << 30) // (es * T * U1 * self.config.vocab_size))))
-            # the joint's persistent wgrad kernel wants a reduction length (chunk * T * U1 lattice rows) that is a multiple of its 64-row
-            # K-tile; other lengths fall to the 128x128 kernel at twice the time (C2: 8 utterances 9.5 ms, 16 utterances 5.3 ms per step)
-            ok = [c for c in range(1, B + 1) if (c * T * U1) % 64 == 0]
-            if ok:
-                chunk = max([c for c in ok if c <= chunk] or [min(ok)])
+            chunk = self.default_loss_chunk(B, T, U1)
         j = self.joint
         return _JointLossFn.apply(enc_state, dec_state, j.forward_layer.weight, j.forward_layer.bias, j.project_layer.weight,
                                   j.project_layer.bias, labels, al, ll, prec, int(chunk), reduction)
+
+    def default_loss_chunk(self, B, T, U1):
+        """utterances per chunk of `loss()`: about 2 GB of logits, adjusted to a lattice-row count the joint's persistent wgrad kernel takes (a
+        reduction length chunk * T * U1 that is a multiple of its 64-row K-tile; other lengths fall to the 128x128 kernel at twice the time:
+        C2, 8 utterances 9.5 ms per step, 16 utterances 5.3 ms)"""
+        es = 2 if ops.joint_logits_dtype(default_precision(), self.joint.forward_layer.out_features) is torch.bfloat16 else 4
+        chunk = max(1, min(B, int((2 << 30) // (es * T * U1 * self.config.vocab_size))))
+        ok = [c for c in range(1, B + 1) if (c * T * U1) % 64 == 0]
+        if ok:
+            chunk = max([c for c in ok if c <= chunk] or [min(ok)])
+        return chunk
 
     def _encode(self, inputs, targets):
         """both encoders of forward() (tt/model.py:58-65): -> (enc_state [B,T,d], dec_state [B,U+1,d])"""
