@@ -544,6 +544,65 @@ def greedy_decode(enc_state, length, sd):
     return tokens[1:]
 
 
+def beam_search(enc_state, length, sd, beam_width=5):
+    """tt/model.py:110-179 with its quirks: the frame loop follows the currently most probable hypothesis (a frame on which it predicts blank
+    expands nothing); on an expanding frame every hypothesis contributes its top `beam_width` non-blank symbols (top beam_width + 1, the blank
+    or else the last one dropped); the child token lists are appended to and never re-seeded from their parents; the first expansion fills
+    the children column-wise with the log-probabilities of the last hypothesis scored."""
+    import copy
+    import heapq
+
+    def posterior(tokens, t):
+        dec, _ = decoder_fwd(np.array([tokens]), sd, None)
+        z, _ = joint_fwd(enc_state[t], dec[0, -1], sd)
+        e = np.exp(z - z.max())
+        return e / e.sum()
+
+    def topk(p, k):
+        idx = np.argsort(-p, kind="stable")[:k]                 # torch.topk returns descending values; ties are not expected on real logits
+        return p[idx].tolist(), idx.tolist()
+
+    hyps = [[0] for _ in range(beam_width)]
+    score = np.zeros((beam_width,), dtype=float)
+    child = [[[0] for _ in range(beam_width)] for _ in range(beam_width)]
+    child_score = np.zeros((beam_width, beam_width), dtype=float)
+    first = True
+    for t in range(int(length)):
+        lead = int(score.argmax())
+        if int(np.argmax(posterior(hyps[lead], t))) == 0:
+            continue
+        for k in range(beam_width):
+            values, indices = topk(posterior(hyps[k], t), beam_width + 1)
+            drop = indices.index(0) if 0 in indices else len(indices) - 1
+            indices.pop(drop)
+            values.pop(drop)
+            for i, tok in enumerate(indices):
+                if first:
+                    child[i][k].append(tok)
+                else:
+                    child[k][i].append(tok)
+            if first:
+                child_score[:, k] = np.log(values)
+            else:
+                child_score[k] = score[k] + np.log(values)
+        if first:
+            first = False
+            for i in range(beam_width):
+                hyps[i] = copy.deepcopy(child[i][0])
+                score[i] = child_score[i, 0]
+        else:
+            best = heapq.nlargest(beam_width, range(beam_width ** 2), child_score.take)
+            for i, idx in enumerate(best):
+                score[i] = child_score[idx // beam_width, idx % beam_width]
+                hyps[i] = copy.deepcopy(child[idx // beam_width][idx % beam_width])
+    return hyps[int(score.argmax())][1:]
+
+
+def recognize_beam_search(inputs, lengths, sd, audio_mask=None):
+    enc, _ = encoder_fwd(inputs, sd, audio_mask)
+    return [beam_search(enc[b], lengths[b], sd) for b in range(inputs.shape[0])]
+
+
 def recognize(inputs, lengths, sd, audio_mask=None):
     enc, _ = encoder_fwd(inputs, sd, audio_mask)
     return [greedy_decode(enc[b], lengths[b], sd) for b in range(inputs.shape[0])]

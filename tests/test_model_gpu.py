@@ -341,3 +341,19 @@ def test_sparse_greedy_decode_identical_tokens(name, graphs):
     hyp = model.recognize(torch.tensor(g[name + "/inputs"], device="cuda"), torch.tensor(g[name + "/lens"]))
     for b, h in enumerate(hyp):
         assert h == g["%s/tokens%d" % (name, b)].tolist(), b
+
+
+@pytest.mark.parametrize("name", ["tiny_klong", "tiny_kshort"])
+def test_beam_search_identical_tokens(name):
+    """Transducer.recognize_beam_search (the reference's beam search, tt/model.py:110-198, quirks included) on the HIP model: the token lists
+    of the reference run"""
+    import os
+    from conftest import GOLDEN
+    z, sd = load_golden(name)
+    g = np.load(os.path.join(GOLDEN, "greedy_sparse.npz"))
+    model = build(sd)
+    with torch.no_grad():
+        model.joint.project_layer.bias[0] += float(g[name + "/blank_bias"])
+    hyp = model.recognize_beam_search(torch.tensor(g[name + "/inputs"][:, :48], device="cuda"), torch.tensor(g[name + "/beam_lens"]))
+    for b, h in enumerate(hyp):
+        assert h == g["%s/beam_tokens%d" % (name, b)].tolist(), b

@@ -105,3 +105,18 @@ def test_sparse_greedy_tokens(golden, request):
     for b, h in enumerate(hyp):
         assert h == g["%s/tokens%d" % (name, b)].tolist()
     assert 0 < sum(len(h) for h in hyp) < 0.25 * int(g[name + "/lens"].sum())
+
+
+def test_beam_search_tokens(golden, request):
+    """the reference's recognize_beam_search (tt/model.py:110-198, width 5) on the same nets (tests/golden/greedy_sparse.npz)"""
+    import os
+    from conftest import GOLDEN
+    z, sd = golden
+    name = request.node.callspec.params["golden"]
+    g = np.load(os.path.join(GOLDEN, "greedy_sparse.npz"))
+    sd = dict(sd)
+    sd["joint.project_layer.bias"] = sd["joint.project_layer.bias"].copy()
+    sd["joint.project_layer.bias"][0] += float(g[name + "/blank_bias"])
+    hyp = O.recognize_beam_search(g[name + "/inputs"][:, :48], g[name + "/beam_lens"], sd)
+    for b, h in enumerate(hyp):
+        assert h == g["%s/beam_tokens%d" % (name, b)].tolist(), b

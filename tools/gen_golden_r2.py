@@ -191,6 +191,14 @@ def sparse_greedy_fixture():
         for b, h in enumerate(hyp):
             out["%s/tokens%d" % (name, b)] = np.array(h, dtype=np.int64)
         print(name, "sparse greedy:", [len(h) for h in hyp], "symbols for", lens.tolist(), "frames")
+        # the reference's beam search (tt/model.py:110-198, width 5) on the first 48 / 31 frames of the same inputs
+        blens = torch.tensor([48, 31, 48])
+        with torch.no_grad():
+            beams = model.recognize_beam_search(x[:, :48], blens)
+        out[name + "/beam_lens"] = blens.numpy()
+        for b, h in enumerate(beams):
+            out["%s/beam_tokens%d" % (name, b)] = np.array(h, dtype=np.int64)
+        print(name, "beam search:", [len(h) for h in beams], "symbols")
     np.savez_compressed(os.path.join(OUT, "greedy_sparse.npz"), **out)
 
 
