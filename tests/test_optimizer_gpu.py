@@ -225,3 +225,68 @@ def test_bf16_weight_shadows_are_transparent(monkeypatch):
     b[1].disable_shadows()
     lb2, _ = step(*b, 8, update=False)
     assert torch.equal(lb2, lb)
+
+
+def test_training_loop_as_train_py_drives_it(tmp_path):
+    """the call sequence of the reference's train() and main() (train.py:21-65,196-263) against the overlay, names and arguments as there:
+    Optimizer(model.parameters(), config.optim), optimizer.epoch(), frequency / time masks on the device batch, model(inputs, targets),
+    RNNTLoss()(logits, targets.int(), inputs_length.int(), targets_length.int()), clip_grad_norm_, optimizer.step(), the logging reads
+    (global_step, lr, count_parameters), save_model(model, optimizer, config, path), decay_lr, and a restart in 'continue' mode"""
+    import random
+    from tt.model import Transducer
+    from tt.optim import Optimizer
+    from tt.utils import AttrDict, count_parameters, frequency_mask_augment, save_model, time_mask_augment
+    from warprnnt_pytorch import RNNTLoss
+    config = AttrDict(dict(model=dict(_cfg(0.1)), optim=dict(type="sgd", lr=0.001, momentum=0.9, decay_ratio=0.5, weight_decay=0, begin_to_adjust_lr=0,
+                                                             nesterov=None, step_wise_update=False),
+                           training=dict(num_gpu=1, max_grad_norm=200, epochs=2)))
+    torch.manual_seed(2)
+    model = Transducer(config.model).cuda()
+    n_params, enc, dec = count_parameters(model)
+    assert n_params == enc + dec + sum(p.numel() for p in model.joint.parameters())
+    optimizer = Optimizer(model.parameters(), config.optim)
+    criterion = RNNTLoss()
+    g = torch.Generator().manual_seed(0)
+    data = [(torch.randn(3, 24, 64, generator=g), torch.tensor([24, 20, 24]), torch.randint(1, 29, (3, 6), generator=g), torch.tensor([6, 6, 4]))
+            for _ in range(3)]
+    np.random.seed(0)
+    random.seed(0)
+    losses = []
+    for epoch in range(2):
+        model.train()
+        optimizer.epoch()
+        for inputs, inputs_length, targets, targets_length in data:
+            max_in, max_tg = inputs_length.max(), targets_length.max()
+            inputs, targets = inputs[:, :max_in, :], targets[:, :max_tg]
+            inputs, inputs_length = inputs.cuda(), inputs_length.cuda()
+            targets, targets_length = targets.cuda(), targets_length.cuda()
+            inputs = time_mask_augment(frequency_mask_augment(inputs, max_mask_frequency=5, mask_num=10), max_mask_time=5, mask_num=10)
+            optimizer.zero_grad()
+            logits = model(inputs, targets)
+            loss = criterion(logits, targets.int(), inputs_length.int(), targets_length.int())
+            loss.backward()
+            losses.append(float(loss))
+            grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), config.training.max_grad_norm)
+            optimizer.step()
+            assert np.isfinite(grad_norm.item()) and loss.shape == (1,)
+        save_name = str(tmp_path / ("m.epoch%d.chkpt" % epoch))
+        save_model(model, optimizer, config, save_name)
+        if epoch >= config.optim.begin_to_adjust_lr:
+            optimizer.decay_lr()
+    assert optimizer.global_step == 7 and optimizer.current_epoch == 2 and abs(optimizer.lr - 0.00025) < 1e-12
+    assert all(np.isfinite(losses))
+    # restart: train.py:196-200,234-241
+    checkpoint = torch.load(str(tmp_path / "m.epoch1.chkpt"))
+    model2 = Transducer(config.model)
+    model2.encoder.load_state_dict(checkpoint["encoder"])
+    model2.decoder.load_state_dict(checkpoint["decoder"])
+    model2.joint.load_state_dict(checkpoint["joint"])
+    model2 = model2.cuda()
+    optimizer2 = Optimizer(model2.parameters(), config.optim)
+    optimizer2.load_state_dict(checkpoint["optimizer"])
+    optimizer2.global_step, optimizer2.current_epoch = checkpoint["step"], checkpoint["epoch"]
+    assert optimizer2.global_step == 7 and optimizer2.current_epoch == 2
+    for a, b in zip(model.parameters(), model2.parameters()):
+        assert torch.equal(a, b)
+    for a, b in zip(optimizer._views(optimizer.state[0]), optimizer2._views(optimizer2.state[0])):
+        assert torch.equal(a, b)

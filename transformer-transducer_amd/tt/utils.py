@@ -155,5 +155,9 @@ def save_model(model, optimizer, config, save_name):
 
 
 def count_parameters(model):
-    total = sum(p.numel() for p in model.parameters())
-    return total, {n: p.numel() for n, p in model.named_parameters()}
+    """(total, audio-encoder, label-encoder) parameter counts as train.py:221-228 unpacks them (tt/utils.py:57-66: names containing
+    'encoder' / 'decoder')"""
+    n_params = sum(p.nelement() for p in model.parameters())
+    enc = sum(p.nelement() for n, p in model.named_parameters() if "encoder" in n)
+    dec = sum(p.nelement() for n, p in model.named_parameters() if "decoder" in n and "encoder" not in n)
+    return n_params, enc, dec
