@@ -164,6 +164,10 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # the collective's workgroups run beside backward on the CUs the encoder-sized persistent GEMMs leave free (ops.reserve_cus(32) below):
+        # keep RCCL's channel count within that reservation unless the caller chose otherwise
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
