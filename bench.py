@@ -87,6 +87,14 @@ def cpu_baseline(model, feats, proj, targets, T, U, n_utt, gpu_costs, reps):
     return n_utt / dt, dt, rel, times
 
 
+def pmc_form(path):
+    """the loss form the committed PMC passes were taken with (tools/update_pmc_json.py)"""
+    try:
+        return json.load(open(path)).get("loss_form", "two-call")
+    except (OSError, ValueError):
+        return None
+
+
 def _sha16(path):
     import hashlib
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
@@ -147,8 +155,11 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "decode"],
                     help="train = the metric (default); decode = greedy decode of the C2 model (SURVEY §8 A10) with the oracle's loop beside it")
     ap.add_argument("--no-weight-shadows", action="store_true", help="convert the f32 master weights to bf16 in every call (round-1 behaviour; A/B)")
-    ap.add_argument("--fused-loss", action="store_true",
-                    help="Transducer.loss(...) (joint + RNN-T loss in chunks, logits never materialised; SURVEY 8f-1) instead of model() + RNNTLoss()")
+    ap.add_argument("--loss-form", default="auto", choices=["auto", "exp", "fused", "two-call"],
+                    help="how the step gets its loss.  two-call: train.py:51-53 as written (logits = model(inputs, targets); criterion(logits, ...)). "
+                         "fused: Transducer.loss, chunked, the same kernels without holding the logits (memory form).  exp: Transducer.loss(exp_domain=True), "
+                         "the projection stores exp(logit - shift) + row sums and the loss never walks the lattice's rows (speed form; bf16 only).  "
+                         "auto = exp in bf16 train mode, two-call otherwise.  Whatever runs first, the JSON line also carries the two-call form's timing.")
     ap.add_argument("--loss-chunk", type=int, default=0, help="utterances per chunk of the fused loss (0 = default: logits chunk <= 2 GB)")
     ap.add_argument("--emit-rate", type=float, default=0.1, help="decode mode: fraction of frames that emit a symbol (blank bias is set for it)")
     args = ap.parse_args()
@@ -207,6 +218,10 @@ def main():
         if kv:
             ops.set_option(int(kv.split(":")[0]), int(kv.split(":")[1]))
 
+    form = args.loss_form
+    if form == "auto":
+        form = "exp" if args.precision == "bf16" else "two-call"
+
     def step(timed, i=0):
         # harness front-end: fixed 80 -> d_model projection (the reference encoder has no input layer)
         ops.gemm(feats, proj, inputs, B * T, d, 80, 80, d, d, gflags)
@@ -214,8 +229,8 @@ def main():
         sync.start_step()
         if timed and rank == 0:
             ops.probe_arm(i % 64)                     # this step's joint-projection launch records into event pair i
-        if args.fused_loss:
-            loss = model.loss(inputs, ilen, targets, tlen, chunk=args.loss_chunk or None)
+        if form != "two-call":
+            loss = model.loss(inputs, ilen, targets, tlen, chunk=args.loss_chunk or None, exp_domain=form == "exp")
         else:
             logits = model(inputs, targets)
             loss = criterion(logits, targets.int(), ilen, tlen)
@@ -249,16 +264,29 @@ def main():
         loss_ms = [(ops.probe_read_ms(i, 1), ops.probe_read_ms(i, 2)) for i in slots]
         attn_ms = [ops.probe_read_ms(i, 3) for i in slots]
         wgrad_ms = [ops.probe_read_ms(i, 4) for i in slots]
+    two_call = None
+    if form != "two-call" and args.mode == "train":
+        # the reference's own call sequence beside the fused form, same model / data / optimizer state, same barrier + synchronize bracket
+        main_form, form = form, "two-call"
+        for _ in range(max(1, args.warmup)):
+            step(False)
+        fence()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(False)
+        fence()
+        two_call = time.perf_counter() - t1
+        form = main_form
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, two_call or 0.0], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+        elapsed, two_call = float(t[0]), (float(t[1]) if two_call is not None else None)
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         utt_s = world * B * args.steps / elapsed
         U1, J = U + 1, cfg["joint"]["inner_size"]
-        B_launch = B if not args.fused_loss else (args.loss_chunk or model.default_loss_chunk(B, T, U1))      # utterances per joint-projection launch
+        B_launch = B if form == "two-call" else (args.loss_chunk or model.default_loss_chunk(B, T, U1, form == "exp"))      # utterances per joint-projection launch
         flop_launch = 2.0 * B_launch * T * U1 * J * V                            # one joint-projection launch
         k_ms = float(np.mean([m for m in probe_ms if m > 0])) if probe_ms else float("nan")
         peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
@@ -267,7 +295,7 @@ def main():
         mfma_busy = None
         pmc = os.path.join(ROOT, "profiles", "pmc_joint_projection.json")
         pmc_build = None
-        if os.path.exists(pmc) and args.workload == "c2" and (B, T, U) == (32, 500, 50) and args.precision == "bf16" and not args.fused_loss:
+        if os.path.exists(pmc) and args.workload == "c2" and (B, T, U) == (32, 500, 50) and args.precision == "bf16" and form == pmc_form(pmc):
             j = json.load(open(pmc))
             # the counters come from separate rocprofv3 --pmc passes (profiles/): valid only for the kernel source they were measured on
             src = os.path.join(ROOT, "transformer-transducer_amd", "csrc", "gemm_fast.hip")
@@ -279,11 +307,12 @@ def main():
                 pmc_build["stale"] = "csrc/gemm_fast.hip changed since the PMC passes: traffic / mfma_busy withheld"
         # the RNN-T loss op at the API boundary: logits read once, gradient written once, alpha / beta / lp_blank / lp_label in f32
         es = 2 if args.precision == "bf16" else 4
-        loss_bytes = B * (2.0 * es * T * U1 * V + 16.0 * T * U1)
+        loss_bytes = B_launch * (2.0 * es * T * U1 * V + 16.0 * T * U1)
         lf = float(np.mean([a for a, b in loss_ms if a > 0 and b > 0])) if loss_ms else float("nan")
         lb = float(np.mean([b for a, b in loss_ms if a > 0 and b > 0])) if loss_ms else float("nan")
         loss_gbs = loss_bytes / ((lf + lb) * 1e-3) / 1e9
-        roof_joint = {"bound": "mfma", "kernel": "gemm_nt_bf16_v8_kernel (joint vocabulary projection, M=%d N=%d K=%d)" % (B_launch * T * U1, V, J),
+        roof_joint = {"bound": "mfma", "kernel": "gemm_nt_bf16_v8_kernel (joint vocabulary projection%s, M=%d N=%d K=%d)"
+                                                 % (", exp-store epilogue" if form == "exp" else "", B_launch * T * U1, V, J),
                       "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                       "traffic": traffic, "mfma_busy": mfma_busy, "kernel_ms": round(k_ms, 4), "pmc": pmc_build}
         # the two weakest kernels of the step, on the record every round
@@ -304,10 +333,23 @@ def main():
         roof_wgrad = {"bound": "mfma", "kernel": "qkv_net weight gradient, one audio layer (M=%d N=%d K=%d, f32 atomics across K ranges)" % (3 * H * Dh, dm, B * T),
                       "achieved": round(wg_flops / (w_ms * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
                       "frac": round(wg_flops / (w_ms * 1e-3) / 1e12 / peak, 4), "traffic": None, "kernel_ms": round(w_ms, 4)}
-        roof_loss = {"bound": "hbm", "kernel": "RNN-T loss op: rnnt_lse_kernel + rnnt_alphabeta_kernel (%.3f ms) + rnnt_grad_kernel (%.3f ms), "
-                                               "logits [%d,%d,%d,%d] %s" % (lf, lb, B, T, U1, V, "bf16" if es == 2 else "f32"),
-                     "achieved": round(loss_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(loss_gbs / HBM_PEAK_GBS, 4),
-                     "traffic": None, "kernel_ms": round(lf + lb, 4)}
+        if form == "exp":
+            # exp-domain form: no pass over the lattice's rows is left - the forward reads the row-sum partials and two entries per row, the
+            # backward writes a factor per row and patches two entries; what remains is the alpha / beta recursion (a serial chain per utterance)
+            nparts = 4 * ((V + 255) // 256)
+            loss_bytes = B_launch * T * U1 * (4.0 * nparts + 2 * 2 + 4 * 4 + 2 * 8 + 2 * 8 + 4 + 2 + 2 * 2 * 2)
+            loss_gbs = loss_bytes / ((lf + lb) * 1e-3) / 1e9
+            roof_loss = {"bound": "hbm", "kernel": "RNN-T loss op, exp-domain form: rnnt_prep_exp_kernel + rnnt_alphabeta_kernel (%.3f ms) + rnnt_scale_exp_kernel "
+                                                   "(%.3f ms), P = exp(logits - shift) [%d,%d,%d,%d] bf16 touched at 2 entries per row" % (lf, lb, B_launch, T, U1, V),
+                         "achieved": round(loss_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(loss_gbs / HBM_PEAK_GBS, 4),
+                         "traffic": None, "kernel_ms": round(lf + lb, 4),
+                         "note": "latency-bound by the lattice recursion (T+U serial steps per utterance, one wave each); the two-call form's loss op moves "
+                                 "%.1f GB per step through rnnt_lse_kernel / rnnt_grad_kernel instead" % (B * (2.0 * es * T * U1 * V) / 1e9)}
+        else:
+            roof_loss = {"bound": "hbm", "kernel": "RNN-T loss op: rnnt_lse_kernel + rnnt_alphabeta_kernel (%.3f ms) + rnnt_grad_kernel (%.3f ms), "
+                                                   "logits [%d,%d,%d,%d] %s" % (lf, lb, B_launch, T, U1, V, "bf16" if es == 2 else "f32"),
+                         "achieved": round(loss_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(loss_gbs / HBM_PEAK_GBS, 4),
+                         "traffic": None, "kernel_ms": round(lf + lb, 4)}
         lattice_run = args.workload == "c5"             # BASELINE configs[4] is the lattice's HBM-roofline run: the loss op is its dominant-kernel line
         out = {
             "metric": "utterances/sec (fwd+bwd) on 80-d fbank T=%d U=%d" % (T, U), "value": round(utt_s, 3), "unit": "utt/s",
@@ -326,8 +368,12 @@ def main():
             "roofline_attn": roof_attn, "roofline_wgrad": roof_wgrad,
             "final_loss": round(float(last.detach()), 4),
         }
-        if args.fused_loss:
-            out["config"]["loss"] = "fused joint + loss (Transducer.loss), chunk %s" % (args.loss_chunk or "default")
+        out["config"]["loss"] = {"two-call": "logits = model(inputs, targets); RNNTLoss()(logits, ...) as in train.py:51-53",
+                                 "fused": "Transducer.loss (fused joint + loss, memory form), %d utterances per chunk" % B_launch,
+                                 "exp": "Transducer.loss(exp_domain=True) (fused joint + loss, exp-domain form), %d utterances per chunk" % B_launch}[form]
+        if two_call is not None:
+            out["two_call_form"] = {"ms_per_step": round(1e3 * two_call / args.steps, 3), "value": round(world * B * args.steps / two_call, 3), "unit": "utt/s",
+                                    "note": "the same %d steps with train.py's own call sequence (model(inputs, targets) + RNNTLoss), timed right after the main region" % args.steps}
         if world == 1 and not args.no_cpu_baseline:
             model.eval()
             with torch.no_grad():

@@ -104,6 +104,30 @@ int ttmi_rnnt_loss_bwd(const void* logits, int dtype, long ldv, const int* label
                        int B, int T, int U1, int V, int blank, const void* workspace, const float* grad_out,
                        int grad_out_stride, float scale, void* grad, long ldg, void* stream);
 
+/* ---- fused joint + loss fast path ("exp-domain" forms; training-sized bf16 problems, ask ttmi_joint_exp_supported first) --------
+ * Replaces the pair JointNet.forward + RNNTLoss (train.py:47-53) when the caller wants the loss only.  The projection GEMM's epilogue
+ * stores P[row, v] = bf16(exp(logit - *shift)) (pitch ldv, a multiple of 64, zeros in columns [V, ldv)) and per-row partial sums of the
+ * unrounded values (rowsum f32 [nparts, rows], nparts = ttmi_joint_exp_nparts(V)); the loss forward then reads the sums and two entries
+ * per row instead of walking the lattice's rows; the loss backward writes per-row factors srow (f32) / srow16 (bf16) and patches the
+ * blank / label entries of P so that d logits[r, :] = srow[r] * P[r, :]; ttmi_joint_bwd_exp consumes that product without forming it
+ * (row factor in the dgrad epilogue and on the wgrad's activation operand; ctx is overwritten).
+ * shift / shift_cur: device scalar (nullable = 0) subtracted before exp; shift_next (device scalar, nullable):
+ * max(itself, max_rows(log-sum-exp) - 40), the value to pass as shift on the next step. */
+int ttmi_joint_exp_supported(int B, int T, int U1, int J, int V, int prec, long ldv);
+int ttmi_joint_exp_nparts(int V);
+int ttmi_joint_fwd_exp(const float* enc, const float* dec, const float* wf, const float* bf, const float* wp, const float* bp,
+                       int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx, float* ws, void* P, long ldv,
+                       float* rowsum, int nparts, const float* shift, void* stream);
+int ttmi_rnnt_loss_fwd_exp(const void* P, long ldv, const float* rowsum, int nparts, const int* labels, const int* act_lens,
+                           const int* label_lens, int B, int T, int U1, int V, int blank, void* workspace, float* costs,
+                           const float* shift_cur, float* shift_next, void* stream);
+int ttmi_rnnt_loss_bwd_exp(void* P, long ldv, const int* labels, const int* act_lens, const int* label_lens, int B, int T, int U1,
+                           int V, int blank, const void* workspace, const float* grad_out, int grad_out_stride, float scale,
+                           float* srow, void* srow16, void* stream);
+int ttmi_joint_bwd_exp(const void* P, long ldg, const float* srow, const void* srow16, const float* enc, const float* dec,
+                       const float* wf, const float* wp, int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx,
+                       float* ws, float* denc, float* ddec, float* g_wf, float* g_bf, float* g_wp, float* g_bp, void* stream);
+
 /* ---- greedy decoding support (Transducer.decode, tt/model.py:70-90): logits rows = consecutive frames against one label
  * state; *out (device u64) = (first row whose argmax != blank) << 32 | symbol, or n << 32 if all rows are blank. */
 int ttmi_greedy_scan(const void* logits, int dtype, long ld, int n, int V, int blank, unsigned long long* out, void* stream);
@@ -146,6 +170,10 @@ int ttmi_gemm(const void* A, const void* B, void* C, const float* bias, const fl
               long sB1, long sB2, long sC1, long sC2, float alpha, float beta, int flags, int splitk, void* stream);
 int ttmi_gemm_nt_bf16(const void* A, const void* B, void* C, int c_dtype, const float* bias, int M, int N, int K, long lda,
                       long ldb, long ldc, void* stream);
+/* bring-up entry of the "exp store" epilogue of the persistent 256x256 kernel: C = bf16(exp(A.B^T + bias - shift)) with zeros in columns [N, ldc),
+ * rowsum [nparts, M] = per-row partial sums (nparts >= 4 * ceil(N / 256); the entries of a row add up to its sum of exponentials) */
+int ttmi_gemm_nt_bf16_exp(const void* A, const void* B, void* C, const float* bias, float* rowsum, int nparts, const float* shift /* device, nullable */, int M, int N, int K,
+                          long lda, long ldb, long ldc, void* stream);
 int ttmi_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
                       float* colsum_a /* nullable: colsum_a[m] += sum_k A[k][m] */, void* stream);
 /* bf16 shadows of GEMM weights.  Every forward call otherwise converts its f32 master weights to bf16 (plain + transposed copies: 118

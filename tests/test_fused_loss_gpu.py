@@ -116,3 +116,80 @@ def test_flat_model_gradients_and_memory(monkeypatch):
     logits_bytes = B * T * (U + 1) * 4352 * 2
     print("peak above baseline: two-call %.0f MB, fused %.0f MB (logits %.0f MB)" % (out[0][2] / 2 ** 20, out[1][2] / 2 ** 20, logits_bytes / 2 ** 20))
     assert out[0][2] - out[1][2] > 1.2 * logits_bytes        # logits + gradient gone, a chunk's worth (1/4) of one buffer remains
+
+
+def _training_sized(monkeypatch, prec):
+    from tt.model import Transducer
+    from tt.utils import AttrDict
+    monkeypatch.setenv("TTMI_PRECISION", prec)
+    side = dict(n_layer=1, d_model=512, n_head=8, d_head=64, d_inner=256)
+    cfg = AttrDict(dict(enc=dict(side, max_input_length=64), dec=dict(side, max_target_length=16),
+                        joint=dict(input_size=1024, inner_size=1024), vocab_size=4334, dropout=0.0))
+    torch.manual_seed(2)
+    model = Transducer(cfg).cuda().train()
+    B, T, U = 8, 200, 20
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(B, T, 512, device="cuda", generator=g)
+    y = torch.randint(1, 4334, (B, U), device="cuda", generator=g)
+    al = torch.full((B,), T, dtype=torch.int32, device="cuda")
+    ll = torch.full((B,), U, dtype=torch.int32, device="cuda")
+    al[2], ll[2] = 150, 11
+    y[5, 3] = 0                                              # a label equal to the blank symbol: both emission terms land on one entry
+    return model, x, y, al, ll
+
+
+def _run(model, x, y, al, ll, **kw):
+    model.zero_grad()
+    xi = x.clone().requires_grad_(True)
+    loss = model.loss(xi, al, y, ll, check_lengths=False, **kw)
+    loss.backward()
+    return float(loss.detach()), torch.cat([xi.grad.reshape(-1)] + [p.grad.reshape(-1) for p in model.parameters()]).cpu().numpy(), \
+        {n: p.grad.cpu().numpy() for n, p in model.named_parameters()}
+
+
+def test_exp_domain_fast_path(monkeypatch):
+    """B=8, T=200, U=20, J=1024, V=4334 in one chunk (33600 lattice rows: the persistent kernels' sizes).  The exp-domain form must be as
+    close to the fp32 pipeline as the plain bf16 form is: both are measured against fp32 and printed."""
+    import ttmi.ops as ops
+    model, x, y, al, ll = _training_sized(monkeypatch, "fp32")
+    ref = _run(model, x, y, al, ll, chunk=8)
+    monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    plain = _run(model, x, y, al, ll, chunk=8)
+    calls = []
+    orig = ops.joint_fwd_exp
+    monkeypatch.setattr(ops, "joint_fwd_exp", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    fast = _run(model, x, y, al, ll, chunk=8, exp_domain=True)
+    assert calls, "the exp-domain kernels did not run"
+    e_plain, e_fast = rel_err(plain[1], ref[1]), rel_err(fast[1], ref[1])
+    print("loss fp32 %.4f  bf16 %.4f  exp-domain %.4f;  gradient error vs fp32: bf16 %.2e, exp-domain %.2e" % (ref[0], plain[0], fast[0], e_plain, e_fast))
+    assert abs(fast[0] - ref[0]) < 2e-4 * ref[0] and abs(plain[0] - ref[0]) < 2e-4 * ref[0]
+    assert e_fast < max(1.5 * e_plain, 5e-3)
+    for n in ref[2]:
+        assert rel_err(fast[2][n], ref[2][n]) < max(2 * rel_err(plain[2][n], ref[2][n]), 5e-3), n
+    # small chunks are outside the fast path: silently the plain form, same numbers as without the switch
+    small = _run(model, x, y, al, ll, chunk=2, exp_domain=True)
+    base = _run(model, x, y, al, ll, chunk=2)
+    assert small[0] == base[0]
+
+
+def test_exp_domain_shift(monkeypatch):
+    """the subtracted shift cancels: any value gives the same loss; large logits raise the value gathered for the next step"""
+    import ttmi.ops as ops
+    from tt.model import _JointLossFn
+    model, x, y, al, ll = _training_sized(monkeypatch, "bf16")
+    _JointLossFn._shift.clear()
+    a = _run(model, x, y, al, ll, chunk=8, exp_domain=True)
+    cur, nxt = _JointLossFn._shift[x.device]
+    assert float(cur) == 0.0 and float(nxt) == 0.0            # logits of a fresh model are far below the margin
+    cur.fill_(7.5)
+    b = _run(model, x, y, al, ll, chunk=8, exp_domain=True)
+    assert abs(a[0] - b[0]) < 1e-4 * a[0] and rel_err(b[1], a[1]) < 5e-3
+    with torch.no_grad():
+        model.joint.project_layer.bias[17] += 70.0            # one huge logit in every row: log-sum-exp ~ 70
+    _JointLossFn._shift.clear()
+    _run(model, x, y, al, ll, chunk=8, exp_domain=True)
+    cur, nxt = _JointLossFn._shift[x.device]
+    assert 25.0 < float(cur) < 35.0 and float(nxt) == 0.0     # ~70 - 40, handed to the next step
+    c = _run(model, x, y, al, ll, chunk=8, exp_domain=True)
+    d = _run(model, x, y, al, ll, chunk=8)
+    assert np.isfinite(c[0]) and abs(c[0] - d[0]) < 2e-4 * d[0]

@@ -9,18 +9,22 @@ OUT=gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT profiles
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/trace.log 2>&1
 python3 tools/prof_summary.py $OUT/trace profiles/${TAG}_bench_kernel_stats.csv "bench.py --steps 4 --warmup 2 (6 steps), C2, $TAG build $COMMIT" > /dev/null
-python3 tools/kernel_exclusive.py $OUT/trace > profiles/${TAG}_bench_step_attribution.txt
+# bench.py times its default (exp-domain) loss form for 2 + 4 steps, then the two-call form for 1 + 4: step 6 from the end is the last exp-domain step
+python3 tools/kernel_exclusive.py $OUT/trace 6 > profiles/${TAG}_bench_step_attribution.txt
+echo "" >> profiles/${TAG}_bench_step_attribution.txt
+echo "# the two-call form (model(inputs, targets) + RNNTLoss), last step of the same run" >> profiles/${TAG}_bench_step_attribution.txt
+python3 tools/kernel_exclusive.py $OUT/trace 1 >> profiles/${TAG}_bench_step_attribution.txt
 python3 tools/gpu_busy.py $OUT/trace >> profiles/${TAG}_bench_step_attribution.txt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/sq.log 2>&1
 F=profiles/${TAG}_pmc_joint_kernels.txt
 echo "# rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline ($TAG build $COMMIT; three separate passes; per-launch values, KB as reported)" > $F
-for k in "gemm_nt_bf16_v8_kernel<unsigned short, 1>" "gemm_nt_bf16_v8_kernel<unsigned short, 2>" "gemm_tn_bf16_v8_kernel" "rnnt_lse_kernel" "rnnt_grad_kernel" "flash_bwd_rel_kernel<64, 0>" "flash_fwd_rel_kernel<64, 0>"; do
+for k in "gemm_nt_bf16_v8_kernel<unsigned short, 3>" "gemm_nt_bf16_v8_kernel<unsigned short, 4>" "gemm_tn_bf16_v8_kernel<2>" "rnnt_prep_exp_kernel" "rnnt_scale_exp_kernel" "gemm_nt_bf16_v8_kernel<unsigned short, 1>" "gemm_tn_bf16_v8_kernel<1>" "rnnt_lse_kernel" "rnnt_grad_kernel" "flash_bwd_rel_kernel<64, 0>" "flash_fwd_rel_kernel<64, 0>"; do
   python3 tools/pmc_summary.py $OUT/fetch FETCH "$k" | sort | awk 'NR%4==1' >> $F
   python3 tools/pmc_summary.py $OUT/write WRITE "$k" | sort | awk 'NR%4==1' >> $F
 done
-python3 tools/pmc_summary.py $OUT/sq SQ "gemm_nt_bf16_v8_kernel<unsigned short, 1>" "gemm_tn_bf16_v8_kernel" | sort >> $F
+python3 tools/pmc_summary.py $OUT/sq SQ "gemm_nt_bf16_v8_kernel<unsigned short, 3>" "gemm_nt_bf16_v8_kernel<unsigned short, 4>" "gemm_tn_bf16_v8_kernel<2>" "gemm_nt_bf16_v8_kernel<unsigned short, 1>" "gemm_tn_bf16_v8_kernel<1>" | sort >> $F
 python3 tools/update_pmc_json.py $OUT/fetch $OUT/write $OUT/sq $COMMIT $TAG > $OUT/pmc_json.log
 cp profiles/${TAG}_* profiles/pmc_joint_projection.json gpurun_out/ 2>/dev/null || true
 tail -3 $OUT/pmc_json.log

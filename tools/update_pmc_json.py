@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Rebuild profiles/pmc_joint_projection.json from the three rocprofv3 --pmc passes of tools/profile_round.sh (GPU box).
-usage: update_pmc_json.py <fetch dir> <write dir> <sq dir> <commit> <round tag>"""
+usage: update_pmc_json.py <fetch dir> <write dir> <sq dir> <commit> <round tag> [loss form: exp (default) | two-call]"""
 import csv
 import glob
 import hashlib
@@ -9,7 +9,10 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "gemm_nt_bf16_v8_kernel<unsigned short, 1>"
+FORM = sys.argv[6] if len(sys.argv) > 6 else "exp"
+# the projection launch of the default bench.py step: exp-store epilogue (LEAN 3) in the exp-domain loss form, bias epilogue (LEAN 1) otherwise
+KERNEL = "gemm_nt_bf16_v8_kernel<unsigned short, 3>" if FORM == "exp" else "gemm_nt_bf16_v8_kernel<unsigned short, 1>"
+NPARTS = 4 * ((4334 + 255) // 256)
 
 
 def values(d, counter):
@@ -30,11 +33,12 @@ j = {
     "source": "profiles/%s_pmc_joint_kernels.txt: rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE and the SQ / GRBM counters in three separate passes of "
               "the same bench.py command (tools/profile_round.sh); means over %d / %d launches" % (sys.argv[5], len(fetch), len(write)),
     "commit": sys.argv[4],
+    "loss_form": FORM,
     "gemm_fast_sha16": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16],
     "fetch_size_kb": mean(fetch), "write_size_kb": mean(write),
     "correction": "gfx950 FETCH_SIZE reads 1/2 of wide (16 B/lane) streaming reads incl. global_load ... lds (MI355X_MICROARCH.md, HBM): traffic = "
                   "2*FETCH + WRITE; FETCH counts L2 misses served by the Infinity Cache too (re-read A panels)",
-    "algorithmic_bytes": 816000.0 * 1024 * 2 + 4334.0 * 1024 * 2 + 816000.0 * 4352 * 2,
+    "algorithmic_bytes": 816000.0 * 1024 * 2 + 4334.0 * 1024 * 2 + 816000.0 * 4352 * 2 + (816000.0 * NPARTS * 4 if FORM == "exp" else 0.0),
     "mfma_busy": round(mean(busy) / (mean(gui) / 8.0 * 1024.0), 3),
     "mfma_busy_source": "SQ_VALU_MFMA_BUSY_CYCLES %.4e / (GRBM_GUI_ACTIVE %.4e / 8 XCDs * 1024 SIMDs)" % (mean(busy), mean(gui)),
 }

@@ -26,6 +26,12 @@ struct NtEpilogue {
     int K2 = 0;
     long lda2 = 0, ldb2 = 0, sB1b = 0, sB2b = 0;
     float* colsum_mid = nullptr;
+    // persistent 256x256 kernel only: "exp store" - C = bf16(exp(acc + bias - exp_shift)) with zeros in columns [N, ldc) and per-row partial
+    // sums rowsum[m * nparts + part] (part < 4 * ceil(N / 256)); rowscale: per-row factor applied together with the tanh' mask; the mask operand is rewritten in place as rowscale[m] * mask
+    float* rowsum = nullptr;
+    int nparts = 0;
+    const float* exp_shift = nullptr;   // device scalar, nullable = 0
+    const float* rowscale = nullptr;
 };
 // C[M,N] = epilogue(A[M,K] . B[N,K]^T); c_dtype 0 = f32, 1 = bf16
 int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const NtEpilogue& epi, int M, int N, int K, long lda,
@@ -39,8 +45,10 @@ inline int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, 
 // C[M,N] (f32) (+)= A[K,M]^T . B[K,N]; with accumulate != 0 (or internal split-K) the result is ADDED atomically to C
 // colsum_a (nullable, f32 [M], accumulated atomically): column sums of A over K - the bias gradient that belongs to this wgrad -
 // taken from the LDS tiles the kernel stages anyway (no extra pass over A)
+// colsum_w (nullable, bf16 [K], 16-byte aligned; persistent 256x256 kernel only): the column sums become sum_k colsum_w[k] A[k][m]
 int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
-                 hipStream_t st, float* colsum_a = nullptr, const FastBatch& batch = FastBatch());
+                 hipStream_t st, float* colsum_a = nullptr, const FastBatch& batch = FastBatch(), const bf16_t* colsum_w = nullptr);
+bool gemm_fast_joint_exp_ok(int M, int V, int J, long ldv);   // sizes at which the exp-store / row-scale / weighted-colsum forms exist
 void gemm_fast_set_version(int v);   // kernel generation for A/B runs, see gemm_fast.hip (default 4)
 void gemm_fast_set_tn_target(int n);
 void gemm_fast_set_reserved_cus(int n);   // process-wide default (measurement switch)

@@ -58,6 +58,14 @@ struct FP {
     int K2;
     long lda2, ldb2, sB1b, sB2b;
     float* colsum_mid;                      // column sums of the FIRST product (rows < M), atomically added; batch strides sV1 / sV2
+    // v8 NT, LEAN 3 ("exp store"): C = bf16(exp(acc + bias - exp_shift)), zeros in columns [N, ldc); rowsum[(tile_n * 4 + wave column) * M + m] =
+    // sum of the row's 64 stored-before-rounding values of that wave (the caller adds the nparts partials of a row)
+    float* rowsum;
+    int nparts;
+    const float* exp_shift;                 // device scalar (nullable = 0): chosen by the caller without a host round trip
+    // v8 NT, LEAN 4: tanh' mask (mask_mode 1) and a per-row factor rowscale[m] on the result; v8 TN: colsum weighted by csw[k] (bf16) instead of ones
+    const float* rowscale;
+    const bf16_t* csw;
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
@@ -303,6 +311,12 @@ __device__ __forceinline__ bf16x4 ds_read_tr16(const char* lds_addr) {
     s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_addr);
     return __builtin_bit_cast(bf16x4, v);
 }
+// The same read as asm.  In front of every ds_read_tr INTRINSIC the compiler puts s_waitcnt vmcnt(0) while LDS-DMA loads are in flight
+// (it cannot tell their destination from the buffer being read), which drains a multi-tile prefetch at the top of every K-tile.  The
+// pipelined kernels order LDS traffic themselves (counted vmcnt + barrier per tile), so they issue the read opaquely; the consumer
+// must sit behind an explicit s_waitcnt lgkmcnt (LDS_TR_WAIT) - the compiler does not know these results are in flight.
+#define LDS_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define LDS_TR_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 template <int NBUF, bool CS>
 __global__ __launch_bounds__(NTH, NBUF == 1 ? 4 : 2) void gemm_tn_bf16_kernel(const FP p_) {
@@ -725,6 +739,7 @@ constexpr int LDS8 = 2 * BUF8 + 8 * 4096;
 // costs the main loop registers in the general instance
 template <typename TC, int LEAN = 0>
 __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
+    constexpr bool MASKED = LEAN == 2 || LEAN == 4;       // epilogues that read the mask operand (same layout as the output)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -891,6 +906,14 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
             const float4 b0 = *reinterpret_cast<const float4*>(p.bias + ln0), b1 = *reinterpret_cast<const float4*>(p.bias + ln0 + 4);
             lb[0] = b0.x; lb[1] = b0.y; lb[2] = b0.z; lb[3] = b0.w; lb[4] = b1.x; lb[5] = b1.y; lb[6] = b1.z; lb[7] = b1.w;
         }
+        float lb3[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float eshift2 = (LEAN == 3 && p.exp_shift ? *p.exp_shift : 0.f) * 1.4426950408889634f;
+        if constexpr (LEAN == 3) {
+            if (p.bias) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) lb3[j] = ln0 + j < p.N ? p.bias[ln0 + j] : 0.f;
+            }
+        }
         const int lm0 = cbm + wr * 128 + (lane >> 3);
         bf16_t* lrow0 = reinterpret_cast<bf16_t*>(p.C) + (long)lm0 * p.ldc + ln0;
         // LEAN 2: the mask vectors of slab mi + 1 are requested before slab mi goes through its LDS transposes and stores
@@ -901,10 +924,10 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
             for (int q = 0; q < 2; ++q)
                 if (lfull && lm0 + mi * 16 + q * 8 < p.M) dst[q] = *reinterpret_cast<const u32x4*>(lmask0 + (long)(mi * 16 + q * 8) * p.ldc);
         };
-        if constexpr (LEAN == 2) mask_fetch(0, mkc);
+        if constexpr (MASKED) mask_fetch(0, mkc);
 #pragma unroll 1
         for (int mi = 0; mi < 8; ++mi) {
-            if constexpr (LEAN == 2) { if (mi + 1 < 8) mask_fetch(mi + 1, mkn); }
+            if constexpr (MASKED) { if (mi + 1 < 8) mask_fetch(mi + 1, mkn); }
             switch (mi) { V8_SLAB(0) V8_SLAB(1) V8_SLAB(2) V8_SLAB(3) V8_SLAB(4) V8_SLAB(5) V8_SLAB(6) V8_SLAB(7) }
             if (LEAN || (sizeof(TC) == 2 && plain8)) {
                 // bf16 output: 8 columns per lane, one 16-byte store - 8 rows x 128 B per instruction
@@ -914,7 +937,34 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                     const int c8 = lane & 7;
                     const f32x4 x0 = *reinterpret_cast<const f32x4*>(img + r * 256 + (((2 * c8) ^ r) << 4));
                     const f32x4 x1 = *reinterpret_cast<const f32x4*>(img + r * 256 + (((2 * c8 + 1) ^ r) << 4));
-                    if constexpr (LEAN) {
+                    if constexpr (LEAN == 3) {
+                        // exp store: every lane of the wave takes part (the row sum is a shuffle over the 8 lanes that share a row)
+                        const int m = lm0 + mi * 16 + q * 8;
+                        const float xs[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                        float e[8], rs = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float z = xs[j] + lb3[j];
+                            e[j] = (ln0 + j < p.N) ? __builtin_amdgcn_exp2f(z * 1.4426950408889634f - eshift2) : 0.f;
+                            rs += e[j];
+                        }
+                        rs += __shfl_xor(rs, 1, 64);
+                        rs += __shfl_xor(rs, 2, 64);
+                        rs += __shfl_xor(rs, 4, 64);
+                        if (m < p.M) {
+                            if ((lane & 7) == 0) p.rowsum[(long)((cbn / T8) * 4 + wc) * p.M + m] = rs;      // part-major: rows of one part are contiguous
+                            bf16_t* dst = lrow0 + (long)(mi * 16 + q * 8) * p.ldc;
+                            if (ln0 + 7 < p.ldc) {
+                                const u32x4 o = {pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]), pack_bf16x2(e[4], e[5]), pack_bf16x2(e[6], e[7])};
+                                if (p.nt) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(dst));
+                                else *reinterpret_cast<u32x4*>(dst) = o;
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 8; ++j)
+                                    if (ln0 + j < p.ldc) dst[j] = f32_to_bf16(e[j]);
+                            }
+                        }
+                    } else if constexpr (LEAN) {
                         const int m = lm0 + mi * 16 + q * 8;
                         if (lfull) {
                             if (m < p.M) {
@@ -927,6 +977,19 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                                         v[2 * j] = p.mask_mode ? v[2 * j] * (1.f - lo * lo) : (lo > 0.f ? v[2 * j] * p.scale : 0.f);
                                         v[2 * j + 1] = p.mask_mode ? v[2 * j + 1] * (1.f - hi * hi) : (hi > 0.f ? v[2 * j + 1] * p.scale : 0.f);
                                     }
+                                }
+                                if constexpr (LEAN == 4) {         // tanh' mask and a per-row factor; the mask operand leaves scaled by the same factor
+                                    const u32x4 mk = mkc[q];
+                                    const float rsc = p.rowscale[m];
+                                    u32x4 ms;
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) {
+                                        const float lo = __uint_as_float(mk[j] << 16), hi = __uint_as_float(mk[j] & 0xffff0000u);
+                                        v[2 * j] *= (1.f - lo * lo) * rsc;
+                                        v[2 * j + 1] *= (1.f - hi * hi) * rsc;
+                                        ms[j] = pack_bf16x2(lo * rsc, hi * rsc);
+                                    }
+                                    *reinterpret_cast<u32x4*>(const_cast<bf16_t*>(p.mask) + (long)m * p.ldc + ln0) = ms;
                                 }
                                 const u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
                                 bf16_t* dst = lrow0 + (long)(mi * 16 + q * 8) * p.ldc;
@@ -943,13 +1006,19 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                                         const float mv = bf16_to_f32(p.mask[(long)m * p.ldc + ln0 + j]);
                                         y = p.mask_mode ? y * (1.f - mv * mv) : (mv > 0.f ? y * p.scale : 0.f);
                                     }
+                                    if constexpr (LEAN == 4) {
+                                        bf16_t* mp = const_cast<bf16_t*>(p.mask) + (long)m * p.ldc + ln0 + j;
+                                        const float mv = bf16_to_f32(*mp), rsc = p.rowscale[m];
+                                        y *= (1.f - mv * mv) * rsc;
+                                        *mp = f32_to_bf16(mv * rsc);
+                                    }
                                     reinterpret_cast<bf16_t*>(C)[(long)m * p.ldc + ln0 + j] = f32_to_bf16(y);
                                 }
                         }
                     } else if constexpr (sizeof(TC) == 2)
                         epi_store8_bf16(p, reinterpret_cast<bf16_t*>(C), cbm + wr * 128 + mi * 16 + r, cbn + wc * 64 + c8 * 8, x0, x1, vec);
                 }
-                if constexpr (LEAN == 2) { mkc[0] = mkn[0]; mkc[1] = mkn[1]; }
+                if constexpr (MASKED) { mkc[0] = mkn[0]; mkc[1] = mkn[1]; }
             } else if constexpr (!LEAN) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1409,7 +1478,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p) {
 // =====================================================================================================================
 constexpr int LDS8T = 2 * BUF8 + 8 * 4096;      // operand buffers + the epilogue's per-wave images
 
-template <bool CS>
+template <int CS>           // column sums of A: 0 = none, 1 = plain (all-ones fragment), 2 = weighted by p.csw[k] (exp-domain loss: bias gradient)
 __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1502,22 +1571,33 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
     f32x4 acc[8][4];
     f32x4 cs = {0.f, 0.f, 0.f, 0.f};
     bf16x8 af[4][2], bfr[4][2];
+    // transposed reads as asm (see LDS_TR): the counted vmcnt + barrier at the end of a phase cover the tiles, V8_LGKM0 these reads
+#define TN8_TR(dst, addr, off) LDS_TR(dst, addr, off)
+    const unsigned lds0 = (unsigned)(size_t)smem;          // LDS byte offset = low half of the flat shared address
     auto read_a = [&](const char* base, int h) {
+        const unsigned b0 = lds0 + (unsigned)(base - smem) + h * HT8;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const char* a = base + h * HT8 + aoff[mt] + ks * 8192;
-                af[mt][ks] = __builtin_shufflevector(ds_read_tr16(a), ds_read_tr16(a + 1024), 0, 1, 2, 3, 4, 5, 6, 7);
+                const unsigned a = b0 + aoff[mt];
+                bf16x4 lo, hi;
+                if (ks == 0) { TN8_TR(lo, a, 0); TN8_TR(hi, a, 1024); }
+                else { TN8_TR(lo, a, 8192); TN8_TR(hi, a, 9216); }
+                af[mt][ks] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
     };
     auto read_b = [&](const char* base) {
+        const unsigned b0 = lds0 + (unsigned)(base - smem);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const char* a = base + boff[nt] + ks * 8192;
-                bfr[nt][ks] = __builtin_shufflevector(ds_read_tr16(a), ds_read_tr16(a + 1024), 0, 1, 2, 3, 4, 5, 6, 7);
+                const unsigned a = b0 + boff[nt];
+                bf16x4 lo, hi;
+                if (ks == 0) { TN8_TR(lo, a, 0); TN8_TR(hi, a, 1024); }
+                else { TN8_TR(lo, a, 8192); TN8_TR(hi, a, 9216); }
+                bfr[nt][ks] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
     };
     auto mma = [&](int mh) {
@@ -1534,14 +1614,44 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
     bf16x8 ones;
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+    long kbeg_cur = 0;                                     // first reduction row of the item being computed
     int cs_unit = -1;                                      // (mh, mt, ks) piece of the column sums this wave owns for the current item
+    // weighted column sums (CS == 2): colsum[m] += sum_k csw[k] A[k][m] - the all-ones fragment becomes the 8 weights of this lane's k-octet
+    // (k = K-tile base + 32 ks + 8 (lane >> 4) + 0..7, the k order of the transposed A fragments).  The 32 weights of the wave's k-half
+    // come through the SCALAR cache (one s_load_dwordx16 a phase ahead of their use): a vector load here would sit in front of the
+    // staged tiles in the vmcnt queue and drain the prefetch.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(4))) const u32x4 cuint4;
+    bf16x8 wcur;
+    u32x4 wq[4];
+    auto fetch_w = [&](int t, int mh) {
+        if constexpr (CS == 2) {
+            if (cs_unit >= 0 && (cs_unit >> 3) == mh) {
+                const long off = __builtin_amdgcn_readfirstlane((int)(kbeg_cur + (long)t * TK)) + (cs_unit & 1) * 32;
+                const cuint4* wp = (const cuint4*)(uintptr_t)(p.csw + off);
+                wq[0] = wp[0]; wq[1] = wp[1]; wq[2] = wp[2]; wq[3] = wp[3];
+            }
+        }
+    };
+    auto select_w = [&](int mh) {
+        if constexpr (CS == 2) {
+            if (cs_unit >= 0 && (cs_unit >> 3) == mh) {
+                const int o = lane >> 4;
+                const u32x4 v = o == 0 ? wq[0] : o == 1 ? wq[1] : o == 2 ? wq[2] : wq[3];
+                wcur = __builtin_bit_cast(bf16x8, v);
+            }
+        }
+    };
     auto colsum_mma = [&](int mh) {
         if (!CS) return;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                if (cs_unit == mh * 8 + mt * 2 + ks) cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[mt][ks], cs, 0, 0, 0);
+                if (cs_unit == mh * 8 + mt * 2 + ks) {
+                    if constexpr (CS == 2) cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcur, af[mt][ks], cs, 0, 0, 0);
+                    else cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[mt][ks], cs, 0, 0, 0);
+                }
     };
 #define V8_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define V8_BAR() __builtin_amdgcn_s_barrier()
@@ -1558,6 +1668,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
         cs = f32x4{0.f, 0.f, 0.f, 0.f};
         cs_unit = CS && tn < 4 ? __builtin_amdgcn_readfirstlane(tn * 4 + wc) : -1;     // column tiles 0..3 share the 16 pieces
         const int cnk = nk;
+        if constexpr (CS == 2) { kbeg_cur = kbeg; if (cnk > 0) fetch_w(0, 0); }
         if (cnk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         V8_BAR();
@@ -1566,14 +1677,17 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
             const int d = t & 1;
             const char* base = smem + d * BUF8;
             const bool more = t + 2 < cnk;
+            fetch_w(t, 1);                                  // weights of phase B, one phase ahead (scalar-cache latency under this phase's MFMAs)
             read_a(base, 0);
             read_b(base);
             if (t + 1 < cnk) stage(1, d ^ 1, t + 1);
             V8_LGKM0();
+            select_w(0);
             V8_BAR();
             mma(0);
             colsum_mma(0);
             V8_BAR();
+            if (t + 1 < cnk) fetch_w(t + 1, 0);             // weights of the next tile's phase A
             read_a(base, 1);
             if (more) {
                 stage(0, d, t + 2); stage(2, d, t + 2); stage(3, d, t + 2);
@@ -1582,6 +1696,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             V8_LGKM0();
+            select_w(1);
             V8_BAR();
             mma(1);
             colsum_mma(1);
@@ -1636,6 +1751,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
 template <bool CS>
 __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v9_kernel(const FP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = (unsigned)(size_t)smem;          // LDS byte offset = low half of the flat shared address (asm reads)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave & 3, wc = wave >> 2;               // waves w and w+4 (SIMD partners) differ in the column half
     const int grp = wave >> 2;
@@ -1727,18 +1843,24 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v9_kernel(const FP p) {
         if (grp == 1) V9_BAR();
         int stg = 0;
         for (int t = 0; t < cnk; ++t) {
-            const char* base = smem + stg * STG9;
+            const unsigned base = lds0 + stg * STG9;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const char* a = base + aoff[i] + ks * (32 * 512);
-                    af[i][ks] = __builtin_shufflevector(ds_read_tr16(a), ds_read_tr16(a + 4 * 512), 0, 1, 2, 3, 4, 5, 6, 7);
+                    const unsigned a = base + aoff[i];
+                    bf16x4 lo, hi;
+                    if (ks == 0) { LDS_TR(lo, a, 0); LDS_TR(hi, a, 4 * 512); }
+                    else { LDS_TR(lo, a, 32 * 512); LDS_TR(hi, a, 36 * 512); }
+                    af[i][ks] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const char* bq = base + boff[i] + ks * (32 * 256);
-                    bfr[i][ks] = __builtin_shufflevector(ds_read_tr16(bq), ds_read_tr16(bq + 4 * 256), 0, 1, 2, 3, 4, 5, 6, 7);
+                    const unsigned bq = base + boff[i];
+                    bf16x4 lo, hi;
+                    if (ks == 0) { LDS_TR(lo, bq, 0); LDS_TR(hi, bq, 4 * 256); }
+                    else { LDS_TR(lo, bq, 32 * 256); LDS_TR(hi, bq, 36 * 256); }
+                    bfr[i][ks] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
             }
             if (t + 2 < cnk) {
@@ -1859,6 +1981,46 @@ static void fill_batch(FP& p, const FastBatch& b) {
     p.nz2 = b.nz2; p.sA1 = b.sA1; p.sA2 = b.sA2; p.sB1 = b.sB1; p.sB2 = b.sB2; p.sC1 = b.sC1; p.sC2 = b.sC2; p.sV1 = b.sV1; p.sV2 = b.sV2;
 }
 
+static void ensure_num_cus() {
+    if (g_num_cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            g_num_cus = n / 8 * 8;        // the persistent tile walks assume a multiple of 8 (one share per XCD)
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+}
+// persistent 256x256 NT kernel: needs several rounds of tiles per CU to amortise its pipeline fill and tail
+static bool nt_v8_eligible(int M, int N, int K) {
+    ensure_num_cus();
+    const long t9 = (long)cdiv(M, T9M) * cdiv(N, T9N);
+    return M >= 1024 && N >= 256 && K >= 128 && K % TK == 0 &&
+           ((g_gemm_fast_version == 8) || (g_gemm_fast_version == 4 && t9 >= g_num_cus * 3 / 4));
+}
+// persistent 256x256 TN kernel (huge-reduction wgrad); S = K-ranges per XCD, strip_in = the M % 256 rows ride inside the kernel
+static bool tn_v8_eligible(int M, int N, int K, bool colsum, int* S_out, bool* strip_in) {
+    ensure_num_cus();
+    const bool tn8 = K % TK == 0 && N >= 256 && N % 256 == 0 && (!colsum || N / 256 >= 4) &&
+                     ((g_gemm_fast_version == 4 && K >= 32768 && M >= 1024) || (g_gemm_fast_version == 8 && K >= 2048 && M >= 256));
+    if (!tn8) return false;
+    const int ncu_x = g_num_cus / 8, tiles_n = N / T8, ntile = (M / T8) * tiles_n;
+    int S = 1;                                          // fill every CU of the XCD, then balance the rounds
+    while (S * ntile < ncu_x || ((S * ntile) % ncu_x != 0 && S * ntile < 8 * ncu_x)) ++S;
+    // the strip rides along inside the kernel when its pieces deal out evenly (one per workgroup of the XCD) behind balanced main
+    // items; otherwise it goes to the 128x128 kernel
+    if (S_out) *S_out = S;
+    if (strip_in) *strip_in = M % T8 != 0 && ncu_x % tiles_n == 0 && (S * ntile) % ncu_x == 0 && g_gemm_fast_version != 8;
+    return true;
+}
+// can the fused joint + loss fast path run at this size?  (projection forward with the exp store, dgrad with the row factor,
+// wgrad with the weighted column sums - all three on the persistent 256x256 kernels)
+bool gemm_fast_joint_exp_ok(int M, int V, int J, long ldv) {
+    bool strip_in = false;
+    if (M <= 0 || V <= 0 || J <= 0 || ldv < V) return false;
+    if (!nt_v8_eligible(M, V, J) || !nt_v8_eligible(M, J, (int)ldv)) return false;
+    if (!tn_v8_eligible(V, J, M, true, nullptr, &strip_in)) return false;
+    return V % T8 == 0 || strip_in;
+}
+
 int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const NtEpilogue& epi, int M, int N, int K, long lda,
                  long ldb, long ldc, hipStream_t st, const FastBatch& batch) {
     TTMI_REQUIRE(gemm_fast_nt_ok(A, B, C, M, N, K, lda, ldb), "gemm_nt_bf16: shape/alignment not supported (M=%d N=%d K=%d)", M,
@@ -1868,6 +2030,7 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.tiles_m = cdiv(M, TM); p.tiles_n = cdiv(N, TN_); p.splitk = 1; p.ksteps = cdiv(K, TK); p.atomic = 0; p.gm = GROUP_M; p.colsum = nullptr;
     p.A2 = epi.A2; p.B2 = epi.B2; p.K2 = epi.K2; p.lda2 = epi.lda2; p.ldb2 = epi.ldb2; p.sB1b = epi.sB1b; p.sB2b = epi.sB2b; p.colsum_mid = epi.colsum_mid;
+    p.rowsum = epi.rowsum; p.nparts = epi.nparts; p.exp_shift = epi.exp_shift; p.rowscale = epi.rowscale; p.csw = nullptr;
     const bool dual = epi.A2 != nullptr;
     if (dual) TTMI_REQUIRE(epi.B2 && epi.K2 >= 8 && epi.K2 % 8 == 0 && aligned16(epi.A2) && aligned16(epi.B2) && epi.lda2 % 8 == 0 && epi.ldb2 % 8 == 0 &&
                            c_dtype == 1, "gemm_nt_bf16: bad second operand pair");
@@ -1876,12 +2039,7 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     TTMI_REQUIRE(nbatch >= 1 && nbatch <= 65535, "gemm_nt_bf16: bad batch count %d", nbatch);
     // 256x256 tiles pay off when the K loop is long enough to amortise the un-overlapped epilogue of a one-workgroup-per-CU
     // kernel and there are enough tiles to fill the chip (joint dgrad: K = 4352 -> 954 vs 880 TFLOP/s; short-K forward: worse)
-    if (g_num_cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            g_num_cus = n / 8 * 8;        // the persistent tile walks assume a multiple of 8 (one share per XCD)
-        if (g_num_cus <= 0) g_num_cus = 256;
-    }
+    ensure_num_cus();
     // persistent kernels: 256x256 tiles (v8) are ~1.8x the cost of 256x128 tiles (v9); take whichever needs less time for its
     // whole number of rounds over the CUs (joint: v8; encoder N = 512 / 1536: v9; N = 2048: v8), the 128x128 kernel for small outputs
     const long t9 = (long)cdiv(M, T9M) * cdiv(N, T9N), t8 = (long)cdiv(M, T8) * cdiv(N, T8);
@@ -1889,7 +2047,11 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     const int reserved = reserved_cus(st);
     const int cus_avail = std::max(8, (g_num_cus - reserved) / 8 * 8);
     const double cost9 = (double)cdiv(t9, cus_avail), cost8 = N >= 256 ? 1.8 * cdiv(t8, t8 < 1024 ? cus_avail : g_num_cus) : 1e30;
-    const bool v9 = pers && ((g_gemm_fast_version == 9) || (g_gemm_fast_version == 4 && t9 >= g_num_cus * 3 / 4 && cost9 <= cost8));
+    // the exp-store / row-scale epilogues exist on the 256x256 kernel only: callers ask gemm_fast_joint_exp_ok() first
+    const bool needs8 = epi.rowsum || epi.rowscale;
+    const bool v8 = nbatch == 1 && !dual && nt_v8_eligible(M, N, K);
+    TTMI_REQUIRE(!needs8 || (v8 && c_dtype == 1), "gemm_nt_bf16: the exp-store / row-scale epilogues exist on the persistent 256x256 kernel only (M=%d N=%d K=%d)", M, N, K);
+    const bool v9 = !needs8 && pers && ((g_gemm_fast_version == 9) || (g_gemm_fast_version == 4 && t9 >= g_num_cus * 3 / 4 && cost9 <= cost8));
     if (v9) {
         p.tiles_m = cdiv(M, T9M); p.tiles_n = cdiv(N, T9N);
         // a persistent grid larger than the CUs that are actually free runs its surplus workgroups AFTER the others (twice the time):
@@ -1942,7 +2104,6 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
         return TTMI_OK;
     }
     // persistent 256x256 kernel: needs several rounds of tiles per CU to amortise its pipeline fill and tail
-    const bool v8 = pers && N >= 256 && ((g_gemm_fast_version == 8) || (g_gemm_fast_version == 4 && t9 >= g_num_cus * 3 / 4));
     if (v8) {
         p.tiles_m = cdiv(M, T8); p.tiles_n = cdiv(N, T8);
         const long nwg8 = (long)p.tiles_m * p.tiles_n;
@@ -1951,9 +2112,19 @@ const int cus8 = nwg8 < 1024 ? std::max(8, (g_num_cus - reserved) / 8 * 8) : g_n
 if (c_dtype == 0) {
             if (int rc = enable_lds(gemm_nt_bf16_v8_kernel<float>, LDS8)) return rc;
             hipLaunchKernelGGL(gemm_nt_bf16_v8_kernel<float>, dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
+        } else if (p.rowsum) {
+            TTMI_REQUIRE(!p.addend && !p.mask && !p.relu && p.drop.p <= 0.f && ldc % 8 == 0 && aligned16(C) && p.nparts >= 4 * p.tiles_n,
+                         "gemm_nt_bf16: exp store needs a plain bf16 output with pitch %% 8 == 0 and nparts >= 4 * column tiles");
+            if (int rc = enable_lds((gemm_nt_bf16_v8_kernel<bf16_t, 3>), LDS8)) return rc;
+            hipLaunchKernelGGL((gemm_nt_bf16_v8_kernel<bf16_t, 3>), dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
         } else if (!p.addend && !p.mask && !p.relu && p.drop.p <= 0.f && ldc % 8 == 0 && aligned16(C) && (!p.bias || aligned16(p.bias))) {
             if (int rc = enable_lds((gemm_nt_bf16_v8_kernel<bf16_t, 1>), LDS8)) return rc;
             hipLaunchKernelGGL((gemm_nt_bf16_v8_kernel<bf16_t, 1>), dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
+        } else if (p.rowscale) {
+            TTMI_REQUIRE(!p.addend && p.mask && p.mask_mode == 1 && !p.bias && !p.relu && p.drop.p <= 0.f && ldc % 8 == 0 && aligned16(C) && aligned16(p.mask),
+                         "gemm_nt_bf16: the row factor needs the tanh-mask bf16 epilogue");
+            if (int rc = enable_lds((gemm_nt_bf16_v8_kernel<bf16_t, 4>), LDS8)) return rc;
+            hipLaunchKernelGGL((gemm_nt_bf16_v8_kernel<bf16_t, 4>), dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
         } else if (!p.addend && p.mask && !p.bias && !p.relu && p.drop.p <= 0.f && ldc % 8 == 0 && aligned16(C) && aligned16(p.mask)) {
             if (int rc = enable_lds((gemm_nt_bf16_v8_kernel<bf16_t, 2>), LDS8)) return rc;
             hipLaunchKernelGGL((gemm_nt_bf16_v8_kernel<bf16_t, 2>), dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
@@ -2005,12 +2176,14 @@ bool gemm_fast_tn_ok(const void* A, const void* B, const void* C, int M, int N, 
 
 // C (f32) += A^T B by atomics when splitk > 1 or accumulate != 0, else C = A^T B
 int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
-                 hipStream_t st, float* colsum_a, const FastBatch& batch) {
+                 hipStream_t st, float* colsum_a, const FastBatch& batch, const bf16_t* colsum_w) {
     TTMI_REQUIRE(gemm_fast_tn_ok(A, B, C, M, N, K, lda, ldb), "gemm_tn_bf16: shape/alignment not supported (M=%d N=%d K=%d)", M,
                  N, K);
     FP p;
     p.A = A; p.B = B; p.C = C; p.bias = nullptr; p.addend = nullptr; p.mask = nullptr; p.mask_mode = 0; p.nt = 0; p.relu = 0; p.scale = 1.f; p.drop = DropSpec();
     p.colsum = colsum_a;
+    p.rowsum = nullptr; p.nparts = 0; p.exp_shift = nullptr; p.rowscale = nullptr; p.csw = colsum_w;
+    TTMI_REQUIRE(!colsum_w || (colsum_a && aligned16(colsum_w)), "gemm_tn_bf16: weighted column sums need colsum_a and 16-byte aligned weights");
     fill_batch(p, batch);
     const int nbatch = batch.nz1 * batch.nz2;
     TTMI_REQUIRE(nbatch >= 1 && nbatch <= 65535, "gemm_tn_bf16: bad batch count %d", nbatch);
@@ -2045,36 +2218,30 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
     }
     // huge-reduction wgrad (the joint projection: K = B*T*U1 rows): persistent 256x256 kernel on the 256-row tiles that are
     // full, the 128x128 kernel below on the remaining M % 256 rows
-    const bool tn8 = nbatch == 1 && accumulate && K % TK == 0 && N >= 256 && N % 256 == 0 && (!colsum_a || N / 256 >= 4) &&
-                     ((g_gemm_fast_version == 4 && K >= 32768 && M >= 1024) || (g_gemm_fast_version == 8 && K >= 2048 && M >= 256));
+    int S = 1;
+    bool strip_in = false;
+    const bool tn8 = nbatch == 1 && accumulate && tn_v8_eligible(M, N, K, colsum_a != nullptr, &S, &strip_in);
+    TTMI_REQUIRE(!colsum_w || tn8, "gemm_tn_bf16: weighted column sums exist on the persistent 256x256 kernel only (M=%d N=%d K=%d)", M, N, K);
     if (tn8) {
-        if (g_num_cus == 0) {
-            int dev = 0, n = 0;
-            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-                g_num_cus = n / 8 * 8;
-            if (g_num_cus <= 0) g_num_cus = 256;
-        }
         const int ncu_x = g_num_cus / 8;
         p.tiles_m = M / T8; p.tiles_n = N / T8;             // full tile rows; the M % 256 strip: see below
-        const int ntile = p.tiles_m * p.tiles_n;
-        int S = 1;                                          // K-ranges per XCD: fill every CU of the XCD, then balance the rounds
-        while (S * ntile < ncu_x || ((S * ntile) % ncu_x != 0 && S * ntile < 8 * ncu_x)) ++S;
         const int nkt = cdiv(K, TK);
-        // the strip rides along inside the kernel when its pieces deal out evenly (one per workgroup of the XCD) behind balanced main items;
-        // otherwise it goes to the 128x128 kernel below
-        const bool strip_in = M % T8 != 0 && ncu_x % p.tiles_n == 0 && (S * ntile) % ncu_x == 0 && g_gemm_fast_version != 8;
         const int Mfull = strip_in ? M : M / T8 * T8;
         p.M = Mfull; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
         p.splitk = S; p.ksteps = cdiv(nkt, 8 * S); p.atomic = 1; p.gm = strip_in ? ncu_x / p.tiles_n : 0;
-        if (colsum_a) {
-            if (int rc = enable_lds(gemm_tn_bf16_v8_kernel<true>, LDS8T)) return rc;
-            hipLaunchKernelGGL(gemm_tn_bf16_v8_kernel<true>, dim3((unsigned)g_num_cus), dim3(NTH8), LDS8T, st, p);
+        if (colsum_a && p.csw) {
+            if (int rc = enable_lds(gemm_tn_bf16_v8_kernel<2>, LDS8T)) return rc;
+            hipLaunchKernelGGL(gemm_tn_bf16_v8_kernel<2>, dim3((unsigned)g_num_cus), dim3(NTH8), LDS8T, st, p);
+        } else if (colsum_a) {
+            if (int rc = enable_lds(gemm_tn_bf16_v8_kernel<1>, LDS8T)) return rc;
+            hipLaunchKernelGGL(gemm_tn_bf16_v8_kernel<1>, dim3((unsigned)g_num_cus), dim3(NTH8), LDS8T, st, p);
         } else {
-            if (int rc = enable_lds(gemm_tn_bf16_v8_kernel<false>, LDS8T)) return rc;
-            hipLaunchKernelGGL(gemm_tn_bf16_v8_kernel<false>, dim3((unsigned)g_num_cus), dim3(NTH8), LDS8T, st, p);
+            if (int rc = enable_lds(gemm_tn_bf16_v8_kernel<0>, LDS8T)) return rc;
+            hipLaunchKernelGGL(gemm_tn_bf16_v8_kernel<0>, dim3((unsigned)g_num_cus), dim3(NTH8), LDS8T, st, p);
         }
         TTMI_LAUNCH_CHECK("gemm_tn_bf16_v8_kernel");
         if (Mfull == M) return TTMI_OK;
+        TTMI_REQUIRE(!colsum_w, "gemm_tn_bf16: weighted column sums need the M %% 256 strip inside the persistent kernel (M=%d N=%d)", M, N);
         A += Mfull; C += (long)Mfull * ldc; M -= Mfull;     // the strip: same call, remaining rows of C
         if (colsum_a) colsum_a += Mfull;
         p.A = A; p.C = C; p.colsum = colsum_a;
@@ -2141,6 +2308,14 @@ int ttmi_gemm_nt_bf16(const void* A, const void* B, void* C, int c_dtype, const 
     NtEpilogue e;
     e.bias = bias;
     return gemm_nt_bf16(static_cast<const bf16_t*>(A), static_cast<const bf16_t*>(B), C, c_dtype, e, M, N, K, lda, ldb, ldc,
+                        static_cast<hipStream_t>(stream), FastBatch());
+}
+// exp store (see NtEpilogue): C = bf16(exp(A.B^T + bias - shift)), rowsum [M, nparts] partial row sums
+int ttmi_gemm_nt_bf16_exp(const void* A, const void* B, void* C, const float* bias, float* rowsum, int nparts, const float* shift, int M, int N, int K,
+                          long lda, long ldb, long ldc, void* stream) {
+    NtEpilogue e;
+    e.bias = bias; e.rowsum = rowsum; e.nparts = nparts; e.exp_shift = shift;
+    return gemm_nt_bf16(static_cast<const bf16_t*>(A), static_cast<const bf16_t*>(B), C, 1, e, M, N, K, lda, ldb, ldc,
                         static_cast<hipStream_t>(stream), FastBatch());
 }
 int ttmi_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,

@@ -738,9 +738,10 @@ size_t ttmi_joint_ws_floats(int B, int T, int U1, int J, int V) {
            al4((size_t)J * (((size_t)V + 63) / 64 * 64));
 }
 
-int ttmi_joint_fwd(const float* enc, const float* dec, const float* wf, const float* bf, const float* wp, const float* bp,
-                   int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx, float* ws, void* logits, long ldv,
-                   void* stream) {
+// rowsum != nullptr: the "exp store" form of the fused joint + loss fast path (logits become exp(z - *shift), see ttmi_joint_fwd_exp)
+static int joint_fwd_impl(const float* enc, const float* dec, const float* wf, const float* bf, const float* wp, const float* bp,
+                          int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx, float* ws, void* logits, long ldv,
+                          float* rowsum, int nparts, const float* shift, void* stream) {
     TTMI_REQUIRE(enc && dec && wf && bf && wp && bp && ctx && ws && logits, "joint_fwd: null pointer");
     TTMI_REQUIRE(B > 0 && T > 0 && U1 > 0 && de > 0 && dd > 0 && J > 0 && V > 0 && ldv >= V, "joint_fwd: bad dims");
     TTMI_REQUIRE((long)B * T * U1 < (1L << 31), "joint_fwd: B*T*(U+1) too large");
@@ -787,16 +788,44 @@ int ttmi_joint_fwd(const float* enc, const float* dec, const float* wf, const fl
     const bf16_t* wp16 = Wp16;
     if (shadow_of(wp, V, J, (V + 63) / 64 * 64, shp)) wp16 = shp.w16;
     else CK(convert_bf16(wp, Wp16, (long)V * J, st));
+    NtEpilogue e;
+    e.bias = bp; e.rowsum = rowsum; e.nparts = nparts; e.exp_shift = shift;
     ttmi_probe_begin(0, st);
-    const int rc = gemm_nt_bf16(H16, wp16, logits, 1, bp, M, V, J, J, J, ldv, st);
+    const int rc = gemm_nt_bf16(H16, wp16, logits, 1, e, M, V, J, J, J, ldv, st);
     ttmi_probe_end(0, st);
     CK(rc);
     return TTMI_OK;
 }
 
-int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float* dec, const float* wf, const float* wp, int B,
-                   int T, int U1, int de, int dd, int J, int V, int prec, const float* ctx, float* ws, float* denc, float* ddec,
-                   float* g_wf, float* g_bf, float* g_wp, float* g_bp, void* stream) {
+int ttmi_joint_fwd(const float* enc, const float* dec, const float* wf, const float* bf, const float* wp, const float* bp,
+                   int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx, float* ws, void* logits, long ldv,
+                   void* stream) {
+    return joint_fwd_impl(enc, dec, wf, bf, wp, bp, B, T, U1, de, dd, J, V, prec, ctx, ws, logits, ldv, nullptr, 0, nullptr, stream);
+}
+
+// ---- exp-domain forms: the fused joint + loss fast path (training-sized bf16 problems; ask ttmi_joint_exp_supported first)
+// forward: P[row, v] = bf16(exp(z[row, v] - *shift)) with pitch ldv (columns [V, ldv) zero), rowsum f32 [nparts, rows] = partial row
+// sums of the unrounded values (nparts = ttmi_joint_exp_nparts(V)); shift: device scalar, nullable = 0.  The loss then needs two
+// entries per row instead of two passes over the lattice (ttmi_rnnt_loss_fwd_exp / _bwd_exp), and the backward below takes
+// d logits = srow[r] * P[r, :] without ever materialising it: the row factor rides in the dgrad epilogue and in the wgrad's H operand.
+int ttmi_joint_exp_supported(int B, int T, int U1, int J, int V, int prec, long ldv) {
+    if (!joint_fast(prec, J) || (long)B * T * U1 >= (1L << 31) || ldv % 64 != 0) return 0;
+    return gemm_fast_joint_exp_ok(B * T * U1, V, J, ldv) ? 1 : 0;
+}
+int ttmi_joint_exp_nparts(int V) { return 4 * ((V + 255) / 256); }
+
+int ttmi_joint_fwd_exp(const float* enc, const float* dec, const float* wf, const float* bf, const float* wp, const float* bp,
+                       int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx, float* ws, void* P, long ldv,
+                       float* rowsum, int nparts, const float* shift, void* stream) {
+    TTMI_REQUIRE(rowsum && nparts >= ttmi_joint_exp_nparts(V), "joint_fwd_exp: rowsum needs >= %d parts per row", ttmi_joint_exp_nparts(V));
+    TTMI_REQUIRE(ttmi_joint_exp_supported(B, T, U1, J, V, prec, ldv), "joint_fwd_exp: size / precision outside the fast path (B=%d T=%d U1=%d J=%d V=%d)", B, T, U1, J, V);
+    return joint_fwd_impl(enc, dec, wf, bf, wp, bp, B, T, U1, de, dd, J, V, prec, ctx, ws, P, ldv, rowsum, nparts, shift, stream);
+}
+
+// srow != nullptr: exp-domain form, d logits[r, :] = srow[r] * dlogits[r, :] (see ttmi_joint_bwd_exp); ctx is then scaled in place
+static int joint_bwd_impl(const void* dlogits, long ldg, const float* enc, const float* dec, const float* wf, const float* wp, int B,
+                          int T, int U1, int de, int dd, int J, int V, int prec, float* ctx, float* ws, float* denc, float* ddec,
+                          float* g_wf, float* g_bf, float* g_wp, float* g_bp, const float* srow, const void* srow16, void* stream) {
     TTMI_REQUIRE(dlogits && enc && dec && wf && wp && ctx && ws && denc && ddec && g_wf && g_bf && g_wp && g_bp,
                  "joint_bwd: null pointer");
     TTMI_REQUIRE(ldg >= V, "joint_bwd: bad pitch");
@@ -822,7 +851,7 @@ int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float*
         bf16_t* dH16 = reinterpret_cast<bf16_t*>(ws);
         bf16_t* WpT16 = reinterpret_cast<bf16_t*>(dPD + 2 * al4((size_t)B * U1 * J));    // [J, ldg], zero beyond V
         TTMI_REQUIRE((size_t)J * ldg <= 2 * al4((size_t)J * (((size_t)V + 63) / 64 * 64)), "joint_bwd: pitch %ld too large for the workspace", ldg);
-        CK(gemm_tn_bf16(dZ, H16, g_wp, V, J, M, ldg, J, J, 1, st, g_bp));      // g_bp = column sums of dZ, fused
+        if (!srow) CK(gemm_tn_bf16(dZ, H16, g_wp, V, J, M, ldg, J, J, 1, st, g_bp));      // g_bp = column sums of dZ, fused
         Shadow shp;
         const bf16_t* wpT16 = WpT16;
         if (shadow_of(wp, V, J, ldg, shp)) wpT16 = shp.wT16;                    // [J, ldg], zero beyond V (kept so by the refresh kernel)
@@ -830,7 +859,13 @@ int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float*
         NtEpilogue e;                                                           // dH * (1 - H^2) in the dgrad epilogue
         e.mask = H16;
         e.mask_mode = 1;
+        e.rowscale = srow;                                                      // exp-domain form: ... * srow[r], and H leaves as srow[r] * H
         CK(gemm_nt_bf16(dZ, wpT16, dH16, 1, e, M, J, (int)ldg, ldg, ldg, J, st));
+        if (srow) {
+            // g_wp = P^T (s . H), g_bp = P^T s: the row factor moved onto the other operand (the dgrad epilogue rewrote H in place)
+            const bf16_t* Hs = reinterpret_cast<const bf16_t*>(ctx);
+            CK(gemm_tn_bf16(dZ, Hs, g_wp, V, J, M, ldg, J, J, 1, st, g_bp, FastBatch(), static_cast<const bf16_t*>(srow16)));
+        }
         CK(fill_zero(dPD, sizeof(float) * (size_t)B * U1 * J, st));
         CK(joint_tanh_bwd(dH16, nullptr, 1, B, T, U1, J, dPE, dPD, st));
     }
@@ -863,6 +898,24 @@ int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float*
     CK(ttmi_launch_gemm(mk(dPE, wf, denc, B * T, de, J, J, din, de, NN_, prec), st));
     CK(ttmi_launch_gemm(mk(dPD, wf + de, ddec, B * U1, dd, J, J, din, dd, NN_, prec), st));
     return TTMI_OK;
+}
+
+int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float* dec, const float* wf, const float* wp, int B,
+                   int T, int U1, int de, int dd, int J, int V, int prec, const float* ctx, float* ws, float* denc, float* ddec,
+                   float* g_wf, float* g_bf, float* g_wp, float* g_bp, void* stream) {
+    return joint_bwd_impl(dlogits, ldg, enc, dec, wf, wp, B, T, U1, de, dd, J, V, prec, const_cast<float*>(ctx), ws, denc, ddec, g_wf,
+                          g_bf, g_wp, g_bp, nullptr, nullptr, stream);
+}
+
+// P (patched by ttmi_rnnt_loss_bwd_exp) and the row factors srow (f32) / srow16 (bf16) stand for d logits = srow[r] * P[r, :].
+// ctx (the hidden activations) is overwritten.
+int ttmi_joint_bwd_exp(const void* P, long ldg, const float* srow, const void* srow16, const float* enc, const float* dec,
+                       const float* wf, const float* wp, int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx,
+                       float* ws, float* denc, float* ddec, float* g_wf, float* g_bf, float* g_wp, float* g_bp, void* stream) {
+    TTMI_REQUIRE(srow && srow16 && aligned16(srow16), "joint_bwd_exp: row factors missing or misaligned");
+    TTMI_REQUIRE(ttmi_joint_exp_supported(B, T, U1, J, V, prec, ldg), "joint_bwd_exp: size / precision outside the fast path");
+    return joint_bwd_impl(P, ldg, enc, dec, wf, wp, B, T, U1, de, dd, J, V, prec, ctx, ws, denc, ddec, g_wf, g_bf, g_wp, g_bp, srow,
+                          srow16, stream);
 }
 
 // ---- bf16 weight shadows

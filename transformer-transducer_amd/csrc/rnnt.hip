@@ -379,6 +379,92 @@ __global__ __launch_bounds__(LSE_WAVES * 64) void rnnt_grad_kernel(
     for (int i = V + lane; i < ldg; i += 64) stf<TL>(g + i, 0.f);
 }
 
+
+// ------------------------------------------------------------------ exp-domain variant (fused joint + loss fast path)
+// The joint's projection GEMM stored P[row, v] = exp(logit - shift) in bf16 plus per-row partial sums of the unrounded values
+// (gemm_fast.hip, "exp store" epilogue).  Nothing below walks the rows: the forward needs S = sum of the partials and two entries
+// per row, the backward leaves the row factor s_r = gscale * exp(alpha + beta - ll - log S) to the consuming GEMMs
+// (d logits[r, v] = s_r * P[r, v] everywhere but at the blank / label columns, which are patched in P here).
+constexpr float EXP_SHIFT_MARGIN = 40.f;
+__global__ __launch_bounds__(256) void rnnt_prep_exp_kernel(
+    const bf16_t* __restrict__ P, long ldv, const float* __restrict__ rowsum, int nparts, const int* __restrict__ labels,
+    const int* __restrict__ act_lens, const int* __restrict__ label_lens, int B, int T, int U1, int V, int blank,
+    float* __restrict__ lse, float* __restrict__ lpb_d, float* __restrict__ lpl_d, const float* __restrict__ shift_cur,
+    float* __restrict__ shift_next) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= (long)B * T * U1) return;
+    const int u = (int)(row % U1);
+    const long bt = row / U1;
+    const int t = (int)(bt % T);
+    const int b = (int)(bt / T);
+    const int Tb = clampi(act_lens[b], 1, T), Ub = clampi(label_lens[b], 0, U1 - 1);
+    if (t >= Tb || u > Ub) return;
+    const long rows = (long)B * T * U1;
+    float S = 0.f;
+    for (int i = 0; i < nparts; ++i) S += rowsum[i * rows + row];        // part-major: coalesced across the block's rows
+    const float l = __logf(S);
+    lse[row] = l;
+    if (shift_next) {
+        // the shift the NEXT step should use: this row's log-sum-exp in logit units, less a margin that keeps exp() far from both
+        // ends of the f32 / bf16 range.  Non-negative floats order like their bit patterns, so an integer atomic max does it.
+        const float cur = shift_cur ? *shift_cur : 0.f;
+        // a row sum that overflowed (logits more than ~88 above the shift in use) says nothing about the scale: step up by 64
+        const float cand = S < 3.0e38f ? l + cur - EXP_SHIFT_MARGIN : cur + 64.f;
+        if (cand > 0.f && cand < 3.0e38f) atomicMax(reinterpret_cast<int*>(shift_next), __float_as_int(cand));
+    }
+    const bf16_t* r = P + row * ldv;
+    const long di = (long)b * diag_stride(T, U1) + (long)(t + u) * U1 + u;
+    const float pb = ldf<bf16_t>(r + blank);
+    lpb_d[di] = (pb > 0.f ? __logf(pb) : NEG) - l;
+    float pl = NEG;
+    if (u < Ub) {
+        const int y = clampi(labels[(long)b * (U1 - 1) + u], 0, V - 1);
+        const float py = ldf<bf16_t>(r + y);
+        pl = (py > 0.f ? __logf(py) : NEG) - l;
+    }
+    lpl_d[di] = pl;
+}
+
+__global__ __launch_bounds__(256) void rnnt_scale_exp_kernel(
+    bf16_t* __restrict__ P, long ldv, const int* __restrict__ labels, const int* __restrict__ act_lens,
+    const int* __restrict__ label_lens, int B, int T, int U1, int V, int blank, const float* __restrict__ lse,
+    const acc_t* __restrict__ alpha_d, const acc_t* __restrict__ beta_d, const acc_t* __restrict__ ll,
+    const float* __restrict__ grad_out, int grad_out_stride, float scale, float* __restrict__ srow, bf16_t* __restrict__ srow16) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= (long)B * T * U1) return;
+    const int u = (int)(row % U1);
+    const long bt = row / U1;
+    const int t = (int)(bt % T);
+    const int b = (int)(bt / T);
+    const int Tb = clampi(act_lens[b], 1, T), Ub = clampi(label_lens[b], 0, U1 - 1);
+    float sr = 0.f;
+    if (t < Tb && u <= Ub) {
+        const acc_t* al = alpha_d + (long)b * diag_stride(T, U1);
+        const acc_t* be = beta_d + (long)b * diag_stride(T, U1);
+        const long di = (long)(t + u) * U1 + u;
+        const acc_t bcur = be[di];
+        sr = scale * grad_out[(long)b * grad_out_stride] * __expf((float)(al[di] - ll[b * 2] + bcur) - lse[row]);
+        // emission terms: e_blank / (s P_blank) = exp(beta[t+1,u] - beta[t,u]) (exp(-beta) at the terminal cell), e_label likewise
+        float rb = 0.f, rl = 0.f;
+        if (t == Tb - 1 && u == Ub) rb = __expf((float)(-bcur));
+        else if (t < Tb - 1) rb = __expf((float)(be[di + U1] - bcur));
+        bf16_t* r = P + row * ldv;
+        int yv = -1;
+        if (u < Ub) {
+            yv = clampi(labels[(long)b * (U1 - 1) + u], 0, V - 1);
+            rl = __expf((float)(be[di + U1 + 1] - bcur));
+        }
+        const float pb = ldf<bf16_t>(r + blank);
+        if (yv == blank) stf<bf16_t>(r + blank, pb * (1.f - rb - rl));
+        else {
+            stf<bf16_t>(r + blank, pb * (1.f - rb));
+            if (yv >= 0) stf<bf16_t>(r + yv, ldf<bf16_t>(r + yv) * (1.f - rl));
+        }
+    }
+    srow[row] = sr;
+    stf<bf16_t>(srow16 + row, sr);
+}
+
 template <int R, int PF>
 void launch_alphabeta(hipStream_t st, int B, const float* lpb, const float* lpl, const int* al, const int* ll_, int T, int U1,
                       acc_t* a, acc_t* b, acc_t* ll, float* costs) {
@@ -481,6 +567,55 @@ int ttmi_rnnt_loss_bwd(const void* logits, int dtype, long ldv, const int* label
                            w.lse, w.alpha, w.beta, w.ll, grad_out, grad_out_stride, scale, static_cast<bf16_t*>(grad), ldg);
     ttmi_probe_end(2, st);
     TTMI_LAUNCH_CHECK("rnnt_grad_kernel");
+    return TTMI_OK;
+}
+
+// Exp-domain forms for the fused joint + loss fast path (see rnnt_prep_exp_kernel).  P bf16 [rows, ldv] = exp(logit - shift) and
+// rowsum f32 [nparts, rows] come from ttmi_joint_fwd_exp; same workspace as above.  shift_cur (device scalar, nullable = 0) is the
+// shift P was formed with; shift_next (device scalar, nullable) receives max(itself, max over rows of log-sum-exp - 40): callers
+// feed it to the next step's forward so that exp() stays inside the bf16 range whatever the scale of the logits.  The backward patches the blank / label entries
+// of P in place and writes the per-row factors srow (f32) and srow16 (bf16): d logits = srow[r] * P[r, :].
+int ttmi_rnnt_loss_fwd_exp(const void* P, long ldv, const float* rowsum, int nparts, const int* labels, const int* act_lens,
+                           const int* label_lens, int B, int T, int U1, int V, int blank, void* workspace, float* costs,
+                           const float* shift_cur, float* shift_next, void* stream) {
+    TTMI_REQUIRE(P && rowsum && (labels || U1 == 1) && act_lens && label_lens && workspace && costs, "rnnt_loss_fwd_exp: null pointer");
+    TTMI_REQUIRE(B > 0 && T > 0 && U1 > 0 && V > 0 && nparts > 0 && ldv >= V, "rnnt_loss_fwd_exp: bad shape");
+    TTMI_REQUIRE(blank >= 0 && blank < V, "rnnt_loss_fwd_exp: blank %d outside [0,%d)", blank, V);
+    TTMI_REQUIRE(U1 <= 1024, "rnnt_loss_fwd_exp: U+1=%d > 1024 unsupported", U1);
+    TTMI_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7) == 0, "rnnt_loss_fwd_exp: workspace must be 8-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Ws w = carve(workspace, B, T, U1);
+    const long rows = (long)B * T * U1;
+    ttmi_probe_begin(1, st);
+    hipLaunchKernelGGL(rnnt_prep_exp_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, st, static_cast<const bf16_t*>(P), ldv, rowsum,
+                       nparts, labels, act_lens, label_lens, B, T, U1, V, blank, w.lse, w.lpb, w.lpl, shift_cur, shift_next);
+    TTMI_LAUNCH_CHECK("rnnt_prep_exp_kernel");
+    if (U1 <= 64) launch_alphabeta<1, 8>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
+    else if (U1 <= 128) launch_alphabeta<2, 8>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
+    else if (U1 <= 256) launch_alphabeta<4, 4>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
+    else if (U1 <= 512) launch_alphabeta<8, 2>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
+    else launch_alphabeta<16, 1>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
+    ttmi_probe_end(1, st);
+    TTMI_LAUNCH_CHECK("rnnt_alphabeta_kernel");
+    return TTMI_OK;
+}
+
+int ttmi_rnnt_loss_bwd_exp(void* P, long ldv, const int* labels, const int* act_lens, const int* label_lens, int B, int T, int U1,
+                           int V, int blank, const void* workspace, const float* grad_out, int grad_out_stride, float scale,
+                           float* srow, void* srow16, void* stream) {
+    TTMI_REQUIRE(P && (labels || U1 == 1) && act_lens && label_lens && workspace && grad_out && srow && srow16,
+                 "rnnt_loss_bwd_exp: null pointer");
+    TTMI_REQUIRE(B > 0 && T > 0 && U1 > 0 && V > 0 && ldv >= V, "rnnt_loss_bwd_exp: bad shape");
+    TTMI_REQUIRE(blank >= 0 && blank < V, "rnnt_loss_bwd_exp: blank %d outside [0,%d)", blank, V);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Ws w = carve(const_cast<void*>(workspace), B, T, U1);
+    const long rows = (long)B * T * U1;
+    ttmi_probe_begin(2, st);
+    hipLaunchKernelGGL(rnnt_scale_exp_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, st, static_cast<bf16_t*>(P), ldv, labels,
+                       act_lens, label_lens, B, T, U1, V, blank, w.lse, w.alpha, w.beta, w.ll, grad_out, grad_out_stride, scale,
+                       srow, static_cast<bf16_t*>(srow16));
+    ttmi_probe_end(2, st);
+    TTMI_LAUNCH_CHECK("rnnt_scale_exp_kernel");
     return TTMI_OK;
 }
 

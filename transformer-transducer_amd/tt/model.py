@@ -46,8 +46,11 @@ class _JointLossFn(torch.autograd.Function):
     logits + gradient -> 0.44 GB per chunk of 2 utterances; C5: 55.8 GB -> 3.5 GB per utterance).  backward() only scales by the
     incoming gradient."""
 
+    # exp-domain fast path: device scalars (shift used by this step, shift gathered for the next one), per device
+    _shift = {}
+
     @staticmethod
-    def forward(ctx, enc, dec, wf, bf, wp, bp, labels, act_lens, label_lens, prec, chunk, reduction):
+    def forward(ctx, enc, dec, wf, bf, wp, bp, labels, act_lens, label_lens, prec, chunk, reduction, exp_domain):
         enc, dec = enc.contiguous(), dec.contiguous()
         params = (wf, bf, wp, bp)
         wf_, bf_, wp_, bp_ = (t.detach() for t in params)
@@ -60,16 +63,42 @@ class _JointLossFn(torch.autograd.Function):
         if need:
             denc, ddec = torch.empty_like(enc), torch.empty_like(dec)
             g = {n: torch.zeros_like(t) for n, t in zip(("wf", "bf", "wp", "bp"), params)}
+        J, V = wf.shape[0], wp.shape[0]
+        if exp_domain:
+            state = _JointLossFn._shift.get(enc.device)
+            if state is None:
+                # first use on this device: one look at a sample of real logits (32 frames of the first utterance) sets the shift,
+                # so that a model whose logits are already large (a loaded checkpoint) cannot overflow exp() on its first step.
+                # The only host synchronisation of this path; afterwards the loss kernels hand the next step's shift over on the device.
+                sample = ops.joint_fwd(enc[:1, :32].contiguous(), dec[:1].contiguous(), wf_, bf_, wp_, bp_, prec)[0]
+                top = float(sample.float().max())
+                state = (torch.full((1,), max(0.0, top - 40.0), device=enc.device), torch.zeros(1, device=enc.device))
+                _JointLossFn._shift[enc.device] = state
+                del sample
+            cur, nxt = state
         for c0 in range(0, B, chunk):
             c1 = min(B, c0 + chunk)
-            logits, saved = ops.joint_fwd(enc[c0:c1], dec[c0:c1], wf_, bf_, wp_, bp_, prec)
             ws = ops.rnnt_workspace(c1 - c0, T, U1, enc.device)
             lab, al, ll = labels[c0:c1], act_lens[c0:c1], label_lens[c0:c1]
+            if exp_domain and ops.joint_exp_supported(c1 - c0, T, U1, J, V, prec):
+                # the projection stores exp(logit - shift) and row sums; the loss reads two entries per row, its gradient stays
+                # factored as (row factor) x P and is consumed in that form (include/ttmi.h, "fused joint + loss fast path")
+                P, rowsum, saved = ops.joint_fwd_exp(enc[c0:c1], dec[c0:c1], wf_, bf_, wp_, bp_, prec, cur)
+                costs[c0:c1] = ops.rnnt_loss_fwd_exp(P, rowsum, lab, al, ll, 0, ws, cur, nxt)
+                if need:
+                    srow, srow16 = ops.rnnt_loss_bwd_exp(P, lab, al, ll, 0, ws, one, 0, scale)
+                    ops.joint_bwd_exp(P, srow, srow16, enc[c0:c1], dec[c0:c1], wf_, wp_, saved, prec, g, out=(denc[c0:c1], ddec[c0:c1]))
+                del P, rowsum, saved
+                continue
+            logits, saved = ops.joint_fwd(enc[c0:c1], dec[c0:c1], wf_, bf_, wp_, bp_, prec)
             costs[c0:c1] = ops.rnnt_loss_fwd(logits, lab, al, ll, 0, ws)
             if need:
                 grad = ops.rnnt_loss_bwd(logits, lab, al, ll, 0, ws, one, 0, scale, inplace=True)
                 ops.joint_bwd(grad, enc[c0:c1], dec[c0:c1], wf_, wp_, saved, prec, g, out=(denc[c0:c1], ddec[c0:c1]))
             del logits, saved
+        if exp_domain:
+            cur.copy_(nxt)
+            nxt.zero_()
         if need:
             ctx.save_for_backward(denc, ddec, *g.values())
         ctx.params = params
@@ -94,7 +123,7 @@ class _JointLossFn(torch.autograd.Function):
                     cb()
             else:
                 rets.append(gp * gout)
-        return (denc * gout, ddec * gout, *rets, None, None, None, None, None, None)
+        return (denc * gout, ddec * gout, *rets, None, None, None, None, None, None, None)
 
 
 class JointNet(nn.Module):
@@ -192,12 +221,16 @@ class Transducer(nn.Module):
     def forward(self, inputs, targets):
         return self.joint(*self._encode(inputs, targets))
 
-    def loss(self, inputs, inputs_length, targets, targets_length, reduction="mean", chunk=None, check_lengths=True):
+    def loss(self, inputs, inputs_length, targets, targets_length, reduction="mean", chunk=None, check_lengths=True, exp_domain=False):
         """Opt-in fused form of train.py:51-53 (`logits = model(inputs, targets); loss = criterion(logits, targets.int(),
         inputs_length.int(), targets_length.int())`) that never materialises the logits (API precedent: tt_espnet/model.py:35-81 returns
         the loss from forward).  Same numbers as the two-call form: the same kernels run, one chunk of `chunk` utterances at a time
         (default: about 2 GB of logits per chunk, adjusted to a row count the persistent wgrad kernel takes), and the chunk's buffer is overwritten by its gradient and consumed by the
-        joint's backward before the next chunk starts.  Returns the loss ([1] for 'mean' / 'sum', [B] for 'none')."""
+        joint's backward before the next chunk starts.  Returns the loss ([1] for 'mean' / 'sum', [B] for 'none').
+
+        exp_domain=True (bf16 mode, training-sized chunks; silently the form above otherwise): the projection stores exp(logit - shift) and
+        per-row sums, so the loss never walks the lattice's rows and its gradient is consumed in factored form (include/ttmi.h).  Same
+        loss and gradients up to bf16 rounding of different intermediates (tests/test_fused_loss_gpu.py states the tolerance)."""
         from warprnnt_pytorch import check_lengths as certify
         enc_state, dec_state = self._encode(inputs, targets)
         B, T, U1 = enc_state.shape[0], enc_state.shape[1], dec_state.shape[1]
@@ -206,17 +239,19 @@ class Transducer(nn.Module):
         ops.weights_fresh()
         prec = default_precision()
         if chunk is None:
-            chunk = self.default_loss_chunk(B, T, U1)
+            chunk = self.default_loss_chunk(B, T, U1, exp_domain)
         j = self.joint
         return _JointLossFn.apply(enc_state, dec_state, j.forward_layer.weight, j.forward_layer.bias, j.project_layer.weight,
-                                  j.project_layer.bias, labels, al, ll, prec, int(chunk), reduction)
+                                  j.project_layer.bias, labels, al, ll, prec, int(chunk), reduction, bool(exp_domain))
 
-    def default_loss_chunk(self, B, T, U1):
-        """utterances per chunk of `loss()`: about 2 GB of logits, adjusted to a lattice-row count the joint's persistent wgrad kernel takes (a
-        reduction length chunk * T * U1 that is a multiple of its 64-row K-tile; other lengths fall to the 128x128 kernel at twice the time:
-        C2, 8 utterances 9.5 ms per step, 16 utterances 5.3 ms)"""
+    def default_loss_chunk(self, B, T, U1, exp_domain=False):
+        """utterances per chunk of `loss()`: about 2 GB of logits (the memory-saving form) or 16 GB (exp_domain: the speed form - every
+        chunk boundary costs a pipeline fill of the three big GEMMs, C2 whole batch 35.0 ms per step, two halves 36.2), adjusted to a
+        lattice-row count the joint's persistent wgrad kernel takes (a reduction length chunk * T * U1 that is a multiple of its 64-row
+        K-tile; other lengths fall to the 128x128 kernel at twice the time: C2, 8 utterances 9.5 ms per step, 16 utterances 5.3 ms)"""
         es = 2 if ops.joint_logits_dtype(default_precision(), self.joint.forward_layer.out_features) is torch.bfloat16 else 4
-        chunk = max(1, min(B, int((2 << 30) // (es * T * U1 * self.config.vocab_size))))
+        budget = (16 << 30) if exp_domain else (2 << 30)
+        chunk = max(1, min(B, int(budget // (es * T * U1 * self.config.vocab_size))))
         ok = [c for c in range(1, B + 1) if (c * T * U1) % 64 == 0]
         if ok:
             chunk = max([c for c in ok if c <= chunk] or [min(ok)])

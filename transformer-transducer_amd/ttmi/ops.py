@@ -292,6 +292,69 @@ def joint_bwd(dlogits, enc, dec, wf, wp, ctx, prec, grads, out=None):
     return denc, ddec
 
 
+# ---- fused joint + loss fast path (exp-domain forms, include/ttmi.h)
+def joint_exp_supported(B, T, U1, J, V, prec):
+    ldv = (V + 63) // 64 * 64
+    return bool(lib().ttmi_joint_exp_supported(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(V), c_int(prec), c_long(ldv)))
+
+
+def joint_fwd_exp(enc, dec, wf, bf, wp, bp, prec, shift=None):
+    """-> (P bf16 [B,T,U1,V] view of a pitch-roundup(V,64) buffer = exp(logits - shift), rowsum f32 [nparts, B*T*U1], ctx)"""
+    B, T, de = enc.shape
+    U1, dd = dec.shape[1], dec.shape[2]
+    J, V = wf.shape[0], wp.shape[0]
+    L_ = lib()
+    L_.ttmi_joint_ctx_floats.restype = ctypes.c_size_t
+    L_.ttmi_joint_ws_floats.restype = ctypes.c_size_t
+    ctx = _f32(L_.ttmi_joint_ctx_floats(c_int(B), c_int(T), c_int(U1), c_int(J)), enc.device)
+    ws = scratch(L_.ttmi_joint_ws_floats(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(V)), enc.device)
+    buf, P = padded_empty((B, T, U1, V), torch.bfloat16, enc.device)
+    nparts = L_.ttmi_joint_exp_nparts(c_int(V))
+    rowsum = torch.empty(nparts, B * T * U1, dtype=torch.float32, device=enc.device)
+    check(L_.ttmi_joint_fwd_exp(_p(enc), _p(dec), _p(wf), _p(bf), _p(wp), _p(bp), c_int(B), c_int(T), c_int(U1), c_int(de),
+                                c_int(dd), c_int(J), c_int(V), c_int(prec), _p(ctx), _p(ws), _p(P), c_long(buf.shape[-1]),
+                                _p(rowsum), c_int(nparts), _p(shift), _stream()), "ttmi_joint_fwd_exp")
+    return P, rowsum, ctx
+
+
+def rnnt_loss_fwd_exp(P, rowsum, labels, act_lens, label_lens, blank, workspace, shift_cur=None, shift_next=None):
+    _need_cuda(P, rowsum, labels, act_lens, label_lens, workspace)
+    B, T, U1, V = P.shape
+    costs = torch.empty(B, dtype=torch.float32, device=P.device)
+    check(lib().ttmi_rnnt_loss_fwd_exp(_p(P), c_long(row_pitch(P)), _p(rowsum), c_int(rowsum.shape[0]), _p(labels), _p(act_lens),
+                                       _p(label_lens), c_int(B), c_int(T), c_int(U1), c_int(V), c_int(blank), _p(workspace),
+                                       _p(costs), _p(shift_cur), _p(shift_next), _stream()), "ttmi_rnnt_loss_fwd_exp")
+    return costs
+
+
+def rnnt_loss_bwd_exp(P, labels, act_lens, label_lens, blank, workspace, grad_out, grad_out_stride, scale):
+    """patches P in place -> (srow f32 [rows], srow16 bf16 [rows]): d logits = srow[r] * P[r, :]"""
+    B, T, U1, V = P.shape
+    rows = B * T * U1
+    srow = torch.empty(rows, dtype=torch.float32, device=P.device)
+    srow16 = torch.empty(rows, dtype=torch.bfloat16, device=P.device)
+    check(lib().ttmi_rnnt_loss_bwd_exp(_p(P), c_long(row_pitch(P)), _p(labels), _p(act_lens), _p(label_lens), c_int(B), c_int(T),
+                                       c_int(U1), c_int(V), c_int(blank), _p(workspace), _p(grad_out), c_int(grad_out_stride),
+                                       c_float(scale), _p(srow), _p(srow16), _stream()), "ttmi_rnnt_loss_bwd_exp")
+    return srow, srow16
+
+
+def joint_bwd_exp(P, srow, srow16, enc, dec, wf, wp, ctx, prec, grads, out=None):
+    B, T, de = enc.shape
+    U1, dd = dec.shape[1], dec.shape[2]
+    J, V = wf.shape[0], wp.shape[0]
+    L_ = lib()
+    L_.ttmi_joint_ws_floats.restype = ctypes.c_size_t
+    ws = scratch(L_.ttmi_joint_ws_floats(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(V)), enc.device)
+    denc, ddec = (torch.empty_like(enc), torch.empty_like(dec)) if out is None else out
+    assert denc.is_contiguous() and ddec.is_contiguous() and denc.shape == enc.shape and ddec.shape == dec.shape
+    check(L_.ttmi_joint_bwd_exp(_p(P), c_long(row_pitch(P)), _p(srow), _p(srow16), _p(enc), _p(dec), _p(wf), _p(wp), c_int(B),
+                                c_int(T), c_int(U1), c_int(de), c_int(dd), c_int(J), c_int(V), c_int(prec), _p(ctx), _p(ws),
+                                _p(denc), _p(ddec), _p(grads["wf"]), _p(grads["bf"]), _p(grads["wp"]), _p(grads["bp"]), _stream()),
+          "ttmi_joint_bwd_exp")
+    return denc, ddec
+
+
 def embed_fwd(tokens, W):
     _need_cuda(tokens, W)
     if tokens.dtype is not torch.long:          # the kernel reads int64 ids; nn.Embedding (tt/decoder.py:26) also takes int32
