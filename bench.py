@@ -160,6 +160,7 @@ def main():
                          "fused: Transducer.loss, chunked, the same kernels without holding the logits (memory form).  exp: Transducer.loss(exp_domain=True), "
                          "the projection stores exp(logit - shift) + row sums and the loss never walks the lattice's rows (speed form; bf16 only).  "
                          "auto = exp in bf16 train mode, two-call otherwise.  Whatever runs first, the JSON line also carries the two-call form's timing.")
+    ap.add_argument("--fused-loss", action="store_true", help="same as --loss-form fused")
     ap.add_argument("--loss-chunk", type=int, default=0, help="utterances per chunk of the fused loss (0 = default: logits chunk <= 2 GB)")
     ap.add_argument("--emit-rate", type=float, default=0.1, help="decode mode: fraction of frames that emit a symbol (blank bias is set for it)")
     args = ap.parse_args()
@@ -218,7 +219,7 @@ def main():
         if kv:
             ops.set_option(int(kv.split(":")[0]), int(kv.split(":")[1]))
 
-    form = args.loss_form
+    form = "fused" if args.fused_loss and args.loss_form == "auto" else args.loss_form
     if form == "auto":
         form = "exp" if args.precision == "bf16" else "two-call"
 

@@ -840,12 +840,32 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
     // persist, see DESIGN.md - and is gone)
     int bm = 0, bn = 0;
     bool live = tile_id(0) < ntiles;               // the ids of one round are a permutation of it*grid .. it*grid + grid - 1
+    // LEAN 1 / 3 (bias and exp-store epilogues): the accumulators START as the bias of their column - nothing is added in the epilogue -
+    // read from a per-wave LDS row (64 floats) that the previous tile's epilogue filled for this tile's columns.  Columns beyond N hold
+    // -3e38 in the exp-store form: exp2 of it is the exact zero the padded pitch needs.
+    constexpr bool BIAS_INIT = LEAN == 1 || LEAN == 3;
+    float* brow = reinterpret_cast<float*>(smem + 2 * BUF8 + 16384 + wave * 256);
+    auto bias_of = [&](int bn_) -> float {
+        const int col = bn_ + wc * 64 + lane;
+        return col < p.N ? (p.bias ? p.bias[col] : 0.f) : (LEAN == 3 ? -3.0e38f : 0.f);
+    };
     if (live) { coords(tile_id(0), bm, bn); sources(bm, bn); prologue(); }
+    if constexpr (BIAS_INIT) { if (live) brow[lane] = bias_of(bn); }
+    const float eshift2 = (LEAN == 3 && p.exp_shift ? *p.exp_shift : 0.f) * 1.4426950408889634f;
     for (int it = 0; it < rounds && live; ++it) {
+        if constexpr (BIAS_INIT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(brow + j * 16 + (lane >> 4) * 4);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i][j] = b4;
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         V8_BAR();
@@ -882,7 +902,14 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
 
         const int cbm = bm, cbn = bn;
         live = tile_id(it + 1) < ntiles;
-        if (live) { coords(tile_id(it + 1), bm, bn); sources(bm, bn); prologue(); }
+        if (live) {
+            coords(tile_id(it + 1), bm, bn);
+            float nb = 0.f;
+            if constexpr (BIAS_INIT) nb = bias_of(bn);     // requested before the operand prefetch, landed by the time that is issued
+            sources(bm, bn);
+            prologue();
+            if constexpr (BIAS_INIT) brow[lane] = nb;      // this tile's row was consumed when its accumulators were set
+        }
 
         // epilogue of (cbm, cbn): acc[mi][ni][j] = C[cbm + wr*128 + mi*16 + (lane & 15)][cbn + wc*64 + ni*16 + (lane >> 4)*4 + j]
         // -> private f32 image [16 rows][64 cols], 16-byte chunk c of row r at slot c ^ r -> rows of 256 B
@@ -897,23 +924,9 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
         // they are never indexed dynamically (which would put all 128 of them in scratch)
 #define V8_SLAB(I) case I: _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) \
             *reinterpret_cast<f32x4*>(img + wrow * 256 + (((ni * 4 + wq) ^ wrow) << 4)) = acc[I][ni]; break;
-        // LEAN: everything that does not depend on the slab is formed once per tile - the lane's 8 bias values, its column test and its row-0
-        // output address
+        // LEAN: everything that does not depend on the slab is formed once per tile - the lane's column test and its row-0 output address
         const int ln0 = cbn + wc * 64 + (lane & 7) * 8;
         const bool lfull = ln0 + 7 < p.N;
-        float lb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (LEAN == 1 && p.bias && lfull) {
-            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + ln0), b1 = *reinterpret_cast<const float4*>(p.bias + ln0 + 4);
-            lb[0] = b0.x; lb[1] = b0.y; lb[2] = b0.z; lb[3] = b0.w; lb[4] = b1.x; lb[5] = b1.y; lb[6] = b1.z; lb[7] = b1.w;
-        }
-        float lb3[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const float eshift2 = (LEAN == 3 && p.exp_shift ? *p.exp_shift : 0.f) * 1.4426950408889634f;
-        if constexpr (LEAN == 3) {
-            if (p.bias) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) lb3[j] = ln0 + j < p.N ? p.bias[ln0 + j] : 0.f;
-            }
-        }
         const int lm0 = cbm + wr * 128 + (lane >> 3);
         bf16_t* lrow0 = reinterpret_cast<bf16_t*>(p.C) + (long)lm0 * p.ldc + ln0;
         // LEAN 2: the mask vectors of slab mi + 1 are requested before slab mi goes through its LDS transposes and stores
@@ -924,6 +937,70 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
             for (int q = 0; q < 2; ++q)
                 if (lfull && lm0 + mi * 16 + q * 8 < p.M) dst[q] = *reinterpret_cast<const u32x4*>(lmask0 + (long)(mi * 16 + q * 8) * p.ldc);
         };
+        if constexpr (LEAN == 1 || LEAN == 3) {
+            // bias / exp epilogues (the K = 1024 projection, where the un-overlapped epilogue is a third of the tile): the bias is already
+            // in the accumulators, the values are rounded to bf16 BEFORE the transposing trip through LDS (half the LDS traffic of
+            // the f32 image), and the trip of slab s overlaps the arithmetic of slab s + 1 (DS operations of a wave execute in order: the
+            // next slab's writes cannot overtake this slab's reads of the same image).
+            // Image: 16 rows x 128 B; the 8-byte piece c = 4 ni + g of row r sits at piece c ^ (r & ~1): the 32 lanes of a half wave write
+            // 64 distinct banks, the 8 lanes that read one row back take its 128 bytes.
+            const int g = lane >> 4;
+            char* img = smem + 2 * BUF8 + wave * 2048;
+            char* wimg = img + wrow * 128;
+            const int wsw = wrow & ~1;
+            const int rr = lane >> 3, c8 = lane & 7;
+            const long part = (long)((cbn / T8) * 4 + wc) * p.M;
+            u32x4 o[2];
+#pragma unroll
+            for (int sl = 0; sl <= 8; ++sl) {
+                if (sl > 0) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int r = q * 8 + rr;
+                        o[q] = *reinterpret_cast<const u32x4*>(img + r * 128 + (((2 * c8) ^ (r & ~1)) << 3));
+                    }
+                }
+                if (sl < 8) {
+                    f32x4 v[4] = {acc[sl & 7][0], acc[sl & 7][1], acc[sl & 7][2], acc[sl & 7][3]};     // unrolled: a static index
+                    float rs = 0.f;
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        if constexpr (LEAN == 3) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                v[ni][j] = __builtin_amdgcn_exp2f(v[ni][j] * 1.4426950408889634f - eshift2);
+                                rs += v[ni][j];
+                            }
+                        }
+                        const uint2 w = {pack_bf16x2(v[ni][0], v[ni][1]), pack_bf16x2(v[ni][2], v[ni][3])};
+                        *reinterpret_cast<uint2*>(wimg + (((ni * 4 + g) ^ wsw) << 3)) = w;
+                    }
+                    if constexpr (LEAN == 3) {
+                        rs += __shfl_xor(rs, 16, 64);
+                        rs += __shfl_xor(rs, 32, 64);
+                        const int m = cbm + wr * 128 + sl * 16 + wrow;
+                        if (g == 0 && m < p.M) p.rowsum[part + m] = rs;       // part-major: 16 consecutive rows per store
+                    }
+                }
+                if (sl > 0) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int m = lm0 + (sl - 1) * 16 + q * 8;
+                        if (m < p.M) {
+                            bf16_t* dst = lrow0 + (long)((sl - 1) * 16 + q * 8) * p.ldc;
+                            if (ln0 + 7 < (LEAN == 3 ? (int)p.ldc : p.N)) {
+                                if (p.nt) __builtin_nontemporal_store(o[q], reinterpret_cast<u32x4*>(dst));
+                                else *reinterpret_cast<u32x4*>(dst) = o[q];
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 8; ++j)
+                                    if (ln0 + j < (LEAN == 3 ? (int)p.ldc : p.N)) dst[j] = (bf16_t)(o[q][j >> 1] >> ((j & 1) * 16));
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
         if constexpr (MASKED) mask_fetch(0, mkc);
 #pragma unroll 1
         for (int mi = 0; mi < 8; ++mi) {
@@ -937,38 +1014,11 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                     const int c8 = lane & 7;
                     const f32x4 x0 = *reinterpret_cast<const f32x4*>(img + r * 256 + (((2 * c8) ^ r) << 4));
                     const f32x4 x1 = *reinterpret_cast<const f32x4*>(img + r * 256 + (((2 * c8 + 1) ^ r) << 4));
-                    if constexpr (LEAN == 3) {
-                        // exp store: every lane of the wave takes part (the row sum is a shuffle over the 8 lanes that share a row)
-                        const int m = lm0 + mi * 16 + q * 8;
-                        const float xs[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-                        float e[8], rs = 0.f;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const float z = xs[j] + lb3[j];
-                            e[j] = (ln0 + j < p.N) ? __builtin_amdgcn_exp2f(z * 1.4426950408889634f - eshift2) : 0.f;
-                            rs += e[j];
-                        }
-                        rs += __shfl_xor(rs, 1, 64);
-                        rs += __shfl_xor(rs, 2, 64);
-                        rs += __shfl_xor(rs, 4, 64);
-                        if (m < p.M) {
-                            if ((lane & 7) == 0) p.rowsum[(long)((cbn / T8) * 4 + wc) * p.M + m] = rs;      // part-major: rows of one part are contiguous
-                            bf16_t* dst = lrow0 + (long)(mi * 16 + q * 8) * p.ldc;
-                            if (ln0 + 7 < p.ldc) {
-                                const u32x4 o = {pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]), pack_bf16x2(e[4], e[5]), pack_bf16x2(e[6], e[7])};
-                                if (p.nt) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(dst));
-                                else *reinterpret_cast<u32x4*>(dst) = o;
-                            } else {
-#pragma unroll
-                                for (int j = 0; j < 8; ++j)
-                                    if (ln0 + j < p.ldc) dst[j] = f32_to_bf16(e[j]);
-                            }
-                        }
-                    } else if constexpr (LEAN) {
+                    if constexpr (MASKED) {
                         const int m = lm0 + mi * 16 + q * 8;
                         if (lfull) {
                             if (m < p.M) {
-                                float v[8] = {x0[0] + lb[0], x0[1] + lb[1], x0[2] + lb[2], x0[3] + lb[3], x1[0] + lb[4], x1[1] + lb[5], x1[2] + lb[6], x1[3] + lb[7]};
+                                float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
                                 if constexpr (LEAN == 2) {         // one 16-byte read of the mask operand (same layout as the output)
                                     const u32x4 mk = mkc[q];
 #pragma unroll
@@ -1001,7 +1051,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                             for (int j = 0; j < 8; ++j)
                                 if (ln0 + j < p.N)
                                 {
-                                    float y = (j < 4 ? x0[j] : x1[j - 4]) + (LEAN == 1 && p.bias ? p.bias[ln0 + j] : 0.f);
+                                    float y = j < 4 ? x0[j] : x1[j - 4];
                                     if constexpr (LEAN == 2) {
                                         const float mv = bf16_to_f32(p.mask[(long)m * p.ldc + ln0 + j]);
                                         y = p.mask_mode ? y * (1.f - mv * mv) : (mv > 0.f ? y * p.scale : 0.f);
@@ -1030,6 +1080,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                 epi_store4<TC>(p, C, m, n0, x, vec);
             }
             }
+        }
         }
     }
 #undef V8_SLAB

@@ -269,6 +269,10 @@ class Transducer(nn.Module):
             # host order: the audio encoder's long kernels are queued FIRST, the label encoder's ~400 tiny launches are issued while the
             # GPU is busy with them (issued first, they left the chip nearly idle for the ~1 ms the host needs to enqueue them)
             enc_state = self.encoder(inputs, audio_mask)
+            # `targets` lives in the main stream's pool but is read by side-stream kernels - in backward as late as the embedding
+            # gradient, the label encoder's last launch: without this its block could be handed to a main-stream allocation (and
+            # overwritten) as soon as autograd drops the graph, while that launch is still queued
+            targets.record_stream(side)
             with torch.cuda.stream(side):
                 dec_state = self.decoder(targets, MaskSpec(1))
             main.wait_stream(side)
