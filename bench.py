@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "decode"],
                     help="train = the metric (default); decode = greedy decode of the C2 model (SURVEY §8 A10) with the oracle's loop beside it")
     ap.add_argument("--no-weight-shadows", action="store_true", help="convert the f32 master weights to bf16 in every call (round-1 behaviour; A/B)")
+    ap.add_argument("--no-grouped-wgrads", action="store_true", help="launch every encoder weight-gradient GEMM on its own (K-split, f32 atomics; A/B switch)")
     ap.add_argument("--loss-form", default="auto", choices=["auto", "exp", "fused", "two-call"],
                     help="how the step gets its loss.  two-call: train.py:51-53 as written (logits = model(inputs, targets); criterion(logits, ...)). "
                          "fused: Transducer.loss, chunked, the same kernels without holding the logits (memory form).  exp: Transducer.loss(exp_domain=True), "
@@ -197,6 +198,8 @@ def main():
     torch.manual_seed(1)                                   # config/aishell.yaml:55 - same init on every rank
     model = Transducer(cfg).to(dev).train()
     flat = FlatModel(model)
+    if args.precision == "bf16" and not args.no_grouped_wgrads:
+        flat.enable_grouped_wgrads()                       # encoder weight gradients four layers at a time: one tile per CU, no K-split atomics
     if args.precision == "bf16" and not args.no_weight_shadows:
         flat.enable_shadows()                              # bf16 weight copies rebuilt once per optimiser step (one launch) instead of per call
     sync = GradSync(flat)

@@ -128,6 +128,35 @@ int ttmi_joint_bwd_exp(const void* P, long ldg, const float* srow, const void* s
                        const float* wf, const float* wp, int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx,
                        float* ws, float* denc, float* ddec, float* g_wf, float* g_bf, float* g_wp, float* g_bp, void* stream);
 
+/* ---- grouped weight gradients (data-parallel hot path): the four weight-gradient GEMMs of an encoder layer are a quarter
+ * of the chip each step; deferred and launched four layers at a time they are 256 tiles, one per CU over the whole reduction - no split along
+ * K, no atomics, bit-identical from run to run and across ranks.  ttmi_attn_bwd_defer / ttmi_ffn_bwd_defer are ttmi_attn_bwd / ttmi_ffn_bwd
+ * minus those GEMMs: the bf16 operands that would have lived in the scratch workspace go to `keep` (ttmi_*_keep_bytes; 256-byte aligned,
+ * caller-owned until the group has run) and `out` receives the problems (2 per call) for ttmi_wgrad_group.  bf16 pipeline only (returns an
+ * error otherwise: callers test ttmi_wgrad_defer_supported first). */
+typedef struct ttmi_wgrad_desc {
+    const void* A;      /* bf16 [K, M], row pitch lda */
+    const void* B;      /* bf16 [K, N], row pitch ldb */
+    float* C;           /* f32 [M, N], row pitch ldc: C += A^T B */
+    float* colsum;      /* nullable, f32 [M]: += column sums of A */
+    int M, N, K;
+    long lda, ldb, ldc;
+} ttmi_wgrad_desc;
+int ttmi_wgrad_group(const ttmi_wgrad_desc* descs /* host array */, int n, void* stream);
+int ttmi_wgrad_defer_supported(long rows, int d, int H, int Dh, int Di, int prec);
+size_t ttmi_attn_bwd_keep_bytes(int B, int L, int d, int H, int Dh);
+size_t ttmi_ffn_bwd_keep_bytes(long rows, int d, int Di);
+int ttmi_attn_bwd_defer(const float* dy, const float* x, const float* qkv_w, const float* o_w, const float* ln_g,
+                        const float* r_emb, const float* r_w_bias, const float* r_bias, int B, int L, int d, int H, int Dh, int K, int mask_kind,
+                        int mask_left, int mask_right, const unsigned char* mask, long mask_sb, long mask_si, int prec,
+                        float p_drop, unsigned seed, const float* ctx, float* ws, float* dx, float* g_qkv_w, float* g_o_w,
+                        float* g_ln_g, float* g_ln_b, float* g_r_emb, float* g_r_w_bias, float* g_r_bias, void* keep,
+                        ttmi_wgrad_desc* out /* 2 entries */, void* stream);
+int ttmi_ffn_bwd_defer(const float* dz, const float* y, const float* w1, const float* w2, const float* ln_g, long rows, int d, int Di,
+                       int prec, float p_drop, float p_layer, unsigned seed, const float* ctx, float* ws, float* dy, float* g_w1,
+                       float* g_b1, float* g_w2, float* g_b2, float* g_ln_g, float* g_ln_b, void* keep,
+                       ttmi_wgrad_desc* out /* 2 entries */, void* stream);
+
 /* ---- greedy decoding support (Transducer.decode, tt/model.py:70-90): logits rows = consecutive frames against one label
  * state; *out (device u64) = (first row whose argmax != blank) << 32 | symbol, or n << 32 if all rows are blank. */
 int ttmi_greedy_scan(const void* logits, int dtype, long ld, int n, int V, int blank, unsigned long long* out, void* stream);

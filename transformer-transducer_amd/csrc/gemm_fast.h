@@ -49,6 +49,14 @@ inline int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, 
 int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
                  hipStream_t st, float* colsum_a = nullptr, const FastBatch& batch = FastBatch(), const bf16_t* colsum_w = nullptr);
 bool gemm_fast_joint_exp_ok(int M, int V, int J, long ldv);   // sizes at which the exp-store / row-scale / weighted-colsum forms exist
+// one weight-gradient problem of a grouped launch: C[M,N] += A[K,M]^T B[K,N] (bf16 operands, f32 C), colsum (nullable, f32 [M]) += column sums of A
+struct TnProblem {
+    const bf16_t* A; const bf16_t* B; float* C; float* colsum;
+    int M, N, K;
+    long lda, ldb, ldc;
+};
+bool gemm_tn_group_fits(const TnProblem& q);
+int gemm_tn_bf16_group(const TnProblem* probs, int n, hipStream_t st);   // deterministic (no atomics) for problems that fit the 256x128 tiling
 void gemm_fast_set_version(int v);   // kernel generation for A/B runs, see gemm_fast.hip (default 4)
 void gemm_fast_set_tn_target(int n);
 void gemm_fast_set_reserved_cus(int n);   // process-wide default (measurement switch)

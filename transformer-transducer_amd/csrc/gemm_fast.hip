@@ -13,6 +13,7 @@
 // Workgroups are renumbered so the 8 that share an XCD (ids equal mod 8) walk a compact 8x8-tile window
 // (A and B panels of ~2 MB each stay in that XCD's 4 MB L2).
 #include "gemm_fast.h"
+#include "ttmi.h"
 #include <mutex>
 
 namespace {
@@ -1976,6 +1977,190 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v9_kernel(const FP p) {
 #undef V9_BAR
 }
 
+// =====================================================================================================================
+// Grouped TN: the weight-gradient GEMMs of several encoder layers in ONE launch (C_q[M_q,N_q] += A_q[K_q,M_q]^T B_q[K_q,N_q], q < 16).
+// A layer's four wgrads are 64 tiles of 256 x 128 - a quarter of the chip - which is why they used to be cut along K into ranges added
+// up with f32 atomics (a third of each launch, and a result that depends on the order the atomics land in).  Four layers together are
+// 256 tiles: every workgroup takes ONE tile over its whole reduction (K = B*T: 250 K-tiles of TN v9's schedule, no split, no atomics),
+// adds it to C with plain read-modify-write (one writer per element: bit-identical from run to run and across ranks), and the tiles of
+// one problem sit on one XCD so that its L2 serves each operand panel to all the tiles that share it.
+// Optional column sums of A_q (the bias gradient that belongs to the wgrad): the all-ones MFMA of TN v9, dealt out so that every row
+// has ONE owner - 16-row tile mt of wave row wr goes to the wave with tn * 2 + wc == mt (column tiles 0 and 1) - and added with plain
+// stores as well.  Needs N_q / 128 >= 2.
+// =====================================================================================================================
+struct TnGroupProb {
+    const bf16_t* A; const bf16_t* B; float* C; float* colsum;
+    int M, N, K, tiles_m;
+    long lda, ldb, ldc;
+    int tile0;                      // first tile of this problem in the launch's tile list
+};
+struct TnGroup {
+    TnGroupProb pr[16];
+    int n, total;
+};
+
+__global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_group_kernel(const TnGroup g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave & 3, wc = wave >> 2;
+    const int grp = wave >> 2;
+    const int xcd = blockIdx.x & 7, cu = blockIdx.x >> 3, ncu = gridDim.x >> 3;
+    const int per_x = (g.total + 7) / 8;                   // XCD x owns tiles [x * per_x, (x + 1) * per_x): consecutive tiles = one problem's
+    const int hi = min((xcd + 1) * per_x, g.total);
+
+    unsigned oA[4], oB[2];
+    const char* baseA = nullptr;
+    const char* baseB = nullptr;
+    long lda = 0, ldb = 0;
+    int nk = 0, q = 0;
+    auto item = [&](int it, int& bm, int& bn, int& tn) {
+        q = 0;
+        while (q + 1 < g.n && it >= g.pr[q + 1].tile0) ++q;
+        const TnGroupProb& pr = g.pr[q];
+        const int t = it - pr.tile0;
+        bm = (t % pr.tiles_m) * T9M;
+        tn = t / pr.tiles_m;
+        bn = tn * T9N;
+        lda = pr.lda; ldb = pr.ldb;
+        nk = pr.K / TK;
+        baseA = reinterpret_cast<const char*>(pr.A);
+        baseB = reinterpret_cast<const char*>(pr.B);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = (wave * 4 + j) * 2 + (lane >> 5);
+            const int c = (lane & 31) ^ (((k & 3) << 2) | (((k >> 3) & 1) << 1));
+            oA[j] = (unsigned)((k * lda + bm + c * 8) * 2);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = (wave * 2 + j) * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ (((k & 3) << 2) | (((k >> 3) & 1) << 1));
+            oB[j] = (unsigned)((k * ldb + bn + c * 8) * 2);
+        }
+    };
+    auto stage = [&](int stg, int kt) {
+        char* dst = smem + stg * STG9;
+        const char* ba = baseA + (long)kt * TK * lda * 2;
+        const char* bb = baseB + (long)kt * TK * ldb * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(ba + oA[j], dst + (wave * 4 + j) * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(bb + oB[j], dst + T9M * 128 + (wave * 2 + j) * 1024);
+    };
+
+    const int gq = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int swz = (qq << 2) | ((gq & 1) << 1);
+    int aoff[4], boff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ca = wr * 64 + i * 16 + 4 * pp, cb = wc * 64 + i * 16 + 4 * pp;
+        aoff[i] = (gq * 8 + qq) * 512 + (((ca >> 3) ^ swz) << 4) + (ca & 7) * 2;
+        boff[i] = T9M * 128 + (gq * 8 + qq) * 256 + (((cb >> 3) ^ swz) << 4) + (cb & 7) * 2;
+    }
+    f32x4 acc[4][4];
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[4][2], bfr[4][2];
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+#define V9_BAR() __builtin_amdgcn_s_barrier()
+
+    int bm = 0, bn = 0, tn = 0;
+    int it = xcd * per_x + cu;
+    bool live = it < hi;
+    if (live) { item(it, bm, bn, tn); stage(0, 0); if (nk > 1) stage(1, 1); }
+    while (live) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        cs = f32x4{0.f, 0.f, 0.f, 0.f};
+        const TnGroupProb cur = g.pr[q];
+        const int cs_mt = (cur.colsum && tn < 2) ? __builtin_amdgcn_readfirstlane(tn * 2 + wc) : -1;
+        const int cnk = nk;
+        if (cnk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        V9_BAR();
+        if (grp == 1) V9_BAR();
+        int stg = 0;
+        for (int t = 0; t < cnk; ++t) {
+            const unsigned base = lds0 + stg * STG9;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned a = base + aoff[i];
+                    bf16x4 lo, hi2;
+                    if (ks == 0) { LDS_TR(lo, a, 0); LDS_TR(hi2, a, 4 * 512); }
+                    else { LDS_TR(lo, a, 32 * 512); LDS_TR(hi2, a, 36 * 512); }
+                    af[i][ks] = __builtin_shufflevector(lo, hi2, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned bq = base + boff[i];
+                    bf16x4 lo, hi2;
+                    if (ks == 0) { LDS_TR(lo, bq, 0); LDS_TR(hi2, bq, 4 * 256); }
+                    else { LDS_TR(lo, bq, 32 * 256); LDS_TR(hi2, bq, 36 * 256); }
+                    bfr[i][ks] = __builtin_shufflevector(lo, hi2, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            }
+            if (t + 2 < cnk) {
+                stage(stg == 0 ? 2 : stg - 1, t + 2);
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            V9_BAR();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt][ks], af[mt][ks], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                if (cs_mt == mt) {
+                    cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[mt][0], cs, 0, 0, 0);
+                    cs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[mt][1], cs, 0, 0, 0);
+                }
+            __builtin_amdgcn_s_setprio(0);
+            V9_BAR();
+            stg = stg == 2 ? 0 : stg + 1;
+        }
+        if (grp == 0) V9_BAR();
+
+        const int cbm = bm, cbn = bn;
+        it += ncu;
+        live = it < hi;
+        if (live) { item(it, bm, bn, tn); stage(0, 0); if (nk > 1) stage(1, 1); }
+
+        // C += tile: 16 rows at a time through a private LDS image in stage 2 (free until the next tile's K-tile 2), one 256-byte row per
+        // instruction; this workgroup is the only writer of these elements
+        float* img = reinterpret_cast<float*>(smem + 2 * STG9 + wave * 4096);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                *reinterpret_cast<f32x4*>(img + (lane & 15) * 64 + ((ni * 4 + (lane >> 4)) ^ (lane & 15)) * 4) = acc[mi][ni];
+            float* crow = cur.C + (long)(cbm + wr * 64 + mi * 16) * cur.ldc + cbn + wc * 64 + lane;
+            float old[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) old[r] = crow[(long)r * cur.ldc];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) crow[(long)r * cur.ldc] = old[r] + img[r * 64 + (((lane >> 2) ^ r) << 2) + (lane & 3)];
+        }
+        if (cs_mt >= 0 && lane < 16) {
+            float* c = cur.colsum + cbm + wr * 64 + cs_mt * 16 + lane;
+            *c = *c + cs[0];
+        }
+    }
+#undef V9_BAR
+}
+
 template <typename K>
 int enable_lds(K kernel, int bytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -2352,7 +2537,53 @@ void gemm_fast_alias_stream(hipStream_t child, hipStream_t parent) {
     if (StreamRes* e = res_entry(dev, child, true)) e->parent = parent;
 }
 
+// Grouped weight gradients (see gemm_tn_bf16_group_kernel).  Problems that do not fit the kernel's tiling run through gemm_tn_bf16 one by one
+// (same results up to the order of their atomics); the rest go out in launches of up to 16 problems.
+bool gemm_tn_group_fits(const TnProblem& q) {
+    return q.A && q.B && q.C && q.M > 0 && q.N > 0 && q.M % T9M == 0 && q.N % T9N == 0 && q.K % TK == 0 && q.K >= 2 * TK && q.lda % 8 == 0 && q.ldb % 8 == 0 && q.lda >= q.M && q.ldb >= q.N && q.ldc >= q.N &&
+           aligned16(q.A) && aligned16(q.B) && (!q.colsum || q.N / T9N >= 2) && (long)q.K * q.lda * 2 < (1L << 32) && (long)q.K * q.ldb * 2 < (1L << 32);
+}
+int gemm_tn_bf16_group(const TnProblem* probs, int n, hipStream_t st) {
+    TTMI_REQUIRE(probs && n >= 0, "gemm_tn_bf16_group: bad arguments");
+    if (g_num_cus == 0) {
+        int dev = 0, cnt = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cnt, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cnt > 0)
+            g_num_cus = cnt / 8 * 8;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    if (int rc = enable_lds(gemm_tn_bf16_group_kernel, LDS9)) return rc;
+    TnGroup g;
+    g.n = 0; g.total = 0;
+    auto flush = [&]() -> int {
+        if (g.n == 0) return TTMI_OK;
+        hipLaunchKernelGGL(gemm_tn_bf16_group_kernel, dim3((unsigned)g_num_cus), dim3(NTH8), LDS9, st, g);
+        TTMI_LAUNCH_CHECK("gemm_tn_bf16_group_kernel");
+        g.n = 0; g.total = 0;
+        return TTMI_OK;
+    };
+    for (int i = 0; i < n; ++i) {
+        const TnProblem& q = probs[i];
+        if (!gemm_tn_group_fits(q)) {
+            if (int rc = gemm_tn_bf16(q.A, q.B, q.C, q.M, q.N, q.K, q.lda, q.ldb, q.ldc, 1, st, q.colsum)) return rc;
+            continue;
+        }
+        TnGroupProb& d = g.pr[g.n];
+        d.A = q.A; d.B = q.B; d.C = q.C; d.colsum = q.colsum; d.M = q.M; d.N = q.N; d.K = q.K; d.tiles_m = q.M / T9M;
+        d.lda = q.lda; d.ldb = q.ldb; d.ldc = q.ldc; d.tile0 = g.total;
+        g.total += d.tiles_m * (q.N / T9N);
+        if (++g.n == 16) { if (int rc = flush()) return rc; }
+    }
+    return flush();
+}
+
 extern "C" {
+// Grouped weight gradients: descs is a HOST array of n problems C[M,N] += A[K,M]^T B[K,N] (bf16 A / B, f32 C; colsum nullable: += column
+// sums of A).  Problems with M % 256 == 0, N % 128 == 0, K % 64 == 0 share launches of the no-atomics grouped kernel (bit-reproducible);
+// anything else runs through ttmi_gemm_tn_bf16's path.
+int ttmi_wgrad_group(const ttmi_wgrad_desc* descs, int n, void* stream) {
+    static_assert(sizeof(ttmi_wgrad_desc) == sizeof(TnProblem), "ttmi_wgrad_desc and TnProblem must share one layout");
+    return gemm_tn_bf16_group(reinterpret_cast<const TnProblem*>(descs), n, static_cast<hipStream_t>(stream));
+}
 // bring-up / test entry points (dtype codes 0 = f32, 1 = bf16)
 int ttmi_gemm_nt_bf16(const void* A, const void* B, void* C, int c_dtype, const float* bias, int M, int N, int K, long lda,
                       long ldb, long ldc, void* stream) {

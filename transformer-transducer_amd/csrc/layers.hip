@@ -10,6 +10,7 @@
 // matrix, so the content GEMM accumulates onto it in place and the softmax runs on that view.  The
 // backward uses the mirror image: dS written through the pitch-L view IS dG in the pitch-(L+1) layout.
 #include "gemm.h"
+#include "ttmi.h"
 #include "rowops.h"
 #include "gemm_fast.h"
 #include "attn_flash.h"
@@ -208,12 +209,13 @@ struct AttnCtx {   // saved for backward.  act = f32 (parity) or bf16 (fast)
     }
 };
 
+static inline size_t keep_al(size_t n) { return (n + 127) & ~(size_t)127; }      // bf16 elements, 256-byte granules
 struct AttnWs {   // scratch (union of forward and backward needs)
     float *E, *cT, *dE, *dcT, *a, *dS, *dqkv, *delta;
     void* dO;
     bf16_t *wqkv16, *wo16, *dqkv16, *dres16, *dS16, *dG16, *E16, *kT16, *ET16;
     long ldp, slab16;
-    AttnWs(Bump& b, const AttnDims& a, bool fast) {
+    AttnWs(Bump& b, const AttnDims& a, bool fast, void* keep = nullptr) {
         E = b.take<float>((size_t)a.L * a.HD);
         cT = b.take<float>((size_t)a.H * a.L);
         dE = b.take<float>((size_t)a.L * a.HD + (size_t)a.H * a.L + 64);   // dE and dcT zeroed together
@@ -236,6 +238,10 @@ struct AttnWs {   // scratch (union of forward and backward needs)
             wo16 = b.take<bf16_t>(a.HD * a.d);
             dqkv16 = b.take<bf16_t>(a.BL * a.W3);
             dres16 = b.take<bf16_t>(a.BL * a.d);
+            if (keep) {      // deferred weight gradients: their A operands must outlive this call (ttmi_attn_bwd_defer)
+                dqkv16 = static_cast<bf16_t*>(keep);
+                dres16 = dqkv16 + keep_al((size_t)a.BL * a.W3);
+            }
         }
     }
 };
@@ -403,11 +409,13 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
 }
 
 // Backward of ttmi_attn_fwd.  dx is written; every g_* buffer is ACCUMULATED into (zero them per step).
-int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const float* o_w, const float* ln_g,
+// keep / out != nullptr: the two weight-gradient GEMMs are described in out[0..1] instead of launched (ttmi_attn_bwd_defer).
+static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, const float* o_w, const float* ln_g,
                   const float* r_emb, const float* r_w_bias, const float* r_bias, int B, int L, int d, int H, int Dh, int K, int mask_kind,
                   int mask_left, int mask_right, const unsigned char* mask, long mask_sb, long mask_si, int prec,
                   float p_drop, unsigned seed, const float* ctx, float* ws, float* dx, float* g_qkv_w, float* g_o_w,
-                  float* g_ln_g, float* g_ln_b, float* g_r_emb, float* g_r_w_bias, float* g_r_bias, void* stream) {
+                  float* g_ln_g, float* g_ln_b, float* g_r_emb, float* g_r_w_bias, float* g_r_bias, void* keep, ttmi_wgrad_desc* out,
+                  void* stream) {
     TTMI_REQUIRE(dy && x && qkv_w && o_w && ln_g && r_emb && r_bias && ctx && ws && dx, "attn_bwd: null pointer");
     TTMI_REQUIRE(g_qkv_w && g_o_w && g_ln_g && g_ln_b && g_r_emb && g_r_w_bias && g_r_bias, "attn_bwd: null gradient pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -416,7 +424,8 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
     const int adt = fast ? DT_BF16 : DT_F32;
     Bump bc(const_cast<float*>(ctx)), bw(ws);
     AttnCtx c(bc, a, fast);
-    AttnWs w(bw, a, fast);
+    AttnWs w(bw, a, fast, keep);
+    TTMI_REQUIRE(!out || (fast && keep && aligned16(keep)), "attn_bwd_defer: bf16 pipeline and a 16-byte aligned keep buffer required");
     const float scale = 1.0f / sqrtf((float)Dh);
     // 1. dres = LN'(dy) -> dx (doubles as the residual gradient)
     // 2. gWo += da^T O ; 3. dO = da Wo, with da = dres * dropout mask of the forward (dres itself stays the residual grad);
@@ -432,7 +441,8 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
     if (fast) {
         Shadow sh;
         const bf16_t* woT16 = shadow_of(o_w, d, (int)a.HD, d, sh) ? sh.wT16 : c.woT16;
-        CK(gemm_tn_bf16(w.dres16, static_cast<bf16_t*>(c.O), g_o_w, d, (int)a.HD, (int)a.BL, d, a.HD, a.HD, 1, fork_stream(st)));
+        if (out) out[0] = ttmi_wgrad_desc{w.dres16, c.O, g_o_w, nullptr, d, (int)a.HD, (int)a.BL, (long)d, (long)a.HD, (long)a.HD};
+        else CK(gemm_tn_bf16(w.dres16, static_cast<bf16_t*>(c.O), g_o_w, d, (int)a.HD, (int)a.BL, d, a.HD, a.HD, 1, fork_stream(st)));
         CK(gemm_nt_bf16(w.dres16, woT16, w.dO, 1, nullptr, (int)a.BL, (int)a.HD, d, d, d, a.HD, st));
     } else {
         CK(wgrad(da, static_cast<float*>(c.O), g_o_w, d, (int)a.HD, (int)a.BL, d, a.HD, a.HD, prec, st));
@@ -539,7 +549,8 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
     // 14. gWqkv += dqkv^T x ; 15. dx += dqkv Wqkv
     if (fast) {
         if (!fastpos) CK(convert_bf16(w.dqkv, w.dqkv16, a.BL * a.W3, st));      // fastpos: dq / dK / dV were written in bf16 by their producers
-        {
+        if (out) out[1] = ttmi_wgrad_desc{w.dqkv16, c.x16, g_qkv_w, nullptr, (int)a.W3, d, (int)a.BL, (long)a.W3, (long)d, (long)d};
+        else {
             hipStream_t fs = fork_stream(st);
             const bool probe = a.BL >= 4096;        // timing probe 4: an audio-sized qkv_net weight gradient, on the stream it is launched on
             if (probe) ttmi_probe_begin(4, fs);
@@ -560,6 +571,31 @@ int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const flo
     }
     join_stream(st);
     return TTMI_OK;
+}
+
+int ttmi_attn_bwd(const float* dy, const float* x, const float* qkv_w, const float* o_w, const float* ln_g,
+                  const float* r_emb, const float* r_w_bias, const float* r_bias, int B, int L, int d, int H, int Dh, int K, int mask_kind,
+                  int mask_left, int mask_right, const unsigned char* mask, long mask_sb, long mask_si, int prec,
+                  float p_drop, unsigned seed, const float* ctx, float* ws, float* dx, float* g_qkv_w, float* g_o_w,
+                  float* g_ln_g, float* g_ln_b, float* g_r_emb, float* g_r_w_bias, float* g_r_bias, void* stream) {
+    return attn_bwd_impl(dy, x, qkv_w, o_w, ln_g, r_emb, r_w_bias, r_bias, B, L, d, H, Dh, K, mask_kind, mask_left, mask_right, mask, mask_sb,
+                         mask_si, prec, p_drop, seed, ctx, ws, dx, g_qkv_w, g_o_w, g_ln_g, g_ln_b, g_r_emb, g_r_w_bias, g_r_bias, nullptr,
+                         nullptr, stream);
+}
+size_t ttmi_attn_bwd_keep_bytes(int B, int L, int d, int H, int Dh) {
+    const size_t BL = (size_t)B * L;
+    return 2 * (keep_al(BL * 3 * H * Dh) + keep_al(BL * d));
+}
+int ttmi_attn_bwd_defer(const float* dy, const float* x, const float* qkv_w, const float* o_w, const float* ln_g,
+                        const float* r_emb, const float* r_w_bias, const float* r_bias, int B, int L, int d, int H, int Dh, int K, int mask_kind,
+                        int mask_left, int mask_right, const unsigned char* mask, long mask_sb, long mask_si, int prec,
+                        float p_drop, unsigned seed, const float* ctx, float* ws, float* dx, float* g_qkv_w, float* g_o_w,
+                        float* g_ln_g, float* g_ln_b, float* g_r_emb, float* g_r_w_bias, float* g_r_bias, void* keep,
+                        ttmi_wgrad_desc* out, void* stream) {
+    TTMI_REQUIRE(keep && out, "attn_bwd_defer: keep buffer and descriptor array required");
+    return attn_bwd_impl(dy, x, qkv_w, o_w, ln_g, r_emb, r_w_bias, r_bias, B, L, d, H, Dh, K, mask_kind, mask_left, mask_right, mask, mask_sb,
+                         mask_si, prec, p_drop, seed, ctx, ws, dx, g_qkv_w, g_o_w, g_ln_g, g_ln_b, g_r_emb, g_r_w_bias, g_r_bias, keep, out,
+                         stream);
 }
 
 // ------------------------------------------------------------------ position-wise FFN (tt/transformer.py:54-58)
@@ -585,7 +621,7 @@ struct FfnWs {
     float *f, *dres, *dh;
     void* da1;
     bf16_t *w1_16, *w2_16, *dres16;
-    FfnWs(Bump& b, long rows, int d, int Di, bool fast) {
+    FfnWs(Bump& b, long rows, int d, int Di, bool fast, void* keep = nullptr) {
         f = b.take<float>(rows * d);
         dres = b.take<float>(rows * d);
         dh = b.take<float>(rows * d);
@@ -595,6 +631,10 @@ struct FfnWs {
             w1_16 = b.take<bf16_t>((size_t)Di * d);
             w2_16 = b.take<bf16_t>((size_t)Di * d);
             dres16 = b.take<bf16_t>(rows * d);
+            if (keep) {      // deferred weight gradients (ttmi_ffn_bwd_defer)
+                da1 = keep;
+                dres16 = static_cast<bf16_t*>(keep) + keep_al((size_t)rows * Di);
+            }
         }
     }
 };
@@ -655,16 +695,17 @@ int ttmi_ffn_fwd(const float* y, const float* w1, const float* b1, const float* 
     return TTMI_OK;
 }
 
-int ttmi_ffn_bwd(const float* dz, const float* y, const float* w1, const float* w2, const float* ln_g, long rows, int d, int Di,
+static int ffn_bwd_impl(const float* dz, const float* y, const float* w1, const float* w2, const float* ln_g, long rows, int d, int Di,
                  int prec, float p_drop, float p_layer, unsigned seed, const float* ctx, float* ws, float* dy, float* g_w1,
-                 float* g_b1, float* g_w2, float* g_b2, float* g_ln_g, float* g_ln_b, void* stream) {
+                 float* g_b1, float* g_w2, float* g_b2, float* g_ln_g, float* g_ln_b, void* keep, ttmi_wgrad_desc* out, void* stream) {
     TTMI_REQUIRE(dz && y && w1 && w2 && ln_g && ctx && ws && dy && g_w1 && g_b1 && g_w2 && g_b2 && g_ln_g && g_ln_b,
                  "ffn_bwd: null pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool fast = ffn_fast(prec, d, Di);
+    TTMI_REQUIRE(!out || (fast && keep && aligned16(keep)), "ffn_bwd_defer: bf16 pipeline and a 16-byte aligned keep buffer required");
     Bump bc(const_cast<float*>(ctx)), bw(ws);
     FfnCtx c(bc, rows, d, Di, fast);
-    FfnWs w(bw, rows, d, Di, fast);
+    FfnWs w(bw, rows, d, Di, fast, keep);
     DropSpec d_out, d_layer;
     d_out.p = p_drop; d_out.seed = seed ^ 0xC3u;
     d_layer.p = p_layer; d_layer.seed = seed ^ 0xD4u;
@@ -688,11 +729,13 @@ int ttmi_ffn_bwd(const float* dz, const float* y, const float* w1, const float* 
         Shadow s1, s2;
         const bf16_t* w1T16 = shadow_of(w1, Di, d, Di, s1) ? s1.wT16 : c.w1T16;
         const bf16_t* w2T16 = shadow_of(w2, d, Di, d, s2) ? s2.wT16 : c.w2T16;
-        CK(gemm_tn_bf16(w.dres16, a1, g_w2, d, Di, (int)rows, d, Di, Di, 1, fork_stream(st)));
+        if (out) out[0] = ttmi_wgrad_desc{w.dres16, a1, g_w2, nullptr, d, Di, (int)rows, (long)d, (long)Di, (long)Di};
+        else CK(gemm_tn_bf16(w.dres16, a1, g_w2, d, Di, (int)rows, d, Di, Di, 1, fork_stream(st)));
         NtEpilogue e;
         e.mask = a1; e.scale = inv_keep;                   // a1 is stored post-dropout: a1 > 0 <=> ReLU active AND kept
         CK(gemm_nt_bf16(w.dres16, w2T16, da1, 1, e, (int)rows, Di, d, d, d, Di, st));
-        CK(gemm_tn_bf16(da1, h, g_w1, Di, d, (int)rows, Di, d, d, 1, fork_stream(st), g_b1));   // g_b1 = column sums of da1, fused
+        if (out) out[1] = ttmi_wgrad_desc{da1, h, g_w1, g_b1, Di, d, (int)rows, (long)Di, (long)d, (long)d};
+        else CK(gemm_tn_bf16(da1, h, g_w1, Di, d, (int)rows, Di, d, d, 1, fork_stream(st), g_b1));   // g_b1 = column sums of da1, fused
         CK(gemm_nt_bf16(da1, w1T16, w.dh, 0, nullptr, (int)rows, d, Di, Di, Di, d, st));
     } else {
         const float* a1 = static_cast<const float*>(c.a1);
@@ -709,6 +752,26 @@ int ttmi_ffn_bwd(const float* dz, const float* y, const float* w1, const float* 
     CK(ln_bwd(w.dh, y, c.mean1, c.rstd1, ln_g, w.dres, rows, d, dy, g_ln_g, g_ln_b, st));
     join_stream(st);
     return TTMI_OK;
+}
+
+int ttmi_ffn_bwd(const float* dz, const float* y, const float* w1, const float* w2, const float* ln_g, long rows, int d, int Di,
+                 int prec, float p_drop, float p_layer, unsigned seed, const float* ctx, float* ws, float* dy, float* g_w1,
+                 float* g_b1, float* g_w2, float* g_b2, float* g_ln_g, float* g_ln_b, void* stream) {
+    return ffn_bwd_impl(dz, y, w1, w2, ln_g, rows, d, Di, prec, p_drop, p_layer, seed, ctx, ws, dy, g_w1, g_b1, g_w2, g_b2, g_ln_g, g_ln_b,
+                        nullptr, nullptr, stream);
+}
+size_t ttmi_ffn_bwd_keep_bytes(long rows, int d, int Di) { return 2 * (keep_al((size_t)rows * Di) + keep_al((size_t)rows * d)); }
+int ttmi_ffn_bwd_defer(const float* dz, const float* y, const float* w1, const float* w2, const float* ln_g, long rows, int d, int Di,
+                       int prec, float p_drop, float p_layer, unsigned seed, const float* ctx, float* ws, float* dy, float* g_w1,
+                       float* g_b1, float* g_w2, float* g_b2, float* g_ln_g, float* g_ln_b, void* keep, ttmi_wgrad_desc* out,
+                       void* stream) {
+    TTMI_REQUIRE(keep && out, "ffn_bwd_defer: keep buffer and descriptor array required");
+    return ffn_bwd_impl(dz, y, w1, w2, ln_g, rows, d, Di, prec, p_drop, p_layer, seed, ctx, ws, dy, g_w1, g_b1, g_w2, g_b2, g_ln_g, g_ln_b,
+                        keep, out, stream);
+}
+// the deferred forms exist on the bf16 pipeline of both sub-layers
+int ttmi_wgrad_defer_supported(long rows, int d, int H, int Dh, int Di, int prec) {
+    return rows > 0 && attn_fast(prec, d, H, Dh) && ffn_fast(prec, d, Di) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------ joint network (tt/model.py:20-39)

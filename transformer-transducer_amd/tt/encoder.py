@@ -31,6 +31,9 @@ class BuildEncoder(nn.Module):
             BaseEncoder(k_len=config.enc.max_input_length, n_head=config.enc.n_head, d_model=config.enc.d_model,
                         d_head=config.enc.d_head, d_inner=config.enc.d_inner, dropout=config.dropout)
             for _ in range(config.enc.n_layer)])
+        # the attention sub-layer of the first layer is the last audio-encoder node of a backward pass: it launches whatever weight
+        # gradients are still queued for a grouped launch (ttmi.ops.WgradQueue; plain attribute, not a parameter or buffer)
+        self.layers[0].MultiHeadAttention.dec_attn.first_layer = True
 
     def forward(self, inputs, mask=None):
         ops.weights_fresh()

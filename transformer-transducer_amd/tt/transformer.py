@@ -61,35 +61,51 @@ def as_mask_spec(mask, B, L):
     return spec
 
 
-def grad_targets(params, names):
+def grad_targets(params, names, late=()):
     """Gradient buffers for a sub-layer's backward.  Parameters that `ttmi.train.FlatModel` manages (attribute
     `_ttmi_direct`, .grad = view of the flat gradient buffer) are accumulated into IN PLACE by the HIP kernels (their
     gradient semantics are += anyway) and autograd gets None for them; everything else gets a fresh zero buffer that is
-    returned to autograd.  Returns (buffers by name, tuple to return to autograd, callbacks to run afterwards)."""
-    bufs, rets, after = {}, [], []
+    returned to autograd.  Returns (buffers by name, tuple to return to autograd, callbacks to run afterwards); with `late` (names whose
+    gradients a deferred grouped launch will write, see ttmi.ops.WgradQueue) the callbacks come back as (now, later)."""
+    bufs, rets, after, later = {}, [], [], []
     for n, prm in zip(names, params):
         if getattr(prm, "_ttmi_direct", False) and prm.grad is not None:
             bufs[n] = prm.grad
             rets.append(None)
             cb = getattr(prm, "_ttmi_on_grad", None)
             if cb is not None:
-                after.append(cb)
+                (later if n in late else after).append(cb)
         else:
             bufs[n] = torch.zeros_like(prm)
             rets.append(bufs[n])
-    return bufs, tuple(rets), after
+    return (bufs, tuple(rets), after) if not late else (bufs, tuple(rets), after, later)
+
+
+def _defer_queue(params, names, late, rows, prec):
+    """the grouped-wgrad queue, if this backward pass may use it: queue enabled (FlatModel.enable_grouped_wgrads), an audio-sized layer
+    (a layer of fewer rows does not fill its share of the grouped launch) and every deferred gradient written in place into a flat buffer
+    (its address must still be valid when the group runs)"""
+    q = ops.wgrad_queue
+    if q is None or rows < 4096 or prec != 1:
+        return None
+    for n, prm in zip(names, params):
+        if n in late and not (getattr(prm, "_ttmi_direct", False) and prm.grad is not None):
+            return None
+    return q
 
 
 class _AttnFn(torch.autograd.Function):
     NAMES = ("qkv_w", "o_w", "ln_g", "ln_b", "r_emb", "r_w_bias", "r_bias")
 
+    LATE = ("qkv_w", "o_w")
+
     @staticmethod
-    def forward(ctx, x, qkv_w, o_w, ln_g, ln_b, r_emb, r_w_bias, r_bias, mask, prec, p_drop, seed):
+    def forward(ctx, x, qkv_w, o_w, ln_g, ln_b, r_emb, r_w_bias, r_bias, mask, prec, p_drop, seed, first_layer=False):
         x = x.contiguous()
         p = dict(zip(_AttnFn.NAMES, (t.detach() for t in (qkv_w, o_w, ln_g, ln_b, r_emb, r_w_bias, r_bias))))
         y, saved = ops.attn_fwd(x, p, mask, prec, p_drop, seed)
         ctx.save_for_backward(x, saved, *p.values())
-        ctx.prec, ctx.p_drop, ctx.seed, ctx.mask = prec, p_drop, seed, mask
+        ctx.prec, ctx.p_drop, ctx.seed, ctx.mask, ctx.first_layer = prec, p_drop, seed, mask, first_layer
         ctx.params = (qkv_w, o_w, ln_g, ln_b, r_emb, r_w_bias, r_bias)
         return y
 
@@ -97,11 +113,21 @@ class _AttnFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, saved, *ps = ctx.saved_tensors
         p = dict(zip(_AttnFn.NAMES, ps))
-        grads, rets, after = grad_targets(ctx.params, _AttnFn.NAMES)
-        dx = ops.attn_bwd(dy.contiguous(), x, p, saved, ctx.prec, grads, ctx.p_drop, ctx.seed, ctx.mask)
+        q = _defer_queue(ctx.params, _AttnFn.NAMES, _AttnFn.LATE, x.shape[0] * x.shape[1], ctx.prec)
+        if q is not None and ops.wgrad_defer_supported(x.shape[0] * x.shape[1], x.shape[2], p["r_emb"].shape[1], p["r_emb"].shape[2],
+                                                      x.shape[2], ctx.prec):          # (Di = d: this sub-layer has no inner width)
+            grads, rets, after, later = grad_targets(ctx.params, _AttnFn.NAMES, _AttnFn.LATE)
+            dx = ops.attn_bwd(dy.contiguous(), x, p, saved, ctx.prec, grads, ctx.p_drop, ctx.seed, ctx.mask, defer=q)
+            q.add_callbacks(later)
+            q.maybe_flush(force=ctx.first_layer)          # a layer boundary: launch if enough layers wait - or if nothing follows
+        else:
+            grads, rets, after = grad_targets(ctx.params, _AttnFn.NAMES)
+            dx = ops.attn_bwd(dy.contiguous(), x, p, saved, ctx.prec, grads, ctx.p_drop, ctx.seed, ctx.mask)
+            if ctx.first_layer:
+                ops.wgrad_flush()
         for cb in after:
             cb()
-        return (dx, *rets, None, None, None, None)
+        return (dx, *rets, None, None, None, None, None)
 
 
 class _FFNFn(torch.autograd.Function):
@@ -117,12 +143,21 @@ class _FFNFn(torch.autograd.Function):
         ctx.params = (w1, b1, w2, b2, ln_g, ln_b)
         return z
 
+    LATE = ("ff_w1", "ff_b1", "ff_w2")
+
     @staticmethod
     def backward(ctx, dz):
         y, saved, *ps = ctx.saved_tensors
         p = dict(zip(_FFNFn.NAMES, ps))
-        grads, rets, after = grad_targets(ctx.params, _FFNFn.NAMES)
-        dy = ops.ffn_bwd(dz.contiguous(), y, p, saved, ctx.prec, grads, *ctx.drop)
+        rows = y.numel() // y.shape[-1]
+        q = _defer_queue(ctx.params, _FFNFn.NAMES, _FFNFn.LATE, rows, ctx.prec)
+        if q is not None and ops.wgrad_defer_supported(rows, y.shape[-1], 1, 8, p["ff_w1"].shape[0], ctx.prec):     # (H, Dh = 1, 8: no heads here)
+            grads, rets, after, later = grad_targets(ctx.params, _FFNFn.NAMES, _FFNFn.LATE)
+            dy = ops.ffn_bwd(dz.contiguous(), y, p, saved, ctx.prec, grads, *ctx.drop, defer=q)
+            q.add_callbacks(later)
+        else:
+            grads, rets, after = grad_targets(ctx.params, _FFNFn.NAMES)
+            dy = ops.ffn_bwd(dz.contiguous(), y, p, saved, ctx.prec, grads, *ctx.drop)
         for cb in after:
             cb()
         return (dy, *rets, None, None, None, None)
@@ -191,7 +226,8 @@ class RelLearnableMultiHeadAttn(RelMultiHeadAttn):
         """batch-major [B, L, d] in/out; mask: MaskSpec."""
         p = _drop_p(self, self.dropout)
         return _AttnFn.apply(x, self.qkv_net.weight, self.o_net.weight, self.layer_norm.weight, self.layer_norm.bias,
-                             r_emb, r_w_bias, r_bias, mask, default_precision() if prec is None else prec, p, _new_seed(p))
+                             r_emb, r_w_bias, r_bias, mask, default_precision() if prec is None else prec, p, _new_seed(p),
+                             getattr(self, "first_layer", False))
 
     def forward(self, w, r_emb, r_w_bias, r_bias, attn_mask=None):
         """reference contract: w [L, B, d] time-major."""

@@ -122,6 +122,56 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, flags, bias=None, aux=None, alpha=1.0,
     return C
 
 
+# ----------------------------------------------------------------------------- grouped weight gradients
+class WgradDesc(ctypes.Structure):
+    """ttmi_wgrad_desc (include/ttmi.h)"""
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("colsum", c_void_p), ("M", c_int), ("N", c_int), ("K", c_int),
+                ("lda", c_long), ("ldb", c_long), ("ldc", c_long)]
+
+
+class WgradQueue:
+    """Weight-gradient GEMMs of audio-sized encoder layers, held back until `group` layers' worth (4 problems each) are waiting and
+    then launched together: 4 layers x 64 tiles = one 256 x 128 tile per CU over the whole reduction, no atomics (ttmi_wgrad_group).
+    Holds the operand buffers alive until then; `after` callbacks (gradient-ready hooks of the deferred parameters) run after the launch."""
+
+    def __init__(self, group=4):
+        self.limit = 4 * group
+        self.descs, self.alive, self.after = [], [], []
+
+    def push(self, descs, tensors):
+        self.descs.extend(WgradDesc.from_buffer_copy(d) for d in descs)
+        self.alive.append(tensors)
+
+    def add_callbacks(self, cbs):
+        self.after.extend(cbs)
+
+    def maybe_flush(self, force=False):
+        if self.descs and (force or len(self.descs) >= self.limit):
+            arr = (WgradDesc * len(self.descs))(*self.descs)
+            check(lib().ttmi_wgrad_group(arr, c_int(len(self.descs)), _stream()), "ttmi_wgrad_group")
+            cbs = self.after
+            self.descs, self.alive, self.after = [], [], []
+            for cb in cbs:
+                cb()
+
+    def discard(self):
+        """an aborted backward pass leaves entries behind: drop them (their gradients are lost with the step)"""
+        self.descs, self.alive, self.after = [], [], []
+
+
+wgrad_queue = None          # set by ttmi.train.FlatModel.enable_grouped_wgrads(); read by the sub-layer backward passes
+
+
+def wgrad_defer_supported(rows, d, H, Dh, Di, prec):
+    return bool(lib().ttmi_wgrad_defer_supported(c_long(rows), c_int(d), c_int(H), c_int(Dh), c_int(Di), c_int(prec)))
+
+
+def wgrad_flush():
+    """launch whatever weight gradients are still queued (end of a backward pass)"""
+    if wgrad_queue is not None:
+        wgrad_queue.maybe_flush(force=True)
+
+
 # ----------------------------------------------------------------------------- sub-layers
 class MaskSpec:
     """Attention mask handed to the kernels as parameters: kind 0 none, 1 causal
@@ -190,14 +240,26 @@ def attn_fwd(x, p, mask, prec, p_drop=0.0, seed=0):
     return y, ctx
 
 
-def attn_bwd(dy, x, p, ctx, prec, grads, p_drop=0.0, seed=0, mask=None):
-    """grads: dict of ZERO-INITIALISED (or running) f32 buffers, accumulated into."""
+def attn_bwd(dy, x, p, ctx, prec, grads, p_drop=0.0, seed=0, mask=None, defer=None):
+    """grads: dict of ZERO-INITIALISED (or running) f32 buffers, accumulated into.  defer: a WgradQueue - the two weight-gradient GEMMs
+    are queued for a grouped launch instead of run here (their gradients appear when the queue is flushed)."""
     B, L, d = x.shape
     K, H, Dh = p["r_emb"].shape
     L_ = lib()
     L_.ttmi_attn_ws_floats.restype = ctypes.c_size_t
     ws = scratch(L_.ttmi_attn_ws_floats(c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh), c_int(prec)), x.device)
     dx = torch.empty_like(x)
+    if defer is not None:
+        L_.ttmi_attn_bwd_keep_bytes.restype = ctypes.c_size_t
+        keep = torch.empty(L_.ttmi_attn_bwd_keep_bytes(c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh)), dtype=torch.uint8, device=x.device)
+        out = (WgradDesc * 2)()
+        check(L_.ttmi_attn_bwd_defer(_p(dy), _p(x), _p(p["qkv_w"]), _p(p["o_w"]), _p(p["ln_g"]), _p(p["r_emb"]), _p(p["r_w_bias"]), _p(p["r_bias"]),
+                                     c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh), c_int(K), *(mask or MaskSpec()).args(), c_int(prec),
+                                     c_float(p_drop), ctypes.c_uint(seed), _p(ctx), _p(ws), _p(dx),
+                                     _p(grads["qkv_w"]), _p(grads["o_w"]), _p(grads["ln_g"]), _p(grads["ln_b"]), _p(grads["r_emb"]),
+                                     _p(grads["r_w_bias"]), _p(grads["r_bias"]), _p(keep), out, _stream()), "ttmi_attn_bwd_defer")
+        defer.push(out, (keep, ctx, grads["qkv_w"], grads["o_w"]))
+        return dx
     check(L_.ttmi_attn_bwd(_p(dy), _p(x), _p(p["qkv_w"]), _p(p["o_w"]), _p(p["ln_g"]), _p(p["r_emb"]), _p(p["r_w_bias"]), _p(p["r_bias"]),
                            c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh), c_int(K), *(mask or MaskSpec()).args(), c_int(prec),
                            c_float(p_drop), ctypes.c_uint(seed), _p(ctx), _p(ws), _p(dx),
@@ -222,13 +284,23 @@ def ffn_fwd(y, p, prec, p_drop=0.0, p_layer=0.0, seed=0):
     return z, ctx
 
 
-def ffn_bwd(dz, y, p, ctx, prec, grads, p_drop=0.0, p_layer=0.0, seed=0):
+def ffn_bwd(dz, y, p, ctx, prec, grads, p_drop=0.0, p_layer=0.0, seed=0, defer=None):
     rows, d = y.numel() // y.shape[-1], y.shape[-1]
     Di = p["ff_w1"].shape[0]
     L_ = lib()
     L_.ttmi_ffn_ws_floats.restype = ctypes.c_size_t
     ws = scratch(L_.ttmi_ffn_ws_floats(c_long(rows), c_int(d), c_int(Di), c_int(prec)), y.device)
     dy = torch.empty_like(y)
+    if defer is not None:
+        L_.ttmi_ffn_bwd_keep_bytes.restype = ctypes.c_size_t
+        keep = torch.empty(L_.ttmi_ffn_bwd_keep_bytes(c_long(rows), c_int(d), c_int(Di)), dtype=torch.uint8, device=y.device)
+        out = (WgradDesc * 2)()
+        check(L_.ttmi_ffn_bwd_defer(_p(dz), _p(y), _p(p["ff_w1"]), _p(p["ff_w2"]), _p(p["ff_ln_g"]), c_long(rows), c_int(d), c_int(Di),
+                                    c_int(prec), c_float(p_drop), c_float(p_layer), ctypes.c_uint(seed), _p(ctx), _p(ws), _p(dy),
+                                    _p(grads["ff_w1"]), _p(grads["ff_b1"]), _p(grads["ff_w2"]), _p(grads["ff_b2"]), _p(grads["ff_ln_g"]),
+                                    _p(grads["ff_ln_b"]), _p(keep), out, _stream()), "ttmi_ffn_bwd_defer")
+        defer.push(out, (keep, ctx, grads["ff_w1"], grads["ff_b1"], grads["ff_w2"]))
+        return dy
     check(L_.ttmi_ffn_bwd(_p(dz), _p(y), _p(p["ff_w1"]), _p(p["ff_w2"]), _p(p["ff_ln_g"]), c_long(rows), c_int(d), c_int(Di),
                           c_int(prec), c_float(p_drop), c_float(p_layer), ctypes.c_uint(seed), _p(ctx), _p(ws), _p(dy), _p(grads["ff_w1"]), _p(grads["ff_b1"]), _p(grads["ff_w2"]),
                           _p(grads["ff_b2"]), _p(grads["ff_ln_g"]), _p(grads["ff_ln_b"]), _stream()), "ttmi_ffn_bwd")

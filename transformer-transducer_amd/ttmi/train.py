@@ -37,7 +37,21 @@ class FlatModel:
         self.shadow = None
 
     def zero_grad(self):
+        if ops.wgrad_queue is not None:
+            ops.wgrad_queue.discard()          # leftovers of an aborted backward pass
         self.grad.zero_()
+
+    def enable_grouped_wgrads(self, layers_per_group=4):
+        """Defer the weight-gradient GEMMs of the audio-sized encoder layers (bf16 pipeline) and launch them `layers_per_group` layers at
+        a time: 4 layers x 64 tiles fill the chip with one tile per CU over the whole reduction, so the K-splits and their f32 atomics go
+        away and the gradients are bit-identical from run to run and across ranks (include/ttmi.h, ttmi_wgrad_group).  The gradients of
+        the deferred weights appear when their group runs - at the latest when the first layer's backward pass ends; gradient-ready
+        hooks (GradSync) fire then.  Process-wide switch: the queue lives in ttmi.ops."""
+        ops.wgrad_queue = ops.WgradQueue(layers_per_group)
+        return self
+
+    def disable_grouped_wgrads(self):
+        ops.wgrad_queue = None
 
     # ---- bf16 shadows of the GEMM weights (include/ttmi.h: ttmi_weight_shadow_*)
     def enable_shadows(self):
