@@ -199,7 +199,7 @@ def main():
     model = Transducer(cfg).to(dev).train()
     flat = FlatModel(model)
     if args.precision == "bf16" and not args.no_grouped_wgrads:
-        flat.enable_grouped_wgrads()                       # encoder weight gradients four layers at a time: one tile per CU, no K-split atomics
+        flat.enable_grouped_wgrads(immediate_first_layer=world > 1)       # encoder weight gradients four layers at a time: one tile per CU, no K-split atomics
     if args.precision == "bf16" and not args.no_weight_shadows:
         flat.enable_shadows()                              # bf16 weight copies rebuilt once per optimiser step (one launch) instead of per call
     sync = GradSync(flat)

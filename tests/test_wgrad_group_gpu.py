@@ -139,3 +139,20 @@ def test_gradient_hooks_fire_after_the_group_has_run(monkeypatch):
     assert len(hooks) == len(flat.params) and all(e[2] for e in hooks), [e for e in hooks if not e[2]]
     # with 2 layers per group the queue empties after layer 1 (8 problems) and again after layer 0 (4 problems)
     assert [n for tag, n in (e[:2] for e in order if e[0] == "flush?") if n] == [4, 8, 4]
+
+
+def test_first_layer_kept_out_of_the_groups_for_data_parallel_runs(monkeypatch):
+    """immediate_first_layer: layers 2 and 1 are launched together when layer 0's backward starts, layer 0 keeps its own launches"""
+    from ttmi import ops
+    enc, flat, x, cot = _layer(monkeypatch)
+    base_g, base_dx = _step(enc, flat, x, cot, 3)
+    sizes = []
+    orig = ops.WgradQueue.maybe_flush
+    monkeypatch.setattr(ops.WgradQueue, "maybe_flush", lambda self, force=False: (sizes.append(len(self.descs)) if force and self.descs else None, orig(self, force))[1])
+    flat.enable_grouped_wgrads(4, immediate_first_layer=True)
+    try:
+        g1, dx1 = _step(enc, flat, x, cot, 3)
+    finally:
+        flat.disable_grouped_wgrads()
+    assert sizes == [8]
+    assert torch.equal(dx1, base_dx) and rel_err(g1.cpu().numpy(), base_g.cpu().numpy()) < 2e-5

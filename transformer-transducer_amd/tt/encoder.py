@@ -34,6 +34,7 @@ class BuildEncoder(nn.Module):
         # the attention sub-layer of the first layer is the last audio-encoder node of a backward pass: it launches whatever weight
         # gradients are still queued for a grouped launch (ttmi.ops.WgradQueue; plain attribute, not a parameter or buffer)
         self.layers[0].MultiHeadAttention.dec_attn.first_layer = True
+        self.layers[0].MultiHeadAttention.pos_ff.first_layer = True
 
     def forward(self, inputs, mask=None):
         ops.weights_fresh()

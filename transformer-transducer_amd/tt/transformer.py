@@ -81,12 +81,12 @@ def grad_targets(params, names, late=()):
     return (bufs, tuple(rets), after) if not late else (bufs, tuple(rets), after, later)
 
 
-def _defer_queue(params, names, late, rows, prec):
+def _defer_queue(params, names, late, rows, prec, first_layer=False):
     """the grouped-wgrad queue, if this backward pass may use it: queue enabled (FlatModel.enable_grouped_wgrads), an audio-sized layer
     (a layer of fewer rows does not fill its share of the grouped launch) and every deferred gradient written in place into a flat buffer
     (its address must still be valid when the group runs)"""
     q = ops.wgrad_queue
-    if q is None or rows < 4096 or prec != 1:
+    if q is None or rows < 4096 or prec != 1 or (first_layer and q.immediate_first_layer):
         return None
     for n, prm in zip(names, params):
         if n in late and not (getattr(prm, "_ttmi_direct", False) and prm.grad is not None):
@@ -113,7 +113,7 @@ class _AttnFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, saved, *ps = ctx.saved_tensors
         p = dict(zip(_AttnFn.NAMES, ps))
-        q = _defer_queue(ctx.params, _AttnFn.NAMES, _AttnFn.LATE, x.shape[0] * x.shape[1], ctx.prec)
+        q = _defer_queue(ctx.params, _AttnFn.NAMES, _AttnFn.LATE, x.shape[0] * x.shape[1], ctx.prec, ctx.first_layer)
         if q is not None and ops.wgrad_defer_supported(x.shape[0] * x.shape[1], x.shape[2], p["r_emb"].shape[1], p["r_emb"].shape[2],
                                                       x.shape[2], ctx.prec):          # (Di = d: this sub-layer has no inner width)
             grads, rets, after, later = grad_targets(ctx.params, _AttnFn.NAMES, _AttnFn.LATE)
@@ -134,12 +134,12 @@ class _FFNFn(torch.autograd.Function):
     NAMES = ("ff_w1", "ff_b1", "ff_w2", "ff_b2", "ff_ln_g", "ff_ln_b")
 
     @staticmethod
-    def forward(ctx, y, w1, b1, w2, b2, ln_g, ln_b, prec, p_drop, p_layer, seed):
+    def forward(ctx, y, w1, b1, w2, b2, ln_g, ln_b, prec, p_drop, p_layer, seed, first_layer=False):
         y = y.contiguous()
         p = dict(zip(_FFNFn.NAMES, (t.detach() for t in (w1, b1, w2, b2, ln_g, ln_b))))
         z, saved = ops.ffn_fwd(y, p, prec, p_drop, p_layer, seed)
         ctx.save_for_backward(y, saved, *p.values())
-        ctx.prec, ctx.drop = prec, (p_drop, p_layer, seed)
+        ctx.prec, ctx.drop, ctx.first_layer = prec, (p_drop, p_layer, seed), first_layer
         ctx.params = (w1, b1, w2, b2, ln_g, ln_b)
         return z
 
@@ -150,7 +150,9 @@ class _FFNFn(torch.autograd.Function):
         y, saved, *ps = ctx.saved_tensors
         p = dict(zip(_FFNFn.NAMES, ps))
         rows = y.numel() // y.shape[-1]
-        q = _defer_queue(ctx.params, _FFNFn.NAMES, _FFNFn.LATE, rows, ctx.prec)
+        if ctx.first_layer and ops.wgrad_queue is not None and ops.wgrad_queue.immediate_first_layer:
+            ops.wgrad_flush()          # first node of the first layer's backward: this layer keeps its own launches, the groups behind it go now
+        q = _defer_queue(ctx.params, _FFNFn.NAMES, _FFNFn.LATE, rows, ctx.prec, ctx.first_layer)
         if q is not None and ops.wgrad_defer_supported(rows, y.shape[-1], 1, 8, p["ff_w1"].shape[0], ctx.prec):     # (H, Dh = 1, 8: no heads here)
             grads, rets, after, later = grad_targets(ctx.params, _FFNFn.NAMES, _FFNFn.LATE)
             dy = ops.ffn_bwd(dz.contiguous(), y, p, saved, ctx.prec, grads, *ctx.drop, defer=q)
@@ -160,7 +162,7 @@ class _FFNFn(torch.autograd.Function):
             dy = ops.ffn_bwd(dz.contiguous(), y, p, saved, ctx.prec, grads, *ctx.drop)
         for cb in after:
             cb()
-        return (dy, *rets, None, None, None, None)
+        return (dy, *rets, None, None, None, None, None)
 
 
 def _drop_p(module, p):
@@ -200,7 +202,7 @@ class PositionwiseFF(nn.Module):
         p = _drop_p(self, self.dropout)
         return _FFNFn.apply(inp, c[0].weight, c[0].bias, c[3].weight, c[3].bias, self.layer_norm.weight,
                             self.layer_norm.bias, default_precision() if prec is None else prec, p, p_layer,
-                            _new_seed(p, p_layer))
+                            _new_seed(p, p_layer), getattr(self, "first_layer", False))
 
 
 class RelMultiHeadAttn(nn.Module):

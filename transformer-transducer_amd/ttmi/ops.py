@@ -134,8 +134,11 @@ class WgradQueue:
     then launched together: 4 layers x 64 tiles = one 256 x 128 tile per CU over the whole reduction, no atomics (ttmi_wgrad_group).
     Holds the operand buffers alive until then; `after` callbacks (gradient-ready hooks of the deferred parameters) run after the launch."""
 
-    def __init__(self, group=4):
+    def __init__(self, group=4, immediate_first_layer=False):
         self.limit = 4 * group
+        # data-parallel runs: the first layer's gradients are the last of the step - whatever is reduced after them overlaps nothing.  Left
+        # out of the groups they are ready as early as before; the layers behind them are launched when the first layer's backward STARTS.
+        self.immediate_first_layer = immediate_first_layer
         self.descs, self.alive, self.after = [], [], []
 
     def push(self, descs, tensors):

@@ -41,13 +41,14 @@ class FlatModel:
             ops.wgrad_queue.discard()          # leftovers of an aborted backward pass
         self.grad.zero_()
 
-    def enable_grouped_wgrads(self, layers_per_group=4):
+    def enable_grouped_wgrads(self, layers_per_group=4, immediate_first_layer=False):
         """Defer the weight-gradient GEMMs of the audio-sized encoder layers (bf16 pipeline) and launch them `layers_per_group` layers at
         a time: 4 layers x 64 tiles fill the chip with one tile per CU over the whole reduction, so the K-splits and their f32 atomics go
         away and the gradients are bit-identical from run to run and across ranks (include/ttmi.h, ttmi_wgrad_group).  The gradients of
         the deferred weights appear when their group runs - at the latest when the first layer's backward pass ends; gradient-ready
-        hooks (GradSync) fire then.  Process-wide switch: the queue lives in ttmi.ops."""
-        ops.wgrad_queue = ops.WgradQueue(layers_per_group)
+        hooks (GradSync) fire then.  immediate_first_layer (data-parallel runs): the first layer keeps its own launches, so that the
+        last gradients of the step are no larger than before.  Process-wide switch: the queue lives in ttmi.ops."""
+        ops.wgrad_queue = ops.WgradQueue(layers_per_group, immediate_first_layer)
         return self
 
     def disable_grouped_wgrads(self):
