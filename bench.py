@@ -162,6 +162,7 @@ def main():
                          "the projection stores exp(logit - shift) + row sums and the loss never walks the lattice's rows (speed form; bf16 only).  "
                          "auto = exp in bf16 train mode, two-call otherwise.  Whatever runs first, the JSON line also carries the two-call form's timing.")
     ap.add_argument("--fused-loss", action="store_true", help="same as --loss-form fused")
+    ap.add_argument("--no-two-call", action="store_true", help="skip the secondary timing of the two-call form (profiling runs: one loss form per trace)")
     ap.add_argument("--loss-chunk", type=int, default=0, help="utterances per chunk of the fused loss (0 = default: logits chunk <= 2 GB)")
     ap.add_argument("--emit-rate", type=float, default=0.1, help="decode mode: fraction of frames that emit a symbol (blank bias is set for it)")
     args = ap.parse_args()
@@ -269,7 +270,7 @@ def main():
         attn_ms = [ops.probe_read_ms(i, 3) for i in slots]
         wgrad_ms = [ops.probe_read_ms(i, 4) for i in slots]
     two_call = None
-    if form != "two-call" and args.mode == "train":
+    if form != "two-call" and args.mode == "train" and not args.no_two_call:
         # the reference's own call sequence beside the fused form, same model / data / optimizer state, same barrier + synchronize bracket
         main_form, form = form, "two-call"
         for _ in range(max(1, args.warmup)):

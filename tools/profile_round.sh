@@ -7,14 +7,14 @@ TAG=$1; COMMIT=$2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT profiles
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/trace.log 2>&1
-python3 tools/prof_summary.py $OUT/trace profiles/${TAG}_bench_kernel_stats.csv "bench.py --steps 4 --warmup 2 (6 steps), C2, $TAG build $COMMIT" > /dev/null
-# bench.py times its default (exp-domain) loss form for 2 + 4 steps, then the two-call form for 1 + 4: step 6 from the end is the last exp-domain step
-python3 tools/kernel_exclusive.py $OUT/trace 6 > profiles/${TAG}_bench_step_attribution.txt
-echo "" >> profiles/${TAG}_bench_step_attribution.txt
-echo "# the two-call form (model(inputs, targets) + RNNTLoss), last step of the same run" >> profiles/${TAG}_bench_step_attribution.txt
-python3 tools/kernel_exclusive.py $OUT/trace 1 >> profiles/${TAG}_bench_step_attribution.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-two-call > $OUT/trace.log 2>&1
+python3 tools/prof_summary.py $OUT/trace profiles/${TAG}_bench_kernel_stats.csv "bench.py --steps 4 --warmup 2 --no-two-call (6 steps, default = exp-domain loss form), C2, $TAG build $COMMIT" > /dev/null
+python3 tools/kernel_exclusive.py $OUT/trace > profiles/${TAG}_bench_step_attribution.txt
 python3 tools/gpu_busy.py $OUT/trace >> profiles/${TAG}_bench_step_attribution.txt
+# the reference's own call sequence (model(inputs, targets) + RNNTLoss) in a trace of its own
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace2 -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --loss-form two-call > $OUT/trace2.log 2>&1
+python3 tools/prof_summary.py $OUT/trace2 profiles/${TAG}_bench_two_call_kernel_stats.csv "bench.py --steps 4 --warmup 2 --loss-form two-call (6 steps), C2, $TAG build $COMMIT" > /dev/null
+python3 tools/kernel_exclusive.py $OUT/trace2 > profiles/${TAG}_bench_two_call_step_attribution.txt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/sq.log 2>&1
