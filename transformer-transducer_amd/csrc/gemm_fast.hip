@@ -933,10 +933,14 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
         // LEAN 2: the mask vectors of slab mi + 1 are requested before slab mi goes through its LDS transposes and stores
         u32x4 mkc[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}}, mkn[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
         const bf16_t* lmask0 = p.mask + (long)lm0 * p.ldc + ln0;
-        auto mask_fetch = [&](int mi, u32x4 (&dst)[2]) {
+        float rsc_c[2] = {0.f, 0.f}, rsc_n[2] = {0.f, 0.f};   // LEAN 4: the row factors travel with the mask vectors
+        auto mask_fetch = [&](int mi, u32x4 (&dst)[2], float (&rs)[2]) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
-                if (lfull && lm0 + mi * 16 + q * 8 < p.M) dst[q] = *reinterpret_cast<const u32x4*>(lmask0 + (long)(mi * 16 + q * 8) * p.ldc);
+                if (lm0 + mi * 16 + q * 8 < p.M) {
+                    if (lfull) dst[q] = *reinterpret_cast<const u32x4*>(lmask0 + (long)(mi * 16 + q * 8) * p.ldc);
+                    if constexpr (LEAN == 4) rs[q] = p.rowscale[lm0 + mi * 16 + q * 8];
+                }
         };
         if constexpr (LEAN == 1 || LEAN == 3) {
             // bias / exp epilogues (the K = 1024 projection, where the un-overlapped epilogue is a third of the tile): the bias is already
@@ -1002,10 +1006,10 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                 }
             }
         } else {
-        if constexpr (MASKED) mask_fetch(0, mkc);
+        if constexpr (MASKED) mask_fetch(0, mkc, rsc_c);
 #pragma unroll 1
         for (int mi = 0; mi < 8; ++mi) {
-            if constexpr (MASKED) { if (mi + 1 < 8) mask_fetch(mi + 1, mkn); }
+            if constexpr (MASKED) { if (mi + 1 < 8) mask_fetch(mi + 1, mkn, rsc_n); }
             switch (mi) { V8_SLAB(0) V8_SLAB(1) V8_SLAB(2) V8_SLAB(3) V8_SLAB(4) V8_SLAB(5) V8_SLAB(6) V8_SLAB(7) }
             if (LEAN || (sizeof(TC) == 2 && plain8)) {
                 // bf16 output: 8 columns per lane, one 16-byte store - 8 rows x 128 B per instruction
@@ -1031,7 +1035,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                                 }
                                 if constexpr (LEAN == 4) {         // tanh' mask and a per-row factor; the mask operand leaves scaled by the same factor
                                     const u32x4 mk = mkc[q];
-                                    const float rsc = p.rowscale[m];
+                                    const float rsc = rsc_c[q];
                                     u32x4 ms;
 #pragma unroll
                                     for (int j = 0; j < 4; ++j) {
@@ -1059,7 +1063,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                                     }
                                     if constexpr (LEAN == 4) {
                                         bf16_t* mp = const_cast<bf16_t*>(p.mask) + (long)m * p.ldc + ln0 + j;
-                                        const float mv = bf16_to_f32(*mp), rsc = p.rowscale[m];
+                                        const float mv = bf16_to_f32(*mp), rsc = rsc_c[q];
                                         y *= (1.f - mv * mv) * rsc;
                                         *mp = f32_to_bf16(mv * rsc);
                                     }
@@ -1069,7 +1073,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
                     } else if constexpr (sizeof(TC) == 2)
                         epi_store8_bf16(p, reinterpret_cast<bf16_t*>(C), cbm + wr * 128 + mi * 16 + r, cbn + wc * 64 + c8 * 8, x0, x1, vec);
                 }
-                if constexpr (MASKED) { mkc[0] = mkn[0]; mkc[1] = mkn[1]; }
+                if constexpr (MASKED) { mkc[0] = mkn[0]; mkc[1] = mkn[1]; rsc_c[0] = rsc_n[0]; rsc_c[1] = rsc_n[1]; }
             } else if constexpr (!LEAN) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
