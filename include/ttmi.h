@@ -205,6 +205,10 @@ int ttmi_gemm_nt_bf16_exp(const void* A, const void* B, void* C, const float* bi
                           long lda, long ldb, long ldc, void* stream);
 int ttmi_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
                       float* colsum_a /* nullable: colsum_a[m] += sum_k A[k][m] */, void* stream);
+/* bring-up entry of the weighted column sums (persistent 256x256 TN kernel only: K >= 32768, M >= 1024, N % 256 == 0, N >= 1024):
+ * C += A^T B and colsum_a[m] += sum_k colsum_w[k] A[k][m] (colsum_w bf16 [K], 16-byte aligned) */
+int ttmi_gemm_tn_bf16_wsum(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, float* colsum_a,
+                           const void* colsum_w, void* stream);
 /* bf16 shadows of GEMM weights.  Every forward call otherwise converts its f32 master weights to bf16 (plain + transposed copies: 118
  * launches per step at C2 for weights that change once per optimiser step).  A training loop registers, per weight w [R, C], a plain bf16
  * copy w16 [R, C] and a transposed one wT16 [C, ldT] (ldT >= R, columns [R, ldT) zero) and rebuilds ALL of them with one launch after each

@@ -214,3 +214,27 @@ def test_streaming_store_path_exact(M, N, K):
     finally:
         ops.set_option(1, 15)
     assert torch.equal(C2, C)
+
+
+@pytest.mark.parametrize("M", [4334, 1024])
+def test_tn_weighted_column_sums_exact(M):
+    """persistent 256x256 TN kernel with column sums weighted per reduction row (the bias gradient of the exp-domain loss form): integer data,
+    so every order of summation gives the same f32; M = 4334 has the ragged strip riding inside the kernel; 3 launches accumulate"""
+    import ctypes
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(21)
+    K, N = 65536 + 64 * 5, 1024
+    lda = (M + 63) // 64 * 64                               # the joint's padded pitch (4352 for V = 4334)
+    A = torch.randint(-1, 2, (K, lda), device="cuda", generator=g).to(torch.bfloat16)[:, :M]
+    B = torch.randint(-1, 2, (K, N), device="cuda", generator=g).to(torch.bfloat16)
+    w = torch.randint(-2, 3, (K,), device="cuda", generator=g).to(torch.bfloat16)
+    C = torch.zeros(M, N, device="cuda")
+    col = torch.zeros(M, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    for _ in range(3):
+        ops.check(ops.lib().ttmi_gemm_tn_bf16_wsum(p(A), p(B), p(C), M, N, K, ctypes.c_long(lda), ctypes.c_long(N), ctypes.c_long(N), p(col), p(w),
+                                                   ops._stream()), "ttmi_gemm_tn_bf16_wsum")
+    want_c = 3 * (A.float().t() @ B.float())
+    want_col = 3 * (A.float() * w.float()[:, None]).sum(0)
+    assert torch.equal(col, want_col)
+    assert torch.equal(C, want_c)

@@ -69,6 +69,10 @@ struct FP {
     const bf16_t* csw;
 };
 
+__device__ __forceinline__ void glds4(const void* gsrc, char* lds_wave_base) {       // 4 bytes per lane: LDS address = base + lane * 4
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -1673,28 +1677,22 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
     long kbeg_cur = 0;                                     // first reduction row of the item being computed
     int cs_unit = -1;                                      // (mh, mt, ks) piece of the column sums this wave owns for the current item
     // weighted column sums (CS == 2): colsum[m] += sum_k csw[k] A[k][m] - the all-ones fragment becomes the 8 weights of this lane's k-octet
-    // (k = K-tile base + 32 ks + 8 (lane >> 4) + 0..7, the k order of the transposed A fragments).  The 32 weights of the wave's k-half
-    // come through the SCALAR cache (one s_load_dwordx16 a phase ahead of their use): a vector load here would sit in front of the
-    // staged tiles in the vmcnt queue and drain the prefetch.
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(4))) const u32x4 cuint4;
+    // (k = K-tile base + 32 ks + 8 (lane >> 4) + 0..7, the k order of the transposed A fragments).  The 64 weights of K-tile t travel like an
+    // operand tile: ONE LDS-DMA instruction of wave 0 (32 lanes x 4 bytes) into slot t & 1 at the head of its epilogue image - free during
+    // the K loop - issued with the A(h1) stage of the same tile, i.e. older than the six loads the counted vmcnt leaves in flight, so the wait
+    // and barrier that publish that stage publish the weights too.  (A vector load into registers would sit in the in-order vmcnt queue
+    // in front of the staged tiles: +35 %; through the scalar cache every wave's lgkmcnt(0) waited out a miss per K-tile: +12 %.)
     bf16x8 wcur;
-    u32x4 wq[4];
-    auto fetch_w = [&](int t, int mh) {
+    auto wload = [&](int t) {
         if constexpr (CS == 2) {
-            if (cs_unit >= 0 && (cs_unit >> 3) == mh) {
-                const long off = __builtin_amdgcn_readfirstlane((int)(kbeg_cur + (long)t * TK)) + (cs_unit & 1) * 32;
-                const cuint4* wp = (const cuint4*)(uintptr_t)(p.csw + off);
-                wq[0] = wp[0]; wq[1] = wp[1]; wq[2] = wp[2]; wq[3] = wp[3];
-            }
+            if (wave == 0 && lane < 32) glds4(p.csw + kbeg_cur + (long)t * TK + lane * 2, smem + 2 * BUF8 + (t & 1) * 128);
         }
     };
-    auto select_w = [&](int mh) {
+    auto fetch_w = [&](int t, int mh) {                   // with the phase's fragment reads, behind the same lgkmcnt(0)
         if constexpr (CS == 2) {
             if (cs_unit >= 0 && (cs_unit >> 3) == mh) {
-                const int o = lane >> 4;
-                const u32x4 v = o == 0 ? wq[0] : o == 1 ? wq[1] : o == 2 ? wq[2] : wq[3];
-                wcur = __builtin_bit_cast(bf16x8, v);
+                const unsigned a = lds0 + 2 * BUF8 + (t & 1) * 128 + (cs_unit & 1) * 64 + (lane >> 4) * 16;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(wcur) : "v"(a) : "memory");
             }
         }
     };
@@ -1724,26 +1722,25 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
         cs = f32x4{0.f, 0.f, 0.f, 0.f};
         cs_unit = CS && tn < 4 ? __builtin_amdgcn_readfirstlane(tn * 4 + wc) : -1;     // column tiles 0..3 share the 16 pieces
         const int cnk = nk;
-        if constexpr (CS == 2) { kbeg_cur = kbeg; if (cnk > 0) fetch_w(0, 0); }
-        if (cnk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (CS == 2) { kbeg_cur = kbeg; if (cnk > 0) wload(0); }      // the image area is free again: the previous item's epilogue is done
+        if (cnk > 1 && CS != 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (CS == 2: tile 0's weights are the newest load - once per item)
         V8_BAR();
         if (wr == 1) V8_BAR();
         for (int t = 0; t < cnk; ++t) {
             const int d = t & 1;
             const char* base = smem + d * BUF8;
             const bool more = t + 2 < cnk;
-            fetch_w(t, 1);                                  // weights of phase B, one phase ahead (scalar-cache latency under this phase's MFMAs)
+            fetch_w(t, 0);
             read_a(base, 0);
             read_b(base);
-            if (t + 1 < cnk) stage(1, d ^ 1, t + 1);
+            if (t + 1 < cnk) { wload(t + 1); stage(1, d ^ 1, t + 1); }
             V8_LGKM0();
-            select_w(0);
             V8_BAR();
             mma(0);
             colsum_mma(0);
             V8_BAR();
-            if (t + 1 < cnk) fetch_w(t + 1, 0);             // weights of the next tile's phase A
+            fetch_w(t, 1);
             read_a(base, 1);
             if (more) {
                 stage(0, d, t + 2); stage(2, d, t + 2); stage(3, d, t + 2);
@@ -1752,7 +1749,6 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             V8_LGKM0();
-            select_w(1);
             V8_BAR();
             mma(1);
             colsum_mma(1);
@@ -2608,5 +2604,10 @@ int ttmi_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int 
                       float* colsum_a, void* stream) {
     return gemm_tn_bf16(static_cast<const bf16_t*>(A), static_cast<const bf16_t*>(B), C, M, N, K, lda, ldb, ldc, accumulate,
                         static_cast<hipStream_t>(stream), colsum_a, FastBatch());
+}
+int ttmi_gemm_tn_bf16_wsum(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, float* colsum_a,
+                           const void* colsum_w, void* stream) {
+    return gemm_tn_bf16(static_cast<const bf16_t*>(A), static_cast<const bf16_t*>(B), C, M, N, K, lda, ldb, ldc, 1,
+                        static_cast<hipStream_t>(stream), colsum_a, FastBatch(), static_cast<const bf16_t*>(colsum_w));
 }
 }
