@@ -118,19 +118,19 @@ def test_flat_model_gradients_and_memory(monkeypatch):
     assert out[0][2] - out[1][2] > 1.2 * logits_bytes        # logits + gradient gone, a chunk's worth (1/4) of one buffer remains
 
 
-def _training_sized(monkeypatch, prec):
+def _training_sized(monkeypatch, prec, J=1024, V=4334):
     from tt.model import Transducer
     from tt.utils import AttrDict
     monkeypatch.setenv("TTMI_PRECISION", prec)
     side = dict(n_layer=1, d_model=512, n_head=8, d_head=64, d_inner=256)
     cfg = AttrDict(dict(enc=dict(side, max_input_length=64), dec=dict(side, max_target_length=16),
-                        joint=dict(input_size=1024, inner_size=1024), vocab_size=4334, dropout=0.0))
+                        joint=dict(input_size=1024, inner_size=J), vocab_size=V, dropout=0.0))
     torch.manual_seed(2)
     model = Transducer(cfg).cuda().train()
     B, T, U = 8, 200, 20
     g = torch.Generator(device="cuda").manual_seed(3)
     x = torch.randn(B, T, 512, device="cuda", generator=g)
-    y = torch.randint(1, 4334, (B, U), device="cuda", generator=g)
+    y = torch.randint(1, V, (B, U), device="cuda", generator=g)
     al = torch.full((B,), T, dtype=torch.int32, device="cuda")
     ll = torch.full((B,), U, dtype=torch.int32, device="cuda")
     al[2], ll[2] = 150, 11
@@ -147,11 +147,12 @@ def _run(model, x, y, al, ll, **kw):
         {n: p.grad.cpu().numpy() for n, p in model.named_parameters()}
 
 
-def test_exp_domain_fast_path(monkeypatch):
-    """B=8, T=200, U=20, J=1024, V=4334 in one chunk (33600 lattice rows: the persistent kernels' sizes).  The exp-domain form must be as
+@pytest.mark.parametrize("J,V", [(1024, 4334), (2048, 6485)])          # C2 and C4 (joint_streaming.yaml) joint dimensions
+def test_exp_domain_fast_path(monkeypatch, J, V):
+    """B=8, T=200, U=20 in one chunk (33600 lattice rows: the persistent kernels' sizes).  The exp-domain form must be as
     close to the fp32 pipeline as the plain bf16 form is: both are measured against fp32 and printed."""
     import ttmi.ops as ops
-    model, x, y, al, ll = _training_sized(monkeypatch, "fp32")
+    model, x, y, al, ll = _training_sized(monkeypatch, "fp32", J, V)
     ref = _run(model, x, y, al, ll, chunk=8)
     monkeypatch.setenv("TTMI_PRECISION", "bf16")
     plain = _run(model, x, y, al, ll, chunk=8)

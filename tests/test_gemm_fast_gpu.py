@@ -216,14 +216,14 @@ def test_streaming_store_path_exact(M, N, K):
     assert torch.equal(C2, C)
 
 
-@pytest.mark.parametrize("M", [4334, 1024])
-def test_tn_weighted_column_sums_exact(M):
+@pytest.mark.parametrize("M,N", [(4334, 1024), (1024, 1024), (6485, 2048)])       # C2 (strip inside the kernel), no strip, C4 (strip on the 128x128 kernel)
+def test_tn_weighted_column_sums_exact(M, N):
     """persistent 256x256 TN kernel with column sums weighted per reduction row (the bias gradient of the exp-domain loss form): integer data,
     so every order of summation gives the same f32; M = 4334 has the ragged strip riding inside the kernel; 3 launches accumulate"""
     import ctypes
     from ttmi import ops
     g = torch.Generator(device="cuda").manual_seed(21)
-    K, N = 65536 + 64 * 5, 1024
+    K = 65536 + 64 * 5
     lda = (M + 63) // 64 * 64                               # the joint's padded pitch (4352 for V = 4334)
     A = torch.randint(-1, 2, (K, lda), device="cuda", generator=g).to(torch.bfloat16)[:, :M]
     B = torch.randint(-1, 2, (K, N), device="cuda", generator=g).to(torch.bfloat16)

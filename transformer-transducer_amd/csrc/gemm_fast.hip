@@ -459,7 +459,11 @@ __global__ __launch_bounds__(NTH, NBUF == 1 ? 4 : 2) void gemm_tn_bf16_kernel(co
 #pragma unroll 8
             for (int rr = 0; rr < 32; ++rr) {
                 const int kr = r0 + rr;
-                cs += bf16_to_f32(*reinterpret_cast<const bf16_t*>(la + kr * 256 + ((((col >> 3) ^ ((kr & 3) << 2))) << 4) + (col & 7) * 2));
+                const float a = bf16_to_f32(*reinterpret_cast<const bf16_t*>(la + kr * 256 + ((((col >> 3) ^ ((kr & 3) << 2))) << 4) + (col & 7) * 2));
+                // weighted form (the ragged M % 256 strip of the joint wgrad in the exp-domain loss form): weight of reduction row k0 + kt*64 + kr;
+                // rows beyond K were staged as zeros, their weights are not read
+                const long kg = k0 + (long)kt * TK + kr;
+                cs += p.csw ? (kg < p.K ? a * bf16_to_f32(p.csw[kg]) : 0.f) : a;
             }
         }
     };
@@ -2250,11 +2254,9 @@ static bool tn_v8_eligible(int M, int N, int K, bool colsum, int* S_out, bool* s
 // can the fused joint + loss fast path run at this size?  (projection forward with the exp store, dgrad with the row factor,
 // wgrad with the weighted column sums - all three on the persistent 256x256 kernels)
 bool gemm_fast_joint_exp_ok(int M, int V, int J, long ldv) {
-    bool strip_in = false;
     if (M <= 0 || V <= 0 || J <= 0 || ldv < V) return false;
     if (!nt_v8_eligible(M, V, J) || !nt_v8_eligible(M, J, (int)ldv)) return false;
-    if (!tn_v8_eligible(V, J, M, true, nullptr, &strip_in)) return false;
-    return V % T8 == 0 || strip_in;
+    return tn_v8_eligible(V, J, M, true, nullptr, nullptr);       // (a ragged V % 256 strip rides inside the kernel or takes the 128x128 kernel: both weight their column sums)
 }
 
 int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const NtEpilogue& epi, int M, int N, int K, long lda,
@@ -2477,7 +2479,6 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
         }
         TTMI_LAUNCH_CHECK("gemm_tn_bf16_v8_kernel");
         if (Mfull == M) return TTMI_OK;
-        TTMI_REQUIRE(!colsum_w, "gemm_tn_bf16: weighted column sums need the M %% 256 strip inside the persistent kernel (M=%d N=%d)", M, N);
         A += Mfull; C += (long)Mfull * ldc; M -= Mfull;     // the strip: same call, remaining rows of C
         if (colsum_a) colsum_a += Mfull;
         p.A = A; p.C = C; p.colsum = colsum_a;
