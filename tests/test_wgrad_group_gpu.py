@@ -156,3 +156,49 @@ def test_first_layer_kept_out_of_the_groups_for_data_parallel_runs(monkeypatch):
         flat.disable_grouped_wgrads()
     assert sizes == [8]
     assert torch.equal(dx1, base_dx) and rel_err(g1.cpu().numpy(), base_g.cpu().numpy()) < 2e-5
+
+
+def test_label_encoder_on_its_side_stream_gets_its_own_lane(monkeypatch):
+    """a whole Transducer whose label encoder is large enough to be deferred too (B*(U+1) >= 4096 rows) and runs on the side stream: its
+    problems are launched on that stream, never together with the audio encoder's"""
+    from tt.model import Transducer
+    from tt.utils import AttrDict
+    from ttmi import ops
+    from ttmi.train import FlatModel
+    from warprnnt_pytorch import RNNTLoss
+    monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    side = dict(n_layer=2, d_model=512, n_head=8, d_head=64, d_inner=1024)
+    cfg = AttrDict(dict(enc=dict(side, max_input_length=16), dec=dict(side, max_target_length=16),
+                        joint=dict(input_size=1024, inner_size=64), vocab_size=29, dropout=0.0, overlap_label_encoder=True))
+    torch.manual_seed(8)
+    model = Transducer(cfg).cuda().train()
+    flat = FlatModel(model)
+    B, T, U = 128, 32, 32
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn(B, T, 512, device="cuda", generator=g)
+    y = torch.randint(1, 29, (B, U), device="cuda", generator=g)
+    al, ll = torch.full((B,), T, dtype=torch.int32, device="cuda"), torch.full((B,), U, dtype=torch.int32, device="cuda")
+
+    def run():
+        flat.zero_grad()
+        RNNTLoss()(model(x, y), y.int(), al, ll).backward()
+        ops.join_side_streams()
+        torch.cuda.synchronize()
+        return flat.grad.clone()
+    base = run()
+    launched = []
+    orig = ops.WgradQueue.maybe_flush
+
+    def spy(self, force=False):
+        n = len(self.descs)
+        orig(self, force)
+        if n and not self.descs:
+            launched.append((torch.cuda.current_stream().cuda_stream, n))
+    monkeypatch.setattr(ops.WgradQueue, "maybe_flush", spy)
+    flat.enable_grouped_wgrads(4)
+    try:
+        got = run()
+    finally:
+        flat.disable_grouped_wgrads()
+    assert sorted(n for _, n in launched) == [8, 8] and launched[0][0] != launched[1][0], launched     # 2 layers x 4 problems per encoder, two streams
+    assert rel_err(got.cpu().numpy(), base.cpu().numpy()) < 2e-5

@@ -53,6 +53,9 @@ class BuildDecoder(nn.Module):
                         n_head=config.dec.n_head, d_model=config.dec.d_model, d_head=config.dec.d_head,
                         d_inner=config.dec.d_inner, dropout=config.dropout)
             for _ in range(config.dec.n_layer)])
+        # first layer = last node of this stack's backward pass: launches weight gradients still queued on its stream (tt/encoder.py)
+        self.layers[0].MultiHeadAttention.dec_attn.first_layer = True
+        self.layers[0].MultiHeadAttention.pos_ff.first_layer = True
 
     def forward(self, inputs, mask=None):
         ops.weights_fresh()

@@ -129,37 +129,67 @@ class WgradDesc(ctypes.Structure):
                 ("lda", c_long), ("ldb", c_long), ("ldc", c_long)]
 
 
+class _WgradLane:
+    __slots__ = ("stream", "descs", "alive", "after")
+
+    def __init__(self, stream):
+        self.stream, self.descs, self.alive, self.after = stream, [], [], []
+
+
 class WgradQueue:
     """Weight-gradient GEMMs of audio-sized encoder layers, held back until `group` layers' worth (4 problems each) are waiting and
     then launched together: 4 layers x 64 tiles = one 256 x 128 tile per CU over the whole reduction, no atomics (ttmi_wgrad_group).
-    Holds the operand buffers alive until then; `after` callbacks (gradient-ready hooks of the deferred parameters) run after the launch."""
+    Holds the operand buffers alive until then; `after` callbacks (gradient-ready hooks of the deferred parameters) run after the launch.
+    One lane per stream: a layer's problems are launched on the stream that produced their operands (the label encoder's backward pass
+    runs on a side stream beside the audio encoder's; their entries never share a launch)."""
 
     def __init__(self, group=4, immediate_first_layer=False):
         self.limit = 4 * group
         # data-parallel runs: the first layer's gradients are the last of the step - whatever is reduced after them overlaps nothing.  Left
         # out of the groups they are ready as early as before; the layers behind them are launched when the first layer's backward STARTS.
         self.immediate_first_layer = immediate_first_layer
-        self.descs, self.alive, self.after = [], [], []
+        self.lanes = {}
+
+    def _lane(self):
+        st = torch.cuda.current_stream()
+        key = (st.device.index, st.cuda_stream)
+        lane = self.lanes.get(key)
+        if lane is None:
+            lane = self.lanes[key] = _WgradLane(st)
+        return lane
+
+    @property
+    def descs(self):
+        return self._lane().descs
 
     def push(self, descs, tensors):
-        self.descs.extend(WgradDesc.from_buffer_copy(d) for d in descs)
-        self.alive.append(tensors)
+        lane = self._lane()
+        lane.descs.extend(WgradDesc.from_buffer_copy(d) for d in descs)
+        lane.alive.append(tensors)
 
     def add_callbacks(self, cbs):
-        self.after.extend(cbs)
+        self._lane().after.extend(cbs)
 
     def maybe_flush(self, force=False):
-        if self.descs and (force or len(self.descs) >= self.limit):
-            arr = (WgradDesc * len(self.descs))(*self.descs)
-            check(lib().ttmi_wgrad_group(arr, c_int(len(self.descs)), _stream()), "ttmi_wgrad_group")
-            cbs = self.after
-            self.descs, self.alive, self.after = [], [], []
+        """the current stream's lane: launch if `group` layers wait (or anything at all with force)"""
+        lane = self._lane()
+        if lane.descs and (force or len(lane.descs) >= self.limit):
+            arr = (WgradDesc * len(lane.descs))(*lane.descs)
+            check(lib().ttmi_wgrad_group(arr, c_int(len(lane.descs)), _stream()), "ttmi_wgrad_group")
+            cbs = lane.after
+            lane.descs, lane.alive, lane.after = [], [], []
             for cb in cbs:
                 cb()
 
+    def flush_all(self):
+        for lane in list(self.lanes.values()):
+            if lane.descs:
+                with torch.cuda.stream(lane.stream):
+                    self.maybe_flush(force=True)
+
     def discard(self):
         """an aborted backward pass leaves entries behind: drop them (their gradients are lost with the step)"""
-        self.descs, self.alive, self.after = [], [], []
+        self.lanes = {}
 
 
 wgrad_queue = None          # set by ttmi.train.FlatModel.enable_grouped_wgrads(); read by the sub-layer backward passes
@@ -169,10 +199,13 @@ def wgrad_defer_supported(rows, d, H, Dh, Di, prec):
     return bool(lib().ttmi_wgrad_defer_supported(c_long(rows), c_int(d), c_int(H), c_int(Dh), c_int(Di), c_int(prec)))
 
 
-def wgrad_flush():
-    """launch whatever weight gradients are still queued (end of a backward pass)"""
+def wgrad_flush(every_stream=False):
+    """launch the weight gradients still queued on the current stream (end of an encoder's backward pass), or on every stream"""
     if wgrad_queue is not None:
-        wgrad_queue.maybe_flush(force=True)
+        if every_stream:
+            wgrad_queue.flush_all()
+        else:
+            wgrad_queue.maybe_flush(force=True)
 
 
 # ----------------------------------------------------------------------------- sub-layers

@@ -202,6 +202,7 @@ class GradSync:
     def finish(self):
         """Wait for outstanding bucket reductions (stream-level wait, no host block on the GPU work);
         reduces any bucket whose hooks did not all fire (parameters unused in this step)."""
+        ops.wgrad_flush(every_stream=True)  # (normally a no-op: each encoder's first layer launches what its stream still holds)
         ops.join_side_streams()             # label-encoder gradients are written in place on the side stream
         if not self.active:
             return
@@ -241,6 +242,7 @@ class FusedOptimizer:
                                    "(use FlatModel.zero_grad(), not zero_grad(set_to_none=True))")
         self.global_step += 1
         self.steps_taken += 1
+        ops.wgrad_flush(every_stream=True)                # grouped weight gradients still queued (none after a complete backward pass)
         ops.join_side_streams()
         scale = 1.0 / self.world
         max_norm = self.max_grad_norm or 0.0
