@@ -84,7 +84,7 @@ def cpu_baseline(model, feats, proj, targets, T, U, n_utt, gpu_costs, reps):
         del z, cache, dz
     dt = float(np.median(times))
     rel = float(np.abs(gpu_costs[:n_utt] - costs).max() / np.abs(costs).max())
-    return n_utt / dt, dt, rel, times
+    return n_utt / dt, dt, rel, times, costs
 
 
 def pmc_form(path):
@@ -384,7 +384,11 @@ def main():
             with torch.no_grad():
                 lg = model(inputs[:args.cpu_utts], targets[:args.cpu_utts])
                 costs = RNNTLoss(reduction="none")(lg, targets[:args.cpu_utts].int(), ilen[:args.cpu_utts], tlen[:args.cpu_utts])
-            v, dt, rel, times = cpu_baseline(model, feats, proj, targets, T, U, args.cpu_utts, costs.float().cpu().numpy(), args.cpu_reps)
+                del lg
+                if form != "two-call":      # the timed loss form on the same sample: its per-utterance costs against the same oracle
+                    costs_form = model.loss(inputs[:args.cpu_utts], ilen[:args.cpu_utts], targets[:args.cpu_utts], tlen[:args.cpu_utts],
+                                            reduction="none", chunk=args.loss_chunk or None, exp_domain=form == "exp")
+            v, dt, rel, times, oracle_costs = cpu_baseline(model, feats, proj, targets, T, U, args.cpu_utts, costs.float().cpu().numpy(), args.cpu_reps)
             out["cpu_baseline"] = {"value": round(v, 4), "unit": "utt/s", "cores": _blas_threads(), "kind": "port",
                                    "sample": "%d utterance(s) of the same workload (B=%d as in BASELINE.md §3), fwd+loss+bwd through "
                                              "oracle/tt_oracle.py (numpy, multithreaded BLAS) + oracle/rnnt_lattice.c, median of %d runs "
@@ -392,6 +396,8 @@ def main():
                                    # the reference's OWN PyTorch CPU path, timed once in the survey container (it cannot travel to the GPU box):
                                    "reference_cpu_probe": {"value": 0.33, "unit": "utt/s", "cores": 8, "source": "BASELINE.md §2 (fwd+bwd, lattice excluded, B=2)"}}
             out["loss_rel_err_vs_oracle"] = float("%.3e" % rel)
+            if form != "two-call":
+                out["loss_rel_err_vs_oracle_timed_form"] = float("%.3e" % (np.abs(costs_form.float().cpu().numpy() - oracle_costs).max() / np.abs(oracle_costs).max()))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -114,6 +114,7 @@ int ttmi_rnnt_loss_bwd(const void* logits, int dtype, long ldv, const int* label
  * shift / shift_cur: device scalar (nullable = 0) subtracted before exp; shift_next (device scalar, nullable):
  * max(itself, max_rows(log-sum-exp) - 40), the value to pass as shift on the next step. */
 int ttmi_joint_exp_supported(int B, int T, int U1, int J, int V, int prec, long ldv);
+int ttmi_joint_exp_fwd_supported(int B, int T, int U1, int J, int V, int prec, long ldv);     /* forward + loss only (no gradients wanted) */
 int ttmi_joint_exp_nparts(int V);
 int ttmi_joint_fwd_exp(const float* enc, const float* dec, const float* wf, const float* bf, const float* wp, const float* bp,
                        int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx, float* ws, void* P, long ldv,

@@ -48,7 +48,7 @@ inline int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, 
 // colsum_w (nullable, bf16 [K], 16-byte aligned; persistent 256x256 kernel only): the column sums become sum_k colsum_w[k] A[k][m]
 int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
                  hipStream_t st, float* colsum_a = nullptr, const FastBatch& batch = FastBatch(), const bf16_t* colsum_w = nullptr);
-bool gemm_fast_joint_exp_ok(int M, int V, int J, long ldv);   // sizes at which the exp-store / row-scale / weighted-colsum forms exist
+bool gemm_fast_joint_exp_ok(int M, int V, int J, long ldv, bool fwd_only = false);   // sizes at which the exp-store / row-scale / weighted-colsum forms exist
 // one weight-gradient problem of a grouped launch: C[M,N] += A[K,M]^T B[K,N] (bf16 operands, f32 C), colsum (nullable, f32 [M]) += column sums of A
 struct TnProblem {
     const bf16_t* A; const bf16_t* B; float* C; float* colsum;

@@ -2253,9 +2253,11 @@ static bool tn_v8_eligible(int M, int N, int K, bool colsum, int* S_out, bool* s
 }
 // can the fused joint + loss fast path run at this size?  (projection forward with the exp store, dgrad with the row factor,
 // wgrad with the weighted column sums - all three on the persistent 256x256 kernels)
-bool gemm_fast_joint_exp_ok(int M, int V, int J, long ldv) {
+bool gemm_fast_joint_exp_ok(int M, int V, int J, long ldv, bool fwd_only) {
     if (M <= 0 || V <= 0 || J <= 0 || ldv < V) return false;
-    if (!nt_v8_eligible(M, V, J) || !nt_v8_eligible(M, J, (int)ldv)) return false;
+    if (!nt_v8_eligible(M, V, J)) return false;
+    if (fwd_only) return true;                                      // (evaluation: only the exp-store projection runs)
+    if (!nt_v8_eligible(M, J, (int)ldv)) return false;
     return tn_v8_eligible(V, J, M, true, nullptr, nullptr);       // (a ragged V % 256 strip rides inside the kernel or takes the 128x128 kernel: both weight their column sums)
 }
 

@@ -875,13 +875,18 @@ int ttmi_joint_exp_supported(int B, int T, int U1, int J, int V, int prec, long 
     if (!joint_fast(prec, J) || (long)B * T * U1 >= (1L << 31) || ldv % 64 != 0) return 0;
     return gemm_fast_joint_exp_ok(B * T * U1, V, J, ldv) ? 1 : 0;
 }
+// forward + loss only (no gradients wanted): the backward GEMMs' size conditions do not apply
+int ttmi_joint_exp_fwd_supported(int B, int T, int U1, int J, int V, int prec, long ldv) {
+    if (!joint_fast(prec, J) || (long)B * T * U1 >= (1L << 31) || ldv % 64 != 0) return 0;
+    return gemm_fast_joint_exp_ok(B * T * U1, V, J, ldv, true) ? 1 : 0;
+}
 int ttmi_joint_exp_nparts(int V) { return 4 * ((V + 255) / 256); }
 
 int ttmi_joint_fwd_exp(const float* enc, const float* dec, const float* wf, const float* bf, const float* wp, const float* bp,
                        int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx, float* ws, void* P, long ldv,
                        float* rowsum, int nparts, const float* shift, void* stream) {
     TTMI_REQUIRE(rowsum && nparts >= ttmi_joint_exp_nparts(V), "joint_fwd_exp: rowsum needs >= %d parts per row", ttmi_joint_exp_nparts(V));
-    TTMI_REQUIRE(ttmi_joint_exp_supported(B, T, U1, J, V, prec, ldv), "joint_fwd_exp: size / precision outside the fast path (B=%d T=%d U1=%d J=%d V=%d)", B, T, U1, J, V);
+    TTMI_REQUIRE(ttmi_joint_exp_fwd_supported(B, T, U1, J, V, prec, ldv), "joint_fwd_exp: size / precision outside the fast path (B=%d T=%d U1=%d J=%d V=%d)", B, T, U1, J, V);
     return joint_fwd_impl(enc, dec, wf, bf, wp, bp, B, T, U1, de, dd, J, V, prec, ctx, ws, P, ldv, rowsum, nparts, shift, stream);
 }
 

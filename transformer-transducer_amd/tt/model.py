@@ -50,13 +50,13 @@ class _JointLossFn(torch.autograd.Function):
     _shift = {}
 
     @staticmethod
-    def forward(ctx, enc, dec, wf, bf, wp, bp, labels, act_lens, label_lens, prec, chunk, reduction, exp_domain):
+    def forward(ctx, enc, dec, wf, bf, wp, bp, labels, act_lens, label_lens, prec, chunk, reduction, exp_domain, grad_mode=True):
         enc, dec = enc.contiguous(), dec.contiguous()
         params = (wf, bf, wp, bp)
         wf_, bf_, wp_, bp_ = (t.detach() for t in params)
         B, T = enc.shape[0], enc.shape[1]
         U1 = dec.shape[1]
-        need = any(ctx.needs_input_grad[:6])
+        need = grad_mode and any(ctx.needs_input_grad[:6])      # (needs_input_grad ignores torch.no_grad(); forward() itself always runs without grad mode)
         costs = torch.empty(B, dtype=torch.float32, device=enc.device)
         one = torch.ones(1, dtype=torch.float32, device=enc.device)
         scale = 1.0 / B if reduction == "mean" else 1.0
@@ -80,7 +80,7 @@ class _JointLossFn(torch.autograd.Function):
             c1 = min(B, c0 + chunk)
             ws = ops.rnnt_workspace(c1 - c0, T, U1, enc.device)
             lab, al, ll = labels[c0:c1], act_lens[c0:c1], label_lens[c0:c1]
-            if exp_domain and ops.joint_exp_supported(c1 - c0, T, U1, J, V, prec):
+            if exp_domain and ops.joint_exp_supported(c1 - c0, T, U1, J, V, prec, fwd_only=not need):
                 # the projection stores exp(logit - shift) and row sums; the loss reads two entries per row, its gradient stays
                 # factored as (row factor) x P and is consumed in that form (include/ttmi.h, "fused joint + loss fast path")
                 P, rowsum, saved = ops.joint_fwd_exp(enc[c0:c1], dec[c0:c1], wf_, bf_, wp_, bp_, prec, cur)
@@ -123,7 +123,7 @@ class _JointLossFn(torch.autograd.Function):
                     cb()
             else:
                 rets.append(gp * gout)
-        return (denc * gout, ddec * gout, *rets, None, None, None, None, None, None, None)
+        return (denc * gout, ddec * gout, *rets, None, None, None, None, None, None, None, None)
 
 
 class JointNet(nn.Module):
@@ -242,7 +242,7 @@ class Transducer(nn.Module):
             chunk = self.default_loss_chunk(B, T, U1, exp_domain)
         j = self.joint
         return _JointLossFn.apply(enc_state, dec_state, j.forward_layer.weight, j.forward_layer.bias, j.project_layer.weight,
-                                  j.project_layer.bias, labels, al, ll, prec, int(chunk), reduction, bool(exp_domain))
+                                  j.project_layer.bias, labels, al, ll, prec, int(chunk), reduction, bool(exp_domain), torch.is_grad_enabled())
 
     def default_loss_chunk(self, B, T, U1, exp_domain=False):
         """utterances per chunk of `loss()`: about 2 GB of logits (the memory-saving form) or 16 GB (exp_domain: the speed form - every

@@ -401,9 +401,10 @@ def joint_bwd(dlogits, enc, dec, wf, wp, ctx, prec, grads, out=None):
 
 
 # ---- fused joint + loss fast path (exp-domain forms, include/ttmi.h)
-def joint_exp_supported(B, T, U1, J, V, prec):
+def joint_exp_supported(B, T, U1, J, V, prec, fwd_only=False):
     ldv = (V + 63) // 64 * 64
-    return bool(lib().ttmi_joint_exp_supported(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(V), c_int(prec), c_long(ldv)))
+    fn = lib().ttmi_joint_exp_fwd_supported if fwd_only else lib().ttmi_joint_exp_supported
+    return bool(fn(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(V), c_int(prec), c_long(ldv)))
 
 
 def joint_fwd_exp(enc, dec, wf, bf, wp, bp, prec, shift=None):
