@@ -402,7 +402,9 @@ __global__ __launch_bounds__(256) void rnnt_prep_exp_kernel(
     const long rows = (long)B * T * U1;
     float S = 0.f;
     for (int i = 0; i < nparts; ++i) S += rowsum[i * rows + row];        // part-major: coalesced across the block's rows
-    const float l = __logf(S);
+    // a row whose every exp(logit - shift) underflowed (its logits sit ~127 below the largest log-sum-exp the shift was taken from) has lost its
+    // information; keep the numbers finite instead of letting -inf / NaN spread through the lattice
+    const float l = S > 1.0e-37f ? __logf(S) : -85.f;
     lse[row] = l;
     if (shift_next) {
         // the shift the NEXT step should use: this row's log-sum-exp in logit units, less a margin that keeps exp() far from both
