@@ -194,3 +194,31 @@ def test_exp_domain_shift(monkeypatch):
     c = _run(model, x, y, al, ll, chunk=8, exp_domain=True)
     d = _run(model, x, y, al, ll, chunk=8)
     assert np.isfinite(c[0]) and abs(c[0] - d[0]) < 2e-4 * d[0]
+
+
+def test_exp_domain_long_label_sequences(monkeypatch):
+    """U + 1 = 201 labels per lattice column block (C5's label length: the 4-slot variant of the alpha / beta kernel) at T = 320, B = 4
+    (257 280 rows in one chunk), ragged lengths: exp-domain form against the plain bf16 form and the fp32 pipeline"""
+    from tt.model import Transducer
+    from tt.utils import AttrDict
+    monkeypatch.setenv("TTMI_PRECISION", "fp32")
+    side = dict(n_layer=1, d_model=512, n_head=8, d_head=64, d_inner=256)
+    cfg = AttrDict(dict(enc=dict(side, max_input_length=64), dec=dict(side, max_target_length=32),
+                        joint=dict(input_size=1024, inner_size=1024), vocab_size=4334, dropout=0.0))
+    torch.manual_seed(4)
+    model = Transducer(cfg).cuda().train()
+    B, T, U = 4, 320, 200
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(B, T, 512, device="cuda", generator=g)
+    y = torch.randint(1, 4334, (B, U), device="cuda", generator=g)
+    al = torch.tensor([T, T - 37, T, T - 5], dtype=torch.int32, device="cuda")
+    ll = torch.tensor([U, U - 60, U - 1, U], dtype=torch.int32, device="cuda")
+    ref = _run(model, x, y, al, ll, chunk=B)
+    monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    plain = _run(model, x, y, al, ll, chunk=B)
+    fast = _run(model, x, y, al, ll, chunk=B, exp_domain=True)
+    e_plain, e_fast = rel_err(plain[1], ref[1]), rel_err(fast[1], ref[1])
+    print("U=200: loss fp32 %.4f  bf16 %.4f  exp-domain %.4f;  gradient error vs fp32: bf16 %.2e, exp-domain %.2e" % (ref[0], plain[0], fast[0], e_plain, e_fast))
+    assert abs(fast[0] - ref[0]) < 2e-4 * ref[0] and abs(plain[0] - ref[0]) < 2e-4 * ref[0]
+    assert fast[0] != plain[0]                               # (the exp-domain kernels ran: the two forms round differently)
+    assert e_fast < max(1.5 * e_plain, 5e-3)
