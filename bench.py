@@ -87,6 +87,50 @@ def cpu_baseline(model, feats, proj, targets, T, U, n_utt, gpu_costs, reps):
     return n_utt / dt, dt, rel, times, costs
 
 
+# ---- multi-rank control flow of the driver contract (covered on CPU by tests/test_bench_flow.py over gloo, world size 2)
+def rank_seed(rank):
+    """every rank draws its own synthetic utterances: generator seed 1234 + rank; the MODEL seed is the same everywhere"""
+    return 1234 + int(rank)
+
+
+def dp_options(world):
+    """what a data-parallel run switches on: the first audio layer keeps its own weight-gradient launches (its gradients are the last of
+    the step - nothing is left to overlap a grouped launch's late all-reduce with), and backward leaves 32 CUs to RCCL's kernels"""
+    return {"immediate_first_layer": world > 1, "reserve_cus": 32 if world > 1 else 0}
+
+
+def fence(world, cuda=True):
+    """barrier over the ranks, then drain the device: both sides of every timed region"""
+    if world > 1:
+        dist.barrier()
+    if cuda:
+        torch.cuda.synchronize()
+
+
+def timed_region(step, steps, warmup, world, cuda=True):
+    """`warmup` untimed steps, fence, EXACTLY `steps` timed ones, fence -> (elapsed, enqueue wall, host CPU) seconds of this rank"""
+    for _ in range(warmup):
+        step(False, 0)
+    fence(world, cuda)
+    t0, c0 = time.perf_counter(), time.process_time()
+    last = None
+    for i in range(steps):
+        last = step(True, i)
+    enqueue = time.perf_counter() - t0               # wall time the host spent issuing the work: its own CPU time + time blocked on a full queue
+    host_cpu = time.process_time() - c0              # CPU time of this process (all threads, incl. autograd's backward thread) over the same window
+    fence(world, cuda)
+    return time.perf_counter() - t0, enqueue, host_cpu, last
+
+
+def max_over_ranks(values, world, device):
+    """the slowest rank's figure for every entry (None entries stay None on every rank)"""
+    if world <= 1:
+        return list(values)
+    t = torch.tensor([v or 0.0 for v in values], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(x) if v is not None else None for x, v in zip(t.tolist(), values)]
+
+
 def pmc_form(path):
     """the loss form the committed PMC passes were taken with (tools/update_pmc_json.py)"""
     try:
@@ -163,6 +207,8 @@ def main():
                          "auto = exp in bf16 train mode, two-call otherwise.  Whatever runs first, the JSON line also carries the two-call form's timing.")
     ap.add_argument("--fused-loss", action="store_true", help="same as --loss-form fused")
     ap.add_argument("--no-two-call", action="store_true", help="skip the secondary timing of the two-call form (profiling runs: one loss form per trace)")
+    ap.add_argument("--no-fp32-form", action="store_true", help="skip the secondary timing of the fp32 mode (the 1e-4 parity path)")
+    ap.add_argument("--fp32-steps", type=int, default=5, help="steps of the fp32-mode secondary timing (at most --steps)")
     ap.add_argument("--loss-chunk", type=int, default=0, help="utterances per chunk of the fused loss (0 = default: logits chunk <= 2 GB)")
     ap.add_argument("--emit-rate", type=float, default=0.1, help="decode mode: fraction of frames that emit a symbol (blank bias is set for it)")
     args = ap.parse_args()
@@ -173,7 +219,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    local = local % max(torch.cuda.device_count(), 1)
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        sys.exit("bench.py: no GPU visible (the MI355X path has no CPU fallback)")
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if local_world > ndev and not os.environ.get("TTMI_BENCH_SHARE_GPUS"):
+        # one rank per GPU is the contract: several ranks on one device would hang in RCCL's rendezvous or measure something else
+        sys.exit("bench.py: %d ranks on this node but only %d GPU(s) visible; launch with --nproc-per-node <= %d "
+                 "(TTMI_BENCH_SHARE_GPUS=1 lets ranks share devices over the gloo backend for rehearsals)" % (local_world, ndev, ndev))
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -200,7 +254,7 @@ def main():
     model = Transducer(cfg).to(dev).train()
     flat = FlatModel(model)
     if args.precision == "bf16" and not args.no_grouped_wgrads:
-        flat.enable_grouped_wgrads(immediate_first_layer=world > 1)       # encoder weight gradients four layers at a time: one tile per CU, no K-split atomics
+        flat.enable_grouped_wgrads(immediate_first_layer=dp_options(world)["immediate_first_layer"])   # encoder weight gradients four layers at a time: one tile per CU, no K-split atomics
     if args.precision == "bf16" and not args.no_weight_shadows:
         flat.enable_shadows()                              # bf16 weight copies rebuilt once per optimiser step (one launch) instead of per call
     sync = GradSync(flat)
@@ -208,7 +262,7 @@ def main():
     criterion = RNNTLoss()
 
     B, T, U, V, d = args.batch, args.T, args.U, cfg["vocab_size"], cfg["enc"]["d_model"]
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    g = torch.Generator(device=dev).manual_seed(rank_seed(rank))
     feats = torch.randn(B, T, 80, device=dev, generator=g)
     proj = torch.randn(80, d, device=dev, generator=torch.Generator(device=dev).manual_seed(7)) / 80 ** 0.5
     targets = torch.randint(1, V, (B, U), device=dev, generator=g)
@@ -227,9 +281,11 @@ def main():
     if form == "auto":
         form = "exp" if args.precision == "bf16" else "two-call"
 
+    reserve = dp_options(world)["reserve_cus"]
+
     def step(timed, i=0):
         # harness front-end: fixed 80 -> d_model projection (the reference encoder has no input layer)
-        ops.gemm(feats, proj, inputs, B * T, d, 80, 80, d, d, gflags)
+        ops.gemm(feats, proj, inputs, B * T, d, 80, 80, d, d, gflags if os.environ["TTMI_PRECISION"] == "bf16" else ops.GEMM_A_KMAJOR)
         flat.zero_grad()
         sync.start_step()
         if timed and rank == 0:
@@ -239,53 +295,44 @@ def main():
         else:
             logits = model(inputs, targets)
             loss = criterion(logits, targets.int(), ilen, tlen)
-        if world > 1:
-            ops.reserve_cus(32)                       # gradient all-reduce kernels run beside backward: the persistent encoder GEMMs leave them 4 CUs per XCD (per-stream state)
+        if reserve:
+            ops.reserve_cus(reserve)                  # gradient all-reduce kernels run beside backward: the persistent encoder GEMMs leave them 4 CUs per XCD (per-stream state)
         loss.backward()
         sync.finish()
-        if world > 1:
+        if reserve:
             ops.reserve_cus(0)                        # the next forward pass gets the whole chip (read at launch time)
         opt.step()
         loss_sum.add_(loss.detach())
         return loss
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        last = step(True, i)
-    enqueue = time.perf_counter() - t0               # host time to issue the work (GPU-bound when well below `elapsed`)
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed, enqueue, host_cpu, last = timed_region(step, args.steps, args.warmup, world)
     if rank == 0:                                     # the probes are read after the timed region: no host sync inside it
         slots = [i % 64 for i in range(max(0, args.steps - 64), args.steps)]
         probe_ms = [ops.probe_read_ms(i) for i in slots]
         loss_ms = [(ops.probe_read_ms(i, 1), ops.probe_read_ms(i, 2)) for i in slots]
         attn_ms = [ops.probe_read_ms(i, 3) for i in slots]
         wgrad_ms = [ops.probe_read_ms(i, 4) for i in slots]
-    two_call = None
-    if form != "two-call" and args.mode == "train" and not args.no_two_call:
-        # the reference's own call sequence beside the fused form, same model / data / optimizer state, same barrier + synchronize bracket
-        main_form, form = form, "two-call"
-        for _ in range(max(1, args.warmup)):
-            step(False)
-        fence()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            step(False)
-        fence()
-        two_call = time.perf_counter() - t1
-        form = main_form
-    if world > 1:
-        t = torch.tensor([elapsed, two_call or 0.0], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, two_call = float(t[0]), (float(t[1]) if two_call is not None else None)
+    def secondary(other_form, precision, steps, warmup):
+        """the same step with another loss form / precision, same model, data and optimiser state, same barrier + synchronize bracket"""
+        nonlocal form
+        main_form, form = form, other_form
+        main_prec = os.environ["TTMI_PRECISION"]
+        os.environ["TTMI_PRECISION"] = precision
+        try:
+            return timed_region(lambda timed, i: step(False), steps, warmup, world)[0]
+        finally:
+            form = main_form
+            os.environ["TTMI_PRECISION"] = main_prec
+
+    two_call = fp32_form = None
+    fp32_steps = max(1, min(args.steps, args.fp32_steps))
+    if form != "two-call" and not args.no_two_call:
+        # the reference's own call sequence (train.py:51-53) beside the fused form
+        two_call = secondary("two-call", args.precision, args.steps, max(1, args.warmup))
+    if args.precision == "bf16" and not args.no_fp32_form and args.workload == "c2":
+        # the fp32 mode: the path that meets north_star's 1e-4 tolerance (tests/test_configs_gpu.py), timed on the same workload
+        fp32_form = secondary("two-call", "fp32", fp32_steps, 1)
+    elapsed, two_call, fp32_form = max_over_ranks([elapsed, two_call, fp32_form], world, dev)
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
@@ -293,9 +340,20 @@ def main():
         U1, J = U + 1, cfg["joint"]["inner_size"]
         B_launch = B if form == "two-call" else (args.loss_chunk or model.default_loss_chunk(B, T, U1, form == "exp"))      # utterances per joint-projection launch
         flop_launch = 2.0 * B_launch * T * U1 * J * V                            # one joint-projection launch
-        k_ms = float(np.mean([m for m in probe_ms if m > 0])) if probe_ms else float("nan")
+        def mean_pos(vals):
+            vals = [v for v in vals if v is not None and v > 0]
+            return float(np.mean(vals)) if vals else None
+
+        def rate(work, ms, unit_div, digits=2):
+            """work / time in the roofline's unit, or None when the probe never fired (never NaN: the line stays strict JSON)"""
+            return None if ms is None else round(work / (ms * 1e-3) / unit_div, digits)
+
+        def frac(a, pk):
+            return None if a is None else round(a / pk, 4)
+
+        k_ms = mean_pos(probe_ms)
         peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
-        ach = flop_launch / (k_ms * 1e-3) / 1e12
+        ach = rate(flop_launch, k_ms, 1e12)
         traffic = None          # HBM-side bytes of one launch from the committed PMC passes (only valid for the default workload)
         mfma_busy = None
         pmc = os.path.join(ROOT, "profiles", "pmc_joint_projection.json")
@@ -313,48 +371,59 @@ def main():
         # the RNN-T loss op at the API boundary: logits read once, gradient written once, alpha / beta / lp_blank / lp_label in f32
         es = 2 if args.precision == "bf16" else 4
         loss_bytes = B_launch * (2.0 * es * T * U1 * V + 16.0 * T * U1)
-        lf = float(np.mean([a for a, b in loss_ms if a > 0 and b > 0])) if loss_ms else float("nan")
-        lb = float(np.mean([b for a, b in loss_ms if a > 0 and b > 0])) if loss_ms else float("nan")
-        loss_gbs = loss_bytes / ((lf + lb) * 1e-3) / 1e9
+        lf = mean_pos([a for a, b in loss_ms if a > 0 and b > 0])
+        lb = mean_pos([b for a, b in loss_ms if a > 0 and b > 0])
+        l_ms = None if lf is None or lb is None else lf + lb
+        loss_gbs = rate(loss_bytes, l_ms, 1e9, 1)
+        ran_exp = form == "exp" and ops.joint_exp_supported(B_launch, T, U1, J, V, 1)       # what Transducer.loss actually selected for these chunks
         roof_joint = {"bound": "mfma", "kernel": "gemm_nt_bf16_v8_kernel (joint vocabulary projection%s, M=%d N=%d K=%d)"
-                                                 % (", exp-store epilogue" if form == "exp" else "", B_launch * T * U1, V, J),
-                      "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                      "traffic": traffic, "mfma_busy": mfma_busy, "kernel_ms": round(k_ms, 4), "pmc": pmc_build}
+                                                 % (", exp-store epilogue" if ran_exp else "", B_launch * T * U1, V, J),
+                      "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": frac(ach, peak),
+                      "traffic": traffic, "mfma_busy": mfma_busy, "kernel_ms": None if k_ms is None else round(k_ms, 4), "pmc": pmc_build}
+        if k_ms is None:
+            roof_joint["reason"] = "probe 0 (joint projection launch) never fired in the timed steps"
         # the two weakest kernels of the step, on the record every round
         enc = cfg["enc"]
         H, Dh, dm = enc["n_head"], enc["d_head"], enc["d_model"]
-        a_ms = float(np.mean([m for m in attn_ms if m > 0])) if any(m > 0 for m in attn_ms) else float("nan")
+        a_ms = mean_pos(attn_ms)
         attn_bytes = B * T * H * Dh * 2.0 * 6 + B * H * T * 8.0       # (q+u), k, v, dO in; dK, dV out (bf16); lse + delta (f32)
         attn_flops = 10.0 * B * H * T * T * Dh                         # S, dP, dV, dK and (in the following launch) dq products
         roof_attn = {"bound": "hbm", "kernel": "attention backward kernel (flash_bwd_rel_kernel), one audio layer (B=%d L=%d H=%d Dh=%d): recomputes P incl. the "
                                                "position term, writes dK / dV and dS twice (bf16) for the dq / dE products" % (B, T, H, Dh),
-                     "achieved": round(attn_bytes / (a_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(attn_bytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(a_ms, 4),
-                     "mfma_tflops": round(0.8 * attn_flops / (a_ms * 1e-3) / 1e12, 1),
+                     "achieved": rate(attn_bytes, a_ms, 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": frac(rate(attn_bytes, a_ms, 1e9, 1), HBM_PEAK_GBS), "traffic": None, "kernel_ms": None if a_ms is None else round(a_ms, 4),
+                     "mfma_tflops": rate(0.8 * attn_flops, a_ms, 1e12, 1),
                      "note": "algorithmic bytes only (q, k, v, dO in; dK, dV out); the dS / dG slabs written (2 x B*H*L*L*2 bytes) are design traffic on top; "
                              "kernel_ms is the first audio layer's launch between two events on its stream"}
-        w_ms = float(np.mean([m for m in wgrad_ms if m > 0])) if any(m > 0 for m in wgrad_ms) else float("nan")
-        wg_flops = 2.0 * (3 * H * Dh) * dm * (B * T)
-        roof_wgrad = {"bound": "mfma", "kernel": "qkv_net weight gradient, one audio layer (M=%d N=%d K=%d, f32 atomics across K ranges)" % (3 * H * Dh, dm, B * T),
-                      "achieved": round(wg_flops / (w_ms * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
-                      "frac": round(wg_flops / (w_ms * 1e-3) / 1e12 / peak, 4), "traffic": None, "kernel_ms": round(w_ms, 4)}
-        if form == "exp":
+        w_ms = mean_pos(wgrad_ms)
+        Di = enc["d_inner"]
+        wg_layer = 2.0 * (B * T) * (3 * H * Dh * dm + H * Dh * dm + 2 * dm * Di)        # qkv_net, o_net, CoreNet.0, CoreNet.3 of one audio layer
+        roof_wgrad = {"bound": "mfma", "kernel": "gemm_tn_bf16_group_kernel: the 16 weight-gradient GEMMs of four audio layers in one launch (256 tiles of "
+                                                 "256x128, one per CU over K=%d, no atomics); first grouped launch of the step" % (B * T),
+                      "achieved": rate(4 * wg_layer, w_ms, 1e12), "peak": peak, "unit": "TFLOP/s",
+                      "frac": frac(rate(4 * wg_layer, w_ms, 1e12), peak), "traffic": None, "kernel_ms": None if w_ms is None else round(w_ms, 4)}
+        if w_ms is None:
+            roof_wgrad["reason"] = "no grouped weight-gradient launch in the timed steps (fp32 mode or --no-grouped-wgrads: per-layer launches)"
+        if a_ms is None:
+            roof_attn["reason"] = "probe 3 (fused attention backward of an audio-sized layer) never fired"
+        if ran_exp:
             # exp-domain form: no pass over the lattice's rows is left - the forward reads the row-sum partials and two entries per row, the
             # backward writes a factor per row and patches two entries; what remains is the alpha / beta recursion (a serial chain per utterance)
             nparts = 4 * ((V + 255) // 256)
-            loss_bytes = B_launch * T * U1 * (4.0 * nparts + 2 * 2 + 4 * 4 + 2 * 8 + 2 * 8 + 4 + 2 + 2 * 2 * 2)
-            loss_gbs = loss_bytes / ((lf + lb) * 1e-3) / 1e9
-            roof_loss = {"bound": "hbm", "kernel": "RNN-T loss op, exp-domain form: rnnt_prep_exp_kernel + rnnt_alphabeta_kernel (%.3f ms) + rnnt_scale_exp_kernel "
-                                                   "(%.3f ms), P = exp(logits - shift) [%d,%d,%d,%d] bf16 touched at 2 entries per row" % (lf, lb, B_launch, T, U1, V),
-                         "achieved": round(loss_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(loss_gbs / HBM_PEAK_GBS, 4),
-                         "traffic": None, "kernel_ms": round(lf + lb, 4),
+            loss_bytes = B_launch * T * U1 * (4.0 * nparts + 2 * 4 + 4 * 4 + 2 * 8 + 2 * 8 + 4 + 2 + 2 * 2 * 2)
+            loss_gbs = rate(loss_bytes, l_ms, 1e9, 1)
+            roof_loss = {"bound": "hbm", "kernel": "RNN-T loss op, exp-domain form: rnnt_prep_exp_kernel + rnnt_alphabeta_kernel (%s ms) + rnnt_scale_exp_kernel "
+                                                   "(%s ms), P = exp(logits - shift) [%d,%d,%d,%d] bf16 patched at 2 entries per row, emission logits f32 [rows, 2]"
+                                                   % (lf and round(lf, 3), lb and round(lb, 3), B_launch, T, U1, V),
+                         "achieved": loss_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac(loss_gbs, HBM_PEAK_GBS),
+                         "traffic": None, "kernel_ms": None if l_ms is None else round(l_ms, 4),
                          "note": "latency-bound by the lattice recursion (T+U serial steps per utterance, one wave each); the two-call form's loss op moves "
                                  "%.1f GB per step through rnnt_lse_kernel / rnnt_grad_kernel instead" % (B * (2.0 * es * T * U1 * V) / 1e9)}
         else:
-            roof_loss = {"bound": "hbm", "kernel": "RNN-T loss op: rnnt_lse_kernel + rnnt_alphabeta_kernel (%.3f ms) + rnnt_grad_kernel (%.3f ms), "
-                                                   "logits [%d,%d,%d,%d] %s" % (lf, lb, B_launch, T, U1, V, "bf16" if es == 2 else "f32"),
-                         "achieved": round(loss_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(loss_gbs / HBM_PEAK_GBS, 4),
-                         "traffic": None, "kernel_ms": round(lf + lb, 4)}
+            roof_loss = {"bound": "hbm", "kernel": "RNN-T loss op: rnnt_lse_kernel + rnnt_alphabeta_kernel (%s ms) + rnnt_grad_kernel (%s ms), "
+                                                   "logits [%d,%d,%d,%d] %s" % (lf and round(lf, 3), lb and round(lb, 3), B_launch, T, U1, V, "bf16" if es == 2 else "f32"),
+                         "achieved": loss_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac(loss_gbs, HBM_PEAK_GBS),
+                         "traffic": None, "kernel_ms": None if l_ms is None else round(l_ms, 4)}
         lattice_run = args.workload == "c5"             # BASELINE configs[4] is the lattice's HBM-roofline run: the loss op is its dominant-kernel line
         out = {
             "metric": "utterances/sec (fwd+bwd) on 80-d fbank T=%d U=%d" % (T, U), "value": round(utt_s, 3), "unit": "utt/s",
@@ -367,18 +436,31 @@ def main():
                                     % args.workload.split("-")[1]) +
                                    ", T=%d U=%d, batch %d/GPU, dropout 0.1, SGD momentum + clip 200" % (T, U, B),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
+            # host side of a step: CPU time this process spent (Python + ctypes + HIP runtime, every thread) and the rest of the enqueue wall
+            # time, i.e. time blocked (full queue, allocator waits).  CPU time well below ms_per_step = the step is GPU-bound.
+            "host_cpu_ms_per_step": round(1e3 * host_cpu / args.steps, 3),
+            "host_blocked_ms_per_step": round(max(0.0, 1e3 * (enqueue - host_cpu) / args.steps), 3),
             "host_enqueue_ms_per_step": round(1e3 * enqueue / args.steps, 3), "model_tflops": round(flops_per_utt(cfg, T, U1) * utt_s / 1e12, 2),
             "roofline": roof_loss if lattice_run else roof_joint,
             "roofline_joint" if lattice_run else "roofline_loss": roof_joint if lattice_run else roof_loss,
             "roofline_attn": roof_attn, "roofline_wgrad": roof_wgrad,
             "final_loss": round(float(last.detach()), 4),
         }
+        ran = "exp" if ran_exp else ("fused" if form != "two-call" else "two-call")       # the form that RAN (exp falls back to the memory form outside the persistent kernels' sizes)
         out["config"]["loss"] = {"two-call": "logits = model(inputs, targets); RNNTLoss()(logits, ...) as in train.py:51-53",
                                  "fused": "Transducer.loss (fused joint + loss, memory form), %d utterances per chunk" % B_launch,
-                                 "exp": "Transducer.loss(exp_domain=True) (fused joint + loss, exp-domain form), %d utterances per chunk" % B_launch}[form]
+                                 "exp": "Transducer.loss(exp_domain=True) (fused joint + loss, exp-domain form), %d utterances per chunk" % B_launch}[ran]
+        if ran != form:
+            out["config"]["loss"] += " [requested: %s; chunks of %d x %d x %d lattice rows are outside the exp-domain kernels' sizes]" % (form, B_launch, T, U1)
+        out["config"]["loss_form"] = ran
         if two_call is not None:
             out["two_call_form"] = {"ms_per_step": round(1e3 * two_call / args.steps, 3), "value": round(world * B * args.steps / two_call, 3), "unit": "utt/s",
                                     "note": "the same %d steps with train.py's own call sequence (model(inputs, targets) + RNNTLoss), timed right after the main region" % args.steps}
+        if fp32_form is not None:
+            out["fp32_form"] = {"ms_per_step": round(1e3 * fp32_form / fp32_steps, 3), "value": round(world * B * fp32_steps / fp32_form, 3), "unit": "utt/s",
+                                "dtype": "f32", "steps": fp32_steps,
+                                "note": "TTMI_PRECISION=fp32 (exact-f32 MFMA everywhere, train.py's call sequence): the mode whose loss and gradients are "
+                                        "within 1e-4 of the oracle (tests/test_configs_gpu.py::test_c2_full_model_fp32_end_to_end), timed right after the main region"}
         if world == 1 and not args.no_cpu_baseline:
             model.eval()
             with torch.no_grad():

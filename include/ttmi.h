@@ -112,16 +112,24 @@ int ttmi_rnnt_loss_bwd(const void* logits, int dtype, long ldv, const int* label
  * blank / label entries of P so that d logits[r, :] = srow[r] * P[r, :]; ttmi_joint_bwd_exp consumes that product without forming it
  * (row factor in the dgrad epilogue and on the wgrad's activation operand; ctx is overwritten).
  * shift / shift_cur: device scalar (nullable = 0) subtracted before exp; shift_next (device scalar, nullable):
- * max(itself, max_rows(log-sum-exp) - 40), the value to pass as shift on the next step. */
+ * max(itself, max_rows(log-sum-exp) - 40), the value to pass as shift on the next step.
+ * emis (nullable, f32 [rows, 2], 8-byte aligned): ttmi_joint_fwd_exp also leaves the logits of `blank` and of each row's next label
+ * (labels int32 [B, U1-1]) in f32 - formed from the bf16 operands the projection multiplies - and ttmi_rnnt_loss_fwd_exp takes the two
+ * emission log-probs from them instead of from bf16-rounded entries of P (loss error of the form: ~5e-5 -> ~1e-5 at C2).
+ * flag (nullable, device int): bit 0 is set when a lattice row's sum underflowed or overflowed (the shift no longer fits the logits);
+ * the costs and gradients of that step are then NaN (never finite-and-wrong): drop the step, run one step in the plain form and take a new
+ * shift from its workspace with ttmi_rnnt_shift_seed (no host synchronisation anywhere in the protocol). */
 int ttmi_joint_exp_supported(int B, int T, int U1, int J, int V, int prec, long ldv);
 int ttmi_joint_exp_fwd_supported(int B, int T, int U1, int J, int V, int prec, long ldv);     /* forward + loss only (no gradients wanted) */
 int ttmi_joint_exp_nparts(int V);
 int ttmi_joint_fwd_exp(const float* enc, const float* dec, const float* wf, const float* bf, const float* wp, const float* bp,
                        int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx, float* ws, void* P, long ldv,
-                       float* rowsum, int nparts, const float* shift, void* stream);
+                       float* rowsum, int nparts, const float* shift, const int* labels, int blank, float* emis, void* stream);
 int ttmi_rnnt_loss_fwd_exp(const void* P, long ldv, const float* rowsum, int nparts, const int* labels, const int* act_lens,
                            const int* label_lens, int B, int T, int U1, int V, int blank, void* workspace, float* costs,
-                           const float* shift_cur, float* shift_next, void* stream);
+                           const float* shift_cur, float* shift_next, const float* emis, int* flag, void* stream);
+int ttmi_rnnt_shift_seed(const void* workspace /* of a plain ttmi_rnnt_loss_fwd */, const int* act_lens, const int* label_lens, int B, int T,
+                         int U1, float* shift_next, void* stream);
 int ttmi_rnnt_loss_bwd_exp(void* P, long ldv, const int* labels, const int* act_lens, const int* label_lens, int B, int T, int U1,
                            int V, int blank, const void* workspace, const float* grad_out, int grad_out_stride, float scale,
                            float* srow, void* srow16, void* stream);
@@ -191,8 +199,8 @@ int ttmi_adam_step(float* p, const float* g, float* m, float* v, long n, float l
 /* ---- bring-up / measurement helpers ------------------------------------------------------------------------------
  * generic MFMA GEMM (every layout / dtype / epilogue; flags = GemmFlags of csrc/gemm.h) and the two throughput
  * kernels; HIP-event probes recorded on the launch stream at five points (0 = joint vocabulary projection, 1 = ttmi_rnnt_loss_fwd's
- * kernels, 2 = ttmi_rnnt_loss_bwd's kernel, 3 = the fused attention backward kernel of a layer with L >= 256, 4 = the qkv_net weight-gradient GEMM of
- * a layer with B*L >= 4096): ttmi_probe_arm(i), 0 <= i < 64, makes the NEXT launch at every point record into its event
+ * kernels, 2 = ttmi_rnnt_loss_bwd's kernel, 3 = the fused attention backward kernel of a layer with L >= 256, 4 = a grouped weight-gradient launch of
+ * ttmi_wgrad_group that fills at least half the chip): ttmi_probe_arm(i), 0 <= i < 64, makes the NEXT launch at every point record into its event
  * pair i; ttmi_probe_point_read_ms(point, i) waits for that pair and returns its duration in ms (< 0: never fired);
  * ttmi_probe_read_ms(i) = point 0. */
 int ttmi_gemm(const void* A, const void* B, void* C, const float* bias, const float* aux, int a_dtype, int b_dtype,

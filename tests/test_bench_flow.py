@@ -1,0 +1,69 @@
+"""bench.py's multi-rank control flow on CPU (gloo, world size 2): per-rank data seeds, what a data-parallel run switches on, the
+barrier-bracketed timed region with EXACTLY K timed steps, and the MAX over ranks that the JSON line's ms_per_step is taken from.
+The GPU step itself is covered by tests/test_dp_nccl_gpu.py; `python bench.py` needs a GPU and says so."""
+import os
+import subprocess
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    calls = []
+
+    def step(timed, i):
+        calls.append((timed, i))
+        time.sleep(0.02 * (rank + 1))                        # rank 1 is twice as slow
+        return rank
+
+    elapsed, enqueue, cpu, last = bench.timed_region(step, 5, 2, world, cuda=False)
+    red = bench.max_over_ranks([elapsed, None, 3.0 + rank], world, torch.device("cpu"))
+    q.put((rank, bench.rank_seed(rank), bench.dp_options(world), calls, elapsed, red, last))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_timed_region_and_max_over_ranks():
+    world, port = 2, 29400 + os.getpid() % 300
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [1234, 1235]                                   # features from manual_seed(1234 + rank)
+    assert all(r[2] == {"immediate_first_layer": True, "reserve_cus": 32} for r in res)
+    for r in res:
+        assert r[3] == [(False, 0)] * 2 + [(True, i) for i in range(5)]          # W untimed, then exactly K timed steps
+        assert r[6] == r[0]
+    slow = res[1][4]
+    assert slow >= 5 * 0.04 and res[0][4] >= 5 * 0.02
+    for r in res:                                                                 # every rank reports the slowest rank's time
+        assert abs(r[5][0] - max(res[0][4], res[1][4])) < 1e-9 and r[5][1] is None and r[5][2] == 4.0
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.dp_options(1) == {"immediate_first_layer": False, "reserve_cus": 0}
+    assert bench.max_over_ranks([1.0, None], 1, None) == [1.0, None]
+
+
+def test_bench_refuses_to_run_without_a_gpu_per_rank():
+    """no silent CPU run and no RCCL rendezvous hang: without a device per local rank bench.py exits at once with a message"""
+    if torch.cuda.device_count() >= 2:
+        return
+    env = dict(os.environ, WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert "GPU" in (out.stderr + out.stdout)

@@ -171,3 +171,125 @@ def test_single_rank_rccl_path_on_one_gpu(monkeypatch):
     mine = flat.grad.cpu().numpy()
     worst = sorted(((rel_err(first[o:o + p.numel()], mine[o:o + p.numel()]), n) for (n, p), o in zip(model.named_parameters(), flat.offsets)), reverse=True)[:4]
     assert rel_err(first, mine) < 1e-5, worst
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the step exactly as `bench.py --gpus N` drives it (bf16, Transducer.loss(exp_domain=True), grouped weight gradients with the first
+# layer kept immediate, bf16 weight shadows, CUs reserved for the collective during backward), at the smallest sizes at which every one
+# of those paths is the one that runs: 2 audio layers of 4096 rows (B=8, T=512), d_model=512, J=1024, V=4334, U=7 (32768 lattice rows)
+def _bench_cfg():
+    from tt.utils import AttrDict
+    side = dict(d_model=512, n_head=8, d_head=64, d_inner=1024)
+    return AttrDict(dict(enc=dict(side, n_layer=2, max_input_length=64), dec=dict(side, n_layer=1, max_target_length=8),
+                         joint=dict(input_size=1024, inner_size=1024), vocab_size=4334, dropout=0.0, overlap_label_encoder=True))
+
+
+def _bench_data(step, rank):
+    g = torch.Generator().manual_seed(1234 + 10 * step + rank)
+    return torch.randn(8, 512, 512, generator=g), torch.randint(1, 4334, (8, 7), generator=g)
+
+
+def _bench_like(dev, world, rank, steps, hooks):
+    """-> (gradient buffer after the LAST step's backward, parameters after `steps` updates, number of collectives seen in flight,
+    whether the exp-domain kernels ran)"""
+    from tt.model import Transducer
+    from ttmi import ops
+    from ttmi.train import FlatModel, FusedOptimizer, GradSync
+    torch.manual_seed(1)
+    model = Transducer(_bench_cfg()).to(dev).train()
+    flat = FlatModel(model)
+    flat.enable_grouped_wgrads(immediate_first_layer=hooks)
+    flat.enable_shadows()
+    sync = GradSync(flat, bucket_mb=4, always_reduce=hooks)
+    opt = FusedOptimizer(flat, kind="sgd", lr=0.00025, momentum=0.9, max_grad_norm=200.0, world=world)
+    il = torch.full((8,), 512, dtype=torch.int32, device=dev)
+    tl = torch.full((8,), 7, dtype=torch.int32, device=dev)
+    assert ops.joint_exp_supported(8, 512, 8, 1024, 4334, 1)
+    n_works, grad = 0, None
+    for step in range(steps):
+        x, y = _bench_data(step, rank)
+        flat.zero_grad()
+        sync.start_step()
+        loss = model.loss(x.to(dev), il, y.to(dev), tl, exp_domain=True)
+        if hooks:
+            ops.reserve_cus(32)
+        loss.backward()
+        n_works = max(n_works, len(sync.works))
+        sync.finish()
+        if hooks:
+            ops.reserve_cus(0)
+        if step == steps - 1:
+            torch.cuda.synchronize()
+            grad = flat.grad.cpu().numpy()
+        opt.step()
+    torch.cuda.synchronize()
+    st = model.joint.exp_shift_state(dev)
+    assert int(st.flag) == 0 and torch.isfinite(flat.flat).all()
+    ops.wgrad_queue = None
+    flat.disable_shadows()
+    return grad, flat.flat.cpu().numpy(), n_works, len(st.pending) > 0 or st.valid, len(sync.buckets)
+
+
+def _solo_bench(port, q):
+    for p in (ROOT, os.path.join(ROOT, "transformer-transducer_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", TTMI_PRECISION="bf16", NCCL_MAX_NCHANNELS="32")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    out = _bench_like(dev, 1, 0, 3, hooks=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put(out)
+
+
+def test_single_rank_rccl_bench_step_on_one_gpu(monkeypatch):
+    """the RCCL-side step of bench.py, as far as one GPU can run it: every bucket's all-reduce launched from the gradient hooks (incl.
+    the deferred hooks of the grouped weight gradients) beside a backward pass whose persistent GEMMs leave the reserved CUs free,
+    against the same three steps without hooks, reservation or process group: same gradients, same parameters."""
+    monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    port = 29900 + os.getpid() % 90
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_solo_bench, args=(port, q))
+    p.start()
+    grad, params, n_works, exp_ran, n_buckets = q.get(timeout=900)
+    p.join(120)
+    assert p.exitcode == 0
+    assert exp_ran and n_buckets >= 4 and n_works >= n_buckets - 1
+    want_grad, want_params, _, _, _ = _bench_like(torch.device("cuda", 0), 1, 0, 3, hooks=False)
+    # grouped weight gradients are bit-reproducible; the joint's and the first layer's K-split sums land in f32 atomic order
+    assert rel_err(grad, want_grad) < 1e-4
+    assert rel_err(params, want_params) < 1e-6
+
+
+def _worker_bench(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "transformer-transducer_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", TTMI_PRECISION="bf16", NCCL_MAX_NCHANNELS="32")
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    grad, params, n_works, exp_ran, n_buckets = _bench_like(dev, world, rank, 3, hooks=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, grad, params, n_works, exp_ran))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL test needs two GPUs (one process per GPU)")
+def test_two_ranks_over_rccl_bench_step():
+    """two ranks, two devices, different utterances: after three bench-like steps both ranks hold bit-identical reduced gradients and
+    parameters (the all-reduce delivers the same sums everywhere; clip / SGD are deterministic), and they differ from a one-rank run"""
+    world, port = 2, 30100 + os.getpid() % 400
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_bench, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(r[4] for r in res) and all(r[3] >= 3 for r in res)
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    assert np.isfinite(res[0][2]).all()

@@ -20,15 +20,21 @@ def fz():
 
 def test_stacking_subsampling_padding_bit_exact(fz):
     """pure data movement: bit-exact against the reference's concat_frame / subsampling / Dataset.pad, through the reference-named
-    functions (numpy in, numpy out) and through the fused batch kernel"""
+    functions (device tensor in, device tensor out) and through the fused batch kernel"""
     from tt import utils as U
     from ttmi import frontend
+    dev = lambda a: torch.tensor(a, device="cuda")
     for left, right in ((3, 0), (2, 1), (0, 0)):
-        assert np.array_equal(U.concat_frame(fz["feat"], left, right), fz["concat_%d_%d" % (left, right)])
-    assert np.array_equal(U.concat_frame(fz["short"], 3, 0), fz["short_concat_3_0"])
-    st = U.concat_frame(fz["feat"], 3, 0)
+        assert np.array_equal(U.concat_frame(dev(fz["feat"]), left, right).cpu().numpy(), fz["concat_%d_%d" % (left, right)])
+    assert np.array_equal(U.concat_frame(dev(fz["short"]), 3, 0).cpu().numpy(), fz["short_concat_3_0"])
+    st = U.concat_frame(dev(fz["feat"]), 3, 0)
     for s in (3, 2, 1):
-        assert np.array_equal(U.subsampling(st, s), fz["sub_%d" % s])
+        assert np.array_equal(U.subsampling(st, s).cpu().numpy(), fz["sub_%d" % s])
+    # host data belongs to the reference's own numpy code (DataLoader workers, tt/dataset.py): without the reference checkout on sys.path
+    # the call fails loudly instead of touching the GPU from what may be a forked worker
+    if not os.path.isdir("/root/reference/tt"):
+        with pytest.raises(ValueError, match="reference"):
+            U.concat_frame(fz["feat"], 3, 0)
     # fused: two utterances of different lengths in one launch, padded to 30 rows like Dataset.pad
     feat = torch.zeros(2, 53, 24, device="cuda")
     feat[0] = torch.tensor(fz["feat"])
@@ -80,10 +86,11 @@ def test_log_mel_vs_oracle(mode):
         assert rel_err(got[b, :nf], want) < 2e-5
         assert (got[b, nf:] == 0).all()
     from tt import utils as U
-    one = U.get_feature(waves[0], 16000, 128) if mode == "ln" else U.get_feature2(waves[0], 16000, 128)
-    assert isinstance(one, np.ndarray) and np.abs(one - got[0]).max() < 1e-3        # (one utterance alone takes other GEMM tiles: f32 rounding differences)
-    ff = U.get_final_feature(waves[1, :9999])
-    assert rel_err(ff, F.final_feature(waves[1, :9999])) < 1e-5
+    w0 = torch.tensor(waves[0], device="cuda")
+    one = U.get_feature(w0, 16000, 128) if mode == "ln" else U.get_feature2(w0, 16000, 128)
+    assert one.is_cuda and np.abs(one.cpu().numpy() - got[0]).max() < 1e-3        # (one utterance alone takes other GEMM tiles: f32 rounding differences)
+    ff = U.get_final_feature(torch.tensor(waves[1, :9999], device="cuda"))
+    assert rel_err(ff.cpu().numpy(), F.final_feature(waves[1, :9999])) < 1e-5
 
 
 def test_feature_pipeline_batch():

@@ -41,3 +41,42 @@ print("overlay ok")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "overlay ok" in out.stdout
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "tt")), reason="reference checkout not present")
+def test_host_side_feature_calls_reach_the_reference_inside_dataloader_workers():
+    """tt/dataset.py calls get_feature2 + concat_frame on numpy data inside AudioDataset.__getitem__, which train.py:174-184 runs in
+    fork-started DataLoader workers after model.cuda(): those calls must never reach the HIP library.  Host data is served by the
+    reference's own numpy functions (librosa / editdistance, absent from this image and unused by concat_frame, are placeholder
+    modules here as in SURVEY.md Appendix B); the result equals the reference-run fixture."""
+    code = r"""
+import sys, types
+sys.dont_write_bytecode = True
+for m in ("librosa", "editdistance"):
+    sys.modules[m] = types.ModuleType(m)
+import numpy as np, torch
+import torch.utils.data as D
+import tt.utils as U
+assert U.__file__.startswith(%r)
+fz = np.load(%r)
+
+class DS(D.Dataset):
+    def __len__(self): return 4
+    def __getitem__(self, i):
+        assert D.get_worker_info() is not None
+        return torch.from_numpy(U.subsampling(U.concat_frame(fz["feat"], 3, 0), 3))
+
+import ttmi
+calls = []
+real = ttmi.lib
+ttmi.lib = lambda: calls.append(1) or real()          # (the forked workers inherit this; any use of the HIP library would be counted there, not here -
+for batch in D.DataLoader(DS(), batch_size=2, num_workers=2):   # so the worker asserts by construction: a HIP call on a box without a GPU raises)
+    for row in batch:
+        assert np.array_equal(row.numpy(), fz["sub_3"])
+assert np.array_equal(U.concat_frame(fz["feat"], 2, 1), fz["concat_2_1"])
+print("workers ok")
+""" % (PKG, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frontend.npz"))
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + REF, PYTHONDONTWRITEBYTECODE="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "workers ok" in out.stdout

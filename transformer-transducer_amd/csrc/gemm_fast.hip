@@ -16,6 +16,9 @@
 #include "ttmi.h"
 #include <mutex>
 
+void ttmi_probe_begin(int slot, hipStream_t st);
+void ttmi_probe_end(int slot, hipStream_t st);
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -2434,7 +2437,8 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
         if (g_num_cus <= 0) g_num_cus = 256;
     }
     // encoder-sized wgrad: persistent 256x128 kernel when its tiles fill the output exactly and the reduction is long enough
-    const bool tn9 = (g_gemm_fast_version == 4 || g_gemm_fast_version == 9) && nbatch == 1 && accumulate && K % TK == 0 && K >= 4096 && K < 32768 &&
+    // (weighted column sums exist on the 256x256 kernel only: such a call never takes this branch)
+    const bool tn9 = !colsum_w && (g_gemm_fast_version == 4 || g_gemm_fast_version == 9) && nbatch == 1 && accumulate && K % TK == 0 && K >= 4096 && K < 32768 &&
                      M % T9M == 0 && N % T9N == 0 && (!colsum_a || N / T9N >= 4) && (long)(M / T9M) * (N / T9N) >= 8;
     if (tn9) {
         p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -2557,9 +2561,15 @@ int gemm_tn_bf16_group(const TnProblem* probs, int n, hipStream_t st) {
     if (int rc = enable_lds(gemm_tn_bf16_group_kernel, LDS9)) return rc;
     TnGroup g;
     g.n = 0; g.total = 0;
+    // data-parallel backward: leave the CUs reserved on this stream to RCCL's kernels, like the v8 / v9 launches do (a persistent grid
+    // larger than the CUs that are free runs its surplus workgroups after the others anyway)
+    const int cus = std::max(8, (g_num_cus - reserved_cus(st)) / 8 * 8);
     auto flush = [&]() -> int {
         if (g.n == 0) return TTMI_OK;
-        hipLaunchKernelGGL(gemm_tn_bf16_group_kernel, dim3((unsigned)g_num_cus), dim3(NTH8), LDS9, st, g);
+        const bool probe = g.total >= 128;      // timing probe 4: a grouped launch that fills at least half the chip
+        if (probe) ttmi_probe_begin(4, st);
+        hipLaunchKernelGGL(gemm_tn_bf16_group_kernel, dim3((unsigned)cus), dim3(NTH8), LDS9, st, g);
+        if (probe) ttmi_probe_end(4, st);
         TTMI_LAUNCH_CHECK("gemm_tn_bf16_group_kernel");
         g.n = 0; g.total = 0;
         return TTMI_OK;

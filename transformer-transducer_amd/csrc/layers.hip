@@ -551,12 +551,7 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
         if (!fastpos) CK(convert_bf16(w.dqkv, w.dqkv16, a.BL * a.W3, st));      // fastpos: dq / dK / dV were written in bf16 by their producers
         if (out) out[1] = ttmi_wgrad_desc{w.dqkv16, c.x16, g_qkv_w, nullptr, (int)a.W3, d, (int)a.BL, (long)a.W3, (long)d, (long)d};
         else {
-            hipStream_t fs = fork_stream(st);
-            const bool probe = a.BL >= 4096;        // timing probe 4: an audio-sized qkv_net weight gradient, on the stream it is launched on
-            if (probe) ttmi_probe_begin(4, fs);
-            const int rc = gemm_tn_bf16(w.dqkv16, c.x16, g_qkv_w, (int)a.W3, d, (int)a.BL, a.W3, d, d, 1, fs);
-            if (probe) ttmi_probe_end(4, fs);
-            CK(rc);
+            CK(gemm_tn_bf16(w.dqkv16, c.x16, g_qkv_w, (int)a.W3, d, (int)a.BL, a.W3, d, d, 1, fork_stream(st)));
         }
         NtEpilogue e;
         e.addend = dx;
@@ -804,7 +799,7 @@ size_t ttmi_joint_ws_floats(int B, int T, int U1, int J, int V) {
 // rowsum != nullptr: the "exp store" form of the fused joint + loss fast path (logits become exp(z - *shift), see ttmi_joint_fwd_exp)
 static int joint_fwd_impl(const float* enc, const float* dec, const float* wf, const float* bf, const float* wp, const float* bp,
                           int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx, float* ws, void* logits, long ldv,
-                          float* rowsum, int nparts, const float* shift, void* stream) {
+                          float* rowsum, int nparts, const float* shift, const int* labels, int blank, float* emis, void* stream) {
     TTMI_REQUIRE(enc && dec && wf && bf && wp && bp && ctx && ws && logits, "joint_fwd: null pointer");
     TTMI_REQUIRE(B > 0 && T > 0 && U1 > 0 && de > 0 && dd > 0 && J > 0 && V > 0 && ldv >= V, "joint_fwd: bad dims");
     TTMI_REQUIRE((long)B * T * U1 < (1L << 31), "joint_fwd: B*T*(U+1) too large");
@@ -846,11 +841,13 @@ static int joint_fwd_impl(const float* enc, const float* dec, const float* wf, c
     TTMI_REQUIRE(ldv % 8 == 0 && aligned16(logits), "joint_fwd: bf16 logits need a 16-byte aligned base and pitch %% 8 == 0");
     bf16_t* H16 = reinterpret_cast<bf16_t*>(ctx);
     bf16_t* Wp16 = reinterpret_cast<bf16_t*>(PD + 2 * al4((size_t)B * U1 * J));
-    CK(joint_tanh_fwd(PE, PD, bf, B, T, U1, J, H16, 1, st));
     Shadow shp;
     const bf16_t* wp16 = Wp16;
     if (shadow_of(wp, V, J, (V + 63) / 64 * 64, shp)) wp16 = shp.w16;
     else CK(convert_bf16(wp, Wp16, (long)V * J, st));
+    // exp-domain form with `emis`: the blank / label logits of every lattice row also leave in f32, from the same bf16 operands the GEMM reads
+    if (emis) CK(joint_tanh_fwd_emis(PE, PD, bf, B, T, U1, J, H16, wp16, bp, labels, V, blank, emis, st));
+    else CK(joint_tanh_fwd(PE, PD, bf, B, T, U1, J, H16, 1, st));
     NtEpilogue e;
     e.bias = bp; e.rowsum = rowsum; e.nparts = nparts; e.exp_shift = shift;
     ttmi_probe_begin(0, st);
@@ -863,7 +860,8 @@ static int joint_fwd_impl(const float* enc, const float* dec, const float* wf, c
 int ttmi_joint_fwd(const float* enc, const float* dec, const float* wf, const float* bf, const float* wp, const float* bp,
                    int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx, float* ws, void* logits, long ldv,
                    void* stream) {
-    return joint_fwd_impl(enc, dec, wf, bf, wp, bp, B, T, U1, de, dd, J, V, prec, ctx, ws, logits, ldv, nullptr, 0, nullptr, stream);
+    return joint_fwd_impl(enc, dec, wf, bf, wp, bp, B, T, U1, de, dd, J, V, prec, ctx, ws, logits, ldv, nullptr, 0, nullptr, nullptr, 0, nullptr,
+                          stream);
 }
 
 // ---- exp-domain forms: the fused joint + loss fast path (training-sized bf16 problems; ask ttmi_joint_exp_supported first)
@@ -884,10 +882,12 @@ int ttmi_joint_exp_nparts(int V) { return 4 * ((V + 255) / 256); }
 
 int ttmi_joint_fwd_exp(const float* enc, const float* dec, const float* wf, const float* bf, const float* wp, const float* bp,
                        int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx, float* ws, void* P, long ldv,
-                       float* rowsum, int nparts, const float* shift, void* stream) {
+                       float* rowsum, int nparts, const float* shift, const int* labels, int blank, float* emis, void* stream) {
     TTMI_REQUIRE(rowsum && nparts >= ttmi_joint_exp_nparts(V), "joint_fwd_exp: rowsum needs >= %d parts per row", ttmi_joint_exp_nparts(V));
+    TTMI_REQUIRE(!emis || ((labels || U1 == 1) && blank >= 0 && blank < V), "joint_fwd_exp: emis needs the labels and a blank index inside [0, V)");
     TTMI_REQUIRE(ttmi_joint_exp_fwd_supported(B, T, U1, J, V, prec, ldv), "joint_fwd_exp: size / precision outside the fast path (B=%d T=%d U1=%d J=%d V=%d)", B, T, U1, J, V);
-    return joint_fwd_impl(enc, dec, wf, bf, wp, bp, B, T, U1, de, dd, J, V, prec, ctx, ws, P, ldv, rowsum, nparts, shift, stream);
+    return joint_fwd_impl(enc, dec, wf, bf, wp, bp, B, T, U1, de, dd, J, V, prec, ctx, ws, P, ldv, rowsum, nparts, shift, labels, blank, emis,
+                          stream);
 }
 
 // srow != nullptr: exp-domain form, d logits[r, :] = srow[r] * dlogits[r, :] (see ttmi_joint_bwd_exp); ctx is then scaled in place

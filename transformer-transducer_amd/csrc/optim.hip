@@ -34,6 +34,12 @@ __global__ __launch_bounds__(64) void sumsq_final_kernel(int nblocks, float* __r
     if (threadIdx.x == 0) *out += acc;
 }
 
+// A step whose gradient norm is not finite is DROPPED (parameters and optimiser state untouched): with clip_grad_norm_ the reference
+// would turn every weight into NaN at this point (train.py:62-65); here it is the exp-domain loss form's way of failing loudly - a step
+// whose shift no longer fitted the logits has NaN costs and gradients (rnnt_prep_exp_kernel) and must not reach the weights.
+__device__ __forceinline__ bool step_dropped(const float* normsq, float max_norm) {
+    return normsq && max_norm > 0.f && !(*normsq < 3.0e38f);          // inf or NaN
+}
 // coef = grad_scale * min(1, max_norm / (grad_scale * sqrt(normsq) + 1e-6))   (torch.nn.utils.clip_grad_norm_)
 __device__ __forceinline__ float clip_coef(const float* normsq, float max_norm, float grad_scale) {
     if (!normsq || max_norm <= 0.f) return grad_scale;
@@ -44,6 +50,7 @@ __device__ __forceinline__ float clip_coef(const float* normsq, float max_norm, 
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom,
                                                   long n, float lr, float momentum, float wd, int nesterov, float max_norm,
                                                   const float* __restrict__ normsq, float grad_scale) {
+    if (step_dropped(normsq, max_norm)) return;
     const float coef = clip_coef(normsq, max_norm, grad_scale);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         float gi = g[i] * coef + wd * p[i];
@@ -60,6 +67,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
                                                    float wd, float bc1, float bc2, float max_norm,
                                                    const float* __restrict__ normsq, float grad_scale) {
+    if (step_dropped(normsq, max_norm)) return;
     const float coef = clip_coef(normsq, max_norm, grad_scale);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float gi = g[i] * coef + wd * p[i];
@@ -116,8 +124,8 @@ int ttmi_adam_step(float* p, const float* g, float* m, float* v, long n, float l
 
 // ---- timing probes: HIP events recorded on the launch stream around named launches --------------------------
 // Probe points: 0 = joint vocabulary projection GEMM (forward), 1 = RNN-T loss forward (log-sum-exp pass + lattice), 2 = RNN-T loss
-// backward (gradient pass), 3 = fused attention backward kernel of an audio-sized layer (L >= 256), 4 = the qkv_net weight-gradient GEMM of
-// an audio-sized layer (rows >= 4096).  Events are owned by the library.  Every point records into whichever of the 64 event pairs was armed
+// backward (gradient pass), 3 = fused attention backward kernel of an audio-sized layer (L >= 256), 4 = a grouped weight-gradient launch
+// (ttmi_wgrad_group, >= 128 tiles).  Events are owned by the library.  Every point records into whichever of the 64 event pairs was armed
 // last, so a timing loop can arm pair i in step i and read them all after its final fence - no host synchronisation inside the
 // timed region.
 constexpr int NPROBE = 64, NPOINT = 5;

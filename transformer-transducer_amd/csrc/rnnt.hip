@@ -386,11 +386,16 @@ __global__ __launch_bounds__(LSE_WAVES * 64) void rnnt_grad_kernel(
 // per row, the backward leaves the row factor s_r = gscale * exp(alpha + beta - ll - log S) to the consuming GEMMs
 // (d logits[r, v] = s_r * P[r, v] everywhere but at the blank / label columns, which are patched in P here).
 constexpr float EXP_SHIFT_MARGIN = 40.f;
+// emis (nullable): f32 [rows, 2] logits of the blank and of the row's next label (ttmi_joint_fwd_exp): the two emission log-probs are then
+// logit - shift - log S instead of the logarithm of a bf16-rounded entry of P (|error| <= 2^-9 per emission, ~5e-5 of a C2 loss).
+// flag (nullable, device int): bit 0 is set when a row of the lattice lost its sum - every exp(logit - shift) underflowed, or the sum overflowed:
+// the shift in use no longer fits the logits.  Such a row's log-sum-exp becomes NaN, so the utterance's cost and every gradient of the step are
+// NaN rather than finite and wrong; callers drop the step and re-seed the shift (ttmi_rnnt_shift_seed).
 __global__ __launch_bounds__(256) void rnnt_prep_exp_kernel(
     const bf16_t* __restrict__ P, long ldv, const float* __restrict__ rowsum, int nparts, const int* __restrict__ labels,
     const int* __restrict__ act_lens, const int* __restrict__ label_lens, int B, int T, int U1, int V, int blank,
     float* __restrict__ lse, float* __restrict__ lpb_d, float* __restrict__ lpl_d, const float* __restrict__ shift_cur,
-    float* __restrict__ shift_next) {
+    float* __restrict__ shift_next, const float* __restrict__ emis, int* __restrict__ flag) {
     const long row = (long)blockIdx.x * 256 + threadIdx.x;
     if (row >= (long)B * T * U1) return;
     const int u = (int)(row % U1);
@@ -402,20 +407,25 @@ __global__ __launch_bounds__(256) void rnnt_prep_exp_kernel(
     const long rows = (long)B * T * U1;
     float S = 0.f;
     for (int i = 0; i < nparts; ++i) S += rowsum[i * rows + row];        // part-major: coalesced across the block's rows
-    // a row whose every exp(logit - shift) underflowed (its logits sit ~127 below the largest log-sum-exp the shift was taken from) has lost its
-    // information; keep the numbers finite instead of letting -inf / NaN spread through the lattice
-    const float l = S > 1.0e-37f ? __logf(S) : -85.f;
+    const bool good = S > 1.0e-37f && S < 3.0e38f;                        // false also for NaN
+    if (!good && flag) atomicOr(flag, 1);
+    const float l = good ? __logf(S) : __int_as_float(0x7fc00000);
     lse[row] = l;
-    if (shift_next) {
+    const float cur = shift_cur ? *shift_cur : 0.f;
+    if (shift_next && good) {
         // the shift the NEXT step should use: this row's log-sum-exp in logit units, less a margin that keeps exp() far from both
         // ends of the f32 / bf16 range.  Non-negative floats order like their bit patterns, so an integer atomic max does it.
-        const float cur = shift_cur ? *shift_cur : 0.f;
-        // a row sum that overflowed (logits more than ~88 above the shift in use) says nothing about the scale: step up by 64
-        const float cand = S < 3.0e38f ? l + cur - EXP_SHIFT_MARGIN : cur + 64.f;
+        const float cand = l + cur - EXP_SHIFT_MARGIN;
         if (cand > 0.f && cand < 3.0e38f) atomicMax(reinterpret_cast<int*>(shift_next), __float_as_int(cand));
     }
     const bf16_t* r = P + row * ldv;
     const long di = (long)b * diag_stride(T, U1) + (long)(t + u) * U1 + u;
+    if (emis) {
+        const float2 z = *reinterpret_cast<const float2*>(emis + row * 2);
+        lpb_d[di] = z.x - cur - l;
+        lpl_d[di] = u < Ub ? z.y - cur - l : NEG;
+        return;
+    }
     const float pb = ldf<bf16_t>(r + blank);
     lpb_d[di] = (pb > 0.f ? __logf(pb) : NEG) - l;
     float pl = NEG;
@@ -425,6 +435,25 @@ __global__ __launch_bounds__(256) void rnnt_prep_exp_kernel(
         pl = (py > 0.f ? __logf(py) : NEG) - l;
     }
     lpl_d[di] = pl;
+}
+
+// max over the lattice rows of (log-sum-exp - margin) into *shift_next, from the workspace a PLAIN ttmi_rnnt_loss_fwd left behind (its lse
+// array, logit units): how the exp-domain form gets its first shift - and a new one after a flagged step - without a host synchronisation
+__global__ __launch_bounds__(256) void rnnt_shift_seed_kernel(const float* __restrict__ lse, const int* __restrict__ act_lens,
+                                                              const int* __restrict__ label_lens, int B, int T, int U1,
+                                                              float* __restrict__ shift_next) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    float cand = 0.f;
+    if (row < (long)B * T * U1) {
+        const int u = (int)(row % U1);
+        const long bt = row / U1;
+        const int t = (int)(bt % T);
+        const int b = (int)(bt / T);
+        const int Tb = clampi(act_lens[b], 1, T), Ub = clampi(label_lens[b], 0, U1 - 1);
+        if (t < Tb && u <= Ub) cand = lse[row] - EXP_SHIFT_MARGIN;
+    }
+    cand = wave_max(cand > 0.f && cand < 3.0e38f ? cand : 0.f);
+    if ((threadIdx.x & 63) == 0 && cand > 0.f) atomicMax(reinterpret_cast<int*>(shift_next), __float_as_int(cand));
 }
 
 __global__ __launch_bounds__(256) void rnnt_scale_exp_kernel(
@@ -579,7 +608,7 @@ int ttmi_rnnt_loss_bwd(const void* logits, int dtype, long ldv, const int* label
 // of P in place and writes the per-row factors srow (f32) and srow16 (bf16): d logits = srow[r] * P[r, :].
 int ttmi_rnnt_loss_fwd_exp(const void* P, long ldv, const float* rowsum, int nparts, const int* labels, const int* act_lens,
                            const int* label_lens, int B, int T, int U1, int V, int blank, void* workspace, float* costs,
-                           const float* shift_cur, float* shift_next, void* stream) {
+                           const float* shift_cur, float* shift_next, const float* emis, int* flag, void* stream) {
     TTMI_REQUIRE(P && rowsum && (labels || U1 == 1) && act_lens && label_lens && workspace && costs, "rnnt_loss_fwd_exp: null pointer");
     TTMI_REQUIRE(B > 0 && T > 0 && U1 > 0 && V > 0 && nparts > 0 && ldv >= V, "rnnt_loss_fwd_exp: bad shape");
     TTMI_REQUIRE(blank >= 0 && blank < V, "rnnt_loss_fwd_exp: blank %d outside [0,%d)", blank, V);
@@ -590,7 +619,7 @@ int ttmi_rnnt_loss_fwd_exp(const void* P, long ldv, const float* rowsum, int npa
     const long rows = (long)B * T * U1;
     ttmi_probe_begin(1, st);
     hipLaunchKernelGGL(rnnt_prep_exp_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, st, static_cast<const bf16_t*>(P), ldv, rowsum,
-                       nparts, labels, act_lens, label_lens, B, T, U1, V, blank, w.lse, w.lpb, w.lpl, shift_cur, shift_next);
+                       nparts, labels, act_lens, label_lens, B, T, U1, V, blank, w.lse, w.lpb, w.lpl, shift_cur, shift_next, emis, flag);
     TTMI_LAUNCH_CHECK("rnnt_prep_exp_kernel");
     if (U1 <= 64) launch_alphabeta<1, 8>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
     else if (U1 <= 128) launch_alphabeta<2, 8>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
@@ -599,6 +628,19 @@ int ttmi_rnnt_loss_fwd_exp(const void* P, long ldv, const float* rowsum, int npa
     else launch_alphabeta<16, 1>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
     ttmi_probe_end(1, st);
     TTMI_LAUNCH_CHECK("rnnt_alphabeta_kernel");
+    return TTMI_OK;
+}
+
+// *shift_next = max(*shift_next, max over the lattice rows of log-sum-exp - 40) from the workspace of a plain ttmi_rnnt_loss_fwd on the same
+// (B, T, U1): seeds the exp-domain form's shift on the device (first step, new weights, or after a flagged step)
+int ttmi_rnnt_shift_seed(const void* workspace, const int* act_lens, const int* label_lens, int B, int T, int U1, float* shift_next,
+                         void* stream) {
+    TTMI_REQUIRE(workspace && act_lens && label_lens && shift_next && B > 0 && T > 0 && U1 > 0, "rnnt_shift_seed: bad arguments");
+    Ws w = carve(const_cast<void*>(workspace), B, T, U1);
+    const long rows = (long)B * T * U1;
+    hipLaunchKernelGGL(rnnt_shift_seed_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w.lse, act_lens,
+                       label_lens, B, T, U1, shift_next);
+    TTMI_LAUNCH_CHECK("rnnt_shift_seed_kernel");
     return TTMI_OK;
 }
 

@@ -485,14 +485,34 @@ __global__ __launch_bounds__(256) void joint_tanh_fwd_bf16x4_kernel(const float*
     }
 }
 
-// J in {256, 512, 1024, 2048}: 8 columns per thread (16-byte stores), the block's 256 / (J/8) thread groups take every groups-th u
+// J in {256, 512, 1024, 2048}: 8 columns per thread (16-byte stores), the block's 256 / (J/8) thread groups take every groups-th u.
+// EMIS (exp-domain loss form): the two logits per lattice row that the loss reads - blank and next label - also leave in f32,
+// emis[row] = (h16 . Wp16[blank] + bp[blank], h16 . Wp16[y] + bp[y]) with the SAME bf16 operands the projection GEMM multiplies (so they
+// agree with its f32 accumulators up to summation order) instead of being read back from the bf16-rounded exp store.  The kernel is
+// bound by its 2 bytes per element of output; the dot products ride in its idle VALU slots, the label rows of Wp16 come from L2.
+struct JointEmis {
+    const bf16_t* Wp16 = nullptr;   // [V, J] bf16, the projection's B operand
+    const float* bp = nullptr;      // [V]
+    const int* labels = nullptr;    // [B, U1 - 1]
+    float* out = nullptr;           // [B * T * U1, 2]
+    int V = 0, blank = 0;
+};
+__device__ __forceinline__ void unpack_bf16x8(const uint4& w, float* f) {
+    f[0] = __uint_as_float(w.x << 16); f[1] = __uint_as_float(w.x & 0xffff0000u);
+    f[2] = __uint_as_float(w.y << 16); f[3] = __uint_as_float(w.y & 0xffff0000u);
+    f[4] = __uint_as_float(w.z << 16); f[5] = __uint_as_float(w.z & 0xffff0000u);
+    f[6] = __uint_as_float(w.w << 16); f[7] = __uint_as_float(w.w & 0xffff0000u);
+}
+template <bool EMIS>
 __global__ __launch_bounds__(256) void joint_tanh_fwd_bf16x8_kernel(const float* __restrict__ PE, const float* __restrict__ PD,
                                                                     const float* __restrict__ bias, int T, int U1, int J,
-                                                                    bf16_t* __restrict__ H) {
+                                                                    bf16_t* __restrict__ H, JointEmis em) {
+    extern __shared__ float part[];        // EMIS: [U1][waves per row][2] partial dot products
     const long bt = blockIdx.x;
     const int b = (int)(bt / T);
     const int tpr = J >> 3, grp = threadIdx.x / tpr, ngrp = 256 / tpr;
-    const int j = (threadIdx.x - grp * tpr) * 8;
+    const int tin = threadIdx.x - grp * tpr;
+    const int j = tin * 8;
     float e[8];
     {
         const float4 p0 = *reinterpret_cast<const float4*>(PE + bt * J + j), p1 = *reinterpret_cast<const float4*>(PE + bt * J + j + 4);
@@ -502,6 +522,9 @@ __global__ __launch_bounds__(256) void joint_tanh_fwd_bf16x8_kernel(const float*
     }
     const float* pd = PD + (long)b * U1 * J + j;
     bf16_t* h = H + bt * U1 * J + j;
+    float wb[8];
+    const int nw = tpr >= 64 ? tpr >> 6 : 1;            // waves that share one row
+    if constexpr (EMIS) unpack_bf16x8(*reinterpret_cast<const uint4*>(em.Wp16 + (long)em.blank * J + j), wb);
 #pragma unroll 4
     for (int u = grp; u < U1; u += ngrp) {
         const float4 d0 = *reinterpret_cast<const float4*>(pd + (long)u * J), d1 = *reinterpret_cast<const float4*>(pd + (long)u * J + 4);
@@ -511,6 +534,72 @@ __global__ __launch_bounds__(256) void joint_tanh_fwd_bf16x8_kernel(const float*
         w.z = pack_bf16x2(fast_tanh(e[4] + d1.x), fast_tanh(e[5] + d1.y));
         w.w = pack_bf16x2(fast_tanh(e[6] + d1.z), fast_tanh(e[7] + d1.w));
         *reinterpret_cast<uint4*>(h + (long)u * J) = w;
+        if constexpr (EMIS) {
+            int y = em.blank;
+            if (u < U1 - 1) {
+                y = em.labels[(long)b * (U1 - 1) + u];
+                y = y < 0 ? 0 : (y >= em.V ? em.V - 1 : y);
+            }
+            float hv[8], wl[8];
+            unpack_bf16x8(w, hv);
+            unpack_bf16x8(*reinterpret_cast<const uint4*>(em.Wp16 + (long)y * J + j), wl);
+            float db = 0.f, dl = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { db = fmaf(hv[i], wb[i], db); dl = fmaf(hv[i], wl[i], dl); }
+            // sum over the lanes of this wave that hold the row (all 64, or an aligned group of tpr = 32)
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                if (o < tpr) { db += __shfl_xor(db, o, 64); dl += __shfl_xor(dl, o, 64); }
+            }
+            if ((tin & 63) == 0) {
+                float* q = part + ((long)u * nw + (tin >> 6)) * 2;
+                q[0] = db; q[1] = dl;
+            }
+        }
+    }
+    if constexpr (EMIS) {
+        __syncthreads();
+        for (int u = threadIdx.x; u < U1; u += 256) {
+            float sb = 0.f, sl = 0.f;
+            for (int i = 0; i < nw; ++i) { sb += part[((long)u * nw + i) * 2]; sl += part[((long)u * nw + i) * 2 + 1]; }     // fixed order
+            int y = em.blank;
+            if (u < U1 - 1) {
+                y = em.labels[(long)b * (U1 - 1) + u];
+                y = y < 0 ? 0 : (y >= em.V ? em.V - 1 : y);
+            }
+            float2 o;
+            o.x = sb + em.bp[em.blank];
+            o.y = sl + em.bp[y];
+            *reinterpret_cast<float2*>(em.out + (bt * U1 + u) * 2) = o;
+        }
+    }
+}
+
+// any J: one wave per lattice row reads H16 back (shapes the 8-column kernel does not take)
+__global__ __launch_bounds__(256) void joint_emis_kernel(const bf16_t* __restrict__ H, long rows, int T, int U1, int J, JointEmis em) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int u = (int)(row % U1);
+    const int b = (int)(row / U1 / T);
+    int y = em.blank;
+    if (u < U1 - 1) {
+        y = em.labels[(long)b * (U1 - 1) + u];
+        y = y < 0 ? 0 : (y >= em.V ? em.V - 1 : y);
+    }
+    const bf16_t* h = H + row * J;
+    const bf16_t *w0 = em.Wp16 + (long)em.blank * J, *w1 = em.Wp16 + (long)y * J;
+    float db = 0.f, dl = 0.f;
+    for (int j = lane; j < J; j += 64) {
+        const float hv = bf16_to_f32(h[j]);
+        db = fmaf(hv, bf16_to_f32(w0[j]), db);
+        dl = fmaf(hv, bf16_to_f32(w1[j]), dl);
+    }
+    db = wave_sum(db);
+    dl = wave_sum(dl);
+    if (lane == 0) {
+        em.out[row * 2] = db + em.bp[em.blank];
+        em.out[row * 2 + 1] = dl + em.bp[y];
     }
 }
 
@@ -880,13 +969,36 @@ int joint_tanh_fwd(const float* PE, const float* PD, const float* bias, int B, i
         hipLaunchKernelGGL(joint_tanh_fwd_kernel<float>, dim3(B * T), dim3(256), 0, st, PE, PD, bias, T, U1, J,
                            static_cast<float*>(H));
     else if ((J == 256 || J == 512 || J == 1024 || J == 2048) && aligned16(PE) && aligned16(PD) && aligned16(bias) && aligned16(H))
-        hipLaunchKernelGGL(joint_tanh_fwd_bf16x8_kernel, dim3(B * T), dim3(256), 0, st, PE, PD, bias, T, U1, J, static_cast<bf16_t*>(H));
+        hipLaunchKernelGGL(joint_tanh_fwd_bf16x8_kernel<false>, dim3(B * T), dim3(256), 0, st, PE, PD, bias, T, U1, J, static_cast<bf16_t*>(H),
+                           JointEmis());
     else if (J % 4 == 0 && aligned16(PE) && aligned16(PD) && aligned16(bias) && (reinterpret_cast<uintptr_t>(H) & 7) == 0)
         hipLaunchKernelGGL(joint_tanh_fwd_bf16x4_kernel, dim3(B * T), dim3(256), 0, st, PE, PD, bias, T, U1, J, static_cast<bf16_t*>(H));
     else
         hipLaunchKernelGGL(joint_tanh_fwd_kernel<bf16_t>, dim3(B * T), dim3(256), 0, st, PE, PD, bias, T, U1, J,
                            static_cast<bf16_t*>(H));
     TTMI_LAUNCH_CHECK("joint_tanh_fwd_kernel");
+    return TTMI_OK;
+}
+
+// bf16 H plus the f32 blank / label logits of every lattice row (exp-domain loss form): emis [B*T*U1, 2]
+int joint_tanh_fwd_emis(const float* PE, const float* PD, const float* bias, int B, int T, int U1, int J, bf16_t* H, const bf16_t* Wp16,
+                        const float* bp, const int* labels, int V, int blank, float* emis, hipStream_t st) {
+    TTMI_REQUIRE(PE && PD && bias && H && Wp16 && bp && emis && (labels || U1 == 1) && B > 0 && T > 0 && U1 > 0 && J > 0 && V > 0 &&
+                 blank >= 0 && blank < V, "joint_tanh_fwd_emis: bad arguments");
+    TTMI_REQUIRE((reinterpret_cast<uintptr_t>(emis) & 7) == 0, "joint_tanh_fwd_emis: emis must be 8-byte aligned");
+    JointEmis em;
+    em.Wp16 = Wp16; em.bp = bp; em.labels = labels; em.out = emis; em.V = V; em.blank = blank;
+    if ((J == 256 || J == 512 || J == 1024 || J == 2048) && aligned16(PE) && aligned16(PD) && aligned16(bias) && aligned16(H) && aligned16(Wp16)) {
+        const int nw = J / 8 >= 64 ? J / 8 / 64 : 1;
+        hipLaunchKernelGGL(joint_tanh_fwd_bf16x8_kernel<true>, dim3(B * T), dim3(256), (size_t)U1 * nw * 2 * sizeof(float), st, PE, PD, bias, T,
+                           U1, J, H, em);
+        TTMI_LAUNCH_CHECK("joint_tanh_fwd_bf16x8_kernel<emis>");
+        return TTMI_OK;
+    }
+    if (int rc = joint_tanh_fwd(PE, PD, bias, B, T, U1, J, H, 1, st)) return rc;
+    const long rows = (long)B * T * U1;
+    hipLaunchKernelGGL(joint_emis_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, H, rows, T, U1, J, em);
+    TTMI_LAUNCH_CHECK("joint_emis_kernel");
     return TTMI_OK;
 }
 

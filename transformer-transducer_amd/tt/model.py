@@ -38,6 +38,61 @@ class _JointFn(torch.autograd.Function):
         return (denc, ddec, *rets, None)
 
 
+class _ExpShift:
+    """Range control of the exp-domain loss form, per JointNet module and device (never shared between models): the device scalars `cur`
+    (shift subtracted before exp in this step) and `nxt` (gathered for the next one), and a sticky device `flag` the loss kernel raises when
+    a lattice row's sum under- or overflowed.  No host synchronisation anywhere:
+
+    * not `valid` (first use, after JointNet.load_state_dict - a hook invalidates it -, or after a flagged step): the step runs the plain
+      fused form, whose log-sum-exp pass also seeds `nxt` (ttmi_rnnt_shift_seed); from the next step on the exp-domain kernels run.
+      Weights overwritten behind the module's back (p.data.copy_) are caught by the flag if their logits left the 40 e-fold margin.
+    * every exp step leaves max(log-sum-exp) - 40 in `nxt`; it becomes `cur` only if an exp (or seeding) chunk actually ran.
+    * the flag is copied to pinned host memory on a side stream and looked at (event query, non-blocking) at the next calls; a flagged
+      step's costs and gradients are NaN by construction (never finite and wrong) and the fused optimiser drops such a step."""
+
+    def __init__(self, device):
+        self.cur = torch.zeros(1, dtype=torch.float32, device=device)
+        self.nxt = torch.zeros(1, dtype=torch.float32, device=device)
+        self.flag = torch.zeros(1, dtype=torch.int32, device=device)
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.copy_stream = torch.cuda.Stream(device)
+        self.pending = []               # (event, generation) of flag copies in flight
+        self.valid, self.gen, self.flagged_steps = False, 0, 0
+
+    def set(self, shift):
+        """start from a known shift (tests, callers that know their logits' scale)"""
+        self.cur.fill_(float(shift))
+        self.nxt.zero_()
+        self.valid = True
+
+    def poll(self):
+        """look at completed flag copies; a raised flag invalidates the shift (the next step re-seeds it in the plain form)"""
+        while self.pending and self.pending[0][0].query():
+            _, gen = self.pending.pop(0)
+            if gen == self.gen and int(self.host[0]) != 0:
+                import warnings
+                self.gen += 1
+                self.flagged_steps += 1
+                self.valid = False
+                self.flag.zero_()
+                warnings.warn("exp-domain RNN-T loss: a lattice row's sum of exponentials under/overflowed (the logits moved by more than "
+                              "the 40 e-fold margin within one step); that step's loss and gradients were NaN and FusedOptimizer dropped "
+                              "it; the next step runs the plain fused form and re-seeds the shift")
+
+    def watch(self):
+        """queue an asynchronous copy of the flag behind the work issued so far"""
+        main = torch.cuda.current_stream(self.cur.device)
+        self.copy_stream.wait_stream(main)
+        with torch.cuda.stream(self.copy_stream):
+            self.host.copy_(self.flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        self.pending.append((ev, self.gen))
+        if len(self.pending) > 8:       # bounded: the oldest copy finished long ago
+            self.pending[0][0].synchronize()
+            self.poll()
+
+
 class _JointLossFn(torch.autograd.Function):
     """joint network + RNN-T loss as ONE op that never holds the [B, T, U+1, V] logits: the batch is cut into chunks
     of utterances; per chunk the logits are produced (ttmi_joint_fwd), reduced to the lattice (ttmi_rnnt_loss_fwd), overwritten IN PLACE
@@ -46,11 +101,9 @@ class _JointLossFn(torch.autograd.Function):
     logits + gradient -> 0.44 GB per chunk of 2 utterances; C5: 55.8 GB -> 3.5 GB per utterance).  backward() only scales by the
     incoming gradient."""
 
-    # exp-domain fast path: device scalars (shift used by this step, shift gathered for the next one), per device
-    _shift = {}
-
     @staticmethod
-    def forward(ctx, enc, dec, wf, bf, wp, bp, labels, act_lens, label_lens, prec, chunk, reduction, exp_domain, grad_mode=True):
+    def forward(ctx, enc, dec, wf, bf, wp, bp, labels, act_lens, label_lens, prec, chunk, reduction, exp_state, grad_mode=True):
+        """exp_state: None (plain fused form) or the JointNet's _ExpShift for this device (exp-domain form)"""
         enc, dec = enc.contiguous(), dec.contiguous()
         params = (wf, bf, wp, bp)
         wf_, bf_, wp_, bp_ = (t.detach() for t in params)
@@ -64,41 +117,40 @@ class _JointLossFn(torch.autograd.Function):
             denc, ddec = torch.empty_like(enc), torch.empty_like(dec)
             g = {n: torch.zeros_like(t) for n, t in zip(("wf", "bf", "wp", "bp"), params)}
         J, V = wf.shape[0], wp.shape[0]
-        if exp_domain:
-            state = _JointLossFn._shift.get(enc.device)
-            if state is None:
-                # first use on this device: one look at a sample of real logits (32 frames of the first utterance) sets the shift,
-                # so that a model whose logits are already large (a loaded checkpoint) cannot overflow exp() on its first step.
-                # The only host synchronisation of this path; afterwards the loss kernels hand the next step's shift over on the device.
-                sample = ops.joint_fwd(enc[:1, :32].contiguous(), dec[:1].contiguous(), wf_, bf_, wp_, bp_, prec)[0]
-                top = float(sample.float().max())
-                state = (torch.full((1,), max(0.0, top - 40.0), device=enc.device), torch.zeros(1, device=enc.device))
-                _JointLossFn._shift[enc.device] = state
-                del sample
-            cur, nxt = state
+        st = exp_state
+        exp_ran = seeded = False
+        if st is not None:
+            st.poll()
         for c0 in range(0, B, chunk):
             c1 = min(B, c0 + chunk)
             ws = ops.rnnt_workspace(c1 - c0, T, U1, enc.device)
             lab, al, ll = labels[c0:c1], act_lens[c0:c1], label_lens[c0:c1]
-            if exp_domain and ops.joint_exp_supported(c1 - c0, T, U1, J, V, prec, fwd_only=not need):
-                # the projection stores exp(logit - shift) and row sums; the loss reads two entries per row, its gradient stays
-                # factored as (row factor) x P and is consumed in that form (include/ttmi.h, "fused joint + loss fast path")
-                P, rowsum, saved = ops.joint_fwd_exp(enc[c0:c1], dec[c0:c1], wf_, bf_, wp_, bp_, prec, cur)
-                costs[c0:c1] = ops.rnnt_loss_fwd_exp(P, rowsum, lab, al, ll, 0, ws, cur, nxt)
+            if st is not None and st.valid and ops.joint_exp_supported(c1 - c0, T, U1, J, V, prec, fwd_only=not need):
+                # the projection stores exp(logit - shift) and row sums; the loss reads the sums and two f32 logits per row, its gradient
+                # stays factored as (row factor) x P and is consumed in that form (include/ttmi.h, "fused joint + loss fast path")
+                P, rowsum, saved, emis = ops.joint_fwd_exp(enc[c0:c1], dec[c0:c1], wf_, bf_, wp_, bp_, prec, st.cur, lab.contiguous(), 0)
+                costs[c0:c1] = ops.rnnt_loss_fwd_exp(P, rowsum, lab, al, ll, 0, ws, st.cur, st.nxt, emis, st.flag)
                 if need:
                     srow, srow16 = ops.rnnt_loss_bwd_exp(P, lab, al, ll, 0, ws, one, 0, scale)
                     ops.joint_bwd_exp(P, srow, srow16, enc[c0:c1], dec[c0:c1], wf_, wp_, saved, prec, g, out=(denc[c0:c1], ddec[c0:c1]))
-                del P, rowsum, saved
+                del P, rowsum, saved, emis
+                exp_ran = True
                 continue
             logits, saved = ops.joint_fwd(enc[c0:c1], dec[c0:c1], wf_, bf_, wp_, bp_, prec)
             costs[c0:c1] = ops.rnnt_loss_fwd(logits, lab, al, ll, 0, ws)
+            if st is not None and not st.valid:                 # the plain form's log-sum-exp pass seeds the shift for the next step
+                ops.rnnt_shift_seed(ws, al, ll, c1 - c0, T, U1, st.nxt)
+                seeded = True
             if need:
                 grad = ops.rnnt_loss_bwd(logits, lab, al, ll, 0, ws, one, 0, scale, inplace=True)
                 ops.joint_bwd(grad, enc[c0:c1], dec[c0:c1], wf_, wp_, saved, prec, g, out=(denc[c0:c1], ddec[c0:c1]))
             del logits, saved
-        if exp_domain:
-            cur.copy_(nxt)
-            nxt.zero_()
+        if st is not None and (exp_ran or seeded):
+            st.cur.copy_(st.nxt)
+            st.nxt.zero_()
+            st.valid = True
+            if exp_ran:
+                st.watch()
         if need:
             ctx.save_for_backward(denc, ddec, *g.values())
         ctx.params = params
@@ -135,6 +187,12 @@ class JointNet(nn.Module):
         self.forward_layer = nn.Linear(input_size, inner_dim, bias=True)
         self.tanh = nn.Tanh()
         self.project_layer = nn.Linear(inner_dim, vocab_size, bias=True)
+        self._register_load_state_dict_pre_hook(self._new_weights)
+
+    def _new_weights(self, *args):
+        """load_state_dict: the logits' scale is unknown again - the exp-domain loss form re-seeds its shift at the next step"""
+        for st in self.__dict__.get("_exp_shift", {}).values():
+            st.valid = False
 
     def forward(self, enc_state, dec_state):
         ops.weights_fresh()
@@ -148,6 +206,15 @@ class JointNet(nn.Module):
         out = _JointFn.apply(enc_state, dec_state, self.forward_layer.weight, self.forward_layer.bias,
                              self.project_layer.weight, self.project_layer.bias, default_precision())
         return out if squeeze is None else out.reshape(*squeeze, out.shape[-1])
+
+    def exp_shift_state(self, device):
+        """this module's range-control state of the exp-domain loss form on `device` (_ExpShift; created on first use, not part of
+        state_dict)"""
+        states = self.__dict__.setdefault("_exp_shift", {})
+        st = states.get(device)
+        if st is None:
+            st = states[device] = _ExpShift(device)
+        return st
 
 
 class _LabelStateGraphs:
@@ -230,7 +297,9 @@ class Transducer(nn.Module):
 
         exp_domain=True (bf16 mode, training-sized chunks; silently the form above otherwise): the projection stores exp(logit - shift) and
         per-row sums, so the loss never walks the lattice's rows and its gradient is consumed in factored form (include/ttmi.h).  Same
-        loss and gradients up to bf16 rounding of different intermediates (tests/test_fused_loss_gpu.py states the tolerance)."""
+        loss and gradients up to bf16 rounding of different intermediates (tests/test_fused_loss_gpu.py states the tolerance).  The first
+        call on a module (and the first after its joint weights were replaced) runs the form above and seeds the shift on the device
+        (_ExpShift): no host synchronisation."""
         from warprnnt_pytorch import check_lengths as certify
         enc_state, dec_state = self._encode(inputs, targets)
         B, T, U1 = enc_state.shape[0], enc_state.shape[1], dec_state.shape[1]
@@ -242,7 +311,8 @@ class Transducer(nn.Module):
             chunk = self.default_loss_chunk(B, T, U1, exp_domain)
         j = self.joint
         return _JointLossFn.apply(enc_state, dec_state, j.forward_layer.weight, j.forward_layer.bias, j.project_layer.weight,
-                                  j.project_layer.bias, labels, al, ll, prec, int(chunk), reduction, bool(exp_domain), torch.is_grad_enabled())
+                                  j.project_layer.bias, labels, al, ll, prec, int(chunk), reduction,
+                                  j.exp_shift_state(enc_state.device) if exp_domain and prec == 1 else None, torch.is_grad_enabled())
 
     def default_loss_chunk(self, B, T, U1, exp_domain=False):
         """utterances per chunk of `loss()`: about 2 GB of logits (the memory-saving form) or 16 GB (exp_domain: the speed form - every

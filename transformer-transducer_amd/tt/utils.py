@@ -82,21 +82,38 @@ def chunk_mask(audio, chunk=16, left_context=64):
     return ((j < lo) | (j > hi)).to(audio.dtype)
 
 
-# ---- feature front-end with the reference's names (tt/utils.py:120-151,182-214,297-329), computed by the HIP kernels of ttmi.frontend.
-# numpy in -> numpy out (so tt/dataset.py keeps working), device tensor in -> device tensor out.  There is no CPU arithmetic here.
-def _dev(x, dtype):
-    if isinstance(x, torch.Tensor):
-        return x.to(device="cuda", dtype=dtype) if not x.is_cuda else x.to(dtype), False
-    import numpy as np
-    return torch.as_tensor(np.ascontiguousarray(x)).to(device="cuda", dtype=dtype), True
+# ---- feature front-end with the reference's names (tt/utils.py:120-151,182-214,297-329).  DEVICE tensors run on the HIP kernels of
+# ttmi.frontend (device tensor in -> device tensor out).  Host inputs (numpy arrays, CPU tensors) are what the reference's own data
+# loading hands these names: tt/dataset.py calls get_feature2 + concat_frame inside AudioDataset.__getitem__, which train.py:174-184 runs
+# in fork-started DataLoader workers AFTER model.cuda() - a forked child must never touch HIP.  Those calls are served by the reference's
+# own numpy functions (the overlay's usual forwarding, see __getattr__); this repo holds no CPU arithmetic for them.  The batched GPU
+# front-end is the opt-in ttmi.frontend.FeaturePipeline.
+def _on_device(x):
+    """True: run the HIP kernels.  Host data, DataLoader workers and forked children of a process that initialised the GPU never do."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda):
+        return False
+    from torch.utils.data import get_worker_info
+    if get_worker_info() is not None or torch.cuda._is_in_bad_fork():
+        raise RuntimeError("tt.utils front-end: a device tensor inside a DataLoader worker / forked child; hand the worker host data "
+                           "(served by the reference's numpy code) or run ttmi.frontend.FeaturePipeline in the training process")
+    return True
+
+
+def _host(name):
+    """the reference's own implementation of `name` for host data"""
+    try:
+        return getattr(_reference_utils(), name)
+    except ImportError as e:
+        raise ValueError("tt.utils.%s: host input (numpy / CPU tensor) is served by the reference's tt/utils.py, which could not be loaded "
+                         "(%s); the MI355X path takes device tensors (there is no CPU path in this package)" % (name, e)) from e
 
 
 def concat_frame(features, left_context_width, right_context_width):
     """[T, F] -> [T, F * (1 + left + right)]: `left` past frames | frame | future frames (placed as the reference places them)"""
+    if not _on_device(features):
+        return _host("concat_frame")(features, left_context_width, right_context_width)
     from ttmi import frontend
-    x, was_np = _dev(features, torch.float32)
-    out = frontend.stack_subsample(x[None], None, left_context_width, right_context_width, 1)[0][0]
-    return out.cpu().numpy() if was_np else out
+    return frontend.stack_subsample(features.float()[None], None, left_context_width, right_context_width, 1)[0][0]
 
 
 def subsampling(features, subsample=3):
@@ -106,31 +123,33 @@ def subsampling(features, subsample=3):
     return features[::subsample].copy()
 
 
-def _log_mel(wave_data, framerate, feature_dim, mode):
+def _log_mel(name, wave_data, framerate, feature_dim, mode):
+    if not _on_device(wave_data):
+        return _host(name)(wave_data, framerate, feature_dim)
     from ttmi import frontend
-    w, was_np = _dev(wave_data, torch.int16)
+    w = wave_data.to(torch.int16)
     n = torch.tensor([w.numel()], dtype=torch.int32, device=w.device)
-    out = frontend.log_mel(w.reshape(1, -1), n, framerate, feature_dim, mode)[0]
-    return out.cpu().numpy() if was_np else out
+    return frontend.log_mel(w.reshape(1, -1), n, framerate, feature_dim, mode)[0]
 
 
 def get_feature(wave_data, framerate, feature_dim=128):
     """int16 samples -> natural-log mel spectrogram [1 + n // 160, feature_dim] (zeros where the power is 0)"""
-    return _log_mel(wave_data, framerate, feature_dim, "ln")
+    return _log_mel("get_feature", wave_data, framerate, feature_dim, "ln")
 
 
 def get_feature2(wave_data, framerate, feature_dim=128):
     """int16 samples -> log10 mel spectrogram (zero power -> log10 of the float64 epsilon)"""
-    return _log_mel(wave_data, framerate, feature_dim, "log10")
+    return _log_mel("get_feature2", wave_data, framerate, feature_dim, "log10")
 
 
 def get_final_feature(samples, sample_rate=16000, feature_dim=128, left=3, right=0, subsample=3):
+    if not _on_device(samples):
+        return _host("get_final_feature")(samples, sample_rate, feature_dim, left, right, subsample)
     from ttmi import frontend
-    w, was_np = _dev(samples, torch.int16)
+    w = samples.to(torch.int16)
     n = torch.tensor([w.numel()], dtype=torch.int32, device=w.device)
     mel = frontend.log_mel(w.reshape(1, -1), n, sample_rate, feature_dim, "ln")
-    out = frontend.stack_subsample(mel, None, left, right, subsample)[0][0]
-    return out.cpu().numpy() if was_np else out
+    return frontend.stack_subsample(mel, None, left, right, subsample)[0][0]
 
 
 def time_mask_augment(inputs, max_mask_time=5, mask_num=10):

@@ -407,8 +407,9 @@ def joint_exp_supported(B, T, U1, J, V, prec, fwd_only=False):
     return bool(fn(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(V), c_int(prec), c_long(ldv)))
 
 
-def joint_fwd_exp(enc, dec, wf, bf, wp, bp, prec, shift=None):
-    """-> (P bf16 [B,T,U1,V] view of a pitch-roundup(V,64) buffer = exp(logits - shift), rowsum f32 [nparts, B*T*U1], ctx)"""
+def joint_fwd_exp(enc, dec, wf, bf, wp, bp, prec, shift=None, labels=None, blank=0):
+    """-> (P bf16 [B,T,U1,V] view of a pitch-roundup(V,64) buffer = exp(logits - shift), rowsum f32 [nparts, B*T*U1], ctx, emis).
+    labels (int32 [B, U1-1]) given: emis f32 [B*T*U1, 2] = the blank's and the next label's logit of every lattice row, else None"""
     B, T, de = enc.shape
     U1, dd = dec.shape[1], dec.shape[2]
     J, V = wf.shape[0], wp.shape[0]
@@ -420,20 +421,33 @@ def joint_fwd_exp(enc, dec, wf, bf, wp, bp, prec, shift=None):
     buf, P = padded_empty((B, T, U1, V), torch.bfloat16, enc.device)
     nparts = L_.ttmi_joint_exp_nparts(c_int(V))
     rowsum = torch.empty(nparts, B * T * U1, dtype=torch.float32, device=enc.device)
+    emis = None
+    if labels is not None:
+        _need_cuda(labels)
+        assert labels.dtype is torch.int32 and labels.is_contiguous() and tuple(labels.shape) == (B, U1 - 1)
+        emis = torch.empty(B * T * U1, 2, dtype=torch.float32, device=enc.device)
     check(L_.ttmi_joint_fwd_exp(_p(enc), _p(dec), _p(wf), _p(bf), _p(wp), _p(bp), c_int(B), c_int(T), c_int(U1), c_int(de),
                                 c_int(dd), c_int(J), c_int(V), c_int(prec), _p(ctx), _p(ws), _p(P), c_long(buf.shape[-1]),
-                                _p(rowsum), c_int(nparts), _p(shift), _stream()), "ttmi_joint_fwd_exp")
-    return P, rowsum, ctx
+                                _p(rowsum), c_int(nparts), _p(shift), _p(labels), c_int(blank), _p(emis), _stream()), "ttmi_joint_fwd_exp")
+    return P, rowsum, ctx, emis
 
 
-def rnnt_loss_fwd_exp(P, rowsum, labels, act_lens, label_lens, blank, workspace, shift_cur=None, shift_next=None):
-    _need_cuda(P, rowsum, labels, act_lens, label_lens, workspace)
+def rnnt_loss_fwd_exp(P, rowsum, labels, act_lens, label_lens, blank, workspace, shift_cur=None, shift_next=None, emis=None, flag=None):
+    """emis: f32 [rows, 2] from joint_fwd_exp (the emission log-probs then come from f32 logits, not from bf16 entries of P); flag: device
+    int32 [1], bit 0 set when a row sum under- / overflowed (that step's costs and gradients are NaN)"""
+    _need_cuda(P, rowsum, labels, act_lens, label_lens, workspace, emis, flag)
     B, T, U1, V = P.shape
     costs = torch.empty(B, dtype=torch.float32, device=P.device)
     check(lib().ttmi_rnnt_loss_fwd_exp(_p(P), c_long(row_pitch(P)), _p(rowsum), c_int(rowsum.shape[0]), _p(labels), _p(act_lens),
                                        _p(label_lens), c_int(B), c_int(T), c_int(U1), c_int(V), c_int(blank), _p(workspace),
-                                       _p(costs), _p(shift_cur), _p(shift_next), _stream()), "ttmi_rnnt_loss_fwd_exp")
+                                       _p(costs), _p(shift_cur), _p(shift_next), _p(emis), _p(flag), _stream()), "ttmi_rnnt_loss_fwd_exp")
     return costs
+
+
+def rnnt_shift_seed(workspace, act_lens, label_lens, B, T, U1, shift_next):
+    """shift_next = max(shift_next, max log-sum-exp - 40) over the lattice rows of a PLAIN rnnt_loss_fwd's workspace (device only)"""
+    check(lib().ttmi_rnnt_shift_seed(_p(workspace), _p(act_lens), _p(label_lens), c_int(B), c_int(T), c_int(U1), _p(shift_next), _stream()),
+          "ttmi_rnnt_shift_seed")
 
 
 def rnnt_loss_bwd_exp(P, labels, act_lens, label_lens, blank, workspace, grad_out, grad_out_stride, scale):
