@@ -306,6 +306,16 @@ def main():
         return loss
 
     elapsed, enqueue, host_cpu, last = timed_region(step, args.steps, args.warmup, world)
+    # what the host itself needs to issue one step: timed on a drained device (inside the timed region the issue loop runs ahead of the GPU
+    # until the HIP queue is full and then waits in the launch calls - spinning, so that wait shows up as CPU time, not as idle time)
+    issue = []
+    for _ in range(3):
+        fence(world)
+        t1 = time.perf_counter()
+        step(False, 0)
+        issue.append(time.perf_counter() - t1)
+    fence(world)
+    host_issue = float(np.median(issue))
     if rank == 0:                                     # the probes are read after the timed region: no host sync inside it
         slots = [i % 64 for i in range(max(0, args.steps - 64), args.steps)]
         probe_ms = [ops.probe_read_ms(i) for i in slots]
@@ -332,7 +342,7 @@ def main():
     if args.precision == "bf16" and not args.no_fp32_form and args.workload == "c2":
         # the fp32 mode: the path that meets north_star's 1e-4 tolerance (tests/test_configs_gpu.py), timed on the same workload
         fp32_form = secondary("two-call", "fp32", fp32_steps, 1)
-    elapsed, two_call, fp32_form = max_over_ranks([elapsed, two_call, fp32_form], world, dev)
+    elapsed, two_call, fp32_form, host_issue = max_over_ranks([elapsed, two_call, fp32_form, host_issue], world, dev)
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
@@ -436,8 +446,11 @@ def main():
                                     % args.workload.split("-")[1]) +
                                    ", T=%d U=%d, batch %d/GPU, dropout 0.1, SGD momentum + clip 200" % (T, U, B),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
-            # host side of a step: CPU time this process spent (Python + ctypes + HIP runtime, every thread) and the rest of the enqueue wall
-            # time, i.e. time blocked (full queue, allocator waits).  CPU time well below ms_per_step = the step is GPU-bound.
+            # host side of a step.  host_issue: wall time to issue ONE step (Python + ctypes + HIP runtime, forward thread and autograd's
+            # backward thread) on a drained device - the host's own cost; well below ms_per_step = the step is GPU-bound.  Inside the timed
+            # region the issue loop runs ahead until the HIP queue is full and then spins in the launch calls: host_enqueue (wall) and
+            # host_cpu (process CPU time, every thread incl. the runtime's) therefore approach ms_per_step and say little by themselves.
+            "host_issue_ms_per_step": round(1e3 * host_issue, 3),
             "host_cpu_ms_per_step": round(1e3 * host_cpu / args.steps, 3),
             "host_blocked_ms_per_step": round(max(0.0, 1e3 * (enqueue - host_cpu) / args.steps), 3),
             "host_enqueue_ms_per_step": round(1e3 * enqueue / args.steps, 3), "model_tflops": round(flops_per_utt(cfg, T, U1) * utt_s / 1e12, 2),

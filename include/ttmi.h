@@ -195,6 +195,9 @@ int ttmi_sgd_step(float* p, const float* g, float* mom, long n, float lr, float 
                   float max_norm, const float* normsq, float grad_scale, void* stream);
 int ttmi_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int step, float max_norm, const float* normsq, float grad_scale, void* stream);
+/* torch.optim.Adadelta(lr, rho, eps, weight_decay), the third type of tt/optim.py:74-81 */
+int ttmi_adadelta_step(float* p, const float* g, float* square_avg, float* acc_delta, long n, float lr, float rho, float eps,
+                       float weight_decay, float max_norm, const float* normsq, float grad_scale, void* stream);
 
 /* ---- bring-up / measurement helpers ------------------------------------------------------------------------------
  * generic MFMA GEMM (every layout / dtype / epilogue; flags = GemmFlags of csrc/gemm.h) and the two throughput

@@ -32,7 +32,7 @@ def _loss(model, x, y):
     return RNNTLoss()(model(x, y), y.int(), torch.full((B,), 20, dtype=torch.int32).cuda(), torch.full((B,), 6, dtype=torch.int32).cuda())
 
 
-@pytest.mark.parametrize("kind,clip", [("sgd", 5.0), ("sgd", 0.0), ("adam", 5.0), ("adam", 0.0)])
+@pytest.mark.parametrize("kind,clip", [("sgd", 5.0), ("sgd", 0.0), ("adam", 5.0), ("adam", 0.0), ("adadelta", 5.0), ("adadelta", 0.0)])
 def test_fused_update_matches_torch_over_five_steps(kind, clip):
     """same gradients fed to both optimizers for five steps: torch.nn.utils.clip_grad_norm_ + torch.optim.{SGD(momentum .9),
     Adam(betas (.9, .98), eps 1e-8)} (tt/optim.py:57-73) against ttmi_sumsq + ttmi_sgd_step / ttmi_adam_step"""
@@ -41,10 +41,11 @@ def test_fused_update_matches_torch_over_five_steps(kind, clip):
     ref = torch.nn.Sequential(torch.nn.Linear(37, 50), torch.nn.Linear(50, 11)).cuda()
     mine = copy.deepcopy(ref)
     flat = FlatModel(mine)
-    lr = 0.05 if kind == "sgd" else 0.01
-    opt = FusedOptimizer(flat, kind=kind, lr=lr, momentum=0.9, weight_decay=1e-3, max_grad_norm=clip)
-    topt = (torch.optim.SGD(ref.parameters(), lr=lr, momentum=0.9, weight_decay=1e-3) if kind == "sgd" else
-            torch.optim.Adam(ref.parameters(), lr=lr, betas=(0.9, 0.98), eps=1e-8, weight_decay=1e-3))
+    lr = {"sgd": 0.05, "adam": 0.01, "adadelta": 1.0}[kind]
+    opt = FusedOptimizer(flat, kind=kind, lr=lr, momentum=0.9, weight_decay=1e-3, max_grad_norm=clip, rho=0.95)
+    topt = {"sgd": lambda: torch.optim.SGD(ref.parameters(), lr=lr, momentum=0.9, weight_decay=1e-3),
+            "adam": lambda: torch.optim.Adam(ref.parameters(), lr=lr, betas=(0.9, 0.98), eps=1e-8, weight_decay=1e-3),
+            "adadelta": lambda: torch.optim.Adadelta(ref.parameters(), lr=lr, rho=0.95, eps=1e-6, weight_decay=1e-3)}[kind]()
     g = torch.Generator(device="cuda").manual_seed(1)
     for step in range(5):
         for pr, pm in zip(ref.parameters(), mine.parameters()):
@@ -150,7 +151,22 @@ def test_reference_shaped_optimizer_wrapper():
     assert opt.current_epoch == 1 and opt.lr == 0.005 and opt.param_groups[0]["lr"] == 0.005
     topt.load_state_dict(opt.state_dict())                  # torch.optim accepts our state_dict as it stands
     with pytest.raises(NotImplementedError):
-        Optimizer(model.parameters(), AttrDict(dict(type="adadelta", lr=1.0)))
+        Optimizer(model.parameters(), AttrDict(dict(type="rmsprop", lr=1.0)))      # build_optimizer's own else-branch (tt/optim.py:83-84)
+    # the third type the reference builds (tt/optim.py:74-81): adadelta through the same wrapper against torch.optim.Adadelta
+    torch.manual_seed(5)
+    m2 = Transducer(_cfg()).cuda().train()
+    r2 = Transducer(_cfg()).cuda().train()
+    r2.load_state_dict(m2.state_dict())
+    o2 = Optimizer(m2.parameters(), AttrDict(dict(type="adadelta", lr=1.0, rho=0.9, eps=1e-6, weight_decay=0.0)))
+    t2 = torch.optim.Adadelta(r2.parameters(), lr=1.0, rho=0.9, eps=1e-6, weight_decay=0.0)
+    for s in range(3):
+        for m, o in ((m2, o2), (r2, t2)):
+            o.zero_grad()
+            _loss(m, *_batch(s)).backward()
+            o.step()
+    for (n, a), b in zip(m2.named_parameters(), r2.parameters()):
+        assert rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy()) < 1e-5, n
+    t2.load_state_dict(o2.state_dict())
 
 
 def test_embedding_index_contract():

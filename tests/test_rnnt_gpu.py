@@ -197,3 +197,28 @@ def test_timing_probes_fire_around_the_loss_kernels():
     assert ops.probe_read_ms(7, 1) > 0 and ops.probe_read_ms(7, 2) > 0
     assert ops.probe_read_ms(7, 1) < 0                   # consumed
     assert ops.probe_read_ms(9, 1) < 0                   # never armed
+
+
+@pytest.mark.parametrize("B,T,U", [(3, 40, 50), (2, 37, 64), (2, 300, 200), (2, 25, 600), (1, 1, 0), (2, 90, 959)])
+def test_lattice_kernels_agree_bit_for_bit(B, T, U):
+    """rnnt_lattice_lds_kernel (one workgroup per utterance and direction: a wave per 64 labels, frontier hand-off through LDS, a helper
+    wave for the memory traffic) walks the same recursion in the same arithmetic as the one-wave kernel of round 1: costs and gradients
+    are identical to the last bit, ragged lengths included; U + 1 = 960 is the widest workgroup (15 + 1 waves)"""
+    from ttmi import ops
+    rng = np.random.default_rng(7 * T + U)
+    V = 6
+    x = (rng.normal(size=(B, T, U + 1, V)) * 2).astype(np.float32)
+    y = rng.integers(1, V, size=(B, U))
+    tl, ul = np.full(B, T), np.full(B, U)
+    if B > 1:
+        tl[1:] = rng.integers(1, T + 1, size=B - 1)
+        ul[1:] = rng.integers(0, U + 1, size=B - 1)
+    try:
+        ops.set_option(9, 1)
+        l_old, g_old = run_hip(x, y.reshape(B, U), tl, ul)
+    finally:
+        ops.set_option(9, 0)
+    l_new, g_new = run_hip(x, y.reshape(B, U), tl, ul)
+    assert np.array_equal(l_old, l_new) and np.array_equal(g_old, g_new)
+    want = O.rnnt_loss(x.astype(np.float64), y, tl, ul)
+    assert abs(l_new[0] - want[0]) / abs(want[0]) < TOL and rel_err(g_new, want[2]) < TOL

@@ -19,6 +19,7 @@
 
 void ttmi_probe_begin(int slot, hipStream_t st);
 void ttmi_probe_end(int slot, hipStream_t st);
+void ttmi_rnnt_set_lattice_version(int v);      // rnnt.hip
 
 namespace {
 
@@ -1015,7 +1016,8 @@ int ttmi_stream_reserve_cus(void* stream, int n) {
 // process-wide switches for A/B measurements.  key 0: 1 = disable the fused attention kernels (bf16 pipeline only);
 // key 1: throughput-GEMM generation (see gemm_fast.hip); key 2: flash-kernel timing switches; key 3: 0 = no wgrad fork
 int ttmi_set_option(int key, int value) {
-    TTMI_REQUIRE(key >= 0 && key <= 8, "set_option: unknown key %d", key);
+    TTMI_REQUIRE(key >= 0 && key <= 9, "set_option: unknown key %d", key);
+    if (key == 9) { ttmi_rnnt_set_lattice_version(value); return TTMI_OK; }
     if (key == 8) { g_inkernel_pos = value; return TTMI_OK; }
     if (key == 6) { gemm_fast_set_reserved_cus(value); return TTMI_OK; }
     if (key == 7) { ttmi_gemm_set_skinny_rows(value); return TTMI_OK; }

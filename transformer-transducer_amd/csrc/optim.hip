@@ -79,6 +79,24 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// torch.optim.Adadelta (tt/optim.py:74-81): sq = rho sq + (1 - rho) g^2; delta = sqrt(acc + eps) / sqrt(sq + eps) g; acc = rho acc + (1 - rho) delta^2;
+// p -= lr delta
+__global__ __launch_bounds__(256) void adadelta_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq,
+                                                       float* __restrict__ acc, long n, float lr, float rho, float eps, float wd,
+                                                       float max_norm, const float* __restrict__ normsq, float grad_scale) {
+    if (step_dropped(normsq, max_norm)) return;
+    const float coef = clip_coef(normsq, max_norm, grad_scale);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i] * coef + wd * p[i];
+        const float s = rho * sq[i] + (1.f - rho) * gi * gi;
+        const float a = acc[i];
+        const float delta = sqrtf(a + eps) / sqrtf(s + eps) * gi;
+        sq[i] = s;
+        acc[i] = rho * a + (1.f - rho) * delta * delta;
+        p[i] -= lr * delta;
+    }
+}
+
 int grid_for(long n) {
     long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -119,6 +137,16 @@ int ttmi_adam_step(float* p, const float* g, float* m, float* v, long n, float l
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n, lr, beta1,
                        beta2, eps, weight_decay, bc1, bc2, max_norm, normsq, grad_scale);
     TTMI_LAUNCH_CHECK("adam_kernel");
+    return TTMI_OK;
+}
+
+// torch.optim.Adadelta step (square_avg, acc_delta state buffers)
+int ttmi_adadelta_step(float* p, const float* g, float* square_avg, float* acc_delta, long n, float lr, float rho, float eps,
+                       float weight_decay, float max_norm, const float* normsq, float grad_scale, void* stream) {
+    TTMI_REQUIRE(p && g && square_avg && acc_delta && n > 0 && rho >= 0.f && rho <= 1.f && eps > 0.f, "adadelta_step: bad arguments");
+    hipLaunchKernelGGL(adadelta_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, square_avg, acc_delta, n, lr,
+                       rho, eps, weight_decay, max_norm, normsq, grad_scale);
+    TTMI_LAUNCH_CHECK("adadelta_kernel");
     return TTMI_OK;
 }
 

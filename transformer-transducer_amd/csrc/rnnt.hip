@@ -318,6 +318,210 @@ __global__ __launch_bounds__(64) void rnnt_alphabeta_kernel(const float* __restr
     }
 }
 
+
+// ------------------------------------------------------------------ alpha / beta, one workgroup per (utterance, direction)
+// The serial chain of the recursion is one log-add-exp per diagonal; everything else is kept off it:
+//   * one COMPUTE wave per 64 labels (lane = label u), all walking the same diagonals: the frontier cell of the neighbouring wave (label
+//     64 w - 1 for alpha, 64 (w + 1) for beta) crosses through an LDS ring of 64 slots.  A slot is ONE 16-byte {value, step tag} granule,
+//     written by one ds_write_b128 of one lane and read by one ds_read_b128 (a lane's 16 bytes move in one LDS cycle), so there is no
+//     separate flag and no barrier per diagonal; the read for step g + 1 is issued at the top of step g and has landed when it is needed
+//     (a consumer that once had to spin stays one step behind its producer).  U + 1 = 201 is 4 waves side by side instead of 4 slots
+//     walked serially by one wave;
+//   * a HELPER wave does all the global traffic: the emission rows of chunk c + 1 (CH diagonals = ONE contiguous span of the diagonal-major
+//     arrays) go straight into LDS by LDS-DMA while the compute waves walk chunk c out of the other buffer, and the alpha / beta rows of
+//     chunk c - 1, which the compute waves left in an LDS ring, are streamed out as whole rows.  The compute waves issue no vector-memory
+//     instruction inside the loop (the one-wave kernel waited on vmcnt for its own prefetch loads and cell stores every few steps), and
+//     their LDS reads of step s + 1 are issued before the arithmetic of step s;
+//   * one workgroup barrier per CH diagonals swaps the buffers.
+// Frontier in fp64 as before (lae).  Cells outside the ragged lattice are written as -1e30 (they are never read).
+constexpr int LAT_NB = 64;            // boundary ring slots; > CH + 1 (a neighbour runs at most one chunk ahead between two barriers)
+struct __attribute__((aligned(16))) LatSlot {
+    acc_t v;
+    int tag;        // steps completed when v was written (g + 1); slot LAT_NB - 1 starts as {initial cell, 0}
+    int pad;
+};
+__device__ __forceinline__ void lat_glds4(const void* gsrc, float* lds_wave_base) {       // 4 bytes per lane: LDS address = base + lane * 4
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+typedef int lat_i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ LatSlot lat_slot_read(const LatSlot* p) {          // one ds_read_b128, never split or cached by the compiler
+    const lat_i4 w = *(const volatile __attribute__((address_space(3))) lat_i4*)(p);       // (a generic volatile access would be a flat_load)
+    LatSlot r;
+    r.v = __longlong_as_double(((long long)w.y << 32) | (unsigned)w.x);
+    r.tag = w.z;
+    r.pad = 0;
+    return r;
+}
+__device__ __forceinline__ void lat_slot_write(LatSlot* p, acc_t v, int tag) {
+    const long long b = __double_as_longlong(v);
+    lat_i4 w;
+    w.x = (int)(b & 0xffffffffLL); w.y = (int)(b >> 32); w.z = tag; w.w = 0;
+    *(volatile __attribute__((address_space(3))) lat_i4*)(p) = w;
+}
+
+template <bool BETA>
+__device__ __forceinline__ void lat_walk(const float* __restrict__ Eb, const float* __restrict__ El, acc_t* __restrict__ A, LatSlot* __restrict__ bnd,
+                                         int CHR, int CH, int U1, int W, int wave, int lane, int Tb, int Ub, int D, int nsteps, int NC,
+                                         acc_t& a) {
+    const int u = wave * 64 + lane;
+    const int uc = u < U1 ? u : U1 - 1;                       // in-range column for the (unconditional) LDS reads
+    const int ul = BETA ? uc : (uc > 0 ? uc - 1 : 0);         // label log-prob column: alpha reads the cell on the left
+    // neighbour hand-off: alpha takes the cell of the wave on the left (its lane 63) into lane 0, beta the one on the right into lane 63
+    const bool consume = BETA ? (wave + 1 < W) : (wave > 0);
+    const bool produce = BETA ? (wave > 0) : (wave + 1 < W);
+    const int edge = BETA ? 63 : 0, pedge = BETA ? 0 : 63;
+    const LatSlot* cring = bnd + (BETA ? wave + 1 : wave - 1) * LAT_NB;
+    LatSlot* pring = bnd + wave * LAT_NB;
+    LatSlot pre;                                              // the neighbour's cell for the NEXT step, read one step ahead
+    pre.v = (acc_t)NEG; pre.tag = 0; pre.pad = 0;
+    if (consume) pre = lat_slot_read(cring + LAT_NB - 1);     // step 0 uses the initial cell (tag 0)
+    for (int c = 0; c < NC; ++c) {
+        const int n = min(CH, nsteps - c * CH);
+        const float* eb = Eb + (c & 1) * CHR;
+        const float* el = El + (c & 1) * CHR;
+        acc_t* ao = A + (long)(c & 1) * CH * U1;
+        // rows of the chunk sit in memory order; alpha walks them upwards (row of step s = s), beta downwards (n - 1 - s)
+        int r = BETA ? n - 1 : 0;
+        float pb = eb[r * U1 + uc], pl = el[r * U1 + ul];
+        for (int s = 0; s < n; ++s) {
+            const int g = c * CH + s;
+            // issue the LDS reads of the next step before this step's arithmetic: emission row and the neighbour's next cell
+            const int rn = BETA ? (s + 1 < n ? r - 1 : r) : (s + 1 < n ? r + 1 : r);
+            const float pb_n = eb[rn * U1 + uc], pl_n = el[rn * U1 + ul];
+            LatSlot nxt;
+            nxt.v = (acc_t)NEG; nxt.tag = 0; nxt.pad = 0;
+            if (consume) nxt = lat_slot_read(cring + (g & (LAT_NB - 1)));        // wanted at step g + 1 with tag g + 1
+            acc_t nb = BETA ? rot_l1(a) : rot_r1(a);
+            if (lane == edge) nb = (acc_t)NEG;
+            if (consume) {
+                while (pre.tag != g) {                        // not published yet (rare after the first steps): poll the slot of step g - 1
+                    __builtin_amdgcn_s_sleep(1);
+                    pre = lat_slot_read(cring + ((g + LAT_NB - 1) & (LAT_NB - 1)));
+                }
+                if (lane == edge) nb = pre.v;
+            }
+            const int d = BETA ? D - 2 - g : 1 + g;
+            const int t = d - u;
+            const bool valid = (u <= Ub) && (t >= 0) && (t < Tb);
+            const bool has_t = BETA ? (t < Tb - 1) : (t > 0);
+            const bool has_u = BETA ? (u < Ub) : (u > 0);
+            const acc_t tt = has_t ? a + (acc_t)pb : (acc_t)NEG;
+            const acc_t tu = has_u ? nb + (acc_t)pl : (acc_t)NEG;
+            a = valid ? lae(tt, tu) : (acc_t)NEG;
+            if (u < U1) ao[r * U1 + u] = a;
+            if (produce && lane == pedge) lat_slot_write(pring + (g & (LAT_NB - 1)), a, g + 1);
+            pb = pb_n; pl = pl_n; pre = nxt; r = rn;
+            // a use of the prefetched registers at the END of the step: the compiler's wait for them lands here, counted (the two LDS
+            // writes above stay in flight), after a whole step of arithmetic - at the first use in the next step it would wait for everything
+            {
+                int lo = (int)(__double_as_longlong(pre.v) & 0xffffffffLL), hi = (int)(__double_as_longlong(pre.v) >> 32);
+                asm volatile("" : "+v"(pb), "+v"(pl), "+v"(lo), "+v"(hi), "+v"(pre.tag));
+                pre.v = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024) void rnnt_lattice_lds_kernel(const float* __restrict__ lpb_d, const float* __restrict__ lpl_d,
+                                                                const int* __restrict__ act_lens, const int* __restrict__ label_lens, int T,
+                                                                int U1, int W, int CH, acc_t* __restrict__ alpha_d,
+                                                                acc_t* __restrict__ beta_d, acc_t* __restrict__ ll, float* __restrict__ costs) {
+    extern __shared__ __attribute__((aligned(16))) char lat_smem[];
+    const int b = blockIdx.x >> 1;
+    const bool do_beta = blockIdx.x & 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool helper = wave == W;
+    const int Tb = clampi(act_lens[b], 1, T), Ub = clampi(label_lens[b], 0, U1 - 1);
+    const int D = Tb + Ub;                       // diagonals 0 .. D-1
+    const long off = (long)b * diag_stride(T, U1);
+    const float* lpb = lpb_d + off;
+    const float* lpl = lpl_d + off;
+    acc_t* out = (do_beta ? beta_d : alpha_d) + off;
+    const int CHR = (CH * U1 + 63) / 64 * 64;   // floats per emission buffer (whole 64-float LDS-DMA pieces)
+    float* Eb = reinterpret_cast<float*>(lat_smem);      // [2][CHR] blank log-probs of the chunk's diagonals
+    float* El = Eb + 2 * CHR;                            // [2][CHR] label log-probs
+    acc_t* A = reinterpret_cast<acc_t*>(El + 2 * CHR);   // [2][CH * U1] the chunk's alpha / beta rows
+    LatSlot* bnd = reinterpret_cast<LatSlot*>(A + 2 * (long)CH * U1 + (((long)CH * U1) & 1));   // [W][LAT_NB], 16-byte aligned
+    const int nsteps = D - 1;
+    const int NC = (nsteps + CH - 1) / CH;
+    // chunk c = steps c CH .. c CH + n - 1.  alpha: step g forms diagonal 1 + g from emission row g; beta: step g forms diagonal D - 2 - g
+    // from emission row D - 2 - g.  row0 = lowest emission row of the chunk (its rows are contiguous in memory either way).
+    auto chunk = [&](int c, int& row0, int& n) {
+        n = min(CH, nsteps - c * CH);
+        row0 = do_beta ? (D - 2 - c * CH - (n - 1)) : c * CH;
+    };
+    auto issue_loads = [&](int c) {              // helper wave: emission rows of chunk c -> LDS (asynchronous)
+        int row0, n;
+        chunk(c, row0, n);
+        const int cnt = n * U1;
+        const float* gb = lpb + (long)row0 * U1;
+        const float* gl = lpl + (long)row0 * U1;
+        float* eb = Eb + (c & 1) * CHR;
+        float* el = El + (c & 1) * CHR;
+        for (int i = 0; i < cnt; i += 64) {
+            const int k = min(i + lane, cnt - 1);          // the last piece re-reads the span's last element instead of running past it
+            lat_glds4(gb + k, eb + i);
+            lat_glds4(gl + k, el + i);
+        }
+    };
+    auto drain = [&](int c) {                    // helper wave: the chunk's alpha / beta rows, LDS -> global, whole rows
+        int row0, n;
+        chunk(c, row0, n);
+        const int cnt = n * U1;
+        const acc_t* src = A + (long)(c & 1) * CH * U1;
+        acc_t* dst = out + (long)(do_beta ? row0 : row0 + 1) * U1;
+        int i = lane;
+        for (; i + 192 < cnt; i += 256) {        // four reads in flight per wait
+            const acc_t v0 = src[i], v1 = src[i + 64], v2 = src[i + 128], v3 = src[i + 192];
+            dst[i] = v0; dst[i + 64] = v1; dst[i + 128] = v2; dst[i + 192] = v3;
+        }
+        for (; i < cnt; i += 64) dst[i] = src[i];
+    };
+    const int u = wave * 64 + lane;
+    acc_t a = (acc_t)NEG;                        // this lane's frontier cell
+    if (!helper) {
+        if (!do_beta) {
+            a = (u == 0) ? 0.0 : (acc_t)NEG;
+            if (u == 0) out[0] = 0.0;
+            if (wave + 1 < W && lane == 63) lat_slot_write(bnd + wave * LAT_NB + LAT_NB - 1, a, 0);
+        } else {
+            const bool term = (u == Ub);
+            if (term) {
+                a = (acc_t)lpb[(long)(D - 1) * U1 + Ub];
+                out[(long)(D - 1) * U1 + Ub] = a;
+            }
+            if (wave > 0 && lane == 0) lat_slot_write(bnd + wave * LAT_NB + LAT_NB - 1, a, 0);
+        }
+    } else if (NC > 0) {
+        issue_loads(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (helper) {
+        for (int c = 0; c < NC; ++c) {
+            if (c + 1 < NC) issue_loads(c + 1);
+            if (c > 0) drain(c - 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (NC > 0) drain(NC - 1);
+        return;
+    }
+    if (!do_beta) {
+        lat_walk<false>(Eb, El, A, bnd, CHR, CH, U1, W, wave, lane, Tb, Ub, D, nsteps, NC, a);
+        if (u == Ub) {
+            const acc_t v = a + (acc_t)lpb[(long)(D - 1) * U1 + Ub];
+            ll[b * 2 + 0] = v;
+            costs[b] = (float)(-v);
+        }
+    } else {
+        lat_walk<true>(Eb, El, A, bnd, CHR, CH, U1, W, wave, lane, Tb, Ub, D, nsteps, NC, a);
+        if (u == 0) ll[b * 2 + 1] = a;
+    }
+}
+
 // ------------------------------------------------------------------ gradient
 template <typename TL>
 __global__ __launch_bounds__(LSE_WAVES * 64) void rnnt_grad_kernel(
@@ -502,6 +706,38 @@ void launch_alphabeta(hipStream_t st, int B, const float* lpb, const float* lpl,
     hipLaunchKernelGGL((rnnt_alphabeta_kernel<R, PF>), dim3(2 * B), dim3(64), 0, st, lpb, lpl, al, ll_, T, U1, a, b, ll, costs);
 }
 
+
+int g_lattice_version = 0;      // ttmi_set_option(9, 1): the round-1 kernel (one wave per utterance and direction) for A/B measurements
+// alpha + beta of B utterances.  Default: rnnt_lattice_lds_kernel (one workgroup per utterance and direction: one wave per 64 labels + a helper
+// wave); the one-wave kernel for U + 1 > 960 (17 waves do not fit a workgroup) and on request.
+int launch_lattice(hipStream_t st, int B, const float* lpb, const float* lpl, const int* al, const int* ll_, int T, int U1, acc_t* a, acc_t* b,
+                   acc_t* ll, float* costs) {
+    const int W = (U1 + 63) / 64;
+    if (g_lattice_version == 0 && W <= 15) {
+        int CH = (120 * 1024) / (32 * U1);
+        CH = CH > 32 ? 32 : (CH < 2 ? 2 : CH);
+        const int CHR = (CH * U1 + 63) / 64 * 64;
+        const size_t lds = (size_t)4 * CHR * 4 + (size_t)2 * CH * U1 * 8 + 16 + (size_t)W * LAT_NB * sizeof(LatSlot) + 64;
+        static size_t enabled = 0;
+        if (lds > enabled) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rnnt_lattice_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) {
+                ttmi_set_error("rnnt lattice: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+                return (int)e;
+            }
+            enabled = lds;
+        }
+        hipLaunchKernelGGL(rnnt_lattice_lds_kernel, dim3(2 * B), dim3((W + 1) * 64), lds, st, lpb, lpl, al, ll_, T, U1, W, CH, a, b, ll, costs);
+        return TTMI_OK;
+    }
+    if (U1 <= 64) launch_alphabeta<1, 8>(st, B, lpb, lpl, al, ll_, T, U1, a, b, ll, costs);
+    else if (U1 <= 128) launch_alphabeta<2, 8>(st, B, lpb, lpl, al, ll_, T, U1, a, b, ll, costs);
+    else if (U1 <= 256) launch_alphabeta<4, 4>(st, B, lpb, lpl, al, ll_, T, U1, a, b, ll, costs);
+    else if (U1 <= 512) launch_alphabeta<8, 2>(st, B, lpb, lpl, al, ll_, T, U1, a, b, ll, costs);
+    else launch_alphabeta<16, 1>(st, B, lpb, lpl, al, ll_, T, U1, a, b, ll, costs);
+    return TTMI_OK;
+}
+
 struct Ws {
     acc_t *alpha, *beta, *ll;
     float *lse, *lpb, *lpl;
@@ -522,6 +758,7 @@ Ws carve(void* ws, int B, int T, int U1) {
 
 }  // namespace
 
+void ttmi_rnnt_set_lattice_version(int v) { g_lattice_version = v; }
 void ttmi_probe_begin(int point, hipStream_t st);      // optim.hip: HIP-event timing probes (point 1 = loss forward, 2 = loss backward)
 void ttmi_probe_end(int point, hipStream_t st);
 
@@ -559,13 +796,10 @@ int ttmi_rnnt_loss_fwd(const void* logits, int dtype, long ldv, const int* label
                            static_cast<const bf16_t*>(logits), ldv, labels, act_lens, label_lens, B, T, U1, V, blank, vec_ok,
                            w.lse, w.lpb, w.lpl);
     TTMI_LAUNCH_CHECK("rnnt_lse_kernel");
-    if (U1 <= 64) launch_alphabeta<1, 8>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
-    else if (U1 <= 128) launch_alphabeta<2, 8>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
-    else if (U1 <= 256) launch_alphabeta<4, 4>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
-    else if (U1 <= 512) launch_alphabeta<8, 2>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
-    else launch_alphabeta<16, 1>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
+    const int lat_rc = launch_lattice(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
     ttmi_probe_end(1, st);
-    TTMI_LAUNCH_CHECK("rnnt_alphabeta_kernel");
+    if (lat_rc) return lat_rc;
+    TTMI_LAUNCH_CHECK("rnnt lattice kernel");
     return TTMI_OK;
 }
 
@@ -621,13 +855,10 @@ int ttmi_rnnt_loss_fwd_exp(const void* P, long ldv, const float* rowsum, int npa
     hipLaunchKernelGGL(rnnt_prep_exp_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, st, static_cast<const bf16_t*>(P), ldv, rowsum,
                        nparts, labels, act_lens, label_lens, B, T, U1, V, blank, w.lse, w.lpb, w.lpl, shift_cur, shift_next, emis, flag);
     TTMI_LAUNCH_CHECK("rnnt_prep_exp_kernel");
-    if (U1 <= 64) launch_alphabeta<1, 8>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
-    else if (U1 <= 128) launch_alphabeta<2, 8>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
-    else if (U1 <= 256) launch_alphabeta<4, 4>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
-    else if (U1 <= 512) launch_alphabeta<8, 2>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
-    else launch_alphabeta<16, 1>(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
+    const int lat_rc = launch_lattice(st, B, w.lpb, w.lpl, act_lens, label_lens, T, U1, w.alpha, w.beta, w.ll, costs);
     ttmi_probe_end(1, st);
-    TTMI_LAUNCH_CHECK("rnnt_alphabeta_kernel");
+    if (lat_rc) return lat_rc;
+    TTMI_LAUNCH_CHECK("rnnt lattice kernel");
     return TTMI_OK;
 }
 

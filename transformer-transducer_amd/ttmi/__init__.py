@@ -23,6 +23,10 @@ def lib():
             raise TTMIError(
                 "libttmi.so not found at %s - the HIP extension is required (no CPU/PyTorch fallback). "
                 "Build it: make -C transformer-transducer_amd/csrc" % LIB_PATH)
+        # torch ships its own libamdhip64; it must be the HIP runtime of the process BEFORE libttmi.so resolves that soname - loaded the
+        # other way round the process holds two runtimes and the library's launches see "no ROCm-capable device" (streams and device
+        # pointers belong to torch's)
+        import torch  # noqa: F401
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ttmi_last_error.restype = ctypes.c_char_p
         _lib.ttmi_rnnt_workspace_bytes.restype = ctypes.c_size_t

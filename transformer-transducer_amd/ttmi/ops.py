@@ -515,6 +515,11 @@ def adam_step(p, g, m, v, lr, betas, eps, weight_decay, step, max_norm, normsq, 
                                c_float(grad_scale), _stream()), "ttmi_adam_step")
 
 
+def adadelta_step(p, g, sq, acc, lr, rho, eps, weight_decay, max_norm, normsq, grad_scale):
+    check(lib().ttmi_adadelta_step(_p(p), _p(g), _p(sq), _p(acc), c_long(p.numel()), c_float(lr), c_float(rho), c_float(eps),
+                                   c_float(weight_decay), c_float(max_norm), _p(normsq), c_float(grad_scale), _stream()), "ttmi_adadelta_step")
+
+
 def probe_arm(slot=0):
     check(lib().ttmi_probe_arm(c_int(slot)), "ttmi_probe_arm")
 

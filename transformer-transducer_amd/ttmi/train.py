@@ -221,13 +221,15 @@ class FusedOptimizer:
     checkpoint (tt/utils.py:80-91) loads here and ours loads into torch.optim.SGD / Adam."""
 
     def __init__(self, flat, kind="sgd", lr=0.00025, momentum=0.9, nesterov=False, weight_decay=0.0, betas=(0.9, 0.98),
-                 eps=1e-8, max_grad_norm=200.0, world=1, decay_ratio=0.5):
-        if kind not in ("sgd", "adam"):
-            raise NotImplementedError("FusedOptimizer: optimizer type %r (sgd and adam are on the MI355X path)" % (kind,))
+                 eps=None, max_grad_norm=200.0, world=1, decay_ratio=0.5, rho=0.9):
+        if kind not in ("sgd", "adam", "adadelta"):
+            raise NotImplementedError("FusedOptimizer: optimizer type %r (tt/optim.py:57-84 builds sgd, adam and adadelta)" % (kind,))
+        if eps is None:
+            eps = 1e-6 if kind == "adadelta" else 1e-8        # torch.optim's defaults
         self.flat, self.kind, self.lr, self.momentum, self.nesterov = flat, kind, lr, momentum, nesterov
         self.weight_decay, self.betas, self.eps, self.max_grad_norm, self.world = weight_decay, betas, eps, max_grad_norm, world
-        self.decay_ratio = decay_ratio
-        self.state = [torch.zeros_like(flat.flat) for _ in range(2 if kind == "adam" else 1)]
+        self.decay_ratio, self.rho = decay_ratio, rho
+        self.state = [torch.zeros_like(flat.flat) for _ in range(1 if kind == "sgd" else 2)]
         self.normsq = torch.zeros(1, dtype=torch.float32, device=flat.flat.device)
         self.global_step = 1                # tt/optim.py:8
         self.current_epoch = 0
@@ -252,6 +254,9 @@ class FusedOptimizer:
         if self.kind == "adam":
             ops.adam_step(flat.flat, flat.grad, self.state[0], self.state[1], self.lr, self.betas, self.eps,
                           self.weight_decay, self.steps_taken, max_norm, self.normsq, scale)
+        elif self.kind == "adadelta":
+            ops.adadelta_step(flat.flat, flat.grad, self.state[0], self.state[1], self.lr, self.rho, self.eps, self.weight_decay,
+                              max_norm, self.normsq, scale)
         else:
             ops.sgd_step(flat.flat, flat.grad, self.state[0], self.lr, self.momentum, self.weight_decay,
                          self.nesterov, max_norm, self.normsq, scale)
@@ -282,6 +287,13 @@ class FusedOptimizer:
             state = {}
             if self.steps_taken > 0 and self.momentum != 0:
                 state = {i: {"momentum_buffer": v.clone()} for i, v in enumerate(self._views(self.state[0]))}
+        elif self.kind == "adadelta":
+            group = dict(lr=self.lr, rho=self.rho, eps=self.eps, weight_decay=self.weight_decay)
+            state = {}
+            if self.steps_taken > 0:
+                sq, acc = self._views(self.state[0]), self._views(self.state[1])
+                state = {i: {"step": torch.tensor(float(self.steps_taken)), "square_avg": sq[i].clone(), "acc_delta": acc[i].clone()}
+                         for i in range(n)}
         else:
             group = dict(lr=self.lr, betas=tuple(self.betas), eps=self.eps, weight_decay=self.weight_decay, amsgrad=False)
             state = {}
@@ -301,6 +313,8 @@ class FusedOptimizer:
         self.weight_decay = g.get("weight_decay", self.weight_decay)
         if self.kind == "sgd":
             self.momentum, self.nesterov = g.get("momentum", self.momentum), g.get("nesterov", self.nesterov)
+        elif self.kind == "adadelta":
+            self.rho, self.eps = g.get("rho", self.rho), g.get("eps", self.eps)
         else:
             self.betas, self.eps = tuple(g.get("betas", self.betas)), g.get("eps", self.eps)
         for b in self.state:
@@ -308,7 +322,7 @@ class FusedOptimizer:
         self.steps_taken = 0
         ids = g["params"]
         st = sd["state"]
-        names = ("momentum_buffer",) if self.kind == "sgd" else ("exp_avg", "exp_avg_sq")
+        names = {"sgd": ("momentum_buffer",), "adam": ("exp_avg", "exp_avg_sq"), "adadelta": ("square_avg", "acc_delta")}[self.kind]
         for k, name in enumerate(names):
             for pos, view in enumerate(self._views(self.state[k])):
                 ent = st.get(ids[pos], st.get(str(ids[pos])))
