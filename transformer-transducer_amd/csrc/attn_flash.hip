@@ -639,6 +639,12 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
     const bf16_t* dobase = p.dO + (long)b * L * p.ld_o + h * DH;
     bf16_t* ds16 = p.dS16 + (long)z * p.slab16;
     bf16_t* dg16 = p.dG16 + (long)z * p.slab16;
+    // the two bf16 slabs of this (b, h) as raw buffers: a store is [descriptor (SGPRs) + per-lane byte offset (one VGPR, fixed for the kernel)
+    // + per-row byte offset (an SGPR)] - no vector address arithmetic per element (64-bit pointer adds were a third of the kernel's VALU
+    // instructions), and a lane whose key does not exist carries an offset past the slab: the hardware drops its store, no branch
+    const __amdgpu_buffer_rsrc_t rs_ds = __builtin_amdgcn_make_buffer_rsrc(ds16, 0, (int)(p.slab16 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dg = __builtin_amdgcn_make_buffer_rsrc(dg16, 0, (int)(p.slab16 * 2), 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFF00u;
 
     const int ldp = (int)p.ldp;
     int* lo_s = reinterpret_cast<int*>(del_s + 32);                          // MK == 4: the tile's 32 (lo, hi) pairs
@@ -837,6 +843,10 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
         // dS16[i][j] at i*ldp + j;  dG16[r][c-1], (r, c) = divmod((i+1) L + j, L+1): j <= i -> (i, L-i+j), j > i -> (i+1, j-i-1), i.e.
         // element i*(ldp-1) + (j <= i ? L-1+j : ldp+j-2), nothing for j == i+1 (c = 0)
         const int ds0 = (i0 + 4 * hh) * ldp + j, dg0 = (i0 + 4 * hh) * (ldp - 1);
+        const unsigned v_ds = kvalid ? (unsigned)((4 * hh * ldp + j) * 2) : OOB;                       // lane part of a dS16 byte offset
+        const unsigned v_lo = kvalid ? (unsigned)((4 * hh * (ldp - 1) + L - 1 + j) * 2) : OOB;         // dG16, j <= i
+        const unsigned v_hi = kvalid ? (unsigned)((4 * hh * (ldp - 1) + ldp + j - 2) * 2) : OOB;       // dG16, j >= i + 2
+        const int s_ds = i0 * ldp * 2, s_dg = i0 * (ldp - 1) * 2;                                       // row part (wave-uniform)
         // pad columns [L, ldp) of both bf16 slabs feed the K loop of the dq / dE products and must be zero: the lanes whose key index falls
         // there write the zeros (no separate strided memsets over B*H*L rows)
         if (!kvalid && j < ldp && !(p.debug & 2)) {
@@ -849,7 +859,6 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
                 }
             }
         }
-        const int gsel_lo = L - 1 + j, gsel_hi = ldp + j - 2;
         // interior tiles (all 32 queries and all 128 keys of the workgroup in range, the j == i+1 diagonal not crossing the tile) take a
         // branch-free element loop; edge and diagonal tiles the general one
         const bool interior = (i0 + 32 <= L) && (jw0 > i0 + 32 || jw0 + 127 < i0 + 1) && !(p.debug & 2);
@@ -868,14 +877,14 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
                 s[r] = kvalid ? pr : 0.f;
                 dp[r] = kvalid ? ds : 0.f;
             }
-            if (kvalid) {
-                const int gsel = dg0 + (jw0 < i0 ? gsel_lo : gsel_hi);
+            {
+                const unsigned v_g = jw0 < i0 ? v_lo : v_hi;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int cq = (r & 3) + 8 * (r >> 2);
                     const bf16_t d16 = f32_to_bf16(dp[r]);
-                    ds16[(unsigned)(ds0 + cq * ldp)] = d16;
-                    dg16[(unsigned)(gsel + cq * (ldp - 1))] = d16;
+                    __builtin_amdgcn_raw_buffer_store_b16(d16, rs_ds, v_ds, s_ds + cq * ldp * 2, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16(d16, rs_dg, v_g, s_dg + cq * (ldp - 1) * 2, 0);
                 }
             }
         } else {
@@ -892,11 +901,11 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
                         pr = __expf(sc - lse_s[q]);
                         ds = pr * (dp[r] - del_s[q]) * p.scale;
                     }
-                    if (!(p.debug & 2)) {
-                        const bf16_t d16 = f32_to_bf16(ds);
-                        ds16[(unsigned)(ds0 + cq * ldp)] = d16;
-                        if (j != i + 1) dg16[(unsigned)(dg0 + cq * (ldp - 1) + (j <= i ? gsel_lo : gsel_hi))] = d16;
-                    }
+                }
+                if (!(p.debug & 2)) {
+                    const bf16_t d16 = f32_to_bf16(ds);
+                    __builtin_amdgcn_raw_buffer_store_b16(d16, rs_ds, inb ? v_ds : OOB, s_ds + cq * ldp * 2, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16(d16, rs_dg, (inb && j != i + 1) ? (j <= i ? v_lo : v_hi) : OOB, s_dg + cq * (ldp - 1) * 2, 0);
                 }
                 s[r] = pr;
                 dp[r] = ds;
