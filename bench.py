@@ -208,6 +208,7 @@ def main():
     ap.add_argument("--fused-loss", action="store_true", help="same as --loss-form fused")
     ap.add_argument("--no-two-call", action="store_true", help="skip the secondary timing of the two-call form (profiling runs: one loss form per trace)")
     ap.add_argument("--no-fp32-form", action="store_true", help="skip the secondary timing of the fp32 mode (the 1e-4 parity path)")
+    ap.add_argument("--no-graph-form", action="store_true", help="skip the secondary timing of the step replayed from a captured HIP graph (ttmi.train.GraphedStep)")
     ap.add_argument("--fp32-steps", type=int, default=5, help="steps of the fp32-mode secondary timing (at most --steps)")
     ap.add_argument("--loss-chunk", type=int, default=0, help="utterances per chunk of the fused loss (0 = default: logits chunk <= 2 GB)")
     ap.add_argument("--emit-rate", type=float, default=0.1, help="decode mode: fraction of frames that emit a symbol (blank bias is set for it)")
@@ -334,8 +335,21 @@ def main():
             form = main_form
             os.environ["TTMI_PRECISION"] = main_prec
 
-    two_call = fp32_form = None
+    two_call = fp32_form = graph_form = graph_issue = None
     fp32_steps = max(1, min(args.steps, args.fp32_steps))
+    if world == 1 and form != "two-call" and args.precision == "bf16" and not args.no_graph_form:
+        # the same step replayed from ONE captured HIP graph (ttmi.train.GraphedStep): one launch per step instead of ~560 from Python
+        from ttmi.train import GraphedStep
+        gstep = GraphedStep(lambda: step(False).detach(), device=dev, warmup=2, exp_state=model.joint.exp_shift_state(dev),
+                            on_replay=(lambda: setattr(opt, "global_step", opt.global_step + 1),))
+        graph_form = timed_region(lambda timed, i: gstep(), args.steps, 1, world)[0]
+        fence(world)
+        t1 = time.perf_counter()
+        gstep()
+        graph_issue = time.perf_counter() - t1
+        fence(world)
+        ops.set_dropout_salt(None)
+        del gstep
     if form != "two-call" and not args.no_two_call:
         # the reference's own call sequence (train.py:51-53) beside the fused form
         two_call = secondary("two-call", args.precision, args.steps, max(1, args.warmup))
@@ -469,6 +483,12 @@ def main():
         if two_call is not None:
             out["two_call_form"] = {"ms_per_step": round(1e3 * two_call / args.steps, 3), "value": round(world * B * args.steps / two_call, 3), "unit": "utt/s",
                                     "note": "the same %d steps with train.py's own call sequence (model(inputs, targets) + RNNTLoss), timed right after the main region" % args.steps}
+        if graph_form is not None:
+            out["graph_replay_form"] = {"ms_per_step": round(1e3 * graph_form / args.steps, 3), "value": round(world * B * args.steps / graph_form, 3), "unit": "utt/s",
+                                        "host_issue_ms_per_step": round(1e3 * graph_issue, 3), "host_launches_per_step": 1,
+                                        "note": "the same %d steps (same loss form, dropout with fresh masks per step, clip + SGD) replayed from one captured HIP "
+                                                "graph, ttmi.train.GraphedStep, timed right after the main region; the headline stays the eager step because "
+                                                "its kernels are timed live by HIP-event probes, which a replayed graph cannot carry" % args.steps}
         if fp32_form is not None:
             out["fp32_form"] = {"ms_per_step": round(1e3 * fp32_form / fp32_steps, 3), "value": round(world * B * fp32_steps / fp32_form, 3), "unit": "utt/s",
                                 "dtype": "f32", "steps": fp32_steps,

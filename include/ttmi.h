@@ -199,6 +199,11 @@ int ttmi_adam_step(float* p, const float* g, float* m, float* v, long n, float l
 int ttmi_adadelta_step(float* p, const float* g, float* square_avg, float* acc_delta, long n, float lr, float rho, float eps,
                        float weight_decay, float max_norm, const float* normsq, float grad_scale, void* stream);
 
+/* Device word (nullable) mixed into every dropout seed when a kernel starts.  Seeds are drawn on the host per sub-layer call; in a step that
+ * is captured as a HIP graph they are baked into the kernel arguments, so the caller bumps this word on the device before each replay
+ * (ttmi.train.GraphedStep) and every step still draws fresh masks.  Forward and backward of one step must see the same value. */
+int ttmi_set_dropout_salt(const unsigned* salt);
+
 /* ---- bring-up / measurement helpers ------------------------------------------------------------------------------
  * generic MFMA GEMM (every layout / dtype / epilogue; flags = GemmFlags of csrc/gemm.h) and the two throughput
  * kernels; HIP-event probes recorded on the launch stream at five points (0 = joint vocabulary projection, 1 = ttmi_rnnt_loss_fwd's

@@ -57,7 +57,17 @@ __device__ __forceinline__ float wave_max(float v) {
 struct DropSpec {
     float p = 0.f;            // drop probability (0 = disabled)
     unsigned seed = 0;
+    // optional device word mixed into the seed when the kernel starts (ttmi_set_dropout_salt): a training step captured in a HIP graph has
+    // its host-drawn seeds baked into the kernel arguments; the caller bumps this word on the device before every replay, so every step
+    // still draws new masks (forward and backward of one step read the same value)
+    const unsigned* salt = nullptr;
 };
+// call ONCE at kernel entry (one scalar load), then use the result with drop_mult
+__device__ __forceinline__ DropSpec drop_live(DropSpec d) {
+    if (d.p > 0.f && d.salt) d.seed ^= *d.salt * 0x9E3779B1u;
+    d.salt = nullptr;
+    return d;
+}
 __host__ __device__ __forceinline__ unsigned ttmi_hash32(unsigned seed, unsigned long long idx) {
     unsigned x = (unsigned)idx * 0x9E3779B1u ^ seed ^ ((unsigned)(idx >> 32) * 0x7F4A7C15u);
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;

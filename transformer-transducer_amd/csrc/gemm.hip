@@ -157,7 +157,9 @@ struct Stager {
 };
 
 template <typename SA, typename SB, typename TC, bool AK, bool BKM, bool BF16C>
-__global__ __launch_bounds__(NT) void gemm_kernel(const KParams p) {
+__global__ __launch_bounds__(NT) void gemm_kernel(const KParams p_) {
+    KParams p = p_;
+    p.drop = drop_live(p.drop);
     using C = Cfg<BF16C>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // layout: [buf0: A | B][buf1: A | B]
@@ -293,7 +295,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const KParams p) {
 constexpr int SK_T = 32, SK_PITCH = 33;
 
 template <bool BKM>
-__global__ __launch_bounds__(NT) void gemm_skinny_f32_kernel(const KParams p) {
+__global__ __launch_bounds__(NT) void gemm_skinny_f32_kernel(const KParams p_) {
+    KParams p = p_;
+    p.drop = drop_live(p.drop);
     __shared__ float red[4][SK_T][SK_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, g = lane >> 5;

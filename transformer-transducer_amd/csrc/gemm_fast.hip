@@ -158,6 +158,7 @@ __global__ __launch_bounds__(NTH, NBUF == 1 ? 4 : 2) void gemm_nt_bf16_kernel(co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     FP p = p_;
+    p.drop = drop_live(p.drop);
     int tm, tn;
     tile_of(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
     const int bm = tm * TM, bn = tn * TN_;
@@ -501,7 +502,9 @@ __global__ __launch_bounds__(NTH, NBUF == 1 ? 4 : 2) void gemm_tn_bf16_kernel(co
 constexpr int T6 = 256, NTH6 = 512, STAGE6 = 2 * 256 * 64 * 2;   // 64 KiB per stage (A 32 KiB | B 32 KiB)
 
 template <typename TC>
-__global__ __launch_bounds__(NTH6, 1) void gemm_nt_bf16_v6_kernel(const FP p) {
+__global__ __launch_bounds__(NTH6, 1) void gemm_nt_bf16_v6_kernel(const FP p_) {
+    FP p = p_;
+    p.drop = drop_live(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;                       // 4 x 2 waves, wave tile 64 (M) x 128 (N)
@@ -750,7 +753,9 @@ constexpr int LDS8 = 2 * BUF8 + 8 * 4096;
 // carry no residual / ReLU / dropout code and test nothing per store, which
 // costs the main loop registers in the general instance
 template <typename TC, int LEAN = 0>
-__global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) {
+__global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p_) {
+    FP p = p_;
+    p.drop = drop_live(p.drop);
     constexpr bool MASKED = LEAN == 2 || LEAN == 4;       // epilogues that read the mask operand (same layout as the output)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1122,7 +1127,9 @@ constexpr int T10 = 256, NTH10 = 256, KS10 = 32, HALF10 = 256 * KS10 * 2, STG10 
 constexpr int NST10 = 5, LDS10 = NST10 * STG10;      // the epilogue's images live in stage 4 (free between tiles)
 
 template <typename TC, int DBG = 0>
-__global__ __launch_bounds__(NTH10, 1) void gemm_nt_bf16_v10_kernel(const FP p) {
+__global__ __launch_bounds__(NTH10, 1) void gemm_nt_bf16_v10_kernel(const FP p_) {
+    FP p = p_;
+    p.drop = drop_live(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
@@ -1313,7 +1320,9 @@ constexpr int T9M = 256, T9N = 128, STG9 = (T9M + T9N) * 64 * 2, LDS9 = 3 * STG9
 // LEAN (as in v8): 1 = plain or bias-only epilogue (either output type), 2 = mask-only (bf16 output), 3 = f32 output + residual addend
 // (+ bias); launcher-checked alignment
 template <typename TC, int LEAN = 0>
-__global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p) {
+__global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p_) {
+    FP p = p_;
+    p.drop = drop_live(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave & 3, wc = wave >> 2;               // waves w and w+4 (SIMD partners) differ in the column half

@@ -62,6 +62,7 @@ int wgrad(const float* dY, const float* X, float* gW, int M, int N, int K, long 
 // ---- intra-call concurrency: weight-gradient GEMMs feed nothing downstream inside a backward call, so they are forked onto a
 // library-owned side stream (one per caller stream) and joined before the call returns (scratch buffers they read are reused by
 // the next call).  ttmi_set_option(3, 0) disables it.
+const unsigned* g_drop_salt = nullptr;     // ttmi_set_dropout_salt: device word mixed into every dropout seed at kernel start (graph replays)
 int g_fork_wgrad = 1;
 int g_gemm_slab = 0;            // ttmi_set_option(5, 1): position-term slab by the batched GEMM (A/B measurements)
 struct SideCtx {
@@ -101,6 +102,10 @@ SideCtx* side_for(hipStream_t main) {
 // so far), or `main` itself when forking is disabled / unavailable
 hipStream_t fork_stream(hipStream_t main) {
     if (!g_fork_wgrad) return main;
+    // no forks inside a stream capture: a fork off the label encoder's side stream (itself forked from the capturing stream) crashes
+    // hipStreamEndCapture on ROCm 7.2 (tools/debug/graph_bisect.py); what the forks overlap in a captured step are a few small GEMMs
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(main, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return main;
     SideCtx* c = side_for(main);
     if (!c) return main;
     hipEvent_t e = c->ev[c->next];
@@ -404,7 +409,7 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
         CK(ttmi_launch_gemm(mk(static_cast<float*>(c.O), o_w, w.a, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, NT_, prec), st));
     }
     DropSpec rd;                                            // self.drop(attn_out), tt/transformer.py:173
-    rd.p = p_drop; rd.seed = seed ^ 0xA1u;
+    rd.p = p_drop; rd.seed = seed ^ 0xA1u; rd.salt = g_drop_salt;
     CK(ln_fwd(x, w.a, ln_g, ln_b, a.BL, d, 1e-5f, c.s1, y, c.mean, c.rstd, st, nullptr, rd));
     return TTMI_OK;
 }
@@ -432,7 +437,7 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
     // 2. gWo += da^T O ; 3. dO = da Wo, with da = dres * dropout mask of the forward (dres itself stays the residual grad);
     //    the bf16 pipeline gets da from the same pass
     DropSpec rd;
-    rd.p = p_drop; rd.seed = seed ^ 0xA1u;
+    rd.p = p_drop; rd.seed = seed ^ 0xA1u; rd.salt = g_drop_salt;
     CK(ln_bwd(dy, c.s1, c.mean, c.rstd, ln_g, nullptr, a.BL, d, dx, g_ln_g, g_ln_b, st, DropSpec(), fast ? w.dres16 : nullptr, rd, nullptr));
     const float* da = dx;
     if (!fast && p_drop > 0.f) {
@@ -654,9 +659,9 @@ int ttmi_ffn_fwd(const float* y, const float* w1, const float* b1, const float* 
     TTMI_REQUIRE(y && w1 && b1 && w2 && b2 && ln_g && ln_b && ctx && ws && z, "ffn_fwd: null pointer");
     TTMI_REQUIRE(p_drop >= 0.f && p_drop < 1.f && p_layer >= 0.f && p_layer < 1.f, "ffn_fwd: dropout probability outside [0,1)");
     DropSpec d_in, d_out, d_layer;          // CoreNet.2, CoreNet.4 (tt/transformer.py:47,49) and the layer's own dropout (:196)
-    d_in.p = p_drop; d_in.seed = seed ^ 0xB2u;
-    d_out.p = p_drop; d_out.seed = seed ^ 0xC3u;
-    d_layer.p = p_layer; d_layer.seed = seed ^ 0xD4u;
+    d_in.p = p_drop; d_in.seed = seed ^ 0xB2u; d_in.salt = g_drop_salt;
+    d_out.p = p_drop; d_out.seed = seed ^ 0xC3u; d_out.salt = g_drop_salt;
+    d_layer.p = p_layer; d_layer.seed = seed ^ 0xD4u; d_layer.salt = g_drop_salt;
     TTMI_REQUIRE(rows > 0 && rows < (1L << 31) && d > 0 && Di > 0, "ffn_fwd: bad dims");
     TTMI_REQUIRE(((reinterpret_cast<uintptr_t>(ctx) | reinterpret_cast<uintptr_t>(ws)) & 255) == 0, "ffn_fwd: ctx/ws must be 256-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -703,8 +708,8 @@ static int ffn_bwd_impl(const float* dz, const float* y, const float* w1, const 
     FfnCtx c(bc, rows, d, Di, fast);
     FfnWs w(bw, rows, d, Di, fast, keep);
     DropSpec d_out, d_layer;
-    d_out.p = p_drop; d_out.seed = seed ^ 0xC3u;
-    d_layer.p = p_layer; d_layer.seed = seed ^ 0xD4u;
+    d_out.p = p_drop; d_out.seed = seed ^ 0xC3u; d_out.salt = g_drop_salt;
+    d_layer.p = p_layer; d_layer.seed = seed ^ 0xD4u; d_layer.salt = g_drop_salt;
     const float inv_keep = 1.f / (1.f - p_drop);
     // df = dres * mask(CoreNet.4); dres itself remains the residual-branch gradient.  bf16 pipeline: df (bf16) and g_b2 = its
     // column sums come out of the LayerNorm-backward pass itself
@@ -1013,6 +1018,14 @@ int ttmi_stream_reserve_cus(void* stream, int n) {
     return TTMI_OK;
 }
 
+// Device word (nullable) that every dropout site mixes into its seed when its kernel starts: seeds are drawn on the host per call and, in a
+// step captured as a HIP graph, baked into the kernel arguments; bumping this word on the device before each replay gives every step
+// new masks.  Forward and backward of one step must see the same value.  Process-wide; nullptr (default) = seeds used as passed.
+int ttmi_set_dropout_salt(const unsigned* salt) {
+    g_drop_salt = salt;
+    return TTMI_OK;
+}
+
 // process-wide switches for A/B measurements.  key 0: 1 = disable the fused attention kernels (bf16 pipeline only);
 // key 1: throughput-GEMM generation (see gemm_fast.hip); key 2: flash-kernel timing switches; key 3: 0 = no wgrad fork
 int ttmi_set_option(int key, int value) {
@@ -1035,7 +1048,7 @@ int ttmi_set_option(int key, int value) {
 // layer out ^0xD4; element index = row * width + column of the masked [rows, width] tensor).
 int ttmi_dropout_apply(const float* in, long n, float p, unsigned seed, float* out, void* stream) {
     DropSpec ds;
-    ds.p = p; ds.seed = seed;
+    ds.p = p; ds.seed = seed; ds.salt = g_drop_salt;
     return dropout_apply(in, n, ds, out, nullptr, static_cast<hipStream_t>(stream));
 }
 

@@ -21,6 +21,8 @@ __global__ __launch_bounds__(WPB * 64) void ln_fwd_kernel(const float* __restric
                                                           int d, float eps, float* __restrict__ s_out, float* __restrict__ y,
                                                           float* __restrict__ mean_o, float* __restrict__ rstd_o, int vec,
                                                           bf16_t* __restrict__ y16, DropSpec rdrop, DropSpec odrop) {
+    rdrop = drop_live(rdrop);
+    odrop = drop_live(odrop);
     const long r = wave_row();
     if (r >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -106,6 +108,7 @@ __global__ __launch_bounds__(WPB * 64) void ln_bwd_dx_kernel(const float* __rest
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const float* __restrict__ g, const float* __restrict__ dadd,
                                                              long rows, int d, float* __restrict__ dx, DropSpec ddrop) {
+    ddrop = drop_live(ddrop);
     const long r = wave_row();
     if (r >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -136,6 +139,7 @@ __global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restr
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             long rows, int d, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, DropSpec ddrop) {
+    ddrop = drop_live(ddrop);
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= d) return;
     const long r0 = (long)blockIdx.y * LNP_ROWS;
@@ -160,6 +164,8 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restri
                                                            int d, float* __restrict__ dx, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, DropSpec ddrop, bf16_t* __restrict__ dx16,
                                                            DropSpec xdrop, float* __restrict__ dx16_colsum) {
+    ddrop = drop_live(ddrop);
+    xdrop = drop_live(xdrop);
     // optional second output for the bf16 pipeline: dx16 = bf16(dx * dropout(xdrop)) (the masked gradient the following
     // GEMMs consume) and its column sums (the bias gradient of the Linear in front of the dropout)
     __shared__ float red[3][4][KV * 256];
@@ -695,6 +701,7 @@ __global__ void convert_bf16_kernel(const float* __restrict__ src, bf16_t* __res
 
 __global__ void dropout_apply_kernel(const float* __restrict__ in, long n, DropSpec ds, float* __restrict__ o32,
                                      bf16_t* __restrict__ o16) {
+    ds = drop_live(ds);
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float v = in[i] * drop_mult(ds, (unsigned long long)i);

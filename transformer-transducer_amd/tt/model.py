@@ -119,7 +119,8 @@ class _JointLossFn(torch.autograd.Function):
         J, V = wf.shape[0], wp.shape[0]
         st = exp_state
         exp_ran = seeded = False
-        if st is not None:
+        capturing = enc.is_cuda and torch.cuda.is_current_stream_capturing()      # (ttmi.train.GraphedStep looks at the flag between replays)
+        if st is not None and not capturing:
             st.poll()
         for c0 in range(0, B, chunk):
             c1 = min(B, c0 + chunk)
@@ -149,7 +150,7 @@ class _JointLossFn(torch.autograd.Function):
             st.cur.copy_(st.nxt)
             st.nxt.zero_()
             st.valid = True
-            if exp_ran:
+            if exp_ran and not capturing:
                 st.watch()
         if need:
             ctx.save_for_backward(denc, ddec, *g.values())
@@ -342,11 +343,14 @@ class Transducer(nn.Module):
             # `targets` lives in the main stream's pool but is read by side-stream kernels - in backward as late as the embedding
             # gradient, the label encoder's last launch: without this its block could be handed to a main-stream allocation (and
             # overwritten) as soon as autograd drops the graph, while that launch is still queued
-            targets.record_stream(side)
+            capturing = torch.cuda.is_current_stream_capturing()    # (a captured step's tensors live in the graph's own pool for its lifetime)
+            if not capturing:
+                targets.record_stream(side)
             with torch.cuda.stream(side):
                 dec_state = self.decoder(targets, MaskSpec(1))
             main.wait_stream(side)
-            dec_state.record_stream(main)
+            if not capturing:
+                dec_state.record_stream(main)
         else:
             enc_state = self.encoder(inputs, audio_mask)
             dec_state = self.decoder(targets, MaskSpec(1))                  # == look_ahead_mask(targets)[:, :, None]

@@ -558,6 +558,19 @@ def dropout_multipliers(n, p, seed, device):
     return out
 
 
+_salt_keep = [None]
+
+
+def set_dropout_salt(t):
+    """t: int32 / uint32 device tensor [1] (or None): a word every dropout site mixes into its seed at kernel start; bump it on the device
+    between steps when the step is replayed from a captured graph (ttmi.train.GraphedStep)"""
+    if t is not None:
+        _need_cuda(t)
+        assert t.numel() == 1 and t.element_size() == 4
+    _salt_keep[0] = t                       # the library holds the raw pointer: keep the tensor alive
+    check(lib().ttmi_set_dropout_salt(_p(t)), "ttmi_set_dropout_salt")
+
+
 def set_option(key, value):
     """process-wide A/B switches (key 0: 1 disables the fused attention kernels of the bf16 pipeline)"""
     check(lib().ttmi_set_option(c_int(key), c_int(value)), "ttmi_set_option")

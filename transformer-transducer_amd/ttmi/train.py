@@ -337,6 +337,67 @@ class FusedOptimizer:
             self.steps_taken = 1            # SGD: torch seeds the momentum buffer with the first gradient; ours has the same value after step 1
 
 
+class GraphedStep:
+    """A whole training step - forward, loss, backward, clip + optimiser, shadow refresh - captured ONCE into a HIP graph and replayed with
+    one launch per step: no Python, no ~560 kernel launches on the host (8 ranks of a data-parallel job share one host).
+
+        step = GraphedStep(lambda: one_step(static_inputs...), exp_state=model.joint.exp_shift_state(dev))
+        for batch in loader:  static_inputs.copy_(batch); loss = step()
+
+    `step_fn` must be free of host synchronisation and must read its batch from tensors that stay at the same address.  What makes the
+    step replayable here: dropout seeds are drawn on the host per call and would be frozen in the graph, so every dropout site mixes in a
+    device word (`salt`, ttmi_set_dropout_salt) that the graph bumps before anything else - each replay draws new masks, forward and
+    backward of one replay agree; the exp-domain loss form's range check (tt.model._ExpShift) is looked at between replays: a raised
+    flag makes the next call run eagerly (the plain form re-seeds the shift) and capture again.  Host-side counters that a captured call
+    would have advanced (FusedOptimizer.global_step, Adam's bias-correction step) are advanced per replay by `on_replay` callbacks;
+    Adam's bias correction is computed on the host per step and is therefore NOT replayable - use SGD / Adadelta, or eager steps."""
+
+    def __init__(self, step_fn, device=None, warmup=3, exp_state=None, on_replay=()):
+        self.step_fn, self.exp_state, self.on_replay = step_fn, exp_state, tuple(on_replay)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.salt = torch.zeros(1, dtype=torch.int32, device=self.device)
+        ops.set_dropout_salt(self.salt)
+        self.stream = torch.cuda.Stream(self.device)
+        self.graph, self.out, self.captures = None, None, 0
+        self._warm(warmup)
+        self._capture()
+
+    def _warm(self, n):
+        """eager steps on the capture stream: scratch arenas, fork streams, kernel attributes, the exp form's shift"""
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            for _ in range(n):
+                self.salt.add_(1)
+                self.out = self.step_fn()
+        cur.wait_stream(self.stream)
+        torch.cuda.synchronize(self.device)
+
+    def _capture(self):
+        if self.exp_state is not None and not self.exp_state.valid:
+            raise RuntimeError("GraphedStep: the exp-domain loss form has no valid shift after the warm-up steps")
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.stream):
+            self.salt.add_(1)
+            self.out = self.step_fn()
+        self.captures += 1
+
+    def __call__(self):
+        st = self.exp_state
+        if st is not None:
+            st.poll()
+            if not st.valid:                # a flagged replay: one eager step (plain form, re-seeds the shift), one more in the exp form, new graph
+                self.graph = None
+                self._warm(2)
+                self._capture()
+        self.graph.replay()
+        for cb in self.on_replay:
+            cb()
+        if st is not None:
+            st.watch()
+        return self.out
+
+
 def save_checkpoint(model, optimizer, path, multi_gpu=False):
     """the reference's `.chkpt` layout (tt/utils.py:80-91): per-module state_dicts (un-prefixed keys), the optimizer's state_dict,
     'epoch' and 'step'.  Rank 0 writes it in data-parallel runs."""
