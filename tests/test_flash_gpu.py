@@ -215,3 +215,56 @@ def test_streaming_config_chunk_mask_is_cached_and_equals_the_tensor_mask(monkey
     y1 = model.encoder(x, a)
     y2 = model.encoder(x, chunk_mask(x, 16, 64)[:, :, None])
     assert torch.equal(y1, y2)
+
+
+@pytest.mark.parametrize("H,L,K,mk,B", [(2, 70, 128, "none", 2), (8, 500, 410, "none", 2), (1, 129, 16, "band", 3), (2, 512, 64, "causal", 1), (1, 1, 8, "none", 2),
+                                        (2, 33, 64, "chunk", 2)])
+def test_one_pass_position_gradients_vs_the_gemm_launches(H, L, K, mk, B, monkeypatch):
+    """attn_dqde_kernel (one workgroup per (b, h): dq = dS k + dG E, dE, dc and d r_w_bias from ONE pass over the two bf16 slabs of the
+    attention backward kernel, k / E slices resident as MFMA fragments, dE rows resident as accumulators) against the round-2 launches
+    (two transposes, the dual-product dq GEMM, the dE GEMM): the same bf16 operands summed in another order - dq is rounded to bf16 once
+    in both - so dx and every gradient agree to bf16 rounding; both sit at the same distance from the float64 oracle."""
+    from tt.encoder import BaseEncoder
+    from tt.transformer import as_mask_spec
+    from ttmi import ops
+    from ttmi.ops import MaskSpec
+    monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    Dh = 64
+    d = H * Dh
+    torch.manual_seed(3 * L + H)
+    layer = BaseEncoder(k_len=K, n_head=H, d_model=d, d_head=Dh, d_inner=64, dropout=0.0).cuda().eval()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, L, d, generator=g).cuda()
+    cot = torch.randn(B, L, d, generator=g).cuda()
+    omask = None
+    if mk == "none":
+        mask = MaskSpec(0)
+    elif mk == "causal":
+        mask, omask = MaskSpec(1), O.look_ahead_mask(L)[:, :, None]
+    elif mk == "band":
+        mask, omask = MaskSpec(2, left=20, right=3), O.context_mask(L, 20, 3)[:, :, None]
+    else:
+        m = O.chunk_mask(L, 16, 32)
+        mask, omask = as_mask_spec(torch.tensor(m != 0).cuda()[:, :, None], B, L), m[:, :, None]
+    y1, dx1, g1 = _run(layer, x, cot, mask)
+    ops.set_option(11, 1)
+    try:
+        y0, dx0, g0 = _run(layer, x, cot, mask)
+    finally:
+        ops.set_option(11, 0)
+    assert torch.equal(y1, y0)
+    sd = {"encoder.layers.0." + k: v.detach().cpu().numpy().astype(np.float64) for k, v in layer.state_dict().items()}
+    prm = O.layer_params(sd, "encoder.", 0)
+    want, cache = O.layer_fwd(x.cpu().numpy().astype(np.float64), prm, omask)
+    dxo, go = O.layer_bwd(cot.cpu().numpy().astype(np.float64), cache, prm)
+    names = {v: k for k, v in O._LAYER_KEYS.items()}
+    worst = {}
+    for n in g1:
+        e10 = rel_err(g1[n].cpu().numpy(), g0[n].cpu().numpy())
+        e1o, e0o = rel_err(g1[n].cpu().numpy(), go[names[n]]), rel_err(g0[n].cpu().numpy(), go[names[n]])
+        worst[n] = (e10, e1o, e0o)
+        assert e10 < 1e-2 and e1o < max(1.3 * e0o, 5e-3), (n, e10, e1o, e0o)
+    e_dx = rel_err(dx1.cpu().numpy(), dx0.cpu().numpy())
+    assert e_dx < 1e-2 and rel_err(dx1.cpu().numpy(), dxo) < max(1.3 * rel_err(dx0.cpu().numpy(), dxo), 5e-3)
+    pos = [n for n in g1 if n in ("r_emb", "r_bias", "r_w_bias")]
+    print("one pass vs GEMM launches (H=%d L=%d %s): dx %.2e; " % (H, L, mk, e_dx) + ", ".join("%s %.1e (oracle %.1e / %.1e)" % ((n,) + worst[n]) for n in pos))

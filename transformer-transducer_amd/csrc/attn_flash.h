@@ -46,6 +46,12 @@ struct FlashParams {
 };
 
 bool flash_supported(int Dh, long ld_qu, long ld_kv, long ld_o);
+// dq (bf16, content + position), dE, dc and d r_w_bias from the two bf16 dS slabs of flash_attn_bwd in one pass (one workgroup per (b, h),
+// Dh = 64, ldp <= 512): see attn_dqde_kernel.  dE / dcT / gu are accumulated into (atomics); dq16 rows are overwritten.
+bool attn_dqde_supported(int Dh, int L, long ldp);
+int attn_dqde(const bf16_t* dS16, const bf16_t* dG16, long slab16, long ldp, const bf16_t* k, long ld_kv, const bf16_t* e16, long ld_e,
+              const bf16_t* qp, long ld_qp, bf16_t* dq16, long ld_dq, float* dE, long ld_de, float* dcT, float* gu, int B, int L, int H,
+              hipStream_t st);
 int flash_attn_fwd(const FlashParams& p, hipStream_t st);
 int flash_attn_bwd(const FlashParams& p, hipStream_t st);
 // G slab of the position term (q E^T + c, column 0 zero, row pitch L+1, bf16) for all (b, h): q rows (b, i) at q[(b*L+i)*ld_q + h*Dh],

@@ -15,6 +15,7 @@
 // 4 waves per workgroup; a wave owns 32 queries (fwd) / 32 keys (bwd); K/V (fwd) or (q+u)/dO (bwd) tiles are staged in
 // LDS with the row XOR swizzle chunk ^= (row >> 1) & (chunks-1).  Head dims 32 and 64.
 #include "attn_flash.h"
+#include <stdlib.h>
 
 void ttmi_probe_begin(int slot, hipStream_t st);
 void ttmi_probe_end(int slot, hipStream_t st);
@@ -1210,6 +1211,214 @@ __global__ __launch_bounds__(256) void flash_delta_kernel(const bf16_t* __restri
 
 bool flash_supported(int Dh, long ld_qu, long ld_kv, long ld_o) {
     return (Dh == 32 || Dh == 64) && ld_qu % 8 == 0 && ld_kv % 8 == 0 && ld_o % 8 == 0;
+}
+
+// ------------------------------------------------------------------ dq, dE, dc, d r_w_bias from the two dS slabs in ONE pass
+// The attention backward kernel leaves dS twice ([i][j] and the shifted [r][c-1] = dG).  Round 2 consumed them with three launches of the
+// generic 128x128 GEMMs - dq = dS k + dG E (both slabs read), dE = sum_b dG^T q (dG read again), plus two transposes that made k and E
+// K-major - at 3 and 1.7 TB/s: N = Dh = 64 fills half a tile and K = L = 500 is eight K-steps.  This kernel is shaped for the operands:
+// one workgroup per (b, h), 8 waves; wave w owns columns [64 w, 64 w + 64) of both slabs - keys of dS, table rows of dG - and keeps
+//   * its 64 x 64 slices of k and of the effective table E as MFMA B fragments in registers for the whole kernel (no transposes),
+//   * its 64 rows of dE (and of dc) as MFMA accumulators for the whole kernel (one atomic flush per (b, h) at the end).
+// The slabs stream through ONCE, 32 rows at a time, straight into A fragments (16-byte loads; the loads of block n + 1 are issued before
+// the cross-wave reduction and the dE products of block n).  Per block: dq partial = dS k (its column sums = d r_w_bias) + dG E, summed
+// over the 8 waves in a fixed order through LDS and stored as bf16 rows; dE += dG^T q and dc += dG^T 1 with dG^T / q^T fragments read
+// transposed (ds_read_b64_tr_b16) from a wave-private image of the block.  L <= 512 (8 waves x 64 columns); longer sequences keep the GEMMs.
+struct PosGradParams {
+    const bf16_t* dS16; const bf16_t* dG16; long slab16; int ldp;
+    const bf16_t* k; long ld_kv;        // key rows: k[(b L + j) ld_kv + h 64 + d]
+    const bf16_t* e16; long ld_e;       // effective table rows: e16[p ld_e + h 64 + d]
+    const bf16_t* qp; long ld_qp;       // plain q rows
+    bf16_t* dq16; long ld_dq;           // out: dq16[(b L + i) ld_dq + h 64 + d]
+    float* dE; long ld_de;              // += : dE[p ld_de + h 64 + d]
+    float* dcT;                         // += : dcT[h L + p]
+    float* gu;                          // += : gu[h 64 + d]  (d r_w_bias)
+    int B, L, H;
+    int dbg;                            // timing experiments (TTMI_PG_DEBUG): 1 no final atomics, 2 no table loads, 4 no main loop, 8 no slab loads
+};
+constexpr int PG_TILE = 32 * 64 * 2;
+constexpr int PG_LDS = 8 * 32 * 64 * 4 + 2 * 8 * PG_TILE + 2 * PG_TILE;        // partial slots | per-wave dS and dG images | two q tiles
+__global__ __launch_bounds__(512, 1) void attn_dqde_kernel(const PosGradParams p) {
+    using T = Tile<64>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* slots = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hh = lane >> 5, row = lane & 31;
+    char* stile = smem + 8 * 32 * 64 * 4 + wave * PG_TILE;                  // this wave's 32 x 64 block of dS ...
+    char* gtile = smem + 8 * 32 * 64 * 4 + 8 * PG_TILE + wave * PG_TILE;     // ... and of dG (swizzled Tile<64> images)
+    char* qtiles = smem + 8 * 32 * 64 * 4 + 16 * PG_TILE;
+    const int z = blockIdx.x, b = z / p.H, h = z % p.H, L = p.L, ldp = p.ldp;
+    const int c0 = 64 * wave;
+    const bf16_t* ds = p.dS16 + (long)z * p.slab16;
+    const bf16_t* dg = p.dG16 + (long)z * p.slab16;
+    const bf16_t* kb = p.k + (long)b * L * p.ld_kv + h * 64;
+    const bf16_t* eb = p.e16 + h * 64;
+    const bf16_t* qb = p.qp + (long)b * L * p.ld_qp + h * 64;
+    // resident B fragments: B[k = column c][n = d], lane n = 32 nt + row, k chunk = 16 ks + 8 hh + (0..7)
+    bf16x8 bk[2][4], be[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = c0 + 16 * ks + 8 * hh + j, cc = min(c, L - 1), d = 32 * nt + row;
+                const bf16_t kv = (p.dbg & 2) ? (bf16_t)0x3c00 : kb[(long)cc * p.ld_kv + d], ev = (p.dbg & 2) ? (bf16_t)0x3c00 : eb[(long)cc * p.ld_e + d];
+                bk[nt][ks][j] = __builtin_bit_cast(__bf16, (unsigned short)(c < L ? kv : (bf16_t)0));
+                be[nt][ks][j] = __builtin_bit_cast(__bf16, (unsigned short)(c < L ? ev : (bf16_t)0));
+            }
+    f32x16 acc_e[2][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_e[0][0][r] = acc_e[0][1][r] = acc_e[1][0][r] = acc_e[1][1][r] = 0.f;
+    float dc_run = 0.f;                            // lane = table row c0 + lane: sum of its dG column over all rows
+    float gu_run[2] = {0.f, 0.f};
+    // slab loads: 8 lanes cover one row's 128 bytes (this wave's 64 columns), a wave-instruction 8 whole row pieces; the chunk a lane fetches
+    // is the one that belongs at its position of the swizzled image, so the registers go to LDS as they are
+    const int lrow = lane >> 3, lpos = lane & 7;
+    u32x4_t rs[4], rg[4];
+    auto load_block = [&](int i0) {
+        if (p.dbg & 8) return;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int tr = 8 * q4 + lrow, r = i0 + tr;
+            const int col = c0 + 8 * (lpos ^ ((tr >> 1) & 7));
+            const bool ok = r < L && col + 8 <= ldp;
+            const long o = (long)min(r, L - 1) * ldp + min(col, ldp - 8);
+            const u32x4_t vs = *reinterpret_cast<const u32x4_t*>(ds + o), vg = *reinterpret_cast<const u32x4_t*>(dg + o);
+            rs[q4] = ok ? vs : u32x4_t{0u, 0u, 0u, 0u};
+            rg[q4] = ok ? vg : u32x4_t{0u, 0u, 0u, 0u};
+        }
+    };
+    auto stage_q = [&](int i0, int buf) {          // 32 plain q rows -> swizzled tile (rows past L: the last row; their dG rows are zero)
+        if (tid < 32 * T::NCH) {
+            const int rr = tid / T::NCH, ch = tid % T::NCH;
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(qb + (long)min(i0 + rr, L - 1) * p.ld_qp + ch * 8);
+            *reinterpret_cast<u32x4_t*>(qtiles + buf * PG_TILE + T::off(rr, ch)) = v;
+        }
+    };
+    load_block(0);
+    stage_q(0, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int i0 = 0; i0 < ((p.dbg & 4) ? 0 : L); i0 += 32) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            *reinterpret_cast<u32x4_t*>(stile + (8 * q4 + lrow) * 128 + lpos * 16) = rs[q4];
+            *reinterpret_cast<u32x4_t*>(gtile + (8 * q4 + lrow) * 128 + lpos * 16) = rg[q4];
+        }
+        if (i0 + 32 < L) load_block(i0 + 32);        // the next block flies under this block's products, reduction and dE work
+        f32x16 acc_q[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_q[0][r] = acc_q[1][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {             // content: dS k
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(stile + T::off(row, 2 * ks + hh));
+            acc_q[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bk[0][ks], acc_q[0], 0, 0, 0);
+            acc_q[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bk[1][ks], acc_q[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {             // column sums of the content part: d r_w_bias
+            float cs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cs += acc_q[nt][r];
+            gu_run[nt] += cs;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {             // position: dG E
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(gtile + T::off(row, 2 * ks + hh));
+            acc_q[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, be[0][ks], acc_q[0], 0, 0, 0);
+            acc_q[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, be[1][ks], acc_q[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            float* sl = slots + wave * 2048 + 32 * nt + row;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sl[((r & 3) + 8 * (r >> 2) + 4 * hh) * 64] = acc_q[nt][r];
+        }
+        __syncthreads();
+        {
+            const int e4 = tid * 4, m = e4 >> 6, n0 = e4 & 63;
+            float4 sum = *reinterpret_cast<const float4*>(slots + e4);
+#pragma unroll
+            for (int w = 1; w < 8; ++w) {
+                const float4 v = *reinterpret_cast<const float4*>(slots + w * 2048 + e4);
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
+            if (i0 + m < L) {
+                uint2 o;
+                o.x = pack_bf16x2(sum.x, sum.y);
+                o.y = pack_bf16x2(sum.z, sum.w);
+                *reinterpret_cast<uint2*>(p.dq16 + ((long)b * L + i0 + m) * p.ld_dq + h * 64 + n0) = o;
+            }
+        }
+        const char* qt = qtiles + cur * PG_TILE;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 q0 = tr_frag<64>(qt, 16 * s2, 0, lane), q1 = tr_frag<64>(qt, 16 * s2, 32, lane);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const bf16x8 a = tr_frag<64>(gtile, 16 * s2, 32 * mt, lane);
+                acc_e[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, q0, acc_e[mt][0], 0, 0, 0);
+                acc_e[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, q1, acc_e[mt][1], 0, 0, 0);
+            }
+        }
+        // dc: the image's column `lane`, 32 rows (an all-ones MFMA would cost 32 accumulator registers for 64 numbers)
+        {
+            float cs = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 32; ++rr)
+                cs += bf16_to_f32(*reinterpret_cast<const bf16_t*>(gtile + T::off(rr, lane >> 3) + (lane & 7) * 2));
+            dc_run += cs;
+        }
+        if (i0 + 32 < L) stage_q(i0 + 32, cur ^ 1);
+        cur ^= 1;
+        __syncthreads();
+    }
+    // one flush per (b, h): rows of the tables this wave owns
+    if (p.dbg & 1) return;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pr = c0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (pr < L) {
+                atomicAdd(p.dE + (long)pr * p.ld_de + h * 64 + row, acc_e[mt][0][r]);
+                atomicAdd(p.dE + (long)pr * p.ld_de + h * 64 + 32 + row, acc_e[mt][1][r]);
+            }
+        }
+    if (c0 + lane < L) atomicAdd(p.dcT + (long)h * L + c0 + lane, dc_run);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const float v = gu_run[nt] + __shfl_xor(gu_run[nt], 32, 64);
+        if (hh == 0) atomicAdd(p.gu + h * 64 + 32 * nt + row, v);
+    }
+}
+
+bool attn_dqde_supported(int Dh, int L, long ldp) { return Dh == 64 && ldp <= 512 && ldp % 8 == 0 && L >= 1; }
+
+int attn_dqde(const bf16_t* dS16, const bf16_t* dG16, long slab16, long ldp, const bf16_t* k, long ld_kv, const bf16_t* e16, long ld_e,
+              const bf16_t* qp, long ld_qp, bf16_t* dq16, long ld_dq, float* dE, long ld_de, float* dcT, float* gu, int B, int L, int H,
+              hipStream_t st) {
+    TTMI_REQUIRE(dS16 && dG16 && k && e16 && qp && dq16 && dE && dcT && gu && B > 0 && H > 0 && attn_dqde_supported(64, L, ldp),
+                 "attn_dqde: bad arguments");
+    TTMI_REQUIRE(aligned16(dS16) && aligned16(dG16) && aligned16(qp) && (slab16 * 2) % 16 == 0 && ld_qp % 8 == 0 && ld_dq % 4 == 0 &&
+                 (reinterpret_cast<uintptr_t>(dq16) & 7) == 0, "attn_dqde: alignment");
+    static bool enabled = false;
+    if (!enabled) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dqde_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PG_LDS) != hipSuccess) {
+            ttmi_set_error("attn_dqde: LDS attribute");
+            return TTMI_EINVAL;
+        }
+        enabled = true;
+    }
+    PosGradParams p;
+    p.dS16 = dS16; p.dG16 = dG16; p.slab16 = slab16; p.ldp = (int)ldp; p.k = k; p.ld_kv = ld_kv; p.e16 = e16; p.ld_e = ld_e; p.qp = qp; p.ld_qp = ld_qp;
+    p.dq16 = dq16; p.ld_dq = ld_dq; p.dE = dE; p.ld_de = ld_de; p.dcT = dcT; p.gu = gu; p.B = B; p.L = L; p.H = H;
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("TTMI_PG_DEBUG"); dbg = e ? atoi(e) : 0; }
+    p.dbg = dbg;
+    hipLaunchKernelGGL(attn_dqde_kernel, dim3(B * H), dim3(512), PG_LDS, st, p);
+    TTMI_LAUNCH_CHECK("attn_dqde_kernel");
+    return TTMI_OK;
 }
 
 // ------------------------------------------------------------------ position-term slab

@@ -64,6 +64,8 @@ int wgrad(const float* dY, const float* X, float* gW, int M, int N, int K, long 
 // the next call).  ttmi_set_option(3, 0) disables it.
 const unsigned* g_drop_salt = nullptr;     // ttmi_set_dropout_salt: device word mixed into every dropout seed at kernel start (graph replays)
 int g_fork_wgrad = 1;
+int g_posgrad_gemms = 0;        // ttmi_set_option(11, 1): dq / dE by the round-2 GEMM launches instead of attn_dqde_kernel (A/B)
+int g_attn_slices = 1;          // ttmi_set_option(10, n): attention backward in n batch slices (see attn_bwd_impl)
 int g_gemm_slab = 0;            // ttmi_set_option(5, 1): position-term slab by the batched GEMM (A/B measurements)
 struct SideCtx {
     int device = -1;
@@ -455,22 +457,77 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
         CK(ttmi_launch_gemm(mk(da, o_w, static_cast<float*>(w.dO), (int)a.BL, (int)a.HD, d, d, a.HD, a.HD, NN_, prec), st));
     }
     const bool fused = attn_fused(fast, a);
+    const bool fastpos = fused && Dh % 8 == 0;      // position/content products on the glds kernels (K-major transposed k, E)
+    // Batch slices (ttmi_set_option(10, n)): the attention backward kernel leaves dS twice in bf16 ([B, H, L, ldp] each: 2 x 129 MB at C2) and
+    // the dq / dE products read them straight back.  Cut into n slices of the batch - kernel, dq product, dE product per slice, over the SAME
+    // slab region - the slabs of a slice (2 x 129 / n MB) are still in the 256 MB Infinity Cache when their readers run.
+    const int nslice = (fastpos && g_attn_slices > 1) ? (g_attn_slices < B ? g_attn_slices : B) : 1;
     if (fused) {
         // 4-6 + 9 fused: recompute P, dS = P (dP - delta) scale, dK and dV straight into dqkv.  dS leaves the kernel twice in
         // bf16 with aligned rows: [i][j] for the content dgrad and the shifted [r][c-1] form (= dG) for the position grads.
-        CK(memset2d(w.dG16, (size_t)w.slab16 * 2, (size_t)w.ldp * 2, (size_t)B * H, st));       // dG row 0 is (almost) never written
+        const int bper = (B + nslice - 1) / nslice;
+        CK(memset2d(w.dG16, (size_t)w.slab16 * 2, (size_t)w.ldp * 2, (size_t)bper * H, st));       // dG row 0 is (almost) never written
         FlashParams f = flash_params(a, c, scale, mask_kind, mask_left, mask_right, mask, mask_sb, mask_si);
         if (attn_inkernel(fast, a)) {                // the kernel recomputes the position term: effective table + bias for this length, as in forward
             CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st, w.E16));
             TTMI_REQUIRE(r_w_bias, "attn_bwd: r_w_bias is required (the attention kernels form q + r_w_bias themselves)");
             flash_inkernel(f, a, c, w, r_w_bias);
+        } else if (fastpos) {
+            CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st, w.E16)); // the effective table of the position products below
         }
         f.dO = static_cast<const bf16_t*>(w.dO);
         f.delta = w.delta;
         f.dS16 = w.dS16; f.dG16 = w.dG16; f.ldp = w.ldp; f.slab16 = w.slab16;
         f.dK = w.dqkv + a.HD; f.dV = w.dqkv + 2 * a.HD; f.ld_dkv = a.W3;
         f.dK16 = w.dqkv16 + a.HD; f.dV16 = w.dqkv16 + 2 * a.HD;
-        CK(flash_attn_bwd(f, st));
+        // one pass over the slabs for dq, dE, dc and d r_w_bias (attn_dqde_kernel) where its shape fits, the round-2 GEMM launches otherwise
+        const bool onepass = fastpos && !g_posgrad_gemms && attn_dqde_supported(Dh, L, w.ldp);
+        if (!fastpos) CK(flash_attn_bwd(f, st));
+        else {
+            CK(fill_zero(w.dE, sizeof(float) * ((size_t)L * a.HD + (size_t)H * L), st));
+            if (!onepass) {
+                // K-major operands of the position / content products, for the whole batch, ahead of the slices
+                // (K runs over the padded pitch ldp: the pad columns of dS16 / dG16 are zeroed by the flash backward kernel itself)
+                CK(transpose_bf16_batched(static_cast<const bf16_t*>(c.qkv) + a.HD, 1, a.W3, B, H, L * a.W3, Dh, L, Dh, w.kT16, w.ldp, st));
+                CK(transpose_bf16_batched(w.E, 0, a.HD, 1, H, 0, Dh, L, Dh, w.ET16, w.ldp, st));
+            }
+            for (int b0 = 0; b0 < B; b0 += bper) {
+                const int nb = B - b0 < bper ? B - b0 : bper;
+                FlashParams fs = f;
+                fs.B = nb;
+                const long r0 = (long)b0 * L;
+                if (fs.qu) fs.qu += r0 * fs.ld_qu;
+                if (fs.qp) fs.qp += r0 * fs.ld_qp;
+                fs.k += r0 * fs.ld_kv; fs.v += r0 * fs.ld_kv;
+                fs.o += r0 * fs.ld_o; fs.dO += r0 * fs.ld_o;
+                fs.lse += (long)b0 * H * L; fs.delta += (long)b0 * H * L;
+                fs.dK += r0 * fs.ld_dkv; fs.dV += r0 * fs.ld_dkv;
+                fs.dK16 += r0 * fs.ld_dkv; fs.dV16 += r0 * fs.ld_dkv;
+                if (fs.mask) fs.mask += (long)b0 * fs.mask_sb * (fs.mask_kind == 4 ? 4 : 1);
+                if (fs.bd) fs.bd += (long)b0 * H * fs.slab;
+                CK(flash_attn_bwd(fs, st));
+                if (onepass) {
+                    const bf16_t* qkv16 = static_cast<const bf16_t*>(c.qkv) + r0 * a.W3;
+                    CK(attn_dqde(w.dS16, w.dG16, w.slab16, w.ldp, qkv16 + a.HD, a.W3, w.E16, a.HD, qkv16, a.W3, w.dqkv16 + r0 * a.W3, a.W3,
+                                 w.dE, a.HD, w.dcT, g_r_w_bias, nb, L, H, st));
+                    continue;
+                }
+                // dq = dS k + dG E in ONE launch: both products accumulate into the same tile, the column sums of the first (d r_w_bias) are taken
+                // in between, and the sum leaves in bf16 - the form the qkv GEMMs read
+                FastBatch fb;
+                fb.nz1 = nb; fb.nz2 = H; fb.sA1 = H * w.slab16; fb.sA2 = w.slab16; fb.sB1 = (long)H * Dh * w.ldp; fb.sB2 = (long)Dh * w.ldp;
+                fb.sC1 = L * a.W3; fb.sC2 = Dh; fb.sV1 = 0; fb.sV2 = Dh;
+                NtEpilogue e;
+                e.A2 = w.dG16; e.B2 = w.ET16; e.K2 = (int)w.ldp; e.lda2 = w.ldp; e.ldb2 = w.ldp; e.sB1b = 0; e.sB2b = (long)Dh * w.ldp;
+                e.colsum_mid = g_r_w_bias;
+                CK(gemm_nt_bf16(w.dS16, w.kT16 + (long)b0 * H * Dh * w.ldp, w.dqkv16 + r0 * a.W3, 1, e, L, Dh, (int)w.ldp, w.ldp, w.ldp, a.W3, st, fb));
+                // dE[p,h,:] += sum_b dG^T q, dc[h][p] += sum_b colsum(dG)
+                FastBatch tb;
+                tb.nz1 = nb; tb.nz2 = H; tb.sA1 = H * w.slab16; tb.sA2 = w.slab16; tb.sB1 = L * a.W3; tb.sB2 = Dh; tb.sC1 = 0; tb.sC2 = Dh;
+                tb.sV1 = 0; tb.sV2 = L;
+                CK(gemm_tn_bf16(w.dG16, static_cast<const bf16_t*>(c.qkv) + r0 * a.W3, w.dE, L, Dh, L, w.ldp, a.W3, a.HD, 1, st, w.dcT, tb));
+            }
+        }
     } else {
         // first L floats of each dS slab lie outside the pitch-L view but inside dG's row 0: zero them
         CK(memset2d(w.dS, (size_t)a.slab * 4, (size_t)L * 4, (size_t)B * H, st));
@@ -489,22 +546,15 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
         // 6. dS = P (dP - rowsum(dP P)) scale
         CK(softmax_bwd(w.dS + L, c.P + L, B * H, L, L, a.slab, scale, st));
     }
-    // 7. dq(content) = dS K -> dqkv[q]
-    const bool fastpos = fused && Dh % 8 == 0;      // position/content products on the glds kernels (K-major transposed k, E)
-    if (fastpos) {
-        // (K runs over the padded pitch ldp: the pad columns of dS16 / dG16 were zeroed by the flash backward kernel itself)
-        CK(transpose_bf16_batched(static_cast<const bf16_t*>(c.qkv) + a.HD, 1, a.W3, B, H, L * a.W3, Dh, L, Dh, w.kT16, w.ldp, st));
-        // (the product itself is issued together with the position part below: one launch, no f32 intermediate)
-    } else {
-        {
-            GemmDesc g = fused ? mkx(w.dS16, DT_BF16, eoff(c.qkv, adt, a.HD), adt, w.dqkv, DT_F32, L, Dh, L, w.ldp, a.W3, a.W3, NN_, prec)
-                               : mkx(w.dS + L, DT_F32, eoff(c.qkv, adt, a.HD), adt, w.dqkv, DT_F32, L, Dh, L, L, a.W3, a.W3, NN_, prec);
-            if (fused) batch_bh(g, a, H * w.slab16, w.slab16, L * a.W3, Dh, L * a.W3, Dh);
-            else batch_bh(g, a, H * a.slab, a.slab, L * a.W3, Dh, L * a.W3, Dh);
-            CK(ttmi_launch_gemm(g, st));
-        }
+    // 7. dq(content) = dS K -> dqkv[q]   (fastpos: issued per batch slice above, together with the position part)
+    if (!fastpos) {
+        GemmDesc g = fused ? mkx(w.dS16, DT_BF16, eoff(c.qkv, adt, a.HD), adt, w.dqkv, DT_F32, L, Dh, L, w.ldp, a.W3, a.W3, NN_, prec)
+                           : mkx(w.dS + L, DT_F32, eoff(c.qkv, adt, a.HD), adt, w.dqkv, DT_F32, L, Dh, L, L, a.W3, a.W3, NN_, prec);
+        if (fused) batch_bh(g, a, H * w.slab16, w.slab16, L * a.W3, Dh, L * a.W3, Dh);
+        else batch_bh(g, a, H * a.slab, a.slab, L * a.W3, Dh, L * a.W3, Dh);
+        CK(ttmi_launch_gemm(g, st));
     }
-    // 8. g r_w_bias += column sums of dq(content)  (fastpos: taken from the accumulators of the fused launch below)
+    // 8. g r_w_bias += column sums of dq(content)  (fastpos: taken from the accumulators of the fused launch)
     if (!fastpos) CK(colsum(w.dqkv, a.W3, a.BL, (int)a.HD, 1, 1, 0, 0, 0, 0, g_r_w_bias, st));
     if (!fused) {
         // 9. dK = dS^T (q + u)
@@ -515,24 +565,9 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
         }
     }
     // 10. dq += dG E ; 11. dE[p,h,:] = sum_b dG^T q ; 12. dc[h][p] = sum_b colsum(dG) ; 13. fold onto the K-row tables
-    if (!(fused && attn_inkernel(fast, a))) CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st));     // (already gathered for the kernel above)
-    CK(fill_zero(w.dE, sizeof(float) * ((size_t)L * a.HD + (size_t)H * L), st));
-    if (fastpos) {
-        CK(transpose_bf16_batched(w.E, 0, a.HD, 1, H, 0, Dh, L, Dh, w.ET16, w.ldp, st));
-        // dq = dS k + dG E in ONE launch: both products accumulate into the same tile, the column sums of the first (d r_w_bias) are taken
-        // in between, and the sum leaves in bf16 - the form the qkv GEMMs read
-        FastBatch fb;
-        fb.nz1 = B; fb.nz2 = H; fb.sA1 = H * w.slab16; fb.sA2 = w.slab16; fb.sB1 = (long)H * Dh * w.ldp; fb.sB2 = (long)Dh * w.ldp;
-        fb.sC1 = L * a.W3; fb.sC2 = Dh; fb.sV1 = 0; fb.sV2 = Dh;
-        NtEpilogue e;
-        e.A2 = w.dG16; e.B2 = w.ET16; e.K2 = (int)w.ldp; e.lda2 = w.ldp; e.ldb2 = w.ldp; e.sB1b = 0; e.sB2b = (long)Dh * w.ldp;
-        e.colsum_mid = g_r_w_bias;
-        CK(gemm_nt_bf16(w.dS16, w.kT16, w.dqkv16, 1, e, L, Dh, (int)w.ldp, w.ldp, w.ldp, a.W3, st, fb));
-        FastBatch tb;
-        tb.nz1 = B; tb.nz2 = H; tb.sA1 = H * w.slab16; tb.sA2 = w.slab16; tb.sB1 = L * a.W3; tb.sB2 = Dh; tb.sC1 = 0; tb.sC2 = Dh;
-        tb.sV1 = 0; tb.sV2 = L;
-        CK(gemm_tn_bf16(w.dG16, static_cast<const bf16_t*>(c.qkv), w.dE, L, Dh, L, w.ldp, a.W3, a.HD, 1, st, w.dcT, tb));
-    } else {
+    if (!fastpos) {
+        if (!(fused && attn_inkernel(fast, a))) CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st));     // (already gathered for the kernel above)
+        CK(fill_zero(w.dE, sizeof(float) * ((size_t)L * a.HD + (size_t)H * L), st));
         {
             GemmDesc g = fused ? mkx(w.dG16, DT_BF16, w.E, DT_F32, w.dqkv, DT_F32, L, Dh, L, w.ldp, a.HD, a.W3, NN_, prec)
                                : mkx(w.dS + 1, DT_F32, w.E, DT_F32, w.dqkv, DT_F32, L, Dh, L, L + 1, a.HD, a.W3, NN_, prec);
@@ -1029,7 +1064,9 @@ int ttmi_set_dropout_salt(const unsigned* salt) {
 // process-wide switches for A/B measurements.  key 0: 1 = disable the fused attention kernels (bf16 pipeline only);
 // key 1: throughput-GEMM generation (see gemm_fast.hip); key 2: flash-kernel timing switches; key 3: 0 = no wgrad fork
 int ttmi_set_option(int key, int value) {
-    TTMI_REQUIRE(key >= 0 && key <= 9, "set_option: unknown key %d", key);
+    TTMI_REQUIRE(key >= 0 && key <= 11, "set_option: unknown key %d", key);
+    if (key == 11) { g_posgrad_gemms = value; return TTMI_OK; }
+    if (key == 10) { g_attn_slices = value < 1 ? 1 : value; return TTMI_OK; }
     if (key == 9) { ttmi_rnnt_set_lattice_version(value); return TTMI_OK; }
     if (key == 8) { g_inkernel_pos = value; return TTMI_OK; }
     if (key == 6) { gemm_fast_set_reserved_cus(value); return TTMI_OK; }
