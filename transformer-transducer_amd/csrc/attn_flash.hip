@@ -1237,118 +1237,148 @@ struct PosGradParams {
     int dbg;                            // timing experiments (TTMI_PG_DEBUG): 1 no final atomics, 2 no table loads, 4 no main loop, 8 no slab loads
 };
 constexpr int PG_TILE = 32 * 64 * 2;
-constexpr int PG_LDS = 8 * 32 * 64 * 4 + 2 * 8 * PG_TILE + 2 * PG_TILE;        // partial slots | per-wave dS and dG images | two q tiles
+constexpr int PG_SLOT = 64 * 36;                                               // floats: a wave's partial dq block as [d][row], row pitch 36 (conflict-free b128)
+constexpr int PG_LDS = 8 * PG_SLOT * 4 + 2 * 8 * PG_TILE + 2 * PG_TILE;        // partial slots | per-wave dS and dG images | two q tiles
 __global__ __launch_bounds__(512, 1) void attn_dqde_kernel(const PosGradParams p) {
     using T = Tile<64>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* slots = reinterpret_cast<float*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hh = lane >> 5, row = lane & 31;
-    char* stile = smem + 8 * 32 * 64 * 4 + wave * PG_TILE;                  // this wave's 32 x 64 block of dS ...
-    char* gtile = smem + 8 * 32 * 64 * 4 + 8 * PG_TILE + wave * PG_TILE;     // ... and of dG (swizzled Tile<64> images)
-    char* qtiles = smem + 8 * 32 * 64 * 4 + 16 * PG_TILE;
+    char* stile = smem + 8 * PG_SLOT * 4 + wave * PG_TILE;                   // this wave's 32 x 64 block of dS ...
+    char* gtile = smem + 8 * PG_SLOT * 4 + 8 * PG_TILE + wave * PG_TILE;      // ... and of dG (swizzled Tile<64> images)
+    char* qtiles = smem + 8 * PG_SLOT * 4 + 16 * PG_TILE;
     const int z = blockIdx.x, b = z / p.H, h = z % p.H, L = p.L, ldp = p.ldp;
     const int c0 = 64 * wave;
-    const bf16_t* ds = p.dS16 + (long)z * p.slab16;
-    const bf16_t* dg = p.dG16 + (long)z * p.slab16;
     const bf16_t* kb = p.k + (long)b * L * p.ld_kv + h * 64;
     const bf16_t* eb = p.e16 + h * 64;
     const bf16_t* qb = p.qp + (long)b * L * p.ld_qp + h * 64;
-    // resident B fragments: B[k = column c][n = d], lane n = 32 nt + row, k chunk = 16 ks + 8 hh + (0..7)
+    const int lrow = lane >> 3, lpos = lane & 7;
+    // slab blocks through raw buffers (descriptor + per-lane offset + scalar row-block offset; a row past L is past the slab and reads as
+    // zero, a chunk past the pitch gets an offset outside the buffer): 8 lanes cover one row's 128 bytes (this wave's 64 columns), a
+    // wave-instruction 8 whole row pieces, and the chunk a lane fetches is the one that belongs at its position of the swizzled image.
+    // dS goes straight into its image by LDS-DMA (issued as soon as the previous block's fragments are in registers), dG through
+    // registers (its image is read until the end of a block).
+    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.dS16 + (long)z * p.slab16), 0, (int)(p.slab16 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.dG16 + (long)z * p.slab16), 0, (int)(p.slab16 * 2), 0x00020000);
+    int voff[4];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        const int tr = 8 * q4 + lrow, col = c0 + 8 * (lpos ^ ((tr >> 1) & 7));
+        voff[q4] = (col + 8 <= ldp && !(p.dbg & 8)) ? (tr * ldp + col) * 2 : 0x7FFFFF00;
+    }
+    u32x4_t rg[4];
+    auto fetch = [&](int i0) {
+        const int soff = i0 * ldp * 2;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (__attribute__((address_space(3))) void*)(stile + q4 * 1024), 16, voff[q4], soff, 0, 0);
+            rg[q4] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, voff[q4], soff, 0);
+        }
+    };
+    fetch(0);                                       // the first block flies under the table prologue
+    // resident B fragments B[k = column c][n = d] (lane n = 32 nt + row; k = 16 ks + 8 hh + 0..7) of this wave's 64 rows of k and of the
+    // table: the rows go through a 64 x 64 image (the wave's partial-sum slot, not yet in use) and are read back by columns - once
     bf16x8 bk[2][4], be[2][4];
+    {
+        char* img = reinterpret_cast<char*>(slots + wave * PG_SLOT);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+        for (int pass = 0; pass < 2; ++pass) {
+            const bf16_t* src = pass == 0 ? kb : eb;
+            const long ld = pass == 0 ? p.ld_kv : p.ld_e;
+            u32x4_t tv[8];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+            for (int it = 0; it < 8; ++it)               // all eight loads in flight, then the (branch-free) zeroing and the image stores
+                tv[it] = *reinterpret_cast<const u32x4_t*>(src + (long)min(c0 + 8 * it + lrow, L - 1) * ld + lpos * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int c = c0 + 16 * ks + 8 * hh + j, cc = min(c, L - 1), d = 32 * nt + row;
-                const bf16_t kv = (p.dbg & 2) ? (bf16_t)0x3c00 : kb[(long)cc * p.ld_kv + d], ev = (p.dbg & 2) ? (bf16_t)0x3c00 : eb[(long)cc * p.ld_e + d];
-                bk[nt][ks][j] = __builtin_bit_cast(__bf16, (unsigned short)(c < L ? kv : (bf16_t)0));
-                be[nt][ks][j] = __builtin_bit_cast(__bf16, (unsigned short)(c < L ? ev : (bf16_t)0));
+            for (int it = 0; it < 8; ++it) {
+                const int r = 8 * it + lrow;
+                const unsigned keep = (c0 + r < L && !(p.dbg & 2)) ? 0xffffffffu : 0u;
+                const u32x4_t v = {tv[it][0] & keep, tv[it][1] & keep, tv[it][2] & keep, tv[it][3] & keep};
+                *reinterpret_cast<u32x4_t*>(img + T::off(r, lpos)) = v;
             }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    bf16x8 f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int d = 32 * nt + row;
+                        f[j] = __builtin_bit_cast(__bf16, *reinterpret_cast<const unsigned short*>(img + T::off(16 * ks + 8 * hh + j, d >> 3) + (d & 7) * 2));
+                    }
+                    if (pass == 0) bk[nt][ks] = f;
+                    else be[nt][ks] = f;
+                }
+        }
+    }
     f32x16 acc_e[2][2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc_e[0][0][r] = acc_e[0][1][r] = acc_e[1][0][r] = acc_e[1][1][r] = 0.f;
-    float dc_run = 0.f;                            // lane = table row c0 + lane: sum of its dG column over all rows
+    float dc4[4] = {0.f, 0.f, 0.f, 0.f};           // lane (cg = lane & 15, rows 8 (lane >> 4) ..+7 of every block): dG column sums of columns 4 cg ..+3
     float gu_run[2] = {0.f, 0.f};
-    // slab loads: 8 lanes cover one row's 128 bytes (this wave's 64 columns), a wave-instruction 8 whole row pieces; the chunk a lane fetches
-    // is the one that belongs at its position of the swizzled image, so the registers go to LDS as they are
-    const int lrow = lane >> 3, lpos = lane & 7;
-    u32x4_t rs[4], rg[4];
-    auto load_block = [&](int i0) {
-        if (p.dbg & 8) return;
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const int tr = 8 * q4 + lrow, r = i0 + tr;
-            const int col = c0 + 8 * (lpos ^ ((tr >> 1) & 7));
-            const bool ok = r < L && col + 8 <= ldp;
-            const long o = (long)min(r, L - 1) * ldp + min(col, ldp - 8);
-            const u32x4_t vs = *reinterpret_cast<const u32x4_t*>(ds + o), vg = *reinterpret_cast<const u32x4_t*>(dg + o);
-            rs[q4] = ok ? vs : u32x4_t{0u, 0u, 0u, 0u};
-            rg[q4] = ok ? vg : u32x4_t{0u, 0u, 0u, 0u};
-        }
+    // q rows in and dq rows out through raw buffers as well (a row past L reads as zero / is not stored; no 64-bit addresses in registers)
+    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(qb), 0, (int)(((long)(L - 1) * p.ld_qp + 64) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.dq16 + (long)b * L * p.ld_dq + h * 64, 0, (int)(((long)(L - 1) * p.ld_dq + 64) * 2), 0x00020000);
+    const int ldq2 = (int)p.ld_qp * 2, ldo2 = (int)p.ld_dq * 2;
+    const int vq = ((tid >> 3) & 31) * ldq2 + (tid & 7) * 16;             // thread (row tid / 8, chunk tid % 8) of a 32-row q tile
+    const int vo = (4 * (tid >> 6)) * ldo2 + (tid & 63) * 2;               // thread (rows 4 (tid / 64) ..+3, column tid % 64) of a 32-row dq block
+    u32x4_t qpre = {0u, 0u, 0u, 0u};               // 32 plain q rows -> swizzled tile, issued early in a block, parked at its end
+    auto load_q = [&](int i0) {
+        if (tid < 32 * T::NCH) qpre = __builtin_amdgcn_raw_buffer_load_b128(rs_q, vq, i0 * ldq2, 0);
     };
-    auto stage_q = [&](int i0, int buf) {          // 32 plain q rows -> swizzled tile (rows past L: the last row; their dG rows are zero)
-        if (tid < 32 * T::NCH) {
-            const int rr = tid / T::NCH, ch = tid % T::NCH;
-            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(qb + (long)min(i0 + rr, L - 1) * p.ld_qp + ch * 8);
-            *reinterpret_cast<u32x4_t*>(qtiles + buf * PG_TILE + T::off(rr, ch)) = v;
-        }
+    auto park_q = [&](int buf) {
+        if (tid < 32 * T::NCH) *reinterpret_cast<u32x4_t*>(qtiles + buf * PG_TILE + T::off(tid >> 3, tid & 7)) = qpre;
     };
-    load_block(0);
-    stage_q(0, 0);
-    __syncthreads();
+    load_q(0);
+    park_q(0);
+    __syncthreads();                                // (also: every wave is done with its slot as a table image)
     int cur = 0;
     for (int i0 = 0; i0 < ((p.dbg & 4) ? 0 : L); i0 += 32) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this block's dS image and dG registers (issued one block ago)
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            *reinterpret_cast<u32x4_t*>(stile + (8 * q4 + lrow) * 128 + lpos * 16) = rs[q4];
-            *reinterpret_cast<u32x4_t*>(gtile + (8 * q4 + lrow) * 128 + lpos * 16) = rg[q4];
-        }
-        if (i0 + 32 < L) load_block(i0 + 32);        // the next block flies under this block's products, reduction and dE work
-        f32x16 acc_q[2];
+        for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<u32x4_t*>(gtile + (8 * q4 + lrow) * 128 + lpos * 16) = rg[q4];
+        bf16x8 a[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc_q[0][r] = acc_q[1][r] = 0.f;
+        for (int ks = 0; ks < 4; ++ks) a[ks] = *reinterpret_cast<const bf16x8*>(stile + T::off(row, 2 * ks + hh));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers: the image may be overwritten
+        if (i0 + 32 < L) { fetch(i0 + 32); load_q(i0 + 32); }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {             // content: dS k
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(stile + T::off(row, 2 * ks + hh));
-            acc_q[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bk[0][ks], acc_q[0], 0, 0, 0);
-            acc_q[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bk[1][ks], acc_q[1], 0, 0, 0);
-        }
+        for (int nt = 0; nt < 2; ++nt) {             // one 32-column half of the block at a time: 16 accumulator registers, not 32
+            f32x16 acc;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {             // column sums of the content part: d r_w_bias
-            float cs = 0.f;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) cs += acc_q[nt][r];
+            for (int ks = 0; ks < 4; ++ks)           // content: dS k
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], bk[nt][ks], acc, 0, 0, 0);
+            float cs = 0.f;                          // column sums of the content part: d r_w_bias
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cs += acc[r];
             gu_run[nt] += cs;
-        }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {             // position: dG E
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(gtile + T::off(row, 2 * ks + hh));
-            acc_q[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, be[0][ks], acc_q[0], 0, 0, 0);
-            acc_q[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, be[1][ks], acc_q[1], 0, 0, 0);
-        }
+            for (int ks = 0; ks < 4; ++ks) {         // position: dG E
+                const bf16x8 ag = *reinterpret_cast<const bf16x8*>(gtile + T::off(row, 2 * ks + hh));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ag, be[nt][ks], acc, 0, 0, 0);
+            }
+            // the wave's partial block as [d][row]: a lane's four consecutive rows are one 16-byte store
+            float* sl = slots + wave * PG_SLOT + (32 * nt + row) * 36 + 4 * hh;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            float* sl = slots + wave * 2048 + 32 * nt + row;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sl[((r & 3) + 8 * (r >> 2) + 4 * hh) * 64] = acc_q[nt][r];
+            for (int g4 = 0; g4 < 4; ++g4)
+                *reinterpret_cast<float4*>(sl + 8 * g4) = make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
         }
         __syncthreads();
         {
-            const int e4 = tid * 4, m = e4 >> 6, n0 = e4 & 63;
-            float4 sum = *reinterpret_cast<const float4*>(slots + e4);
+            const int d = tid & 63, m0 = 4 * (tid >> 6);           // this thread: column d, rows m0 ..+3; a wave = 4 whole rows of 128 bytes
+            float4 sum = *reinterpret_cast<const float4*>(slots + d * 36 + m0);
 #pragma unroll
             for (int w = 1; w < 8; ++w) {
-                const float4 v = *reinterpret_cast<const float4*>(slots + w * 2048 + e4);
+                const float4 v = *reinterpret_cast<const float4*>(slots + w * PG_SLOT + d * 36 + m0);
                 sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
             }
-            if (i0 + m < L) {
-                uint2 o;
-                o.x = pack_bf16x2(sum.x, sum.y);
-                o.y = pack_bf16x2(sum.z, sum.w);
-                *reinterpret_cast<uint2*>(p.dq16 + ((long)b * L + i0 + m) * p.ld_dq + h * 64 + n0) = o;
-            }
+            const int so = i0 * ldo2;
+            __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16(sum.x), rs_o, vo, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16(sum.y), rs_o, vo, so + ldo2, 0);
+            __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16(sum.z), rs_o, vo, so + 2 * ldo2, 0);
+            __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16(sum.w), rs_o, vo, so + 3 * ldo2, 0);
         }
         const char* qt = qtiles + cur * PG_TILE;
 #pragma unroll
@@ -1361,15 +1391,17 @@ __global__ __launch_bounds__(512, 1) void attn_dqde_kernel(const PosGradParams p
                 acc_e[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, q1, acc_e[mt][1], 0, 0, 0);
             }
         }
-        // dc: the image's column `lane`, 32 rows (an all-ones MFMA would cost 32 accumulator registers for 64 numbers)
+        // dc: 8 rows x 4 columns of the dG image per lane and block (8-byte reads); the four row groups meet once, after the loop
         {
-            float cs = 0.f;
+            const int cg = lane & 15, r8 = 8 * (lane >> 4);
 #pragma unroll
-            for (int rr = 0; rr < 32; ++rr)
-                cs += bf16_to_f32(*reinterpret_cast<const bf16_t*>(gtile + T::off(rr, lane >> 3) + (lane & 7) * 2));
-            dc_run += cs;
+            for (int rr = 0; rr < 8; ++rr) {
+                const uint2 w = *reinterpret_cast<const uint2*>(gtile + T::off(r8 + rr, cg >> 1) + (cg & 1) * 8);
+                dc4[0] += __uint_as_float(w.x << 16); dc4[1] += __uint_as_float(w.x & 0xffff0000u);
+                dc4[2] += __uint_as_float(w.y << 16); dc4[3] += __uint_as_float(w.y & 0xffff0000u);
+            }
         }
-        if (i0 + 32 < L) stage_q(i0 + 32, cur ^ 1);
+        if (i0 + 32 < L) park_q(cur ^ 1);
         cur ^= 1;
         __syncthreads();
     }
@@ -1385,7 +1417,14 @@ __global__ __launch_bounds__(512, 1) void attn_dqde_kernel(const PosGradParams p
                 atomicAdd(p.dE + (long)pr * p.ld_de + h * 64 + 32 + row, acc_e[mt][1][r]);
             }
         }
-    if (c0 + lane < L) atomicAdd(p.dcT + (long)h * L + c0 + lane, dc_run);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float v = dc4[e];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        const int pc = c0 + 4 * (lane & 15) + e;
+        if (lane < 16 && pc < L) atomicAdd(p.dcT + (long)h * L + pc, v);
+    }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const float v = gu_run[nt] + __shfl_xor(gu_run[nt], 32, 64);
