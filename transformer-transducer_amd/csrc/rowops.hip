@@ -4,6 +4,7 @@
 // wave reductions by __shfl_xor; cross-row reductions finish with float atomics (agent scope).
 // Reference arithmetic: tt/transformer.py:52-58,148-175, tt/decoder.py:26,39, tt/model.py:33-37.
 #include "rowops.h"
+#include <type_traits>
 #ifndef LN_BWD_GRID
 #define LN_BWD_GRID 512
 #endif
@@ -509,65 +510,95 @@ __device__ __forceinline__ void unpack_bf16x8(const uint4& w, float* f) {
     f[4] = __uint_as_float(w.z << 16); f[5] = __uint_as_float(w.z & 0xffff0000u);
     f[6] = __uint_as_float(w.w << 16); f[7] = __uint_as_float(w.w & 0xffff0000u);
 }
+// sum over the lanes of a row of the joint block by DPP moves only (no LDS crossbar: __shfl_xor is a ds_bpermute): after the two quad
+// permutes and the two mirrors every lane holds its 16-lane row's sum; row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3) carry the
+// totals up, so lane 31 of each half holds the sum of its 32 lanes after the first and lane 63 the sum of all 64 after the second
+template <bool FULL64>
+__device__ __forceinline__ float dpp_row_sum(float v) {
+    auto mv = [](float x, auto ctrl, auto rmask) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(rmask)::value, 0xF, false));
+    };
+    v += mv(v, std::integral_constant<int, 0xB1>(), std::integral_constant<int, 0xF>());      // quad_perm [1,0,3,2]
+    v += mv(v, std::integral_constant<int, 0x4E>(), std::integral_constant<int, 0xF>());      // quad_perm [2,3,0,1]
+    v += mv(v, std::integral_constant<int, 0x141>(), std::integral_constant<int, 0xF>());     // row_half_mirror
+    v += mv(v, std::integral_constant<int, 0x140>(), std::integral_constant<int, 0xF>());     // row_mirror
+    v += mv(v, std::integral_constant<int, 0x142>(), std::integral_constant<int, 0xA>());     // row_bcast:15 into rows 1 and 3
+    if constexpr (FULL64) v += mv(v, std::integral_constant<int, 0x143>(), std::integral_constant<int, 0xC>());   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+constexpr int JT_TT = 4;             // frames per block: the label-encoder rows PD[b, u, :] (and, with EMIS, the rows of Wp16 of b's labels) are
+                                     // read once per u and used for four frames - these L2 reads, not the 2 bytes per element of output, held the kernel at 3.2 TB/s
 template <bool EMIS>
 __global__ __launch_bounds__(256) void joint_tanh_fwd_bf16x8_kernel(const float* __restrict__ PE, const float* __restrict__ PD,
                                                                     const float* __restrict__ bias, int T, int U1, int J,
                                                                     bf16_t* __restrict__ H, JointEmis em) {
-    extern __shared__ float part[];        // EMIS: [U1][waves per row][2] partial dot products
-    const long bt = blockIdx.x;
-    const int b = (int)(bt / T);
+    extern __shared__ float part[];        // EMIS: [JT_TT][U1][waves per row][2] partial dot products
+    const int tblocks = (T + JT_TT - 1) / JT_TT;
+    const int b = blockIdx.x / tblocks, t0 = (blockIdx.x % tblocks) * JT_TT;
+    const int nt = min(JT_TT, T - t0);
+    const long bt0 = (long)b * T + t0;
     const int tpr = J >> 3, grp = threadIdx.x / tpr, ngrp = 256 / tpr;
     const int tin = threadIdx.x - grp * tpr;
     const int j = tin * 8;
-    float e[8];
+    float e[JT_TT][8];
     {
-        const float4 p0 = *reinterpret_cast<const float4*>(PE + bt * J + j), p1 = *reinterpret_cast<const float4*>(PE + bt * J + j + 4);
         const float4 b0 = *reinterpret_cast<const float4*>(bias + j), b1 = *reinterpret_cast<const float4*>(bias + j + 4);
-        e[0] = p0.x + b0.x; e[1] = p0.y + b0.y; e[2] = p0.z + b0.z; e[3] = p0.w + b0.w;
-        e[4] = p1.x + b1.x; e[5] = p1.y + b1.y; e[6] = p1.z + b1.z; e[7] = p1.w + b1.w;
+#pragma unroll
+        for (int tt = 0; tt < JT_TT; ++tt) {
+            const long r = bt0 + (tt < nt ? tt : 0);
+            const float4 p0 = *reinterpret_cast<const float4*>(PE + r * J + j), p1 = *reinterpret_cast<const float4*>(PE + r * J + j + 4);
+            e[tt][0] = p0.x + b0.x; e[tt][1] = p0.y + b0.y; e[tt][2] = p0.z + b0.z; e[tt][3] = p0.w + b0.w;
+            e[tt][4] = p1.x + b1.x; e[tt][5] = p1.y + b1.y; e[tt][6] = p1.z + b1.z; e[tt][7] = p1.w + b1.w;
+        }
     }
     const float* pd = PD + (long)b * U1 * J + j;
-    bf16_t* h = H + bt * U1 * J + j;
     float wb[8];
     const int nw = tpr >= 64 ? tpr >> 6 : 1;            // waves that share one row
     if constexpr (EMIS) unpack_bf16x8(*reinterpret_cast<const uint4*>(em.Wp16 + (long)em.blank * J + j), wb);
-#pragma unroll 4
+#pragma unroll 2
     for (int u = grp; u < U1; u += ngrp) {
         const float4 d0 = *reinterpret_cast<const float4*>(pd + (long)u * J), d1 = *reinterpret_cast<const float4*>(pd + (long)u * J + 4);
-        uint4 w;
-        w.x = pack_bf16x2(fast_tanh(e[0] + d0.x), fast_tanh(e[1] + d0.y));
-        w.y = pack_bf16x2(fast_tanh(e[2] + d0.z), fast_tanh(e[3] + d0.w));
-        w.z = pack_bf16x2(fast_tanh(e[4] + d1.x), fast_tanh(e[5] + d1.y));
-        w.w = pack_bf16x2(fast_tanh(e[6] + d1.z), fast_tanh(e[7] + d1.w));
-        *reinterpret_cast<uint4*>(h + (long)u * J) = w;
+        float wl[8];
         if constexpr (EMIS) {
             int y = em.blank;
             if (u < U1 - 1) {
                 y = em.labels[(long)b * (U1 - 1) + u];
                 y = y < 0 ? 0 : (y >= em.V ? em.V - 1 : y);
             }
-            float hv[8], wl[8];
-            unpack_bf16x8(w, hv);
             unpack_bf16x8(*reinterpret_cast<const uint4*>(em.Wp16 + (long)y * J + j), wl);
-            float db = 0.f, dl = 0.f;
+        }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { db = fmaf(hv[i], wb[i], db); dl = fmaf(hv[i], wl[i], dl); }
-            // sum over the lanes of this wave that hold the row (all 64, or an aligned group of tpr = 32)
+        for (int tt = 0; tt < JT_TT; ++tt) {
+            if (tt < nt) {                                  // (block-uniform)
+                uint4 w;
+                w.x = pack_bf16x2(fast_tanh(e[tt][0] + d0.x), fast_tanh(e[tt][1] + d0.y));
+                w.y = pack_bf16x2(fast_tanh(e[tt][2] + d0.z), fast_tanh(e[tt][3] + d0.w));
+                w.z = pack_bf16x2(fast_tanh(e[tt][4] + d1.x), fast_tanh(e[tt][5] + d1.y));
+                w.w = pack_bf16x2(fast_tanh(e[tt][6] + d1.z), fast_tanh(e[tt][7] + d1.w));
+                *reinterpret_cast<uint4*>(H + ((bt0 + tt) * U1 + u) * J + j) = w;
+                if constexpr (EMIS) {
+                    float hv[8];
+                    unpack_bf16x8(w, hv);
+                    float db = 0.f, dl = 0.f;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                if (o < tpr) { db += __shfl_xor(db, o, 64); dl += __shfl_xor(dl, o, 64); }
-            }
-            if ((tin & 63) == 0) {
-                float* q = part + ((long)u * nw + (tin >> 6)) * 2;
-                q[0] = db; q[1] = dl;
+                    for (int i = 0; i < 8; ++i) { db = fmaf(hv[i], wb[i], db); dl = fmaf(hv[i], wl[i], dl); }
+                    // sum over the lanes of this wave that hold the row (all 64, or an aligned group of tpr = 32): the group's last lane gets it
+                    if (tpr >= 64) { db = dpp_row_sum<true>(db); dl = dpp_row_sum<true>(dl); }
+                    else { db = dpp_row_sum<false>(db); dl = dpp_row_sum<false>(dl); }
+                    if ((tin & 63) == 63 || (tpr == 32 && (tin & 31) == 31)) {
+                        float* q = part + (((long)tt * U1 + u) * nw + (tin >> 6)) * 2;
+                        q[0] = db; q[1] = dl;
+                    }
+                }
             }
         }
     }
     if constexpr (EMIS) {
         __syncthreads();
-        for (int u = threadIdx.x; u < U1; u += 256) {
+        for (int i = threadIdx.x; i < nt * U1; i += 256) {
+            const int tt = i / U1, u = i - tt * U1;
             float sb = 0.f, sl = 0.f;
-            for (int i = 0; i < nw; ++i) { sb += part[((long)u * nw + i) * 2]; sl += part[((long)u * nw + i) * 2 + 1]; }     // fixed order
+            for (int w = 0; w < nw; ++w) { sb += part[((long)i * nw + w) * 2]; sl += part[((long)i * nw + w) * 2 + 1]; }     // fixed order
             int y = em.blank;
             if (u < U1 - 1) {
                 y = em.labels[(long)b * (U1 - 1) + u];
@@ -576,7 +607,7 @@ __global__ __launch_bounds__(256) void joint_tanh_fwd_bf16x8_kernel(const float*
             float2 o;
             o.x = sb + em.bp[em.blank];
             o.y = sl + em.bp[y];
-            *reinterpret_cast<float2*>(em.out + (bt * U1 + u) * 2) = o;
+            *reinterpret_cast<float2*>(em.out + ((bt0 + tt) * U1 + u) * 2) = o;
         }
     }
 }
@@ -976,8 +1007,8 @@ int joint_tanh_fwd(const float* PE, const float* PD, const float* bias, int B, i
         hipLaunchKernelGGL(joint_tanh_fwd_kernel<float>, dim3(B * T), dim3(256), 0, st, PE, PD, bias, T, U1, J,
                            static_cast<float*>(H));
     else if ((J == 256 || J == 512 || J == 1024 || J == 2048) && aligned16(PE) && aligned16(PD) && aligned16(bias) && aligned16(H))
-        hipLaunchKernelGGL(joint_tanh_fwd_bf16x8_kernel<false>, dim3(B * T), dim3(256), 0, st, PE, PD, bias, T, U1, J, static_cast<bf16_t*>(H),
-                           JointEmis());
+        hipLaunchKernelGGL(joint_tanh_fwd_bf16x8_kernel<false>, dim3(B * cdiv(T, JT_TT)), dim3(256), 0, st, PE, PD, bias, T, U1, J,
+                           static_cast<bf16_t*>(H), JointEmis());
     else if (J % 4 == 0 && aligned16(PE) && aligned16(PD) && aligned16(bias) && (reinterpret_cast<uintptr_t>(H) & 7) == 0)
         hipLaunchKernelGGL(joint_tanh_fwd_bf16x4_kernel, dim3(B * T), dim3(256), 0, st, PE, PD, bias, T, U1, J, static_cast<bf16_t*>(H));
     else
@@ -995,10 +1026,12 @@ int joint_tanh_fwd_emis(const float* PE, const float* PD, const float* bias, int
     TTMI_REQUIRE((reinterpret_cast<uintptr_t>(emis) & 7) == 0, "joint_tanh_fwd_emis: emis must be 8-byte aligned");
     JointEmis em;
     em.Wp16 = Wp16; em.bp = bp; em.labels = labels; em.out = emis; em.V = V; em.blank = blank;
-    if ((J == 256 || J == 512 || J == 1024 || J == 2048) && aligned16(PE) && aligned16(PD) && aligned16(bias) && aligned16(H) && aligned16(Wp16)) {
+    const size_t part_bytes = (size_t)JT_TT * U1 * (J / 8 >= 64 ? J / 8 / 64 : 1) * 2 * sizeof(float);
+    if ((J == 256 || J == 512 || J == 1024 || J == 2048) && aligned16(PE) && aligned16(PD) && aligned16(bias) && aligned16(H) && aligned16(Wp16) &&
+        part_bytes <= 60 * 1024) {
         const int nw = J / 8 >= 64 ? J / 8 / 64 : 1;
-        hipLaunchKernelGGL(joint_tanh_fwd_bf16x8_kernel<true>, dim3(B * T), dim3(256), (size_t)U1 * nw * 2 * sizeof(float), st, PE, PD, bias, T,
-                           U1, J, H, em);
+        hipLaunchKernelGGL(joint_tanh_fwd_bf16x8_kernel<true>, dim3(B * cdiv(T, JT_TT)), dim3(256), (size_t)JT_TT * U1 * nw * 2 * sizeof(float), st,
+                           PE, PD, bias, T, U1, J, H, em);
         TTMI_LAUNCH_CHECK("joint_tanh_fwd_bf16x8_kernel<emis>");
         return TTMI_OK;
     }
