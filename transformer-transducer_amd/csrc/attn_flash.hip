@@ -592,6 +592,25 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_rel_kernel(const FlashParams
 // from a slab but recomputed like in flash_fwd_rel_kernel: for a wave's 32 keys and a 32-query tile the p' = L-1-i+j values form one
 // window of 63 table rows; G = Qsel . Eext_window^T is two 32x32 MFMA blocks (rows = queries, columns = p'; q_i below L, q_{i+1} above,
 // both with the other side's table rows zeroed in the block that holds p' = L), skewed through a private LDS image [p'][query].
+// Loads the compiler does not know about (flash_bwd_rel_kernel's tile prefetch): between their issue and their first use a step issues
+// its 64 dS / dG stores, and vmcnt is a 6-bit in-order counter - the compiler's own wait for such a load is vmcnt(0), i.e. it drains all
+// 64 stores once per step.  Issued by asm, the loads are invisible to its scoreboard; the kernel waits for them itself with
+// s_waitcnt vmcnt(63) (everything but the 63 youngest operations, which are stores) and hands the registers over through pg_ready.
+__device__ __forceinline__ u32x4_t ld16_async(const void* p) {
+    u32x4_t v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ float ld4f_async(const void* p) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ int ld4i_async(const void* p) {
+    int v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
 template <int DH, int MK>
 __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams p) {
     using T = Tile<DH>;
@@ -692,34 +711,38 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
         }
         if (tid < 160) ctile[(wbase + tid - L) & 255] = load_c(wbase + tid);
     };
+    // (every load and every park below is executed by ALL threads - 32 rows x NCH chunks = one chunk per thread for Dh = 64; the few
+    // scalars are fetched and parked redundantly by the 8 threads that share tid & 31.  Loads under `if (tid < ..)` put a control-flow
+    // join behind them, and at a join the compiler waits for vmcnt(0): that drained the tile's 64 dS / dG stores once per step.)
+    constexpr bool ALLCH = 32 * T::NCH >= 256;
     auto fetch_bias = [&](int i0) {
-        if (p.debug & 1) return;
         const int wbase = L - 32 - i0 + jw0;
-        if (tid < 32 * T::NCH) {
-            epre = load_chunk(wbase + tid / T::NCH, tid % T::NCH);
-            ppre = *reinterpret_cast<const u32x4_t*>(pbase + (long)min(i0 + 32 + tid / T::NCH, L - 1) * p.ld_qp + (tid % T::NCH) * 8);
+        if (ALLCH || tid < 32 * T::NCH) {
+            int src;
+            ext_row(wbase + tid / T::NCH, src);
+            epre = ld16_async(ebase + (long)src * p.ld_e + (tid % T::NCH) * 8);
+            ppre = ld16_async(pbase + (long)min(i0 + 32 + tid / T::NCH, L - 1) * p.ld_qp + (tid % T::NCH) * 8);
         }
-        if (tid < 32) cpre = load_c(wbase + tid);
+        int srcc;
+        ext_row(wbase + (tid & 31), srcc);
+        cpre = ld4f_async(cbase + srcc);
     };
     int parked_i0 = 0;
     auto park_bias = [&]() {
-        if (p.debug & 1) return;
         const int wbase = L - 32 - parked_i0 + jw0;
-        if (tid < 32 * T::NCH) {
+        if (ALLCH || tid < 32 * T::NCH) {
+            int src;                                              // (rows of the extended table that do not exist read as zero: decided here, after the wait)
+            if (!ext_row(wbase + tid / T::NCH, src)) epre = u32x4_t{0u, 0u, 0u, 0u};
             *reinterpret_cast<u32x4_t*>(etile + T::off((wbase + tid / T::NCH - L) & 255, tid % T::NCH)) = epre;
             *reinterpret_cast<u32x4_t*>(ptile + T::off((parked_i0 + 32 + tid / T::NCH) & 63, tid % T::NCH)) = ppre;
             *reinterpret_cast<u32x4_t*>(qtile + T::off((parked_i0 + 32 + tid / T::NCH) & 63, tid % T::NCH)) = add_u(ppre);
         }
-        if (tid < 32) ctile[(wbase + tid - L) & 255] = cpre;
+        int srcc;
+        ctile[(wbase + (tid & 31) - L) & 255] = ext_row(wbase + (tid & 31), srcc) ? cpre : 0.f;
     };
     // result: the bias in the layout of the score accumulator, which it initialises (S = bias + (q+u).k comes out of the MFMA chain itself: no
     // separate registers for the bias, no add per element)
     auto read_bias = [&](int i0, f32x16& bv) {
-        if (p.debug & 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bv[r] = 0.f;
-            return;
-        }
         const int pe_w = L - 32 - i0 + jw0 + 32 * wave;           // p' of the wave's window column 0
         asm volatile("" ::: "memory");
         auto emit = [&](int blk, const f32x16& g) {               // lane = window column of the block; queries 8 g4 + 4 hh + (0..3): + cext[column], to bf16
@@ -805,30 +828,47 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
         iend = (int)min((long)L, (long)jw0 + 127 + p.mask_left + 1);
         if (iend <= ibeg) { ibeg = 0; iend = 0; }
     }
-    RowStage<DH, 32> stO;
-    stO.load(dobase, p.ld_o, ibeg, L - 1, tid);
-    if (!(p.debug & 1) && ibeg < iend) stage_window(ibeg - 32);        // rows wbase(ibeg) + 32 .. + 191: step(ibeg) parks the 32 below them
+    u32x4_t opre = {0u, 0u, 0u, 0u};                                    // dO rows of the next tile, one 16-byte chunk per thread
+    auto fetch_do = [&](int i0) {
+        if (ALLCH || tid < 32 * T::NCH) opre = ld16_async(dobase + (long)min(i0 + tid / T::NCH, L - 1) * p.ld_o + (tid % T::NCH) * 8);
+    };
+    fetch_do(ibeg);
+    if (ibeg < iend) stage_window(ibeg - 32);        // rows wbase(ibeg) + 32 .. + 191: step(ibeg) parks the 32 below them
     fetch_bias(ibeg);
-    auto step = [&](int i0) {
+    float lse_pre = 0.f, del_pre = 0.f;
+    int lo_pre = 0, hi_pre = 0;
+    auto fetch_rows = [&](int i0) {                                     // log-sum-exp, delta (and the mask interval) of the 32 queries of tile i0
+        const int ii = min(i0 + (tid & 31), L - 1);
+        lse_pre = ld4f_async(p.lse + (long)z * L + ii);
+        del_pre = ld4f_async(p.delta + (long)z * L + ii);
+        if constexpr (MK == 4) {
+            const int* r = reinterpret_cast<const int*>(p.mask) + (long)b * p.mask_sb + 2 * ii;
+            lo_pre = ld4i_async(r);
+            hi_pre = ld4i_async(r + 1);
+        }
+    };
+    fetch_rows(ibeg);
+    auto step = [&](int i0, bool first) {
         __syncthreads();
-        stO.store(dotile, tid);
+        // the prefetched registers: issued one step ago, in front of that step's 64 slab stores (the very first tile: in front of nothing)
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+        asm volatile("" : "+v"(opre), "+v"(epre), "+v"(ppre), "+v"(cpre), "+v"(lse_pre), "+v"(del_pre), "+v"(lo_pre), "+v"(hi_pre));
+        if (ALLCH || tid < 32 * T::NCH) *reinterpret_cast<u32x4_t*>(dotile + T::off(tid / T::NCH, tid % T::NCH)) = opre;
         parked_i0 = i0;
         const char* qcur = qtile + (i0 & 32) * T::ROWB;     // this tile's 32 (q+u) rows inside the ring (same swizzle phase: 32 rows = 4 periods)
         park_bias();
-        if (tid < 32) {
-            const int ii = min(i0 + tid, L - 1);
-            lse_s[tid] = p.lse[(long)z * L + ii];
-            del_s[tid] = p.delta[(long)z * L + ii];
-            if constexpr (MK == 4) {
-                const int* r = reinterpret_cast<const int*>(p.mask) + (long)b * p.mask_sb + 2 * ii;
-                lo_s[tid] = r[0];
-                hi_s[tid] = r[1];
-            }
+        lse_s[tid & 31] = lse_pre;                                  // the tile's row statistics arrived with its operands (not a load between two barriers)
+        del_s[tid & 31] = del_pre;
+        if constexpr (MK == 4) {
+            lo_s[tid & 31] = lo_pre;
+            hi_s[tid & 31] = hi_pre;
         }
         __syncthreads();
         if (i0 + 32 < iend) {                                       // next tile's operands and bias fly under this tile's MFMAs
-            stO.load(dobase, p.ld_o, i0 + 32, L - 1, tid);
+            fetch_do(i0 + 32);
             fetch_bias(i0 + 32);
+            fetch_rows(i0 + 32);
         }
         f32x16 s, dp;
         read_bias(i0, s);
@@ -850,7 +890,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
         const int s_ds = i0 * ldp * 2, s_dg = i0 * (ldp - 1) * 2;                                       // row part (wave-uniform)
         // pad columns [L, ldp) of both bf16 slabs feed the K loop of the dq / dE products and must be zero: the lanes whose key index falls
         // there write the zeros (no separate strided memsets over B*H*L rows)
-        if (!kvalid && j < ldp && !(p.debug & 2)) {
+        if (!kvalid && j < ldp) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cq = (r & 3) + 8 * (r >> 2);
@@ -862,7 +902,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
         }
         // interior tiles (all 32 queries and all 128 keys of the workgroup in range, the j == i+1 diagonal not crossing the tile) take a
         // branch-free element loop; edge and diagonal tiles the general one
-        const bool interior = (i0 + 32 <= L) && (jw0 > i0 + 32 || jw0 + 127 < i0 + 1) && !(p.debug & 2);
+        const bool interior = (i0 + 32 <= L) && (jw0 > i0 + 32 || jw0 + 127 < i0 + 1);
         if (interior) {
             // all 32 queries in range, the whole tile on one side of the j == i+1 diagonal: branch-free score loop, then ONE predicated
             // region for the lanes whose key exists
@@ -903,7 +943,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
                         ds = pr * (dp[r] - del_s[q]) * p.scale;
                     }
                 }
-                if (!(p.debug & 2)) {
+                {
                     const bf16_t d16 = f32_to_bf16(ds);
                     __builtin_amdgcn_raw_buffer_store_b16(d16, rs_ds, inb ? v_ds : OOB, s_ds + cq * ldp * 2, 0);
                     __builtin_amdgcn_raw_buffer_store_b16(d16, rs_dg, (inb && j != i + 1) ? (j <= i ? v_lo : v_hi) : OOB, s_dg + cq * (ldp - 1) * 2, 0);
@@ -926,8 +966,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
         }
     };
     for (int i0 = ibeg; i0 < iend; i0 += 64) {
-        step(i0);
-        if (i0 + 32 < iend) step(i0 + 32);
+        step(i0, i0 == ibeg);
+        if (i0 + 32 < iend) step(i0 + 32, false);
     }
     if (kvalid) {
         float* dkrow = p.dK + ((long)b * L + j) * p.ld_dkv + h * DH;
