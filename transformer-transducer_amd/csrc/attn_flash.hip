@@ -667,6 +667,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
     constexpr unsigned OOB = 0xFFFFFF00u;
 
     const int ldp = (int)p.ldp;
+    const float c2 = p.scale * 1.4426950408889634f;                         // scale * log2(e)
     int* lo_s = reinterpret_cast<int*>(del_s + 32);                          // MK == 4: the tile's 32 (lo, hi) pairs
     int* hi_s = lo_s + 32;
     constexpr int GPB = 36;                                                  // image row pitch in bf16 (32 queries + 4): 72 bytes
@@ -745,22 +746,24 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
     auto read_bias = [&](int i0, f32x16& bv) {
         const int pe_w = L - 32 - i0 + jw0 + 32 * wave;           // p' of the wave's window column 0
         asm volatile("" ::: "memory");
-        auto emit = [&](int blk, const f32x16& g) {               // lane = window column of the block; queries 8 g4 + 4 hh + (0..3): + cext[column], to bf16
-            const float cv = ctile[(pe_w + 32 * blk + (lane & 31) - L) & 255];
+        // lane = window column of the block; cext[column] is the accumulators' INITIAL value (the chain adds q . E onto it: no add per element)
+        auto cinit = [&](int blk) -> float { return ctile[(pe_w + 32 * blk + (lane & 31) - L) & 255]; };
+        auto emit = [&](int blk, const f32x16& g) {               // queries 8 g4 + 4 hh + (0..3) of this column, to bf16
             bf16_t* col = gs + (32 * blk + (lane & 31)) * GPB;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 uint2 w;
-                w.x = pack_bf16x2(g[4 * g4] + cv, g[4 * g4 + 1] + cv);
-                w.y = pack_bf16x2(g[4 * g4 + 2] + cv, g[4 * g4 + 3] + cv);
+                w.x = pack_bf16x2(g[4 * g4], g[4 * g4 + 1]);
+                w.y = pack_bf16x2(g[4 * g4 + 2], g[4 * g4 + 3]);
                 *reinterpret_cast<uint2*>(col + 8 * g4 + 4 * hh) = w;
             }
         };
         const bool all_low = pe_w + 63 <= L - 1, all_up = pe_w >= L + 1;
         if (all_low || all_up) {                                  // both blocks on one side of p' = L: two independent MFMA chains, interleaved
             f32x16 g0, g1;
+            const float c0v = cinit(0), c1v = cinit(1);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { g0[r] = c0v; g1[r] = c1v; }
             const int qrow = (i0 + (lane & 31) + (all_low ? 0 : 1)) & 63;
             const int e0 = (pe_w + (lane & 31) - L) & 255, e1 = (pe_w + 32 + (lane & 31) - L) & 255;
 #pragma unroll
@@ -778,8 +781,9 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
         for (int blk = 0; blk < 2; ++blk) {
             const int pe0 = pe_w + 32 * blk;
             f32x16 g;
+            const float cv = cinit(blk);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) g[r] = 0.f;
+            for (int r = 0; r < 16; ++r) g[r] = cv;
             const int erow = (pe0 + (lane & 31) - L) & 255;          // ring slot of this lane's table row
             if (pe0 + 31 <= L - 1) {
 #pragma unroll
@@ -817,7 +821,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qi = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            bv[r] = bf16_to_f32(gs[(31 - qi + (lane & 31)) * GPB + qi]);
+            const float v = bf16_to_f32(gs[(31 - qi + (lane & 31)) * GPB + qi]);
+            bv[r] = kvalid ? v : NEGBIG;                          // a key that does not exist: exp2 underflows to 0, so P = dS = 0 with no further test
         }
     };
     // narrow structured masks (launcher's choice, p.bwd_skip): both bf16 slabs were zeroed up front and only the query tiles that can see
@@ -858,8 +863,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
         parked_i0 = i0;
         const char* qcur = qtile + (i0 & 32) * T::ROWB;     // this tile's 32 (q+u) rows inside the ring (same swizzle phase: 32 rows = 4 periods)
         park_bias();
-        lse_s[tid & 31] = lse_pre;                                  // the tile's row statistics arrived with its operands (not a load between two barriers)
-        del_s[tid & 31] = del_pre;
+        lse_s[tid & 31] = lse_pre * 1.4426950408889634f;            // the tile's row statistics arrived with its operands; parked pre-multiplied:
+        del_s[tid & 31] = del_pre * p.scale;                        // p = exp2(s c2 - lse log2 e), dS = p (dP scale - delta scale)
         if constexpr (MK == 4) {
             lo_s[tid & 31] = lo_pre;
             hi_s[tid & 31] = hi_pre;
@@ -911,12 +916,11 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
                 const int q = (r & 3) + 8 * (r >> 2) + 4 * hh;
                 float pr = 0.f, ds = 0.f;
                 if (!(MK == 4 ? (j < lo_s[q] || j > hi_s[q]) : is_masked<MK>(p, b, i0 + q, j))) {
-                    const float sc = s[r] * p.scale;
-                    pr = __expf(sc - lse_s[q]);
-                    ds = pr * (dp[r] - del_s[q]) * p.scale;
+                    pr = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse_s[q]));
+                    ds = pr * fmaf(dp[r], p.scale, -del_s[q]);
                 }
-                s[r] = kvalid ? pr : 0.f;
-                dp[r] = kvalid ? ds : 0.f;
+                s[r] = pr;
+                dp[r] = ds;
             }
             {
                 const unsigned v_g = jw0 < i0 ? v_lo : v_hi;
@@ -938,9 +942,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
                 float pr = 0.f, ds = 0.f;
                 if (inb) {
                     if (!(MK == 4 ? (j < lo_s[q] || j > hi_s[q]) : is_masked<MK>(p, b, i, j))) {
-                        const float sc = s[r] * p.scale;
-                        pr = __expf(sc - lse_s[q]);
-                        ds = pr * (dp[r] - del_s[q]) * p.scale;
+                        pr = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse_s[q]));
+                        ds = pr * fmaf(dp[r], p.scale, -del_s[q]);
                     }
                 }
                 {
