@@ -320,6 +320,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_rel_kernel(const FlashParams
     bf16_t* gs = gs_all + wave * 32 * GP + ii * GP;            // this lane's query row of the wave's private image
     const int z = blockIdx.y, b = z / p.H, h = z % p.H;
     const int L = p.L;
+    const float c2 = p.scale * 1.4426950408889634f;            // scale * log2(e)
     const int i0w = blockIdx.x * 128;
     const int i = i0w + wave * 32 + ii;
     const int ic = min(i, L - 1);
@@ -408,14 +409,22 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_rel_kernel(const FlashParams
         if (p.debug & 1) return;
         asm volatile("" ::: "memory");                         // (the image is written as uint2 and read as bf16: keep the compiler from reordering across)
         const int pe_w = L - 128 - i0w + j0 + eoff;            // p' of the wave's window row 0
-        auto emit = [&](int blk, const f32x16& g) {            // + cext, to bf16, into this lane's image row: window columns 32 blk + 8 g4 + 4 hh + (0..3)
+        // cext of the block's window columns is the accumulators' INITIAL value (the chain adds E . q onto it: no add per element afterwards)
+        auto cinit = [&](int blk, f32x16& g) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int col = 32 * blk + 8 * g4 + 4 * hh;
                 const float4 cv = *reinterpret_cast<const float4*>(ctile + ((pe_w + col - L) & 255));     // slots count from p' - L: a multiple of 4 here
+                g[4 * g4] = cv.x; g[4 * g4 + 1] = cv.y; g[4 * g4 + 2] = cv.z; g[4 * g4 + 3] = cv.w;
+            }
+        };
+        auto emit = [&](int blk, const f32x16& g) {            // to bf16, into this lane's image row: window columns 32 blk + 8 g4 + 4 hh + (0..3)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int col = 32 * blk + 8 * g4 + 4 * hh;
                 uint2 w;
-                w.x = pack_bf16x2(g[4 * g4] + cv.x, g[4 * g4 + 1] + cv.y);
-                w.y = pack_bf16x2(g[4 * g4 + 2] + cv.z, g[4 * g4 + 3] + cv.w);
+                w.x = pack_bf16x2(g[4 * g4], g[4 * g4 + 1]);
+                w.y = pack_bf16x2(g[4 * g4 + 2], g[4 * g4 + 3]);
                 *reinterpret_cast<uint2*>(gs + col) = w;
             }
         };
@@ -424,8 +433,9 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_rel_kernel(const FlashParams
             // the common case (the tile is wholly below or wholly above the j = i + 1 diagonal): three independent accumulator chains, their
             // MFMAs interleaved - a block's four dependent MFMAs alone leave the pipe idle for the accumulator latency
             f32x16 g0, g1, g2;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; g2[r] = 0.f; }
+            cinit(0, g0);
+            cinit(1, g1);
+            cinit(2, g2);
             const int e0 = (pe_w + ii - L) & 255, e1 = (pe_w + 32 + ii - L) & 255, e2 = (pe_w + 64 + ii - L) & 255;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -445,8 +455,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_rel_kernel(const FlashParams
         for (int blk = 0; blk < 3; ++blk) {
             const int pe0 = pe_w + 32 * blk;
             f32x16 g;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) g[r] = 0.f;
+            cinit(blk, g);
             const int erow = (pe0 + ii - L) & 255;             // ring slot of this lane's table row
             if (pe0 + 31 <= L - 1) {
 #pragma unroll
@@ -492,32 +501,53 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_rel_kernel(const FlashParams
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ktile + T::off(32 * sub + (lane & 31), 2 * ks + hh));
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
         }
+        // The running maximum m is kept in log2 units (score * scale * log2 e) and is only RAISED when a sub-tile beats it by more than 8
+        // (P then stays below 2^8: harmless in f32 sums and in the bf16 operand, whose rounding is relative): most sub-tiles rescale nothing.
+        const bool plain = MK == 0 && jb + 32 <= L;                 // wave-uniform: no key of the sub-tile is masked or beyond the sequence
         float pmax = NEGBIG;
+        if (plain) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            float v = NEGBIG;
-            const bool msk = MK == 4 ? (j < mlo || j > mhi) : is_masked<MK>(p, b, ic, j);
-            if (j < L && !msk) v = s[r] * p.scale;
-            s[r] = v;
-            pmax = fmaxf(pmax, v);
+            for (int r = 0; r < 16; ++r) pmax = fmaxf(pmax, s[r]);
+            pmax *= c2;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float v = NEGBIG;
+                const bool msk = MK == 4 ? (j < mlo || j > mhi) : is_masked<MK>(p, b, ic, j);
+                if (j < L && !msk) v = s[r] * c2;
+                s[r] = v;
+                pmax = fmaxf(pmax, v);
+            }
         }
         pmax = fmaxf(pmax, __shfl_xor(pmax, 32, 64));
-        const float mn = fmaxf(m, pmax);
-        const float alpha = __expf(m - mn);
-        float psum = 0.f;
+        const float mn = pmax > m + 8.f ? pmax : m;
+        if (__builtin_amdgcn_ballot_w64(mn != m)) {
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            l *= alpha;
+            m = mn;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float pr = s[r] > 0.5f * NEGBIG ? __expf(s[r] - mn) : 0.f;
-            s[r] = pr;
-            psum += pr;
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
         }
-        l = l * alpha + psum;
-        m = mn;
+        float psum = 0.f;
+        if (plain) {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+            for (int r = 0; r < 16; ++r) {
+                const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -m));
+                s[r] = pr;
+                psum += pr;
+            }
+        } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            for (int r = 0; r < 16; ++r) {
+                const float pr = s[r] > 0.5f * NEGBIG ? __builtin_amdgcn_exp2f(s[r] - m) : 0.f;
+                s[r] = pr;
+                psum += pr;
+            }
+        }
+        l += psum;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const bf16x8 pb = pack8(s, 8 * s2);
@@ -583,7 +613,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_rel_kernel(const FlashParams
                 w.y = pack_bf16x2(o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
                 *reinterpret_cast<uint2*>(orow + d) = w;
             }
-        if (hh == 0) p.lse[(long)z * L + i] = m + __logf(l);
+        if (hh == 0) p.lse[(long)z * L + i] = m * 0.6931471805599453f + __logf(l);
     }
 }
 
