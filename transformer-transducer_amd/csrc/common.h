@@ -52,8 +52,11 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// Counter-based dropout: keep element `idx` of dropout site `seed` iff hash(seed, idx) >= p * 2^32.
-// Stateless, so the backward pass regenerates the identical mask from (seed, idx).  Returns 0 or 1/(1-p).
+// Counter-based dropout.  ONE 32-bit hash word serves an aligned group of four consecutive elements: element idx is kept iff
+//     rotl(hash(seed, idx >> 2), 8 (idx & 3)) ^ K[idx & 3]  >=  p * 2^32
+// (the finalizer's bytes are mixed, so the four rotations decide near-independently; v_mul_lo_u32 is quarter rate and the hash has four of
+// them, which made the mask the bound of the LayerNorm kernels while every element had its own word).  Stateless: the backward pass
+// regenerates the identical mask from (seed, idx).  Multipliers are 0 or 1/(1-p).
 struct DropSpec {
     float p = 0.f;            // drop probability (0 = disabled)
     unsigned seed = 0;
@@ -62,7 +65,7 @@ struct DropSpec {
     // still draws new masks (forward and backward of one step read the same value)
     const unsigned* salt = nullptr;
 };
-// call ONCE at kernel entry (one scalar load), then use the result with drop_mult
+// call ONCE at kernel entry (one scalar load), then use the result with drop_mult / drop_mult4
 __device__ __forceinline__ DropSpec drop_live(DropSpec d) {
     if (d.p > 0.f && d.salt) d.seed ^= *d.salt * 0x9E3779B1u;
     d.salt = nullptr;
@@ -73,10 +76,29 @@ __host__ __device__ __forceinline__ unsigned ttmi_hash32(unsigned seed, unsigned
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
 }
+__host__ __device__ __forceinline__ unsigned drop_lane_word(unsigned h, unsigned k) {      // k = idx & 3
+    const unsigned r = (h << (8u * k)) | (h >> ((32u - 8u * k) & 31u));
+    return r ^ (k * 0x9E3779B9u);
+}
 __host__ __device__ __forceinline__ float drop_mult(const DropSpec& d, unsigned long long idx) {
     if (d.p <= 0.f) return 1.f;
     const unsigned thresh = (unsigned)(d.p * 4294967296.0);
-    return ttmi_hash32(d.seed, idx) >= thresh ? 1.f / (1.f - d.p) : 0.f;
+    return drop_lane_word(ttmi_hash32(d.seed, idx >> 2), (unsigned)idx & 3u) >= thresh ? 1.f / (1.f - d.p) : 0.f;
+}
+// the multipliers of elements idx .. idx + 3: one hash word when idx is a multiple of four (the vector paths), four otherwise
+__host__ __device__ __forceinline__ void drop_mult4(const DropSpec& d, unsigned long long idx, float (&m)[4]) {
+    if (d.p <= 0.f) { m[0] = m[1] = m[2] = m[3] = 1.f; return; }
+    if ((idx & 3ull) == 0) {
+        const unsigned thresh = (unsigned)(d.p * 4294967296.0);
+        const float keep = 1.f / (1.f - d.p);
+        const unsigned h = ttmi_hash32(d.seed, idx >> 2);
+        m[0] = h >= thresh ? keep : 0.f;
+        m[1] = (((h << 8) | (h >> 24)) ^ 0x9E3779B9u) >= thresh ? keep : 0.f;
+        m[2] = (((h << 16) | (h >> 16)) ^ (2u * 0x9E3779B9u)) >= thresh ? keep : 0.f;
+        m[3] = (((h << 24) | (h >> 8)) ^ (3u * 0x9E3779B9u)) >= thresh ? keep : 0.f;
+    } else {
+        for (int j = 0; j < 4; ++j) m[j] = drop_mult(d, idx + j);
+    }
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -644,8 +644,10 @@ __device__ __forceinline__ void epi_store4(const FP& p, TC* C, int m, int n0, f3
             }
         }
         if (p.drop.p > 0.f) {
+            float dm[4];
+            drop_mult4(p.drop, (unsigned long long)ci, dm);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= drop_mult(p.drop, (unsigned long long)(ci + j));
+            for (int j = 0; j < 4; ++j) v[j] *= dm[j];
         }
         if constexpr (sizeof(TC) == 4) {
             const f32x4 o = {v[0], v[1], v[2], v[3]};
@@ -702,8 +704,10 @@ __device__ __forceinline__ void epi_math4(const FP& p, int m, int n0, f32x4 x, f
         }
     }
     if (p.drop.p > 0.f) {
+        float dm[4];
+        drop_mult4(p.drop, (unsigned long long)ci, dm);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] *= drop_mult(p.drop, (unsigned long long)(ci + j));
+        for (int j = 0; j < 4; ++j) v[j] *= dm[j];
     }
 }
 

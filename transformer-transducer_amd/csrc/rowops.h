@@ -15,9 +15,17 @@ struct MaskDesc {
 // y = LN(x + res) * g + b ; optionally stores s = x + res, mean, rstd (for backward)
 // y (f32, optional) and/or y16 (bf16, optional) receive the normalised output
 // res_drop: dropout applied to `res` before the add; out_drop: dropout applied to the normalised output
+// pre (optional): a second norm of the SAME row in the same pass - h16 = bf16(LN(y; pre->g, pre->b)), its statistics to pre->mean / rstd
+struct LnPreNorm {
+    const float* g = nullptr;
+    const float* b = nullptr;
+    bf16_t* h16 = nullptr;
+    float* mean = nullptr;
+    float* rstd = nullptr;
+};
 int ln_fwd(const float* x, const float* res, const float* g, const float* b, long rows, int d, float eps, float* s_out,
            float* y, float* mean, float* rstd, hipStream_t st, bf16_t* y16 = nullptr, DropSpec res_drop = DropSpec(),
-           DropSpec out_drop = DropSpec());
+           DropSpec out_drop = DropSpec(), const LnPreNorm* pre = nullptr);
 // dx = dadd + LN'(dy) ; dgamma/dbeta accumulated atomically (caller zeroes them once per step)
 // dy_drop: the forward applied dropout to the LN output, so dy is masked/scaled identically on the way in
 // dx16 (optional, bf16 pipeline): bf16(dx * dropout(dx16_drop)) - the masked gradient the following GEMMs consume - and, with
