@@ -166,6 +166,32 @@ int ttmi_ffn_bwd_defer(const float* dz, const float* y, const float* w1, const f
                        float* g_b1, float* g_w2, float* g_b2, float* g_ln_g, float* g_ln_b, void* keep,
                        ttmi_wgrad_desc* out /* 2 entries */, void* stream);
 
+/* ---- one encoder layer per call: RelLearnableDecoderLayer.forward (tt/transformer.py:188-197) = ttmi_attn_fwd + ttmi_ffn_fwd, and
+ * their backward, behind ONE entry each.  Where ttmi_layer_fused() is 1 (bf16 pipeline, d % 4 == 0, d <= 512) the calls share three passes
+ * the sub-layer boundary forces apart: the FFN's pre-norm comes out of the attention sub-layer's post-norm pass, the two LayerNorm backward
+ * passes that meet at y are one kernel (dy is never stored), and the bf16 copy of the layer's input is taken from its producer (x16_in: bf16
+ * [B*L, d] or NULL; z16_out: bf16 [B*L, d] or NULL - hand a layer's z16_out to the next layer as x16_in, to forward AND backward).
+ * Otherwise they run the sub-layer calls back to back.  ctx_attn / ctx_ffn: ttmi_attn_ctx_floats / ttmi_ffn_ctx_floats, saved for backward;
+ * ws: ttmi_layer_ws_floats; y ([B, L, d], the attention sub-layer's output) is an output of forward and an input of backward.
+ * ttmi_layer_bwd with keep_attn / keep_ffn / out (ttmi_*_bwd_keep_bytes; 4 descriptors: CoreNet.3, CoreNet.0, o_net, qkv_net) defers the
+ * weight-gradient GEMMs as ttmi_*_bwd_defer do; all three NULL runs them here. */
+int ttmi_layer_fused(int d, int H, int Dh, int Di, int prec);
+size_t ttmi_layer_ws_floats(int B, int L, int d, int H, int Dh, int Di, int prec);
+int ttmi_layer_fwd(const float* x, const void* x16_in, const float* qkv_w, const float* o_w, const float* ln_g, const float* ln_b, const float* r_emb,
+                   const float* r_w_bias, const float* r_bias, const float* w1, const float* b1, const float* w2, const float* b2,
+                   const float* ff_ln_g, const float* ff_ln_b, int B, int L, int d, int H, int Dh, int K, int Di, int mask_kind, int mask_left,
+                   int mask_right, const unsigned char* mask, long mask_sb, long mask_si, int prec, float p_drop_attn, unsigned seed_attn,
+                   float p_drop_ffn, float p_layer, unsigned seed_ffn, float* ctx_attn, float* ctx_ffn, float* ws, float* y, float* z,
+                   void* z16_out, void* stream);
+int ttmi_layer_bwd(const float* dz, const float* x, const void* x16_in, const float* y, const float* qkv_w, const float* o_w, const float* ln_g,
+                   const float* r_emb, const float* r_w_bias, const float* r_bias, const float* w1, const float* w2, const float* ff_ln_g, int B,
+                   int L, int d, int H, int Dh, int K, int Di, int mask_kind, int mask_left, int mask_right, const unsigned char* mask,
+                   long mask_sb, long mask_si, int prec, float p_drop_attn, unsigned seed_attn, float p_drop_ffn, float p_layer,
+                   unsigned seed_ffn, const float* ctx_attn, const float* ctx_ffn, float* ws, float* dx, float* g_qkv_w, float* g_o_w,
+                   float* g_ln_g, float* g_ln_b, float* g_r_emb, float* g_r_w_bias, float* g_r_bias, float* g_w1, float* g_b1, float* g_w2,
+                   float* g_b2, float* g_ff_ln_g, float* g_ff_ln_b, void* keep_attn, void* keep_ffn, ttmi_wgrad_desc* out /* 4 entries */,
+                   void* stream);
+
 /* ---- greedy decoding support (Transducer.decode, tt/model.py:70-90): logits rows = consecutive frames against one label
  * state; *out (device u64) = (first row whose argmax != blank) << 32 | symbol, or n << 32 if all rows are blank. */
 int ttmi_greedy_scan(const void* logits, int dtype, long ld, int n, int V, int blank, unsigned long long* out, void* stream);

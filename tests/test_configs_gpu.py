@@ -199,15 +199,15 @@ def test_c2_full_model_fp32_end_to_end(monkeypatch):
     inp = torch.randn(B, T, 512, generator=gen)
     tgt = torch.randint(1, V, (B, U), generator=gen)
     tl, ul = np.array([T, 431], dtype=np.int32), np.array([U, 37], dtype=np.int32)
-    saved = []                                               # (ctx, rows, d, Di) of every FFN forward, in host issue order
-    real_ffn_fwd = ops.ffn_fwd
+    saved = []                                               # (FFN ctx, rows, d, Di) of every layer's forward, in host issue order
+    real_layer_fwd = ops.layer_fwd
 
-    def spy(y, p, prec, *a, **k):
-        z, ctx = real_ffn_fwd(y, p, prec, *a, **k)
-        saved.append((ctx, y.numel() // y.shape[-1], y.shape[-1], p["ff_w1"].shape[0], tuple(y.shape[:-1])))
-        return z, ctx
+    def spy(x, x16, pa, pf, *a, **k):
+        out = real_layer_fwd(x, x16, pa, pf, *a, **k)
+        saved.append((out[4], x.numel() // x.shape[-1], x.shape[-1], pf["ff_w1"].shape[0], tuple(x.shape[:-1])))
+        return out
 
-    monkeypatch.setattr(ops, "ffn_fwd", spy)
+    monkeypatch.setattr(ops, "layer_fwd", spy)
     x = inp.cuda().requires_grad_(True)
     logits = model(x, tgt.cuda())
     loss = RNNTLoss()(logits, tgt.int().cuda(), torch.tensor(tl).cuda(), torch.tensor(ul).cuda())

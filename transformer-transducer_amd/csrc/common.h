@@ -41,10 +41,18 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
 
+// sum over the 64 lanes, returned in every lane: five DPP adds inside the rows of 16, two row broadcasts, one readlane (the __shfl_xor
+// butterfly is six ds_bpermute round trips through the LDS crossbar; the LayerNorm kernels chain two to four of these per row)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+#define TTMI_DPP_ADD(ctrl, rmask) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, false))
+    TTMI_DPP_ADD(0xB1, 0xF);      // quad_perm [1,0,3,2]
+    TTMI_DPP_ADD(0x4E, 0xF);      // quad_perm [2,3,0,1]
+    TTMI_DPP_ADD(0x141, 0xF);     // row_half_mirror
+    TTMI_DPP_ADD(0x140, 0xF);     // row_mirror: every lane holds its row's sum
+    TTMI_DPP_ADD(0x142, 0xA);     // row_bcast:15 into rows 1 and 3
+    TTMI_DPP_ADD(0x143, 0xC);     // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+#undef TTMI_DPP_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

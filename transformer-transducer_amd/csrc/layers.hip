@@ -255,6 +255,12 @@ struct AttnWs {   // scratch (union of forward and backward needs)
 };
 
 
+// what the layer-level backward hands the attention sub-layer instead of dy (ln_bwd_pair): the FFN's pre-norm operands and gradient targets
+struct LnPairIn {
+    const float *dh, *y, *mean1, *rstd1, *g1, *dres1;
+    float *dgamma1, *dbeta1;
+};
+
 FlashParams flash_params(const AttnDims& a, const AttnCtx& c, float scale, int mask_kind, int mask_left, int mask_right,
                          const unsigned char* mask, long mask_sb, long mask_si) {
     FlashParams f;
@@ -318,10 +324,13 @@ size_t ttmi_attn_ws_floats(int B, int L, int d, int H, int Dh, int prec) {
 // mask_kind: 0 none, 1 causal (look_ahead_mask), 2 band(left,right) (context_mask), 3 uint8 tensor (b,i,j) at
 // mask[b*mask_sb + i*mask_si + j], nonzero = masked.  prec: 0 = exact-f32 MFMA, 1 = bf16 MFMA (bf16 q/k/v/O in HBM,
 // dense projections on the glds kernels).  ctx/ws must be 256-byte aligned.
-int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const float* ln_g, const float* ln_b,
+// x16_in (optional, bf16 pipeline): the bf16 copy of x, made by whoever produced x (the previous layer's last norm): no conversion pass here.
+// pre (optional): the norm the NEXT sub-layer applies to y (the FFN's pre-norm), formed in the same pass as y.
+static int attn_fwd_impl(const float* x, const float* qkv_w, const float* o_w, const float* ln_g, const float* ln_b,
                   const float* r_emb, const float* r_w_bias, const float* r_bias, int B, int L, int d, int H, int Dh, int K,
                   int mask_kind, int mask_left, int mask_right, const unsigned char* mask, long mask_sb, long mask_si,
-                  int prec, float p_drop, unsigned seed, float* ctx, float* ws, float* y, void* stream) {
+                  int prec, float p_drop, unsigned seed, float* ctx, float* ws, float* y, const bf16_t* x16_in, const LnPreNorm* pre,
+                  void* stream) {
     TTMI_REQUIRE(x && qkv_w && o_w && ln_g && ln_b && r_emb && r_w_bias && r_bias && ctx && ws && y, "attn_fwd: null pointer");
     TTMI_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "attn_fwd: dropout probability %f outside [0,1)", p_drop);
     TTMI_REQUIRE(B > 0 && L > 0 && d > 0 && H > 0 && Dh > 0 && K > 0, "attn_fwd: bad dims");
@@ -336,13 +345,15 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
     AttnWs w(bw, a, fast);
     const float scale = 1.0f / sqrtf((float)Dh);
     // 1. qkv = x Wqkv^T ; 2. qu = q + r_w_bias
+    TTMI_REQUIRE(!x16_in || (fast && aligned16(x16_in)), "attn_fwd: a bf16 copy of x is taken by the bf16 pipeline only (16-byte aligned)");
     if (fast) {
-        CK(convert_bf16(x, c.x16, a.BL * d, st));
+        if (!x16_in) CK(convert_bf16(x, c.x16, a.BL * d, st));
+        const bf16_t* x16 = x16_in ? x16_in : c.x16;
         Shadow sh;
         const bf16_t* wqkv16 = w.wqkv16;
         if (shadow_of(qkv_w, (int)a.W3, d, a.W3, sh)) wqkv16 = sh.w16;                          // kept current by the optimiser step
         else CK(transpose_convert_bf16(qkv_w, (int)a.W3, d, c.wqkvT16, a.W3, st, w.wqkv16));   // Wqkv (bf16) and Wqkv^T [d, W3] for backward
-        CK(gemm_nt_bf16(c.x16, wqkv16, c.qkv, 1, nullptr, (int)a.BL, (int)a.W3, d, d, d, a.W3, st));
+        CK(gemm_nt_bf16(x16, wqkv16, c.qkv, 1, nullptr, (int)a.BL, (int)a.W3, d, d, d, a.W3, st));
         if (!attn_inkernel(fast, a))
             CK(add_row_bias_bf16(static_cast<bf16_t*>(c.qkv), a.W3, r_w_bias, a.BL, (int)a.HD, static_cast<bf16_t*>(c.qu), a.HD, st));
     } else {
@@ -412,8 +423,16 @@ int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const fl
     }
     DropSpec rd;                                            // self.drop(attn_out), tt/transformer.py:173
     rd.p = p_drop; rd.seed = seed ^ 0xA1u; rd.salt = g_drop_salt;
-    CK(ln_fwd(x, w.a, ln_g, ln_b, a.BL, d, 1e-5f, c.s1, y, c.mean, c.rstd, st, nullptr, rd));
+    CK(ln_fwd(x, w.a, ln_g, ln_b, a.BL, d, 1e-5f, c.s1, y, c.mean, c.rstd, st, nullptr, rd, DropSpec(), pre));
     return TTMI_OK;
+}
+
+int ttmi_attn_fwd(const float* x, const float* qkv_w, const float* o_w, const float* ln_g, const float* ln_b,
+                  const float* r_emb, const float* r_w_bias, const float* r_bias, int B, int L, int d, int H, int Dh, int K,
+                  int mask_kind, int mask_left, int mask_right, const unsigned char* mask, long mask_sb, long mask_si,
+                  int prec, float p_drop, unsigned seed, float* ctx, float* ws, float* y, void* stream) {
+    return attn_fwd_impl(x, qkv_w, o_w, ln_g, ln_b, r_emb, r_w_bias, r_bias, B, L, d, H, Dh, K, mask_kind, mask_left, mask_right, mask, mask_sb,
+                         mask_si, prec, p_drop, seed, ctx, ws, y, nullptr, nullptr, stream);
 }
 
 // Backward of ttmi_attn_fwd.  dx is written; every g_* buffer is ACCUMULATED into (zero them per step).
@@ -423,8 +442,8 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
                   int mask_left, int mask_right, const unsigned char* mask, long mask_sb, long mask_si, int prec,
                   float p_drop, unsigned seed, const float* ctx, float* ws, float* dx, float* g_qkv_w, float* g_o_w,
                   float* g_ln_g, float* g_ln_b, float* g_r_emb, float* g_r_w_bias, float* g_r_bias, void* keep, ttmi_wgrad_desc* out,
-                  void* stream) {
-    TTMI_REQUIRE(dy && x && qkv_w && o_w && ln_g && r_emb && r_bias && ctx && ws && dx, "attn_bwd: null pointer");
+                  void* stream, const bf16_t* x16_in = nullptr, const LnPairIn* pair = nullptr) {
+    TTMI_REQUIRE((dy || pair) && x && qkv_w && o_w && ln_g && r_emb && r_bias && ctx && ws && dx, "attn_bwd: null pointer");
     TTMI_REQUIRE(g_qkv_w && g_o_w && g_ln_g && g_ln_b && g_r_emb && g_r_w_bias && g_r_bias, "attn_bwd: null gradient pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const AttnDims a(B, L, d, H, Dh, K);
@@ -440,7 +459,14 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
     //    the bf16 pipeline gets da from the same pass
     DropSpec rd;
     rd.p = p_drop; rd.seed = seed ^ 0xA1u; rd.salt = g_drop_salt;
-    CK(ln_bwd(dy, c.s1, c.mean, c.rstd, ln_g, nullptr, a.BL, d, dx, g_ln_g, g_ln_b, st, DropSpec(), fast ? w.dres16 : nullptr, rd, nullptr));
+    if (pair) {          // the layer-level call: dy is still in two pieces (the FFN's pre-norm input gradient and its residual branch)
+        TTMI_REQUIRE(fast, "attn_bwd: the paired LayerNorm backward belongs to the bf16 pipeline");
+        CK(ln_bwd_pair(pair->dh, pair->y, pair->mean1, pair->rstd1, pair->g1, pair->dres1, c.s1, c.mean, c.rstd, ln_g, a.BL, d, dx, pair->dgamma1,
+                       pair->dbeta1, g_ln_g, g_ln_b, w.dres16, rd, st));
+    } else {
+        CK(ln_bwd(dy, c.s1, c.mean, c.rstd, ln_g, nullptr, a.BL, d, dx, g_ln_g, g_ln_b, st, DropSpec(), fast ? w.dres16 : nullptr, rd, nullptr));
+    }
+    const bf16_t* x16 = x16_in ? x16_in : c.x16;
     const float* da = dx;
     if (!fast && p_drop > 0.f) {
         CK(dropout_apply(dx, a.BL * d, rd, w.a, nullptr, st));
@@ -590,9 +616,9 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
     // 14. gWqkv += dqkv^T x ; 15. dx += dqkv Wqkv
     if (fast) {
         if (!fastpos) CK(convert_bf16(w.dqkv, w.dqkv16, a.BL * a.W3, st));      // fastpos: dq / dK / dV were written in bf16 by their producers
-        if (out) out[1] = ttmi_wgrad_desc{w.dqkv16, c.x16, g_qkv_w, nullptr, (int)a.W3, d, (int)a.BL, (long)a.W3, (long)d, (long)d};
+        if (out) out[1] = ttmi_wgrad_desc{w.dqkv16, x16, g_qkv_w, nullptr, (int)a.W3, d, (int)a.BL, (long)a.W3, (long)d, (long)d};
         else {
-            CK(gemm_tn_bf16(w.dqkv16, c.x16, g_qkv_w, (int)a.W3, d, (int)a.BL, a.W3, d, d, 1, fork_stream(st)));
+            CK(gemm_tn_bf16(w.dqkv16, x16, g_qkv_w, (int)a.W3, d, (int)a.BL, a.W3, d, d, 1, fork_stream(st)));
         }
         NtEpilogue e;
         e.addend = dx;
@@ -688,9 +714,10 @@ size_t ttmi_ffn_ws_floats(long rows, int d, int Di, int prec) {
 }
 
 // z = LN(y + W2 relu(W1 LN(y) + b1) + b2), the SAME (ln_g, ln_b) in both norms.
-int ttmi_ffn_fwd(const float* y, const float* w1, const float* b1, const float* w2, const float* b2, const float* ln_g,
+// pre_normed: h = LN(y), mean1, rstd1 are already in ctx (the producer of y formed them, LnPreNorm); z16_out (optional): bf16 copy of z
+static int ffn_fwd_impl(const float* y, const float* w1, const float* b1, const float* w2, const float* b2, const float* ln_g,
                  const float* ln_b, long rows, int d, int Di, int prec, float p_drop, float p_layer, unsigned seed, float* ctx,
-                 float* ws, float* z, void* stream) {
+                 float* ws, float* z, bool pre_normed, bf16_t* z16_out, void* stream) {
     TTMI_REQUIRE(y && w1 && b1 && w2 && b2 && ln_g && ln_b && ctx && ws && z, "ffn_fwd: null pointer");
     TTMI_REQUIRE(p_drop >= 0.f && p_drop < 1.f && p_layer >= 0.f && p_layer < 1.f, "ffn_fwd: dropout probability outside [0,1)");
     DropSpec d_in, d_out, d_layer;          // CoreNet.2, CoreNet.4 (tt/transformer.py:47,49) and the layer's own dropout (:196)
@@ -704,8 +731,9 @@ int ttmi_ffn_fwd(const float* y, const float* w1, const float* b1, const float* 
     Bump bc(ctx), bw(ws);
     FfnCtx c(bc, rows, d, Di, fast);
     FfnWs w(bw, rows, d, Di, fast);
+    TTMI_REQUIRE(!pre_normed || fast, "ffn_fwd: a pre-normed input belongs to the bf16 pipeline");
     if (fast) {
-        CK(ln_fwd(y, nullptr, ln_g, ln_b, rows, d, 1e-5f, nullptr, nullptr, c.mean1, c.rstd1, st, static_cast<bf16_t*>(c.h)));
+        if (!pre_normed) CK(ln_fwd(y, nullptr, ln_g, ln_b, rows, d, 1e-5f, nullptr, nullptr, c.mean1, c.rstd1, st, static_cast<bf16_t*>(c.h)));
         Shadow s1, s2;
         const bf16_t *w1_16 = w.w1_16, *w2_16 = w.w2_16;
         if (shadow_of(w1, Di, d, Di, s1)) w1_16 = s1.w16;
@@ -727,14 +755,21 @@ int ttmi_ffn_fwd(const float* y, const float* w1, const float* b1, const float* 
         g2.bias = b2;
         CK(ttmi_launch_gemm(g2, st));
     }
-    CK(ln_fwd(y, w.f, ln_g, ln_b, rows, d, 1e-5f, c.s2, z, c.mean2, c.rstd2, st, nullptr, d_out, d_layer));
+    CK(ln_fwd(y, w.f, ln_g, ln_b, rows, d, 1e-5f, c.s2, z, c.mean2, c.rstd2, st, z16_out, d_out, d_layer));
     return TTMI_OK;
+}
+
+int ttmi_ffn_fwd(const float* y, const float* w1, const float* b1, const float* w2, const float* b2, const float* ln_g,
+                 const float* ln_b, long rows, int d, int Di, int prec, float p_drop, float p_layer, unsigned seed, float* ctx,
+                 float* ws, float* z, void* stream) {
+    return ffn_fwd_impl(y, w1, b1, w2, b2, ln_g, ln_b, rows, d, Di, prec, p_drop, p_layer, seed, ctx, ws, z, false, nullptr, stream);
 }
 
 static int ffn_bwd_impl(const float* dz, const float* y, const float* w1, const float* w2, const float* ln_g, long rows, int d, int Di,
                  int prec, float p_drop, float p_layer, unsigned seed, const float* ctx, float* ws, float* dy, float* g_w1,
-                 float* g_b1, float* g_w2, float* g_b2, float* g_ln_g, float* g_ln_b, void* keep, ttmi_wgrad_desc* out, void* stream) {
-    TTMI_REQUIRE(dz && y && w1 && w2 && ln_g && ctx && ws && dy && g_w1 && g_b1 && g_w2 && g_b2 && g_ln_g && g_ln_b,
+                 float* g_b1, float* g_w2, float* g_b2, float* g_ln_g, float* g_ln_b, void* keep, ttmi_wgrad_desc* out, void* stream,
+                 bool skip_pre_norm = false) {
+    TTMI_REQUIRE(dz && y && w1 && w2 && ln_g && ctx && ws && (dy || skip_pre_norm) && g_w1 && g_b1 && g_w2 && g_b2 && g_ln_g && g_ln_b,
                  "ffn_bwd: null pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool fast = ffn_fast(prec, d, Di);
@@ -785,7 +820,8 @@ static int ffn_bwd_impl(const float* dz, const float* y, const float* w1, const 
         CK(wgrad(da1, h, g_w1, Di, d, (int)rows, Di, d, d, prec, st));
         CK(ttmi_launch_gemm(mk(da1, w1, w.dh, (int)rows, d, Di, Di, d, d, NN_, prec), st));
     }
-    CK(ln_bwd(w.dh, y, c.mean1, c.rstd1, ln_g, w.dres, rows, d, dy, g_ln_g, g_ln_b, st));
+    // (skip_pre_norm: the layer-level call - w.dh and w.dres stay in the workspace for the attention sub-layer's paired LayerNorm backward)
+    if (!skip_pre_norm) CK(ln_bwd(w.dh, y, c.mean1, c.rstd1, ln_g, w.dres, rows, d, dy, g_ln_g, g_ln_b, st));
     join_stream(st);
     return TTMI_OK;
 }
@@ -808,6 +844,76 @@ int ttmi_ffn_bwd_defer(const float* dz, const float* y, const float* w1, const f
 // the deferred forms exist on the bf16 pipeline of both sub-layers
 int ttmi_wgrad_defer_supported(long rows, int d, int H, int Dh, int Di, int prec) {
     return rows > 0 && attn_fast(prec, d, H, Dh) && ffn_fast(prec, d, Di) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ one encoder layer per call (RelLearnableDecoderLayer.forward, tt/transformer.py:188-197)
+// z = FFN(ATTN(x)).  Besides halving the host's calls, the layer-level entry removes three passes over the residual stream that the
+// sub-layer boundary forced: the FFN's pre-norm is formed by the attention sub-layer's post-norm pass (y is not read back), the two LayerNorm
+// backward passes that meet at y run as one kernel (dy is never stored), and the bf16 copy of a layer's input comes from the pass that
+// produced it (x16_in / z16_out) instead of a conversion launch.  Same arithmetic as the two sub-layer calls, in the same order per element.
+static size_t ws_round(size_t floats) { return (floats + 63) & ~size_t(63); }
+int ttmi_layer_fused(int d, int H, int Dh, int Di, int prec) {
+    return attn_fast(prec, d, H, Dh) && ffn_fast(prec, d, Di) && ln_bwd_pair_supported(d) ? 1 : 0;
+}
+size_t ttmi_layer_ws_floats(int B, int L, int d, int H, int Dh, int Di, int prec) {
+    return ws_round(ttmi_attn_ws_floats(B, L, d, H, Dh, prec)) + ws_round(ttmi_ffn_ws_floats((long)B * L, d, Di, prec)) + ws_round((size_t)B * L * d) + 64;
+}
+
+int ttmi_layer_fwd(const float* x, const void* x16_in, const float* qkv_w, const float* o_w, const float* ln_g, const float* ln_b, const float* r_emb,
+                   const float* r_w_bias, const float* r_bias, const float* w1, const float* b1, const float* w2, const float* b2,
+                   const float* ff_ln_g, const float* ff_ln_b, int B, int L, int d, int H, int Dh, int K, int Di, int mask_kind, int mask_left,
+                   int mask_right, const unsigned char* mask, long mask_sb, long mask_si, int prec, float p_drop_attn, unsigned seed_attn,
+                   float p_drop_ffn, float p_layer, unsigned seed_ffn, float* ctx_attn, float* ctx_ffn, float* ws, float* y, float* z,
+                   void* z16_out, void* stream) {
+    TTMI_REQUIRE(ctx_attn && ctx_ffn && ws && y && z && ff_ln_g && ff_ln_b, "layer_fwd: null pointer");
+    TTMI_REQUIRE(B > 0 && L > 0 && d > 0 && H > 0 && Dh > 0 && Di > 0, "layer_fwd: bad dims");
+    TTMI_REQUIRE((reinterpret_cast<uintptr_t>(ctx_ffn) & 255) == 0, "layer_fwd: ctx_ffn must be 256-byte aligned");
+    const bool fuse = ttmi_layer_fused(d, H, Dh, Di, prec) != 0;
+    TTMI_REQUIRE(fuse || (!x16_in && !z16_out), "layer_fwd: bf16 copies of the residual stream exist in the fused bf16 pipeline only (ttmi_layer_fused)");
+    const long rows = (long)B * L;
+    float* ws_ffn = ws + ws_round(ttmi_attn_ws_floats(B, L, d, H, Dh, prec));
+    LnPreNorm pre;
+    if (fuse) {
+        Bump bc(ctx_ffn);
+        FfnCtx fc(bc, rows, d, Di, true);
+        pre.g = ff_ln_g; pre.b = ff_ln_b; pre.h16 = static_cast<bf16_t*>(fc.h); pre.mean = fc.mean1; pre.rstd = fc.rstd1;
+    }
+    CK(attn_fwd_impl(x, qkv_w, o_w, ln_g, ln_b, r_emb, r_w_bias, r_bias, B, L, d, H, Dh, K, mask_kind, mask_left, mask_right, mask, mask_sb, mask_si,
+                     prec, p_drop_attn, seed_attn, ctx_attn, ws, y, static_cast<const bf16_t*>(x16_in), fuse ? &pre : nullptr, stream));
+    return ffn_fwd_impl(y, w1, b1, w2, b2, ff_ln_g, ff_ln_b, rows, d, Di, prec, p_drop_ffn, p_layer, seed_ffn, ctx_ffn, ws_ffn, z, fuse,
+                        static_cast<bf16_t*>(z16_out), stream);
+}
+
+// Backward of ttmi_layer_fwd: dx is written, every g_* buffer is accumulated into.  keep_attn / keep_ffn / out (all or none; bf16 pipeline):
+// the four weight-gradient GEMMs are described in out[0..3] (CoreNet.3, CoreNet.0 + bias, o_net, qkv_net) instead of launched, their
+// operands kept in the two keep buffers (ttmi_ffn_bwd_keep_bytes / ttmi_attn_bwd_keep_bytes) - and in x16_in, where given.
+int ttmi_layer_bwd(const float* dz, const float* x, const void* x16_in, const float* y, const float* qkv_w, const float* o_w, const float* ln_g,
+                   const float* r_emb, const float* r_w_bias, const float* r_bias, const float* w1, const float* w2, const float* ff_ln_g, int B,
+                   int L, int d, int H, int Dh, int K, int Di, int mask_kind, int mask_left, int mask_right, const unsigned char* mask,
+                   long mask_sb, long mask_si, int prec, float p_drop_attn, unsigned seed_attn, float p_drop_ffn, float p_layer,
+                   unsigned seed_ffn, const float* ctx_attn, const float* ctx_ffn, float* ws, float* dx, float* g_qkv_w, float* g_o_w,
+                   float* g_ln_g, float* g_ln_b, float* g_r_emb, float* g_r_w_bias, float* g_r_bias, float* g_w1, float* g_b1, float* g_w2,
+                   float* g_b2, float* g_ff_ln_g, float* g_ff_ln_b, void* keep_attn, void* keep_ffn, ttmi_wgrad_desc* out, void* stream) {
+    TTMI_REQUIRE(dz && x && y && ctx_attn && ctx_ffn && ws && dx, "layer_bwd: null pointer");
+    TTMI_REQUIRE(B > 0 && L > 0 && d > 0 && H > 0 && Dh > 0 && Di > 0, "layer_bwd: bad dims");
+    TTMI_REQUIRE((!out && !keep_attn && !keep_ffn) || (out && keep_attn && keep_ffn), "layer_bwd: keep buffers and descriptors come together");
+    const bool fuse = ttmi_layer_fused(d, H, Dh, Di, prec) != 0;
+    TTMI_REQUIRE(fuse || !x16_in, "layer_bwd: a bf16 copy of x exists in the fused bf16 pipeline only");
+    const long rows = (long)B * L;
+    float* ws_ffn = ws + ws_round(ttmi_attn_ws_floats(B, L, d, H, Dh, prec));
+    float* dy = ws_ffn + ws_round(ttmi_ffn_ws_floats(rows, d, Di, prec));
+    CK(ffn_bwd_impl(dz, y, w1, w2, ff_ln_g, rows, d, Di, prec, p_drop_ffn, p_layer, seed_ffn, ctx_ffn, ws_ffn, fuse ? nullptr : dy, g_w1, g_b1, g_w2,
+                    g_b2, g_ff_ln_g, g_ff_ln_b, keep_ffn, out, stream, fuse));
+    LnPairIn pair;
+    if (fuse) {
+        Bump bc(const_cast<float*>(ctx_ffn)), bw(ws_ffn);
+        FfnCtx fc(bc, rows, d, Di, true);
+        FfnWs fw(bw, rows, d, Di, true, keep_ffn);
+        pair = LnPairIn{fw.dh, y, fc.mean1, fc.rstd1, ff_ln_g, fw.dres, g_ff_ln_g, g_ff_ln_b};
+    }
+    return attn_bwd_impl(fuse ? nullptr : dy, x, qkv_w, o_w, ln_g, r_emb, r_w_bias, r_bias, B, L, d, H, Dh, K, mask_kind, mask_left, mask_right, mask,
+                         mask_sb, mask_si, prec, p_drop_attn, seed_attn, ctx_attn, ws, dx, g_qkv_w, g_o_w, g_ln_g, g_ln_b, g_r_emb, g_r_w_bias,
+                         g_r_bias, keep_attn, out ? out + 2 : nullptr, stream, static_cast<const bf16_t*>(x16_in), fuse ? &pair : nullptr);
 }
 
 // ------------------------------------------------------------------ joint network (tt/model.py:20-39)

@@ -33,6 +33,12 @@ int ln_fwd(const float* x, const float* res, const float* g, const float* b, lon
 int ln_bwd(const float* dy, const float* s, const float* mean, const float* rstd, const float* g, const float* dadd, long rows,
            int d, float* dx, float* dgamma, float* dbeta, hipStream_t st, DropSpec dy_drop = DropSpec(), bf16_t* dx16 = nullptr,
            DropSpec dx16_drop = DropSpec(), float* dx16_colsum = nullptr);
+// the FFN's pre-norm backward and the attention sub-layer's post-norm backward of one layer in one pass (d % 4 == 0, d <= 512):
+//   dy = LN1'(dh; y, mean1, rstd1, g1) + dres1 ; dx = LN2'(dy; s, mean2, rstd2, g2) ; dx16 = bf16(dx * dropout(dx16_drop)); dy is not stored
+bool ln_bwd_pair_supported(int d);
+int ln_bwd_pair(const float* dh, const float* y, const float* mean1, const float* rstd1, const float* g1, const float* dres1, const float* s,
+                const float* mean2, const float* rstd2, const float* g2, long rows, int d, float* dx, float* dgamma1, float* dbeta1,
+                float* dgamma2, float* dbeta2, bf16_t* dx16, DropSpec dx16_drop, hipStream_t st);
 // out[i] = in[i] * dropout_multiplier(i)  (out f32 and/or bf16); with p = 0 this is the plain f32 -> bf16 conversion
 int dropout_apply(const float* in, long n, DropSpec ds, float* out32, bf16_t* out16, hipStream_t st);
 // in-place P = softmax_j(scale * S) over the batched score view (nb slabs, L rows of ld floats each)

@@ -386,6 +386,140 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restri
     }
 }
 
+// The two LayerNorm backward passes that meet at a layer's middle (tt/transformer.py:54-58 and :172-175), in ONE pass over the rows:
+//     dy  = LN1'(dh; y, mean1, rstd1, g1) + dres1          the FFN's pre-norm, plus the FFN's residual branch  (= gradient of the layer's y)
+//     dx  = LN2'(dy; s, mean2, rstd2, g2)                  the attention sub-layer's post-norm             (= residual gradient of the layer's x)
+//     dx16 = bf16(dx * dropout(xdrop))                     the o_net GEMMs' operand
+// dy never exists in memory (one 32 MB write and read per layer at C2), both norms' gamma / beta sums ride along as in ln_bwd_fused_kernel.
+template <int KV>
+__global__ __launch_bounds__(256) void ln_bwd_pair_kernel(const float* __restrict__ dh, const float* __restrict__ y,
+                                                          const float* __restrict__ mean1, const float* __restrict__ rstd1,
+                                                          const float* __restrict__ g1, const float* __restrict__ dres1,
+                                                          const float* __restrict__ s, const float* __restrict__ mean2,
+                                                          const float* __restrict__ rstd2, const float* __restrict__ g2, long rows, int d,
+                                                          float* __restrict__ dx, float* __restrict__ dgamma1, float* __restrict__ dbeta1,
+                                                          float* __restrict__ dgamma2, float* __restrict__ dbeta2,
+                                                          bf16_t* __restrict__ dx16, DropSpec xdrop) {
+    xdrop = drop_live(xdrop);
+    __shared__ float red[4][4][KV * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float gam1[KV][4], gam2[KV][4], ag1[KV][4], ab1[KV][4], ag2[KV][4], ab2[KV][4];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+        const int c0 = k * 256 + lane * 4;
+        const float4 a = c0 < d ? *reinterpret_cast<const float4*>(g1 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 b = c0 < d ? *reinterpret_cast<const float4*>(g2 + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        gam1[k][0] = a.x; gam1[k][1] = a.y; gam1[k][2] = a.z; gam1[k][3] = a.w;
+        gam2[k][0] = b.x; gam2[k][1] = b.y; gam2[k][2] = b.z; gam2[k][3] = b.w;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ag1[k][c] = ab1[k][c] = ag2[k][c] = ab2[k][c] = 0.f;
+    }
+    const float invd = 1.f / d;
+    struct RowIn {
+        float4 a[KV], b[KV], e[KV], f[KV];
+        float mu1, rs1, mu2, rs2;
+    };
+    const long stride = (long)gridDim.x * 4;
+    auto fetch = [&](long r, RowIn& in) {
+        const unsigned long long base = (unsigned long long)r * d;
+        in.mu1 = mean1[r]; in.rs1 = rstd1[r];
+        in.mu2 = mean2[r]; in.rs2 = rstd2[r];
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const int c0 = k * 256 + lane * 4;
+            if (c0 < d) {
+                in.a[k] = *reinterpret_cast<const float4*>(dh + base + c0);
+                in.b[k] = *reinterpret_cast<const float4*>(y + base + c0);
+                in.e[k] = *reinterpret_cast<const float4*>(dres1 + base + c0);
+                in.f[k] = *reinterpret_cast<const float4*>(s + base + c0);
+            }
+        }
+    };
+    long r = (long)blockIdx.x * 4 + wave;
+    RowIn cur, nxt;
+    if (r < rows) fetch(r, cur);
+    for (; r < rows; r += stride) {
+        if (r + stride < rows) fetch(r + stride, nxt);
+        const unsigned long long base = (unsigned long long)r * d;
+        float v[KV][4], xh[KV][4];
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            if (k * 256 + lane * 4 < d) {
+                const float4 a = cur.a[k], b = cur.b[k];
+                const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    v[k][c] = av[c];
+                    xh[k][c] = (bv[c] - cur.mu1) * cur.rs1;
+                    const float dxh = v[k][c] * gam1[k][c];
+                    m1 += dxh;
+                    m2 += dxh * xh[k][c];
+                    ag1[k][c] += v[k][c] * xh[k][c];
+                    ab1[k][c] += v[k][c];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[k][c] = xh[k][c] = 0.f;
+            }
+        }
+        m1 = wave_sum(m1) * invd;
+        m2 = wave_sum(m2) * invd;
+        float n1 = 0.f, n2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            if (k * 256 + lane * 4 < d) {
+                const float4 e = cur.e[k], f = cur.f[k];
+                const float ev[4] = {e.x, e.y, e.z, e.w}, fv[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    v[k][c] = cur.rs1 * (v[k][c] * gam1[k][c] - m1 - xh[k][c] * m2) + ev[c];        // dy
+                    xh[k][c] = (fv[c] - cur.mu2) * cur.rs2;
+                    const float dxh = v[k][c] * gam2[k][c];
+                    n1 += dxh;
+                    n2 += dxh * xh[k][c];
+                    ag2[k][c] += v[k][c] * xh[k][c];
+                    ab2[k][c] += v[k][c];
+                }
+            }
+        }
+        n1 = wave_sum(n1) * invd;
+        n2 = wave_sum(n2) * invd;
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+            const int c0 = k * 256 + lane * 4;
+            if (c0 < d) {
+                float o[4], m[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = cur.rs2 * (v[k][c] * gam2[k][c] - n1 - xh[k][c] * n2);
+                *reinterpret_cast<float4*>(dx + base + c0) = make_float4(o[0], o[1], o[2], o[3]);
+                drop_mult4(xdrop, base + c0, m);
+                uint2 w;
+                w.x = pack_bf16x2(o[0] * m[0], o[1] * m[1]);
+                w.y = pack_bf16x2(o[2] * m[2], o[3] * m[3]);
+                *reinterpret_cast<uint2*>(dx16 + base + c0) = w;
+            }
+        }
+        cur = nxt;
+    }
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            red[0][wave][k * 256 + lane * 4 + c] = ag1[k][c];
+            red[1][wave][k * 256 + lane * 4 + c] = ab1[k][c];
+            red[2][wave][k * 256 + lane * 4 + c] = ag2[k][c];
+            red[3][wave][k * 256 + lane * 4 + c] = ab2[k][c];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) {
+        atomicAdd(dgamma1 + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(dbeta1 + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        atomicAdd(dgamma2 + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
+        atomicAdd(dbeta2 + c, red[3][0][c] + red[3][1][c] + red[3][2][c] + red[3][3][c]);
+    }
+}
+
 // ------------------------------------------------------------------ masked softmax on the score view
 __device__ __forceinline__ bool masked_at(const MaskDesc& m, int b, int i, int j) {
     switch (m.kind) {
@@ -1055,6 +1189,25 @@ int ln_bwd(const float* dy, const float* s, const float* mean, const float* rstd
         if (int rc = dropout_apply(dx, rows * d, dx16_drop, nullptr, dx16, st)) return rc;
         if (dx16_colsum) return colsum_bf16(dx16, d, rows, d, dx16_colsum, st, 1, 1, 0, 0, 0);
     }
+    return TTMI_OK;
+}
+
+bool ln_bwd_pair_supported(int d) { return d % 4 == 0 && d <= 512; }
+int ln_bwd_pair(const float* dh, const float* y, const float* mean1, const float* rstd1, const float* g1, const float* dres1, const float* s,
+                const float* mean2, const float* rstd2, const float* g2, long rows, int d, float* dx, float* dgamma1, float* dbeta1,
+                float* dgamma2, float* dbeta2, bf16_t* dx16, DropSpec dx16_drop, hipStream_t st) {
+    TTMI_REQUIRE(dh && y && mean1 && rstd1 && g1 && dres1 && s && mean2 && rstd2 && g2 && dx && dgamma1 && dbeta1 && dgamma2 && dbeta2 && dx16 &&
+                 rows > 0, "ln_bwd_pair: bad arguments");
+    TTMI_REQUIRE(ln_bwd_pair_supported(d) && aligned16(dh) && aligned16(y) && aligned16(dres1) && aligned16(s) && aligned16(g1) && aligned16(g2) &&
+                 aligned16(dx) && (reinterpret_cast<uintptr_t>(dx16) & 7) == 0, "ln_bwd_pair: d %% 4 == 0, d <= 512 and 16-byte aligned rows required");
+    const int grid = (int)std::min<long>(cdiv(rows, 4), g_ln_bwd_grid);
+    if (d <= 256)
+        hipLaunchKernelGGL(ln_bwd_pair_kernel<1>, dim3(grid), dim3(256), 0, st, dh, y, mean1, rstd1, g1, dres1, s, mean2, rstd2, g2, rows, d, dx,
+                           dgamma1, dbeta1, dgamma2, dbeta2, dx16, dx16_drop);
+    else
+        hipLaunchKernelGGL(ln_bwd_pair_kernel<2>, dim3(grid), dim3(256), 0, st, dh, y, mean1, rstd1, g1, dres1, s, mean2, rstd2, g2, rows, d, dx,
+                           dgamma1, dbeta1, dgamma2, dbeta2, dx16, dx16_drop);
+    TTMI_LAUNCH_CHECK("ln_bwd_pair_kernel");
     return TTMI_OK;
 }
 

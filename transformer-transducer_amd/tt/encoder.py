@@ -16,8 +16,8 @@ class BaseEncoder(nn.Module):
         self.r_bias = nn.Parameter(torch.randn((k_len, n_head), dtype=torch.float32))
         self.MultiHeadAttention = RelLearnableDecoderLayer(n_head, d_model, d_head, d_inner, dropout, **kwargs)
 
-    def forward_bm(self, x, mask):
-        return self.MultiHeadAttention.forward_bm(x, self.r_emb, self.r_w_bias, self.r_bias, mask)
+    def forward_bm(self, x, mask, x16=None, want16=False):
+        return self.MultiHeadAttention.forward_bm(x, self.r_emb, self.r_w_bias, self.r_bias, mask, x16=x16, want16=want16)
 
     def forward(self, inputs, enc_attn_mask=None):      # reference contract: time-major [T, B, d]
         assert inputs.dim() == 3
@@ -39,7 +39,12 @@ class BuildEncoder(nn.Module):
     def forward(self, inputs, mask=None):
         ops.weights_fresh()
         spec = as_mask_spec(mask, inputs.size(0), inputs.size(1))     # converted once, shared by every layer
-        x = inputs
-        for layer in self.layers:
-            x = layer.forward_bm(x, spec)
+        # fused layers hand their output to the next one in both forms: f32 (the residual stream) and bf16 (the next layer's GEMM operand)
+        x, x16 = inputs, None
+        fused = x.is_cuda and all(layer.MultiHeadAttention.fused() for layer in self.layers)
+        for i, layer in enumerate(self.layers):
+            if fused and i + 1 < len(self.layers):
+                x, x16 = layer.forward_bm(x, spec, x16=x16, want16=True)
+            else:
+                x = layer.forward_bm(x, spec, x16=x16)
         return x

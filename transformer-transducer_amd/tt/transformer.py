@@ -165,6 +165,52 @@ class _FFNFn(torch.autograd.Function):
         return (dy, *rets, None, None, None, None, None)
 
 
+class _LayerFn(torch.autograd.Function):
+    """One encoder layer = ONE C-ABI call per direction (ttmi_layer_fwd / ttmi_layer_bwd): the attention sub-layer and the FFN share the
+    passes over the residual stream that two calls force apart (ttmi.h).  x16 / the second output: bf16 copies of the layer's input and
+    output, handed from layer to layer by the stacks (never differentiated: they are copies of x and z)."""
+    NAMES = _AttnFn.NAMES + _FFNFn.NAMES
+    LATE = _AttnFn.LATE + _FFNFn.LATE
+
+    @staticmethod
+    def forward(ctx, x, x16, mask, prec, p_attn, seed_attn, p_ffn, p_layer, seed_ffn, first_layer, want16, *params):
+        x = x.contiguous()
+        p = dict(zip(_LayerFn.NAMES, (t.detach() for t in params)))
+        y, z, z16, ctx_a, ctx_f = ops.layer_fwd(x, x16, p, p, mask, prec, p_attn, seed_attn, p_ffn, p_layer, seed_ffn, want16)
+        ctx.save_for_backward(x, y, ctx_a, ctx_f, *p.values())
+        ctx.x16 = x16
+        ctx.args = (prec, mask, p_attn, seed_attn, p_ffn, p_layer, seed_ffn)
+        ctx.first_layer, ctx.params = first_layer, params
+        if z16 is None:
+            return z, None
+        ctx.mark_non_differentiable(z16)
+        return z, z16
+
+    @staticmethod
+    def backward(ctx, dz, _dz16=None):
+        x, y, ctx_a, ctx_f, *ps = ctx.saved_tensors
+        p = dict(zip(_LayerFn.NAMES, ps))
+        prec, mask, p_attn, seed_attn, p_ffn, p_layer, seed_ffn = ctx.args
+        rows, d = x.shape[0] * x.shape[1], x.shape[2]
+        if ctx.first_layer and ops.wgrad_queue is not None and ops.wgrad_queue.immediate_first_layer:
+            ops.wgrad_flush()          # first node of the first layer's backward: this layer keeps its own launches, the groups behind it go now
+        q = _defer_queue(ctx.params, _LayerFn.NAMES, _LayerFn.LATE, rows, prec, ctx.first_layer)
+        kw = dict(mask=mask, p_attn=p_attn, seed_attn=seed_attn, p_ffn=p_ffn, p_layer=p_layer, seed_ffn=seed_ffn)
+        if q is not None and ops.wgrad_defer_supported(rows, d, p["r_emb"].shape[1], p["r_emb"].shape[2], p["ff_w1"].shape[0], prec):
+            grads, rets, after, later = grad_targets(ctx.params, _LayerFn.NAMES, _LayerFn.LATE)
+            dx = ops.layer_bwd(dz.contiguous(), x, ctx.x16, y, p, p, ctx_a, ctx_f, prec, grads, defer=q, **kw)
+            q.add_callbacks(later)
+            q.maybe_flush(force=ctx.first_layer)          # a layer boundary: launch if enough layers wait - or if nothing follows
+        else:
+            grads, rets, after = grad_targets(ctx.params, _LayerFn.NAMES)
+            dx = ops.layer_bwd(dz.contiguous(), x, ctx.x16, y, p, p, ctx_a, ctx_f, prec, grads, **kw)
+            if ctx.first_layer:
+                ops.wgrad_flush()
+        for cb in after:
+            cb()
+        return (dx, None, None, None, None, None, None, None, None, None, None, *rets)
+
+
 def _drop_p(module, p):
     """dropout probability in effect (nn.Dropout semantics: active only in training mode)"""
     return float(p) if (module.training and p) else 0.0
@@ -245,9 +291,24 @@ class RelLearnableDecoderLayer(nn.Module):
         self.pos_ff = PositionwiseFF(d_model, d_inner, dropout)
         self.dropout = nn.Dropout(dropout)
 
-    def forward_bm(self, x, r_emb, r_w_bias, r_bias, mask, prec=None):
-        return self.pos_ff(self.dec_attn.forward_bm(x, r_emb, r_w_bias, r_bias, mask, prec), prec,
-                           _drop_p(self, self.dropout.p))
+    def forward_bm(self, x, r_emb, r_w_bias, r_bias, mask, prec=None, x16=None, want16=False):
+        """batch-major [B, L, d] in/out through ONE call per direction (_LayerFn).  x16: the bf16 copy of x the previous layer returned;
+        want16: return (z, bf16 copy of z) for the next layer - both only where ops.layer_fused() says the layer runs fused."""
+        a, f = self.dec_attn, self.pos_ff
+        prec = default_precision() if prec is None else prec
+        pa, pf, pl = _drop_p(a, a.dropout), _drop_p(f, f.dropout), _drop_p(self, self.dropout.p)
+        seed_attn = _new_seed(pa)                      # (drawn in the order the two sub-layer calls draw them)
+        seed_ffn = _new_seed(pf, pl)
+        c = f.CoreNet
+        z, z16 = _LayerFn.apply(x, x16, mask, prec, pa, seed_attn, pf, pl, seed_ffn, getattr(a, "first_layer", False), want16,
+                                a.qkv_net.weight, a.o_net.weight, a.layer_norm.weight, a.layer_norm.bias, r_emb, r_w_bias, r_bias,
+                                c[0].weight, c[0].bias, c[3].weight, c[3].bias, f.layer_norm.weight, f.layer_norm.bias)
+        return (z, z16) if want16 else z
+
+    def fused(self, prec=None):
+        """does this layer run the fused layer-level kernels (may bf16 copies of the residual stream be handed to / taken from it)?"""
+        a, f = self.dec_attn, self.pos_ff
+        return ops.layer_fused(a.d_model, a.n_head, a.d_head, f.d_inner, default_precision() if prec is None else prec)
 
     def forward(self, input, r_emb, r_w_bias, r_bias, attn_mask=None):
         L, B = input.size(0), input.size(1)

@@ -343,6 +343,67 @@ def ffn_bwd(dz, y, p, ctx, prec, grads, p_drop=0.0, p_layer=0.0, seed=0, defer=N
     return dy
 
 
+def layer_fused(d, H, Dh, Di, prec):
+    """do the layer-level calls share passes between the sub-layers (bf16 pipeline at these widths) - i.e. may x16 / z16 be passed?"""
+    return bool(lib().ttmi_layer_fused(c_int(d), c_int(H), c_int(Dh), c_int(Di), c_int(prec)))
+
+
+def _layer_ws(L_, B, L, d, H, Dh, Di, prec, device):
+    L_.ttmi_layer_ws_floats.restype = ctypes.c_size_t
+    return scratch(L_.ttmi_layer_ws_floats(c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh), c_int(Di), c_int(prec)), device)
+
+
+def layer_fwd(x, x16, pa, pf, mask, prec, p_attn=0.0, seed_attn=0, p_ffn=0.0, p_layer=0.0, seed_ffn=0, want16=False):
+    """one encoder layer (attention sub-layer + FFN) in one call: -> (y, z, z16 or None, ctx_attn, ctx_ffn).  pa / pf: the parameter
+    dicts of attn_fwd / ffn_fwd; x16: bf16 copy of x from the previous layer's z16 (or None); want16: also return bf16(z)."""
+    _need_cuda(x)
+    B, L, d = x.shape
+    K, H, Dh = pa["r_emb"].shape
+    Di = pf["ff_w1"].shape[0]
+    L_ = lib()
+    L_.ttmi_attn_ctx_floats.restype = ctypes.c_size_t
+    L_.ttmi_ffn_ctx_floats.restype = ctypes.c_size_t
+    ctx_a = _f32(L_.ttmi_attn_ctx_floats(c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh), c_int(prec)), x.device)
+    ctx_f = _f32(L_.ttmi_ffn_ctx_floats(c_long(B * L), c_int(d), c_int(Di), c_int(prec)), x.device)
+    ws = _layer_ws(L_, B, L, d, H, Dh, Di, prec, x.device)
+    y, z = torch.empty_like(x), torch.empty_like(x)
+    z16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want16 else None
+    check(L_.ttmi_layer_fwd(_p(x), _p(x16), _p(pa["qkv_w"]), _p(pa["o_w"]), _p(pa["ln_g"]), _p(pa["ln_b"]), _p(pa["r_emb"]), _p(pa["r_w_bias"]),
+                            _p(pa["r_bias"]), _p(pf["ff_w1"]), _p(pf["ff_b1"]), _p(pf["ff_w2"]), _p(pf["ff_b2"]), _p(pf["ff_ln_g"]),
+                            _p(pf["ff_ln_b"]), c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh), c_int(K), c_int(Di), *mask.args(), c_int(prec),
+                            c_float(p_attn), ctypes.c_uint(seed_attn), c_float(p_ffn), c_float(p_layer), ctypes.c_uint(seed_ffn), _p(ctx_a),
+                            _p(ctx_f), _p(ws), _p(y), _p(z), _p(z16), _stream()), "ttmi_layer_fwd")
+    return y, z, z16, ctx_a, ctx_f
+
+
+def layer_bwd(dz, x, x16, y, pa, pf, ctx_a, ctx_f, prec, grads, mask=None, p_attn=0.0, seed_attn=0, p_ffn=0.0, p_layer=0.0, seed_ffn=0, defer=None):
+    """backward of layer_fwd -> dx; grads: running f32 buffers by parameter name (both sub-layers'), accumulated into.  defer: a WgradQueue
+    that takes the layer's four weight-gradient GEMMs."""
+    B, L, d = x.shape
+    K, H, Dh = pa["r_emb"].shape
+    Di = pf["ff_w1"].shape[0]
+    L_ = lib()
+    ws = _layer_ws(L_, B, L, d, H, Dh, Di, prec, x.device)
+    dx = torch.empty_like(x)
+    keep_a = keep_f = out = None
+    if defer is not None:
+        L_.ttmi_attn_bwd_keep_bytes.restype = ctypes.c_size_t
+        L_.ttmi_ffn_bwd_keep_bytes.restype = ctypes.c_size_t
+        keep_a = torch.empty(L_.ttmi_attn_bwd_keep_bytes(c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh)), dtype=torch.uint8, device=x.device)
+        keep_f = torch.empty(L_.ttmi_ffn_bwd_keep_bytes(c_long(B * L), c_int(d), c_int(Di)), dtype=torch.uint8, device=x.device)
+        out = (WgradDesc * 4)()
+    check(L_.ttmi_layer_bwd(_p(dz), _p(x), _p(x16), _p(y), _p(pa["qkv_w"]), _p(pa["o_w"]), _p(pa["ln_g"]), _p(pa["r_emb"]), _p(pa["r_w_bias"]),
+                            _p(pa["r_bias"]), _p(pf["ff_w1"]), _p(pf["ff_w2"]), _p(pf["ff_ln_g"]), c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh),
+                            c_int(K), c_int(Di), *(mask or MaskSpec()).args(), c_int(prec), c_float(p_attn), ctypes.c_uint(seed_attn),
+                            c_float(p_ffn), c_float(p_layer), ctypes.c_uint(seed_ffn), _p(ctx_a), _p(ctx_f), _p(ws), _p(dx),
+                            _p(grads["qkv_w"]), _p(grads["o_w"]), _p(grads["ln_g"]), _p(grads["ln_b"]), _p(grads["r_emb"]), _p(grads["r_w_bias"]),
+                            _p(grads["r_bias"]), _p(grads["ff_w1"]), _p(grads["ff_b1"]), _p(grads["ff_w2"]), _p(grads["ff_b2"]),
+                            _p(grads["ff_ln_g"]), _p(grads["ff_ln_b"]), _p(keep_a), _p(keep_f), out, _stream()), "ttmi_layer_bwd")
+    if defer is not None:
+        defer.push(out, (keep_a, keep_f, ctx_a, ctx_f, x16, grads["qkv_w"], grads["o_w"], grads["ff_w1"], grads["ff_b1"], grads["ff_w2"]))
+    return dx
+
+
 def joint_logits_dtype(prec, J):
     return torch.bfloat16 if lib().ttmi_joint_logits_dtype(c_int(prec), c_int(J)) == 1 else torch.float32
 
