@@ -181,6 +181,7 @@ class _LayerFn(torch.autograd.Function):
         ctx.x16 = x16
         ctx.args = (prec, mask, p_attn, seed_attn, p_ffn, p_layer, seed_ffn)
         ctx.first_layer, ctx.params = first_layer, params
+        ctx.set_materialize_grads(False)               # (no zero-filled gradient for the bf16 copy: it is never differentiated)
         if z16 is None:
             return z, None
         ctx.mark_non_differentiable(z16)
@@ -189,6 +190,8 @@ class _LayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz, _dz16=None):
         x, y, ctx_a, ctx_f, *ps = ctx.saved_tensors
+        if dz is None:                                 # the layer's output did not reach the loss
+            return (None,) * (11 + len(ps))
         p = dict(zip(_LayerFn.NAMES, ps))
         prec, mask, p_attn, seed_attn, p_ffn, p_layer, seed_ffn = ctx.args
         rows, d = x.shape[0] * x.shape[1], x.shape[2]
