@@ -87,6 +87,18 @@ def cpu_baseline(model, feats, proj, targets, T, U, n_utt, gpu_costs, reps):
     return n_utt / dt, dt, rel, times, costs
 
 
+def encoder_floor(model, enc_states, dec_states, targets, T, U, n_utt, oracle_costs):
+    """per-utterance costs of the ORACLE's joint + lattice (float64 joint, C lattice) on the GPU's encoder states, against the all-oracle
+    costs: the part of the loss error that is already in the encoder outputs, whatever the joint and the loss do afterwards"""
+    from oracle import tt_oracle as O
+    from oracle.rnnt_c import rnnt_loss_c
+    sd = {k: v.detach().double().cpu().numpy() for k, v in model.state_dict().items() if k.startswith("joint.")}
+    z, _ = O.joint_fwd(enc_states, dec_states, sd)
+    y = targets[:n_utt].cpu().numpy()
+    costs = rnnt_loss_c(z.astype(np.float32), y, np.full(n_utt, T, dtype=np.int32), np.full(n_utt, U, dtype=np.int32), want_grad=False)[1]
+    return float(np.abs(costs.astype(np.float64) - oracle_costs).max() / np.abs(oracle_costs).max())
+
+
 # ---- multi-rank control flow of the driver contract (covered on CPU by tests/test_bench_flow.py over gloo, world size 2)
 def rank_seed(rank):
     """every rank draws its own synthetic utterances: generator seed 1234 + rank; the MODEL seed is the same everywhere"""
@@ -503,7 +515,10 @@ def main():
                 if form != "two-call":      # the timed loss form on the same sample: its per-utterance costs against the same oracle
                     costs_form = model.loss(inputs[:args.cpu_utts], ilen[:args.cpu_utts], targets[:args.cpu_utts], tlen[:args.cpu_utts],
                                             reduction="none", chunk=args.loss_chunk or None, exp_domain=form == "exp")
+                enc_s, dec_s = model._encode(inputs[:args.cpu_utts], targets[:args.cpu_utts])      # the timed precision's encoder states of the same sample
+                enc_s, dec_s = enc_s.double().cpu().numpy(), dec_s.double().cpu().numpy()
             v, dt, rel, times, oracle_costs = cpu_baseline(model, feats, proj, targets, T, U, args.cpu_utts, costs.float().cpu().numpy(), args.cpu_reps)
+            floor = encoder_floor(model, enc_s, dec_s, targets, T, U, args.cpu_utts, oracle_costs)
             out["cpu_baseline"] = {"value": round(v, 4), "unit": "utt/s", "cores": _blas_threads(), "kind": "port",
                                    "sample": "%d utterance(s) of the same workload (B=%d as in BASELINE.md §3), fwd+loss+bwd through "
                                              "oracle/tt_oracle.py (numpy, multithreaded BLAS) + oracle/rnnt_lattice.c, median of %d runs "
@@ -511,6 +526,9 @@ def main():
                                    # the reference's OWN PyTorch CPU path, timed once in the survey container (it cannot travel to the GPU box):
                                    "reference_cpu_probe": {"value": 0.33, "unit": "utt/s", "cores": 8, "source": "BASELINE.md §2 (fwd+bwd, lattice excluded, B=2)"}}
             out["loss_rel_err_vs_oracle"] = float("%.3e" % rel)
+            # how much of that distance the encoders' precision alone accounts for: the ORACLE's float64 joint + lattice fed the GPU's encoder
+            # states of the same sample (bf16 mode: 12 / 6 layers of bf16 GEMM operands leave ~2e-3 relative error on the states)
+            out["loss_rel_err_encoder_states_only"] = float("%.3e" % floor)
             if form != "two-call":
                 out["loss_rel_err_vs_oracle_timed_form"] = float("%.3e" % (np.abs(costs_form.float().cpu().numpy() - oracle_costs).max() / np.abs(oracle_costs).max()))
         print(json.dumps(out), flush=True)

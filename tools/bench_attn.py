@@ -16,6 +16,8 @@ ops.set_option(2, int(os.environ.get("TTMI_FLASH_DEBUG", "0")))
 ops.set_option(0, int(os.environ.get("TTMI_NO_FLASH", "0")))
 ops.set_option(4, int(os.environ.get("TTMI_TN_TARGET", "512")))
 ops.set_option(3, int(os.environ.get("TTMI_FORK", "1")))
+if os.environ.get("TTMI_LN_GRID"):
+    ops.set_option(12, int(os.environ["TTMI_LN_GRID"]))
 ops.set_option(10, int(os.environ.get("TTMI_SLICES", "1")))   # attention backward in n batch slices (slabs stay in the Infinity Cache)
 ops.set_option(5, int(os.environ.get("TTMI_SLAB", "0")))      # 1 = slab by GEMM; 2 / 4 = skip the slab kernel's MFMA part / stores
 B, L = int(os.environ.get("B", 32)), int(os.environ.get("L", 500))

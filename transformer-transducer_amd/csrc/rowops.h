@@ -26,6 +26,7 @@ struct LnPreNorm {
 int ln_fwd(const float* x, const float* res, const float* g, const float* b, long rows, int d, float eps, float* s_out,
            float* y, float* mean, float* rstd, hipStream_t st, bf16_t* y16 = nullptr, DropSpec res_drop = DropSpec(),
            DropSpec out_drop = DropSpec(), const LnPreNorm* pre = nullptr);
+extern int g_ln_bwd_grid;       // workgroups of the grid-stride LayerNorm backward kernels (ttmi_set_option(12, n))
 // dx = dadd + LN'(dy) ; dgamma/dbeta accumulated atomically (caller zeroes them once per step)
 // dy_drop: the forward applied dropout to the LN output, so dy is masked/scaled identically on the way in
 // dx16 (optional, bf16 pipeline): bf16(dx * dropout(dx16_drop)) - the masked gradient the following GEMMs consume - and, with

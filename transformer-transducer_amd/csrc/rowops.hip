@@ -6,7 +6,7 @@
 #include "rowops.h"
 #include <type_traits>
 #ifndef LN_BWD_GRID
-#define LN_BWD_GRID 512
+#define LN_BWD_GRID 384
 #endif
 #include <algorithm>
 
