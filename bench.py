@@ -448,15 +448,15 @@ def main():
             nparts = 4 * ((V + 255) // 256)
             loss_bytes = B_launch * T * U1 * (4.0 * nparts + 2 * 4 + 4 * 4 + 2 * 8 + 2 * 8 + 4 + 2 + 2 * 2 * 2)
             loss_gbs = rate(loss_bytes, l_ms, 1e9, 1)
-            roof_loss = {"bound": "hbm", "kernel": "RNN-T loss op, exp-domain form: rnnt_prep_exp_kernel + rnnt_alphabeta_kernel (%s ms) + rnnt_scale_exp_kernel "
+            roof_loss = {"bound": "hbm", "kernel": "RNN-T loss op, exp-domain form: rnnt_prep_exp_kernel + rnnt_lattice_lds_kernel (%s ms) + rnnt_scale_exp_kernel "
                                                    "(%s ms), P = exp(logits - shift) [%d,%d,%d,%d] bf16 patched at 2 entries per row, emission logits f32 [rows, 2]"
                                                    % (lf and round(lf, 3), lb and round(lb, 3), B_launch, T, U1, V),
                          "achieved": loss_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac(loss_gbs, HBM_PEAK_GBS),
                          "traffic": None, "kernel_ms": None if l_ms is None else round(l_ms, 4),
-                         "note": "latency-bound by the lattice recursion (T+U serial steps per utterance, one wave each); the two-call form's loss op moves "
+                         "note": "latency-bound by the lattice recursion (T+U serial steps per utterance; one workgroup per utterance and direction, one wave per 64 labels); the two-call form's loss op moves "
                                  "%.1f GB per step through rnnt_lse_kernel / rnnt_grad_kernel instead" % (B * (2.0 * es * T * U1 * V) / 1e9)}
         else:
-            roof_loss = {"bound": "hbm", "kernel": "RNN-T loss op: rnnt_lse_kernel + rnnt_alphabeta_kernel (%s ms) + rnnt_grad_kernel (%s ms), "
+            roof_loss = {"bound": "hbm", "kernel": "RNN-T loss op: rnnt_lse_kernel + rnnt_lattice_lds_kernel (%s ms) + rnnt_grad_kernel (%s ms), "
                                                    "logits [%d,%d,%d,%d] %s" % (lf and round(lf, 3), lb and round(lb, 3), B_launch, T, U1, V, "bf16" if es == 2 else "f32"),
                          "achieved": loss_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac(loss_gbs, HBM_PEAK_GBS),
                          "traffic": None, "kernel_ms": None if l_ms is None else round(l_ms, 4)}

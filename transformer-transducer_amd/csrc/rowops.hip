@@ -916,6 +916,7 @@ __global__ __launch_bounds__(256) void joint_tanh_bwd_kernel(const TH* __restric
         if (t0 + tt < T) dPE[((long)b * T + t0 + tt) * J + j] = accE[tt];
 }
 
+constexpr int JT_TC4 = 16;     // frames per block of the kernel below (32: fewer atomics but 0.52 -> 0.87 ms, too few blocks in flight; measured round 3)
 // bf16 pipeline: dP = dH * (1 - H^2) was already formed in the dgrad GEMM's epilogue; this only reduces it:
 // dPE[b,t,:] = sum_u dP[b,t,u,:], dPD[b,u,:] += sum_t dP[b,t,u,:].  4 columns per thread, 8-byte loads.
 __global__ __launch_bounds__(256) void joint_sum_bwd_bf16x4_kernel(const bf16_t* __restrict__ dP, int T, int U1, int J,
@@ -923,17 +924,17 @@ __global__ __launch_bounds__(256) void joint_sum_bwd_bf16x4_kernel(const bf16_t*
     __shared__ float xch[4 * 256];                     // per wave: 256 column sums on their way to lane-contiguous atomics
     const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
     const bool act = j < J;                            // (whole waves stay alive: the exchange is per wave)
-    const int t0 = blockIdx.y * JT_TC;
+    const int t0 = blockIdx.y * JT_TC4;
     const int b = blockIdx.z;
-    float accE[JT_TC][4];
+    float accE[JT_TC4][4];
 #pragma unroll
-    for (int i = 0; i < JT_TC; ++i)
+    for (int i = 0; i < JT_TC4; ++i)
 #pragma unroll
         for (int c = 0; c < 4; ++c) accE[i][c] = 0.f;
     for (int u = 0; u < U1; ++u) {
         float accD[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int tt = 0; tt < JT_TC; ++tt) {
+        for (int tt = 0; tt < JT_TC4; ++tt) {
             const int t = t0 + tt;
             if (t < T && act) {
                 const uint2 w = *reinterpret_cast<const uint2*>(dP + (((long)b * T + t) * U1 + u) * J + j);
@@ -955,7 +956,7 @@ __global__ __launch_bounds__(256) void joint_sum_bwd_bf16x4_kernel(const bf16_t*
         }
     }
 #pragma unroll
-    for (int tt = 0; tt < JT_TC; ++tt)
+    for (int tt = 0; tt < JT_TC4; ++tt)
         if (t0 + tt < T && act)
             *reinterpret_cast<float4*>(dPE + ((long)b * T + t0 + tt) * J + j) = make_float4(accE[tt][0], accE[tt][1], accE[tt][2], accE[tt][3]);
 }
@@ -1328,7 +1329,7 @@ int joint_tanh_bwd(const void* dH, const void* H, int h_dtype, int B, int T, int
     TTMI_REQUIRE(dH && dPE && dPD && B > 0 && T > 0 && U1 > 0 && J > 0, "joint_tanh_bwd: bad arguments");
     if (!H) {     // dH already holds dH * (1 - H^2) (formed in the dgrad epilogue)
         TTMI_REQUIRE(h_dtype == 1 && J % 4 == 0 && aligned16(dPE) && (reinterpret_cast<uintptr_t>(dH) & 7) == 0, "joint_tanh_bwd: pre-multiplied input needs bf16, J %% 4 == 0");
-        hipLaunchKernelGGL(joint_sum_bwd_bf16x4_kernel, dim3(cdiv(J, 1024), cdiv(T, JT_TC), B), dim3(256), 0, st,
+        hipLaunchKernelGGL(joint_sum_bwd_bf16x4_kernel, dim3(cdiv(J, 1024), cdiv(T, JT_TC4), B), dim3(256), 0, st,
                            static_cast<const bf16_t*>(dH), T, U1, J, dPE, dPD);
         TTMI_LAUNCH_CHECK("joint_sum_bwd_bf16 kernel");
         return TTMI_OK;
