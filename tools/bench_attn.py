@@ -22,17 +22,18 @@ ops.set_option(10, int(os.environ.get("TTMI_SLICES", "1")))   # attention backwa
 ops.set_option(5, int(os.environ.get("TTMI_SLAB", "0")))      # 1 = slab by GEMM; 2 / 4 = skip the slab kernel's MFMA part / stores
 B, L = int(os.environ.get("B", 32)), int(os.environ.get("L", 500))
 torch.manual_seed(0)
-layer = BaseEncoder(k_len=410, n_head=8, d_model=512, d_head=64, d_inner=1024, dropout=0.0).cuda()
+layer = BaseEncoder(k_len=int(os.environ.get("K", 410)), n_head=8, d_model=512, d_head=64, d_inner=1024, dropout=float(os.environ.get("DROPOUT", 0.0))).cuda()
+MASK = MaskSpec(int(os.environ.get("MASK", 0)))      # 1 = causal (the label encoder)
 x = torch.randn(B, L, 512, device="cuda", requires_grad=True)
 cot = torch.randn(B, L, 512, device="cuda")
 for it in range(6):
-    y = layer.forward_bm(x, MaskSpec(0))
+    y = layer.forward_bm(x, MASK)
     (y * cot).sum().backward()
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record()
 for it in range(10):
-    y = layer.forward_bm(x, MaskSpec(0))
+    y = layer.forward_bm(x, MASK)
     (y * cot).sum().backward()
 e.record()
 torch.cuda.synchronize()

@@ -623,9 +623,12 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_rel_kernel(const FlashParams
 // window of 63 table rows; G = Qsel . Eext_window^T is two 32x32 MFMA blocks (rows = queries, columns = p'; q_i below L, q_{i+1} above,
 // both with the other side's table rows zeroed in the block that holds p' = L), skewed through a private LDS image [p'][query].
 // Loads the compiler does not know about (flash_bwd_rel_kernel's tile prefetch): between their issue and their first use a step issues
-// its 64 dS / dG stores, and vmcnt is a 6-bit in-order counter - the compiler's own wait for such a load is vmcnt(0), i.e. it drains all
+// its 32 dS / dG store instructions (16 elements x 2 slabs per wave), and vmcnt is an in-order counter - the compiler's own wait for such a load is vmcnt(0), i.e. it drains all
 // 64 stores once per step.  Issued by asm, the loads are invisible to its scoreboard; the kernel waits for them itself with
-// s_waitcnt vmcnt(63) (everything but the 63 youngest operations, which are stores) and hands the registers over through pg_ready.
+// s_waitcnt vmcnt(32) - everything but the 32 youngest operations, and EVERY path of a step issues at least its 32 slab stores after the
+// prefetch (checked in the ISA: Sx32 per step) - and hands the registers over through an empty asm with "+v" operands.  (A first version
+// waited for vmcnt(63), taking a step's stores for 64: that guaranteed nothing - the loads were merely always back by then, until B = 8 x
+// L = 2000 under the full model's memory traffic let one land after the loop, in registers that by then held an address: a rare illegal access.)
 __device__ __forceinline__ u32x4_t ld16_async(const void* p) {
     u32x4_t v;
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
@@ -744,7 +747,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
     };
     // (every load and every park below is executed by ALL threads - 32 rows x NCH chunks = one chunk per thread for Dh = 64; the few
     // scalars are fetched and parked redundantly by the 8 threads that share tid & 31.  Loads under `if (tid < ..)` put a control-flow
-    // join behind them, and at a join the compiler waits for vmcnt(0): that drained the tile's 64 dS / dG stores once per step.)
+    // join behind them, and at a join the compiler waits for vmcnt(0): that drained the tile's dS / dG stores once per step.)
     constexpr bool ALLCH = 32 * T::NCH >= 256;
     auto fetch_bias = [&](int i0) {
         const int wbase = L - 32 - i0 + jw0;
@@ -885,9 +888,9 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
     fetch_rows(ibeg);
     auto step = [&](int i0, bool first) {
         __syncthreads();
-        // the prefetched registers: issued one step ago, in front of that step's 64 slab stores (the very first tile: in front of nothing)
+        // the prefetched registers: issued one step ago, in front of that step's 32 slab store instructions (the very first tile: in front of nothing)
         if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         asm volatile("" : "+v"(opre), "+v"(epre), "+v"(ppre), "+v"(cpre), "+v"(lse_pre), "+v"(del_pre), "+v"(lo_pre), "+v"(hi_pre));
         if (ALLCH || tid < 32 * T::NCH) *reinterpret_cast<u32x4_t*>(dotile + T::off(tid / T::NCH, tid % T::NCH)) = opre;
         parked_i0 = i0;

@@ -298,6 +298,8 @@ class RelLearnableDecoderLayer(nn.Module):
         """batch-major [B, L, d] in/out through ONE call per direction (_LayerFn).  x16: the bf16 copy of x the previous layer returned;
         want16: return (z, bf16 copy of z) for the next layer - both only where ops.layer_fused() says the layer runs fused."""
         a, f = self.dec_attn, self.pos_ff
+        if os.environ.get("TTMI_SUBLAYER_CALLS"):      # measurement / debugging: the two sub-layer calls of rounds 1-2 instead of the layer-level one
+            return f(a.forward_bm(x, r_emb, r_w_bias, r_bias, mask, prec), prec, _drop_p(self, self.dropout.p))
         prec = default_precision() if prec is None else prec
         pa, pf, pl = _drop_p(a, a.dropout), _drop_p(f, f.dropout), _drop_p(self, self.dropout.p)
         seed_attn = _new_seed(pa)                      # (drawn in the order the two sub-layer calls draw them)
@@ -311,6 +313,8 @@ class RelLearnableDecoderLayer(nn.Module):
     def fused(self, prec=None):
         """does this layer run the fused layer-level kernels (may bf16 copies of the residual stream be handed to / taken from it)?"""
         a, f = self.dec_attn, self.pos_ff
+        if os.environ.get("TTMI_SUBLAYER_CALLS"):
+            return False
         return ops.layer_fused(a.d_model, a.n_head, a.d_head, f.d_inner, default_precision() if prec is None else prec)
 
     def forward(self, input, r_emb, r_w_bias, r_bias, attn_mask=None):

@@ -30,6 +30,9 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.ttmi_last_error.restype = ctypes.c_char_p
         _lib.ttmi_rnnt_workspace_bytes.restype = ctypes.c_size_t
+        for kv in filter(None, os.environ.get("TTMI_OPTIONS", "").split(",")):       # measurement switches (ttmi_set_option), e.g. "11=1,12=256"
+            k, v = kv.split("=")
+            _lib.ttmi_set_option(int(k), int(v))
     return _lib
 
 

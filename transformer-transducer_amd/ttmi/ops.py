@@ -4,12 +4,22 @@ torch is plumbing only (device memory, current stream).  Every function here
 launches hand-written HIP kernels; none has a PyTorch/CPU fallback.
 """
 import ctypes
+import os
+import sys
 
 import torch
 
 from . import check, lib
 
 c_int, c_long, c_float, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
+
+
+_TRACE = bool(os.environ.get("TTMI_TRACE_CALLS"))       # debugging: name and shape of every layer-level call on stderr before it is issued
+
+
+def _trace(name, *dims):
+    if _TRACE:
+        print("[ttmi] %s %s stream %x" % (name, dims, torch.cuda.current_stream().cuda_stream), file=sys.stderr, flush=True)
 
 
 def _p(t):
@@ -260,6 +270,7 @@ def scratch_generation(device, stream):
 
 def attn_fwd(x, p, mask, prec, p_drop=0.0, seed=0):
     """p: dict of parameter tensors (qkv_w, o_w, ln_g, ln_b, r_emb, r_w_bias, r_bias)."""
+    _trace("attn_fwd", tuple(x.shape))
     _need_cuda(x)
     B, L, d = x.shape
     K, H, Dh = p["r_emb"].shape
@@ -279,6 +290,7 @@ def attn_fwd(x, p, mask, prec, p_drop=0.0, seed=0):
 def attn_bwd(dy, x, p, ctx, prec, grads, p_drop=0.0, seed=0, mask=None, defer=None):
     """grads: dict of ZERO-INITIALISED (or running) f32 buffers, accumulated into.  defer: a WgradQueue - the two weight-gradient GEMMs
     are queued for a grouped launch instead of run here (their gradients appear when the queue is flushed)."""
+    _trace("attn_bwd", tuple(x.shape))
     B, L, d = x.shape
     K, H, Dh = p["r_emb"].shape
     L_ = lib()
@@ -305,6 +317,7 @@ def attn_bwd(dy, x, p, ctx, prec, grads, p_drop=0.0, seed=0, mask=None, defer=No
 
 
 def ffn_fwd(y, p, prec, p_drop=0.0, p_layer=0.0, seed=0):
+    _trace("ffn_fwd", tuple(y.shape))
     rows, d = y.numel() // y.shape[-1], y.shape[-1]
     Di = p["ff_w1"].shape[0]
     L_ = lib()
@@ -321,6 +334,7 @@ def ffn_fwd(y, p, prec, p_drop=0.0, p_layer=0.0, seed=0):
 
 
 def ffn_bwd(dz, y, p, ctx, prec, grads, p_drop=0.0, p_layer=0.0, seed=0, defer=None):
+    _trace("ffn_bwd", tuple(y.shape))
     rows, d = y.numel() // y.shape[-1], y.shape[-1]
     Di = p["ff_w1"].shape[0]
     L_ = lib()
@@ -356,6 +370,7 @@ def _layer_ws(L_, B, L, d, H, Dh, Di, prec, device):
 def layer_fwd(x, x16, pa, pf, mask, prec, p_attn=0.0, seed_attn=0, p_ffn=0.0, p_layer=0.0, seed_ffn=0, want16=False):
     """one encoder layer (attention sub-layer + FFN) in one call: -> (y, z, z16 or None, ctx_attn, ctx_ffn).  pa / pf: the parameter
     dicts of attn_fwd / ffn_fwd; x16: bf16 copy of x from the previous layer's z16 (or None); want16: also return bf16(z)."""
+    _trace("layer_fwd", tuple(x.shape))
     _need_cuda(x)
     B, L, d = x.shape
     K, H, Dh = pa["r_emb"].shape
@@ -379,6 +394,7 @@ def layer_fwd(x, x16, pa, pf, mask, prec, p_attn=0.0, seed_attn=0, p_ffn=0.0, p_
 def layer_bwd(dz, x, x16, y, pa, pf, ctx_a, ctx_f, prec, grads, mask=None, p_attn=0.0, seed_attn=0, p_ffn=0.0, p_layer=0.0, seed_ffn=0, defer=None):
     """backward of layer_fwd -> dx; grads: running f32 buffers by parameter name (both sub-layers'), accumulated into.  defer: a WgradQueue
     that takes the layer's four weight-gradient GEMMs."""
+    _trace("layer_bwd", tuple(x.shape))
     B, L, d = x.shape
     K, H, Dh = pa["r_emb"].shape
     Di = pf["ff_w1"].shape[0]
