@@ -517,6 +517,23 @@ def main():
                                             reduction="none", chunk=args.loss_chunk or None, exp_domain=form == "exp")
                 enc_s, dec_s = model._encode(inputs[:args.cpu_utts], targets[:args.cpu_utts])      # the timed precision's encoder states of the same sample
                 enc_s, dec_s = enc_s.double().cpu().numpy(), dec_s.double().cpu().numpy()
+                # the whole batch's loss in the timed form against the fp32 mode of the same model (the mode the tests hold within 1e-6 of the
+                # oracle, tests/test_configs_gpu.py::test_c2_full_model_fp32_end_to_end): what the precision mode does to the step's LOSS - the
+                # mean over the batch that train.py:53 computes - as opposed to the worst single utterance of the oracle sample below
+                batch_rel = None
+                if args.precision == "bf16" and args.workload == "c2":
+                    c16 = (model.loss(inputs, ilen, targets, tlen, reduction="none", chunk=args.loss_chunk or None, exp_domain=form == "exp")
+                           if form != "two-call" else RNNTLoss(reduction="none")(model(inputs, targets), targets.int(), ilen, tlen)).double()
+                    os.environ["TTMI_PRECISION"] = "fp32"
+                    try:
+                        ops.weights_fresh()
+                        c32 = RNNTLoss(reduction="none")(model(inputs, targets), targets.int(), ilen, tlen).double()
+                    finally:
+                        os.environ["TTMI_PRECISION"] = args.precision
+                        ops.weights_fresh()
+                    batch_rel = float((c16.mean() - c32.mean()).abs() / c32.mean())
+                    utt_rel = float(((c16 - c32).abs() / c32).max())
+                    del c16, c32
             v, dt, rel, times, oracle_costs = cpu_baseline(model, feats, proj, targets, T, U, args.cpu_utts, costs.float().cpu().numpy(), args.cpu_reps)
             floor = encoder_floor(model, enc_s, dec_s, targets, T, U, args.cpu_utts, oracle_costs)
             out["cpu_baseline"] = {"value": round(v, 4), "unit": "utt/s", "cores": _blas_threads(), "kind": "port",
@@ -529,6 +546,9 @@ def main():
             # how much of that distance the encoders' precision alone accounts for: the ORACLE's float64 joint + lattice fed the GPU's encoder
             # states of the same sample (bf16 mode: 12 / 6 layers of bf16 GEMM operands leave ~2e-3 relative error on the states)
             out["loss_rel_err_encoder_states_only"] = float("%.3e" % floor)
+            if batch_rel is not None:
+                out["loss_rel_err_batch_vs_fp32_mode"] = {"batch_mean": float("%.3e" % batch_rel), "worst_utterance": float("%.3e" % utt_rel), "utterances": B,
+                                                          "note": "the timed form's loss of the whole batch against TTMI_PRECISION=fp32 on the same weights and inputs (eval mode)"}
             if form != "two-call":
                 out["loss_rel_err_vs_oracle_timed_form"] = float("%.3e" % (np.abs(costs_form.float().cpu().numpy() - oracle_costs).max() / np.abs(oracle_costs).max()))
         print(json.dumps(out), flush=True)
