@@ -15,6 +15,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch
 
+np.set_printoptions(formatter={"float_kind": lambda v: "%.3g" % v})      # (array2string would print 1.6e-04 as 0.)
+
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=50)
 ap.add_argument("--n", type=int, default=2)
