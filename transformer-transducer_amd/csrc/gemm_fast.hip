@@ -753,7 +753,8 @@ __device__ __forceinline__ void epi_store8_bf16(const FP& p, bf16_t* C, int m, i
 constexpr int T8 = 256, NTH8 = 512, HT8 = 128 * 64 * 2, BUF8 = 4 * HT8;   // buffer: [A h0 | A h1 | B h0 | B h1]
 constexpr int LDS8 = 2 * BUF8 + 8 * 4096;
 
-// LEAN: 1 = the instance for bias-only bf16 outputs (the joint forward), 2 = for mask-only ones (the joint dgrad's tanh', ReLU'): their epilogues
+// LEAN: 1 = the instance for bias-only bf16 outputs (the joint forward), 2 = for mask-only ones (the joint dgrad's tanh', ReLU'), 5 = bias + ReLU + dropout
+// (the FFN's first Linear): their epilogues
 // carry no residual / ReLU / dropout code and test nothing per store, which
 // costs the main loop registers in the general instance
 template <typename TC, int LEAN = 0>
@@ -864,7 +865,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p_) {
     // LEAN 1 / 3 (bias and exp-store epilogues): the accumulators START as the bias of their column - nothing is added in the epilogue -
     // read from a per-wave LDS row (64 floats) that the previous tile's epilogue filled for this tile's columns.  Columns beyond N hold
     // -3e38 in the exp-store form: exp2 of it is the exact zero the padded pitch needs.
-    constexpr bool BIAS_INIT = LEAN == 1 || LEAN == 3;
+    constexpr bool BIAS_INIT = LEAN == 1 || LEAN == 3 || LEAN == 5;
     float* brow = reinterpret_cast<float*>(smem + 2 * BUF8 + 16384 + wave * 256);
     auto bias_of = [&](int bn_) -> float {
         const int col = bn_ + wc * 64 + lane;
@@ -962,8 +963,8 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p_) {
                     if constexpr (LEAN == 4) rs[q] = p.rowscale[lm0 + mi * 16 + q * 8];
                 }
         };
-        if constexpr (LEAN == 1 || LEAN == 3) {
-            // bias / exp epilogues (the K = 1024 projection, where the un-overlapped epilogue is a third of the tile): the bias is already
+        if constexpr (LEAN == 1 || LEAN == 3 || LEAN == 5) {
+            // bias / exp / bias + ReLU + dropout epilogues (the K = 1024 projection, where the un-overlapped epilogue is a third of the tile): the bias is already
             // in the accumulators, the values are rounded to bf16 BEFORE the transposing trip through LDS (half the LDS traffic of
             // the f32 image), and the trip of slab s overlaps the arithmetic of slab s + 1 (DS operations of a wave execute in order: the
             // next slab's writes cannot overtake this slab's reads of the same image).
@@ -996,6 +997,12 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p_) {
                                 v[ni][j] = __builtin_amdgcn_exp2f(v[ni][j] * 1.4426950408889634f - eshift2);
                                 rs += v[ni][j];
                             }
+                        }
+                        if constexpr (LEAN == 5) {        // ReLU, then the dropout mask of the lane's four consecutive columns (one hash word)
+                            float dm[4];
+                            drop_mult4(p.drop, (unsigned long long)(cbm + wr * 128 + sl * 16 + wrow) * p.ldc + (cbn + wc * 64 + ni * 16 + g * 4), dm);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[ni][j] = fmaxf(v[ni][j], 0.f) * dm[j];
                         }
                         const uint2 w = {pack_bf16x2(v[ni][0], v[ni][1]), pack_bf16x2(v[ni][2], v[ni][3])};
                         *reinterpret_cast<uint2*>(wimg + (((ni * 4 + g) ^ wsw) << 3)) = w;
@@ -2376,6 +2383,9 @@ if (c_dtype == 0) {
         } else if (!p.addend && !p.mask && !p.relu && p.drop.p <= 0.f && ldc % 8 == 0 && aligned16(C) && (!p.bias || aligned16(p.bias))) {
             if (int rc = enable_lds((gemm_nt_bf16_v8_kernel<bf16_t, 1>), LDS8)) return rc;
             hipLaunchKernelGGL((gemm_nt_bf16_v8_kernel<bf16_t, 1>), dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
+        } else if (!p.addend && !p.mask && p.relu && !p.rowscale && ldc % 8 == 0 && aligned16(C) && (!p.bias || aligned16(p.bias))) {
+            if (int rc = enable_lds((gemm_nt_bf16_v8_kernel<bf16_t, 5>), LDS8)) return rc;
+            hipLaunchKernelGGL((gemm_nt_bf16_v8_kernel<bf16_t, 5>), dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
         } else if (p.rowscale) {
             TTMI_REQUIRE(!p.addend && p.mask && p.mask_mode == 1 && !p.bias && !p.relu && p.drop.p <= 0.f && ldc % 8 == 0 && aligned16(C) && aligned16(p.mask),
                          "gemm_nt_bf16: the row factor needs the tanh-mask bf16 epilogue");
