@@ -41,6 +41,9 @@ struct FlashParams {
     int mask_kind = 0, mask_left = 0, mask_right = 0;   // kind 2: the band; kind 4: bounds on the intervals' reach from the diagonal (-1 = unknown)
     const unsigned char* mask = nullptr;
     long mask_sb = 0, mask_si = 0;
+    float* zero_f32 = nullptr;    // flash_attn_bwd only: zero_n floats to clear (the dE / dc accumulators of the position gradients) and, with
+    long zero_n = 0;              // zero_dg_row0, row 0 of every dG16 slab (the shifted store never writes it) - by the delta kernel's launch
+    int zero_dg_row0 = 0;
     int bwd_skip = 0;             // set by flash_attn_bwd: dS16 / dG16 are pre-zeroed, the kernel walks only the query tiles its key block can meet
     int debug = 0;                // measurement only (ttmi_set_option(2, bits)): 1 = skip the bias read, 2 = skip the dS write
 };

@@ -1261,8 +1261,17 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) 
 // delta[z, i] = sum_d dO[b,i,h,d] * O[b,i,h,d]
 template <int DH>
 __global__ __launch_bounds__(256) void flash_delta_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O, long ld, int B,
-                                                          int L, int H, float* __restrict__ delta) {
+                                                          int L, int H, float* __restrict__ delta, float* __restrict__ zero_f32, long zero_n,
+                                                          bf16_t* __restrict__ dG16, long slab16, int ldp) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;          // (b, i, h)
+    // small zero fills of the backward pass that would otherwise be launches of their own (FlashParams::zero_*)
+    const long nthreads = (long)gridDim.x * 256;
+    for (long t = idx; t < zero_n; t += nthreads) zero_f32[t] = 0.f;
+    if (dG16) {
+        const int w = ldp >> 1;                                      // row 0 of a slab as 32-bit words (ldp % 8 == 0, slabs 16-byte aligned)
+        for (long t = idx; t < (long)B * H * w; t += nthreads)
+            reinterpret_cast<uint32_t*>(dG16 + (t / w) * slab16)[t % w] = 0u;
+    }
     if (idx >= (long)B * L * H) return;
     const int h = (int)(idx % H);
     const long bi = idx / H;
@@ -1729,8 +1738,9 @@ int flash_attn_bwd(const FlashParams& p, hipStream_t st) {
         }
         q.bwd_skip = 1;
     }
-    if (p.Dh == 64) hipLaunchKernelGGL(flash_delta_kernel<64>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta);
-    else hipLaunchKernelGGL(flash_delta_kernel<32>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta);
+    bf16_t* zg = p.zero_dg_row0 ? p.dG16 : nullptr;
+    if (p.Dh == 64) hipLaunchKernelGGL(flash_delta_kernel<64>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta, p.zero_f32, p.zero_f32 ? p.zero_n : 0L, zg, p.slab16, (int)p.ldp);
+    else hipLaunchKernelGGL(flash_delta_kernel<32>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta, p.zero_f32, p.zero_f32 ? p.zero_n : 0L, zg, p.slab16, (int)p.ldp);
     // in-kernel position term: (64 + 32 + 64 + 256) tile rows + cext ring + lse / delta + lo / hi + 4 private images of [64][36] bf16
 #define BWD_LAUNCH(MKV) do { \
         if (p.e16) { \

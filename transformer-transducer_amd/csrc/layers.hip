@@ -199,6 +199,8 @@ struct AttnCtx {   // saved for backward.  act = f32 (parity) or bf16 (fast)
     float *P, *s1, *mean, *rstd, *lse;     // P: f32 probabilities (unfused path) or the bf16 position-term slab (fused path, first half)
     bf16_t* x16 = nullptr;                 // bf16 copy of the input (fast): the qkv wgrad reads it again in backward
     bf16_t *wqkvT16 = nullptr, *woT16 = nullptr;   // transposed bf16 weights for the dgrads, made in forward from the same read as the plain copies
+    bf16_t* E16s = nullptr;                // in-kernel position term: the effective table (bf16) and its bias for this length, gathered by the
+    float* cTs = nullptr;                  // forward pass and read again by the backward kernels (no second gather launch)
     AttnCtx(Bump& b, const AttnDims& a, bool fast) {
         const size_t es = fast ? 2 : 4;
         qkv = b.take<char>(a.BL * a.W3 * es);
@@ -213,6 +215,10 @@ struct AttnCtx {   // saved for backward.  act = f32 (parity) or bf16 (fast)
             x16 = b.take<bf16_t>(a.BL * a.d);
             wqkvT16 = b.take<bf16_t>(a.W3 * a.d);
             woT16 = b.take<bf16_t>(a.HD * a.d);
+            if (attn_inkernel(fast, a)) {
+                E16s = b.take<bf16_t>((size_t)a.L * a.HD);
+                cTs = b.take<float>((size_t)a.H * a.L);
+            }
         }
     }
 };
@@ -279,15 +285,15 @@ FlashParams flash_params(const AttnDims& a, const AttnCtx& c, float scale, int m
 }
 
 // position term formed inside the attention kernels: plain q (first third of the qkv rows), the effective table in bf16 and its bias
-void flash_inkernel(FlashParams& f, const AttnDims& a, const AttnCtx& c, const AttnWs& w, const float* r_w_bias) {
+void flash_inkernel(FlashParams& f, const AttnDims& a, const AttnCtx& c, const bf16_t* E16, const float* cT, const float* r_w_bias) {
     f.bd = nullptr;
     f.qu = nullptr;
     f.u = r_w_bias;
     f.qp = static_cast<const bf16_t*>(c.qkv);
     f.ld_qp = a.W3;
-    f.e16 = w.E16;
+    f.e16 = E16;
     f.ld_e = a.HD;
-    f.cT = w.cT;
+    f.cT = cT;
 }
 
 int memset2d(void* p, size_t pitch, size_t width, size_t height, hipStream_t st) {
@@ -362,7 +368,7 @@ static int attn_fwd_impl(const float* x, const float* qkv_w, const float* o_w, c
     }
     // 3. effective tables for this length (clamped rows when L > K); the fused kernels' bf16 copy comes out of the same launch
     const bool inkernel = attn_inkernel(fast, a);
-    CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st, inkernel ? w.E16 : nullptr));
+    CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, inkernel ? c.cTs : w.cT, st, inkernel ? c.E16s : nullptr));
     // 4. G = q E^T + c into the pitch-(L+1) slab, column 0 zero - unless the fused kernels form the position term themselves
     if (inkernel) {
     } else if (attn_fused(fast, a) && g_gemm_slab == 0 && (size_t)16 * (L + 1) * 4 + 32 <= 160 * 1024) {
@@ -390,7 +396,7 @@ static int attn_fwd_impl(const float* x, const float* qkv_w, const float* o_w, c
     if (attn_fused(fast, a)) {
         // 5-7 fused: softmax((q+u) k^T + shifted(G)) V without materialising the probabilities
         FlashParams f = flash_params(a, c, scale, mask_kind, mask_left, mask_right, mask, mask_sb, mask_si);
-        if (inkernel) flash_inkernel(f, a, c, w, r_w_bias);
+        if (inkernel) flash_inkernel(f, a, c, c.E16s, c.cTs, r_w_bias);
         CK(flash_attn_fwd(f, st));
     } else {
         // 5. S = shifted(G) + (q+u) k^T, accumulated through the pitch-L view
@@ -492,12 +498,19 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
         // 4-6 + 9 fused: recompute P, dS = P (dP - delta) scale, dK and dV straight into dqkv.  dS leaves the kernel twice in
         // bf16 with aligned rows: [i][j] for the content dgrad and the shifted [r][c-1] form (= dG) for the position grads.
         const int bper = (B + nslice - 1) / nslice;
-        CK(memset2d(w.dG16, (size_t)w.slab16 * 2, (size_t)w.ldp * 2, (size_t)bper * H, st));       // dG row 0 is (almost) never written
+        // one pass over the slabs for dq, dE, dc and d r_w_bias (attn_dqde_kernel) where its shape fits, the round-2 GEMM launches otherwise
+        const bool onepass = fastpos && !g_posgrad_gemms && attn_dqde_supported(Dh, L, w.ldp);
+        // the small zero fills of this pass (dG row 0 of every slab, the dE / dc accumulators) ride in the delta kernel's launch where one
+        // launch covers the batch; sliced runs keep the memsets (the accumulators must survive from slice to slice)
+        const bool fillz = fastpos && nslice == 1;
+        if (!fillz) CK(memset2d(w.dG16, (size_t)w.slab16 * 2, (size_t)w.ldp * 2, (size_t)bper * H, st));       // dG row 0 is (almost) never written
         FlashParams f = flash_params(a, c, scale, mask_kind, mask_left, mask_right, mask, mask_sb, mask_si);
-        if (attn_inkernel(fast, a)) {                // the kernel recomputes the position term: effective table + bias for this length, as in forward
-            CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st, w.E16));
+        const bf16_t* E16 = w.E16;
+        if (attn_inkernel(fast, a)) {                // the kernel recomputes the position term from the table + bias the forward pass gathered for this length
             TTMI_REQUIRE(r_w_bias, "attn_bwd: r_w_bias is required (the attention kernels form q + r_w_bias themselves)");
-            flash_inkernel(f, a, c, w, r_w_bias);
+            if (!onepass) CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st, w.E16));     // (the GEMM launches transpose the f32 table)
+            else E16 = c.E16s;
+            flash_inkernel(f, a, c, c.E16s, c.cTs, r_w_bias);
         } else if (fastpos) {
             CK(relpos_gather(r_emb, r_bias, K, L, H, Dh, w.E, w.cT, st, w.E16)); // the effective table of the position products below
         }
@@ -506,11 +519,10 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
         f.dS16 = w.dS16; f.dG16 = w.dG16; f.ldp = w.ldp; f.slab16 = w.slab16;
         f.dK = w.dqkv + a.HD; f.dV = w.dqkv + 2 * a.HD; f.ld_dkv = a.W3;
         f.dK16 = w.dqkv16 + a.HD; f.dV16 = w.dqkv16 + 2 * a.HD;
-        // one pass over the slabs for dq, dE, dc and d r_w_bias (attn_dqde_kernel) where its shape fits, the round-2 GEMM launches otherwise
-        const bool onepass = fastpos && !g_posgrad_gemms && attn_dqde_supported(Dh, L, w.ldp);
+        if (fillz) { f.zero_f32 = w.dE; f.zero_n = (long)L * a.HD + (long)H * L; f.zero_dg_row0 = 1; }
         if (!fastpos) CK(flash_attn_bwd(f, st));
         else {
-            CK(fill_zero(w.dE, sizeof(float) * ((size_t)L * a.HD + (size_t)H * L), st));
+            if (!fillz) CK(fill_zero(w.dE, sizeof(float) * ((size_t)L * a.HD + (size_t)H * L), st));
             if (!onepass) {
                 // K-major operands of the position / content products, for the whole batch, ahead of the slices
                 // (K runs over the padded pitch ldp: the pad columns of dS16 / dG16 are zeroed by the flash backward kernel itself)
@@ -534,7 +546,7 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
                 CK(flash_attn_bwd(fs, st));
                 if (onepass) {
                     const bf16_t* qkv16 = static_cast<const bf16_t*>(c.qkv) + r0 * a.W3;
-                    CK(attn_dqde(w.dS16, w.dG16, w.slab16, w.ldp, qkv16 + a.HD, a.W3, w.E16, a.HD, qkv16, a.W3, w.dqkv16 + r0 * a.W3, a.W3,
+                    CK(attn_dqde(w.dS16, w.dG16, w.slab16, w.ldp, qkv16 + a.HD, a.W3, E16, a.HD, qkv16, a.W3, w.dqkv16 + r0 * a.W3, a.W3,
                                  w.dE, a.HD, w.dcT, g_r_w_bias, nb, L, H, st));
                     continue;
                 }
