@@ -165,6 +165,9 @@ class _FFNFn(torch.autograd.Function):
         return (dy, *rets, None, None, None, None, None)
 
 
+_SUBLAYER_CALLS = bool(os.environ.get("TTMI_SUBLAYER_CALLS"))       # read once: (A/B runs and debugging only)
+
+
 class _LayerFn(torch.autograd.Function):
     """One encoder layer = ONE C-ABI call per direction (ttmi_layer_fwd / ttmi_layer_bwd): the attention sub-layer and the FFN share the
     passes over the residual stream that two calls force apart (ttmi.h).  x16 / the second output: bf16 copies of the layer's input and
@@ -298,7 +301,7 @@ class RelLearnableDecoderLayer(nn.Module):
         """batch-major [B, L, d] in/out through ONE call per direction (_LayerFn).  x16: the bf16 copy of x the previous layer returned;
         want16: return (z, bf16 copy of z) for the next layer - both only where ops.layer_fused() says the layer runs fused."""
         a, f = self.dec_attn, self.pos_ff
-        if os.environ.get("TTMI_SUBLAYER_CALLS"):      # measurement / debugging: the two sub-layer calls of rounds 1-2 instead of the layer-level one
+        if _SUBLAYER_CALLS:                            # measurement / debugging: the two sub-layer calls of rounds 1-2 instead of the layer-level one
             return f(a.forward_bm(x, r_emb, r_w_bias, r_bias, mask, prec), prec, _drop_p(self, self.dropout.p))
         prec = default_precision() if prec is None else prec
         pa, pf, pl = _drop_p(a, a.dropout), _drop_p(f, f.dropout), _drop_p(self, self.dropout.p)
@@ -313,7 +316,7 @@ class RelLearnableDecoderLayer(nn.Module):
     def fused(self, prec=None):
         """does this layer run the fused layer-level kernels (may bf16 copies of the residual stream be handed to / taken from it)?"""
         a, f = self.dec_attn, self.pos_ff
-        if os.environ.get("TTMI_SUBLAYER_CALLS"):
+        if _SUBLAYER_CALLS:
             return False
         return ops.layer_fused(a.d_model, a.n_head, a.d_head, f.d_inner, default_precision() if prec is None else prec)
 
