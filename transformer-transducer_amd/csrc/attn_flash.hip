@@ -889,8 +889,11 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
     auto step = [&](int i0, bool first) {
         __syncthreads();
         // the prefetched registers: issued one step ago, in front of that step's 32 slab store instructions (the very first tile: in front of nothing)
+        // (16 accumulator elements x one store into each of the two slabs: the count the wait below leaves in flight - keep the two in step)
+        constexpr int SLAB_STORES_PER_STEP = 2 * 16;
+        static_assert(SLAB_STORES_PER_STEP == 32 && SLAB_STORES_PER_STEP <= 63, "the prefetch wait below counts a step's slab store instructions");
         if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLAB_STORES_PER_STEP) : "memory");
         asm volatile("" : "+v"(opre), "+v"(epre), "+v"(ppre), "+v"(cpre), "+v"(lse_pre), "+v"(del_pre), "+v"(lo_pre), "+v"(hi_pre));
         if (ALLCH || tid < 32 * T::NCH) *reinterpret_cast<u32x4_t*>(dotile + T::off(tid / T::NCH, tid % T::NCH)) = opre;
         parked_i0 = i0;
