@@ -113,9 +113,11 @@ int ttmi_rnnt_loss_bwd(const void* logits, int dtype, long ldv, const int* label
  * (row factor in the dgrad epilogue and on the wgrad's activation operand; ctx is overwritten).
  * shift / shift_cur: device scalar (nullable = 0) subtracted before exp; shift_next (device scalar, nullable):
  * max(itself, max_rows(log-sum-exp) - 40), the value to pass as shift on the next step.
- * emis (nullable, f32 [rows, 2], 8-byte aligned): ttmi_joint_fwd_exp also leaves the logits of `blank` and of each row's next label
- * (labels int32 [B, U1-1]) in f32 - formed from the bf16 operands the projection multiplies - and ttmi_rnnt_loss_fwd_exp takes the two
- * emission log-probs from them instead of from bf16-rounded entries of P (loss error of the form: ~5e-5 -> ~1e-5 at C2).
+ * emis (nullable, f32 [rows, 4], 16-byte aligned): ttmi_joint_fwd_exp also leaves the logits of `blank` and of each row's next label
+ * (labels int32 [B, U1-1]) in f32, twice: formed from the bf16 operands the projection multiplies (entries 0, 1: what P and its row
+ * sums contain) and from the unrounded hidden row with the f32 weight (entries 2, 3).  ttmi_rnnt_loss_fwd_exp exchanges the two columns'
+ * terms of the row sum for the accurate ones and takes the emission log-probs from entries 2, 3: the bf16 rounding of the projection
+ * weight is the same in every row, so the blank column's error does not average out along an alignment.
  * flag (nullable, device int): bit 0 is set when a lattice row's sum underflowed or overflowed (the shift no longer fits the logits);
  * the costs and gradients of that step are then NaN (never finite-and-wrong): drop the step, run one step in the plain form and take a new
  * shift from its workspace with ttmi_rnnt_shift_seed (no host synchronisation anywhere in the protocol). */

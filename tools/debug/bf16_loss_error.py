@@ -101,7 +101,7 @@ def report(tag):
 
 report("step 0")
 done = 0
-for stop in sorted({10, 25, args.steps}):
+for stop in sorted({10, 25, 50, 80, 120, args.steps}):
     if stop > args.steps:
         break
     while done < stop:

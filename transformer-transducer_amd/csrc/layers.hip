@@ -1004,8 +1004,9 @@ static int joint_fwd_impl(const float* enc, const float* dec, const float* wf, c
     const bf16_t* wp16 = Wp16;
     if (shadow_of(wp, V, J, (V + 63) / 64 * 64, shp)) wp16 = shp.w16;
     else CK(convert_bf16(wp, Wp16, (long)V * J, st));
-    // exp-domain form with `emis`: the blank / label logits of every lattice row also leave in f32, from the same bf16 operands the GEMM reads
-    if (emis) CK(joint_tanh_fwd_emis(PE, PD, bf, B, T, U1, J, H16, wp16, bp, labels, V, blank, emis, st));
+    // exp-domain form with `emis`: the blank / label logits of every lattice row also leave in f32 - from the same bf16 operands the GEMM reads
+    // (what P and its row sums contain) and from f32 operands (what the loss makes the emission log-probs of)
+    if (emis) CK(joint_tanh_fwd_emis(PE, PD, bf, B, T, U1, J, H16, wp16, wp, bp, labels, V, blank, emis, st));
     else CK(joint_tanh_fwd(PE, PD, bf, B, T, U1, J, H16, 1, st));
     NtEpilogue e;
     e.bias = bp; e.rowsum = rowsum; e.nparts = nparts; e.exp_shift = shift;

@@ -590,8 +590,8 @@ __global__ __launch_bounds__(LSE_WAVES * 64) void rnnt_grad_kernel(
 // per row, the backward leaves the row factor s_r = gscale * exp(alpha + beta - ll - log S) to the consuming GEMMs
 // (d logits[r, v] = s_r * P[r, v] everywhere but at the blank / label columns, which are patched in P here).
 constexpr float EXP_SHIFT_MARGIN = 40.f;
-// emis (nullable): f32 [rows, 2] logits of the blank and of the row's next label (ttmi_joint_fwd_exp): the two emission log-probs are then
-// logit - shift - log S instead of the logarithm of a bf16-rounded entry of P (|error| <= 2^-9 per emission, ~5e-5 of a C2 loss).
+// emis (nullable): f32 [rows, 4] from ttmi_joint_fwd_exp - the logits of the blank and of the row's next label, first as the GEMM formed them
+// (bf16 operands), then from f32 operands: the emission log-probs are logit_f32 - shift - log S', S' = S with those two columns' terms exchanged.
 // flag (nullable, device int): bit 0 is set when a row of the lattice lost its sum - every exp(logit - shift) underflowed, or the sum overflowed:
 // the shift in use no longer fits the logits.  Such a row's log-sum-exp becomes NaN, so the utterance's cost and every gradient of the step are
 // NaN rather than finite and wrong; callers drop the step and re-seed the shift (ttmi_rnnt_shift_seed).
@@ -611,11 +611,22 @@ __global__ __launch_bounds__(256) void rnnt_prep_exp_kernel(
     const long rows = (long)B * T * U1;
     float S = 0.f;
     for (int i = 0; i < nparts; ++i) S += rowsum[i * rows + row];        // part-major: coalesced across the block's rows
+    const float cur = shift_cur ? *shift_cur : 0.f;
+    float zb = 0.f, zy = 0.f;
+    if (emis) {
+        // the two columns the loss reads (blank, next label) enter the row's softmax with their f32-operand logits: their terms of the sum,
+        // which the GEMM formed from bf16 operands, are exchanged for the accurate ones.  The bf16 rounding of the projection weights is the
+        // same number in every row, so the blank column's error does not average out along an alignment - it was most of the loss error.
+        const float4 z = *reinterpret_cast<const float4*>(emis + row * 4);
+        zb = z.z;
+        zy = z.w;
+        S += __expf(zb - cur) - __expf(z.x - cur);
+        if (u < Ub && clampi(labels[(long)b * (U1 - 1) + u], 0, V - 1) != blank) S += __expf(zy - cur) - __expf(z.y - cur);
+    }
     const bool good = S > 1.0e-37f && S < 3.0e38f;                        // false also for NaN
     if (!good && flag) atomicOr(flag, 1);
     const float l = good ? __logf(S) : __int_as_float(0x7fc00000);
     lse[row] = l;
-    const float cur = shift_cur ? *shift_cur : 0.f;
     if (shift_next && good) {
         // the shift the NEXT step should use: this row's log-sum-exp in logit units, less a margin that keeps exp() far from both
         // ends of the f32 / bf16 range.  Non-negative floats order like their bit patterns, so an integer atomic max does it.
@@ -625,9 +636,8 @@ __global__ __launch_bounds__(256) void rnnt_prep_exp_kernel(
     const bf16_t* r = P + row * ldv;
     const long di = (long)b * diag_stride(T, U1) + (long)(t + u) * U1 + u;
     if (emis) {
-        const float2 z = *reinterpret_cast<const float2*>(emis + row * 2);
-        lpb_d[di] = z.x - cur - l;
-        lpl_d[di] = u < Ub ? z.y - cur - l : NEG;
+        lpb_d[di] = zb - cur - l;
+        lpl_d[di] = u < Ub ? zy - cur - l : NEG;
         return;
     }
     const float pb = ldf<bf16_t>(r + blank);

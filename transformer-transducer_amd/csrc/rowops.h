@@ -64,10 +64,11 @@ int embed_bwd(const long* tokens, const float* dout, long n, int d, int V, int p
 // H[b,t,u,:] = tanh(PE[b,t,:] + PD[b,u,:] + bias)    (H f32 or bf16)
 int joint_tanh_fwd(const float* PE, const float* PD, const float* bias, int B, int T, int U1, int J, void* H, int h_dtype,
                    hipStream_t st);
-// the same with bf16 H, plus emis[row] = (logit of `blank`, logit of the row's next label labels[b][u]) in f32, formed from the bf16 H and
-// the bf16 projection weight Wp16 [V, J] the GEMM multiplies (exp-domain loss form; row (b,t,U1-1) has no label: entry 1 = blank's)
+// the same with bf16 H, plus emis[row] = 4 f32 logits: (blank, the row's next label labels[b][u]) formed from the bf16 H and the bf16
+// projection weight Wp16 [V, J] exactly as the GEMM multiplies them, and the same two from the unrounded hidden row and the f32 master
+// weight Wp32 (exp-domain loss form; row (b,t,U1-1) has no label: its label entries = the blank's)
 int joint_tanh_fwd_emis(const float* PE, const float* PD, const float* bias, int B, int T, int U1, int J, bf16_t* H, const bf16_t* Wp16,
-                        const float* bp, const int* labels, int V, int blank, float* emis, hipStream_t st);
+                        const float* Wp32, const float* bp, const int* labels, int V, int blank, float* emis, hipStream_t st);
 // dpre = dH * (1 - H^2);  dPE[b,t,:] = sum_u dpre, dPD[b,u,:] += sum_t dpre (atomic; caller zeroes dPD)
 int joint_tanh_bwd(const void* dH, const void* H, int h_dtype, int B, int T, int U1, int J, float* dPE, float* dPD,
                    hipStream_t st);

@@ -742,9 +742,10 @@ __global__ __launch_bounds__(256) void joint_tanh_fwd_bf16x4_kernel(const float*
 // bound by its 2 bytes per element of output; the dot products ride in its idle VALU slots, the label rows of Wp16 come from L2.
 struct JointEmis {
     const bf16_t* Wp16 = nullptr;   // [V, J] bf16, the projection's B operand
+    const float* Wp32 = nullptr;    // [V, J] f32, the master weight the bf16 copy was rounded from
     const float* bp = nullptr;      // [V]
     const int* labels = nullptr;    // [B, U1 - 1]
-    float* out = nullptr;           // [B * T * U1, 2]
+    float* out = nullptr;           // [B * T * U1, 4]: blank / label logit from the GEMM's operands, blank / label logit from f32 operands
     int V = 0, blank = 0;
 };
 __device__ __forceinline__ void unpack_bf16x8(const uint4& w, float* f) {
@@ -775,7 +776,7 @@ template <bool EMIS>
 __global__ __launch_bounds__(256) void joint_tanh_fwd_bf16x8_kernel(const float* __restrict__ PE, const float* __restrict__ PD,
                                                                     const float* __restrict__ bias, int T, int U1, int J,
                                                                     bf16_t* __restrict__ H, JointEmis em) {
-    extern __shared__ float part[];        // EMIS: [JT_TT][U1][waves per row][2] partial dot products
+    extern __shared__ float part[];        // EMIS: [JT_TT][U1][waves per row][4] partial dot products
     const int tblocks = (T + JT_TT - 1) / JT_TT;
     const int b = blockIdx.x / tblocks, t0 = (blockIdx.x % tblocks) * JT_TT;
     const int nt = min(JT_TT, T - t0);
@@ -795,13 +796,17 @@ __global__ __launch_bounds__(256) void joint_tanh_fwd_bf16x8_kernel(const float*
         }
     }
     const float* pd = PD + (long)b * U1 * J + j;
-    float wb[8];
+    float wb[8], wb32[8];
     const int nw = tpr >= 64 ? tpr >> 6 : 1;            // waves that share one row
-    if constexpr (EMIS) unpack_bf16x8(*reinterpret_cast<const uint4*>(em.Wp16 + (long)em.blank * J + j), wb);
+    if constexpr (EMIS) {
+        unpack_bf16x8(*reinterpret_cast<const uint4*>(em.Wp16 + (long)em.blank * J + j), wb);
+        const float4 a0 = *reinterpret_cast<const float4*>(em.Wp32 + (long)em.blank * J + j), a1 = *reinterpret_cast<const float4*>(em.Wp32 + (long)em.blank * J + j + 4);
+        wb32[0] = a0.x; wb32[1] = a0.y; wb32[2] = a0.z; wb32[3] = a0.w; wb32[4] = a1.x; wb32[5] = a1.y; wb32[6] = a1.z; wb32[7] = a1.w;
+    }
 #pragma unroll 2
     for (int u = grp; u < U1; u += ngrp) {
         const float4 d0 = *reinterpret_cast<const float4*>(pd + (long)u * J), d1 = *reinterpret_cast<const float4*>(pd + (long)u * J + 4);
-        float wl[8];
+        float wl[8], wl32[8];
         if constexpr (EMIS) {
             int y = em.blank;
             if (u < U1 - 1) {
@@ -809,28 +814,37 @@ __global__ __launch_bounds__(256) void joint_tanh_fwd_bf16x8_kernel(const float*
                 y = y < 0 ? 0 : (y >= em.V ? em.V - 1 : y);
             }
             unpack_bf16x8(*reinterpret_cast<const uint4*>(em.Wp16 + (long)y * J + j), wl);
+            const float4 a0 = *reinterpret_cast<const float4*>(em.Wp32 + (long)y * J + j), a1 = *reinterpret_cast<const float4*>(em.Wp32 + (long)y * J + j + 4);
+            wl32[0] = a0.x; wl32[1] = a0.y; wl32[2] = a0.z; wl32[3] = a0.w; wl32[4] = a1.x; wl32[5] = a1.y; wl32[6] = a1.z; wl32[7] = a1.w;
         }
 #pragma unroll
         for (int tt = 0; tt < JT_TT; ++tt) {
             if (tt < nt) {                                  // (block-uniform)
+                const float th[8] = {fast_tanh(e[tt][0] + d0.x), fast_tanh(e[tt][1] + d0.y), fast_tanh(e[tt][2] + d0.z), fast_tanh(e[tt][3] + d0.w),
+                                     fast_tanh(e[tt][4] + d1.x), fast_tanh(e[tt][5] + d1.y), fast_tanh(e[tt][6] + d1.z), fast_tanh(e[tt][7] + d1.w)};
                 uint4 w;
-                w.x = pack_bf16x2(fast_tanh(e[tt][0] + d0.x), fast_tanh(e[tt][1] + d0.y));
-                w.y = pack_bf16x2(fast_tanh(e[tt][2] + d0.z), fast_tanh(e[tt][3] + d0.w));
-                w.z = pack_bf16x2(fast_tanh(e[tt][4] + d1.x), fast_tanh(e[tt][5] + d1.y));
-                w.w = pack_bf16x2(fast_tanh(e[tt][6] + d1.z), fast_tanh(e[tt][7] + d1.w));
+                w.x = pack_bf16x2(th[0], th[1]);
+                w.y = pack_bf16x2(th[2], th[3]);
+                w.z = pack_bf16x2(th[4], th[5]);
+                w.w = pack_bf16x2(th[6], th[7]);
                 *reinterpret_cast<uint4*>(H + ((bt0 + tt) * U1 + u) * J + j) = w;
                 if constexpr (EMIS) {
+                    // two logits twice: from the operands the GEMM multiplies (bf16 h, bf16 weights: what P and its row sum contain) and from the
+                    // unrounded h with the f32 master weights (what the emission log-probs should be made of)
                     float hv[8];
                     unpack_bf16x8(w, hv);
-                    float db = 0.f, dl = 0.f;
+                    float db = 0.f, dl = 0.f, db32 = 0.f, dl32 = 0.f;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) { db = fmaf(hv[i], wb[i], db); dl = fmaf(hv[i], wl[i], dl); }
+                    for (int i = 0; i < 8; ++i) {
+                        db = fmaf(hv[i], wb[i], db); dl = fmaf(hv[i], wl[i], dl);
+                        db32 = fmaf(th[i], wb32[i], db32); dl32 = fmaf(th[i], wl32[i], dl32);
+                    }
                     // sum over the lanes of this wave that hold the row (all 64, or an aligned group of tpr = 32): the group's last lane gets it
-                    if (tpr >= 64) { db = dpp_row_sum<true>(db); dl = dpp_row_sum<true>(dl); }
-                    else { db = dpp_row_sum<false>(db); dl = dpp_row_sum<false>(dl); }
+                    if (tpr >= 64) { db = dpp_row_sum<true>(db); dl = dpp_row_sum<true>(dl); db32 = dpp_row_sum<true>(db32); dl32 = dpp_row_sum<true>(dl32); }
+                    else { db = dpp_row_sum<false>(db); dl = dpp_row_sum<false>(dl); db32 = dpp_row_sum<false>(db32); dl32 = dpp_row_sum<false>(dl32); }
                     if ((tin & 63) == 63 || (tpr == 32 && (tin & 31) == 31)) {
-                        float* q = part + (((long)tt * U1 + u) * nw + (tin >> 6)) * 2;
-                        q[0] = db; q[1] = dl;
+                        float* q = part + (((long)tt * U1 + u) * nw + (tin >> 6)) * 4;
+                        *reinterpret_cast<float4*>(q) = make_float4(db, dl, db32, dl32);
                     }
                 }
             }
@@ -840,17 +854,18 @@ __global__ __launch_bounds__(256) void joint_tanh_fwd_bf16x8_kernel(const float*
         __syncthreads();
         for (int i = threadIdx.x; i < nt * U1; i += 256) {
             const int tt = i / U1, u = i - tt * U1;
-            float sb = 0.f, sl = 0.f;
-            for (int w = 0; w < nw; ++w) { sb += part[((long)i * nw + w) * 2]; sl += part[((long)i * nw + w) * 2 + 1]; }     // fixed order
+            float sb = 0.f, sl = 0.f, sb32 = 0.f, sl32 = 0.f;
+            for (int w = 0; w < nw; ++w) {                                              // fixed order
+                const float4 q = *reinterpret_cast<const float4*>(part + ((long)i * nw + w) * 4);
+                sb += q.x; sl += q.y; sb32 += q.z; sl32 += q.w;
+            }
             int y = em.blank;
             if (u < U1 - 1) {
                 y = em.labels[(long)b * (U1 - 1) + u];
                 y = y < 0 ? 0 : (y >= em.V ? em.V - 1 : y);
             }
-            float2 o;
-            o.x = sb + em.bp[em.blank];
-            o.y = sl + em.bp[y];
-            *reinterpret_cast<float2*>(em.out + ((bt0 + tt) * U1 + u) * 2) = o;
+            const float bb = em.bp[em.blank], by = em.bp[y];
+            *reinterpret_cast<float4*>(em.out + ((bt0 + tt) * U1 + u) * 4) = make_float4(sb + bb, sl + by, sb32 + bb, sl32 + by);
         }
     }
 }
@@ -869,17 +884,22 @@ __global__ __launch_bounds__(256) void joint_emis_kernel(const bf16_t* __restric
     }
     const bf16_t* h = H + row * J;
     const bf16_t *w0 = em.Wp16 + (long)em.blank * J, *w1 = em.Wp16 + (long)y * J;
-    float db = 0.f, dl = 0.f;
+    const float *f0 = em.Wp32 + (long)em.blank * J, *f1 = em.Wp32 + (long)y * J;
+    float db = 0.f, dl = 0.f, db32 = 0.f, dl32 = 0.f;
     for (int j = lane; j < J; j += 64) {
-        const float hv = bf16_to_f32(h[j]);
+        const float hv = bf16_to_f32(h[j]);                 // (only the rounded h exists here: the second pair corrects the weights' rounding alone)
         db = fmaf(hv, bf16_to_f32(w0[j]), db);
         dl = fmaf(hv, bf16_to_f32(w1[j]), dl);
+        db32 = fmaf(hv, f0[j], db32);
+        dl32 = fmaf(hv, f1[j], dl32);
     }
     db = wave_sum(db);
     dl = wave_sum(dl);
+    db32 = wave_sum(db32);
+    dl32 = wave_sum(dl32);
     if (lane == 0) {
-        em.out[row * 2] = db + em.bp[em.blank];
-        em.out[row * 2 + 1] = dl + em.bp[y];
+        const float bb = em.bp[em.blank], by = em.bp[y];
+        *reinterpret_cast<float4*>(em.out + row * 4) = make_float4(db + bb, dl + by, db32 + bb, dl32 + by);
     }
 }
 
@@ -1302,17 +1322,16 @@ int joint_tanh_fwd(const float* PE, const float* PD, const float* bias, int B, i
 
 // bf16 H plus the f32 blank / label logits of every lattice row (exp-domain loss form): emis [B*T*U1, 2]
 int joint_tanh_fwd_emis(const float* PE, const float* PD, const float* bias, int B, int T, int U1, int J, bf16_t* H, const bf16_t* Wp16,
-                        const float* bp, const int* labels, int V, int blank, float* emis, hipStream_t st) {
-    TTMI_REQUIRE(PE && PD && bias && H && Wp16 && bp && emis && (labels || U1 == 1) && B > 0 && T > 0 && U1 > 0 && J > 0 && V > 0 &&
+                        const float* Wp32, const float* bp, const int* labels, int V, int blank, float* emis, hipStream_t st) {
+    TTMI_REQUIRE(PE && PD && bias && H && Wp16 && Wp32 && bp && emis && (labels || U1 == 1) && B > 0 && T > 0 && U1 > 0 && J > 0 && V > 0 &&
                  blank >= 0 && blank < V, "joint_tanh_fwd_emis: bad arguments");
-    TTMI_REQUIRE((reinterpret_cast<uintptr_t>(emis) & 7) == 0, "joint_tanh_fwd_emis: emis must be 8-byte aligned");
+    TTMI_REQUIRE(aligned16(emis), "joint_tanh_fwd_emis: emis must be 16-byte aligned");
     JointEmis em;
-    em.Wp16 = Wp16; em.bp = bp; em.labels = labels; em.out = emis; em.V = V; em.blank = blank;
-    const size_t part_bytes = (size_t)JT_TT * U1 * (J / 8 >= 64 ? J / 8 / 64 : 1) * 2 * sizeof(float);
+    em.Wp16 = Wp16; em.Wp32 = Wp32; em.bp = bp; em.labels = labels; em.out = emis; em.V = V; em.blank = blank;
+    const size_t part_bytes = (size_t)JT_TT * U1 * (J / 8 >= 64 ? J / 8 / 64 : 1) * 4 * sizeof(float);
     if ((J == 256 || J == 512 || J == 1024 || J == 2048) && aligned16(PE) && aligned16(PD) && aligned16(bias) && aligned16(H) && aligned16(Wp16) &&
-        part_bytes <= 60 * 1024) {
-        const int nw = J / 8 >= 64 ? J / 8 / 64 : 1;
-        hipLaunchKernelGGL(joint_tanh_fwd_bf16x8_kernel<true>, dim3(B * cdiv(T, JT_TT)), dim3(256), (size_t)JT_TT * U1 * nw * 2 * sizeof(float), st,
+        aligned16(Wp32) && part_bytes <= 60 * 1024) {
+        hipLaunchKernelGGL(joint_tanh_fwd_bf16x8_kernel<true>, dim3(B * cdiv(T, JT_TT)), dim3(256), part_bytes, st,
                            PE, PD, bias, T, U1, J, H, em);
         TTMI_LAUNCH_CHECK("joint_tanh_fwd_bf16x8_kernel<emis>");
         return TTMI_OK;

@@ -486,7 +486,8 @@ def joint_exp_supported(B, T, U1, J, V, prec, fwd_only=False):
 
 def joint_fwd_exp(enc, dec, wf, bf, wp, bp, prec, shift=None, labels=None, blank=0):
     """-> (P bf16 [B,T,U1,V] view of a pitch-roundup(V,64) buffer = exp(logits - shift), rowsum f32 [nparts, B*T*U1], ctx, emis).
-    labels (int32 [B, U1-1]) given: emis f32 [B*T*U1, 2] = the blank's and the next label's logit of every lattice row, else None"""
+    labels (int32 [B, U1-1]) given: emis f32 [B*T*U1, 4] = the blank's and the next label's logit of every lattice row (from the GEMM's bf16
+    operands, then from f32 operands), else None"""
     B, T, de = enc.shape
     U1, dd = dec.shape[1], dec.shape[2]
     J, V = wf.shape[0], wp.shape[0]
@@ -502,7 +503,7 @@ def joint_fwd_exp(enc, dec, wf, bf, wp, bp, prec, shift=None, labels=None, blank
     if labels is not None:
         _need_cuda(labels)
         assert labels.dtype is torch.int32 and labels.is_contiguous() and tuple(labels.shape) == (B, U1 - 1)
-        emis = torch.empty(B * T * U1, 2, dtype=torch.float32, device=enc.device)
+        emis = torch.empty(B * T * U1, 4, dtype=torch.float32, device=enc.device)
     check(L_.ttmi_joint_fwd_exp(_p(enc), _p(dec), _p(wf), _p(bf), _p(wp), _p(bp), c_int(B), c_int(T), c_int(U1), c_int(de),
                                 c_int(dd), c_int(J), c_int(V), c_int(prec), _p(ctx), _p(ws), _p(P), c_long(buf.shape[-1]),
                                 _p(rowsum), c_int(nparts), _p(shift), _p(labels), c_int(blank), _p(emis), _stream()), "ttmi_joint_fwd_exp")
@@ -510,7 +511,7 @@ def joint_fwd_exp(enc, dec, wf, bf, wp, bp, prec, shift=None, labels=None, blank
 
 
 def rnnt_loss_fwd_exp(P, rowsum, labels, act_lens, label_lens, blank, workspace, shift_cur=None, shift_next=None, emis=None, flag=None):
-    """emis: f32 [rows, 2] from joint_fwd_exp (the emission log-probs then come from f32 logits, not from bf16 entries of P); flag: device
+    """emis: f32 [rows, 4] from joint_fwd_exp (the emission log-probs then come from f32 logits, not from bf16 entries of P); flag: device
     int32 [1], bit 0 set when a row sum under- / overflowed (that step's costs and gradients are NaN)"""
     _need_cuda(P, rowsum, labels, act_lens, label_lens, workspace, emis, flag)
     B, T, U1, V = P.shape
