@@ -944,7 +944,8 @@ static inline bool joint_input_fast(int prec, int B, int T, int U1, int de, int 
     if (!joint_fast(prec, J) || de % 8 || dd % 8 || (long)B * T < 1024) return false;
     const size_t M = (size_t)B * T * U1, din = (size_t)de + dd;
     const size_t need = al8((size_t)B * T * de) + al8((size_t)B * U1 * dd) + al8((size_t)B * T * J) + al8((size_t)B * U1 * J) + al8(din * J) + 8;
-    return need <= (size_t)M * J;                           // bf16 elements behind dH16 (backward); the forward pass needs less
+    // bf16 elements behind dH16 (backward); the forward pass has the whole region (2 M J elements) for its copies and the weight's second split term
+    return need <= (size_t)M * J && need + al8(din * J) <= 2 * (size_t)M * J;
 }
 // dtype of the logits this configuration produces / expects: 0 = f32, 1 = bf16
 int ttmi_joint_logits_dtype(int prec, int J) { return joint_fast(prec, J) ? 1 : 0; }
@@ -982,6 +983,15 @@ static int joint_fwd_impl(const float* enc, const float* dec, const float* wf, c
         else CK(convert_bf16(wf, Wf16, (long)J * din, st));
         CK(gemm_nt_bf16(enc16, wf16, PE, 0, nullptr, B * T, J, de, de, din, J, st));
         CK(gemm_nt_bf16(dec16, wf16 + de, PD, 0, nullptr, B * U1, J, dd, dd, din, J, st));
+        // second term of the weight's bf16 split (w ~ w16 + lo16): the rounding of [We | Wd] is ONE pattern applied to every frame and label, so
+        // its effect on the loss does not average out over a batch; two small GEMMs more (1 % of the projection's work) take it out
+        bf16_t* Wf16lo = Wf16 + al8((size_t)J * din);
+        CK(bf16_residual(wf, wf16, Wf16lo, (long)J * din, st));
+        NtEpilogue ea, eb;
+        ea.addend = PE;
+        eb.addend = PD;
+        CK(gemm_nt_bf16(enc16, Wf16lo, PE, 0, ea, B * T, J, de, de, din, J, st));
+        CK(gemm_nt_bf16(dec16, Wf16lo + de, PD, 0, eb, B * U1, J, dd, dd, din, J, st));
     } else {
         CK(ttmi_launch_gemm(mk(enc, wf, PE, B * T, J, de, de, din, J, NT_, prec), st));
         CK(ttmi_launch_gemm(mk(dec, wf + de, PD, B * U1, J, dd, dd, din, J, NT_, prec), st));

@@ -981,6 +981,12 @@ __global__ __launch_bounds__(256) void joint_sum_bwd_bf16x4_kernel(const bf16_t*
             *reinterpret_cast<float4*>(dPE + ((long)b * T + t0 + tt) * J + j) = make_float4(accE[tt][0], accE[tt][1], accE[tt][2], accE[tt][3]);
 }
 
+// lo[i] = bf16(src[i] - float(hi[i])): the second term of a two-term bf16 split of an f32 weight (hi = bf16(src))
+__global__ void bf16_residual_kernel(const float* __restrict__ src, const bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) lo[i] = f32_to_bf16(src[i] - bf16_to_f32(hi[i]));
+}
+
 __global__ void convert_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i + 3 < n) {
@@ -1370,6 +1376,13 @@ int fill_zero(void* p, size_t bytes, hipStream_t st) {
         ttmi_set_error("fill_zero: %s", hipGetErrorString(e));
         return (int)e;
     }
+    return TTMI_OK;
+}
+
+int bf16_residual(const float* src, const bf16_t* hi, bf16_t* lo, long n, hipStream_t st) {
+    TTMI_REQUIRE(src && hi && lo && n > 0, "bf16_residual: bad arguments");
+    hipLaunchKernelGGL(bf16_residual_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, src, hi, lo, n);
+    TTMI_LAUNCH_CHECK("bf16_residual_kernel");
     return TTMI_OK;
 }
 
