@@ -995,6 +995,17 @@ static int joint_fwd_impl(const float* enc, const float* dec, const float* wf, c
     } else {
         CK(ttmi_launch_gemm(mk(enc, wf, PE, B * T, J, de, de, din, J, NT_, prec), st));
         CK(ttmi_launch_gemm(mk(dec, wf + de, PD, B * U1, J, dd, dd, din, J, NT_, prec), st));
+        if (prec == 1 && (size_t)M >= (size_t)din) {
+            // the same second split term on the generic kernel (it rounds f32 operands to bf16 while staging): the residual of the weight's
+            // rounding in f32, in the first workspace region (dH's, free in the forward pass: M J >= din J floats), accumulated with beta = 1
+            float* R = ws;
+            CK(bf16_residual_f32(wf, R, (long)J * din, st));
+            GemmDesc g1 = mk(enc, R, PE, B * T, J, de, de, din, J, NT_, prec), g2 = mk(dec, R + de, PD, B * U1, J, dd, dd, din, J, NT_, prec);
+            g1.beta = 1.f;
+            g2.beta = 1.f;
+            CK(ttmi_launch_gemm(g1, st));
+            CK(ttmi_launch_gemm(g2, st));
+        }
     }
     if (!fast) {
         float* Hh = ctx;

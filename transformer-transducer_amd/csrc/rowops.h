@@ -77,6 +77,8 @@ int fill_zero(void* p, size_t bytes, hipStream_t st);
 int convert_bf16(const float* src, bf16_t* dst, long n, hipStream_t st);
 // lo (bf16) = src - float(hi): the second term of the two-term bf16 split src ~ hi + lo
 int bf16_residual(const float* src, const bf16_t* hi, bf16_t* lo, long n, hipStream_t st);
+// r (f32) = src - float(bf16(src)): the same term for kernels that round f32 operands while staging them
+int bf16_residual_f32(const float* src, float* r, long n, hipStream_t st);
 // dst[c, r] (bf16, pitch ldd >= R, columns [R, ldd) zero) = src[r, c] (f32, [R, C] dense)
 // plain (optional): also the untransposed bf16 copy [R, C] (forward passes get both from one read of the weight)
 int transpose_convert_bf16(const float* src, int R, int C, bf16_t* dst, long ldd, hipStream_t st, bf16_t* plain = nullptr);

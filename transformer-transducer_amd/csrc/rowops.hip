@@ -987,6 +987,12 @@ __global__ void bf16_residual_kernel(const float* __restrict__ src, const bf16_t
     if (i < n) lo[i] = f32_to_bf16(src[i] - bf16_to_f32(hi[i]));
 }
 
+// r[i] = src[i] - float(bf16(src[i])) in f32 (what a kernel that rounds its operands while staging turns into the same second split term)
+__global__ void bf16_residual_f32_kernel(const float* __restrict__ src, float* __restrict__ r, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) r[i] = src[i] - bf16_to_f32(f32_to_bf16(src[i]));
+}
+
 __global__ void convert_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i + 3 < n) {
@@ -1383,6 +1389,13 @@ int bf16_residual(const float* src, const bf16_t* hi, bf16_t* lo, long n, hipStr
     TTMI_REQUIRE(src && hi && lo && n > 0, "bf16_residual: bad arguments");
     hipLaunchKernelGGL(bf16_residual_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, src, hi, lo, n);
     TTMI_LAUNCH_CHECK("bf16_residual_kernel");
+    return TTMI_OK;
+}
+
+int bf16_residual_f32(const float* src, float* r, long n, hipStream_t st) {
+    TTMI_REQUIRE(src && r && n > 0, "bf16_residual_f32: bad arguments");
+    hipLaunchKernelGGL(bf16_residual_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, src, r, n);
+    TTMI_LAUNCH_CHECK("bf16_residual_f32_kernel");
     return TTMI_OK;
 }
 
