@@ -316,12 +316,13 @@ class Transducer(nn.Module):
                                   j.exp_shift_state(enc_state.device) if exp_domain and prec == 1 else None, torch.is_grad_enabled())
 
     def default_loss_chunk(self, B, T, U1, exp_domain=False):
-        """utterances per chunk of `loss()`: about 2 GB of logits (the memory-saving form) or 16 GB (exp_domain: the speed form - every
-        chunk boundary costs a pipeline fill of the three big GEMMs, C2 whole batch 35.0 ms per step, two halves 36.2), adjusted to a
+        """utterances per chunk of `loss()`: about 2 GB of logits (the memory-saving form) or 32 GB (exp_domain: the speed form - every
+        chunk boundary costs a pipeline fill of the three big GEMMs and one more lattice launch: C2 whole batch 35.0 ms per step, two
+        halves 36.2; C5's 28 GB in one chunk 102.0 ms, in two 104.2 - on 288 GB of HBM the budget is not the constraint), adjusted to a
         lattice-row count the joint's persistent wgrad kernel takes (a reduction length chunk * T * U1 that is a multiple of its 64-row
         K-tile; other lengths fall to the 128x128 kernel at twice the time: C2, 8 utterances 9.5 ms per step, 16 utterances 5.3 ms)"""
         es = 2 if ops.joint_logits_dtype(default_precision(), self.joint.forward_layer.out_features) is torch.bfloat16 else 4
-        budget = (16 << 30) if exp_domain else (2 << 30)
+        budget = (32 << 30) if exp_domain else (2 << 30)
         chunk = max(1, min(B, int(budget // (es * T * U1 * self.config.vocab_size))))
         ok = [c for c in range(1, B + 1) if (c * T * U1) % 64 == 0]
         if ok:
