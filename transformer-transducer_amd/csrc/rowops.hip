@@ -655,17 +655,38 @@ __global__ void relpos_gather_kernel(const float* __restrict__ r_emb, const floa
 
 __global__ void relpos_scatter_kernel(const float* __restrict__ dE, const float* __restrict__ dcT, int K, int L, int H, int Dh,
                                       float* __restrict__ g_emb, float* __restrict__ g_bias) {
+    // rows p >= L - K of the effective table map one to one onto table rows e = p + K - L; the L - K rows below (sequences longer than the
+    // table) all fold onto row 0 - relpos_fold_row0_kernel sums those in chunks first (as atomics from here they serialised on one row:
+    // 0.19 ms per audio layer at L = 2000)
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long n = (long)L * H * Dh;
     if (idx < n) {
         const int p = (int)(idx / (H * Dh));
-        const int e = max(0, p + K - L);
-        atomicAdd(g_emb + (long)e * H * Dh + idx % (H * Dh), dE[idx]);
+        const int e = p + K - L;
+        if (e >= 0) atomicAdd(g_emb + (long)e * H * Dh + idx % (H * Dh), dE[idx]);
     }
     if (idx < (long)L * H) {
         const int h = (int)(idx / L), p = (int)(idx % L);
-        const int e = max(0, p + K - L);
-        atomicAdd(g_bias + (long)e * H + h, dcT[idx]);
+        const int e = p + K - L;
+        if (e >= 0) atomicAdd(g_bias + (long)e * H + h, dcT[idx]);
+    }
+}
+
+constexpr int FOLD_ROWS = 32;
+__global__ __launch_bounds__(256) void relpos_fold_row0_kernel(const float* __restrict__ dE, const float* __restrict__ dcT, int nclamp, int L,
+                                                               int H, int Dh, float* __restrict__ g_emb, float* __restrict__ g_bias) {
+    const int c = blockIdx.x * 256 + threadIdx.x;                 // column of the [L, H*Dh] table gradient
+    const int p0 = blockIdx.y * FOLD_ROWS, p1 = min(p0 + FOLD_ROWS, nclamp);
+    const int HD = H * Dh;
+    if (c < HD) {
+        float acc = 0.f;
+        for (int p = p0; p < p1; ++p) acc += dE[(long)p * HD + c];
+        atomicAdd(g_emb + c, acc);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < H) {
+        float acc = 0.f;
+        for (int p = p0; p < p1; ++p) acc += dcT[(long)threadIdx.x * L + p];
+        atomicAdd(g_bias + threadIdx.x, acc);
     }
 }
 
@@ -1297,6 +1318,11 @@ int relpos_scatter(const float* dE, const float* dcT, int K, int L, int H, int D
     hipLaunchKernelGGL(relpos_scatter_kernel, dim3(cdiv((long)L * H * Dh, 256)), dim3(256), 0, st, dE, dcT, K, L, H, Dh, g_r_emb,
                        g_r_bias);
     TTMI_LAUNCH_CHECK("relpos_scatter_kernel");
+    if (L > K) {
+        hipLaunchKernelGGL(relpos_fold_row0_kernel, dim3(cdiv(H * Dh, 256), cdiv(L - K, FOLD_ROWS)), dim3(256), 0, st, dE, dcT, L - K, L, H, Dh,
+                           g_r_emb, g_r_bias);
+        TTMI_LAUNCH_CHECK("relpos_fold_row0_kernel");
+    }
     return TTMI_OK;
 }
 
