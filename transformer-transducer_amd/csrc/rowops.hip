@@ -654,21 +654,21 @@ __global__ void relpos_gather_kernel(const float* __restrict__ r_emb, const floa
 }
 
 __global__ void relpos_scatter_kernel(const float* __restrict__ dE, const float* __restrict__ dcT, int K, int L, int H, int Dh,
-                                      float* __restrict__ g_emb, float* __restrict__ g_bias) {
+                                      float* __restrict__ g_emb, float* __restrict__ g_bias, int folded) {
     // rows p >= L - K of the effective table map one to one onto table rows e = p + K - L; the L - K rows below (sequences longer than the
-    // table) all fold onto row 0 - relpos_fold_row0_kernel sums those in chunks first (as atomics from here they serialised on one row:
-    // 0.19 ms per audio layer at L = 2000)
+    // table) all fold onto row 0.  folded: relpos_fold_row0_kernel sums those in chunks (as atomics from here they serialise on one row:
+    // 0.19 ms per audio layer at L = 2000, K = 410); a few dozen such rows (C2: 90) are cheaper as atomics than as a second launch
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long n = (long)L * H * Dh;
     if (idx < n) {
         const int p = (int)(idx / (H * Dh));
         const int e = p + K - L;
-        if (e >= 0) atomicAdd(g_emb + (long)e * H * Dh + idx % (H * Dh), dE[idx]);
+        if (e >= 0 || !folded) atomicAdd(g_emb + (long)max(e, 0) * H * Dh + idx % (H * Dh), dE[idx]);
     }
     if (idx < (long)L * H) {
         const int h = (int)(idx / L), p = (int)(idx % L);
         const int e = p + K - L;
-        if (e >= 0) atomicAdd(g_bias + (long)e * H + h, dcT[idx]);
+        if (e >= 0 || !folded) atomicAdd(g_bias + (long)max(e, 0) * H + h, dcT[idx]);
     }
 }
 
@@ -1315,10 +1315,11 @@ int relpos_gather(const float* r_emb, const float* r_bias, int K, int L, int H, 
 int relpos_scatter(const float* dE, const float* dcT, int K, int L, int H, int Dh, float* g_r_emb, float* g_r_bias,
                    hipStream_t st) {
     TTMI_REQUIRE(dE && dcT && g_r_emb && g_r_bias, "relpos_scatter: bad arguments");
+    const int folded = L - K >= 256;
     hipLaunchKernelGGL(relpos_scatter_kernel, dim3(cdiv((long)L * H * Dh, 256)), dim3(256), 0, st, dE, dcT, K, L, H, Dh, g_r_emb,
-                       g_r_bias);
+                       g_r_bias, folded);
     TTMI_LAUNCH_CHECK("relpos_scatter_kernel");
-    if (L > K) {
+    if (folded) {
         hipLaunchKernelGGL(relpos_fold_row0_kernel, dim3(cdiv(H * Dh, 256), cdiv(L - K, FOLD_ROWS)), dim3(256), 0, st, dE, dcT, L - K, L, H, Dh,
                            g_r_emb, g_r_bias);
         TTMI_LAUNCH_CHECK("relpos_fold_row0_kernel");
