@@ -288,7 +288,7 @@ def main():
 
     for kv in os.environ.get("TTMI_OPTIONS", "").split(","):          # measurement switches, e.g. TTMI_OPTIONS=3:0 (no wgrad fork); see include/ttmi.h
         if kv:
-            ops.set_option(int(kv.split(":")[0]), int(kv.split(":")[1]))
+            ops.set_option(*(int(v) for v in kv.replace("=", ":").split(":")))          # "k:v" or "k=v" (the library loader reads the same variable)
 
     form = "fused" if args.fused_loss and args.loss_form == "auto" else args.loss_form
     if form == "auto":

@@ -64,6 +64,8 @@ int wgrad(const float* dY, const float* X, float* gW, int M, int N, int K, long 
 // the next call).  ttmi_set_option(3, 0) disables it.
 const unsigned* g_drop_salt = nullptr;     // ttmi_set_dropout_salt: device word mixed into every dropout seed at kernel start (graph replays)
 int g_fork_wgrad = 1;
+int g_split_weights = 0;        // ttmi_set_option(13, 1): EXPERIMENT - o_net and CoreNet.3 (the two encoder GEMMs with f32 outputs) add the second term of
+                                // their weight's bf16 split, as the joint's input layer does; needs weight shadows (the free plain-copy region holds the term)
 int g_posgrad_gemms = 0;        // ttmi_set_option(11, 1): dq / dE by the round-2 GEMM launches instead of attn_dqde_kernel (A/B)
 int g_attn_slices = 1;          // ttmi_set_option(10, n): attention backward in n batch slices (see attn_bwd_impl)
 int g_gemm_slab = 0;            // ttmi_set_option(5, 1): position-term slab by the batched GEMM (A/B measurements)
@@ -424,6 +426,12 @@ static int attn_fwd_impl(const float* x, const float* qkv_w, const float* o_w, c
         if (shadow_of(o_w, d, (int)a.HD, d, sh)) wo16 = sh.w16;
         else CK(transpose_convert_bf16(o_w, d, (int)a.HD, c.woT16, d, st, w.wo16));              // Wo (bf16) and Wo^T [HD, d] for backward
         CK(gemm_nt_bf16(static_cast<bf16_t*>(c.O), wo16, w.a, 0, nullptr, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, st));
+        if (g_split_weights && wo16 != w.wo16) {
+            CK(bf16_residual(o_w, wo16, w.wo16, (long)d * a.HD, st));
+            NtEpilogue e2;
+            e2.addend = w.a;
+            CK(gemm_nt_bf16(static_cast<bf16_t*>(c.O), w.wo16, w.a, 0, e2, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, st));
+        }
     } else {
         CK(ttmi_launch_gemm(mk(static_cast<float*>(c.O), o_w, w.a, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, NT_, prec), st));
     }
@@ -756,6 +764,12 @@ static int ffn_fwd_impl(const float* y, const float* w1, const float* b1, const 
         e1.bias = b1; e1.relu = 1; e1.drop = d_in;
         CK(gemm_nt_bf16(static_cast<bf16_t*>(c.h), w1_16, c.a1, 1, e1, (int)rows, Di, d, d, d, Di, st));
         CK(gemm_nt_bf16(static_cast<bf16_t*>(c.a1), w2_16, w.f, 0, b2, (int)rows, d, Di, Di, Di, d, st));
+        if (g_split_weights && w2_16 != w.w2_16) {
+            CK(bf16_residual(w2, w2_16, w.w2_16, (long)d * Di, st));
+            NtEpilogue e2;
+            e2.addend = w.f;
+            CK(gemm_nt_bf16(static_cast<bf16_t*>(c.a1), w.w2_16, w.f, 0, e2, (int)rows, d, Di, Di, Di, d, st));
+        }
     } else {
         float* h = static_cast<float*>(c.h);
         float* a1 = static_cast<float*>(c.a1);
@@ -1204,7 +1218,8 @@ int ttmi_set_dropout_salt(const unsigned* salt) {
 // process-wide switches for A/B measurements.  key 0: 1 = disable the fused attention kernels (bf16 pipeline only);
 // key 1: throughput-GEMM generation (see gemm_fast.hip); key 2: flash-kernel timing switches; key 3: 0 = no wgrad fork
 int ttmi_set_option(int key, int value) {
-    TTMI_REQUIRE(key >= 0 && key <= 12, "set_option: unknown key %d", key);
+    TTMI_REQUIRE(key >= 0 && key <= 13, "set_option: unknown key %d", key);
+    if (key == 13) { g_split_weights = value; return TTMI_OK; }
     if (key == 12) { g_ln_bwd_grid = value < 1 ? 1 : value; return TTMI_OK; }
     if (key == 11) { g_posgrad_gemms = value; return TTMI_OK; }
     if (key == 10) { g_attn_slices = value < 1 ? 1 : value; return TTMI_OK; }

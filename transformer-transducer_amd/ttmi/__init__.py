@@ -31,7 +31,7 @@ def lib():
         _lib.ttmi_last_error.restype = ctypes.c_char_p
         _lib.ttmi_rnnt_workspace_bytes.restype = ctypes.c_size_t
         for kv in filter(None, os.environ.get("TTMI_OPTIONS", "").split(",")):       # measurement switches (ttmi_set_option), e.g. "11=1,12=256"
-            k, v = kv.split("=")
+            k, v = kv.replace(":", "=").split("=")
             _lib.ttmi_set_option(int(k), int(v))
     return _lib
 
