@@ -272,7 +272,10 @@ int ttmi_stream_reserve_cus(void* stream, int n);
  * 2: flash-kernel timing bits; 3: 0 = no side-stream wgrad fork; 4: split-K workgroup target; 5: 1 = position-term slab by batched GEMM;
  * 6: process-wide default of ttmi_stream_reserve_cus for streams that never set one;
  * 7: exact-f32 products with at most n rows use the skinny 32x32 split-reduction kernel (default 128, 0 = never: greedy decode A/B);
- * 8: 0 = the fused attention kernels read the position term from a [B,H,L,L+1] bf16 slab (round-1 design) instead of forming it themselves */
+ * 8: 0 = the fused attention kernels read the position term from a [B,H,L,L+1] bf16 slab (round-1 design) instead of forming it themselves;
+ * 9: 1 = one-wave lattice kernel (round 2) instead of the workgroup-per-utterance one; 10: batch slices of the attention backward; 11: 1 = dq / dE /
+ * dc by the round-2 GEMM launches instead of attn_dqde_kernel; 12: workgroups of the grid-stride LayerNorm backward kernels; 13: 1 = o_net and
+ * CoreNet.3 add the second term of their weight's bf16 split (needs weight shadows; lower bf16 loss error, +3 % step time) */
 int ttmi_set_option(int key, int value);
 int ttmi_dropout_apply(const float* in, long n, float p, unsigned seed, float* out, void* stream);
 int ttmi_probe_arm(int slot);
