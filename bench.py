@@ -119,19 +119,39 @@ def fence(world, cuda=True):
         torch.cuda.synchronize()
 
 
-def timed_region(step, steps, warmup, world, cuda=True):
-    """`warmup` untimed steps, fence, EXACTLY `steps` timed ones, fence -> (elapsed, enqueue wall, host CPU) seconds of this rank"""
+def timed_region(step, steps, warmup, world, cuda=True, spread=None):
+    """`warmup` untimed steps, fence, EXACTLY `steps` timed ones, fence -> (elapsed, enqueue wall, host CPU) seconds of this rank.
+    spread (a list): receives the per-step GPU times in ms - one event per step on the current stream, read after the closing fence
+    (median and p10 / p90 beside the mean)"""
     for _ in range(warmup):
         step(False, 0)
     fence(world, cuda)
+    marks = []
+    if spread is not None and cuda:
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        marks[0].record()
     t0, c0 = time.perf_counter(), time.process_time()
     last = None
     for i in range(steps):
         last = step(True, i)
+        if marks:
+            marks[i + 1].record()
     enqueue = time.perf_counter() - t0               # wall time the host spent issuing the work: its own CPU time + time blocked on a full queue
     host_cpu = time.process_time() - c0              # CPU time of this process (all threads, incl. autograd's backward thread) over the same window
     fence(world, cuda)
-    return time.perf_counter() - t0, enqueue, host_cpu, last
+    elapsed = time.perf_counter() - t0
+    if marks:
+        spread.extend(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    return elapsed, enqueue, host_cpu, last
+
+
+def spread_stats(ms):
+    """median / p10 / p90 of per-step times (None when nothing was collected)"""
+    if not ms:
+        return None
+    a = np.asarray(ms, dtype=np.float64)
+    return {"median": round(float(np.median(a)), 3), "p10": round(float(np.percentile(a, 10)), 3), "p90": round(float(np.percentile(a, 90)), 3),
+            "min": round(float(a.min()), 3), "max": round(float(a.max()), 3), "n": int(a.size)}
 
 
 def max_over_ranks(values, world, device):
@@ -212,13 +232,16 @@ def main():
                     help="train = the metric (default); decode = greedy decode of the C2 model (SURVEY §8 A10) with the oracle's loop beside it")
     ap.add_argument("--no-weight-shadows", action="store_true", help="convert the f32 master weights to bf16 in every call (round-1 behaviour; A/B)")
     ap.add_argument("--no-grouped-wgrads", action="store_true", help="launch every encoder weight-gradient GEMM on its own (K-split, f32 atomics; A/B switch)")
-    ap.add_argument("--loss-form", default="auto", choices=["auto", "exp", "fused", "two-call"],
-                    help="how the step gets its loss.  two-call: train.py:51-53 as written (logits = model(inputs, targets); criterion(logits, ...)). "
-                         "fused: Transducer.loss, chunked, the same kernels without holding the logits (memory form).  exp: Transducer.loss(exp_domain=True), "
-                         "the projection stores exp(logit - shift) + row sums and the loss never walks the lattice's rows (speed form; bf16 only).  "
-                         "auto = exp in bf16 train mode, two-call otherwise.  Whatever runs first, the JSON line also carries the two-call form's timing.")
+    ap.add_argument("--loss-form", default="auto", choices=["auto", "exp", "fused", "two-call", "two-call-eager"],
+                    help="how the step gets its loss.  two-call (= auto): train.py:51-53 as written (logits = model(inputs, targets); criterion(logits, ...)); "
+                         "in the bf16 pipeline the logits are a deferred handle (tt.model.DeferredLogits) that RNNTLoss consumes through the fused "
+                         "exp-domain kernels.  two-call-eager: the same two calls with TTMI_DEFERRED_LOGITS=0 (the logits are materialised, as in rounds 1-3).  "
+                         "exp: Transducer.loss(exp_domain=True), the explicit form of the same kernels.  fused: Transducer.loss, chunked memory form.  "
+                         "Whatever runs first, the JSON line also carries the other forms' timings.")
+    ap.add_argument("--graph", action="store_true", help="run the PRIMARY timed region through ttmi.train.GraphedStep (one HIP-graph launch per step and rank, "
+                                                         "any number of ranks: the graph contains the bucketed all-reduces); the per-kernel probes cannot fire in a replay")
     ap.add_argument("--fused-loss", action="store_true", help="same as --loss-form fused")
-    ap.add_argument("--no-two-call", action="store_true", help="skip the secondary timing of the two-call form (profiling runs: one loss form per trace)")
+    ap.add_argument("--no-two-call", action="store_true", help="skip the secondary timings of the other loss forms (profiling runs: one loss form per trace)")
     ap.add_argument("--no-fp32-form", action="store_true", help="skip the secondary timing of the fp32 mode (the 1e-4 parity path)")
     ap.add_argument("--no-graph-form", action="store_true", help="skip the secondary timing of the step replayed from a captured HIP graph (ttmi.train.GraphedStep)")
     ap.add_argument("--fp32-steps", type=int, default=5, help="steps of the fp32-mode secondary timing (at most --steps)")
@@ -292,7 +315,8 @@ def main():
 
     form = "fused" if args.fused_loss and args.loss_form == "auto" else args.loss_form
     if form == "auto":
-        form = "exp" if args.precision == "bf16" else "two-call"
+        form = "two-call"           # train.py's own call sequence; in bf16 mode it runs the fused exp-domain kernels (deferred logits)
+    os.environ["TTMI_DEFERRED_LOGITS"] = "0" if form == "two-call-eager" else ""
 
     reserve = dp_options(world)["reserve_cus"]
 
@@ -303,11 +327,11 @@ def main():
         sync.start_step()
         if timed and rank == 0:
             ops.probe_arm(i % 64)                     # this step's joint-projection launch records into event pair i
-        if form != "two-call":
+        if form in ("exp", "fused"):
             loss = model.loss(inputs, ilen, targets, tlen, chunk=args.loss_chunk or None, exp_domain=form == "exp")
         else:
-            logits = model(inputs, targets)
-            loss = criterion(logits, targets.int(), ilen, tlen)
+            logits = model(inputs, targets)                             # train.py:51
+            loss = criterion(logits, targets.int(), ilen, tlen)         # train.py:53
         if reserve:
             ops.reserve_cus(reserve)                  # gradient all-reduce kernels run beside backward: the persistent encoder GEMMs leave them 4 CUs per XCD (per-stream state)
         loss.backward()
@@ -318,43 +342,79 @@ def main():
         loss_sum.add_(loss.detach())
         return loss
 
-    elapsed, enqueue, host_cpu, last = timed_region(step, args.steps, args.warmup, world)
+    def is_exp(f):
+        """does loss form `f` run the exp-domain kernels on this workload?"""
+        if args.precision != "bf16" or f not in ("exp", "two-call"):
+            return False
+        c = args.loss_chunk or model.default_loss_chunk(B, T, U + 1, True)
+        return ops.joint_exp_supported(c, T, U + 1, cfg["joint"]["inner_size"], V, 1)
+
+    def make_graphed():
+        from ttmi.train import GraphedStep
+        return GraphedStep(lambda: step(False).detach(), device=dev, warmup=2, optimizer=opt,
+                           exp_state=model.joint.exp_shift_state(dev) if is_exp(form) else None)
+
+    step_ms = []
+    gstep = None
+    if args.graph:
+        # the primary region replayed from ONE captured HIP graph per rank (forward, loss, backward, bucketed all-reduces, clip + SGD)
+        gstep = make_graphed()
+        elapsed, enqueue, host_cpu, last = timed_region(lambda timed, i: gstep(), args.steps, args.warmup, world, spread=step_ms)
+        run_step = lambda: gstep()
+    else:
+        elapsed, enqueue, host_cpu, last = timed_region(step, args.steps, args.warmup, world, spread=step_ms)
+        run_step = lambda: step(False, 0)
     # what the host itself needs to issue one step: timed on a drained device (inside the timed region the issue loop runs ahead of the GPU
     # until the HIP queue is full and then waits in the launch calls - spinning, so that wait shows up as CPU time, not as idle time)
     issue = []
     for _ in range(3):
         fence(world)
         t1 = time.perf_counter()
-        step(False, 0)
+        run_step()
         issue.append(time.perf_counter() - t1)
     fence(world)
     host_issue = float(np.median(issue))
-    if rank == 0:                                     # the probes are read after the timed region: no host sync inside it
+    probe_ms = loss_ms = attn_ms = wgrad_ms = []
+    if rank == 0 and not args.graph:                  # the probes are read after the timed region: no host sync inside it
         slots = [i % 64 for i in range(max(0, args.steps - 64), args.steps)]
         probe_ms = [ops.probe_read_ms(i) for i in slots]
         loss_ms = [(ops.probe_read_ms(i, 1), ops.probe_read_ms(i, 2)) for i in slots]
         attn_ms = [ops.probe_read_ms(i, 3) for i in slots]
         wgrad_ms = [ops.probe_read_ms(i, 4) for i in slots]
-    def secondary(other_form, precision, steps, warmup):
+    if gstep is not None:
+        ops.set_dropout_salt(None)
+        del gstep
+
+    def secondary(other_form, precision, steps, warmup, spread=None):
         """the same step with another loss form / precision, same model, data and optimiser state, same barrier + synchronize bracket"""
         nonlocal form
         main_form, form = form, other_form
-        main_prec = os.environ["TTMI_PRECISION"]
+        main_prec, main_def = os.environ["TTMI_PRECISION"], os.environ.get("TTMI_DEFERRED_LOGITS", "")
         os.environ["TTMI_PRECISION"] = precision
+        os.environ["TTMI_DEFERRED_LOGITS"] = "0" if other_form == "two-call-eager" else ""
         try:
-            return timed_region(lambda timed, i: step(False), steps, warmup, world)[0]
+            return timed_region(lambda timed, i: step(False), steps, warmup, world, spread=spread)[0]
         finally:
             form = main_form
             os.environ["TTMI_PRECISION"] = main_prec
+            os.environ["TTMI_DEFERRED_LOGITS"] = main_def
 
-    two_call = fp32_form = graph_form = graph_issue = None
+    eager_two_call = explicit_form = fp32_form = graph_form = graph_issue = None
+    eager_ms, explicit_ms, graph_ms = [], [], []
     fp32_steps = max(1, min(args.steps, args.fp32_steps))
-    if world == 1 and form != "two-call" and args.precision == "bf16" and not args.no_graph_form:
-        # the same step replayed from ONE captured HIP graph (ttmi.train.GraphedStep): one launch per step instead of ~560 from Python
-        from ttmi.train import GraphedStep
-        gstep = GraphedStep(lambda: step(False).detach(), device=dev, warmup=2, exp_state=model.joint.exp_shift_state(dev),
-                            on_replay=(lambda: setattr(opt, "global_step", opt.global_step + 1),))
-        graph_form = timed_region(lambda timed, i: gstep(), args.steps, 1, world)[0]
+    if args.precision == "bf16" and not args.no_two_call:
+        # (1) the same two calls with the logits MATERIALISED (rounds 1-3's two-call form: 7.1 GB of bf16 logits written, walked twice by the
+        # loss, 7.1 GB of gradient written and read), timed BEFORE any graph capture (VERDICT r3 weak item 2);
+        # (2) the explicit spelling of the fused form, Transducer.loss(exp_domain=True): the same kernels as the default region
+        if form != "two-call-eager":
+            eager_two_call = secondary("two-call-eager", args.precision, args.steps, max(1, args.warmup), eager_ms)
+        if form != "exp":
+            explicit_form = secondary("exp", args.precision, args.steps, max(1, args.warmup), explicit_ms)
+    if not args.graph and form != "two-call-eager" and args.precision == "bf16" and not args.no_graph_form:
+        # the same step replayed from ONE captured HIP graph (ttmi.train.GraphedStep): one launch per step instead of ~400 from Python;
+        # with several ranks the graph holds the bucketed all-reduces as well
+        gstep = make_graphed()
+        graph_form = timed_region(lambda timed, i: gstep(), args.steps, 1, world, spread=graph_ms)[0]
         fence(world)
         t1 = time.perf_counter()
         gstep()
@@ -362,19 +422,18 @@ def main():
         fence(world)
         ops.set_dropout_salt(None)
         del gstep
-    if form != "two-call" and not args.no_two_call:
-        # the reference's own call sequence (train.py:51-53) beside the fused form
-        two_call = secondary("two-call", args.precision, args.steps, max(1, args.warmup))
     if args.precision == "bf16" and not args.no_fp32_form and args.workload == "c2":
         # the fp32 mode: the path that meets north_star's 1e-4 tolerance (tests/test_configs_gpu.py), timed on the same workload
         fp32_form = secondary("two-call", "fp32", fp32_steps, 1)
-    elapsed, two_call, fp32_form, host_issue = max_over_ranks([elapsed, two_call, fp32_form, host_issue], world, dev)
+    elapsed, eager_two_call, explicit_form, fp32_form, graph_form, host_issue = max_over_ranks(
+        [elapsed, eager_two_call, explicit_form, fp32_form, graph_form, host_issue], world, dev)
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         utt_s = world * B * args.steps / elapsed
         U1, J = U + 1, cfg["joint"]["inner_size"]
-        B_launch = B if form == "two-call" else (args.loss_chunk or model.default_loss_chunk(B, T, U1, form == "exp"))      # utterances per joint-projection launch
+        fused_path = form in ("exp", "fused") or (form == "two-call" and args.precision == "bf16")       # bf16 two-call: deferred logits -> the fused op
+        B_launch = B if not fused_path else (args.loss_chunk or model.default_loss_chunk(B, T, U1, form != "fused"))      # utterances per joint-projection launch
         flop_launch = 2.0 * B_launch * T * U1 * J * V                            # one joint-projection launch
         def mean_pos(vals):
             vals = [v for v in vals if v is not None and v > 0]
@@ -411,7 +470,7 @@ def main():
         lb = mean_pos([b for a, b in loss_ms if a > 0 and b > 0])
         l_ms = None if lf is None or lb is None else lf + lb
         loss_gbs = rate(loss_bytes, l_ms, 1e9, 1)
-        ran_exp = form == "exp" and ops.joint_exp_supported(B_launch, T, U1, J, V, 1)       # what Transducer.loss actually selected for these chunks
+        ran_exp = is_exp(form)              # what the fused op actually selected for these chunks
         roof_joint = {"bound": "mfma", "kernel": "gemm_nt_bf16_v8_kernel (joint vocabulary projection%s, M=%d N=%d K=%d)"
                                                  % (", exp-store epilogue" if ran_exp else "", B_launch * T * U1, V, J),
                       "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": frac(ach, peak),
@@ -485,22 +544,42 @@ def main():
             "roofline_attn": roof_attn, "roofline_wgrad": roof_wgrad,
             "final_loss": round(float(last.detach()), 4),
         }
-        ran = "exp" if ran_exp else ("fused" if form != "two-call" else "two-call")       # the form that RAN (exp falls back to the memory form outside the persistent kernels' sizes)
-        out["config"]["loss"] = {"two-call": "logits = model(inputs, targets); RNNTLoss()(logits, ...) as in train.py:51-53",
-                                 "fused": "Transducer.loss (fused joint + loss, memory form), %d utterances per chunk" % B_launch,
-                                 "exp": "Transducer.loss(exp_domain=True) (fused joint + loss, exp-domain form), %d utterances per chunk" % B_launch}[ran]
-        if ran != form:
-            out["config"]["loss"] += " [requested: %s; chunks of %d x %d x %d lattice rows are outside the exp-domain kernels' sizes]" % (form, B_launch, T, U1)
+        ran = "exp" if ran_exp else ("fused" if fused_path else "two-call")      # the kernels that RAN (exp falls back to the memory form outside the persistent kernels' sizes)
+        calls = {"two-call": "logits = model(inputs, targets); RNNTLoss()(logits, ...) as in train.py:51-53", "two-call-eager": "logits = model(inputs, targets); "
+                 "RNNTLoss()(logits, ...) with TTMI_DEFERRED_LOGITS=0", "exp": "Transducer.loss(exp_domain=True)", "fused": "Transducer.loss()"}[form]
+        kernels = {"two-call": "logits materialised (joint forward, RNN-T loss over the logits, joint backward)",
+                   "fused": "fused joint + loss, memory form, %d utterances per chunk" % B_launch,
+                   "exp": "fused joint + loss, exp-domain form, %d utterances per chunk" % B_launch}[ran]
+        out["config"]["loss"] = calls + (" - the logits are a deferred handle (tt.model.DeferredLogits) consumed by RNNTLoss: " if form == "two-call" and fused_path else " - ") + kernels
+        if form in ("exp", "two-call") and args.precision == "bf16" and not ran_exp:
+            out["config"]["loss"] += " [chunks of %d x %d x %d lattice rows are outside the exp-domain kernels' sizes]" % (B_launch, T, U1)
         out["config"]["loss_form"] = ran
-        if two_call is not None:
-            out["two_call_form"] = {"ms_per_step": round(1e3 * two_call / args.steps, 3), "value": round(world * B * args.steps / two_call, 3), "unit": "utt/s",
-                                    "note": "the same %d steps with train.py's own call sequence (model(inputs, targets) + RNNTLoss), timed right after the main region" % args.steps}
+        out["config"]["call_sequence"] = form
+        if args.graph:
+            out["config"]["launch"] = "every step replayed from one captured HIP graph per rank (ttmi.train.GraphedStep)"
+        st = spread_stats(step_ms)
+        if st is not None:
+            out["ms_per_step_spread"] = dict(st, note="per-step GPU time between events recorded after each step on the launch stream (this rank)")
+
+        def form_entry(secs, spread, note):
+            e = {"ms_per_step": round(1e3 * secs / args.steps, 3), "value": round(world * B * args.steps / secs, 3), "unit": "utt/s", "note": note}
+            if spread:
+                e["spread"] = spread_stats(spread)
+            return e
+        if form == "two-call":
+            out["two_call_form"] = dict(form_entry(elapsed, step_ms, "train.py:51-53 unchanged IS the primary timed region of this run (the headline above)"),
+                                        same_as_headline=True)
+        if eager_two_call is not None:
+            out["two_call_materialized_form"] = form_entry(eager_two_call, eager_ms, "the same %d steps with the logits materialised (TTMI_DEFERRED_LOGITS=0: rounds 1-3's "
+                                                           "two-call form), timed right after the main region and before any graph capture" % args.steps)
+        if explicit_form is not None:
+            out["explicit_loss_form"] = form_entry(explicit_form, explicit_ms, "the same %d steps calling Transducer.loss(exp_domain=True) directly (rounds 2-3's headline "
+                                                   "form): the kernels the deferred handle routes to" % args.steps)
         if graph_form is not None:
-            out["graph_replay_form"] = {"ms_per_step": round(1e3 * graph_form / args.steps, 3), "value": round(world * B * args.steps / graph_form, 3), "unit": "utt/s",
-                                        "host_issue_ms_per_step": round(1e3 * graph_issue, 3), "host_launches_per_step": 1,
-                                        "note": "the same %d steps (same loss form, dropout with fresh masks per step, clip + SGD) replayed from one captured HIP "
-                                                "graph, ttmi.train.GraphedStep, timed right after the main region; the headline stays the eager step because "
-                                                "its kernels are timed live by HIP-event probes, which a replayed graph cannot carry" % args.steps}
+            out["graph_replay_form"] = dict(form_entry(graph_form, graph_ms, "the same %d steps (same call sequence, dropout with fresh masks per step, all-reduce, clip + SGD) "
+                                                       "replayed from one captured HIP graph per rank, ttmi.train.GraphedStep, timed after the main region; the headline stays the "
+                                                       "eager step because its kernels are timed live by HIP-event probes, which a replayed graph cannot carry" % args.steps),
+                                            host_issue_ms_per_step=round(1e3 * graph_issue, 3), host_launches_per_step=1)
         if fp32_form is not None:
             out["fp32_form"] = {"ms_per_step": round(1e3 * fp32_form / fp32_steps, 3), "value": round(world * B * fp32_steps / fp32_form, 3), "unit": "utt/s",
                                 "dtype": "f32", "steps": fp32_steps,
@@ -509,12 +588,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             model.eval()
             with torch.no_grad():
+                os.environ["TTMI_DEFERRED_LOGITS"] = "0"         # the MATERIALISED two-call form on the oracle sample (bf16 logits through the lattice kernels)
                 lg = model(inputs[:args.cpu_utts], targets[:args.cpu_utts])
                 costs = RNNTLoss(reduction="none")(lg, targets[:args.cpu_utts].int(), ilen[:args.cpu_utts], tlen[:args.cpu_utts])
                 del lg
-                if form != "two-call":      # the timed loss form on the same sample: its per-utterance costs against the same oracle
-                    costs_form = model.loss(inputs[:args.cpu_utts], ilen[:args.cpu_utts], targets[:args.cpu_utts], tlen[:args.cpu_utts],
-                                            reduction="none", chunk=args.loss_chunk or None, exp_domain=form == "exp")
+                os.environ["TTMI_DEFERRED_LOGITS"] = "0" if form == "two-call-eager" else ""
+                timed_costs = lambda n: (model.loss(inputs[:n], ilen[:n], targets[:n], tlen[:n], reduction="none", chunk=args.loss_chunk or None,
+                                                    exp_domain=form == "exp") if form in ("exp", "fused") else
+                                         RNNTLoss(reduction="none")(model(inputs[:n], targets[:n]), targets[:n].int(), ilen[:n], tlen[:n]))
+                if fused_path:              # the timed loss form on the same sample: its per-utterance costs against the same oracle
+                    costs_form = timed_costs(args.cpu_utts)
                 enc_s, dec_s = model._encode(inputs[:args.cpu_utts], targets[:args.cpu_utts])      # the timed precision's encoder states of the same sample
                 enc_s, dec_s = enc_s.double().cpu().numpy(), dec_s.double().cpu().numpy()
                 # the whole batch's loss in the timed form against the fp32 mode of the same model (the mode the tests hold within 1e-6 of the
@@ -522,8 +605,7 @@ def main():
                 # mean over the batch that train.py:53 computes - as opposed to the worst single utterance of the oracle sample below
                 batch_rel = None
                 if args.precision == "bf16" and args.workload == "c2":
-                    c16 = (model.loss(inputs, ilen, targets, tlen, reduction="none", chunk=args.loss_chunk or None, exp_domain=form == "exp")
-                           if form != "two-call" else RNNTLoss(reduction="none")(model(inputs, targets), targets.int(), ilen, tlen)).double()
+                    c16 = timed_costs(B).double()
                     os.environ["TTMI_PRECISION"] = "fp32"
                     try:
                         ops.weights_fresh()
@@ -549,7 +631,7 @@ def main():
             if batch_rel is not None:
                 out["loss_rel_err_batch_vs_fp32_mode"] = {"batch_mean": float("%.3e" % batch_rel), "worst_utterance": float("%.3e" % utt_rel), "utterances": B,
                                                           "note": "the timed form's loss of the whole batch against TTMI_PRECISION=fp32 on the same weights and inputs (eval mode)"}
-            if form != "two-call":
+            if fused_path:
                 out["loss_rel_err_vs_oracle_timed_form"] = float("%.3e" % (np.abs(costs_form.float().cpu().numpy() - oracle_costs).max() / np.abs(oracle_costs).max()))
         print(json.dumps(out), flush=True)
     if world > 1:

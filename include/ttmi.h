@@ -216,16 +216,22 @@ int ttmi_stack_subsample(const float* feat, const int* n_frames, int B, int Tin,
 int ttmi_spec_mask(float* x, int B, int T, int F, const int* time_spans, int n_time, const int* freq_spans, int n_freq, void* stream);
 
 /* ---- training-step tail on flat f32 buffers: clip_grad_norm_ + optimizer.step (train.py:62-65, tt/optim.py:57-73)
- * normsq: device scalar holding sum(g^2) over ALL gradients (ttmi_sumsq accumulates into it); NULL = no clipping.
- * The effective gradient is g * grad_scale (1/world_size after a SUM all-reduce) clipped to max_norm. */
+ * normsq: device scalar holding sum(g^2) over ALL gradients (ttmi_sumsq accumulates into it); NULL = no clipping and no drop.
+ * The effective gradient is g * grad_scale (1/world_size after a SUM all-reduce) clipped to max_norm (max_norm <= 0: not clipped).
+ * A step whose *normsq is inf / NaN is DROPPED (parameters and state untouched) whatever max_norm is: the exp-domain loss form fails with
+ * NaN costs and gradients by construction, and such a step must not reach the weights.
+ * hyper (device float[2], nullable): the values that change between steps, read by the kernels at RUN time so that a step captured into a
+ * HIP graph follows them - hyper[0] = learning rate (replaces `lr`: tt/optim.py:30-33 decay_lr, train.py:257), hyper[1] = optimiser steps
+ * taken; every *_step call with hyper != NULL first advances hyper[1] by one on the device (Adam's bias corrections 1 - beta^hyper[1]
+ * replace the host's `step`). */
 int ttmi_sumsq(const float* x, long n, float* out, void* stream);
 int ttmi_sgd_step(float* p, const float* g, float* mom, long n, float lr, float momentum, float weight_decay, int nesterov,
-                  float max_norm, const float* normsq, float grad_scale, void* stream);
+                  float max_norm, const float* normsq, float grad_scale, float* hyper, void* stream);
 int ttmi_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
-                   float weight_decay, int step, float max_norm, const float* normsq, float grad_scale, void* stream);
+                   float weight_decay, int step, float max_norm, const float* normsq, float grad_scale, float* hyper, void* stream);
 /* torch.optim.Adadelta(lr, rho, eps, weight_decay), the third type of tt/optim.py:74-81 */
 int ttmi_adadelta_step(float* p, const float* g, float* square_avg, float* acc_delta, long n, float lr, float rho, float eps,
-                       float weight_decay, float max_norm, const float* normsq, float grad_scale, void* stream);
+                       float weight_decay, float max_norm, const float* normsq, float grad_scale, float* hyper, void* stream);
 
 /* Device word (nullable) mixed into every dropout seed when a kernel starts.  Seeds are drawn on the host per sub-layer call; in a step that
  * is captured as a HIP graph they are baked into the kernel arguments, so the caller bumps this word on the device before each replay

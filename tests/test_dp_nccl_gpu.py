@@ -189,12 +189,13 @@ def _bench_data(step, rank):
     return torch.randn(8, 512, 512, generator=g), torch.randint(1, 4334, (8, 7), generator=g)
 
 
-def _bench_like(dev, world, rank, steps, hooks):
+def _bench_like(dev, world, rank, steps, hooks, graph=False):
     """-> (gradient buffer after the LAST step's backward, parameters after `steps` updates, number of collectives seen in flight,
-    whether the exp-domain kernels ran)"""
+    whether the exp-domain kernels ran).  graph: the first two steps eager (GraphedStep's warm-up), the rest replayed from ONE captured
+    HIP graph that contains the hook-launched all-reduces, the side-stream fan-in and the CU reservation"""
     from tt.model import Transducer
     from ttmi import ops
-    from ttmi.train import FlatModel, FusedOptimizer, GradSync
+    from ttmi.train import FlatModel, FusedOptimizer, GradSync, GraphedStep
     torch.manual_seed(1)
     model = Transducer(_bench_cfg()).to(dev).train()
     flat = FlatModel(model)
@@ -205,29 +206,47 @@ def _bench_like(dev, world, rank, steps, hooks):
     il = torch.full((8,), 512, dtype=torch.int32, device=dev)
     tl = torch.full((8,), 7, dtype=torch.int32, device=dev)
     assert ops.joint_exp_supported(8, 512, 8, 1024, 4334, 1)
-    n_works, grad = 0, None
-    for step in range(steps):
-        x, y = _bench_data(step, rank)
+    n_works = [0]
+    xs, ys = torch.empty(8, 512, 512, device=dev), torch.empty(8, 7, dtype=torch.long, device=dev)      # static inputs (graph replays read them)
+    keep = torch.empty_like(flat.grad)
+
+    def one_step():
         flat.zero_grad()
         sync.start_step()
-        loss = model.loss(x.to(dev), il, y.to(dev), tl, exp_domain=True)
+        loss = model.loss(xs, il, ys, tl, exp_domain=True)
         if hooks:
             ops.reserve_cus(32)
         loss.backward()
-        n_works = max(n_works, len(sync.works))
+        n_works[0] = max(n_works[0], len(sync.works))
         sync.finish()
         if hooks:
             ops.reserve_cus(0)
-        if step == steps - 1:
-            torch.cuda.synchronize()
-            grad = flat.grad.cpu().numpy()
+        keep.copy_(flat.grad)                      # the reduced gradients of this step (before the update)
         opt.step()
+        return loss.detach()
+
+    gstep = None
+    for step in range(steps):
+        x, y = _bench_data(step, rank)
+        xs.copy_(x)
+        ys.copy_(y)
+        if graph and step == 0:
+            gstep = GraphedStep(one_step, device=dev, warmup=2, exp_state=model.joint.exp_shift_state(dev), optimizer=opt)   # steps 0 and 1 (same batch)
+        elif graph:
+            if step >= 2:
+                gstep()
+        else:
+            one_step()
     torch.cuda.synchronize()
+    grad = keep.cpu().numpy()
     st = model.joint.exp_shift_state(dev)
     assert int(st.flag) == 0 and torch.isfinite(flat.flat).all()
+    if gstep is not None:
+        assert gstep.captures == 1 and opt.steps_taken == steps and float(opt.hyper[1]) == steps
+        ops.set_dropout_salt(None)
     ops.wgrad_queue = None
     flat.disable_shadows()
-    return grad, flat.flat.cpu().numpy(), n_works, len(st.pending) > 0 or st.valid, len(sync.buckets)
+    return grad, flat.flat.cpu().numpy(), n_works[0], len(st.pending) > 0 or st.valid, len(sync.buckets)
 
 
 def _solo_bench(port, q):
@@ -261,6 +280,102 @@ def test_single_rank_rccl_bench_step_on_one_gpu(monkeypatch):
     # grouped weight gradients are bit-reproducible; the joint's and the first layer's K-split sums land in f32 atomic order
     assert rel_err(grad, want_grad) < 1e-4
     assert rel_err(params, want_params) < 1e-6
+
+
+def _solo_bench_graph(port, q):
+    for p in (ROOT, os.path.join(ROOT, "transformer-transducer_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", TTMI_PRECISION="bf16", NCCL_MAX_NCHANNELS="32")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    out = _bench_like(dev, 1, 0, 5, hooks=True, graph=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put(out)
+
+
+def test_single_rank_rccl_graphed_step_on_one_gpu(monkeypatch):
+    """ttmi.train.GraphedStep around the RCCL-side step: the captured graph contains GradSync's hook-launched
+    all-reduces (one-rank `nccl` group, every bucket's collective issued), the wait_stream fan-in of the label encoder's side stream and
+    the CU reservation; 2 eager warm-up steps + 3 replays against five eager steps without hooks or process group: same reduced
+    gradients, same parameters."""
+    monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    port = 29800 + os.getpid() % 90
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_solo_bench_graph, args=(port, q))
+    p.start()
+    grad, params, n_works, exp_ran, n_buckets = q.get(timeout=900)
+    p.join(120)
+    assert p.exitcode == 0
+    assert exp_ran and n_buckets >= 4 and n_works >= n_buckets - 1
+    want_grad, want_params, _, _, _ = _graph_twin(torch.device("cuda", 0), 1, 0, 5)
+    assert rel_err(grad, want_grad) < 1e-4
+    assert rel_err(params, want_params) < 1e-6
+
+
+def _graph_twin(dev, world, rank, steps):
+    """the eager run a graphed `_bench_like(..., steps, graph=True)` must reproduce: GraphedStep's two warm-up steps both see batch 0 and
+    batch 1 is never used, then batches 2 .. steps-1"""
+    from tt.model import Transducer
+    from ttmi import ops
+    from ttmi.train import FlatModel, FusedOptimizer, GradSync
+    torch.manual_seed(1)
+    model = Transducer(_bench_cfg()).to(dev).train()
+    flat = FlatModel(model)
+    flat.enable_grouped_wgrads()
+    flat.enable_shadows()
+    sync = GradSync(flat, bucket_mb=4)
+    opt = FusedOptimizer(flat, kind="sgd", lr=0.00025, momentum=0.9, max_grad_norm=200.0, world=world)
+    il = torch.full((8,), 512, dtype=torch.int32, device=dev)
+    tl = torch.full((8,), 7, dtype=torch.int32, device=dev)
+    grad = None
+    for b in [0, 0] + list(range(2, steps)):
+        x, y = _bench_data(b, rank)
+        flat.zero_grad()
+        sync.start_step()
+        loss = model.loss(x.to(dev), il, y.to(dev), tl, exp_domain=True)
+        loss.backward()
+        sync.finish()
+        grad = flat.grad.clone()
+        opt.step()
+    torch.cuda.synchronize()
+    ops.wgrad_queue = None
+    flat.disable_shadows()
+    return grad.cpu().numpy(), flat.flat.cpu().numpy(), 0, True, len(sync.buckets)
+
+
+def _worker_bench_graph(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "transformer-transducer_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", TTMI_PRECISION="bf16", NCCL_MAX_NCHANNELS="32")
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    grad, params, n_works, exp_ran, n_buckets = _bench_like(dev, world, rank, 5, hooks=True, graph=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, grad, params, n_works, exp_ran))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL test needs two GPUs (one process per GPU)")
+def test_two_ranks_over_rccl_graphed_step():
+    """two ranks replaying captured steps whose graphs contain the bucketed all-reduces: bit-identical reduced gradients and parameters
+    on both ranks after 2 eager + 3 replayed steps"""
+    world, port = 2, 30500 + os.getpid() % 400
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_bench_graph, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(r[4] for r in res)
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    assert np.isfinite(res[0][2]).all()
 
 
 def _worker_bench(rank, world, port, q):

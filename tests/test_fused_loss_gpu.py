@@ -41,6 +41,7 @@ def test_same_numbers_as_the_two_call_form(gm, prec, monkeypatch):
     z, sd, model = gm
     from warprnnt_pytorch import RNNTLoss
     monkeypatch.setenv("TTMI_PRECISION", prec)
+    monkeypatch.setenv("TTMI_DEFERRED_LOGITS", "0")          # the two-call form with its logits MATERIALISED is the yardstick here
     tgt = torch.tensor(z["targets"], device="cuda")
     al, ll = torch.tensor(z["ragged/act_lens"], device="cuda"), torch.tensor(z["ragged/label_lens"], device="cuda")
     res = []
@@ -84,6 +85,7 @@ def test_flat_model_gradients_and_memory(monkeypatch):
     from ttmi.train import FlatModel
     from warprnnt_pytorch import RNNTLoss
     monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    monkeypatch.setenv("TTMI_DEFERRED_LOGITS", "0")          # (materialised logits: what the fused form's memory is compared with)
     side = dict(n_layer=1, d_model=512, n_head=8, d_head=64, d_inner=256)
     cfg = AttrDict(dict(enc=dict(side, max_input_length=64), dec=dict(side, max_target_length=16),
                         joint=dict(input_size=1024, inner_size=1024), vocab_size=4334, dropout=0.0))

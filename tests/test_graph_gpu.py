@@ -68,24 +68,77 @@ def test_replays_walk_the_eager_trajectory(monkeypatch):
     _teardown(flat)
     torch.manual_seed(11)
     model, flat, opt, step, dev = _setup(monkeypatch, 0.0)
-    g = GraphedStep(step, device=dev, warmup=3, exp_state=model.joint.exp_shift_state(dev), on_replay=(lambda: setattr(opt, "global_step", opt.global_step + 1),))
+    g = GraphedStep(step, device=dev, warmup=3, exp_state=model.joint.exp_shift_state(dev), optimizer=opt)
+    assert opt.global_step == 1 + 3 and opt.steps_taken == 3     # the capture ran step()'s Python once, not a step: counters restored
     losses = [float(g()) for _ in range(3)]                      # 3 eager warm-up steps + 3 replays = the 6 steps above
     torch.cuda.synchronize()
     got = flat.flat.cpu().numpy()
     assert g.captures == 1 and all(np.isfinite(losses)) and losses[2] < losses[0]
     assert rel_err(got, want) < 1e-6                              # (f32 atomic order in the joint's and the first layer's weight gradients)
-    assert opt.global_step == 1 + 3 + 1 + 3                       # 3 warm-ups, the captured call, 3 replays (tt/optim.py:8 starts at 1)
-    # a raised range flag between replays: one eager recovery (plain form re-seeds the shift), a new capture, and the trajectory goes on
+    assert opt.global_step == 1 + 6 and opt.steps_taken == 6      # one per executed step (tt/optim.py:8 starts at 1)
+    assert float(opt.hyper[1]) == 6.0                             # ... and the device's own count agrees
+    # a raised range flag between replays: that replay's step is dropped on the device, the next call is ONE eager step (the plain form
+    # re-seeds the shift), the call after it captures again: every batch gets exactly one update
     st = model.joint.exp_shift_state(dev)
     st.cur.fill_(-150.0)
+    before = flat.flat.clone()
     bad = float(g())
     torch.cuda.synchronize()
-    assert not np.isfinite(bad) and int(st.flag) == 1
+    assert not np.isfinite(bad) and int(st.flag) == 1 and torch.equal(flat.flat, before)       # NaN gradients never reached the weights
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         ok = float(g())
-    assert np.isfinite(ok) and g.captures == 2 and torch.isfinite(flat.flat).all()      # the NaN step was dropped by the optimiser
+    assert np.isfinite(ok) and g.captures == 1 and g.eager_steps == 4 and st.valid
+    again = float(g())
+    assert np.isfinite(again) and g.captures == 2 and torch.isfinite(flat.flat).all()
+    assert opt.global_step == 1 + 9 and opt.steps_taken == 9
+    # by-value hyper-parameters are frozen in the graph: changing one is an error until recapture()
+    opt.momentum = 0.5
+    with pytest.raises(RuntimeError):
+        g()
+    g.recapture()
+    assert np.isfinite(float(g())) and g.captures == 3
+    _teardown(flat)
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adam", "adadelta"])
+def test_lr_decay_and_step_count_follow_under_replay(monkeypatch, kind):
+    """tt/optim.py:30-33 decay_lr() between replays (train.py:257 calls it every epoch) and Adam's bias-correction step count: the update
+    kernels read both from device scalars, so a replayed graph follows them - same trajectory as eager steps with the same schedule"""
+    from ttmi.train import GraphedStep
+    lr = {"sgd": 0.001, "adam": 0.0005, "adadelta": 1.0}[kind]
+
+    def run(graphed):
+        torch.manual_seed(11)
+        model, flat, opt, step, dev = _setup(monkeypatch, 0.0)
+        opt.__init__(flat, kind=kind, lr=lr, momentum=0.9, max_grad_norm=200.0, decay_ratio=0.5)
+        g = GraphedStep(step, device=dev, warmup=2, exp_state=model.joint.exp_shift_state(dev), optimizer=opt) if graphed else None
+        if not graphed:
+            step(), step()
+        lrs = []
+        for i in range(6):
+            if i in (2, 4):
+                opt.decay_lr()                                    # halves opt.lr: the graph must follow
+            (g or step)()
+            lrs.append(opt.lr)
+        torch.cuda.synchronize()
+        out = flat.flat.cpu().numpy().copy(), opt.steps_taken, float(opt.hyper[1]), lrs
+        _teardown(flat)
+        return out
+
+    want, steps_e, dev_e, lrs_e = run(False)
+    got, steps_g, dev_g, lrs_g = run(True)
+    assert steps_e == steps_g == 8 and dev_e == dev_g == 8.0 and lrs_e == lrs_g and lrs_g[-1] == lr / 4
+    assert rel_err(got, want) < 2e-6
+    # and the schedule matters: without the decays the parameters end somewhere else (the check above is not vacuous)
+    torch.manual_seed(11)
+    model, flat, opt, step, dev = _setup(monkeypatch, 0.0)
+    opt.__init__(flat, kind=kind, lr=lr, momentum=0.9, max_grad_norm=200.0, decay_ratio=0.5)
+    for _ in range(8):
+        step()
+    torch.cuda.synchronize()
+    assert rel_err(flat.flat.cpu().numpy(), want) > 10 * rel_err(got, want)
     _teardown(flat)
 
 

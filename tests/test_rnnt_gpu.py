@@ -199,7 +199,11 @@ def test_timing_probes_fire_around_the_loss_kernels():
     assert ops.probe_read_ms(9, 1) < 0                   # never armed
 
 
-@pytest.mark.parametrize("B,T,U", [(3, 40, 50), (2, 37, 64), (2, 300, 200), (2, 25, 600), (1, 1, 0), (2, 90, 959)])
+@pytest.mark.parametrize("B,T,U", [(3, 40, 50), (2, 37, 64), (2, 300, 200), (2, 25, 600), (1, 1, 0), (2, 90, 959),
+                                   # odd CH * (U + 1) (chunk of CH diagonals x U + 1 labels): the shapes at which round 3's boundary ring sat 8 bytes
+                                   # off its 16-byte granules - U + 1 = 201 -> CH 19, 149 -> 25, 255 -> 15, 129 -> 29; many utterances
+                                   # per launch so that workgroups of different phase share CUs while the ring is polled
+                                   (24, 220, 200), (16, 160, 148), (16, 120, 254), (16, 200, 128)])
 def test_lattice_kernels_agree_bit_for_bit(B, T, U):
     """rnnt_lattice_lds_kernel (one workgroup per utterance and direction: a wave per 64 labels, frontier hand-off through LDS, a helper
     wave for the memory traffic) walks the same recursion in the same arithmetic as the one-wave kernel of round 1: costs and gradients

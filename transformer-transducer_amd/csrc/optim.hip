@@ -37,9 +37,16 @@ __global__ __launch_bounds__(64) void sumsq_final_kernel(int nblocks, float* __r
 // A step whose gradient norm is not finite is DROPPED (parameters and optimiser state untouched): with clip_grad_norm_ the reference
 // would turn every weight into NaN at this point (train.py:62-65); here it is the exp-domain loss form's way of failing loudly - a step
 // whose shift no longer fitted the logits has NaN costs and gradients (rnnt_prep_exp_kernel) and must not reach the weights.
-__device__ __forceinline__ bool step_dropped(const float* normsq, float max_norm) {
-    return normsq && max_norm > 0.f && !(*normsq < 3.0e38f);          // inf or NaN
+// The drop does not depend on clipping being on (max_norm): whoever passes `normsq` gets it (FusedOptimizer always does; round 3 skipped the
+// norm when max_norm == 0 - tt.optim.Optimizer, where train.py clips by itself - and a flagged exp-domain step then reached the weights).
+__device__ __forceinline__ bool step_dropped(const float* normsq) {
+    return normsq && !(*normsq < 3.0e38f);          // inf or NaN
 }
+// Hyper-parameters that change between steps live in a small DEVICE array the kernels read at run time (`hyper`, may be NULL = use the
+// by-value arguments): hyper[0] = learning rate, hyper[1] = number of optimiser steps taken so far (Adam's bias-correction exponent,
+// advanced on the device by optim_tick_kernel).  A step captured into a HIP graph (ttmi.train.GraphedStep) therefore follows
+// Optimizer.decay_lr() (tt/optim.py:30-33, train.py:257) and Adam's step count under replay - by-value arguments are frozen at capture.
+__global__ void optim_tick_kernel(float* __restrict__ hyper) { hyper[1] += 1.f; }
 // coef = grad_scale * min(1, max_norm / (grad_scale * sqrt(normsq) + 1e-6))   (torch.nn.utils.clip_grad_norm_)
 __device__ __forceinline__ float clip_coef(const float* normsq, float max_norm, float grad_scale) {
     if (!normsq || max_norm <= 0.f) return grad_scale;
@@ -49,8 +56,9 @@ __device__ __forceinline__ float clip_coef(const float* normsq, float max_norm, 
 
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom,
                                                   long n, float lr, float momentum, float wd, int nesterov, float max_norm,
-                                                  const float* __restrict__ normsq, float grad_scale) {
-    if (step_dropped(normsq, max_norm)) return;
+                                                  const float* __restrict__ normsq, float grad_scale, const float* __restrict__ hyper) {
+    if (step_dropped(normsq)) return;
+    if (hyper) lr = hyper[0];
     const float coef = clip_coef(normsq, max_norm, grad_scale);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         float gi = g[i] * coef + wd * p[i];
@@ -66,8 +74,13 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
                                                    float wd, float bc1, float bc2, float max_norm,
-                                                   const float* __restrict__ normsq, float grad_scale) {
-    if (step_dropped(normsq, max_norm)) return;
+                                                   const float* __restrict__ normsq, float grad_scale, const float* __restrict__ hyper) {
+    if (step_dropped(normsq)) return;
+    if (hyper) {                                    // (hyper[1] was advanced by optim_tick_kernel just before this launch: counts from 1)
+        lr = hyper[0];
+        bc1 = 1.f - powf(b1, hyper[1]);
+        bc2 = 1.f - powf(b2, hyper[1]);
+    }
     const float coef = clip_coef(normsq, max_norm, grad_scale);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float gi = g[i] * coef + wd * p[i];
@@ -83,8 +96,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // p -= lr delta
 __global__ __launch_bounds__(256) void adadelta_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq,
                                                        float* __restrict__ acc, long n, float lr, float rho, float eps, float wd,
-                                                       float max_norm, const float* __restrict__ normsq, float grad_scale) {
-    if (step_dropped(normsq, max_norm)) return;
+                                                       float max_norm, const float* __restrict__ normsq, float grad_scale,
+                                                       const float* __restrict__ hyper) {
+    if (step_dropped(normsq)) return;
+    if (hyper) lr = hyper[0];
     const float coef = clip_coef(normsq, max_norm, grad_scale);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float gi = g[i] * coef + wd * p[i];
@@ -120,32 +135,36 @@ int ttmi_sumsq(const float* x, long n, float* out, void* stream) {
 
 // torch.optim.SGD step on a flat buffer with the gradient clip folded in (normsq may be NULL = no clipping).
 // The effective gradient is g * grad_scale (e.g. 1/world_size after a SUM all-reduce), clipped to max_norm.
+// hyper (device, may be NULL): see optim_tick_kernel above - hyper[0] replaces `lr` at run time.  A non-finite *normsq drops the step.
 int ttmi_sgd_step(float* p, const float* g, float* mom, long n, float lr, float momentum, float weight_decay, int nesterov,
-                  float max_norm, const float* normsq, float grad_scale, void* stream) {
+                  float max_norm, const float* normsq, float grad_scale, float* hyper, void* stream) {
     TTMI_REQUIRE(p && g && n > 0 && (mom || momentum == 0.f), "sgd_step: bad arguments");
+    if (hyper) hipLaunchKernelGGL(optim_tick_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), hyper);
     hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, mom, n, lr,
-                       momentum, weight_decay, nesterov, max_norm, normsq, grad_scale);
+                       momentum, weight_decay, nesterov, max_norm, normsq, grad_scale, hyper);
     TTMI_LAUNCH_CHECK("sgd_kernel");
     return TTMI_OK;
 }
 
 // torch.optim.Adam step (step counts from 1)
 int ttmi_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
-                   float weight_decay, int step, float max_norm, const float* normsq, float grad_scale, void* stream) {
-    TTMI_REQUIRE(p && g && m && v && n > 0 && step > 0, "adam_step: bad arguments");
-    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+                   float weight_decay, int step, float max_norm, const float* normsq, float grad_scale, float* hyper, void* stream) {
+    TTMI_REQUIRE(p && g && m && v && n > 0 && (step > 0 || hyper), "adam_step: bad arguments");
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);      // (replaced on the device when hyper is given)
+    if (hyper) hipLaunchKernelGGL(optim_tick_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), hyper);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n, lr, beta1,
-                       beta2, eps, weight_decay, bc1, bc2, max_norm, normsq, grad_scale);
+                       beta2, eps, weight_decay, bc1, bc2, max_norm, normsq, grad_scale, hyper);
     TTMI_LAUNCH_CHECK("adam_kernel");
     return TTMI_OK;
 }
 
 // torch.optim.Adadelta step (square_avg, acc_delta state buffers)
 int ttmi_adadelta_step(float* p, const float* g, float* square_avg, float* acc_delta, long n, float lr, float rho, float eps,
-                       float weight_decay, float max_norm, const float* normsq, float grad_scale, void* stream) {
+                       float weight_decay, float max_norm, const float* normsq, float grad_scale, float* hyper, void* stream) {
     TTMI_REQUIRE(p && g && square_avg && acc_delta && n > 0 && rho >= 0.f && rho <= 1.f && eps > 0.f, "adadelta_step: bad arguments");
+    if (hyper) hipLaunchKernelGGL(optim_tick_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), hyper);
     hipLaunchKernelGGL(adadelta_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, square_avg, acc_delta, n, lr,
-                       rho, eps, weight_decay, max_norm, normsq, grad_scale);
+                       rho, eps, weight_decay, max_norm, normsq, grad_scale, hyper);
     TTMI_LAUNCH_CHECK("adadelta_kernel");
     return TTMI_OK;
 }

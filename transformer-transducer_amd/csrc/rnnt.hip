@@ -340,6 +340,9 @@ struct __attribute__((aligned(16))) LatSlot {
     int tag;        // steps completed when v was written (g + 1); slot LAT_NB - 1 starts as {initial cell, 0}
     int pad;
 };
+static_assert(sizeof(LatSlot) == 16 && alignof(LatSlot) == 16, "a boundary slot is one 16-byte LDS granule: {value, tag} travel in one ds_read/write_b128");
+// byte offset of the boundary ring inside the kernel's dynamic LDS (launch-time check: must be a multiple of 16)
+constexpr size_t lat_ring_offset(int CHR, int CH, int U1) { return (size_t)4 * CHR * 4 + (size_t)2 * CH * U1 * 8; }
 __device__ __forceinline__ void lat_glds4(const void* gsrc, float* lds_wave_base) {       // 4 bytes per lane: LDS address = base + lane * 4
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
@@ -443,7 +446,11 @@ __global__ __launch_bounds__(1024) void rnnt_lattice_lds_kernel(const float* __r
     float* Eb = reinterpret_cast<float*>(lat_smem);      // [2][CHR] blank log-probs of the chunk's diagonals
     float* El = Eb + 2 * CHR;                            // [2][CHR] label log-probs
     acc_t* A = reinterpret_cast<acc_t*>(El + 2 * CHR);   // [2][CH * U1] the chunk's alpha / beta rows
-    LatSlot* bnd = reinterpret_cast<LatSlot*>(A + 2 * (long)CH * U1 + (((long)CH * U1) & 1));   // [W][LAT_NB], 16-byte aligned
+    // [W][LAT_NB].  16-byte aligned by construction: the emission buffers are 4 CHR floats (CHR a multiple of 64) and A holds 2 CH U1 doubles
+    // = a multiple of 16 bytes whatever the parity of CH U1.  (Round 3 added ((CH U1) & 1) doubles here, which moved the ring 8 bytes OFF
+    // alignment whenever CH U1 is odd - the default C5 shape, U1 = 201, CH = 19 - and with it split every {value, tag} granule the tag
+    // protocol needs to move as one ds_read_b128 / ds_write_b128.)
+    LatSlot* bnd = reinterpret_cast<LatSlot*>(A + 2 * (long)CH * U1);
     const int nsteps = D - 1;
     const int NC = (nsteps + CH - 1) / CH;
     // chunk c = steps c CH .. c CH + n - 1.  alpha: step g forms diagonal 1 + g from emission row g; beta: step g forms diagonal D - 2 - g
@@ -727,7 +734,11 @@ int launch_lattice(hipStream_t st, int B, const float* lpb, const float* lpl, co
         int CH = (120 * 1024) / (32 * U1);
         CH = CH > 32 ? 32 : (CH < 2 ? 2 : CH);
         const int CHR = (CH * U1 + 63) / 64 * 64;
-        const size_t lds = (size_t)4 * CHR * 4 + (size_t)2 * CH * U1 * 8 + 16 + (size_t)W * LAT_NB * sizeof(LatSlot) + 64;
+        const size_t lds = lat_ring_offset(CHR, CH, U1) + (size_t)W * LAT_NB * sizeof(LatSlot) + 64;
+        if (lat_ring_offset(CHR, CH, U1) % 16 != 0) {
+            ttmi_set_error("rnnt lattice: boundary ring at LDS offset %zu is not 16-byte aligned (CH %d, U1 %d)", lat_ring_offset(CHR, CH, U1), CH, U1);
+            return TTMI_EINVAL;
+        }
         static size_t enabled = 0;
         if (lds > enabled) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rnnt_lattice_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -2,6 +2,7 @@
 forward(inputs[B,T,d], targets[B,U]) -> logits[B,T,U+1,V], decode/recognize (greedy), beam search."""
 import copy
 import heapq
+import os
 
 import numpy as np
 import torch
@@ -102,7 +103,7 @@ class _JointLossFn(torch.autograd.Function):
     incoming gradient."""
 
     @staticmethod
-    def forward(ctx, enc, dec, wf, bf, wp, bp, labels, act_lens, label_lens, prec, chunk, reduction, exp_state, grad_mode=True):
+    def forward(ctx, enc, dec, wf, bf, wp, bp, labels, act_lens, label_lens, prec, chunk, reduction, exp_state, grad_mode=True, blank=0):
         """exp_state: None (plain fused form) or the JointNet's _ExpShift for this device (exp-domain form)"""
         enc, dec = enc.contiguous(), dec.contiguous()
         params = (wf, bf, wp, bp)
@@ -129,21 +130,21 @@ class _JointLossFn(torch.autograd.Function):
             if st is not None and st.valid and ops.joint_exp_supported(c1 - c0, T, U1, J, V, prec, fwd_only=not need):
                 # the projection stores exp(logit - shift) and row sums; the loss reads the sums and two f32 logits per row, its gradient
                 # stays factored as (row factor) x P and is consumed in that form (include/ttmi.h, "fused joint + loss fast path")
-                P, rowsum, saved, emis = ops.joint_fwd_exp(enc[c0:c1], dec[c0:c1], wf_, bf_, wp_, bp_, prec, st.cur, lab.contiguous(), 0)
-                costs[c0:c1] = ops.rnnt_loss_fwd_exp(P, rowsum, lab, al, ll, 0, ws, st.cur, st.nxt, emis, st.flag)
+                P, rowsum, saved, emis = ops.joint_fwd_exp(enc[c0:c1], dec[c0:c1], wf_, bf_, wp_, bp_, prec, st.cur, lab.contiguous(), blank)
+                costs[c0:c1] = ops.rnnt_loss_fwd_exp(P, rowsum, lab, al, ll, blank, ws, st.cur, st.nxt, emis, st.flag)
                 if need:
-                    srow, srow16 = ops.rnnt_loss_bwd_exp(P, lab, al, ll, 0, ws, one, 0, scale)
+                    srow, srow16 = ops.rnnt_loss_bwd_exp(P, lab, al, ll, blank, ws, one, 0, scale)
                     ops.joint_bwd_exp(P, srow, srow16, enc[c0:c1], dec[c0:c1], wf_, wp_, saved, prec, g, out=(denc[c0:c1], ddec[c0:c1]))
                 del P, rowsum, saved, emis
                 exp_ran = True
                 continue
             logits, saved = ops.joint_fwd(enc[c0:c1], dec[c0:c1], wf_, bf_, wp_, bp_, prec)
-            costs[c0:c1] = ops.rnnt_loss_fwd(logits, lab, al, ll, 0, ws)
+            costs[c0:c1] = ops.rnnt_loss_fwd(logits, lab, al, ll, blank, ws)
             if st is not None and not st.valid:                 # the plain form's log-sum-exp pass seeds the shift for the next step
                 ops.rnnt_shift_seed(ws, al, ll, c1 - c0, T, U1, st.nxt)
                 seeded = True
             if need:
-                grad = ops.rnnt_loss_bwd(logits, lab, al, ll, 0, ws, one, 0, scale, inplace=True)
+                grad = ops.rnnt_loss_bwd(logits, lab, al, ll, blank, ws, one, 0, scale, inplace=True)
                 ops.joint_bwd(grad, enc[c0:c1], dec[c0:c1], wf_, wp_, saved, prec, g, out=(denc[c0:c1], ddec[c0:c1]))
             del logits, saved
         if st is not None and (exp_ran or seeded):
@@ -176,7 +177,130 @@ class _JointLossFn(torch.autograd.Function):
                     cb()
             else:
                 rets.append(gp * gout)
-        return (denc * gout, ddec * gout, *rets, None, None, None, None, None, None, None, None)
+        return (denc * gout, ddec * gout, *rets, None, None, None, None, None, None, None, None, None)
+
+
+def deferred_logits_enabled(config, prec):
+    """does Transducer.forward hand out a DeferredLogits handle?  TTMI_DEFERRED_LOGITS=0 / 1 (read per call, like TTMI_PRECISION) or
+    config.deferred_logits (True / False) decide; unset: on in the bf16 pipeline (the throughput mode - its logits are 7 GB of bf16 per
+    C2 step that train.py:51-53 only ever hands to the loss), off in the fp32 parity mode."""
+    env = os.environ.get("TTMI_DEFERRED_LOGITS")
+    if env is not None and env != "":
+        return env != "0"
+    if config is not None and config.deferred_logits is not None:
+        return bool(config.deferred_logits)
+    return prec == 1
+
+
+def _meta_functions():
+    """Tensor methods / property getters a DeferredLogits answers from its own metadata, without producing the logits"""
+    T = torch.Tensor
+    fns = {T.size, T.dim, T.ndimension, T.numel, T.nelement, T.element_size, T.is_floating_point, T.is_complex, T.get_device, T.__len__}
+    # (not stride / is_contiguous: the eager logits are a [..., :V] view of a pitched buffer - those come from the real tensor)
+    for name in ("shape", "dtype", "device", "ndim", "is_cuda", "is_cpu", "layout", "is_sparse", "is_quantized", "is_meta", "is_nested",
+                 "requires_grad", "itemsize", "names"):
+        fns.add(getattr(T, name).__get__)
+    return frozenset(fns)
+
+
+class DeferredLogits(torch.Tensor):
+    """What `logits = model(inputs, targets)` (train.py:51, tt/model.py:58-68) returns in the bf16 pipeline: a tensor-shaped HANDLE on the
+    two encoder states.  train.py:53 hands it to `RNNTLoss` unchanged, and the `warprnnt_pytorch` shim then runs joint + loss as ONE fused
+    op on those states (`_JointLossFn`: the exp-domain form when its kernels take the sizes, else the chunked memory form) - the
+    [B, T, U+1, V] logits (7.1 GB of bf16 per C2 step, written once and walked twice by the loss) are never formed, which is what
+    `Transducer.loss(..., exp_domain=True)` does for callers that changed their code.
+
+    Any OTHER use - arithmetic, indexing, `.float()`, `softmax`, printing, `.data_ptr()`, `.stride()`, `torch.save`, a different loss -
+    materialises exactly the tensor `model.joint(enc_state, dec_state)` returns today (same autograd graph into the encoders, same bits;
+    produced once and kept) and carries on with it, and a handle that has been materialised is consumed by `RNNTLoss` as an ordinary
+    logits tensor.  Metadata (`shape`, `size()`, `dim()`, `dtype`, `device`, `is_cuda`, `numel()`, `len()`, `requires_grad`) is answered
+    from the handle.  Implementation: a storage-less wrapper subclass (`Tensor._make_wrapper_subclass`) whose `__torch_function__`
+    swaps the handle for the real logits before any function that is not a metadata query runs."""
+
+    @staticmethod
+    def __new__(cls, joint, enc_state, dec_state, prec):
+        B, T = enc_state.shape[0], enc_state.shape[1]
+        U1 = dec_state.shape[1]
+        J, V = joint.forward_layer.out_features, joint.project_layer.out_features
+        grad_mode = torch.is_grad_enabled()
+        needs = grad_mode and (enc_state.requires_grad or dec_state.requires_grad or any(p.requires_grad for p in joint.parameters()))
+        self = torch.Tensor._make_wrapper_subclass(cls, (B, T, U1, V), dtype=ops.joint_logits_dtype(prec, J), device=enc_state.device,
+                                                   requires_grad=bool(needs))
+        self._joint, self._enc, self._dec, self._prec, self._grad_mode, self._real = joint, enc_state, dec_state, prec, grad_mode, None
+        if needs:
+            # a gradient that arrives at the HANDLE (a caller below the Python API recorded it as an autograd input, e.g. a foreign
+            # autograd.Function applied to it directly) belongs to the real logits: pass it on into their graph
+            with torch._C.DisableTorchFunctionSubclass():
+                torch.Tensor.register_hook(self, self._forward_gradient)
+        return self
+
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def _forward_gradient(self, grad):
+        if self._real is not None and self._real.requires_grad:
+            torch.autograd.backward(self._real, grad)
+        return None
+
+    @property
+    def is_materialized(self):
+        return self._real is not None
+
+    def _produce(self):
+        j = self._joint
+        ops.weights_fresh()
+        return _JointFn.apply(self._enc, self._dec, j.forward_layer.weight, j.forward_layer.bias, j.project_layer.weight,
+                              j.project_layer.bias, self._prec)
+
+    def materialize(self):
+        """-> the real logits (produced on first use under the grad mode of the forward call that made the handle, then kept)"""
+        if self._real is None:
+            with torch.set_grad_enabled(self._grad_mode):
+                self._real = self._produce()
+        return self._real
+
+    def rnnt_loss(self, labels, act_lens, label_lens, blank=0, reduction="mean"):
+        """the loss of train.py:53 on this handle's logits without forming them (called by warprnnt_pytorch.rnnt_loss; arguments already
+        certified there).  None when this case has to go through the real logits (per-utterance costs that need gradients)."""
+        if self._real is not None:
+            return None
+        grad = self._grad_mode and torch.is_grad_enabled()
+        if reduction == "none" and grad and self.requires_grad:
+            return None                     # per-utterance upstream gradients cannot be folded into weight gradients formed in the forward pass
+        j = self._joint
+        B, T, U1 = self.shape[0], self.shape[1], self.shape[2]
+        ops.weights_fresh()
+        exp = self._prec == 1 and os.environ.get("TTMI_DEFERRED_EXP", "1") != "0"
+        chunk = j.default_loss_chunk(B, T, U1, exp, self._prec)
+        return _JointLossFn.apply(self._enc, self._dec, j.forward_layer.weight, j.forward_layer.bias, j.project_layer.weight,
+                                  j.project_layer.bias, labels, act_lens, label_lens, self._prec, int(chunk), reduction,
+                                  j.exp_shift_state(self._enc.device) if exp else None, grad, int(blank))
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in _META_FUNCTIONS:
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+
+        def real(a):
+            if isinstance(a, DeferredLogits):
+                return a.materialize()
+            if isinstance(a, (list, tuple)):
+                return type(a)(real(x) for x in a)
+            return a
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*real(args), **{k: real(v) for k, v in kwargs.items()})
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        # reached only by callers below the Python API (the handle has no storage): give them the real values, detached
+        import torch.utils._pytree as pytree
+        args, kwargs = pytree.tree_map_only(DeferredLogits, lambda a: a.materialize().detach(), (args, kwargs or {}))
+        return func(*args, **kwargs)
+
+
+_META_FUNCTIONS = _meta_functions()
 
 
 class JointNet(nn.Module):
@@ -216,6 +340,21 @@ class JointNet(nn.Module):
         if st is None:
             st = states[device] = _ExpShift(device)
         return st
+
+    def default_loss_chunk(self, B, T, U1, exp_domain=False, prec=None):
+        """utterances per chunk of `loss()`: about 2 GB of logits (the memory-saving form) or 32 GB (exp_domain: the speed form - every
+        chunk boundary costs a pipeline fill of the three big GEMMs and one more lattice launch: C2 whole batch 35.0 ms per step, two
+        halves 36.2; C5's 28 GB in one chunk 102.0 ms, in two 104.2 - on 288 GB of HBM the budget is not the constraint), adjusted to a
+        lattice-row count the joint's persistent wgrad kernel takes (a reduction length chunk * T * U1 that is a multiple of its 64-row
+        K-tile; other lengths fall to the 128x128 kernel at twice the time: C2, 8 utterances 9.5 ms per step, 16 utterances 5.3 ms)"""
+        prec = default_precision() if prec is None else prec
+        es = 2 if ops.joint_logits_dtype(prec, self.forward_layer.out_features) is torch.bfloat16 else 4
+        budget = (32 << 30) if exp_domain else (2 << 30)
+        chunk = max(1, min(B, int(budget // (es * T * U1 * self.project_layer.out_features))))
+        ok = [c for c in range(1, B + 1) if (c * T * U1) % 64 == 0]
+        if ok:
+            chunk = max([c for c in ok if c <= chunk] or [min(ok)])
+        return chunk
 
 
 class _LabelStateGraphs:
@@ -287,7 +426,14 @@ class Transducer(nn.Module):
             raise AttributeError("'BuildDecoder' object has no attribute 'embedding' (share_embedding is broken upstream)")
 
     def forward(self, inputs, targets):
-        return self.joint(*self._encode(inputs, targets))
+        """-> logits [B, T, U+1, V] (tt/model.py:58-68).  In the bf16 pipeline the return value is a DeferredLogits handle on the two
+        encoder states: `RNNTLoss` (train.py:53) consumes it through the fused joint + loss kernels, anything else makes it produce
+        the real logits first - train.py:51-53 runs unchanged and on the fast path (deferred_logits_enabled for the switches)."""
+        enc_state, dec_state = self._encode(inputs, targets)
+        prec = default_precision()
+        if enc_state.is_cuda and deferred_logits_enabled(self.config, prec):
+            return DeferredLogits(self.joint, enc_state, dec_state, prec)
+        return self.joint(enc_state, dec_state)
 
     def loss(self, inputs, inputs_length, targets, targets_length, reduction="mean", chunk=None, check_lengths=True, exp_domain=False):
         """Opt-in fused form of train.py:51-53 (`logits = model(inputs, targets); loss = criterion(logits, targets.int(),
@@ -316,18 +462,8 @@ class Transducer(nn.Module):
                                   j.exp_shift_state(enc_state.device) if exp_domain and prec == 1 else None, torch.is_grad_enabled())
 
     def default_loss_chunk(self, B, T, U1, exp_domain=False):
-        """utterances per chunk of `loss()`: about 2 GB of logits (the memory-saving form) or 32 GB (exp_domain: the speed form - every
-        chunk boundary costs a pipeline fill of the three big GEMMs and one more lattice launch: C2 whole batch 35.0 ms per step, two
-        halves 36.2; C5's 28 GB in one chunk 102.0 ms, in two 104.2 - on 288 GB of HBM the budget is not the constraint), adjusted to a
-        lattice-row count the joint's persistent wgrad kernel takes (a reduction length chunk * T * U1 that is a multiple of its 64-row
-        K-tile; other lengths fall to the 128x128 kernel at twice the time: C2, 8 utterances 9.5 ms per step, 16 utterances 5.3 ms)"""
-        es = 2 if ops.joint_logits_dtype(default_precision(), self.joint.forward_layer.out_features) is torch.bfloat16 else 4
-        budget = (32 << 30) if exp_domain else (2 << 30)
-        chunk = max(1, min(B, int(budget // (es * T * U1 * self.config.vocab_size))))
-        ok = [c for c in range(1, B + 1) if (c * T * U1) % 64 == 0]
-        if ok:
-            chunk = max([c for c in ok if c <= chunk] or [min(ok)])
-        return chunk
+        """utterances per chunk of `loss()` (JointNet.default_loss_chunk)"""
+        return self.joint.default_loss_chunk(B, T, U1, exp_domain)
 
     def _encode(self, inputs, targets):
         """both encoders of forward() (tt/model.py:58-65): -> (enc_state [B,T,d], dec_state [B,U+1,d])"""

@@ -581,21 +581,22 @@ def sumsq(x, out):
     check(lib().ttmi_sumsq(_p(x), c_long(x.numel()), _p(out), _stream()), "ttmi_sumsq")
 
 
-def sgd_step(p, g, mom, lr, momentum, weight_decay, nesterov, max_norm, normsq, grad_scale):
+def sgd_step(p, g, mom, lr, momentum, weight_decay, nesterov, max_norm, normsq, grad_scale, hyper=None):
+    """hyper: device f32 [2] = (learning rate, steps taken), read (and the count advanced) by the kernels at run time - see include/ttmi.h"""
     check(lib().ttmi_sgd_step(_p(p), _p(g), _p(mom), c_long(p.numel()), c_float(lr), c_float(momentum), c_float(weight_decay),
-                              c_int(1 if nesterov else 0), c_float(max_norm), _p(normsq), c_float(grad_scale), _stream()),
+                              c_int(1 if nesterov else 0), c_float(max_norm), _p(normsq), c_float(grad_scale), _p(hyper), _stream()),
           "ttmi_sgd_step")
 
 
-def adam_step(p, g, m, v, lr, betas, eps, weight_decay, step, max_norm, normsq, grad_scale):
+def adam_step(p, g, m, v, lr, betas, eps, weight_decay, step, max_norm, normsq, grad_scale, hyper=None):
     check(lib().ttmi_adam_step(_p(p), _p(g), _p(m), _p(v), c_long(p.numel()), c_float(lr), c_float(betas[0]), c_float(betas[1]),
                                c_float(eps), c_float(weight_decay), c_int(step), c_float(max_norm), _p(normsq),
-                               c_float(grad_scale), _stream()), "ttmi_adam_step")
+                               c_float(grad_scale), _p(hyper), _stream()), "ttmi_adam_step")
 
 
-def adadelta_step(p, g, sq, acc, lr, rho, eps, weight_decay, max_norm, normsq, grad_scale):
+def adadelta_step(p, g, sq, acc, lr, rho, eps, weight_decay, max_norm, normsq, grad_scale, hyper=None):
     check(lib().ttmi_adadelta_step(_p(p), _p(g), _p(sq), _p(acc), c_long(p.numel()), c_float(lr), c_float(rho), c_float(eps),
-                                   c_float(weight_decay), c_float(max_norm), _p(normsq), c_float(grad_scale), _stream()), "ttmi_adadelta_step")
+                                   c_float(weight_decay), c_float(max_norm), _p(normsq), c_float(grad_scale), _p(hyper), _stream()), "ttmi_adadelta_step")
 
 
 def probe_arm(slot=0):

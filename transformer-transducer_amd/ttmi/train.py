@@ -226,40 +226,70 @@ class FusedOptimizer:
             raise NotImplementedError("FusedOptimizer: optimizer type %r (tt/optim.py:57-84 builds sgd, adam and adadelta)" % (kind,))
         if eps is None:
             eps = 1e-6 if kind == "adadelta" else 1e-8        # torch.optim's defaults
-        self.flat, self.kind, self.lr, self.momentum, self.nesterov = flat, kind, lr, momentum, nesterov
+        self.flat, self.kind, self.momentum, self.nesterov = flat, kind, momentum, nesterov
         self.weight_decay, self.betas, self.eps, self.max_grad_norm, self.world = weight_decay, betas, eps, max_grad_norm, world
         self.decay_ratio, self.rho = decay_ratio, rho
         self.state = [torch.zeros_like(flat.flat) for _ in range(1 if kind == "sgd" else 2)]
         self.normsq = torch.zeros(1, dtype=torch.float32, device=flat.flat.device)
+        # what changes between steps lives on the DEVICE, where the update kernels read it at run time: (learning rate, optimiser steps taken).
+        # A step captured into a HIP graph (GraphedStep) would otherwise replay the values of the moment of capture - decay_lr() silently
+        # ignored, Adam's bias correction frozen.  `lr` and `steps_taken` are host mirrors; assigning to them writes the device copy.
+        self.hyper = torch.zeros(2, dtype=torch.float32, device=flat.flat.device)
+        self.lr = lr
         self.global_step = 1                # tt/optim.py:8
         self.current_epoch = 0
         self.steps_taken = 0                # Adam's bias-correction exponent (torch keeps it per parameter in state['step'])
 
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        self._lr = float(value)
+        self.hyper[0:1].fill_(self._lr)     # (a device fill on the current stream: ordered before the next step / replay issued on it)
+
+    @property
+    def steps_taken(self):
+        return self._steps
+
+    @steps_taken.setter
+    def steps_taken(self, value):
+        self._steps = int(value)
+        self.hyper[1:2].fill_(float(self._steps))
+
+    def host_counters(self):
+        return self.global_step, self._steps
+
+    def set_host_counters(self, counters):
+        """host mirrors only (the device count is advanced by the kernels themselves): GraphedStep around a capture / per replay"""
+        self.global_step, self._steps = counters
+
     def step(self):
-        """gradients in flat.grad are SUMS over ranks; the 1/world averaging is folded into the update."""
+        """gradients in flat.grad are SUMS over ranks; the 1/world averaging is folded into the update.  A step whose gradient norm is
+        not finite is dropped on the device (parameters and state untouched), with or without clipping."""
         flat = self.flat
         for p, o in zip(flat.params, flat.offsets):       # the kernels read flat.grad: a .grad that was re-pointed (zero_grad(set_to_none),
             if p.grad is None or p.grad.data_ptr() != flat.grad.data_ptr() + 4 * o:       # p.grad = ...) would be silently ignored
                 raise RuntimeError("FusedOptimizer.step: a parameter's .grad no longer aliases the flat gradient buffer "
                                    "(use FlatModel.zero_grad(), not zero_grad(set_to_none=True))")
         self.global_step += 1
-        self.steps_taken += 1
+        self._steps += 1                    # (host mirror; the kernels advance hyper[1] themselves)
         ops.wgrad_flush(every_stream=True)                # grouped weight gradients still queued (none after a complete backward pass)
         ops.join_side_streams()
         scale = 1.0 / self.world
         max_norm = self.max_grad_norm or 0.0
         self.normsq.zero_()
-        if max_norm > 0:
-            ops.sumsq(flat.grad, self.normsq)
+        ops.sumsq(flat.grad, self.normsq)   # always: the norm is also what drops a NaN step (train.py's own clip_grad_norm_ leaves NaNs in place)
         if self.kind == "adam":
-            ops.adam_step(flat.flat, flat.grad, self.state[0], self.state[1], self.lr, self.betas, self.eps,
-                          self.weight_decay, self.steps_taken, max_norm, self.normsq, scale)
+            ops.adam_step(flat.flat, flat.grad, self.state[0], self.state[1], self._lr, self.betas, self.eps,
+                          self.weight_decay, self._steps, max_norm, self.normsq, scale, self.hyper)
         elif self.kind == "adadelta":
-            ops.adadelta_step(flat.flat, flat.grad, self.state[0], self.state[1], self.lr, self.rho, self.eps, self.weight_decay,
-                              max_norm, self.normsq, scale)
+            ops.adadelta_step(flat.flat, flat.grad, self.state[0], self.state[1], self._lr, self.rho, self.eps, self.weight_decay,
+                              max_norm, self.normsq, scale, self.hyper)
         else:
-            ops.sgd_step(flat.flat, flat.grad, self.state[0], self.lr, self.momentum, self.weight_decay,
-                         self.nesterov, max_norm, self.normsq, scale)
+            ops.sgd_step(flat.flat, flat.grad, self.state[0], self._lr, self.momentum, self.weight_decay,
+                         self.nesterov, max_norm, self.normsq, scale, self.hyper)
         flat.refresh_shadows()              # the kernels above changed the weights behind torch's back: rebuild the bf16 copies (one launch)
 
     def grad_norm(self):
@@ -338,59 +368,107 @@ class FusedOptimizer:
 
 
 class GraphedStep:
-    """A whole training step - forward, loss, backward, clip + optimiser, shadow refresh - captured ONCE into a HIP graph and replayed with
-    one launch per step: no Python, no ~560 kernel launches on the host (8 ranks of a data-parallel job share one host).
+    """A whole training step - forward, loss, backward, gradient all-reduce, clip + optimiser, shadow refresh - captured ONCE into a HIP
+    graph and replayed with one launch per step: no Python, no ~400 kernel launches on the host (8 ranks of a data-parallel job share one
+    host).
 
-        step = GraphedStep(lambda: one_step(static_inputs...), exp_state=model.joint.exp_shift_state(dev))
+        step = GraphedStep(lambda: one_step(static_inputs...), optimizer=opt, exp_state=model.joint.exp_shift_state(dev))
         for batch in loader:  static_inputs.copy_(batch); loss = step()
 
     `step_fn` must be free of host synchronisation and must read its batch from tensors that stay at the same address.  What makes the
-    step replayable here: dropout seeds are drawn on the host per call and would be frozen in the graph, so every dropout site mixes in a
-    device word (`salt`, ttmi_set_dropout_salt) that the graph bumps before anything else - each replay draws new masks, forward and
-    backward of one replay agree; the exp-domain loss form's range check (tt.model._ExpShift) is looked at between replays: a raised
-    flag makes the next call run eagerly (the plain form re-seeds the shift) and capture again.  Host-side counters that a captured call
-    would have advanced (FusedOptimizer.global_step, Adam's bias-correction step) are advanced per replay by `on_replay` callbacks;
-    Adam's bias correction is computed on the host per step and is therefore NOT replayable - use SGD / Adadelta, or eager steps."""
+    step replayable here:
+    * dropout seeds are drawn on the host per call and would be frozen in the graph, so every dropout site mixes in a device word (`salt`,
+      ttmi_set_dropout_salt) that the graph bumps before anything else - each replay draws new masks, forward and backward of one replay
+      agree;
+    * the learning rate and the optimiser's step count (Adam's bias corrections) are DEVICE scalars the update kernels read at run time
+      (FusedOptimizer.hyper): `decay_lr()` / `opt.lr = ...` between replays takes effect, all three optimiser kinds replay.  Other
+      hyper-parameters (momentum, betas, weight decay, clip norm, world size) are by-value kernel arguments: GraphedStep snapshots them at
+      capture and RAISES at the next call if one changed (re-capture with `recapture()`);
+    * `GradSync`'s bucketed all-reduces are launched from autograd hooks inside the captured region and become graph nodes (RCCL
+      collectives are capturable; every rank must capture and replay the same sequence); with a process group initialised the capture
+      runs in `thread_local` error mode so that the process group's watchdog thread may keep polling its events;
+    * the exp-domain loss form's range check (tt.model._ExpShift) is looked at between replays: after a raised flag (that replay's step was
+      dropped on the device: NaN gradients) the NEXT call runs ONE eager step in place of a replay - the plain loss form, which re-seeds
+      the shift - and returns its loss; the call after that captures again (a capture executes nothing) and replays.  Every batch gets
+      exactly one optimiser update.
+    Host-side counters (`optimizer.global_step`, its step-count mirror) are restored after a capture - which runs `step_fn`'s Python once
+    without executing a step - and advanced by one per replay.  The `warmup` eager steps of the constructor ARE real steps on whatever the
+    static input tensors hold (they update the weights and the counters); fill the static inputs with the first batch before constructing."""
 
-    def __init__(self, step_fn, device=None, warmup=3, exp_state=None, on_replay=()):
-        self.step_fn, self.exp_state, self.on_replay = step_fn, exp_state, tuple(on_replay)
+    def __init__(self, step_fn, device=None, warmup=3, exp_state=None, on_replay=(), optimizer=None, capture_error_mode=None):
+        self.step_fn, self.exp_state, self.on_replay, self.optimizer = step_fn, exp_state, tuple(on_replay), optimizer
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        if capture_error_mode is None:
+            capture_error_mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+        self.capture_error_mode = capture_error_mode
         self.salt = torch.zeros(1, dtype=torch.int32, device=self.device)
         ops.set_dropout_salt(self.salt)
         self.stream = torch.cuda.Stream(self.device)
-        self.graph, self.out, self.captures = None, None, 0
+        self.graph, self.out, self.captures, self.eager_steps = None, None, 0, 0
         self._warm(warmup)
         self._capture()
 
-    def _warm(self, n):
-        """eager steps on the capture stream: scratch arenas, fork streams, kernel attributes, the exp form's shift"""
+    def _baked(self):
+        """by-value kernel arguments of the optimiser step: frozen in the graph"""
+        o = self.optimizer
+        if o is None:
+            return None
+        return (o.kind, o.momentum, o.nesterov, o.weight_decay, tuple(o.betas), o.eps, o.rho, o.max_grad_norm, o.world)
+
+    def _eager(self):
+        """one eager step on the capture stream (same streams, arenas and allocator pools as the captured one)"""
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
-            for _ in range(n):
-                self.salt.add_(1)
-                self.out = self.step_fn()
+            self.salt.add_(1)
+            self.out = self.step_fn()
         cur.wait_stream(self.stream)
+        self.eager_steps += 1
+        return self.out
+
+    def _warm(self, n):
+        """eager steps: scratch arenas, fork streams, kernel attributes, the exp form's shift"""
+        for _ in range(n):
+            self._eager()
         torch.cuda.synchronize(self.device)
 
     def _capture(self):
         if self.exp_state is not None and not self.exp_state.valid:
             raise RuntimeError("GraphedStep: the exp-domain loss form has no valid shift after the warm-up steps")
+        counters = self.optimizer.host_counters() if self.optimizer is not None else None
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self.stream):
+        with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode=self.capture_error_mode):
             self.salt.add_(1)
             self.out = self.step_fn()
+        if counters is not None:
+            self.optimizer.set_host_counters(counters)          # the capture ran step_fn's Python, not a step
+        self.baked = self._baked()
         self.captures += 1
+
+    def recapture(self):
+        """capture again (after changing a by-value hyper-parameter of the optimiser, or the step function's behaviour)"""
+        torch.cuda.synchronize(self.device)
+        self.graph = None
+        self._capture()
 
     def __call__(self):
         st = self.exp_state
         if st is not None:
             st.poll()
-            if not st.valid:                # a flagged replay: one eager step (plain form, re-seeds the shift), one more in the exp form, new graph
-                self.graph = None
-                self._warm(2)
-                self._capture()
+            if not st.valid:                # the previous replay was flagged (and dropped on the device): this batch gets ONE eager step -
+                self.graph = None           # the plain form, which re-seeds the shift -, the next call captures again
+                out = self._eager()
+                return out
+        if self.graph is None:
+            self._capture()
+        if self.baked != self._baked():
+            raise RuntimeError("GraphedStep: an optimiser hyper-parameter that is a by-value kernel argument (kind, momentum, nesterov, "
+                               "weight_decay, betas, eps, rho, max_grad_norm, world) changed since the capture; call recapture().  "
+                               "(lr and the step count are read on the device and may change freely.)")
         self.graph.replay()
+        if self.optimizer is not None:
+            g, s = self.optimizer.host_counters()
+            self.optimizer.set_host_counters((g + 1, s + 1))
         for cb in self.on_replay:
             cb()
         if st is not None:

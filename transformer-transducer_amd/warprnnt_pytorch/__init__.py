@@ -108,7 +108,15 @@ def rnnt_loss(acts, labels, act_lens, label_lens, blank=0, reduction="mean", che
     if not acts.is_cuda:
         raise ValueError("RNNTLoss: acts must live on the GPU (the MI355X build has no CPU path)")
     labels, act_lens, label_lens = (t.to(acts.device) for t in (labels, act_lens, label_lens))
-    _certify(acts, labels, act_lens, label_lens, check_lengths)
+    _certify(acts, labels, act_lens, label_lens, check_lengths)      # (shape / dtype queries only: a DeferredLogits handle stays a handle)
+    fused = getattr(acts, "rnnt_loss", None)
+    if fused is not None:
+        # `acts` is the handle Transducer.forward returns in the bf16 pipeline (tt.model.DeferredLogits): joint + loss run as one fused op on
+        # the encoder states it carries and the logits are never formed - train.py:51-53 as written, on the path of Transducer.loss
+        out = fused(labels, act_lens, label_lens, int(blank), reduction)
+        if out is not None:
+            return out
+        acts = acts.materialize()           # (per-utterance costs with gradients, or a handle that was already used as a tensor)
     return _RNNTLossFn.apply(acts, labels, act_lens, label_lens, int(blank), reduction)
 
 
