@@ -311,8 +311,9 @@ def test_single_rank_rccl_graphed_step_on_one_gpu(monkeypatch):
     assert p.exitcode == 0
     assert exp_ran and n_buckets >= 4 and n_works >= n_buckets - 1
     want_grad, want_params, _, _, _ = _graph_twin(torch.device("cuda", 0), 1, 0, 5)
-    assert rel_err(grad, want_grad) < 1e-4
+    print("graphed RCCL step vs eager twin: gradients %.2e, parameters %.2e" % (rel_err(grad, want_grad), rel_err(params, want_params)))
     assert rel_err(params, want_params) < 1e-6
+    assert rel_err(grad, want_grad) < 1e-4
 
 
 def _graph_twin(dev, world, rank, steps):

@@ -306,3 +306,70 @@ def test_exp_domain_long_label_sequences(monkeypatch):
     assert abs(fast[0] - ref[0]) < 2e-4 * ref[0] and abs(plain[0] - ref[0]) < 2e-4 * ref[0]
     assert fast[0] != plain[0]                               # (the exp-domain kernels ran: the two forms round differently)
     assert e_fast < max(1.5 * e_plain, 5e-3)
+
+
+@pytest.mark.parametrize("B,T,U", [(7, 187, 29), (5, 333, 21), (3, 487, 42), (33, 50, 19)])
+def test_exp_domain_runs_at_any_row_count_vs_oracle(monkeypatch, B, T, U):
+    """train.py:32-35 trims every batch to its own maximum lengths, so B * T * (U + 1) is arbitrary; round 3's exp-domain path needed a
+    multiple of 64 (the wgrad's K-tile) and silently fell back otherwise.  Now the library pads the reduction:
+    odd row counts, ragged lengths - the exp-domain kernels must RUN, and costs / gradients are held to the
+    oracle's joint (float64) + C lattice on the same encoder states, with the bounds of test_exp_domain_vs_oracle."""
+    import ttmi.ops as ops
+    from oracle import tt_oracle as O
+    from oracle.rnnt_c import rnnt_loss_c
+    from tt.model import _JointLossFn
+    model, _, _, _, _ = _training_sized(monkeypatch, "bf16")
+    g = torch.Generator(device="cuda").manual_seed(100 * B + U)
+    x = torch.randn(B, T, 512, device="cuda", generator=g)
+    y = torch.randint(1, 4334, (B, U), device="cuda", generator=g)
+    al = torch.randint(T // 2, T + 1, (B,), device="cuda", generator=g).int()
+    ll = torch.randint(U // 2, U + 1, (B,), device="cuda", generator=g).int()
+    al[0], ll[0] = T, U
+    rows = B * T * (U + 1)
+    j = model.joint
+    chunk = j.default_loss_chunk(B, T, U + 1, True, 1)
+    assert (chunk * T * (U + 1)) % 64 != 0 and chunk * T * (U + 1) >= 32768, (rows, chunk)       # the case round 3 could not run
+    with torch.no_grad():
+        enc_s, dec_s = model._encode(x, y)
+    st = j.exp_shift_state(x.device)
+    st.set(0.0)
+    calls = []
+    orig = ops.joint_bwd_exp
+    monkeypatch.setattr(ops, "joint_bwd_exp", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    enc_l, dec_l = enc_s.clone().requires_grad_(True), dec_s.clone().requires_grad_(True)
+    model.zero_grad()
+    loss = _JointLossFn.apply(enc_l, dec_l, j.forward_layer.weight, j.forward_layer.bias, j.project_layer.weight, j.project_layer.bias,
+                              y.int().contiguous(), al, ll, 1, chunk, "mean", st, True)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert len(calls) == -(-B // chunk) and int(st.flag) == 0                   # every chunk took the exp-domain kernels
+    sd = {"joint." + k: v.detach().double().cpu().numpy() for k, v in j.state_dict().items()}
+    z, cache = O.joint_fwd(enc_s.double().cpu().numpy(), dec_s.double().cpu().numpy(), sd)
+    want_loss, want_costs, dz = rnnt_loss_c(z.astype(np.float32), y.int().cpu().numpy(), al.cpu().numpy(), ll.cpu().numpy())
+    grads = {}
+    denc, ddec = O.joint_bwd(dz.astype(np.float64), cache, sd, grads)
+    el = abs(float(loss.detach()) - float(want_loss)) / float(want_loss)
+    errs = {"denc": rel_err(enc_l.grad.cpu().numpy(), denc), "ddec": rel_err(dec_l.grad.cpu().numpy(), ddec)}
+    for k, p in j.named_parameters():
+        errs["g_" + k] = rel_err(p.grad.cpu().numpy(), grads["joint." + k])
+    print("exp-domain form at %d rows (%d per chunk, %d mod 64): loss rel %.2e, %s" % (rows, chunk * T * (U + 1), (chunk * T * (U + 1)) % 64, el,
+                                                                                      ", ".join("%s %.2e" % kv for kv in errs.items())))
+    assert el < 5e-5
+    for k, e in errs.items():
+        assert e < 1.5e-2, (k, e)
+    assert errs["g_project_layer.bias"] < 5e-3
+
+
+def test_exp_domain_warns_once_when_it_cannot_run(monkeypatch):
+    """a lattice too small for the persistent kernels: the plain fused form runs (same numbers as without the switch) and says so, once"""
+    import warnings
+    import tt.model as M
+    model, x, y, al, ll = _training_sized(monkeypatch, "bf16")
+    M._warned_no_exp.clear()
+    base = _run(model, x[:2], y[:2], al[:2].clone().fill_(200), ll[:2].clone().fill_(20))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        a = _run(model, x[:2], y[:2], al[:2].clone().fill_(200), ll[:2].clone().fill_(20), exp_domain=True)
+        b = _run(model, x[:2], y[:2], al[:2].clone().fill_(200), ll[:2].clone().fill_(20), exp_domain=True)
+    assert a[0] == base[0] == b[0]
+    assert sum("outside the persistent" in str(m.message) for m in w) == 1

@@ -130,7 +130,9 @@ def test_lr_decay_and_step_count_follow_under_replay(monkeypatch, kind):
     want, steps_e, dev_e, lrs_e = run(False)
     got, steps_g, dev_g, lrs_g = run(True)
     assert steps_e == steps_g == 8 and dev_e == dev_g == 8.0 and lrs_e == lrs_g and lrs_g[-1] == lr / 4
-    assert rel_err(got, want) < 2e-6
+    # (SGD's update is linear in the gradient: f32 atomic-order noise stays noise.  Adam / Adadelta normalise the update per element, so
+    # the same noise moves near-zero gradients' updates by whole steps: two eager runs differ as much)
+    assert rel_err(got, want) < (2e-6 if kind == "sgd" else 2e-4)
     # and the schedule matters: without the decays the parameters end somewhere else (the check above is not vacuous)
     torch.manual_seed(11)
     model, flat, opt, step, dev = _setup(monkeypatch, 0.0)

@@ -2281,7 +2281,9 @@ bool gemm_fast_joint_exp_ok(int M, int V, int J, long ldv, bool fwd_only) {
     if (!nt_v8_eligible(M, V, J)) return false;
     if (fwd_only) return true;                                      // (evaluation: only the exp-store projection runs)
     if (!nt_v8_eligible(M, J, (int)ldv)) return false;
-    return tn_v8_eligible(V, J, M, true, nullptr, nullptr);       // (a ragged V % 256 strip rides inside the kernel or takes the 128x128 kernel: both weight their column sums)
+    // the wgrad's reduction runs over the lattice rows PADDED to its 64-row K-tile (the caller's buffers have room for the pad rows and
+    // joint_bwd_impl zero-fills them): any row count of a training-sized batch qualifies, not only multiples of 64
+    return tn_v8_eligible(V, J, (M + TK - 1) / TK * TK, true, nullptr, nullptr);       // (a ragged V % 256 strip rides inside the kernel or takes the 128x128 kernel: both weight their column sums)
 }
 
 int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const NtEpilogue& epi, int M, int N, int K, long lda,

@@ -964,7 +964,8 @@ static inline bool joint_input_fast(int prec, int B, int T, int U1, int de, int 
 // dtype of the logits this configuration produces / expects: 0 = f32, 1 = bf16
 int ttmi_joint_logits_dtype(int prec, int J) { return joint_fast(prec, J) ? 1 : 0; }
 
-size_t ttmi_joint_ctx_floats(int B, int T, int U1, int J) { return al4((size_t)B * T * U1 * J); }
+// (room for the lattice rows padded to 64: the exp-domain wgrad reduces over whole 64-row K-tiles, ttmi_joint_exp_padded_rows)
+size_t ttmi_joint_ctx_floats(int B, int T, int U1, int J) { return al4(((size_t)B * T * U1 + 63) / 64 * 64 * J); }
 size_t ttmi_joint_ws_floats(int B, int T, int U1, int J, int V) {
     return al4((size_t)B * T * U1 * J) + 2 * al4((size_t)B * T * J) + 2 * al4((size_t)B * U1 * J) +
            al4((size_t)J * (((size_t)V + 63) / 64 * 64));
@@ -1074,6 +1075,8 @@ int ttmi_joint_exp_fwd_supported(int B, int T, int U1, int J, int V, int prec, l
     return gemm_fast_joint_exp_ok(B * T * U1, V, J, ldv, true) ? 1 : 0;
 }
 int ttmi_joint_exp_nparts(int V) { return 4 * ((V + 255) / 256); }
+// rows the caller's P and srow16 buffers must have room for: the lattice rows rounded up to the wgrad's 64-row reduction tile
+long ttmi_joint_exp_padded_rows(int B, int T, int U1) { return ((long)B * T * U1 + 63) / 64 * 64; }
 
 int ttmi_joint_fwd_exp(const float* enc, const float* dec, const float* wf, const float* bf, const float* wp, const float* bp,
                        int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx, float* ws, void* P, long ldv,
@@ -1125,9 +1128,19 @@ static int joint_bwd_impl(const void* dlogits, long ldg, const float* enc, const
         e.rowscale = srow;                                                      // exp-domain form: ... * srow[r], and H leaves as srow[r] * H
         CK(gemm_nt_bf16(dZ, wpT16, dH16, 1, e, M, J, (int)ldg, ldg, ldg, J, st));
         if (srow) {
-            // g_wp = P^T (s . H), g_bp = P^T s: the row factor moved onto the other operand (the dgrad epilogue rewrote H in place)
+            // g_wp = P^T (s . H), g_bp = P^T s: the row factor moved onto the other operand (the dgrad epilogue rewrote H in place).
+            // The reduction runs over whole 64-row K-tiles: rows [M, Mp) of P, of s . H and of the bf16 row factors are zero-filled here
+            // (the buffers have room for them: ttmi_joint_exp_padded_rows / ttmi_joint_ctx_floats), so they add exact zeros - before
+            // round 4 a batch whose row count was not a multiple of 64 silently left the exp-domain path (train.py:32-35 trims every
+            // batch to its own maxima, so that was most batches)
             const bf16_t* Hs = reinterpret_cast<const bf16_t*>(ctx);
-            CK(gemm_tn_bf16(dZ, Hs, g_wp, V, J, M, ldg, J, J, 1, st, g_bp, FastBatch(), static_cast<const bf16_t*>(srow16)));
+            const int Mp = (M + 63) / 64 * 64;
+            if (Mp != M) {
+                CK(fill_zero(const_cast<bf16_t*>(dZ) + (size_t)M * ldg, sizeof(bf16_t) * (size_t)(Mp - M) * ldg, st));
+                CK(fill_zero(const_cast<bf16_t*>(Hs) + (size_t)M * J, sizeof(bf16_t) * (size_t)(Mp - M) * J, st));
+                CK(fill_zero(const_cast<bf16_t*>(static_cast<const bf16_t*>(srow16)) + M, sizeof(bf16_t) * (size_t)(Mp - M), st));
+            }
+            CK(gemm_tn_bf16(dZ, Hs, g_wp, V, J, Mp, ldg, J, J, 1, st, g_bp, FastBatch(), static_cast<const bf16_t*>(srow16)));
         }
         CK(fill_zero(dPD, sizeof(float) * (size_t)B * U1 * J, st));
         CK(joint_tanh_bwd(dH16, nullptr, 1, B, T, U1, J, dPE, dPD, st));

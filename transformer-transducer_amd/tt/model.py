@@ -94,6 +94,22 @@ class _ExpShift:
             self.poll()
 
 
+_warned_no_exp = set()
+
+
+def _warn_no_exp(Bc, T, U1, J, V):
+    """one warning per shape class: the exp-domain form was asked for and cannot run (the plain fused form runs instead - same loss and
+    gradients up to bf16 rounding, about 4 ms slower per C2-sized step)"""
+    key = (J, V, Bc * T * U1 < 32768)
+    if key in _warned_no_exp:
+        return
+    _warned_no_exp.add(key)
+    import warnings
+    warnings.warn("exp-domain RNN-T loss form: a chunk of %d x %d x %d lattice rows with joint sizes J=%d, V=%d is outside the persistent "
+                  "kernels' sizes (they need >= 32768 lattice rows per chunk, J a multiple of 64 and >= 256, V >= 1024); the plain fused "
+                  "joint + loss form runs instead" % (Bc, T, U1, J, V))
+
+
 class _JointLossFn(torch.autograd.Function):
     """joint network + RNN-T loss as ONE op that never holds the [B, T, U+1, V] logits: the batch is cut into chunks
     of utterances; per chunk the logits are produced (ttmi_joint_fwd), reduced to the lattice (ttmi_rnnt_loss_fwd), overwritten IN PLACE
@@ -127,7 +143,10 @@ class _JointLossFn(torch.autograd.Function):
             c1 = min(B, c0 + chunk)
             ws = ops.rnnt_workspace(c1 - c0, T, U1, enc.device)
             lab, al, ll = labels[c0:c1], act_lens[c0:c1], label_lens[c0:c1]
-            if st is not None and st.valid and ops.joint_exp_supported(c1 - c0, T, U1, J, V, prec, fwd_only=not need):
+            exp_ok = st is not None and ops.joint_exp_supported(c1 - c0, T, U1, J, V, prec, fwd_only=not need)
+            if st is not None and not exp_ok:
+                _warn_no_exp(c1 - c0, T, U1, J, V)
+            if exp_ok and st.valid:
                 # the projection stores exp(logit - shift) and row sums; the loss reads the sums and two f32 logits per row, its gradient
                 # stays factored as (row factor) x P and is consumed in that form (include/ttmi.h, "fused joint + loss fast path")
                 P, rowsum, saved, emis = ops.joint_fwd_exp(enc[c0:c1], dec[c0:c1], wf_, bf_, wp_, bp_, prec, st.cur, lab.contiguous(), blank)
@@ -342,19 +361,18 @@ class JointNet(nn.Module):
         return st
 
     def default_loss_chunk(self, B, T, U1, exp_domain=False, prec=None):
-        """utterances per chunk of `loss()`: about 2 GB of logits (the memory-saving form) or 32 GB (exp_domain: the speed form - every
-        chunk boundary costs a pipeline fill of the three big GEMMs and one more lattice launch: C2 whole batch 35.0 ms per step, two
-        halves 36.2; C5's 28 GB in one chunk 102.0 ms, in two 104.2 - on 288 GB of HBM the budget is not the constraint), adjusted to a
-        lattice-row count the joint's persistent wgrad kernel takes (a reduction length chunk * T * U1 that is a multiple of its 64-row
-        K-tile; other lengths fall to the 128x128 kernel at twice the time: C2, 8 utterances 9.5 ms per step, 16 utterances 5.3 ms)"""
+        """utterances per chunk of the fused joint + loss: about 2 GB of logits (the memory-saving form) or 32 GB (exp_domain: the speed
+        form - every chunk boundary costs a pipeline fill of the three big GEMMs and one more lattice launch: C2 whole batch 35.0 ms per
+        step, two halves 36.2; C5's 28 GB in one chunk 102.0 ms, in two 104.2 - on 288 GB of HBM the budget is not the constraint).  The
+        chunks are balanced (B = 33 at a budget of 32 gives 17 + 16, not 32 + 1: every chunk stays above the persistent kernels' minimum
+        row count).  Any row count runs the exp-domain kernels: the library pads the wgrad's reduction to its 64-row tile (round 3 needed
+        chunk * T * U1 % 64 == 0 and fell back to the plain form otherwise - half of all real batches at B = 32)."""
         prec = default_precision() if prec is None else prec
         es = 2 if ops.joint_logits_dtype(prec, self.forward_layer.out_features) is torch.bfloat16 else 4
         budget = (32 << 30) if exp_domain else (2 << 30)
         chunk = max(1, min(B, int(budget // (es * T * U1 * self.project_layer.out_features))))
-        ok = [c for c in range(1, B + 1) if (c * T * U1) % 64 == 0]
-        if ok:
-            chunk = max([c for c in ok if c <= chunk] or [min(ok)])
-        return chunk
+        n = -(-B // chunk)
+        return -(-B // n)
 
 
 class _LabelStateGraphs:

@@ -484,6 +484,12 @@ def joint_exp_supported(B, T, U1, J, V, prec, fwd_only=False):
     return bool(fn(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(V), c_int(prec), c_long(ldv)))
 
 
+def exp_padded_rows(B, T, U1):
+    f = lib().ttmi_joint_exp_padded_rows
+    f.restype = c_long
+    return int(f(c_int(B), c_int(T), c_int(U1)))
+
+
 def joint_fwd_exp(enc, dec, wf, bf, wp, bp, prec, shift=None, labels=None, blank=0):
     """-> (P bf16 [B,T,U1,V] view of a pitch-roundup(V,64) buffer = exp(logits - shift), rowsum f32 [nparts, B*T*U1], ctx, emis).
     labels (int32 [B, U1-1]) given: emis f32 [B*T*U1, 4] = the blank's and the next label's logit of every lattice row (from the GEMM's bf16
@@ -496,7 +502,11 @@ def joint_fwd_exp(enc, dec, wf, bf, wp, bp, prec, shift=None, labels=None, blank
     L_.ttmi_joint_ws_floats.restype = ctypes.c_size_t
     ctx = _f32(L_.ttmi_joint_ctx_floats(c_int(B), c_int(T), c_int(U1), c_int(J)), enc.device)
     ws = scratch(L_.ttmi_joint_ws_floats(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(V)), enc.device)
-    buf, P = padded_empty((B, T, U1, V), torch.bfloat16, enc.device)
+    # room for the lattice rows padded to the wgrad's 64-row reduction tile (ttmi_joint_bwd_exp zero-fills the pad rows: include/ttmi.h)
+    rows, ldv = B * T * U1, (V + 63) // 64 * 64
+    rows_p = exp_padded_rows(B, T, U1)
+    buf = torch.empty(rows_p * ldv, dtype=torch.bfloat16, device=enc.device)[:rows * ldv].view(B, T, U1, ldv)
+    P = buf[..., :V]
     nparts = L_.ttmi_joint_exp_nparts(c_int(V))
     rowsum = torch.empty(nparts, B * T * U1, dtype=torch.float32, device=enc.device)
     emis = None
@@ -533,7 +543,7 @@ def rnnt_loss_bwd_exp(P, labels, act_lens, label_lens, blank, workspace, grad_ou
     B, T, U1, V = P.shape
     rows = B * T * U1
     srow = torch.empty(rows, dtype=torch.float32, device=P.device)
-    srow16 = torch.empty(rows, dtype=torch.bfloat16, device=P.device)
+    srow16 = torch.empty(exp_padded_rows(B, T, U1), dtype=torch.bfloat16, device=P.device)[:rows]      # (pad rows: zero-filled by ttmi_joint_bwd_exp)
     check(lib().ttmi_rnnt_loss_bwd_exp(_p(P), c_long(row_pitch(P)), _p(labels), _p(act_lens), _p(label_lens), c_int(B), c_int(T),
                                        c_int(U1), c_int(V), c_int(blank), _p(workspace), _p(grad_out), c_int(grad_out_stride),
                                        c_float(scale), _p(srow), _p(srow16), _stream()), "ttmi_rnnt_loss_bwd_exp")
