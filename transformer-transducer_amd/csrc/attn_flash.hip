@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_rel_kernel(const FlashParams
     };
     auto sub_step = [&](int jb, int sub) {
         f32x16 s;                                                         // the position term initialises the score accumulator
-        if (p.debug & 1) {
+        if (p.debug & (1 | 128)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
         } else {
@@ -496,10 +496,12 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_rel_kernel(const FlashParams
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = bf16_to_f32(gr[(r & 3) + 8 * (r >> 2)]);
         }
+        if (!(p.debug & 32)) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ktile + T::off(32 * sub + (lane & 31), 2 * ks + hh));
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+        }
         }
         // The running maximum m is kept in log2 units (score * scale * log2 e) and is only RAISED when a sub-tile beats it by more than 8
         // (P then stays below 2^8: harmless in f32 sums and in the bf16 operand, whose rounding is relative): most sub-tiles rescale nothing.
@@ -532,7 +534,10 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_rel_kernel(const FlashParams
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
         }
         float psum = 0.f;
-        if (plain) {
+        if (p.debug & 8) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) psum += s[r];
+        } else if (plain) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -m));
@@ -548,6 +553,11 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_rel_kernel(const FlashParams
             }
         }
         l += psum;
+        if (p.debug & 16) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[0][r] += s[r];
+            return;
+        }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const bf16x8 pb = pack8(s, 8 * s2);
@@ -586,11 +596,13 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_rel_kernel(const FlashParams
     fetch_e(jbeg);
     for (int j0 = jbeg; j0 < jend; j0 += 64) {
         __syncthreads();
-        stK.store(ktile, tid);
-        stV.store(vtile, tid);
-        park_e(j0);
+        if (!(p.debug & 64)) {
+            stK.store(ktile, tid);
+            stV.store(vtile, tid);
+            park_e(j0);
+        }
         __syncthreads();
-        if (j0 + 64 < jend) {
+        if (j0 + 64 < jend && !(p.debug & 256)) {
             stK.load(kbase, p.ld_kv, j0 + 64, L - 1, tid);
             stV.load(vbase, p.ld_kv, j0 + 64, L - 1, tid);
             fetch_e(j0 + 64);
