@@ -270,3 +270,53 @@ def test_one_pass_position_gradients_vs_the_gemm_launches(H, L, K, mk, B, monkey
     assert e_dx < 1e-2 and rel_err(dx1.cpu().numpy(), dxo) < max(1.3 * rel_err(dx0.cpu().numpy(), dxo), 5e-3)
     pos = [n for n in g1 if n in ("r_emb", "r_bias", "r_w_bias")]
     print("one pass vs GEMM launches (H=%d L=%d %s): dx %.2e; " % (H, L, mk, e_dx) + ", ".join("%s %.1e (oracle %.1e / %.1e)" % ((n,) + worst[n]) for n in pos))
+
+
+@pytest.mark.parametrize("L,K,mk", [(500, 410, "none"), (257, 300, "none"), (300, 64, "causal"), (448, 410, "band"), (320, 100, "tensor"), (512, 410, "chunk"),
+                                    (193, 410, "none")])
+def test_resident_forward_kernel_is_bit_identical_to_the_tiled_one(L, K, mk, monkeypatch):
+    """flash_fwd_res_kernel (round 4: one workgroup per head, the position table resident in LDS, K / V in phases of 128 keys) against
+    flash_fwd_rel_kernel (four workgroups per head, 64-key steps): the same operands in the same accumulation order and the same order of
+    key tiles in the online softmax - outputs and every gradient that flows from them agree to the last bit; fully masked tiles that only
+    one of the two skips contribute exact zeros.  Every mask kind, both table branches (L <= K, L > K), lengths off the 64- and 128-key
+    grids; and against the float64 oracle with the file's bounds."""
+    from tt.encoder import BaseEncoder
+    from ttmi import ops
+    from ttmi.ops import MaskSpec
+    monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    H, Dh, B = 2, 64, 3
+    d = H * Dh
+    torch.manual_seed(L)
+    layer = BaseEncoder(k_len=K, n_head=H, d_model=d, d_head=Dh, d_inner=96, dropout=0.0).cuda().eval()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, L, d, generator=g).cuda()
+    cot = torch.randn(B, L, d, generator=g).cuda()
+    omask = None
+    if mk == "none":
+        mask = MaskSpec(0)
+    elif mk == "causal":
+        mask, omask = MaskSpec(1), O.look_ahead_mask(L)[:, :, None]
+    elif mk == "band":
+        mask, omask = MaskSpec(2, left=37, right=5), O.context_mask(L, 37, 5)[:, :, None]
+    elif mk == "tensor":
+        m = O.chunk_mask(L, 16, 48)
+        mask, omask = MaskSpec(3, tensor=torch.tensor(m[None].astype(np.uint8)).cuda()), m[:, :, None]
+    else:
+        m = O.chunk_mask(L, 16, 64)
+        i = np.arange(L)
+        lo, hi = np.maximum((i // 16) * 16 - 64, 0), np.minimum((i // 16 + 1) * 16 - 1, L - 1)
+        mask = MaskSpec(4, left=64 + 15, right=15, tensor=torch.tensor(np.stack([lo, hi], -1)[None].astype(np.int32)).cuda())
+        omask = m[:, :, None]
+    try:
+        ops.set_option(14, 0)
+        y0, dx0, g0 = _run(layer, x, cot, mask)
+    finally:
+        ops.set_option(14, 1)
+    y1, dx1, g1 = _run(layer, x, cot, mask)
+    assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
+    for n in g0:                                                  # (dE / dc / weight gradients are f32 atomic sums: equal up to their order)
+        assert rel_err(g1[n].cpu().numpy(), g0[n].cpu().numpy()) < 1e-5, n
+    sd = {"encoder.layers.0." + k: v.detach().cpu().numpy().astype(np.float64) for k, v in layer.state_dict().items()}
+    prm = O.layer_params(sd, "encoder.", 0)
+    want, cache = O.layer_fwd(x.cpu().numpy().astype(np.float64), prm, omask)
+    assert rel_err(y1.cpu().numpy(), want) < 3e-2

@@ -15,7 +15,7 @@ f = glob.glob(O + "/**/attn_kernel_stats.csv", recursive=True)[0]
 out = []
 for r in csv.DictReader(open(f)):
     n = r["Name"]
-    for k in ("flash_fwd_rel", "flash_bwd_rel", "attn_dqde", "flash_delta", "attn_fwd2", "attn_bwd2"):
+    for k in ("flash_fwd_res", "flash_fwd_rel", "flash_bwd_rel", "attn_dqde", "flash_delta", "attn_fwd2", "attn_bwd2"):
         if k in n:
             out.append("%s %.1f us" % (k, float(r["AverageNs"]) / 1e3))
 print("debug %4s: %s" % (dbg, ", ".join(out)), flush=True)

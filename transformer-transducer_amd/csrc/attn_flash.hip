@@ -629,6 +629,378 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_rel_kernel(const FlashParams
     }
 }
 
+// ------------------------------------------------------------------ forward, ONE workgroup per (b, h) with the position table resident in LDS
+// (round 4).  flash_fwd_rel_kernel above cuts a head into four 128-query workgroups that each stream all K / V tiles (PMC: 149 MB fetched for 49 MB of
+// q, k, v) through a loop of 64-key steps with two barriers and a one-step register prefetch per step.  Here a head is one 512-thread workgroup
+// (B*H = 256 heads = one per CU at C2 / C4, a single round): 8 waves x 64 queries (two 32-query blocks per wave, one after the other), the head's
+// whole effective table E (L rows + a zero row, <= 66 KB, fetched by LDS-DMA) and its extended bias stay in LDS for the whole kernel, K / V arrive
+// in PHASES of 128 keys (register prefetch one phase ahead, 2 barriers per phase), and inside a phase a wave runs 2 key tiles = 56 MFMAs with no
+// synchronisation at all.  Same arithmetic per (query block, key tile) as flash_fwd_rel_kernel (same operands, same accumulation order over
+// Dh; the online softmax visits the key tiles in the same order): bit-identical outputs.  Dh = 64, L <= 512.
+// Measured on the way (C2 audio layer, tools/exp_attn.sh): the tiled kernel 99 us; the first resident version 87 us, of which 30 us were its
+// skeleton (the table copied through registers in a dependent loop, q fragments reloaded at 8 block switches, row-strided output stores) and
+// 17 us the image read - the compiler had merged the sixteen 2-byte reads of a sub-tile into four ds_read_b64 at 2-byte alignment, which the
+// LDS executes several times slower than aligned ones.
+constexpr int RES_PH = 128;                                     // keys per phase
+constexpr int RES_GP = 100;                                     // image row pitch in bf16 (96 window columns + 4)
+constexpr int RES_EROWS = 513;                                  // table rows in LDS: L <= 512 rows + the zero row
+constexpr int RES_CX = 1028;                                    // extended bias: index p' - L + 512, p' - L in [-512, 515]
+constexpr int RES_LDS = RES_EROWS * 128 + 2 * RES_PH * 128 + RES_CX * 4 + 64 * 4 + 8 * 32 * RES_GP * 2;
+static_assert(RES_LDS <= 160 * 1024, "flash_fwd_res_kernel: LDS budget");
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk2(float lo, float hi) {               // ONE v_cvt_pk_bf16_f32 (pack_bf16x2 converts each half and ORs)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
+}
+// bf16 at an LDS address -> f32 in ONE aligned 2-byte read: ds_read_u16_d16_hi puts the halfword into bits [31:16] of a register that holds
+// zero, which IS the float
+__device__ __forceinline__ float lds_bf16_as_f32(const bf16_t* lds_addr) {
+    float v = 0.f;
+    asm volatile("ds_read_u16_d16_hi %0, %1" : "+v"(v) : "v"((unsigned)(size_t)lds_addr));
+    return v;
+}
+template <int MK>
+__global__ __launch_bounds__(512, 2) void flash_fwd_res_kernel(const FlashParams p) {
+    constexpr int DH = 64;
+    using T = Tile<DH>;
+    constexpr int KS = DH / 16, DT = DH / 32, GP = RES_GP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* etile = smem;                                         // [L + 1][DH], row L = zeros
+    char* ktile = smem + RES_EROWS * T::ROWB;                   // [128][DH]
+    char* vtile = ktile + RES_PH * T::ROWB;
+    float* cx = reinterpret_cast<float*>(vtile + RES_PH * T::ROWB);
+    float* u_s = cx + RES_CX;                                   // r_w_bias of this head
+    bf16_t* gs_all = reinterpret_cast<bf16_t*>(u_s + 64);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, ii = lane & 31;
+    bf16_t* gs_w = gs_all + wave * 32 * GP;                     // the wave's private image [32 queries][GP]
+    bf16_t* gs = gs_w + ii * GP;                                // this lane's query row of it
+    const int z = blockIdx.x, b = z / p.H, h = z % p.H;
+    const int L = p.L;
+    const float c2 = p.scale * 1.4426950408889634f;             // scale * log2(e)
+    const bf16_t* kbase = p.k + (long)b * L * p.ld_kv + h * DH;
+    const bf16_t* vbase = p.v + (long)b * L * p.ld_kv + h * DH;
+    const bf16_t* ebase = p.e16 + h * DH;
+    const float* cbase = p.cT + (long)h * L;
+    const bf16_t* qbase = p.qp + (long)b * L * p.ld_qp + h * DH;
+
+    // ---- K / V of phase 0 into registers; the table by LDS-DMA (1 KiB = 8 rows per wave-instruction, swizzle applied to the SOURCE chunk);
+    // its last L % 8 rows, the zero row and the bias through registers
+    u32x4_t kpre[2], vpre[2];                                   // 128 rows x 8 chunks = 1024 chunks per operand: 2 per thread
+    auto fetch_kv = [&](int j0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int c = tid + 512 * k;
+            const long off = (long)min(j0 + c / T::NCH, L - 1) * p.ld_kv + (c % T::NCH) * 8;
+            kpre[k] = *reinterpret_cast<const u32x4_t*>(kbase + off);
+            vpre[k] = *reinterpret_cast<const u32x4_t*>(vbase + off);
+        }
+    };
+    auto park_kv = [&]() {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int c = tid + 512 * k;
+            *reinterpret_cast<u32x4_t*>(ktile + T::off(c / T::NCH, c % T::NCH)) = kpre[k];
+            *reinterpret_cast<u32x4_t*>(vtile + T::off(c / T::NCH, c % T::NCH)) = vpre[k];
+        }
+    };
+    const int npiece = L / 8;
+    for (int pc = wave; pc < npiece; pc += 8) {                 // (wave-uniform piece index: the LDS destination is M0 + lane * 16)
+        const int row = pc * 8 + (lane >> 3), cdst = lane & 7;
+        const int csrc = cdst ^ ((row >> 1) & (T::NCH - 1));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ebase + (long)row * p.ld_e + csrc * 8),
+                                         (__attribute__((address_space(3))) void*)(etile + pc * 1024), 16, 0, 0);
+    }
+    fetch_kv(0);
+    if (tid < (L + 1 - npiece * 8) * T::NCH) {
+        const int row = npiece * 8 + tid / T::NCH, ch = tid % T::NCH;
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (row < L) v = *reinterpret_cast<const u32x4_t*>(ebase + (long)row * p.ld_e + ch * 8);
+        *reinterpret_cast<u32x4_t*>(etile + T::off(row, ch)) = v;
+    }
+    {
+        float cv[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {                            // cext[p'] at index p' - L + 512: c[p'] (p' < L), 0 (p' = L), c[p' - L - 1] (p' > L)
+            const int c = tid + 512 * k, pe = c - 512 + L;
+            const int src = pe < L ? pe : pe - L - 1;
+            const bool ok = pe >= 0 && pe != L && src < L;
+            cv[k] = cbase[ok ? src : 0];
+            if (!ok) cv[k] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (tid + 512 * k < RES_CX) cx[tid + 512 * k] = cv[k];
+    }
+    if (tid < DH) u_s[tid] = p.u[h * DH + tid];                 // (q + u is formed when a block starts)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the table pieces have landed (the loop's first barrier publishes them)
+    // extended-table row p' -> LDS row (L = the zero row)
+    auto erow_of = [&](int pe) -> int {
+        const int src = pe <= L ? pe : pe - L - 1;
+        return (pe >= 0 && src < L) ? src : L;
+    };
+
+    const int nph = (L + RES_PH - 1) / RES_PH;
+#pragma unroll 1
+    for (int qb = 0; qb < 2; ++qb) {
+        // ---- this pass's query block of the wave: 32 queries i0 .. i0 + 31
+        const int i0 = wave * 64 + qb * 32;
+        const bool live = i0 < L;                               // (wave-uniform)
+        const int i = i0 + ii, ic = min(i, L - 1);
+        f32x16 o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+        float mq = NEGBIG, lq = 0.f;
+        // key range this block's queries can see (wave-uniform), from the mask parameters
+        int mlo = 0, mhi = 0x7fffffff;
+        int jbeg = 0, jend = L;
+        if constexpr (MK == 1) jend = min(L, i0 + 32);
+        if constexpr (MK == 2) {
+            jbeg = max(0, i0 - p.mask_left);
+            jend = (int)min((long)L, (long)min(i0 + 31, L - 1) + p.mask_right + 1);
+        }
+        if constexpr (MK == 4) {
+            const int* r = reinterpret_cast<const int*>(p.mask) + (long)b * p.mask_sb + 2 * ic;
+            mlo = r[0];
+            mhi = r[1];
+            int lo = mlo, hi = mhi;
+#pragma unroll
+            for (int sft = 16; sft >= 1; sft >>= 1) {
+                lo = min(lo, __shfl_xor(lo, sft, 64));
+                hi = max(hi, __shfl_xor(hi, sft, 64));
+            }
+            jbeg = max(0, lo);
+            jend = (int)min((long)L, (long)hi + 1);
+        }
+        if (jend <= jbeg) { jbeg = 0; jend = L; }
+        jbeg &= ~63;
+        const bf16_t* prow = qbase + (long)ic * p.ld_qp;
+        const bf16_t* prow1 = qbase + (long)min(ic + 1, L - 1) * p.ld_qp;
+        bf16x8 qf[KS], qp[KS], qp1[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qp[ks] = *reinterpret_cast<const bf16x8*>(prow + 16 * ks + 8 * hh);
+            qp1[ks] = *reinterpret_cast<const bf16x8*>(prow1 + 16 * ks + 8 * hh);
+        }
+
+        // G^T blocks of a 64-key tile -> the wave's private image gs[query][window column]; window column 0 is p' = L - 32 - i0 + j0
+        auto cinit = [&](int pe_w, int blk, f32x16& g) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int col = 32 * blk + 8 * g4 + 4 * hh;
+                const float4 cv = *reinterpret_cast<const float4*>(cx + (pe_w + col - L + 512));     // (pe_w - L is a multiple of 32)
+                g[4 * g4] = cv.x; g[4 * g4 + 1] = cv.y; g[4 * g4 + 2] = cv.z; g[4 * g4 + 3] = cv.w;
+            }
+        };
+        auto emit = [&](int blk, const f32x16& g) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int col = 32 * blk + 8 * g4 + 4 * hh;
+                uint2 w;
+                w.x = cvt_pk2(g[4 * g4], g[4 * g4 + 1]);
+                w.y = cvt_pk2(g[4 * g4 + 2], g[4 * g4 + 3]);
+                *reinterpret_cast<uint2*>(gs + col) = w;
+            }
+        };
+        auto one_side = [&](int pe_w, const bf16x8 (&qs)[KS]) {       // the whole window on one side of p' = L: three plain chains
+            f32x16 ga, gb;
+            auto chain = [&](int blk, f32x16& g) {
+                cinit(pe_w, blk, g);
+                const int er = erow_of(pe_w + 32 * blk + ii);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 f = *reinterpret_cast<const bf16x8*>(etile + T::off(er, 2 * ks + hh));
+                    g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f, qs[ks], g, 0, 0, 0);
+                }
+            };
+            chain(0, ga);
+            chain(1, gb);
+            emit(0, ga);
+            chain(2, ga);
+            emit(1, gb);
+            emit(2, ga);
+        };
+        auto position = [&](int j0) {
+            if (p.debug & 1) return;
+            asm volatile("" ::: "memory");
+            const int pe_w = L - 32 - i0 + j0;
+            if (pe_w + 95 <= L - 1) one_side(pe_w, qp);
+            else if (pe_w >= L + 1) one_side(pe_w, qp1);
+            else {
+#pragma unroll 1
+                for (int blk = 0; blk < 3; ++blk) {
+                    const int pe0 = pe_w + 32 * blk;
+                    f32x16 g;
+                    cinit(pe_w, blk, g);
+                    const int erow = erow_of(pe0 + ii);
+                    if (pe0 + 31 <= L - 1) {
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            const bf16x8 ef = *reinterpret_cast<const bf16x8*>(etile + T::off(erow, 2 * ks + hh));
+                            g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ef, qp[ks], g, 0, 0, 0);
+                        }
+                    } else if (pe0 >= L + 1) {
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            const bf16x8 ef = *reinterpret_cast<const bf16x8*>(etile + T::off(erow, 2 * ks + hh));
+                            g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ef, qp1[ks], g, 0, 0, 0);
+                        }
+                    } else {                                   // the block that holds p' = L: rows below it take q_i, rows above it q_{i+1}
+                        const bool lower = pe0 + ii <= L - 1;
+                        bf16x8 zero;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) zero[e] = (__bf16)0.0f;
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            const bf16x8 ef = *reinterpret_cast<const bf16x8*>(etile + T::off(erow, 2 * ks + hh));
+                            g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lower ? ef : zero, qp[ks], g, 0, 0, 0);
+                            g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lower ? zero : ef, qp1[ks], g, 0, 0, 0);
+                        }
+                    }
+                    emit(blk, g);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the image is read back by asm loads the compiler does not order against these writes
+        };
+        // 32 keys jb .. jb + 31 (rows kr0 .. of the phase's K / V tiles) against the block's 32 queries; sub = which half of the 64-key window
+        auto sub_step = [&](int jb, int kr0, int sub) {
+            f32x16 s;
+            if (p.debug & (1 | 128)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            } else {
+                const bf16_t* gr = gs + 31 - ii + 32 * sub + 4 * hh;  // key jj of the tile sits at window column 31 - ii + jj
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = lds_bf16_as_f32(gr + (r & 3) + 8 * (r >> 2));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            if (!(p.debug & 32)) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ktile + T::off(kr0 + ii, 2 * ks + hh));
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+                }
+            }
+            const bool plain = MK == 0 && jb + 32 <= L;       // wave-uniform: no key of the sub-tile is masked or beyond the sequence
+            float pmax = NEGBIG;
+            if (plain) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pmax = fmaxf(pmax, s[r]);
+                pmax *= c2;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    float v = NEGBIG;
+                    const bool msk = MK == 4 ? (j < mlo || j > mhi) : is_masked<MK>(p, b, ic, j);
+                    if (j < L && !msk) v = s[r] * c2;
+                    s[r] = v;
+                    pmax = fmaxf(pmax, v);
+                }
+            }
+            pmax = fmaxf(pmax, __shfl_xor(pmax, 32, 64));
+            const float mn = pmax > mq + 8.f ? pmax : mq;
+            if (__builtin_amdgcn_ballot_w64(mn != mq)) {
+                const float alpha = __builtin_amdgcn_exp2f(mq - mn);
+                lq *= alpha;
+                mq = mn;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            }
+            float psum = 0.f;
+            if (p.debug & 8) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) psum += s[r];
+            } else if (plain) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -mq));
+                    s[r] = pr;
+                    psum += pr;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pr = s[r] > 0.5f * NEGBIG ? __builtin_amdgcn_exp2f(s[r] - mq) : 0.f;
+                    s[r] = pr;
+                    psum += pr;
+                }
+            }
+            lq += psum;
+            if (p.debug & 16) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[0][r] += s[r];
+                return;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pb = pack8(s, 8 * s2);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const bf16x8 vf = tr_frag<DH>(vtile, kr0 + 16 * s2, 32 * dt, lane);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o[dt], 0, 0, 0);
+                }
+            }
+        };
+
+#pragma unroll 1
+        for (int ph = 0; ph < nph; ++ph) {
+            __syncthreads();                                    // every wave is done with the K / V rows in LDS (very first phase: nothing)
+            park_kv();
+            __syncthreads();                                    // (very first phase: also publishes the table, the bias and u)
+            if (ph + 1 < nph) fetch_kv((ph + 1) * RES_PH);
+            else if (qb == 0) fetch_kv(0);                      // the second pass starts over at key 0
+            if (ph == 0) {                                      // q + u, formed once per block (u sits in LDS)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const float4 ua = *reinterpret_cast<const float4*>(u_s + 16 * ks + 8 * hh), ub = *reinterpret_cast<const float4*>(u_s + 16 * ks + 8 * hh + 4);
+                    const float uv[8] = {ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, ub.z, ub.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) qf[ks][e] = (__bf16)((float)qp[ks][e] + uv[e]);
+                }
+            }
+            const int pj0 = ph * RES_PH;
+            if (!live || pj0 >= jend || pj0 + RES_PH <= jbeg || (p.debug & 512)) continue;    // nothing of this phase is visible to the block
+#pragma unroll 1
+            for (int kt = 0; kt < RES_PH / 64; ++kt) {
+                const int j0 = pj0 + 64 * kt;
+                if (j0 >= jend || j0 + 64 <= jbeg) continue;
+                position(j0);
+                sub_step(j0, 64 * kt, 0);
+                if (j0 + 32 < jend) sub_step(j0 + 32, 64 * kt + 32, 1);
+            }
+        }
+
+        // ---- the block's output rows: through the wave's image (32 rows x 128 bytes, pitch 200) so that they leave as whole 128-byte rows
+        lq += __shfl_xor(lq, 32, 64);
+        if (live) {
+            const float inv = 1.f / lq;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int d = 32 * dt + 8 * g4 + 4 * hh;
+                    uint2 w;
+                    w.x = cvt_pk2(o[dt][4 * g4] * inv, o[dt][4 * g4 + 1] * inv);
+                    w.y = cvt_pk2(o[dt][4 * g4 + 2] * inv, o[dt][4 * g4 + 3] * inv);
+                    *reinterpret_cast<uint2*>(gs + d) = w;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: its DS operations execute in order)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = 8 * k + (lane >> 3), ch = lane & 7;
+                const uint2 a = *reinterpret_cast<const uint2*>(gs_w + row * GP + ch * 8), c = *reinterpret_cast<const uint2*>(gs_w + row * GP + ch * 8 + 4);
+                if (i0 + row < L) *reinterpret_cast<uint4*>(p.o + ((long)b * L + i0 + row) * p.ld_o + h * DH + ch * 8) = make_uint4(a.x, a.y, c.x, c.y);
+            }
+            if (hh == 0 && i < L) p.lse[(long)z * L + i] = mq * 0.6931471805599453f + __logf(lq);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ backward (dK, dV, dS), position term recomputed in the kernel
 // Same structure as flash_bwd_kernel below (key on the lane, dS leaves twice in bf16 for the dq / dE products); the bias tile is not read
 // from a slab but recomputed like in flash_fwd_rel_kernel: for a wave's 32 keys and a 32-query tile the p' = L-1-i+j values form one
@@ -924,7 +1296,12 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
             fetch_rows(i0 + 32);
         }
         f32x16 s, dp;
-        read_bias(i0, s);
+        if (p.debug & 8) {                                          // (timing experiments: no position term)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        } else {
+            read_bias(i0, s);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) dp[r] = 0.f;
 #pragma unroll
@@ -971,12 +1348,13 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
                 dp[r] = ds;
             }
             {
-                const unsigned v_g = jw0 < i0 ? v_lo : v_hi;
+                const unsigned v_g = (p.debug & 2) ? OOB : (jw0 < i0 ? v_lo : v_hi);
+                const unsigned v_d = (p.debug & 2) ? OOB : v_ds;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int cq = (r & 3) + 8 * (r >> 2);
                     const bf16_t d16 = f32_to_bf16(dp[r]);
-                    __builtin_amdgcn_raw_buffer_store_b16(d16, rs_ds, v_ds, s_ds + cq * ldp * 2, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16(d16, rs_ds, v_d, s_ds + cq * ldp * 2, 0);
                     __builtin_amdgcn_raw_buffer_store_b16(d16, rs_dg, v_g, s_dg + cq * (ldp - 1) * 2, 0);
                 }
             }
@@ -1002,6 +1380,11 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
                 s[r] = pr;
                 dp[r] = ds;
             }
+        }
+        if (p.debug & 16) {                                         // (timing experiments: no dV / dK products)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dv[0][r] += s[r]; dk[0][r] += dp[r]; }
+            return;
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -1232,6 +1615,11 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) 
                 s[r] = pr;
                 dp[r] = ds;
             }
+        }
+        if (p.debug & 16) {                                         // (timing experiments: no dV / dK products)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dv[0][r] += s[r]; dk[0][r] += dp[r]; }
+            return;
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -1688,12 +2076,30 @@ int relpos_slab(const bf16_t* q, long ld_q, const bf16_t* E, long ld_e, const fl
     return TTMI_OK;
 }
 
+int g_fwd_resident = 1;         // ttmi_set_option(14, 0): the round-2/3 forward kernel (four workgroups per head) for A/B measurements
+void flash_set_resident(int v) { g_fwd_resident = v; }
 int flash_attn_fwd(const FlashParams& p, hipStream_t st) {
     TTMI_REQUIRE((p.qu || p.e16) && p.k && p.v && (p.bd || p.e16) && p.o && p.lse, "flash_attn_fwd: null pointer");
     if (p.e16) {                                    // position term (and q + u) formed in the kernel: no slab, no q+u tensor
         TTMI_REQUIRE(p.qp && p.cT && p.u && flash_supported(p.Dh, p.ld_qp, p.ld_kv, p.ld_o) && p.ld_qp % 8 == 0 && p.ld_e % 8 == 0 && aligned16(p.qp) &&
                      aligned16(p.e16) && aligned16(p.k) && aligned16(p.v) && (reinterpret_cast<uintptr_t>(p.o) & 7) == 0,
                      "flash_attn_fwd: in-kernel position term needs 16-byte aligned q / E with pitches %% 8 == 0");
+        if (p.Dh == 64 && p.L >= 192 && p.L <= 512 && g_fwd_resident) {
+            // one workgroup per head, table resident in LDS (flash_fwd_res_kernel)
+#define FWDS_LAUNCH(MKV) do { \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_fwd_res_kernel<MKV>), hipFuncAttributeMaxDynamicSharedMemorySize, RES_LDS) != hipSuccess) { ttmi_set_error("flash_attn_fwd: LDS attribute"); return TTMI_EINVAL; } \
+            hipLaunchKernelGGL((flash_fwd_res_kernel<MKV>), dim3(p.B * p.H), dim3(512), RES_LDS, st, p); } while (0)
+            switch (p.mask_kind) {
+                case 1: FWDS_LAUNCH(1); break;
+                case 2: FWDS_LAUNCH(2); break;
+                case 3: FWDS_LAUNCH(3); break;
+                case 4: FWDS_LAUNCH(4); break;
+                default: FWDS_LAUNCH(0); break;
+            }
+#undef FWDS_LAUNCH
+            TTMI_LAUNCH_CHECK("flash_fwd_res_kernel");
+            return TTMI_OK;
+        }
         dim3 grid(cdiv(p.L, 128), p.B * p.H);
         TTMI_REQUIRE(grid.y <= 65535, "flash_attn_fwd: B*H too large");
 #define FWDR_LAUNCH(MKV) do { \
