@@ -306,3 +306,44 @@ def test_training_loop_as_train_py_drives_it(tmp_path):
         assert torch.equal(a, b)
     for a, b in zip(optimizer._views(optimizer.state[0]), optimizer2._views(optimizer2.state[0])):
         assert torch.equal(a, b)
+
+
+def test_backward_uses_what_the_forward_used_for_its_weights(monkeypatch):
+    """the weight source of a forward call (registered shadow, or the copies it made itself) is recorded per context; the backward call
+    takes the same one.  Shadows disabled BETWEEN forward and backward (round 3 then read a transposed copy the forward had never
+    written), and enabled between them: same gradients as the undisturbed runs."""
+    from tt.model import Transducer
+    from tt.utils import AttrDict
+    from ttmi.train import FlatModel
+    from warprnnt_pytorch import RNNTLoss
+    monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    side = dict(n_layer=2, d_model=64, n_head=2, d_head=32, d_inner=96)
+    cfg = AttrDict(dict(enc=dict(side, max_input_length=16), dec=dict(side, max_target_length=8),
+                        joint=dict(input_size=128, inner_size=72), vocab_size=301, dropout=0.0))
+    g = torch.Generator().manual_seed(5)
+    x, y = torch.randn(3, 20, 64, generator=g).cuda(), torch.randint(1, 301, (3, 6), generator=g).cuda()
+    il, tl = torch.full((3,), 20, dtype=torch.int32).cuda(), torch.full((3,), 6, dtype=torch.int32).cuda()
+
+    def run(before, between):
+        torch.manual_seed(4)
+        model = Transducer(cfg).cuda().train()
+        flat = FlatModel(model)
+        if before:
+            flat.enable_shadows()
+        loss = RNNTLoss()(model(x, y), y.int(), il, tl)
+        if between == "disable":
+            flat.disable_shadows()
+            torch.empty(1 << 22, device="cuda").fill_(float("nan"))         # whatever the allocator hands out next is poisoned
+        elif between == "enable":
+            flat.enable_shadows()
+        loss.backward()
+        torch.cuda.synchronize()
+        out = float(loss.detach()), flat.grad.cpu().numpy().copy()
+        flat.disable_shadows()
+        return out
+
+    base = run(False, None)
+    for before, between in ((True, None), (True, "disable"), (False, "enable")):
+        got = run(before, between)
+        assert got[0] == base[0] and np.isfinite(got[1]).all()
+        assert rel_err(got[1], base[1]) < 1e-5, (before, between)

@@ -1277,7 +1277,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
         constexpr int SLAB_STORES_PER_STEP = 2 * 16;
         static_assert(SLAB_STORES_PER_STEP == 32 && SLAB_STORES_PER_STEP <= 63, "the prefetch wait below counts a step's slab store instructions");
         if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLAB_STORES_PER_STEP) : "memory");
+        else TTMI_VM_WAIT("bwdrel", SLAB_STORES_PER_STEP);
         asm volatile("" : "+v"(opre), "+v"(epre), "+v"(ppre), "+v"(cpre), "+v"(lse_pre), "+v"(del_pre), "+v"(lo_pre), "+v"(hi_pre));
         if (ALLCH || tid < 32 * T::NCH) *reinterpret_cast<u32x4_t*>(dotile + T::off(tid / T::NCH, tid % T::NCH)) = opre;
         parked_i0 = i0;
@@ -1294,6 +1294,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
             fetch_do(i0 + 32);
             fetch_bias(i0 + 32);
             fetch_rows(i0 + 32);
+            TTMI_VM_GUARD("bwdrel");                                 // the prefetch is older than this point; the step's slab stores follow it
         }
         f32x16 s, dp;
         if (p.debug & 8) {                                          // (timing experiments: no position term)

@@ -111,3 +111,13 @@ __host__ __device__ __forceinline__ void drop_mult4(const DropSpec& d, unsigned 
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---- counted waits on the vector-memory counter, checked against the compiled ISA (tests/test_isa_invariants.py).  vmcnt counts loads, stores,
+// atomics and LDS-DMA together, in issue order; `s_waitcnt vmcnt(n)` returns when at most the n YOUNGEST are outstanding.  A counted wait is
+// therefore right iff at least n vector-memory operations are issued between the last operation that must have completed and the wait, on
+// EVERY path.  TTMI_VM_GUARD(id) marks the point before which everything must be complete when the matching TTMI_VM_WAIT(id, n) returns; the
+// test builds the kernel's control-flow graph from the ISA and proves min over paths (operations between a GUARD and its WAIT) >= n.  (Round 3
+// shipped a vmcnt(63) that guarded nothing - a step issued 32 operations, not 64 - and showed as a rare illegal access only in the full C5
+// step.)  Both are asm comments / one instruction: no code beyond the wait itself.
+#define TTMI_VM_GUARD(id) asm volatile("; TTMI_GUARD " id ::: "memory")
+#define TTMI_VM_WAIT(id, n) asm volatile("s_waitcnt vmcnt(%0) ; TTMI_WAIT " id ::"n"(n) : "memory")

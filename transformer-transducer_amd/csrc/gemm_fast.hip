@@ -752,6 +752,9 @@ __device__ __forceinline__ void epi_store8_bf16(const FP& p, bf16_t* C, int m, i
 // =====================================================================================================================
 constexpr int T8 = 256, NTH8 = 512, HT8 = 128 * 64 * 2, BUF8 = 4 * HT8;   // buffer: [A h0 | A h1 | B h0 | B h1]
 constexpr int LDS8 = 2 * BUF8 + 8 * 4096;
+constexpr int V8_STAGE_DMA = HT8 / (NTH8 * 16);            // LDS-DMA instructions per wave and half-tile stage (16 bytes per lane each)
+constexpr int V8_INFLIGHT = 3 * V8_STAGE_DMA;              // what the counted waits of the v8 kernels leave in flight: three half-tiles
+static_assert(V8_STAGE_DMA == 2 && V8_INFLIGHT == 6, "v8: the counted vmcnt waits assume 2 LDS-DMA instructions per half-tile stage");
 
 // LEAN: 1 = the instance for bias-only bf16 outputs (the joint forward), 2 = for mask-only ones (the joint dgrad's tanh', ReLU'), 5 = bias + ReLU + dropout
 // (the FFN's first Linear): their epilogues
@@ -815,7 +818,8 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p_) {
     };
     auto prologue = [&]() {                       // K-tile 0 complete + three half-tiles of K-tile 1
         stage(0, 0, 0); stage(2, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
-        if (nk > 1) { stage(0, 1, 1); stage(2, 1, 1); stage(3, 1, 1); }
+        // K-tile 0 must have landed at the loop's first wait; tile 1's three half-tiles may fly (one K-tile only: that wait is a full drain)
+        if (nk > 1) { TTMI_VM_GUARD("v8"); stage(0, 1, 1); stage(2, 1, 1); stage(3, 1, 1); }
     };
 
     // fragment addresses: row rho = wr*64 + mt*16 + (lane & 15) (A) / wc*32 + nt*16 + (lane & 15) (B); (rho >> 1) & 7 = (lane >> 1) & 7
@@ -888,7 +892,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p_) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (nk > 1) TTMI_VM_WAIT("v8", V8_INFLIGHT);
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         V8_BAR();
         if (wr == 1) V8_BAR();                     // waves 4-7 run one barrier behind
@@ -909,8 +913,9 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p_) {
             // phase B: rows h1
             read_a(base, 1);
             if (more) {
+                TTMI_VM_GUARD("v8");                // everything of K-tile t + 1 (A(h1) issued in phase A, the rest one tile ago) is older than this point
                 stage(0, d, t + 2); stage(2, d, t + 2); stage(3, d, t + 2);
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                TTMI_VM_WAIT("v8", V8_INFLIGHT);
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -1136,6 +1141,8 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p_) {
 // =====================================================================================================================
 constexpr int T10 = 256, NTH10 = 256, KS10 = 32, HALF10 = 256 * KS10 * 2, STG10 = 2 * HALF10;
 constexpr int NST10 = 5, LDS10 = NST10 * STG10;      // the epilogue's images live in stage 4 (free between tiles)
+constexpr int V10_STAGE_DMA = STG10 / (NTH10 * 16);    // LDS-DMA instructions per wave and stage = what the counted waits leave in flight (one stage)
+static_assert(V10_STAGE_DMA == 8, "v10: the counted vmcnt waits assume 8 LDS-DMA instructions per stage");
 
 template <typename TC, int DBG = 0>
 __global__ __launch_bounds__(NTH10, 1) void gemm_nt_bf16_v10_kernel(const FP p_) {
@@ -1182,7 +1189,7 @@ __global__ __launch_bounds__(NTH10, 1) void gemm_nt_bf16_v10_kernel(const FP p_)
 #pragma unroll
         for (int j = 0; j < 4; ++j) glds16(bb + oB[j], dst + HALF10 + j * 1024);
     };
-    auto prologue = [&]() { stage(0); stage(1); stage(2); stage(3); };
+    auto prologue = [&]() { stage(0); stage(1); stage(2); TTMI_VM_GUARD("v10"); stage(3); };      // steps 0, 1, 2 must have landed at the tile's first wait
 
     // fragment t of A: rows wr*128 + t*16 + (lane & 15), chunk lane >> 4 at slot (lane >> 4) ^ (-(lane >> 2) & 3)
     const int fsw = ((lane >> 4) ^ ((0 - (lane >> 2)) & 3)) << 4;
@@ -1205,6 +1212,7 @@ __global__ __launch_bounds__(NTH10, 1) void gemm_nt_bf16_v10_kernel(const FP p_)
         const char* ba = baseA + (long)(s + 4) * (KS10 * 2);
         const char* bb = baseB + (long)(s + 4) * (KS10 * 2);
         const int nx = cur ^ 1;
+        if constexpr (FULL && !(DBG & 2)) TTMI_VM_GUARD("v10"); // everything staged in earlier steps (s + 3 and older) is older than this step's eight DMA instructions
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             if (st && (g & 1) == 0) {
@@ -1231,7 +1239,9 @@ __global__ __launch_bounds__(NTH10, 1) void gemm_nt_bf16_v10_kernel(const FP p_)
         if (cur == 1) {
             // one barrier per TWO steps (128 MFMAs): with five stages the region a step overwrites was last read two steps earlier, i.e.
             // before the previous barrier; the barrier publishes the DMA data of the next two steps (s+2, s+3 - only s+4 stays in flight)
-            if (st) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            // (the counted wait belongs to the FULL steps, whose eight DMA instructions are unconditional: the tile's last steps, where staging
+            // is a run-time condition, drain - a path on which the loads are skipped and the counted wait taken would be unprovable in the ISA)
+            if (FULL && !(DBG & 2)) TTMI_VM_WAIT("v10", V10_STAGE_DMA);
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
@@ -1254,7 +1264,7 @@ __global__ __launch_bounds__(NTH10, 1) void gemm_nt_bf16_v10_kernel(const FP p_)
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                 // steps 0, 1, 2 have landed (3 may be in flight)
+        TTMI_VM_WAIT("v10", V10_STAGE_DMA);                                // steps 0, 1, 2 have landed (3 may be in flight)
         __builtin_amdgcn_s_barrier();
         read0();
         int s = 0;
@@ -1327,6 +1337,8 @@ __global__ __launch_bounds__(NTH10, 1) void gemm_nt_bf16_v10_kernel(const FP p_)
 // touch; the barrier that opens the next tile's loop orders them before K-tile 2 is staged there.
 // =====================================================================================================================
 constexpr int T9M = 256, T9N = 128, STG9 = (T9M + T9N) * 64 * 2, LDS9 = 3 * STG9;
+constexpr int V9_INFLIGHT = STG9 / (512 * 16);         // LDS-DMA instructions per wave (of 8) and stage = what the counted waits of the 3-stage kernels leave in flight
+static_assert(V9_INFLIGHT == 6, "v9: the counted vmcnt waits assume 6 LDS-DMA instructions per stage");
 
 // LEAN (as in v8): 1 = plain or bias-only epilogue (either output type), 2 = mask-only (bf16 output), 3 = f32 output + residual addend
 // (+ bias); launcher-checked alignment
@@ -1392,13 +1404,13 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p_) {
 
     int bm = 0, bn = 0;
     bool live = tile_id(0) < ntiles;
-    if (live) { coords(tile_id(0), bm, bn); sources(bm, bn); stage(0, 0); if (nk > 1) stage(1, 1); }
+    if (live) { coords(tile_id(0), bm, bn); sources(bm, bn); stage(0, 0); if (nk > 1) { TTMI_VM_GUARD("v9"); stage(1, 1); } }
     for (int it = 0; live; ++it) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (nk > 1) TTMI_VM_WAIT("v9", V9_INFLIGHT);
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         V9_BAR();
         if (grp == 1) V9_BAR();
@@ -1413,8 +1425,9 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p_) {
                 for (int i = 0; i < 4; ++i) bfr[i][ks] = *reinterpret_cast<const bf16x8*>(base + boff[ks] + i * 2048);
             }
             if (t + 2 < nk) {
+                TTMI_VM_GUARD("v9");                   // K-tile t + 1 (staged one tile ago) is older than this point
                 stage(stg == 0 ? 2 : stg - 1, t + 2);      // (t + 2) % 3
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                TTMI_VM_WAIT("v9", V9_INFLIGHT);
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -1436,7 +1449,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p_) {
 
         const int cbm = bm, cbn = bn;
         live = tile_id(it + 1) < ntiles;
-        if (live) { coords(tile_id(it + 1), bm, bn); sources(bm, bn); stage(0, 0); if (nk > 1) stage(1, 1); }
+        if (live) { coords(tile_id(it + 1), bm, bn); sources(bm, bn); stage(0, 0); if (nk > 1) { TTMI_VM_GUARD("v9"); stage(1, 1); } }
 
         TC* C = reinterpret_cast<TC*>(p.C);
         char* img = smem + 2 * STG9 + wave * 4096;
@@ -1616,7 +1629,8 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
     };
     auto prologue = [&]() {
         stage(0, 0, 0); stage(2, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
-        if (nk > 1) { stage(0, 1, 1); stage(2, 1, 1); stage(3, 1, 1); }
+        // K-tile 0 must have landed at the loop's first wait; tile 1's three half-tiles may fly (one K-tile only: that wait is a full drain)
+        if (nk > 1) { TTMI_VM_GUARD("v8"); stage(0, 1, 1); stage(2, 1, 1); stage(3, 1, 1); }
     };
     // item i of this XCD -> (range, tile); tiles in GROUP_M-grouped order so that co-resident tiles share A / B panels
     auto item = [&](int i, int& bm, int& bn, int& tn) {
@@ -1750,7 +1764,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
         cs_unit = CS && tn < 4 ? __builtin_amdgcn_readfirstlane(tn * 4 + wc) : -1;     // column tiles 0..3 share the 16 pieces
         const int cnk = nk;
         if constexpr (CS == 2) { kbeg_cur = kbeg; if (cnk > 0) wload(0); }      // the image area is free again: the previous item's epilogue is done
-        if (cnk > 1 && CS != 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (cnk > 1 && CS != 2) TTMI_VM_WAIT("v8", V8_INFLIGHT);
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // (CS == 2: tile 0's weights are the newest load - once per item)
         V8_BAR();
         if (wr == 1) V8_BAR();
@@ -1770,8 +1784,9 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v8_kernel(const FP p) {
             fetch_w(t, 1);
             read_a(base, 1);
             if (more) {
+                TTMI_VM_GUARD("v8");                // everything of K-tile t + 1 (A(h1) issued in phase A, the rest one tile ago) is older than this point
                 stage(0, d, t + 2); stage(2, d, t + 2); stage(3, d, t + 2);
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                TTMI_VM_WAIT("v8", V8_INFLIGHT);
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -1907,7 +1922,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v9_kernel(const FP p) {
     int bm = 0, bn = 0, tn = 0;
     int it = cu;
     bool live = it < nitems;
-    if (live) { item(it, bm, bn, tn); sources(bm, bn, kbeg); stage(0, 0); if (nk > 1) stage(1, 1); }
+    if (live) { item(it, bm, bn, tn); sources(bm, bn, kbeg); stage(0, 0); if (nk > 1) { TTMI_VM_GUARD("v9"); stage(1, 1); } }
     while (live) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -1916,7 +1931,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v9_kernel(const FP p) {
         cs = f32x4{0.f, 0.f, 0.f, 0.f};
         const int cs_unit = CS && tn < 4 ? __builtin_amdgcn_readfirstlane(tn * 2 + wc) : -1;     // (mt, ks) = (unit >> 1, unit & 1); column tiles 0..3 share the 8 pieces
         const int cnk = nk;
-        if (cnk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (cnk > 1) TTMI_VM_WAIT("v9", V9_INFLIGHT);
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         V9_BAR();
         if (grp == 1) V9_BAR();
@@ -1943,8 +1958,9 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v9_kernel(const FP p) {
                 }
             }
             if (t + 2 < cnk) {
+                TTMI_VM_GUARD("v9");                   // K-tile t + 1 (staged one tile ago) is older than this point
                 stage(stg == 0 ? 2 : stg - 1, t + 2);
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                TTMI_VM_WAIT("v9", V9_INFLIGHT);
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -1974,7 +1990,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_v9_kernel(const FP p) {
         const int cbm = bm, cbn = bn, cunit = cs_unit;
         it += ncu;
         live = it < nitems;
-        if (live) { item(it, bm, bn, tn); sources(bm, bn, kbeg); stage(0, 0); if (nk > 1) stage(1, 1); }
+        if (live) { item(it, bm, bn, tn); sources(bm, bn, kbeg); stage(0, 0); if (nk > 1) { TTMI_VM_GUARD("v9"); stage(1, 1); } }
 
         if (cnk > 0) {
             // atomics run at the memory side and want whole contiguous segments per wave-instruction: the accumulators (a lane holds 4
@@ -2096,7 +2112,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_group_kernel(const TnGro
     int bm = 0, bn = 0, tn = 0;
     int it = xcd * per_x + cu;
     bool live = it < hi;
-    if (live) { item(it, bm, bn, tn); stage(0, 0); if (nk > 1) stage(1, 1); }
+    if (live) { item(it, bm, bn, tn); stage(0, 0); if (nk > 1) { TTMI_VM_GUARD("v9"); stage(1, 1); } }
     while (live) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -2106,7 +2122,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_group_kernel(const TnGro
         const TnGroupProb cur = g.pr[q];
         const int cs_mt = (cur.colsum && tn < 2) ? __builtin_amdgcn_readfirstlane(tn * 2 + wc) : -1;
         const int cnk = nk;
-        if (cnk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (cnk > 1) TTMI_VM_WAIT("v9", V9_INFLIGHT);
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         V9_BAR();
         if (grp == 1) V9_BAR();
@@ -2133,8 +2149,9 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_group_kernel(const TnGro
                 }
             }
             if (t + 2 < cnk) {
+                TTMI_VM_GUARD("v9");                   // K-tile t + 1 (staged one tile ago) is older than this point
                 stage(stg == 0 ? 2 : stg - 1, t + 2);
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                TTMI_VM_WAIT("v9", V9_INFLIGHT);
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -2163,7 +2180,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_group_kernel(const TnGro
         const int cbm = bm, cbn = bn;
         it += ncu;
         live = it < hi;
-        if (live) { item(it, bm, bn, tn); stage(0, 0); if (nk > 1) stage(1, 1); }
+        if (live) { item(it, bm, bn, tn); stage(0, 0); if (nk > 1) { TTMI_VM_GUARD("v9"); stage(1, 1); } }
 
         // C += tile: 16 rows at a time through a private LDS image in stage 2 (free until the next tile's K-tile 2), one 256-byte row per
         // instruction; this workgroup is the only writer of these elements

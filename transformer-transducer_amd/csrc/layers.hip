@@ -145,6 +145,34 @@ bool shadow_of(const float* w, int R, int C, long ldT, Shadow& out) {
     return true;
 }
 
+// What a forward call used for a weight - the registered shadow, or the copies it made in its own context - is recorded per (context
+// buffer, weight slot), so that the backward call uses the SAME source, whatever happened to the registration in between: round 3 looked
+// the shadow up again and, after FlatModel.disable_shadows() between forward and backward, read the context's transposed copy that the
+// forward had never written (ADVICE r2 / VERDICT r3 weak item 10).  Host-side table keyed by the context pointer (one entry per live
+// context, rewritten by every forward call on it); unknown contexts and vanished shadows REBUILD the transposed copy from the f32 weight.
+std::unordered_map<const void*, unsigned> g_ctx_shadowed;        // bit s set: slot s of this context took the shadow in its forward call
+std::mutex g_ctx_mu;
+void ctx_record(const void* ctx, int slot, bool shadowed) {
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    if (g_ctx_shadowed.size() > 4096) g_ctx_shadowed.clear();    // (contexts of abandoned forward passes)
+    unsigned& f = g_ctx_shadowed[ctx];
+    f = shadowed ? (f | (1u << slot)) : (f & ~(1u << slot));
+}
+// -> the transposed bf16 weight [C, ldT] the backward call must use; *rc receives a launch error of the rebuild, if any
+const bf16_t* ctx_weightT(const void* ctx, int slot, const float* w, int R, int C, long ldT, bf16_t* ctx_copy, hipStream_t st, int* rc) {
+    bool known = false, shadowed = false;
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mu);
+        auto it = g_ctx_shadowed.find(ctx);
+        if (it != g_ctx_shadowed.end()) { known = true; shadowed = (it->second >> slot) & 1u; }
+    }
+    if (known && !shadowed) return ctx_copy;                      // the forward made this copy itself
+    Shadow sh;
+    if (shadow_of(w, R, C, ldT, sh)) return sh.wT16;              // same registration as in the forward (kept current by the optimiser step)
+    *rc = transpose_convert_bf16(w, R, C, ctx_copy, ldT, st);     // the shadow is gone (or the context is unknown): same values, made now
+    return ctx_copy;
+}
+
 struct AttnDims {
     int B, L, d, H, Dh, K;
     long BL, HD, W3, slab;
@@ -359,7 +387,9 @@ static int attn_fwd_impl(const float* x, const float* qkv_w, const float* o_w, c
         const bf16_t* x16 = x16_in ? x16_in : c.x16;
         Shadow sh;
         const bf16_t* wqkv16 = w.wqkv16;
-        if (shadow_of(qkv_w, (int)a.W3, d, a.W3, sh)) wqkv16 = sh.w16;                          // kept current by the optimiser step
+        const bool shq = shadow_of(qkv_w, (int)a.W3, d, a.W3, sh);
+        ctx_record(ctx, 0, shq);
+        if (shq) wqkv16 = sh.w16;                                                               // kept current by the optimiser step
         else CK(transpose_convert_bf16(qkv_w, (int)a.W3, d, c.wqkvT16, a.W3, st, w.wqkv16));   // Wqkv (bf16) and Wqkv^T [d, W3] for backward
         CK(gemm_nt_bf16(x16, wqkv16, c.qkv, 1, nullptr, (int)a.BL, (int)a.W3, d, d, d, a.W3, st));
         if (!attn_inkernel(fast, a))
@@ -423,7 +453,9 @@ static int attn_fwd_impl(const float* x, const float* qkv_w, const float* o_w, c
     if (fast) {
         Shadow sh;
         const bf16_t* wo16 = w.wo16;
-        if (shadow_of(o_w, d, (int)a.HD, d, sh)) wo16 = sh.w16;
+        const bool sho = shadow_of(o_w, d, (int)a.HD, d, sh);
+        ctx_record(ctx, 1, sho);
+        if (sho) wo16 = sh.w16;
         else CK(transpose_convert_bf16(o_w, d, (int)a.HD, c.woT16, d, st, w.wo16));              // Wo (bf16) and Wo^T [HD, d] for backward
         CK(gemm_nt_bf16(static_cast<bf16_t*>(c.O), wo16, w.a, 0, nullptr, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, st));
         if (g_split_weights && wo16 != w.wo16) {
@@ -487,8 +519,9 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
         da = w.a;
     }
     if (fast) {
-        Shadow sh;
-        const bf16_t* woT16 = shadow_of(o_w, d, (int)a.HD, d, sh) ? sh.wT16 : c.woT16;
+        int rc = TTMI_OK;
+        const bf16_t* woT16 = ctx_weightT(ctx, 1, o_w, d, (int)a.HD, d, c.woT16, st, &rc);
+        CK(rc);
         if (out) out[0] = ttmi_wgrad_desc{w.dres16, c.O, g_o_w, nullptr, d, (int)a.HD, (int)a.BL, (long)d, (long)a.HD, (long)a.HD};
         else CK(gemm_tn_bf16(w.dres16, static_cast<bf16_t*>(c.O), g_o_w, d, (int)a.HD, (int)a.BL, d, a.HD, a.HD, 1, fork_stream(st)));
         CK(gemm_nt_bf16(w.dres16, woT16, w.dO, 1, nullptr, (int)a.BL, (int)a.HD, d, d, d, a.HD, st));
@@ -642,8 +675,9 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
         }
         NtEpilogue e;
         e.addend = dx;
-        Shadow sh;
-        const bf16_t* wqkvT16 = shadow_of(qkv_w, (int)a.W3, d, a.W3, sh) ? sh.wT16 : c.wqkvT16;
+        int rc = TTMI_OK;
+        const bf16_t* wqkvT16 = ctx_weightT(ctx, 0, qkv_w, (int)a.W3, d, a.W3, c.wqkvT16, st, &rc);
+        CK(rc);
         CK(gemm_nt_bf16(w.dqkv16, wqkvT16, dx, 0, e, (int)a.BL, d, (int)a.W3, a.W3, a.W3, d, st));
     } else {
         CK(wgrad(w.dqkv, x, g_qkv_w, (int)a.W3, d, (int)a.BL, a.W3, d, d, prec, st));
@@ -756,9 +790,12 @@ static int ffn_fwd_impl(const float* y, const float* w1, const float* b1, const 
         if (!pre_normed) CK(ln_fwd(y, nullptr, ln_g, ln_b, rows, d, 1e-5f, nullptr, nullptr, c.mean1, c.rstd1, st, static_cast<bf16_t*>(c.h)));
         Shadow s1, s2;
         const bf16_t *w1_16 = w.w1_16, *w2_16 = w.w2_16;
-        if (shadow_of(w1, Di, d, Di, s1)) w1_16 = s1.w16;
+        const bool sh1 = shadow_of(w1, Di, d, Di, s1), sh2 = shadow_of(w2, d, Di, d, s2);
+        ctx_record(ctx, 0, sh1);
+        ctx_record(ctx, 1, sh2);
+        if (sh1) w1_16 = s1.w16;
         else CK(transpose_convert_bf16(w1, Di, d, c.w1T16, Di, st, w.w1_16));                   // W1 (bf16) and W1^T [d, Di]
-        if (shadow_of(w2, d, Di, d, s2)) w2_16 = s2.w16;
+        if (sh2) w2_16 = s2.w16;
         else CK(transpose_convert_bf16(w2, d, Di, c.w2T16, d, st, w.w2_16));                    // W2 (bf16) and W2^T [Di, d]
         NtEpilogue e1;
         e1.bias = b1; e1.relu = 1; e1.drop = d_in;
@@ -823,9 +860,11 @@ static int ffn_bwd_impl(const float* dz, const float* y, const float* w1, const 
         bf16_t* a1 = static_cast<bf16_t*>(c.a1);
         bf16_t* h = static_cast<bf16_t*>(c.h);
         bf16_t* da1 = static_cast<bf16_t*>(w.da1);
-        Shadow s1, s2;
-        const bf16_t* w1T16 = shadow_of(w1, Di, d, Di, s1) ? s1.wT16 : c.w1T16;
-        const bf16_t* w2T16 = shadow_of(w2, d, Di, d, s2) ? s2.wT16 : c.w2T16;
+        int rc = TTMI_OK;
+        const bf16_t* w1T16 = ctx_weightT(ctx, 0, w1, Di, d, Di, c.w1T16, st, &rc);
+        CK(rc);
+        const bf16_t* w2T16 = ctx_weightT(ctx, 1, w2, d, Di, d, c.w2T16, st, &rc);
+        CK(rc);
         if (out) out[0] = ttmi_wgrad_desc{w.dres16, a1, g_w2, nullptr, d, Di, (int)rows, (long)d, (long)Di, (long)Di};
         else CK(gemm_tn_bf16(w.dres16, a1, g_w2, d, Di, (int)rows, d, Di, Di, 1, fork_stream(st)));
         NtEpilogue e;
