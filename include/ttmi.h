@@ -197,6 +197,17 @@ int ttmi_layer_bwd(const float* dz, const float* x, const void* x16_in, const fl
 /* ---- greedy decoding support (Transducer.decode, tt/model.py:70-90): logits rows = consecutive frames against one label
  * state; *out (device u64) = (first row whose argmax != blank) << 32 | symbol, or n << 32 if all rows are blank. */
 int ttmi_greedy_scan(const void* logits, int dtype, long ld, int n, int V, int blank, unsigned long long* out, void* stream);
+/* Batched greedy decoding (tt/model.py:92-108 recognize -> decode for every utterance), all utterances of a batch in lockstep over SYMBOL steps:
+ * after step s every utterance still decoding holds exactly s + 1 tokens, so one label-encoder call of length s + 1 serves the batch exactly.
+ * ttmi_greedy_scan_batch: logits [B, n, V] (row pitch ld) = the joint of frames t[b] .. t[b] + n - 1 of every utterance against its own label state;
+ * key[b] (device u64, n << 32 before the call) = min over the utterance's frames that exist (t[b] + r < T_len[b]) and whose argmax is not `blank`
+ * of (r << 32 | symbol); utterances with need[b] == 0 are left alone.  ttmi_greedy_advance consumes key: symbol found -> hist[b][n_hist] =
+ * symbol, t[b] += r + 1, count[b] += 1, need[b] = 0; none -> t[b] += n, and need[b] = 0, done[b] = 1 once t[b] >= T_len[b]; key is reset;
+ * flags[0] = utterances that still need a symbol in this step, flags[1] = utterances not finished (one 8-byte read per scan for the host). */
+int ttmi_greedy_scan_batch(const void* logits, int dtype, long ld, int B, int n, int V, int blank, const int* t, const int* T_len,
+                           const int* need, unsigned long long* key, void* stream);
+int ttmi_greedy_advance(unsigned long long* key, int B, int n, int n_hist, long* hist, long ld_hist, int* t, const int* T_len, int* need,
+                        int* done, int* count, int* flags, void* stream);
 
 /* ---- feature front-end on the GPU: replaces the data loader's per-utterance numpy code.
  * ttmi_logmel: get_feature / get_feature2 (tt/utils.py:182-207: librosa.feature.melspectrogram(y, sr, n_fft=512, hop_length=160, n_mels), then

@@ -357,3 +357,30 @@ def test_beam_search_identical_tokens(name):
     hyp = model.recognize_beam_search(torch.tensor(g[name + "/inputs"][:, :48], device="cuda"), torch.tensor(g[name + "/beam_lens"]))
     for b, h in enumerate(hyp):
         assert h == g["%s/beam_tokens%d" % (name, b)].tolist(), b
+
+
+@pytest.mark.parametrize("graphs", [True, False])
+def test_batched_greedy_decode_equals_one_utterance_at_a_time(graphs):
+    """Transducer.decode_batch (round 4: the whole batch in lockstep over symbol steps - one joint call per scanned block, one label-encoder
+    call per step, positions / histories / flags on the device) returns what decode() returns utterance by utterance: ragged lengths, an
+    utterance that never emits, one of length 1, histories longer than the label encoder's table, every block size"""
+    from tt.model import Transducer
+    from tt.utils import AttrDict
+    side = dict(n_layer=2, d_model=64, n_head=2, d_head=32, d_inner=96)
+    cfg = AttrDict(dict(enc=dict(side, max_input_length=16), dec=dict(side, max_target_length=8),
+                        joint=dict(input_size=128, inner_size=48), vocab_size=29, dropout=0.0, decode_graphs=graphs))
+    torch.manual_seed(9)
+    model = Transducer(cfg).cuda().eval()
+    with torch.no_grad():
+        model.joint.project_layer.bias[0] += 0.9
+    x = torch.randn(6, 120, 64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    x[3] = 0.0
+    lens = [120, 77, 1, 120, 33, 100]
+    with torch.no_grad():
+        enc = model.encoder(x)
+        enc[3] = enc[3] * 0.0 - 50.0 * model.joint.forward_layer.weight[:, :64].sum(0).sign()     # utterance 3: blank everywhere
+        want = [model.decode(enc[b], lens[b]) for b in range(6)]
+        assert max(len(w) for w in want) > 8 and min(len(w) for w in want) <= 1
+        for block in (1, 5, 64, 300):
+            assert model.decode_batch(enc, lens, block=block) == want, block
+        assert model.decode_batch(enc[:1], lens[:1]) == want[:1]

@@ -56,16 +56,30 @@ def run(utts=8, T=500, emit_rate=0.1, precision="fp32", block=64):
         torch.cuda.synchronize()
         t_enc = time.perf_counter() - t0
         t0 = time.perf_counter()
-        hyps = [model.decode(enc_states[b], lens[b], block=args.block) for b in range(args.utts)]
+        hyps1 = [model.decode(enc_states[b], lens[b], block=args.block) for b in range(args.utts)]
+        torch.cuda.synchronize()
+        t_dec1 = time.perf_counter() - t0
+        # the batched form (what recognize() runs): every utterance in lockstep over symbol steps, one label-encoder call per step
+        blocks = [0]
+        from ttmi import ops
+        orig = ops.greedy_advance
+        ops.greedy_advance = lambda *a, **k: (blocks.__setitem__(0, blocks[0] + 1), orig(*a, **k))[1]
+        t0 = time.perf_counter()
+        hyps = model.decode_batch(enc_states, lens, block=args.block)
         torch.cuda.synchronize()
         t_dec = time.perf_counter() - t0
+        ops.greedy_advance = orig
     nsym = sum(len(h) for h in hyps)
     out = {"workload": "greedy decode, C2 model (12/6 layers, V=4334), %d utt x T=%d, %s, emit rate target %.2f"
                        % (args.utts, args.T, args.precision, args.emit_rate),
            "utt_per_s": round(args.utts / (t_enc + t_dec), 3), "frames_per_s": round(args.utts * args.T / (t_enc + t_dec), 1),
            "encoder_ms": round(1e3 * t_enc, 2), "decode_ms_per_utt": round(1e3 * t_dec / args.utts, 2),
-           "symbols_per_utt": round(nsym / args.utts, 1), "ms_per_symbol": round(1e3 * t_dec / max(nsym, 1), 3),
-           "host_syncs_per_utt_approx": round((nsym + args.utts * -(-args.T // args.block)) / args.utts, 1)}
+           "symbols_per_utt": round(nsym / args.utts, 1), "ms_per_symbol_step": round(1e3 * t_dec / max(max(len(h) for h in hyps), 1), 3),
+           "host_syncs_per_batch": blocks[0], "host_syncs_per_utt": round(blocks[0] / args.utts, 1),
+           "decode": "Transducer.decode_batch: the batch in lockstep over symbol steps (one joint call per scanned block, one label-encoder graph replay per step)",
+           "one_utterance_at_a_time": {"utt_per_s": round(args.utts / (t_enc + t_dec1), 3), "decode_ms_per_utt": round(1e3 * t_dec1 / args.utts, 2),
+                                       "tokens_identical_to_batched": hyps1 == hyps,
+                                       "host_syncs_per_utt_approx": round((nsym + args.utts * -(-args.T // args.block)) / args.utts, 1)}}
 
     return out, model, inputs, lens, hyps
 

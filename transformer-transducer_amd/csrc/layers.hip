@@ -1304,6 +1304,16 @@ int ttmi_greedy_scan(const void* logits, int dtype, long ld, int n, int V, int b
     return greedy_scan(logits, dtype, ld, n, V, blank, out, static_cast<hipStream_t>(stream));
 }
 
+// batched greedy decoding, every utterance of a batch in lockstep over symbol steps (ttmi.h)
+int ttmi_greedy_scan_batch(const void* logits, int dtype, long ld, int B, int n, int V, int blank, const int* t, const int* T_len,
+                           const int* need, unsigned long long* key, void* stream) {
+    return greedy_scan_batch(logits, dtype, ld, B, n, V, blank, t, T_len, need, key, static_cast<hipStream_t>(stream));
+}
+int ttmi_greedy_advance(unsigned long long* key, int B, int n, int n_hist, long* hist, long ld_hist, int* t, const int* T_len, int* need,
+                        int* done, int* count, int* flags, void* stream) {
+    return greedy_advance(key, B, n, n_hist, hist, ld_hist, t, T_len, need, done, count, flags, static_cast<hipStream_t>(stream));
+}
+
 // ------------------------------------------------------------------ embedding (tt/decoder.py:26,39)
 int ttmi_embed_fwd(const long* tokens, const float* W, long n, int d, int V, float* out, void* stream) {
     return embed_fwd(tokens, W, n, d, V, out, static_cast<hipStream_t>(stream));

@@ -89,6 +89,11 @@ int colsum_bf16(const bf16_t* in, long ld, long rows, int cols, float* out, hipS
                 long si2 = 0, long so2 = 0);   // batch z = z1*nz2+z2 reads in + z1*si1 + z2*si2, adds into out + z2*so2
 // out (device u64) = (first row whose argmax != blank) << 32 | that argmax, or n << 32 when every row is blank
 int greedy_scan(const void* logits, int dtype, long ld, int n, int V, int blank, unsigned long long* out, hipStream_t st);
+// batched lockstep greedy decoding (see rowops.hip): per-utterance scan of a block of frames and the state update that consumes it
+int greedy_scan_batch(const void* logits, int dtype, long ld, int B, int n, int V, int blank, const int* t, const int* T_len, const int* need,
+                      unsigned long long* key, hipStream_t st);
+int greedy_advance(unsigned long long* key, int B, int n, int n_hist, long* hist, long ld_hist, int* t, const int* T_len, int* need, int* done,
+                   int* count, int* flags, hipStream_t st);
 // batched transpose to bf16: for z = z1*nz2+z2, dst[z][c][r] = src[z1*s1 + z2*s2 + r*ld + c] (r < R, c < C), dst pitch ldd >= R with
 // zero fill in [R, ldd), dst slab = C*ldd.  src_dtype 0 = f32, 1 = bf16.  Produces the K-major operands of the position products.
 int transpose_bf16_batched(const void* src, int src_dtype, long ld, int nz1, int nz2, long s1, long s2, int R, int C, bf16_t* dst,

@@ -1185,7 +1185,86 @@ __global__ __launch_bounds__(256) void greedy_scan_kernel(const TL* __restrict__
     if (lane == 0 && bi != blank) atomicMin(out, ((unsigned long long)row << 32) | (unsigned)bi);
 }
 
+// ---- batched greedy decoding in lockstep over SYMBOL steps (tt/model.py:70-108, every utterance of a batch at once): after step s every
+// utterance still decoding holds exactly s + 1 tokens, so ONE label-encoder call of length s + 1 serves the whole batch exactly (the
+// relative-position term depends on the sequence length: utterances of different history lengths cannot share a padded call).
+// greedy_scan_batch: logits [B, n, V] = the joint of frames t_b .. t_b + n - 1 of every utterance against its own label state; per utterance
+// the first frame (inside its length) whose argmax is not blank -> key[b] = frame offset << 32 | symbol (atomicMin; key[b] = n << 32 before).
+template <typename TL>
+__global__ __launch_bounds__(256) void greedy_scan_batch_kernel(const TL* __restrict__ logits, long ld, int B, int n, int V, int blank,
+                                                                const int* __restrict__ t, const int* __restrict__ T_len,
+                                                                const int* __restrict__ need, unsigned long long* __restrict__ key) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B * n) return;
+    const int b = row / n, r = row - b * n;
+    if (!need[b] || t[b] + r >= T_len[b]) return;       // (wave-uniform) this utterance has its symbol already, or the frame does not exist
+    const TL* p = logits + (long)row * ld;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int v = lane; v < V; v += 64) {
+        float x;
+        if constexpr (sizeof(TL) == 4) x = p[v];
+        else x = bf16_to_f32(p[v]);
+        if (x > best) { best = x; bi = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0 && bi != blank) atomicMin(key + b, ((unsigned long long)r << 32) | (unsigned)bi);
+}
+// one thread per utterance: consume key[b].  A symbol found: append it to the history (column n_hist), move past its frame, this utterance
+// is served for the step; none in these n frames: move on n frames, finished when the utterance has no frames left.  flags[0] = utterances
+// that still need a symbol in this step (the host scans another block), flags[1] = utterances not finished; key is reset for the next scan.
+__global__ void greedy_advance_kernel(unsigned long long* __restrict__ key, int B, int n, int n_hist, long* __restrict__ hist, long ld_hist,
+                                      int* __restrict__ t, const int* __restrict__ T_len, int* __restrict__ need, int* __restrict__ done,
+                                      int* __restrict__ count, int* __restrict__ flags) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const unsigned long long k = key[b];
+    key[b] = (unsigned long long)n << 32;
+    if (need[b]) {
+        const int row = (int)(k >> 32);
+        if (row < n) {
+            hist[(long)b * ld_hist + n_hist] = (long)(unsigned)(k & 0xffffffffu);
+            t[b] += row + 1;                                       // the emitting frame is consumed (at most one symbol per frame)
+            count[b] += 1;
+            need[b] = 0;
+        } else {
+            t[b] += n;
+            if (t[b] >= T_len[b]) { need[b] = 0; done[b] = 1; }
+        }
+    }
+    if (need[b]) atomicAdd(flags, 1);
+    if (!done[b]) atomicAdd(flags + 1, 1);
+}
+
 }  // namespace
+
+int greedy_scan_batch(const void* logits, int dtype, long ld, int B, int n, int V, int blank, const int* t, const int* T_len, const int* need,
+                      unsigned long long* key, hipStream_t st) {
+    TTMI_REQUIRE(logits && t && T_len && need && key && B > 0 && n > 0 && V > 0 && ld >= V, "greedy_scan_batch: bad arguments");
+    if (dtype == 0)
+        hipLaunchKernelGGL(greedy_scan_batch_kernel<float>, dim3(cdiv((long)B * n, 4)), dim3(256), 0, st, static_cast<const float*>(logits), ld, B, n, V,
+                           blank, t, T_len, need, key);
+    else
+        hipLaunchKernelGGL(greedy_scan_batch_kernel<bf16_t>, dim3(cdiv((long)B * n, 4)), dim3(256), 0, st, static_cast<const bf16_t*>(logits), ld, B, n,
+                           V, blank, t, T_len, need, key);
+    TTMI_LAUNCH_CHECK("greedy_scan_batch_kernel");
+    return TTMI_OK;
+}
+
+int greedy_advance(unsigned long long* key, int B, int n, int n_hist, long* hist, long ld_hist, int* t, const int* T_len, int* need, int* done,
+                   int* count, int* flags, hipStream_t st) {
+    TTMI_REQUIRE(key && hist && t && T_len && need && done && count && flags && B > 0 && n > 0 && n_hist >= 1 && n_hist < ld_hist,
+                 "greedy_advance: bad arguments");
+    if (hipMemsetAsync(flags, 0, 2 * sizeof(int), st) != hipSuccess) { ttmi_set_error("greedy_advance: memset failed"); return TTMI_EINVAL; }
+    hipLaunchKernelGGL(greedy_advance_kernel, dim3(cdiv(B, 64)), dim3(64), 0, st, key, B, n, n_hist, hist, ld_hist, t, T_len, need, done, count, flags);
+    TTMI_LAUNCH_CHECK("greedy_advance_kernel");
+    return TTMI_OK;
+}
 
 int ln_fwd(const float* x, const float* res, const float* g, const float* b, long rows, int d, float eps, float* s_out,
            float* y, float* mean, float* rstd, hipStream_t st, bf16_t* y16, DropSpec res_drop, DropSpec out_drop, const LnPreNorm* pre) {

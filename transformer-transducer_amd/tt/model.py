@@ -378,14 +378,15 @@ class JointNet(nn.Module):
 class _LabelStateGraphs:
     """Greedy decoding re-runs the label encoder on the whole token history after every emitted symbol (tt/model.py:75,88 of the
     reference): ~100 tiny launches whose cost is the host issuing them.  One captured graph per history length L replays them with a
-    single launch; the token history lives on the device (`master`), each graph reads its own static copy and writes a static output.
-    Graphs are captured lazily, share one memory pool and are dropped when the label encoder's parameter storage or the precision
-    mode changes."""
+    single launch; the token histories live on the device (`master` [B, MAX_L]), each graph reads its own static copy and writes a static
+    output.  B = 1: `Transducer.decode` (one utterance); B > 1: `Transducer.decode_batch` (every utterance of a batch in lockstep: all
+    histories have the same length).  Graphs are captured lazily, share one memory pool and are dropped when the label encoder's
+    parameter storage or the precision mode changes."""
     MAX_L = 128
 
-    def __init__(self, model, device):
-        self.decoder, self.device = model.decoder, device
-        self.master = torch.zeros(1, self.MAX_L, dtype=torch.long, device=device)
+    def __init__(self, model, device, batch=1):
+        self.decoder, self.device, self.batch = model.decoder, device, batch
+        self.master = torch.zeros(batch, self.MAX_L, dtype=torch.long, device=device)
         self.stream = torch.cuda.Stream(device)
         self.pool = torch.cuda.graph_pool_handle()
         self.graphs = {}
@@ -395,7 +396,7 @@ class _LabelStateGraphs:
         cur = torch.cuda.current_stream(device)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
-            self.decoder(torch.zeros(1, self.MAX_L, dtype=torch.long, device=device))
+            self.decoder(torch.zeros(batch, self.MAX_L, dtype=torch.long, device=device))
         cur.wait_stream(self.stream)
         self.arena = ops.scratch_generation(device, self.stream)
 
@@ -407,7 +408,7 @@ class _LabelStateGraphs:
         self.master[0, pos] = tok                                   # a device fill, no synchronisation
 
     def state(self, L):
-        """label-encoder output at the last position of master[:, :L] -> [1, 1, d] (static buffer of graph L)"""
+        """label-encoder output at the last position of master[:, :L] -> [B, 1, d] (static buffer of graph L)"""
         if ops.scratch_generation(self.device, self.stream) != self.arena:      # the arena moved: every graph points at freed memory
             self.graphs.clear()
             self.arena = ops.scratch_generation(self.device, self.stream)
@@ -569,18 +570,75 @@ class Transducer(nn.Module):
             t += row + 1                                                    # the emitting frame is consumed
         return token_list[1:]
 
-    def _label_state_graphs(self, dev):
-        """the per-model graph cache of `decode` (None: CPU tensors, or switched off with config.decode_graphs = False)"""
+    def _label_state_graphs(self, dev, batch=1):
+        """the per-model graph caches of `decode` / `decode_batch` (None: CPU tensors, or switched off with config.decode_graphs = False)"""
         if dev.type != "cuda" or self.config.decode_graphs is False:
             return None
-        g = self.__dict__.get("_decode_graphs")
+        cache = self.__dict__.setdefault("_decode_graphs", {})
+        g = cache.get(batch)
         if g is None or g.device != dev or g.key != _LabelStateGraphs.weights_key(self):
-            g = self.__dict__["_decode_graphs"] = _LabelStateGraphs(self, dev)
+            if len(cache) > 4:
+                cache.clear()                                       # (batch sizes come and go: keep a handful of graph sets)
+            g = cache[batch] = _LabelStateGraphs(self, dev, batch)
         return g
+
+    @torch.no_grad()
+    def decode_batch(self, enc_states, lengths, block=64):
+        """Greedy decoding of EVERY utterance of a batch at once: the token lists `decode(enc_states[b], lengths[b])` returns, for all b
+        (tt/model.py:92-108 loops over the utterances, one host round trip per frame each).  The batch advances in lockstep over SYMBOL
+        steps: in step s every utterance still decoding looks for its next non-blank frame (blocks of `block` frames from its own position,
+        scored against its own label state: one joint call for the whole batch, ttmi_greedy_scan_batch / ttmi_greedy_advance keep positions,
+        histories and flags on the device), then ONE label-encoder call of length s + 1 re-computes all label states (every history has
+        exactly s + 1 tokens - the relative-position term depends on the sequence length, so utterances of different history lengths
+        could not share a call).  Host synchronisations: one 8-byte read per scanned block of the whole batch (about one per symbol step)
+        instead of one per symbol and utterance; label-encoder launches: one (graph replay) per symbol step instead of one per symbol and
+        utterance.  Same arithmetic per utterance as `decode`: same tokens."""
+        dev = enc_states.device
+        B, T = enc_states.shape[0], enc_states.shape[1]
+        T_len = torch.as_tensor(lengths, dtype=torch.int32).to(dev).clamp(max=T).contiguous()
+        graphs = self._label_state_graphs(dev, B)
+        hist = torch.zeros(B, T + 2, dtype=torch.long, device=dev)   # column 0 = the start symbol (blank); at most one symbol per frame
+        t = torch.zeros(B, dtype=torch.int32, device=dev)
+        need = torch.ones(B, dtype=torch.int32, device=dev)
+        done = torch.zeros(B, dtype=torch.int32, device=dev)
+        count = torch.zeros(B, dtype=torch.int32, device=dev)
+        flags = torch.zeros(2, dtype=torch.int32, device=dev)
+        key = torch.full((B,), block << 32, dtype=torch.int64, device=dev)
+        rows = torch.arange(block, device=dev, dtype=torch.long)[None, :]
+        bidx = torch.arange(B, device=dev)[:, None]
+
+        def label_states(n_hist):
+            """label-encoder outputs at the last position of every history (all of length n_hist) -> [B, 1, d]"""
+            if graphs is not None and n_hist <= graphs.MAX_L:
+                graphs.master[:, :n_hist].copy_(hist[:, :n_hist])
+                return graphs.state(n_hist)
+            return self.decoder(hist[:, :n_hist].contiguous())[:, -1:, :]
+
+        n_hist = 1
+        dec_state = label_states(n_hist)
+        while True:
+            torch.sub(1, done, out=need)
+            while True:
+                idx = (t.long()[:, None] + rows).clamp_(max=T - 1)                             # frames t_b .. t_b + block - 1 (beyond T_b: ignored by the scan)
+                logits = self.joint(enc_states[bidx, idx], dec_state)                             # [B, block, 1, V]
+                ops.greedy_scan_batch(logits[:, :, 0, :], t, T_len, need, key)
+                ops.greedy_advance(key, block, n_hist, hist, t, T_len, need, done, count, flags)
+                pending, alive = flags.tolist()                                                   # the batch's one host round trip per block
+                if pending == 0:
+                    break
+            if alive == 0:
+                break
+            n_hist += 1
+            dec_state = label_states(n_hist)
+        final = hist.cpu()
+        counts = count.cpu().tolist()
+        return [final[b, 1:1 + counts[b]].tolist() for b in range(B)]
 
     @torch.no_grad()
     def recognize(self, inputs, inputs_length=None, audio_mask=None):
         enc_states = self.encoder(inputs, audio_mask)
+        if enc_states.is_cuda and inputs.size(0) > 1 and self.config.batched_decode is not False:
+            return self.decode_batch(enc_states, inputs_length)
         return [self.decode(enc_states[b], inputs_length[b]) for b in range(inputs.size(0))]
 
     @torch.no_grad()

@@ -701,3 +701,21 @@ def greedy_scan(logits2d, blank=0):
     key = int(out.item())
     row, tok = key >> 32, key & 0xffffffff
     return (row, tok) if row < n else (n, None)
+
+
+def greedy_scan_batch(logits, t, T_len, need, key, blank=0):
+    """logits [B, n, V] (f32 / bf16, row pitch = stride(-2)): per utterance the first existing frame of the block whose argmax is not blank
+    -> key[b] (include/ttmi.h: ttmi_greedy_scan_batch); device only, no synchronisation"""
+    B, n, V = logits.shape
+    _need_cuda(logits, t, T_len, need, key)
+    check(lib().ttmi_greedy_scan_batch(_p(logits), c_int(_DT[logits.dtype]), c_long(logits.stride(-2)), c_int(B), c_int(n), c_int(V), c_int(blank),
+                                       _p(t), _p(T_len), _p(need), _p(key), _stream()), "ttmi_greedy_scan_batch")
+
+
+def greedy_advance(key, n, n_hist, hist, t, T_len, need, done, count, flags):
+    """consume key (ttmi_greedy_advance): histories, frame positions and the need / done flags move on the device; flags[0] = utterances
+    that still need a symbol in this step, flags[1] = utterances not finished"""
+    B = key.shape[0]
+    assert hist.dtype is torch.long and hist.stride(1) == 1
+    check(lib().ttmi_greedy_advance(_p(key), c_int(B), c_int(n), c_int(n_hist), _p(hist), c_long(hist.stride(0)), _p(t), _p(T_len), _p(need),
+                                    _p(done), _p(count), _p(flags), _stream()), "ttmi_greedy_advance")
