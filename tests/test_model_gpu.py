@@ -266,7 +266,8 @@ def test_decode_graphs_match_eager_and_follow_weight_updates():
 
     eager, graphed = both()
     assert len(eager[0]) > 8 and graphed == eager          # histories longer than the label encoder's table (K = 8) included
-    assert model.__dict__["_decode_graphs"].graphs                      # graphs were captured and are reused below
+    sets = model.__dict__["_decode_graphs"]                              # one graph set per batch size (3 here: decode_batch)
+    assert sets and all(g.graphs for g in sets.values())                # graphs were captured and are reused below
     assert model.recognize(x, lens) == eager
     with torch.no_grad():
         for p_ in model.decoder.parameters():
