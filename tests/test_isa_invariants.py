@@ -183,6 +183,27 @@ def test_attention_counted_waits(tmp_path):
             assert min_vmem_between(ins, labels, gid, i) is not None, kname
         n_kernels += 1
     assert n_kernels >= 8                            # head dims 32 / 64 x the mask kinds
+    # the second-generation kernel (LDS-DMA staging): the same count under its own tag, and every SGPR-based asm access opens with s_nop 4
+    n2 = 0
+    for kname, body in kernels_of(asm).items():
+        if "flash_bwd_rel2_kernel" not in kname:
+            continue
+        ins, labels = parse(body)
+        waits = [(i, x["wait"]) for i, x in enumerate(ins) if x.get("wait")]
+        assert waits and all(w == ("bwdrel2", 32) for _, w in waits), (kname, waits)
+        assert not any(x.get("untagged") for x in ins), kname
+        stores = sum(1 for x in ins if x["op"].startswith("buffer_store_short"))
+        assert stores == 128, (kname, stores)         # 2 unrolled steps x (interior + diagonal / edge) x 32
+        for i, (gid, n) in waits:
+            assert min_vmem_between(ins, labels, gid, i) is not None, kname
+        for k, x in enumerate(ins):                  # hazard: VALU write of an SGPR (v_readlane) -> vector-memory read of it needs 5 wait states
+            t = x.get("text", "")
+            if (x["op"].startswith("global_load") and re.search(r"\bs\[\d+:\d+\]", t)) and x["op"] != "global_load_lds_dwordx4":
+                assert ins[k - 1]["op"] == "s_nop" and ins[k - 1]["text"].split()[1] == "4", (kname, t)
+            if x["op"] == "global_load_lds_dwordx4" and re.search(r"\bs\[\d+:\d+\]", t):
+                assert ins[k - 1]["op"] == "s_nop" and ins[k - 1]["text"].split()[1] == "4" and ins[k - 2]["op"] == "s_mov_b32", (kname, t)
+        n2 += 1
+    assert n2 == 5                                   # the five mask kinds
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")

@@ -57,6 +57,7 @@ int attn_dqde(const bf16_t* dS16, const bf16_t* dG16, long slab16, long ldp, con
               hipStream_t st);
 int flash_attn_fwd(const FlashParams& p, hipStream_t st);
 void flash_set_resident(int v);     // 1 (default): one workgroup per head with the table resident in LDS where it applies; 0: round-3 kernels
+void flash_set_bwd_gen(int v);      // 2 (default): flash_bwd_rel2_kernel (LDS-DMA staging, register skew, one barrier per step); 1: the round-3 kernel
 int flash_attn_bwd(const FlashParams& p, hipStream_t st);
 // G slab of the position term (q E^T + c, column 0 zero, row pitch L+1, bf16) for all (b, h): q rows (b, i) at q[(b*L+i)*ld_q + h*Dh],
 // E rows p at E[p*ld_e + h*Dh], c[h][p]

@@ -1427,6 +1427,436 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel_kernel(const FlashParams
     }
 }
 
+// ------------------------------------------------------------------ backward (dK, dV, dS), position term in the kernel: second generation
+// Same arithmetic, slabs and launch geometry as flash_bwd_rel_kernel (one 256-thread workgroup per 128 keys of a head, key on the lane,
+// 32-query steps, Dh = 64); what changed is everything around the arithmetic.  Cycle stamps inside the round-3 kernel (tools/debug/
+// bwd_stamps.py: one wave, C2 audio layer) read 169k cycles per workgroup: 23k of prologue (the 160-row table window staged through
+// registers in a dependent loop), then per step ~6.9k on an interior tile - 2.0k for the position tile (two MFMA chains, a bf16 image
+// written to LDS and read back by sixteen 2-byte reads, in front of the score MFMAs that wait for it as their accumulator), 1.75k for the
+// element loop and its 32 slab stores, 0.85k waiting for and parking the prefetch, two barriers - and 10.9k on the 6 of 16 tiles that touch
+// the diagonal or the sequence end (one branch per element).  Here:
+//   * the table window, the dO tile and the rows of the next table block arrive by LDS-DMA (global_load_lds_dwordx4: no registers, no park;
+//     rows of the extended table that do not exist are fetched from a zero page), the prologue's 6 KiB per wave are in flight at once;
+//   * rings sized so that ONE barrier per step suffices (plain q / q + u rows: 128 slots, dO: two tiles, row statistics: two sets);
+//   * the position tile is skewed in registers: both 32-column blocks of G are packed into one bf16 pair per element (the forward pass
+//     rounds its position scores to bf16 too) and one ds_bpermute_b32 per element moves the pair from window column 31 - q + j to key j;
+//     the score and dP chains start from per-lane constants and run beside the G chains, bias and content meet in one add per element;
+//   * diagonal and end tiles run a branch-free element loop with per-element selects (stores dropped by out-of-range offsets).
+__device__ __attribute__((aligned(128))) const unsigned g_attn_zero_page[32] = {};
+// one LDS-DMA instruction: 16 bytes per lane from `g` to (wave-uniform LDS address) + lane * 16.  Issued by asm so that the compiler does
+// not order its own LDS accesses behind it (it waits for vmcnt(0) in front of every LDS access it cannot prove disjoint from a DMA it
+// knows about); completion is this kernel's own business (counted vmcnt wait + barrier).
+__device__ __forceinline__ void lds_dma16(const void* g, unsigned lds_wave_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_wave_addr) : "memory", "m0");
+}
+// the same with the address as (wave-uniform base in SGPRs) + (32-bit unsigned byte offset per lane): no 64-bit vector arithmetic.
+// HAZARD: a vector-memory instruction must not read an SGPR within 5 wait states of a VALU write to it (v_readlane restoring a spilled
+// SGPR pair is such a write, and the compiler places it right in front of the asm); the hazard recognizer does not look inside inline
+// asm, so every SGPR-based access here opens with `s_nop 4`.  (Found as a memory fault in the mask-kind-3 / -4 instances only - the ones
+// whose SGPR pressure spills the bases to VGPR lanes.)
+__device__ __forceinline__ void lds_dma16_s(const void* base, unsigned off, unsigned lds_wave_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_wave_addr) : "memory", "m0");
+}
+__device__ __forceinline__ u32x4_t ld16_async_s(const void* base, unsigned off) {
+    u32x4_t v;
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
+    return v;
+}
+__device__ __forceinline__ float ld4f_async_s(const void* base, unsigned off) {
+    float v;
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
+    return v;
+}
+__device__ __forceinline__ int ld4i_async_s(const void* base, unsigned off) {
+    int v;
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
+    return v;
+}
+#ifdef TTMI_STAMPS
+__device__ unsigned long long g_bwd_stamps[1024];
+#define STAMP(k) do { if (stamp_on) g_bwd_stamps[stamp_n * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP_NEXT() do { ++stamp_n; } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#define STAMP_NEXT() do {} while (0)
+#endif
+constexpr int BWD2_LDS = (256 + 128 + 128 + 64) * 128 + 256 * 4 + 4 * 64 * 4 + 64 * 4;
+template <int MK>
+__global__ __launch_bounds__(256, 2) void flash_bwd_rel2_kernel(const FlashParams p) {
+    constexpr int DH = 64, KS = 4, DT = 2;
+    using T = Tile<DH>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* etile = smem;                                          // ring of 256 extended-table rows (slot = (p' - L) & 255)
+    char* ptile = smem + 256 * 128;                              // plain q rows, ring of 128 (slot = row & 127)
+    char* qtile = ptile + 128 * 128;                             // q + u rows, same ring
+    char* dotile = qtile + 128 * 128;                            // two dO tiles of 32 rows (step parity)
+    float* ctile = reinterpret_cast<float*>(dotile + 64 * 128);  // extended bias, ring of 256
+    float* lse_s = ctile + 256;                                  // [2][32] row statistics of the tile (step parity)
+    float* del_s = lse_s + 64;
+    int* lo_s = reinterpret_cast<int*>(del_s + 64);              // MK == 4: the tile's key intervals
+    int* hi_s = lo_s + 64;
+    float* u_s = reinterpret_cast<float*>(hi_s + 64);            // r_w_bias of this head
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hh = lane >> 5, jj = lane & 31;
+    const int z = blockIdx.y, b = z / p.H, h = z % p.H;
+    const int L = p.L;
+#ifdef TTMI_STAMPS
+    const bool stamp_on = blockIdx.x == 1 && blockIdx.y == 5 && tid == 0;
+    int stamp_n = 0;
+    STAMP(0);
+    STAMP_NEXT();
+#endif
+    const int jw0 = blockIdx.x * 128;
+    const int j = jw0 + wave * 32 + jj;
+    const int jc = min(j, L - 1);
+    const bool kvalid = j < L;
+    const bf16_t* krow = p.k + ((long)b * L + jc) * p.ld_kv + h * DH;
+    const bf16_t* vrow = p.v + ((long)b * L + jc) * p.ld_kv + h * DH;
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = *reinterpret_cast<const bf16x8*>(krow + 16 * ks + 8 * hh);
+        vf[ks] = *reinterpret_cast<const bf16x8*>(vrow + 16 * ks + 8 * hh);
+    }
+    f32x16 dk[DT], dv[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+    const bf16_t* dobase = p.dO + (long)b * L * p.ld_o + h * DH;
+    const bf16_t* pbase = p.qp + (long)b * L * p.ld_qp + h * DH;
+    const bf16_t* ebase = p.e16 + h * DH;
+    const float* cbase = p.cT + (long)h * L;
+    bf16_t* ds16 = p.dS16 + (long)z * p.slab16;
+    bf16_t* dg16 = p.dG16 + (long)z * p.slab16;
+    const __amdgpu_buffer_rsrc_t rs_ds = __builtin_amdgcn_make_buffer_rsrc(ds16, 0, (int)(p.slab16 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dg = __builtin_amdgcn_make_buffer_rsrc(dg16, 0, (int)(p.slab16 * 2), 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFF00u;
+    const int ldp = (int)p.ldp;
+    const float c2 = p.scale * 1.4426950408889634f;                         // scale * log2(e)
+    const unsigned lds0 = (unsigned)(size_t)smem;                            // LDS byte address of the arena (DMA destinations)
+    // this lane inside a wave's 1 KiB DMA piece = 8 rows of a 32-row block: row 8 wave + lane / 8, and the source chunk that belongs at the
+    // lane's position of the swizzled image (every 32-row block starts at a slot that is a multiple of 32: same swizzle phase)
+    const int rib = 8 * wave + (lane >> 3);
+    const int csrc8 = ((lane & 7) ^ ((rib >> 1) & 7)) * 8;
+    // Extended table row p' -> table row: p' (p' < L), p' - L - 1 (p' > L); p' = L is the zero row.  Rows outside [0, 2 L] are never met by
+    // a (query, key) pair that exists (p' = L - 1 - i + j), so they are fetched clamped and hold whatever row that is; the ONE row that must
+    // read as zeros, p' = L, is fetched clamped as well and overwritten in LDS by the lanes that fetched it (patch_zero_row, after the wait
+    // for the fetch and before the barrier that publishes the block).  All fetches are (uniform base) + (32-bit lane offset).
+    auto tab_row = [&](int pe) -> int { return min(max(pe < L ? pe : pe - L - 1, 0), L - 1); };
+    const unsigned ld_e2 = (unsigned)p.ld_e * 2u, ld_o2 = (unsigned)p.ld_o * 2u, ld_qp2 = (unsigned)p.ld_qp * 2u;
+    const float* lse_z = p.lse + (long)z * L;
+    const float* del_z = p.delta + (long)z * L;
+    auto dma_e_block = [&](int pe0) {                                        // 32 extended-table rows pe0 .. pe0 + 31 (pe0 - L a multiple of 32) into the ring
+        lds_dma16_s(ebase, (unsigned)tab_row(pe0 + rib) * ld_e2 + csrc8 * 2, lds0 + (((pe0 - L) & 255) + 8 * wave) * 128);
+    };
+    auto patch_zero_row = [&](int pe0) {                                     // this lane's 16 bytes of the block it fetched, if they belong to p' = L
+        if (pe0 + rib == L) *reinterpret_cast<u32x4_t*>(etile + (((pe0 - L) & 255) + rib) * 128 + (lane & 7) * 16) = u32x4_t{0u, 0u, 0u, 0u};
+    };
+    auto dma_do = [&](int i0, int par) {
+        lds_dma16_s(dobase, (unsigned)min(i0 + rib, L - 1) * ld_o2 + csrc8 * 2, lds0 + (256 + 128 + 128) * 128 + par * 4096 + wave * 1024);
+    };
+    auto add_u = [&](u32x4_t v) -> u32x4_t {
+        const float4 ua = *reinterpret_cast<const float4*>(u_s + (tid & 7) * 8), ub = *reinterpret_cast<const float4*>(u_s + (tid & 7) * 8 + 4);
+        u32x4_t o;
+        o[0] = cvt_pk2(__uint_as_float(v[0] << 16) + ua.x, __uint_as_float(v[0] & 0xffff0000u) + ua.y);
+        o[1] = cvt_pk2(__uint_as_float(v[1] << 16) + ua.z, __uint_as_float(v[1] & 0xffff0000u) + ua.w);
+        o[2] = cvt_pk2(__uint_as_float(v[2] << 16) + ub.x, __uint_as_float(v[2] & 0xffff0000u) + ub.y);
+        o[3] = cvt_pk2(__uint_as_float(v[3] << 16) + ub.z, __uint_as_float(v[3] & 0xffff0000u) + ub.w);
+        return o;
+    };
+    // what still travels through registers (asm loads, handed over after the counted wait): the plain q rows i0 + 32 .. i0 + 63 (q + u is
+    // formed when they are parked), the 32 new bias values, the tile's row statistics - each executed by ALL threads, redundantly where
+    // fewer values exist (a load under `if (tid < ..)` puts a control-flow join behind it, where the compiler waits for vmcnt(0))
+    u32x4_t ppre = {0u, 0u, 0u, 0u};
+    float cpre = 0.f, lse_pre = 0.f, del_pre = 0.f;
+    int lo_pre = 0, hi_pre = 0;
+    auto prefetch = [&](int i0, int par) {                                   // everything tile i0 needs that is not in LDS yet
+        const int wbase = L - 32 - i0 + jw0;
+        dma_do(i0, par);
+        dma_e_block(wbase);
+        ppre = ld16_async_s(pbase, (unsigned)min(i0 + 32 + (tid >> 3), L - 1) * ld_qp2 + (tid & 7) * 16);
+        cpre = ld4f_async_s(cbase, (unsigned)tab_row(wbase + (tid & 31)) * 4u);
+        const unsigned ii4 = (unsigned)min(i0 + (tid & 31), L - 1) * 4u;
+        lse_pre = ld4f_async_s(lse_z, ii4);
+        del_pre = ld4f_async_s(del_z, ii4);
+        if constexpr (MK == 4) {
+            const int* r = reinterpret_cast<const int*>(p.mask) + (long)b * p.mask_sb;
+            lo_pre = ld4i_async_s(r, 2u * ii4);
+            hi_pre = ld4i_async_s(r, 2u * ii4 + 4u);
+        }
+    };
+    int ibeg = 0, iend = L;
+    if (p.bwd_skip) {
+        ibeg = max(0, jw0 - p.mask_right) & ~63;
+        iend = (int)min((long)L, (long)jw0 + 127 + p.mask_left + 1);
+        if (iend <= ibeg) { ibeg = 0; iend = 0; }
+    }
+    // ---- prologue: the 160 window rows above the first tile's new block, the first tile's own plain q rows (through registers: + u), the bias
+    // of those 160 rows, then the first tile's prefetch - all in flight together
+    if (ibeg < iend) {
+        const int wb = L - ibeg + jw0;                                       // = window base of tile ibeg, + 32
+#pragma unroll
+        for (int k = 0; k < 5; ++k) dma_e_block(wb + 32 * k);
+        const u32x4_t q0 = *reinterpret_cast<const u32x4_t*>(pbase + (long)min(ibeg + (tid >> 3), L - 1) * p.ld_qp + (tid & 7) * 8);
+        const bool cok = wb + tid != L;
+        const float cv = cbase[tab_row(wb + tid)];
+        if (tid < DH) u_s[tid] = p.u[h * DH + tid];
+        prefetch(ibeg, 0);
+        __syncthreads();                                                     // u_s
+        const int slot = (ibeg + (tid >> 3)) & 127;
+        *reinterpret_cast<u32x4_t*>(ptile + T::off(slot, tid & 7)) = q0;
+        *reinterpret_cast<u32x4_t*>(qtile + T::off(slot, tid & 7)) = add_u(q0);
+        if (tid < 160) ctile[(wb + tid - L) & 255] = cok ? cv : 0.f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the window blocks have landed: the row p' = L, if one of them holds it, becomes zeros
+#pragma unroll
+        for (int k = 0; k < 5; ++k) patch_zero_row(wb + 32 * k);
+    }
+    // lane parts of the slab byte offsets (fixed for the kernel; a lane whose key does not exist carries an offset past the slab: the hardware drops its stores)
+    const unsigned v_ds = kvalid ? (unsigned)((4 * hh * ldp + j) * 2) : OOB;                       // dS16[i][j]
+    const unsigned v_lo = kvalid ? (unsigned)((4 * hh * (ldp - 1) + L - 1 + j) * 2) : OOB;         // dG16, j <= i
+    const unsigned v_hi = kvalid ? (unsigned)((4 * hh * (ldp - 1) + ldp + j - 2) * 2) : OOB;       // dG16, j >= i + 2
+    // skew of the position tile: element r of this lane (query qi = cq(r) + 4 hh, key jj) sits at window column 31 - qi + jj: block 1 iff jj > qi,
+    // lane (31 - qi + jj) & 31 of the same half
+    const int a4 = 4 * (31 - 4 * hh + jj), hb = 128 * hh, jq = jj - 4 * hh;
+    // fragment reads of the swizzled tiles: chunk 2 ks + hh of row r sits at r * 128 + (((2 ks + hh) ^ ((r >> 1) & 7)) << 4) = r * 128 + (sw ^ (ks << 5)),
+    // sw = (hh ^ ((r >> 1) & 7)) << 4: one v_xad_u32 per read.  Every row read below is jj or jj + 1 plus a multiple of 32: two lane constants.
+    const unsigned sw0 = (unsigned)((hh ^ ((jj >> 1) & 7)) << 4), sw1 = (unsigned)((hh ^ (((jj + 1) >> 1) & 7)) << 4);
+    auto frag = [&](const char* tile, unsigned rowbytes, unsigned sw, int ks) -> bf16x8 {
+        return *reinterpret_cast<const bf16x8*>(tile + ((sw ^ (unsigned)(ks << 5)) + rowbytes));
+    };
+    constexpr int SLAB_STORES_PER_STEP = 2 * 16;
+    static_assert(SLAB_STORES_PER_STEP == 32, "the prefetch wait counts a step's slab store instructions");
+
+    auto step = [&](int i0, int par, bool first) {
+        STAMP(0);
+        // the prefetch of this tile: issued one step ago, in front of that step's 32 slab store instructions (the very first tile: in front of nothing)
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else TTMI_VM_WAIT("bwdrel2", SLAB_STORES_PER_STEP);
+        asm volatile("" : "+v"(ppre), "+v"(cpre), "+v"(lse_pre), "+v"(del_pre), "+v"(lo_pre), "+v"(hi_pre));
+        {
+            const int slot = (i0 + 32 + (tid >> 3)) & 127;
+            *reinterpret_cast<u32x4_t*>(ptile + T::off(slot, tid & 7)) = ppre;
+            *reinterpret_cast<u32x4_t*>(qtile + T::off(slot, tid & 7)) = add_u(ppre);
+            const int wbase = L - 32 - i0 + jw0;
+            ctile[(wbase + (tid & 31) - L) & 255] = wbase + (tid & 31) != L ? cpre : 0.f;
+            patch_zero_row(wbase);
+            lse_s[32 * par + (tid & 31)] = lse_pre * 1.4426950408889634f;    // parked pre-multiplied: p = exp2(s c2 - lse log2 e), dS = p (dP scale - delta scale)
+            del_s[32 * par + (tid & 31)] = del_pre * p.scale;
+            if constexpr (MK == 4) {
+                lo_s[32 * par + (tid & 31)] = lo_pre;
+                hi_s[32 * par + (tid & 31)] = hi_pre;
+            }
+        }
+        STAMP(1);
+        __syncthreads();                                                     // the only barrier of a step (ring sizes: see the kernel's header)
+        STAMP(2);
+        if (i0 + 32 < iend) {
+            prefetch(i0 + 32, par ^ 1);
+            TTMI_VM_GUARD("bwdrel2");                                        // the prefetch is older than this point; the step's slab stores follow it
+        }
+        STAMP(3);
+        const char* qcur = qtile + (i0 & 127) * 128;
+        const char* docur = dotile + par * 4096;
+        // the score accumulator starts as the position term (S = bias + (q + u) . k comes out of the MFMA chain itself).  A key that does not
+        // exist gets no special value: its lane's scores only ever reach its own columns of dK / dV, which are not stored, and its slab stores
+        // carry an out-of-range offset
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        STAMP(4);
+        if (!(p.debug & 8)) {
+            // G = Qsel . Eext_window^T + cext: two 32-column blocks of the wave's 63-column window (rows = queries, lane = window column)
+            const int pe_w = L - 32 - i0 + jw0 + 32 * wave;                 // p' of the wave's window column 0
+            f32x16 g0, g1;
+            const bool all_low = pe_w + 63 <= L - 1, all_up = pe_w >= L + 1;
+            if (all_low || all_up) {                                         // both blocks on one side of p' = L: two independent chains
+                const int e0 = (pe_w + jj - L) & 255, e1 = (pe_w + 32 + jj - L) & 255;
+                const float c0v = ctile[e0], c1v = ctile[e1];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { g0[r] = c0v; g1[r] = c1v; }
+                const unsigned qb = (unsigned)((i0 + jj + (all_low ? 0 : 1)) & 127) * 128u, qsw = all_low ? sw0 : sw1;
+                const unsigned e0b = (unsigned)e0 * 128u, e1b = (unsigned)e1 * 128u;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 qa = frag(ptile, qb, qsw, ks);
+                    const bf16x8 f0 = frag(etile, e0b, sw0, ks);
+                    const bf16x8 f1 = frag(etile, e1b, sw0, ks);
+                    g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, f0, g0, 0, 0, 0);
+                    g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, f1, g1, 0, 0, 0);
+                }
+            } else {
+                auto gblock = [&](int blk) -> f32x16 {
+                    const int pe0 = pe_w + 32 * blk;
+                    const int erow = (pe0 + jj - L) & 255;                   // ring slot of this lane's table row
+                    f32x16 g;
+                    const float cv = ctile[erow];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) g[r] = cv;
+                    const int qlo = (i0 + jj) & 127, qup = (i0 + jj + 1) & 127;
+                    if (pe0 + 31 <= L - 1 || pe0 >= L + 1) {
+                        const int qrow = pe0 >= L + 1 ? qup : qlo;
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            const bf16x8 qa = *reinterpret_cast<const bf16x8*>(ptile + T::off(qrow, 2 * ks + hh));
+                            const bf16x8 ef = *reinterpret_cast<const bf16x8*>(etile + T::off(erow, 2 * ks + hh));
+                            g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, ef, g, 0, 0, 0);
+                        }
+                    } else {                                                 // the block that holds p' = L: columns below it take q_i, columns above it q_{i+1}
+                        const bool lower = pe0 + jj <= L - 1;
+                        bf16x8 zero;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) zero[e] = (__bf16)0.0f;
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            const bf16x8 qa = *reinterpret_cast<const bf16x8*>(ptile + T::off(qlo, 2 * ks + hh));
+                            const bf16x8 qb = *reinterpret_cast<const bf16x8*>(ptile + T::off(qup, 2 * ks + hh));
+                            const bf16x8 ef = *reinterpret_cast<const bf16x8*>(etile + T::off(erow, 2 * ks + hh));
+                            g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, lower ? ef : zero, g, 0, 0, 0);
+                            g = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qb, lower ? zero : ef, g, 0, 0, 0);
+                        }
+                    }
+                    return g;
+                };
+                g0 = gblock(0);
+                g1 = gblock(1);
+            }
+            // skew in registers: one bf16 pair (block 0 | block 1) per element, one cross-lane move per element
+            int a4s = a4, jqs = jq;
+            asm volatile("" : "+v"(a4s), "+v"(jqs));                        // (opaque per step: sixteen hoisted addresses and sixteen hoisted lane masks cost more registers than the kernel has)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cq = (r & 3) + 8 * (r >> 2);
+                const unsigned pk = cvt_pk2(g0[r], g1[r]);
+                const unsigned got = (unsigned)__builtin_amdgcn_ds_bpermute((int)((((unsigned)(a4s - 4 * cq)) & 124u) | (unsigned)hb), (int)pk);
+                s[r] = __uint_as_float(jqs > cq ? (got & 0xffff0000u) : (got << 16));
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 qa = frag(qcur, (unsigned)jj * 128u, sw0, ks);
+            const bf16x8 da = frag(docur, (unsigned)jj * 128u, sw0, ks);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
+        }
+        STAMP(5);
+        const int s_ds = i0 * ldp * 2, s_dg = i0 * (ldp - 1) * 2;            // row part of the slab offsets (wave-uniform)
+        // pad columns [L, ldp) of both bf16 slabs feed the K loop of the dq / dE products and must be zero: the lanes whose key index falls
+        // there write the zeros (no separate strided memsets over B*H*L rows)
+        if (!kvalid && j < ldp) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cq = (r & 3) + 8 * (r >> 2);
+                if (i0 + cq + 4 * hh < L) {
+                    ds16[(unsigned)((i0 + 4 * hh + cq) * ldp + j)] = 0;
+                    dg16[(unsigned)((i0 + 4 * hh + cq) * ldp + j)] = 0;
+                }
+            }
+        }
+        const float* lse_c = lse_s + 32 * par + 4 * hh;
+        const float* del_c = del_s + 32 * par + 4 * hh;
+        const int jw = jw0 + 32 * wave;
+        // this wave's 32 x 32 tile entirely on one side of the j == i + 1 diagonal, all 32 queries in range: one slab offset pair for the tile
+        const bool interior = (i0 + 32 <= L) && (jw + 31 <= i0 || jw >= i0 + 33);
+        if (interior) {
+            const unsigned v_g = (p.debug & 2) ? OOB : (jw < i0 ? v_lo : v_hi);
+            const unsigned v_d = (p.debug & 2) ? OOB : v_ds;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cq = (r & 3) + 8 * (r >> 2), q = cq + 4 * hh;
+                float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse_c[cq]));
+                float ds = pr * fmaf(dp[r], p.scale, -del_c[cq]);
+                if constexpr (MK != 0) {
+                    if (MK == 4 ? (j < lo_s[32 * par + q] || j > hi_s[32 * par + q]) : is_masked<MK>(p, b, i0 + q, jc)) { pr = 0.f; ds = 0.f; }
+                }
+                s[r] = pr;
+                dp[r] = ds;
+                const bf16_t d16 = f32_to_bf16(ds);
+                __builtin_amdgcn_raw_buffer_store_b16(d16, rs_ds, v_d, s_ds + cq * ldp * 2, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(d16, rs_dg, v_g, s_dg + cq * (ldp - 1) * 2, 0);
+            }
+        } else {
+            const int dj = j - i0 - 4 * hh;                                  // j - i = dj - cq
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cq = (r & 3) + 8 * (r >> 2), q = cq + 4 * hh;
+                const bool rowok = i0 + q < L;
+                float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse_c[cq]));
+                float ds = pr * fmaf(dp[r], p.scale, -del_c[cq]);
+                bool dead = !rowok;
+                if constexpr (MK != 0) dead = dead || (MK == 4 ? (j < lo_s[32 * par + q] || j > hi_s[32 * par + q]) : is_masked<MK>(p, b, min(i0 + q, L - 1), jc));
+                if (dead) { pr = 0.f; ds = 0.f; }
+                s[r] = pr;
+                dp[r] = ds;
+                const bf16_t d16 = f32_to_bf16(ds);
+                const unsigned v_d = rowok ? v_ds : OOB;
+                const unsigned v_g = (rowok && dj != cq + 1) ? (dj <= cq ? v_lo : v_hi) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b16(d16, rs_ds, v_d, s_ds + cq * ldp * 2, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(d16, rs_dg, v_g, s_dg + cq * (ldp - 1) * 2, 0);
+            }
+        }
+        STAMP(6);
+        if (p.debug & 16) {                                                  // (timing experiments: no dV / dK products)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dv[0][r] += s[r]; dk[0][r] += dp[r]; }
+            return;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 pb = pack8(s, 8 * s2);
+            const bf16x8 dsb = pack8(dp, 8 * s2);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16x8 a_do = tr_frag<DH>(docur, 16 * s2, 32 * dt, lane);
+                const bf16x8 a_qu = tr_frag<DH>(qcur, 16 * s2, 32 * dt, lane);
+                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_do, pb, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_qu, dsb, dk[dt], 0, 0, 0);
+            }
+        }
+        STAMP(7);
+        STAMP_NEXT();
+    };
+    for (int i0 = ibeg; i0 < iend; i0 += 64) {
+        step(i0, 0, i0 == ibeg);
+        if (i0 + 32 < iend) step(i0 + 32, 1, false);
+    }
+#ifdef TTMI_STAMPS
+    stamp_n = 17;
+    STAMP(0);
+#endif
+    if (kvalid) {
+        float* dkrow = p.dK + ((long)b * L + j) * p.ld_dkv + h * DH;
+        float* dvrow = p.dV + ((long)b * L + j) * p.ld_dkv + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d = 32 * dt + 8 * g4 + 4 * hh;
+                if (p.dK16) {      // bf16, the form the qkv dgrad / wgrad GEMMs read (no f32 copy, no conversion pass over dqkv)
+                    const long o16 = ((long)b * L + j) * p.ld_dkv + h * DH + d;
+                    uint2 wk, wv;
+                    wk.x = cvt_pk2(dk[dt][4 * g4], dk[dt][4 * g4 + 1]); wk.y = cvt_pk2(dk[dt][4 * g4 + 2], dk[dt][4 * g4 + 3]);
+                    wv.x = cvt_pk2(dv[dt][4 * g4], dv[dt][4 * g4 + 1]); wv.y = cvt_pk2(dv[dt][4 * g4 + 2], dv[dt][4 * g4 + 3]);
+                    *reinterpret_cast<uint2*>(p.dK16 + o16) = wk;
+                    *reinterpret_cast<uint2*>(p.dV16 + o16) = wv;
+                } else {
+                    *reinterpret_cast<float4*>(dkrow + d) = make_float4(dk[dt][4 * g4], dk[dt][4 * g4 + 1], dk[dt][4 * g4 + 2], dk[dt][4 * g4 + 3]);
+                    *reinterpret_cast<float4*>(dvrow + d) = make_float4(dv[dt][4 * g4], dv[dt][4 * g4 + 1], dv[dt][4 * g4 + 2], dv[dt][4 * g4 + 3]);
+                }
+            }
+    }
+#ifdef TTMI_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(1);
+#endif
+}
+#ifdef TTMI_STAMPS
+}  // namespace
+extern "C" int ttmi_debug_bwd_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_stamps), sizeof(unsigned long long) * n);
+}
+namespace {
+#endif
+
 // ------------------------------------------------------------------ backward (dK, dV, dS)
 template <int DH, int MK>
 __global__ __launch_bounds__(256, 2) void flash_bwd_kernel(const FlashParams p) {
@@ -2138,6 +2568,8 @@ int flash_attn_fwd(const FlashParams& p, hipStream_t st) {
     return TTMI_OK;
 }
 
+int g_bwd_gen = 2;              // ttmi_set_option(15, 1): the round-3 backward kernel (register-staged prefetch, LDS image skew) for A/B measurements
+void flash_set_bwd_gen(int v) { g_bwd_gen = v; }
 int flash_attn_bwd(const FlashParams& p, hipStream_t st) {
     TTMI_REQUIRE((p.qu || p.e16) && p.k && p.v && (p.bd || p.e16) && p.o && p.lse && p.dO && p.delta && p.dS16 && p.dG16 && p.dK && p.dV, "flash_attn_bwd: null pointer");
     TTMI_REQUIRE(!p.e16 || (p.qp && p.cT && p.u && p.ld_qp % 8 == 0 && p.ld_e % 8 == 0 && aligned16(p.qp) && aligned16(p.e16)),
@@ -2165,7 +2597,10 @@ int flash_attn_bwd(const FlashParams& p, hipStream_t st) {
     else hipLaunchKernelGGL(flash_delta_kernel<32>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta, p.zero_f32, p.zero_f32 ? p.zero_n : 0L, zg, p.slab16, (int)p.ldp);
     // in-kernel position term: (64 + 32 + 64 + 256) tile rows + cext ring + lse / delta + lo / hi + 4 private images of [64][36] bf16
 #define BWD_LAUNCH(MKV) do { \
-        if (p.e16) { \
+        if (p.e16 && p.Dh == 64 && g_bwd_gen >= 2) { \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_bwd_rel2_kernel<MKV>), hipFuncAttributeMaxDynamicSharedMemorySize, BWD2_LDS) != hipSuccess) { ttmi_set_error("flash_attn_bwd: LDS attribute"); return TTMI_EINVAL; } \
+            hipLaunchKernelGGL((flash_bwd_rel2_kernel<MKV>), grid, dim3(256), BWD2_LDS, st, q); \
+        } else if (p.e16) { \
             if (p.Dh == 64) { const int lds = 416 * 128 + 256 * 4 + 256 + 256 + 4 * 64 * 36 * 2 + 256; \
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_bwd_rel_kernel<64, MKV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) { ttmi_set_error("flash_attn_bwd: LDS attribute"); return TTMI_EINVAL; } \
                 hipLaunchKernelGGL((flash_bwd_rel_kernel<64, MKV>), grid, dim3(256), lds, st, q); } \

@@ -1270,7 +1270,8 @@ int ttmi_set_dropout_salt(const unsigned* salt) {
 // process-wide switches for A/B measurements.  key 0: 1 = disable the fused attention kernels (bf16 pipeline only);
 // key 1: throughput-GEMM generation (see gemm_fast.hip); key 2: flash-kernel timing switches; key 3: 0 = no wgrad fork
 int ttmi_set_option(int key, int value) {
-    TTMI_REQUIRE(key >= 0 && key <= 14, "set_option: unknown key %d", key);
+    TTMI_REQUIRE(key >= 0 && key <= 15, "set_option: unknown key %d", key);
+    if (key == 15) { flash_set_bwd_gen(value); return TTMI_OK; }
     if (key == 14) { flash_set_resident(value); return TTMI_OK; }
     if (key == 13) { g_split_weights = value; return TTMI_OK; }
     if (key == 12) { g_ln_bwd_grid = value < 1 ? 1 : value; return TTMI_OK; }
