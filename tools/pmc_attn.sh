@@ -14,7 +14,7 @@ for d in "ab":
     for f in glob.glob(O+"/%s/**/*counter_collection.csv"%d, recursive=True):
         for r in csv.DictReader(open(f)):
             n=r["Kernel_Name"]
-            for k in ("flash_bwd_rel","flash_fwd_rel","flash_fwd_res","attn_dqde"):
+            for k in ("flash_bwd_rel2","flash_fwd_res","attn_dqde"):
                 if k in n: acc[(k,r["Counter_Name"])].append(float(r["Counter_Value"]))
     for k,v in sorted(acc.items()): print(k, "n=%d mean=%.4e"%(len(v), sum(v)/len(v)))
 PY

@@ -1480,9 +1480,12 @@ __device__ unsigned long long g_bwd_stamps[1024];
 #define STAMP(k) do {} while (0)
 #define STAMP_NEXT() do {} while (0)
 #endif
+#ifndef BWD2_MINB
+#define BWD2_MINB 2
+#endif
 constexpr int BWD2_LDS = (256 + 128 + 128 + 64) * 128 + 256 * 4 + 4 * 64 * 4 + 64 * 4;
 template <int MK>
-__global__ __launch_bounds__(256, 2) void flash_bwd_rel2_kernel(const FlashParams p) {
+__global__ __launch_bounds__(256, BWD2_MINB) void flash_bwd_rel2_kernel(const FlashParams p) {
     constexpr int DH = 64, KS = 4, DT = 2;
     using T = Tile<DH>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1723,12 +1726,18 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_rel2_kernel(const FlashParam
             // skew in registers: one bf16 pair (block 0 | block 1) per element, one cross-lane move per element
             int a4s = a4, jqs = jq;
             asm volatile("" : "+v"(a4s), "+v"(jqs));                        // (opaque per step: sixteen hoisted addresses and sixteen hoisted lane masks cost more registers than the kernel has)
+            // (all sixteen moves are issued before the first result is used: taken one at a time each costs an LDS round trip)
+            unsigned got[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cq = (r & 3) + 8 * (r >> 2);
-                const unsigned pk = cvt_pk2(g0[r], g1[r]);
-                const unsigned got = (unsigned)__builtin_amdgcn_ds_bpermute((int)((((unsigned)(a4s - 4 * cq)) & 124u) | (unsigned)hb), (int)pk);
-                s[r] = __uint_as_float(jqs > cq ? (got & 0xffff0000u) : (got << 16));
+                got[r] = (unsigned)__builtin_amdgcn_ds_bpermute((int)((((unsigned)(a4s - 4 * cq)) & 124u) | (unsigned)hb), (int)cvt_pk2(g0[r], g1[r]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cq = (r & 3) + 8 * (r >> 2);
+                s[r] = __uint_as_float(jqs > cq ? (got[r] & 0xffff0000u) : (got[r] << 16));
             }
         }
 #pragma unroll
