@@ -220,10 +220,11 @@ def test_streaming_config_chunk_mask_is_cached_and_equals_the_tensor_mask(monkey
 
 
 @pytest.mark.parametrize("H,L,K,mk,B", [(2, 70, 128, "none", 2), (8, 500, 410, "none", 2), (1, 129, 16, "band", 3), (2, 512, 64, "causal", 1), (1, 1, 8, "none", 2),
-                                        (2, 33, 64, "chunk", 2)])
+                                        (2, 33, 64, "chunk", 2), (2, 700, 64, "none", 2), (1, 1100, 410, "band", 1), (2, 513, 600, "causal", 1)])
 def test_one_pass_position_gradients_vs_the_gemm_launches(H, L, K, mk, B, monkeypatch):
     """attn_dqde_kernel (one workgroup per (b, h): dq = dS k + dG E, dE, dc and d r_w_bias from ONE pass over the two bf16 slabs of the
-    attention backward kernel, k / E slices resident as MFMA fragments, dE rows resident as accumulators) against the round-2 launches
+    attention backward kernel, k / E slices resident as MFMA fragments, dE rows resident as accumulators; L > 512: one workgroup per group of
+    512 columns, f32 partial dq rows summed by a second launch) against the round-2 launches
     (two transposes, the dual-product dq GEMM, the dE GEMM): the same bf16 operands summed in another order - dq is rounded to bf16 once
     in both - so dx and every gradient agree to bf16 rounding; both sit at the same distance from the float64 oracle."""
     from tt.encoder import BaseEncoder

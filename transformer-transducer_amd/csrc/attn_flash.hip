@@ -2162,6 +2162,7 @@ struct PosGradParams {
     float* dcT;                         // += : dcT[h L + p]
     float* gu;                          // += : gu[h 64 + d]  (d r_w_bias)
     int B, L, H;
+    float* part;                        // column groups (L > 512): f32 partial dq rows part[((group B + b) L + i) H 64 + h 64 + d] instead of dq16
     int dbg;                            // timing experiments (TTMI_PG_DEBUG): 1 no final atomics, 2 no table loads, 4 no main loop, 8 no slab loads
 };
 constexpr int PG_TILE = 32 * 64 * 2;
@@ -2176,7 +2177,15 @@ __global__ __launch_bounds__(512, 1) void attn_dqde_kernel(const PosGradParams p
     char* gtile = smem + 8 * PG_SLOT * 4 + 8 * PG_TILE + wave * PG_TILE;      // ... and of dG (swizzled Tile<64> images)
     char* qtiles = smem + 8 * PG_SLOT * 4 + 16 * PG_TILE;
     const int z = blockIdx.x, b = z / p.H, h = z % p.H, L = p.L, ldp = p.ldp;
-    const int c0 = 64 * wave;
+#ifdef TTMI_STAMPS
+    const bool stamp_on = (p.dbg & 64) && blockIdx.x == 5 && tid == 0;
+    int stamp_n = 0;
+    STAMP(0);
+    STAMP_NEXT();
+#endif
+    // sequences longer than 512: blockIdx.y = column group of 512 (keys of dS, table rows of dG); a group's dq is a partial sum, written in
+    // f32 and summed over the groups by dq_group_sum_kernel; dE / dc rows belong to exactly one group
+    const int c0 = 512 * (int)blockIdx.y + 64 * wave;
     const bf16_t* kb = p.k + (long)b * L * p.ld_kv + h * 64;
     const bf16_t* eb = p.e16 + h * 64;
     const bf16_t* qb = p.qp + (long)b * L * p.ld_qp + h * 64;
@@ -2262,14 +2271,18 @@ __global__ __launch_bounds__(512, 1) void attn_dqde_kernel(const PosGradParams p
     __syncthreads();                                // (also: every wave is done with its slot as a table image)
     int cur = 0;
     for (int i0 = 0; i0 < ((p.dbg & 4) ? 0 : L); i0 += 32) {
+        STAMP(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this block's dS image and dG registers (issued one block ago)
+        STAMP(1);
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<u32x4_t*>(gtile + (8 * q4 + lrow) * 128 + lpos * 16) = rg[q4];
         bf16x8 a[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) a[ks] = *reinterpret_cast<const bf16x8*>(stile + T::off(row, 2 * ks + hh));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers: the image may be overwritten
+        STAMP(2);
         if (i0 + 32 < L) { fetch(i0 + 32); load_q(i0 + 32); }
+        STAMP(3);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {             // one 32-column half of the block at a time: 16 accumulator registers, not 32
             f32x16 acc;
@@ -2293,7 +2306,9 @@ __global__ __launch_bounds__(512, 1) void attn_dqde_kernel(const PosGradParams p
             for (int g4 = 0; g4 < 4; ++g4)
                 *reinterpret_cast<float4*>(sl + 8 * g4) = make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
         }
+        STAMP(4);
         __syncthreads();
+        STAMP(5);
         {
             const int d = tid & 63, m0 = 4 * (tid >> 6);           // this thread: column d, rows m0 ..+3; a wave = 4 whole rows of 128 bytes
             float4 sum = *reinterpret_cast<const float4*>(slots + d * 36 + m0);
@@ -2302,12 +2317,22 @@ __global__ __launch_bounds__(512, 1) void attn_dqde_kernel(const PosGradParams p
                 const float4 v = *reinterpret_cast<const float4*>(slots + w * PG_SLOT + d * 36 + m0);
                 sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
             }
+            if (p.part) {                                  // (workgroup-uniform)
+                float* pr = p.part + (((long)blockIdx.y * p.B + b) * L + i0 + m0) * ((long)p.H * 64) + h * 64 + d;
+                const long rp = (long)p.H * 64;
+                if (i0 + m0 < L) pr[0] = sum.x;
+                if (i0 + m0 + 1 < L) pr[rp] = sum.y;
+                if (i0 + m0 + 2 < L) pr[2 * rp] = sum.z;
+                if (i0 + m0 + 3 < L) pr[3 * rp] = sum.w;
+            } else {
             const int so = i0 * ldo2;
             __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16(sum.x), rs_o, vo, so, 0);
             __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16(sum.y), rs_o, vo, so + ldo2, 0);
             __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16(sum.z), rs_o, vo, so + 2 * ldo2, 0);
             __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16(sum.w), rs_o, vo, so + 3 * ldo2, 0);
+            }
         }
+        STAMP(6);
         const char* qt = qtiles + cur * PG_TILE;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -2319,6 +2344,7 @@ __global__ __launch_bounds__(512, 1) void attn_dqde_kernel(const PosGradParams p
                 acc_e[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, q1, acc_e[mt][1], 0, 0, 0);
             }
         }
+        STAMP(7);
         // dc: 8 rows x 4 columns of the dG image per lane and block (8-byte reads); the four row groups meet once, after the loop
         {
             const int cg = lane & 15, r8 = 8 * (lane >> 4);
@@ -2329,10 +2355,17 @@ __global__ __launch_bounds__(512, 1) void attn_dqde_kernel(const PosGradParams p
                 dc4[2] += __uint_as_float(w.y << 16); dc4[3] += __uint_as_float(w.y & 0xffff0000u);
             }
         }
+        STAMP(8);
         if (i0 + 32 < L) park_q(cur ^ 1);
         cur ^= 1;
         __syncthreads();
+        STAMP(9);
+        STAMP_NEXT();
     }
+#ifdef TTMI_STAMPS
+    stamp_n = 20;
+    STAMP(0);
+#endif
     // one flush per (b, h): rows of the tables this wave owns
     if (p.dbg & 1) return;
 #pragma unroll
@@ -2360,13 +2393,33 @@ __global__ __launch_bounds__(512, 1) void attn_dqde_kernel(const PosGradParams p
     }
 }
 
-bool attn_dqde_supported(int Dh, int L, long ldp) { return Dh == 64 && ldp <= 512 && ldp % 8 == 0 && L >= 1; }
+// dq16 rows = bf16(sum over the column groups of their f32 partial rows): four consecutive d per thread
+__global__ __launch_bounds__(256) void dq_group_sum_kernel(const float* __restrict__ part, int ngroup, long rows, int hd, bf16_t* __restrict__ dq16, long ld_dq) {
+    const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= rows * hd) return;
+    const long r = e / hd;
+    const int c = (int)(e - r * hd);
+    float4 acc = *reinterpret_cast<const float4*>(part + e);
+    for (int g = 1; g < ngroup; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(part + (long)g * rows * hd + e);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    uint2 w;
+    w.x = cvt_pk2(acc.x, acc.y);
+    w.y = cvt_pk2(acc.z, acc.w);
+    *reinterpret_cast<uint2*>(dq16 + r * ld_dq + c) = w;
+}
+
+bool attn_dqde_supported(int Dh, int L, long ldp) { return Dh == 64 && ldp <= 8 * 512 && ldp % 8 == 0 && L >= 1; }
+int attn_dqde_groups(long ldp) { return (int)((ldp + 511) / 512); }
 
 int attn_dqde(const bf16_t* dS16, const bf16_t* dG16, long slab16, long ldp, const bf16_t* k, long ld_kv, const bf16_t* e16, long ld_e,
               const bf16_t* qp, long ld_qp, bf16_t* dq16, long ld_dq, float* dE, long ld_de, float* dcT, float* gu, int B, int L, int H,
-              hipStream_t st) {
+              hipStream_t st, float* part) {
     TTMI_REQUIRE(dS16 && dG16 && k && e16 && qp && dq16 && dE && dcT && gu && B > 0 && H > 0 && attn_dqde_supported(64, L, ldp),
                  "attn_dqde: bad arguments");
+    const int ngroup = attn_dqde_groups(ldp);
+    TTMI_REQUIRE(ngroup == 1 || (part && aligned16(part)), "attn_dqde: sequences longer than 512 need the partial-sum workspace (groups x B x L x H x 64 floats)");
     TTMI_REQUIRE(aligned16(dS16) && aligned16(dG16) && aligned16(qp) && (slab16 * 2) % 16 == 0 && ld_qp % 8 == 0 && ld_dq % 4 == 0 &&
                  (reinterpret_cast<uintptr_t>(dq16) & 7) == 0, "attn_dqde: alignment");
     static bool enabled = false;
@@ -2380,11 +2433,17 @@ int attn_dqde(const bf16_t* dS16, const bf16_t* dG16, long slab16, long ldp, con
     PosGradParams p;
     p.dS16 = dS16; p.dG16 = dG16; p.slab16 = slab16; p.ldp = (int)ldp; p.k = k; p.ld_kv = ld_kv; p.e16 = e16; p.ld_e = ld_e; p.qp = qp; p.ld_qp = ld_qp;
     p.dq16 = dq16; p.ld_dq = ld_dq; p.dE = dE; p.ld_de = ld_de; p.dcT = dcT; p.gu = gu; p.B = B; p.L = L; p.H = H;
+    p.part = ngroup > 1 ? part : nullptr;
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("TTMI_PG_DEBUG"); dbg = e ? atoi(e) : 0; }
     p.dbg = dbg;
-    hipLaunchKernelGGL(attn_dqde_kernel, dim3(B * H), dim3(512), PG_LDS, st, p);
+    hipLaunchKernelGGL(attn_dqde_kernel, dim3(B * H, ngroup), dim3(512), PG_LDS, st, p);
     TTMI_LAUNCH_CHECK("attn_dqde_kernel");
+    if (ngroup > 1) {
+        const long rows = (long)B * L;
+        hipLaunchKernelGGL(dq_group_sum_kernel, dim3(cdiv(rows * H * 64 / 4, 256)), dim3(256), 0, st, part, ngroup, rows, H * 64, dq16, ld_dq);
+        TTMI_LAUNCH_CHECK("dq_group_sum_kernel");
+    }
     return TTMI_OK;
 }
 

@@ -587,8 +587,10 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
                 CK(flash_attn_bwd(fs, st));
                 if (onepass) {
                     const bf16_t* qkv16 = static_cast<const bf16_t*>(c.qkv) + r0 * a.W3;
+                    // (sequences longer than 512: the column groups' f32 partial dq rows live in the f32 dS slab region, unused on this path:
+                    // B H L (L + 1) floats against groups x B L H 64)
                     CK(attn_dqde(w.dS16, w.dG16, w.slab16, w.ldp, qkv16 + a.HD, a.W3, E16, a.HD, qkv16, a.W3, w.dqkv16 + r0 * a.W3, a.W3,
-                                 w.dE, a.HD, w.dcT, g_r_w_bias, nb, L, H, st));
+                                 w.dE, a.HD, w.dcT, g_r_w_bias, nb, L, H, st, w.dS));
                     continue;
                 }
                 // dq = dS k + dG E in ONE launch: both products accumulate into the same tile, the column sums of the first (d r_w_bias) are taken
