@@ -1763,6 +1763,8 @@ __global__ __launch_bounds__(256, BWD2_MINB) void flash_bwd_rel2_kernel(const Fl
         }
         const float* lse_c = lse_s + 32 * par + 4 * hh;
         const float* del_c = del_s + 32 * par + 4 * hh;
+        const int* lo_c = lo_s + 32 * par + 4 * hh;                          // (MK == 4; the interval test is two compares and an OR: `||` compiles to a branch per element)
+        const int* hi_c = hi_s + 32 * par + 4 * hh;
         const int jw = jw0 + 32 * wave;
         // this wave's 32 x 32 tile entirely on one side of the j == i + 1 diagonal, all 32 queries in range: one slab offset pair for the tile
         const bool interior = (i0 + 32 <= L) && (jw + 31 <= i0 || jw >= i0 + 33);
@@ -1775,7 +1777,9 @@ __global__ __launch_bounds__(256, BWD2_MINB) void flash_bwd_rel2_kernel(const Fl
                 float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse_c[cq]));
                 float ds = pr * fmaf(dp[r], p.scale, -del_c[cq]);
                 if constexpr (MK != 0) {
-                    if (MK == 4 ? (j < lo_s[32 * par + q] || j > hi_s[32 * par + q]) : is_masked<MK>(p, b, i0 + q, jc)) { pr = 0.f; ds = 0.f; }
+                    const bool msk = MK == 4 ? (bool)((int)(j < lo_c[cq]) | (int)(j > hi_c[cq])) : is_masked<MK>(p, b, i0 + q, jc);
+                    pr = msk ? 0.f : pr;
+                    ds = msk ? 0.f : ds;
                 }
                 s[r] = pr;
                 dp[r] = ds;
@@ -1792,8 +1796,9 @@ __global__ __launch_bounds__(256, BWD2_MINB) void flash_bwd_rel2_kernel(const Fl
                 float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse_c[cq]));
                 float ds = pr * fmaf(dp[r], p.scale, -del_c[cq]);
                 bool dead = !rowok;
-                if constexpr (MK != 0) dead = dead || (MK == 4 ? (j < lo_s[32 * par + q] || j > hi_s[32 * par + q]) : is_masked<MK>(p, b, min(i0 + q, L - 1), jc));
-                if (dead) { pr = 0.f; ds = 0.f; }
+                if constexpr (MK != 0) dead = (bool)((int)dead | (int)(MK == 4 ? (bool)((int)(j < lo_c[cq]) | (int)(j > hi_c[cq])) : is_masked<MK>(p, b, min(i0 + q, L - 1), jc)));
+                pr = dead ? 0.f : pr;
+                ds = dead ? 0.f : ds;
                 s[r] = pr;
                 dp[r] = ds;
                 const bf16_t d16 = f32_to_bf16(ds);
