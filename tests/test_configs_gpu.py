@@ -304,3 +304,81 @@ def test_c2_full_model_bf16_exp_form_end_to_end(monkeypatch):
     for n, e in errs.items():       # the matrices that hold 90 % of the parameters: no ReLU decision in front of their gradient
         if n.startswith("joint.") or (n.startswith("encoder.") and n.endswith(("qkv_net.weight", "o_net.weight", "CoreNet.3.weight"))):
             assert e < 1.5e-2, (n, e)
+
+
+def test_c2_bf16_loss_error_bound_along_a_training_trajectory(monkeypatch):
+    """The bf16 mode's loss error is a property of the STATE, not only of the initial weights: the C2 model, 25 SGD steps of
+    bench.py's own loop (B = 32, T = 500, U = 50, dropout on, exp-domain loss, clip + SGD), and at the states after 0 / 10 / 25 steps the
+    per-utterance costs of a B = 2 sample in eval mode - the timed form (bf16 encoders, exp-domain joint + loss) - against the float64 oracle on
+    the same weights.  The state after 10 steps is the hard one: the cost has just fallen from ~4450 to ~650 and the logits have grown to ~24,
+    so the same few hundredths of a nat are a several times larger RELATIVE error.  Measured over the rounds' builds (tools/debug/
+    bf16_loss_error.py, profiles/r0*_bf16_loss_error*.log): 2e-6 ... 1.9e-4 per utterance, of which the encoders' bf16 operands alone
+    (oracle joint + lattice on the GPU's encoder states) carry 1e-6 ... 1.9e-4 - systematic weight rounding that does not average out over
+    an alignment's ~550 emissions.  What is asserted is the bound that HOLDS in this mode: 3e-4 per utterance at every state; `north_star`'s
+    1e-4 is met by TTMI_PRECISION=fp32 (test_c2_full_model_fp32_end_to_end: <= 1e-6) and, in this mode, only at some states."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from oracle.rnnt_c import rnnt_loss_c
+    from tt.model import Transducer, _JointLossFn
+    from ttmi.train import FlatModel, FusedOptimizer, GradSync
+    monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(1)
+    model = Transducer(bench.c2_config()).to(dev).train()
+    flat = FlatModel(model)
+    flat.enable_grouped_wgrads()
+    flat.enable_shadows()
+    sync = GradSync(flat)
+    opt = FusedOptimizer(flat, kind="sgd", lr=0.00025, momentum=0.9, max_grad_norm=200.0)
+    B, T, U, V, d = 32, 500, 50, 4334, 512
+    g = torch.Generator(device=dev).manual_seed(1234)
+    feats = torch.randn(B, T, 80, device=dev, generator=g)
+    proj = torch.randn(80, d, device=dev, generator=torch.Generator(device=dev).manual_seed(7)) / 80 ** 0.5
+    targets = torch.randint(1, V, (B, U), device=dev, generator=g)
+    ilen = torch.full((B,), T, dtype=torch.int32, device=dev)
+    tlen = torch.full((B,), U, dtype=torch.int32, device=dev)
+    inputs = (feats.reshape(-1, 80) @ proj).reshape(B, T, d).contiguous()
+
+    def errors():
+        """(timed form, encoder states only): worst relative cost error of the B = 2 sample against the float64 oracle"""
+        n = 2
+        model.eval()
+        x, y, il, tl = inputs[:n], targets[:n], ilen[:n], tlen[:n]
+        sd64 = {k: (v.detach().cpu().numpy().astype(np.float64) if v.dtype == torch.float32 else v.detach().cpu().numpy())
+                for k, v in model.state_dict().items()}
+        z64, _ = O.transducer_fwd(x.cpu().numpy().astype(np.float64), y.cpu().numpy(), sd64)
+        want = rnnt_loss_c(z64.astype(np.float32), y.cpu().numpy(), il.cpu().numpy(), tl.cpu().numpy(), want_grad=False)[1].astype(np.float64)
+        with torch.no_grad():
+            enc_s, dec_s = model._encode(x, y)
+            j = model.joint
+            stt = j.exp_shift_state(dev)
+            if not stt.valid:
+                stt.set(0.0)
+            costs = _JointLossFn.apply(enc_s, dec_s, j.forward_layer.weight, j.forward_layer.bias, j.project_layer.weight, j.project_layer.bias,
+                                       y.int().contiguous(), il, tl, 1, n, "none", stt, False)
+            torch.cuda.synchronize()
+            assert int(stt.flag) == 0
+            z, _ = O.joint_fwd(enc_s.double().cpu().numpy(), dec_s.double().cpu().numpy(), sd64)
+        c_enc = rnnt_loss_c(z.astype(np.float32), y.cpu().numpy(), il.cpu().numpy(), tl.cpu().numpy(), want_grad=False)[1].astype(np.float64)
+        model.train()
+        return (float(np.max(np.abs(costs.double().cpu().numpy() - want) / want)), float(np.max(np.abs(c_enc - want) / want)), float(want.mean()))
+
+    done, seen = 0, []
+    for stop in (0, 10, 25):
+        while done < stop:
+            flat.zero_grad()
+            sync.start_step()
+            loss = model.loss(inputs, ilen, targets, tlen, exp_domain=True)
+            loss.backward()
+            sync.finish()
+            opt.step()
+            done += 1
+        torch.cuda.synchronize()
+        seen.append((stop,) + errors())
+    print("bf16 loss error along the trajectory (worst of 2 utterances; timed form / encoder states only / oracle cost): "
+          + "; ".join("step %d: %.2e / %.2e / %.0f" % s for s in seen))
+    for stop, e_timed, e_enc, cost in seen:
+        assert e_timed < 3e-4 and e_enc < 3e-4, (stop, e_timed, e_enc)
+    assert seen[-1][3] < 0.25 * seen[0][3]              # the loop did train (4450 -> ~430)
