@@ -181,7 +181,7 @@ def decode_mode(args):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_decode
     prec = "fp32" if "--precision" not in sys.argv else args.precision      # token parity is an fp32 claim
-    out, model, inputs, lens, hyps = bench_decode.run(8, args.T, args.emit_rate, prec)
+    out, model, inputs, lens, hyps = bench_decode.run(args.batch, args.T, args.emit_rate, prec)      # (default: 32 utterances, BASELINE configs[1]'s batch)
     if not args.no_cpu_baseline:
         from oracle import tt_oracle as O
         n = args.cpu_utts

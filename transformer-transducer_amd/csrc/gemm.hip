@@ -420,7 +420,12 @@ int ttmi_launch_gemm(const GemmDesc& d, hipStream_t st) {
     };
     p.vecA = vec_ok(d.A, ea, d.lda, d.sA1, d.sA2);
     p.vecB = vec_ok(d.B, eb, d.ldb, d.sB1, d.sB2);
-    if (!bf16c && g_skinny_rows > 0 && d.M <= g_skinny_rows && (d.flags & GEMM_A_KMAJOR) && !(d.flags & GEMM_ATOMIC) && d.splitk == 1 &&
+    // ... and products of up to 2048 rows whose 128 x 128 tiling would leave more than half of the CUs without a workgroup: the batched greedy
+    // decoder's label-encoder calls (B x history rows, 512 ... 1536 columns: 16 ... 48 such tiles, each walking K in 16-wide barrier steps
+    // for ~100 us; 32 x 32 tiles with the reduction split over a workgroup's waves: ~10 us.  decode_batch at 8 utterances: 26 -> 63 utt/s)
+    const long tiles128 = (long)cdiv(d.N, BN) * cdiv(d.M, BM) * d.nz1 * d.nz2;
+    const bool few_tiles = d.M <= 2048 && tiles128 < 128;
+    if (!bf16c && g_skinny_rows > 0 && (d.M <= g_skinny_rows || few_tiles) && (d.flags & GEMM_A_KMAJOR) && !(d.flags & GEMM_ATOMIC) && d.splitk == 1 &&
         d.c_dtype == DT_F32 && d.K > 0 && (long)d.nz1 * d.nz2 <= 65535) {
         dim3 sgrid(cdiv(d.N, SK_T), cdiv(d.M, SK_T), d.nz1 * d.nz2);
         if (d.flags & GEMM_B_KMAJOR) hipLaunchKernelGGL(gemm_skinny_f32_kernel<true>, sgrid, dim3(NT), 0, st, p);
