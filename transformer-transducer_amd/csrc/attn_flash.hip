@@ -1013,19 +1013,21 @@ __global__ __launch_bounds__(512, 2) void flash_fwd_res_kernel(const FlashParams
 // prefetch (checked in the ISA: Sx32 per step) - and hands the registers over through an empty asm with "+v" operands.  (A first version
 // waited for vmcnt(63), taking a step's stores for 64: that guaranteed nothing - the loads were merely always back by then, until B = 8 x
 // L = 2000 under the full model's memory traffic let one land after the loop, in registers that by then held an address: a rare illegal access.)
+// (outputs are early-clobber: the destination registers must not double as the address operand, and nothing may be allocated over them
+// between the issue and the hand-over after the wait - the "+v" hand-over keeps them live, the compiler never sees a use before it)
 __device__ __forceinline__ u32x4_t ld16_async(const void* p) {
     u32x4_t v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory");
     return v;
 }
 __device__ __forceinline__ float ld4f_async(const void* p) {
     float v;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    asm volatile("global_load_dword %0, %1, off" : "=&v"(v) : "v"(p) : "memory");
     return v;
 }
 __device__ __forceinline__ int ld4i_async(const void* p) {
     int v;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    asm volatile("global_load_dword %0, %1, off" : "=&v"(v) : "v"(p) : "memory");
     return v;
 }
 template <int DH, int MK>
@@ -1459,17 +1461,17 @@ __device__ __forceinline__ void lds_dma16_s(const void* base, unsigned off, unsi
 }
 __device__ __forceinline__ u32x4_t ld16_async_s(const void* base, unsigned off) {
     u32x4_t v;
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(v) : "v"(off), "s"(base) : "memory");
     return v;
 }
 __device__ __forceinline__ float ld4f_async_s(const void* base, unsigned off) {
     float v;
-    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=&v"(v) : "v"(off), "s"(base) : "memory");
     return v;
 }
 __device__ __forceinline__ int ld4i_async_s(const void* base, unsigned off) {
     int v;
-    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
+    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=&v"(v) : "v"(off), "s"(base) : "memory");
     return v;
 }
 #ifdef TTMI_STAMPS

@@ -62,7 +62,17 @@ int wgrad(const float* dY, const float* X, float* gW, int M, int N, int K, long 
 // ---- intra-call concurrency: weight-gradient GEMMs feed nothing downstream inside a backward call, so they are forked onto a
 // library-owned side stream (one per caller stream) and joined before the call returns (scratch buffers they read are reused by
 // the next call).  ttmi_set_option(3, 0) disables it.
-const unsigned* g_drop_salt = nullptr;     // ttmi_set_dropout_salt: device word mixed into every dropout seed at kernel start (graph replays)
+// ttmi_set_dropout_salt: device word mixed into every dropout seed at kernel start (graph replays).  One slot per device: a word lives in ONE
+// device's memory, and a process that drives several devices must not hand it to kernels of another one (the slot is looked up by the
+// calling thread's current device, at set time and at every launch site).
+constexpr int MAX_SALT_DEV = 16;
+const unsigned* g_drop_salts[MAX_SALT_DEV] = {};
+static inline const unsigned* drop_salt_here() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_SALT_DEV) return nullptr;
+    return g_drop_salts[dev];
+}
+#define g_drop_salt drop_salt_here()
 int g_fork_wgrad = 1;
 int g_split_weights = 0;        // ttmi_set_option(13, 1): EXPERIMENT - o_net and CoreNet.3 (the two encoder GEMMs with f32 outputs) add the second term of
                                 // their weight's bf16 split, as the joint's input layer does; needs weight shadows (the free plain-copy region holds the term)
@@ -1265,7 +1275,9 @@ int ttmi_stream_reserve_cus(void* stream, int n) {
 // step captured as a HIP graph, baked into the kernel arguments; bumping this word on the device before each replay gives every step
 // new masks.  Forward and backward of one step must see the same value.  Process-wide; nullptr (default) = seeds used as passed.
 int ttmi_set_dropout_salt(const unsigned* salt) {
-    g_drop_salt = salt;
+    int dev = 0;
+    TTMI_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_SALT_DEV, "set_dropout_salt: no current device / more than %d devices", MAX_SALT_DEV);
+    g_drop_salts[dev] = salt;
     return TTMI_OK;
 }
 
