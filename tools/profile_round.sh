@@ -20,11 +20,11 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- p
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-two-call --no-fp32-form --no-graph-form > $OUT/sq.log 2>&1
 F=profiles/${TAG}_pmc_joint_kernels.txt
 echo "# rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline ($TAG build $COMMIT; three separate passes; per-launch values, KB as reported)" > $F
-for k in "gemm_nt_bf16_v8_kernel<unsigned short, 3>" "gemm_nt_bf16_v8_kernel<unsigned short, 4>" "gemm_tn_bf16_v8_kernel<2>" "rnnt_prep_exp_kernel" "rnnt_scale_exp_kernel" "gemm_nt_bf16_v8_kernel<unsigned short, 1>" "gemm_tn_bf16_v8_kernel<1>" "rnnt_lse_kernel" "rnnt_grad_kernel" "flash_bwd_rel_kernel<64, 0>" "flash_fwd_rel_kernel<64, 0>" "attn_dqde_kernel" "rnnt_lattice_lds_kernel" "ln_bwd_fused_kernel<2>" "ln_fwd_kernel"; do
+for k in "gemm_nt_bf16_v8_kernel<unsigned short, 3>" "gemm_nt_bf16_v8_kernel<unsigned short, 4>" "gemm_tn_bf16_v8_kernel<2>" "rnnt_prep_exp_kernel" "rnnt_scale_exp_kernel" "gemm_nt_bf16_v8_kernel<unsigned short, 1>" "gemm_tn_bf16_v8_kernel<1>" "rnnt_lse_kernel" "rnnt_grad_kernel" "flash_bwd_rel2_kernel<0>" "flash_fwd_res_kernel<0>" "attn_dqde_kernel" "rnnt_lattice_lds_kernel" "ln_bwd_fused_kernel<2>" "ln_fwd_kernel"; do
   python3 tools/pmc_summary.py $OUT/fetch FETCH "$k" | sort | awk 'NR%4==1' >> $F
   python3 tools/pmc_summary.py $OUT/write WRITE "$k" | sort | awk 'NR%4==1' >> $F
 done
-python3 tools/pmc_summary.py $OUT/sq SQ "gemm_nt_bf16_v8_kernel<unsigned short, 3>" "gemm_nt_bf16_v8_kernel<unsigned short, 4>" "gemm_tn_bf16_v8_kernel<2>" "gemm_nt_bf16_v8_kernel<unsigned short, 1>" "gemm_tn_bf16_v8_kernel<1>" | sort >> $F
+python3 tools/pmc_summary.py $OUT/sq SQ "gemm_nt_bf16_v8_kernel<unsigned short, 3>" "gemm_nt_bf16_v8_kernel<unsigned short, 4>" "gemm_tn_bf16_v8_kernel<2>" "gemm_nt_bf16_v8_kernel<unsigned short, 1>" "gemm_tn_bf16_v8_kernel<1>" "flash_bwd_rel2_kernel<0>" "flash_fwd_res_kernel<0>" "attn_dqde_kernel" | sort >> $F
 python3 tools/update_pmc_json.py $OUT/fetch $OUT/write $OUT/sq $COMMIT $TAG > $OUT/pmc_json.log
 cp profiles/${TAG}_* profiles/pmc_joint_projection.json gpurun_out/ 2>/dev/null || true
 tail -3 $OUT/pmc_json.log
