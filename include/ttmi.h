@@ -293,7 +293,8 @@ int ttmi_stream_reserve_cus(void* stream, int n);
  * 9: 1 = one-wave lattice kernel (round 2) instead of the workgroup-per-utterance one; 10: batch slices of the attention backward; 11: 1 = dq / dE /
  * dc by the round-2 GEMM launches instead of attn_dqde_kernel; 12: workgroups of the grid-stride LayerNorm backward kernels; 13: 1 = o_net and
  * CoreNet.3 add the second term of their weight's bf16 split (needs weight shadows; lower bf16 loss error, +3 % step time); 14: 0 = the tiled attention
- * forward kernel instead of the one-workgroup-per-head one; 15: 1 = the round-3 attention backward kernel instead of flash_bwd_rel2_kernel */
+ * forward kernel instead of the one-workgroup-per-head one; 15: 1 = the round-3 attention backward kernel instead of flash_bwd_rel2_kernel;
+ * 16: 1 = the position-table gradients go through dE / dc and a relpos_scatter launch (round 3) instead of straight out of attn_dqde_kernel */
 int ttmi_set_option(int key, int value);
 int ttmi_dropout_apply(const float* in, long n, float p, unsigned seed, float* out, void* stream);
 int ttmi_probe_arm(int slot);

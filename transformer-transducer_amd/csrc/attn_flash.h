@@ -52,12 +52,13 @@ bool flash_supported(int Dh, long ld_qu, long ld_kv, long ld_o);
 // dq (bf16, content + position), dE, dc and d r_w_bias from the two bf16 dS slabs of flash_attn_bwd in one pass (one workgroup per (b, h),
 // Dh = 64, ldp <= 4096): see attn_dqde_kernel.  dE / dcT / gu are accumulated into (atomics); dq16 rows are overwritten.  Sequences longer than
 // 512 run one workgroup per (b, h, group of 512 columns); the groups' partial dq rows go through `part` (attn_dqde_groups(ldp) * B * L * H * 64
-// floats, 16-byte aligned) and are summed by a second small launch.
+// floats, 16-byte aligned) and are summed by a second small launch.  With g_emb / g_bias (the gradients of r_emb [K, H, 64] and r_bias [K, H]) the
+// table-gradient rows go straight into them (effective row p -> table row max(0, p + K - L)): dE / dcT stay untouched, no relpos_scatter follows.
 bool attn_dqde_supported(int Dh, int L, long ldp);
 int attn_dqde_groups(long ldp);
 int attn_dqde(const bf16_t* dS16, const bf16_t* dG16, long slab16, long ldp, const bf16_t* k, long ld_kv, const bf16_t* e16, long ld_e,
               const bf16_t* qp, long ld_qp, bf16_t* dq16, long ld_dq, float* dE, long ld_de, float* dcT, float* gu, int B, int L, int H,
-              hipStream_t st, float* part = nullptr);
+              hipStream_t st, float* part = nullptr, float* g_emb = nullptr, float* g_bias = nullptr, int K = 0);
 int flash_attn_fwd(const FlashParams& p, hipStream_t st);
 void flash_set_resident(int v);     // 1 (default): one workgroup per head with the table resident in LDS where it applies; 0: round-3 kernels
 void flash_set_bwd_gen(int v);      // 2 (default): flash_bwd_rel2_kernel (LDS-DMA staging, register skew, one barrier per step); 1: the round-3 kernel

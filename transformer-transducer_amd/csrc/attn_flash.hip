@@ -2170,6 +2170,8 @@ struct PosGradParams {
     float* gu;                          // += : gu[h 64 + d]  (d r_w_bias)
     int B, L, H;
     float* part;                        // column groups (L > 512): f32 partial dq rows part[((group B + b) L + i) H 64 + h 64 + d] instead of dq16
+    float* g_emb; float* g_bias; int K; // if set: the flush goes straight into the table gradients r_emb [K, H, 64] / r_bias [K, H] (row p of the
+                                        // effective table = table row max(0, p + K - L)); dE / dcT are not touched and no relpos_scatter launch follows
     int dbg;                            // timing experiments (TTMI_PG_DEBUG): 1 no final atomics, 2 no table loads, 4 no main loop, 8 no slab loads
 };
 constexpr int PG_TILE = 32 * 64 * 2;
@@ -2375,6 +2377,51 @@ __global__ __launch_bounds__(512, 1) void attn_dqde_kernel(const PosGradParams p
 #endif
     // one flush per (b, h): rows of the tables this wave owns
     if (p.dbg & 1) return;
+    if (p.g_emb) {
+        // straight into the table gradients: effective row pr is table row pr + K - L; the rows below L - K all ARE table row 0 (sequences
+        // longer than the table) and are summed in the wave before they leave - one add per wave and column, not one per row
+        const int HD = p.H * 64, shift = p.K - L;
+        float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pr = c0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (pr < L) {
+                    const int e = pr + shift;
+                    if (e <= 0) { f0 += acc_e[mt][0][r]; f1 += acc_e[mt][1][r]; }
+                    else {
+                        atomicAdd(p.g_emb + (long)e * HD + h * 64 + row, acc_e[mt][0][r]);
+                        atomicAdd(p.g_emb + (long)e * HD + h * 64 + 32 + row, acc_e[mt][1][r]);
+                    }
+                }
+            }
+        if (c0 + shift <= 0 && c0 < L) {                     // (wave-uniform: this wave owns rows that fold onto table row 0)
+            f0 += __shfl_xor(f0, 32, 64);
+            f1 += __shfl_xor(f1, 32, 64);
+            if (hh == 0) {
+                atomicAdd(p.g_emb + h * 64 + row, f0);
+                atomicAdd(p.g_emb + h * 64 + 32 + row, f1);
+            }
+        }
+        float cf = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = dc4[e];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int pc = c0 + 4 * (lane & 15) + e;
+            if (lane < 16 && pc < L) {
+                if (pc + shift <= 0) cf += v;
+                else atomicAdd(p.g_bias + (long)(pc + shift) * p.H + h, v);
+            }
+        }
+        if (c0 + shift <= 0 && c0 < L) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) cf += __shfl_xor(cf, o, 64);
+            if (lane == 0) atomicAdd(p.g_bias + h, cf);
+        }
+    } else {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -2392,6 +2439,7 @@ __global__ __launch_bounds__(512, 1) void attn_dqde_kernel(const PosGradParams p
         v += __shfl_xor(v, 32, 64);
         const int pc = c0 + 4 * (lane & 15) + e;
         if (lane < 16 && pc < L) atomicAdd(p.dcT + (long)h * L + pc, v);
+    }
     }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -2422,7 +2470,7 @@ int attn_dqde_groups(long ldp) { return (int)((ldp + 511) / 512); }
 
 int attn_dqde(const bf16_t* dS16, const bf16_t* dG16, long slab16, long ldp, const bf16_t* k, long ld_kv, const bf16_t* e16, long ld_e,
               const bf16_t* qp, long ld_qp, bf16_t* dq16, long ld_dq, float* dE, long ld_de, float* dcT, float* gu, int B, int L, int H,
-              hipStream_t st, float* part) {
+              hipStream_t st, float* part, float* g_emb, float* g_bias, int K) {
     TTMI_REQUIRE(dS16 && dG16 && k && e16 && qp && dq16 && dE && dcT && gu && B > 0 && H > 0 && attn_dqde_supported(64, L, ldp),
                  "attn_dqde: bad arguments");
     const int ngroup = attn_dqde_groups(ldp);
@@ -2441,6 +2489,8 @@ int attn_dqde(const bf16_t* dS16, const bf16_t* dG16, long slab16, long ldp, con
     p.dS16 = dS16; p.dG16 = dG16; p.slab16 = slab16; p.ldp = (int)ldp; p.k = k; p.ld_kv = ld_kv; p.e16 = e16; p.ld_e = ld_e; p.qp = qp; p.ld_qp = ld_qp;
     p.dq16 = dq16; p.ld_dq = ld_dq; p.dE = dE; p.ld_de = ld_de; p.dcT = dcT; p.gu = gu; p.B = B; p.L = L; p.H = H;
     p.part = ngroup > 1 ? part : nullptr;
+    TTMI_REQUIRE(!g_emb || (g_bias && K >= 1), "attn_dqde: direct table-gradient flush needs r_emb, r_bias gradients and the table length");
+    p.g_emb = g_emb; p.g_bias = g_bias; p.K = K;
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("TTMI_PG_DEBUG"); dbg = e ? atoi(e) : 0; }
     p.dbg = dbg;

@@ -77,6 +77,7 @@ int g_fork_wgrad = 1;
 int g_split_weights = 0;        // ttmi_set_option(13, 1): EXPERIMENT - o_net and CoreNet.3 (the two encoder GEMMs with f32 outputs) add the second term of
                                 // their weight's bf16 split, as the joint's input layer does; needs weight shadows (the free plain-copy region holds the term)
 int g_posgrad_gemms = 0;        // ttmi_set_option(11, 1): dq / dE by the round-2 GEMM launches instead of attn_dqde_kernel (A/B)
+int g_scatter_launch = 0;       // ttmi_set_option(16, 1): attn_dqde_kernel leaves dE / dc and relpos_scatter folds them (round 3; A/B)
 int g_attn_slices = 1;          // ttmi_set_option(10, n): attention backward in n batch slices (see attn_bwd_impl)
 int g_gemm_slab = 0;            // ttmi_set_option(5, 1): position-term slab by the batched GEMM (A/B measurements)
 struct SideCtx {
@@ -541,6 +542,7 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
     }
     const bool fused = attn_fused(fast, a);
     const bool fastpos = fused && Dh % 8 == 0;      // position/content products on the glds kernels (K-major transposed k, E)
+    bool direct_tables = false;
     // Batch slices (ttmi_set_option(10, n)): the attention backward kernel leaves dS twice in bf16 ([B, H, L, ldp] each: 2 x 129 MB at C2) and
     // the dq / dE products read them straight back.  Cut into n slices of the batch - kernel, dq product, dE product per slice, over the SAME
     // slab region - the slabs of a slice (2 x 129 / n MB) are still in the 256 MB Infinity Cache when their readers run.
@@ -551,6 +553,9 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
         const int bper = (B + nslice - 1) / nslice;
         // one pass over the slabs for dq, dE, dc and d r_w_bias (attn_dqde_kernel) where its shape fits, the round-2 GEMM launches otherwise
         const bool onepass = fastpos && !g_posgrad_gemms && attn_dqde_supported(Dh, L, w.ldp);
+        // ... which then also folds its table-gradient rows straight into r_emb / r_bias' gradients (no dE / dc round trip, no relpos_scatter
+        // launch: 18 x ~20 us per C2 step), unless so many rows clamp onto table row 0 that the chunked fold is the better tool (C5)
+        direct_tables = onepass && L - K < 256 && !g_scatter_launch;
         // the small zero fills of this pass (dG row 0 of every slab, the dE / dc accumulators) ride in the delta kernel's launch where one
         // launch covers the batch; sliced runs keep the memsets (the accumulators must survive from slice to slice)
         const bool fillz = fastpos && nslice == 1;
@@ -600,7 +605,7 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
                     // (sequences longer than 512: the column groups' f32 partial dq rows live in the f32 dS slab region, unused on this path:
                     // B H L (L + 1) floats against groups x B L H 64)
                     CK(attn_dqde(w.dS16, w.dG16, w.slab16, w.ldp, qkv16 + a.HD, a.W3, E16, a.HD, qkv16, a.W3, w.dqkv16 + r0 * a.W3, a.W3,
-                                 w.dE, a.HD, w.dcT, g_r_w_bias, nb, L, H, st, w.dS));
+                                 w.dE, a.HD, w.dcT, g_r_w_bias, nb, L, H, st, w.dS, direct_tables ? g_r_emb : nullptr, direct_tables ? g_r_bias : nullptr, K));
                     continue;
                 }
                 // dq = dS k + dG E in ONE launch: both products accumulate into the same tile, the column sums of the first (d r_w_bias) are taken
@@ -677,7 +682,7 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
         if (fused) CK(colsum_bf16(w.dG16, w.ldp, L, L, w.dcT, st, B, H, H * w.slab16, w.slab16, L));
         else CK(colsum(w.dS + 1, L + 1, L, L, B, H, H * a.slab, a.slab, 0, L, w.dcT, st));
     }
-    CK(relpos_scatter(w.dE, w.dcT, K, L, H, Dh, g_r_emb, g_r_bias, st));
+    if (!direct_tables) CK(relpos_scatter(w.dE, w.dcT, K, L, H, Dh, g_r_emb, g_r_bias, st));
     // 14. gWqkv += dqkv^T x ; 15. dx += dqkv Wqkv
     if (fast) {
         if (!fastpos) CK(convert_bf16(w.dqkv, w.dqkv16, a.BL * a.W3, st));      // fastpos: dq / dK / dV were written in bf16 by their producers
@@ -1284,7 +1289,8 @@ int ttmi_set_dropout_salt(const unsigned* salt) {
 // process-wide switches for A/B measurements.  key 0: 1 = disable the fused attention kernels (bf16 pipeline only);
 // key 1: throughput-GEMM generation (see gemm_fast.hip); key 2: flash-kernel timing switches; key 3: 0 = no wgrad fork
 int ttmi_set_option(int key, int value) {
-    TTMI_REQUIRE(key >= 0 && key <= 15, "set_option: unknown key %d", key);
+    TTMI_REQUIRE(key >= 0 && key <= 16, "set_option: unknown key %d", key);
+    if (key == 16) { g_scatter_launch = value; return TTMI_OK; }
     if (key == 15) { flash_set_bwd_gen(value); return TTMI_OK; }
     if (key == 14) { flash_set_resident(value); return TTMI_OK; }
     if (key == 13) { g_split_weights = value; return TTMI_OK; }
