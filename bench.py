@@ -243,6 +243,8 @@ def main():
     ap.add_argument("--fused-loss", action="store_true", help="same as --loss-form fused")
     ap.add_argument("--no-two-call", action="store_true", help="skip the secondary timings of the other loss forms (profiling runs: one loss form per trace)")
     ap.add_argument("--no-fp32-form", action="store_true", help="skip the secondary timing of the fp32 mode (the 1e-4 parity path)")
+    ap.add_argument("--graph-form", action="store_true", help="multi-rank runs: also time the secondary graph_replay_form (every rank captures the step incl. its all-reduces; "
+                    "default on one rank only, see the comment at its call site)")
     ap.add_argument("--no-graph-form", action="store_true", help="skip the secondary timing of the step replayed from a captured HIP graph (ttmi.train.GraphedStep)")
     ap.add_argument("--fp32-steps", type=int, default=5, help="steps of the fp32-mode secondary timing (at most --steps)")
     ap.add_argument("--loss-chunk", type=int, default=0, help="utterances per chunk of the fused loss (0 = default: logits chunk <= 2 GB)")
@@ -410,18 +412,28 @@ def main():
             eager_two_call = secondary("two-call-eager", args.precision, args.steps, max(1, args.warmup), eager_ms)
         if form != "exp":
             explicit_form = secondary("exp", args.precision, args.steps, max(1, args.warmup), explicit_ms)
-    if not args.graph and form != "two-call-eager" and args.precision == "bf16" and not args.no_graph_form:
-        # the same step replayed from ONE captured HIP graph (ttmi.train.GraphedStep): one launch per step instead of ~400 from Python;
-        # with several ranks the graph holds the bucketed all-reduces as well
-        gstep = make_graphed()
-        graph_form = timed_region(lambda timed, i: gstep(), args.steps, 1, world, spread=graph_ms)[0]
-        fence(world)
-        t1 = time.perf_counter()
-        gstep()
-        graph_issue = time.perf_counter() - t1
-        fence(world)
+    graph_error = None
+    # the same step replayed from ONE captured HIP graph (ttmi.train.GraphedStep): one launch per step instead of ~400 from Python; with several
+    # ranks the graph holds the bucketed all-reduces as well.  As a SECONDARY it runs on one rank by default: a capture that fails on some
+    # rank of a multi-rank job (a backend whose collectives cannot be captured - gloo's host-staged all-reduce raises inside the capture -, a
+    # collective library that objects) would take the finished primary measurement down with it or leave the ranks waiting for each other;
+    # `--graph-form` asks for it on N ranks (nccl only), `--graph` makes it the primary region.
+    want_graph = world == 1 or (args.graph_form and args.backend == "nccl")
+    if not args.graph and form != "two-call-eager" and args.precision == "bf16" and not args.no_graph_form and want_graph:
+        try:
+            gstep = make_graphed()
+            graph_form = timed_region(lambda timed, i: gstep(), args.steps, 1, world, spread=graph_ms)[0]
+            fence(world)
+            t1 = time.perf_counter()
+            gstep()
+            graph_issue = time.perf_counter() - t1
+            fence(world)
+            del gstep
+        except Exception as e:      # (one rank: report and carry on - the primary region is already measured)
+            if world > 1:
+                raise
+            graph_form, graph_issue, graph_error = None, None, "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200])
         ops.set_dropout_salt(None)
-        del gstep
     if args.precision == "bf16" and not args.no_fp32_form and args.workload == "c2":
         # the fp32 mode: the path that meets north_star's 1e-4 tolerance (tests/test_configs_gpu.py), timed on the same workload
         fp32_form = secondary("two-call", "fp32", fp32_steps, 1)
@@ -582,6 +594,10 @@ def main():
                                                        "replayed from one captured HIP graph per rank, ttmi.train.GraphedStep, timed after the main region; the headline stays the "
                                                        "eager step because its kernels are timed live by HIP-event probes, which a replayed graph cannot carry" % args.steps),
                                             host_issue_ms_per_step=round(1e3 * graph_issue, 3), host_launches_per_step=1)
+        elif graph_error is not None:
+            out["graph_replay_form"] = {"error": graph_error, "note": "the capture of the step failed on this run; the primary region is unaffected"}
+        elif world > 1 and not args.graph and not args.no_graph_form:
+            out["graph_replay_form"] = {"skipped": "secondary graph capture runs on one rank by default; `--graph-form` (nccl) times it on N ranks, `--graph` makes it the primary region"}
         if fp32_form is not None:
             out["fp32_form"] = {"ms_per_step": round(1e3 * fp32_form / fp32_steps, 3), "value": round(world * B * fp32_steps / fp32_form, 3), "unit": "utt/s",
                                 "dtype": "f32", "steps": fp32_steps,
