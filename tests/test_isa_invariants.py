@@ -204,6 +204,19 @@ def test_attention_counted_waits(tmp_path):
                 assert ins[k - 1]["op"] == "s_nop" and ins[k - 1]["text"].split()[1] == "4" and ins[k - 2]["op"] == "s_mov_b32", (kname, t)
         n2 += 1
     assert n2 == 5                                   # the five mask kinds
+    # attn_dqde_kernel: its slab / q prefetch is issued from asm too (raw-buffer form): same 5-wait-state rule, and no hand-placed counted wait
+    nd = 0
+    for kname, body in kernels_of(asm).items():
+        if "attn_dqde_kernel" not in kname:
+            continue
+        ins, labels = parse(body)
+        assert not any(x.get("untagged") for x in ins) and not any(x.get("wait") for x in ins), kname
+        loads = [k for k, x in enumerate(ins) if x["op"].startswith("buffer_load_dwordx4")]
+        assert len(loads) >= 9, (kname, len(loads))   # 4 quarters x (dS to LDS + dG to registers) + the q rows, per block
+        for k in loads:
+            assert ins[k - 1]["op"] == "s_nop" and ins[k - 1]["text"].split()[1] == "4", (kname, ins[k].get("text"))
+        nd += 1
+    assert nd == 1
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")

@@ -2174,6 +2174,28 @@ struct PosGradParams {
                                         // effective table = table row max(0, p + K - L)); dE / dcT are not touched and no relpos_scatter launch follows
     int dbg;                            // timing experiments (TTMI_PG_DEBUG): 1 no final atomics, 2 no table loads, 4 no main loop, 8 no slab loads
 };
+// Raw-buffer accesses issued from inline asm (descriptor in four SGPRs + 32-bit lane offset + scalar offset; a lane offset past num_records reads as
+// zero / is not stored, like the builtins).  Why asm: while a load to LDS that the COMPILER knows about is in flight it waits for vmcnt(0) in front
+// of every LDS access it cannot prove disjoint from it - in this kernel that put three full drains INSIDE the prefetch of the next block
+// (`buffer_load ... lds` x1, vmcnt(1), x3, vmcnt(0), the dG loads, vmcnt(0), the q load, vmcnt(0): found in the ISA in round 4) and another in
+// front of the partial-sum stores; the prefetch never overlapped anything.  Issued from asm, the kernel's own wait at the top of a block is the
+// only one.  (s_nop 4: an SGPR written by VALU - v_readlane of a spilled descriptor - needs 5 wait states before a vector-memory read.)
+typedef unsigned u32x4s_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4s_t raw_rsrc(const void* base, unsigned bytes) {
+    // (readfirstlane: the descriptor must LIVE in SGPRs; without it one build of this file allocated it to a VGPR tuple under the "s" constraint,
+    // which the assembler rejects - the value is wave-uniform anyway)
+    const unsigned long long a = (unsigned long long)(size_t)base;
+    return u32x4s_t{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu)),
+                    (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
+}
+__device__ __forceinline__ void buf_dma16(u32x4s_t rsrc, unsigned voff, int soff, unsigned lds_wave_addr) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(lds_wave_addr) : "memory", "m0");
+}
+__device__ __forceinline__ u32x4_t buf_ld16_async(u32x4s_t rsrc, unsigned voff, int soff) {
+    u32x4_t v;
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    return v;
+}
 constexpr int PG_TILE = 32 * 64 * 2;
 constexpr int PG_SLOT = 64 * 36;                                               // floats: a wave's partial dq block as [d][row], row pitch 36 (conflict-free b128)
 constexpr int PG_LDS = 8 * PG_SLOT * 4 + 2 * 8 * PG_TILE + 2 * PG_TILE;        // partial slots | per-wave dS and dG images | two q tiles
@@ -2204,8 +2226,9 @@ __global__ __launch_bounds__(512, 1) void attn_dqde_kernel(const PosGradParams p
     // wave-instruction 8 whole row pieces, and the chunk a lane fetches is the one that belongs at its position of the swizzled image.
     // dS goes straight into its image by LDS-DMA (issued as soon as the previous block's fragments are in registers), dG through
     // registers (its image is read until the end of a block).
-    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.dS16 + (long)z * p.slab16), 0, (int)(p.slab16 * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.dG16 + (long)z * p.slab16), 0, (int)(p.slab16 * 2), 0x00020000);
+    const u32x4s_t rs_s = raw_rsrc(p.dS16 + (long)z * p.slab16, (unsigned)(p.slab16 * 2));
+    const u32x4s_t rs_g = raw_rsrc(p.dG16 + (long)z * p.slab16, (unsigned)(p.slab16 * 2));
+    const unsigned stile_lds = (unsigned)(size_t)stile;
     int voff[4];
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
@@ -2213,15 +2236,19 @@ __global__ __launch_bounds__(512, 1) void attn_dqde_kernel(const PosGradParams p
         voff[q4] = (col + 8 <= ldp && !(p.dbg & 8)) ? (tr * ldp + col) * 2 : 0x7FFFFF00;
     }
     u32x4_t rg[4];
-    auto fetch = [&](int i0) {
+    // One quarter (8 rows) of the next block's two slab tiles.  The quarters are issued at four points of a block, not in one burst: a CU takes
+    // in ~10 bytes per cycle, a block's 68 KB are ~7k cycles of that, and a wave that issues into a full queue stands still - with all nine loads
+    // of every wave in one place (round 3, and the first asm version) the eight waves queued for 6 - 8k cycles and THEN computed for 5k with the
+    // memory pipeline idle (tools/debug/dqde_stamps.py).
+    auto fetch_piece = [&](int q4, int i0) {
         const int soff = i0 * ldp * 2;
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (__attribute__((address_space(3))) void*)(stile + q4 * 1024), 16, voff[q4], soff, 0, 0);
-            rg[q4] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, voff[q4], soff, 0);
-        }
+        buf_dma16(rs_s, (unsigned)voff[q4], soff, stile_lds + q4 * 1024);
+        rg[q4] = buf_ld16_async(rs_g, (unsigned)voff[q4], soff);
     };
-    fetch(0);                                       // the first block flies under the table prologue
+    auto fetch = [&](int i0) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) fetch_piece(q4, i0);
+    };
     // resident B fragments B[k = column c][n = d] (lane n = 32 nt + row; k = 16 ks + 8 hh + 0..7) of this wave's 64 rows of k and of the
     // table: the rows go through a 64 x 64 image (the wave's partial-sum slot, not yet in use) and are read back by columns - once
     bf16x8 bk[2][4], be[2][4];
@@ -2263,26 +2290,28 @@ __global__ __launch_bounds__(512, 1) void attn_dqde_kernel(const PosGradParams p
     float dc4[4] = {0.f, 0.f, 0.f, 0.f};           // lane (cg = lane & 15, rows 8 (lane >> 4) ..+7 of every block): dG column sums of columns 4 cg ..+3
     float gu_run[2] = {0.f, 0.f};
     // q rows in and dq rows out through raw buffers as well (a row past L reads as zero / is not stored; no 64-bit addresses in registers)
-    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(qb), 0, (int)(((long)(L - 1) * p.ld_qp + 64) * 2), 0x00020000);
+    const u32x4s_t rs_q = raw_rsrc(qb, (unsigned)(((long)(L - 1) * p.ld_qp + 64) * 2));
     const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.dq16 + (long)b * L * p.ld_dq + h * 64, 0, (int)(((long)(L - 1) * p.ld_dq + 64) * 2), 0x00020000);
     const int ldq2 = (int)p.ld_qp * 2, ldo2 = (int)p.ld_dq * 2;
-    const int vq = ((tid >> 3) & 31) * ldq2 + (tid & 7) * 16;             // thread (row tid / 8, chunk tid % 8) of a 32-row q tile
+    const unsigned vq = tid < 32 * T::NCH ? (unsigned)(((tid >> 3) & 31) * ldq2 + (tid & 7) * 16) : 0xFFFFFF00u;   // thread (row tid / 8, chunk tid % 8) of a 32-row q tile (the other half: out of range, reads zeros)
     const int vo = (4 * (tid >> 6)) * ldo2 + (tid & 63) * 2;               // thread (rows 4 (tid / 64) ..+3, column tid % 64) of a 32-row dq block
-    u32x4_t qpre = {0u, 0u, 0u, 0u};               // 32 plain q rows -> swizzled tile, issued early in a block, parked at its end
+    u32x4_t qpre = {0u, 0u, 0u, 0u};               // 32 plain q rows -> swizzled tile, fetched one block ahead with the slab rows, parked at the top of their block
     auto load_q = [&](int i0) {
-        if (tid < 32 * T::NCH) qpre = __builtin_amdgcn_raw_buffer_load_b128(rs_q, vq, i0 * ldq2, 0);
+        qpre = buf_ld16_async(rs_q, vq, i0 * ldq2);        // (every thread: a load under `if` puts a join behind it, where the compiler drains)
     };
     auto park_q = [&](int buf) {
         if (tid < 32 * T::NCH) *reinterpret_cast<u32x4_t*>(qtiles + buf * PG_TILE + T::off(tid >> 3, tid & 7)) = qpre;
     };
+    fetch(0);
     load_q(0);
-    park_q(0);
-    __syncthreads();                                // (also: every wave is done with its slot as a table image)
+    __syncthreads();                                // every wave is done with its slot as a table image
     int cur = 0;
     for (int i0 = 0; i0 < ((p.dbg & 4) ? 0 : L); i0 += 32) {
         STAMP(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this block's dS image and dG registers (issued one block ago)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this block's dS image, dG registers and q rows (issued one block ago, from asm: handed over here)
+        asm volatile("" : "+v"(rg[0]), "+v"(rg[1]), "+v"(rg[2]), "+v"(rg[3]), "+v"(qpre));
         STAMP(1);
+        park_q(cur);                                 // this block's q rows (read by the dE products behind the block's first barrier; the other buffer may still be read by a slow wave's previous block)
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<u32x4_t*>(gtile + (8 * q4 + lrow) * 128 + lpos * 16) = rg[q4];
         bf16x8 a[4];
@@ -2290,7 +2319,8 @@ __global__ __launch_bounds__(512, 1) void attn_dqde_kernel(const PosGradParams p
         for (int ks = 0; ks < 4; ++ks) a[ks] = *reinterpret_cast<const bf16x8*>(stile + T::off(row, 2 * ks + hh));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers: the image may be overwritten
         STAMP(2);
-        if (i0 + 32 < L) { fetch(i0 + 32); load_q(i0 + 32); }
+        const bool more = i0 + 32 < L;               // (workgroup-uniform)
+        if (more) fetch_piece(0, i0 + 32);
         STAMP(3);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {             // one 32-column half of the block at a time: 16 accumulator registers, not 32
@@ -2314,6 +2344,7 @@ __global__ __launch_bounds__(512, 1) void attn_dqde_kernel(const PosGradParams p
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4)
                 *reinterpret_cast<float4*>(sl + 8 * g4) = make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
+            if (more) fetch_piece(1 + nt, i0 + 32);
         }
         STAMP(4);
         __syncthreads();
@@ -2341,6 +2372,7 @@ __global__ __launch_bounds__(512, 1) void attn_dqde_kernel(const PosGradParams p
             __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16(sum.w), rs_o, vo, so + 3 * ldo2, 0);
             }
         }
+        if (more) { fetch_piece(3, i0 + 32); load_q(i0 + 32); }
         STAMP(6);
         const char* qt = qtiles + cur * PG_TILE;
 #pragma unroll
@@ -2365,7 +2397,6 @@ __global__ __launch_bounds__(512, 1) void attn_dqde_kernel(const PosGradParams p
             }
         }
         STAMP(8);
-        if (i0 + 32 < L) park_q(cur ^ 1);
         cur ^= 1;
         __syncthreads();
         STAMP(9);
