@@ -58,7 +58,11 @@ bool attn_dqde_supported(int Dh, int L, long ldp);
 int attn_dqde_groups(long ldp);
 int attn_dqde(const bf16_t* dS16, const bf16_t* dG16, long slab16, long ldp, const bf16_t* k, long ld_kv, const bf16_t* e16, long ld_e,
               const bf16_t* qp, long ld_qp, bf16_t* dq16, long ld_dq, float* dE, long ld_de, float* dcT, float* gu, int B, int L, int H,
-              hipStream_t st, float* part = nullptr, float* g_emb = nullptr, float* g_bias = nullptr, int K = 0);
+              hipStream_t st, float* part = nullptr, float* g_emb = nullptr, float* g_bias = nullptr, int K = 0, float* part_e = nullptr,
+              float* part_c = nullptr);
+// With part_e [B, L, H 64] / part_c [B, H, L] attn_dqde leaves every (b, h)'s table-gradient rows by plain stores (no atomics); this sums them over
+// b into the gradients of r_emb [K, H, 64] / r_bias [K, H] (+=; effective row p -> table row max(0, p + K - L)).  Meant for a side stream.
+int attn_table_grads(const float* part_e, const float* part_c, int B, int L, int H, int K, float* g_emb, float* g_bias, hipStream_t st);
 int flash_attn_fwd(const FlashParams& p, hipStream_t st);
 void flash_set_resident(int v);     // 1 (default): one workgroup per head with the table resident in LDS where it applies; 0: round-3 kernels
 void flash_set_bwd_gen(int v);      // 2 (default): flash_bwd_rel2_kernel (LDS-DMA staging, register skew, one barrier per step); 1: the round-3 kernel

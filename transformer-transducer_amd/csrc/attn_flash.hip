@@ -2172,6 +2172,8 @@ struct PosGradParams {
     float* part;                        // column groups (L > 512): f32 partial dq rows part[((group B + b) L + i) H 64 + h 64 + d] instead of dq16
     float* g_emb; float* g_bias; int K; // if set: the flush goes straight into the table gradients r_emb [K, H, 64] / r_bias [K, H] (row p of the
                                         // effective table = table row max(0, p + K - L)); dE / dcT are not touched and no relpos_scatter launch follows
+    float* part_e; float* part_c;       // if set: no atomics at all - this (b, h)'s rows leave by plain stores, part_e[(b L + p) H 64 + h 64 + d],
+                                        // part_c[(b H + h) L + p]; table_grad_reduce_kernel sums them over b (attn_table_grads)
     int dbg;                            // timing experiments (TTMI_PG_DEBUG): 1 no final atomics, 2 no table loads, 4 no main loop, 8 no slab loads
 };
 // Raw-buffer accesses issued from inline asm (descriptor in four SGPRs + 32-bit lane offset + scalar offset; a lane offset past num_records reads as
@@ -2408,7 +2410,30 @@ __global__ __launch_bounds__(512, 1) void attn_dqde_kernel(const PosGradParams p
 #endif
     // one flush per (b, h): rows of the tables this wave owns
     if (p.dbg & 1) return;
-    if (p.g_emb) {
+    if (p.part_e) {
+        // 32 workgroups (the batch) hold rows of the SAME table gradient; as f32 atomics their 33 MB per C2 layer take 27 us of the kernel's 97 (the
+        // chip's ~1.3 TB/s of added bytes).  Plain stores here, summed over b by a small kernel that runs beside the GEMMs that follow.
+        float* pe = p.part_e + (long)b * L * ((long)p.H * 64) + h * 64 + row;
+        const long rp = (long)p.H * 64;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pr = c0 + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (pr < L) {
+                    pe[pr * rp] = acc_e[mt][0][r];
+                    pe[pr * rp + 32] = acc_e[mt][1][r];
+                }
+            }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = dc4[e];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int pc = c0 + 4 * (lane & 15) + e;
+            if (lane < 16 && pc < L) p.part_c[((long)b * p.H + h) * L + pc] = v;
+        }
+    } else if (p.g_emb) {
         // straight into the table gradients: effective row pr is table row pr + K - L; the rows below L - K all ARE table row 0 (sequences
         // longer than the table) and are summed in the wave before they leave - one add per wave and column, not one per row
         const int HD = p.H * 64, shift = p.K - L;
@@ -2496,12 +2521,55 @@ __global__ __launch_bounds__(256) void dq_group_sum_kernel(const float* __restri
     *reinterpret_cast<uint2*>(dq16 + r * ld_dq + c) = w;
 }
 
+// Table gradients from the per-(b, h) rows attn_dqde_kernel stored: g_emb[max(0, p + K - L)][h][d] += sum_b part_e[b][p][h][d], g_bias likewise.
+// One thread per four columns of an effective row; rows that map one to one onto a table row (e > 0) have a single owner and are added in
+// place, the rows that clamp onto table row 0 (and row e = 0 itself) go by atomics (a few dozen rows where this path is used: L - K < 256).
+__global__ __launch_bounds__(256) void table_grad_reduce_kernel(const float* __restrict__ part_e, const float* __restrict__ part_c, int B, int L, int H,
+                                                                int K, float* __restrict__ g_emb, float* __restrict__ g_bias) {
+    const int HD = H * 64;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long n4 = (long)L * HD / 4;
+    if (idx < n4) {
+        const int pr = (int)(idx / (HD / 4)), c4 = (int)(idx % (HD / 4)) * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b = 0; b < B; ++b) {
+            const float4 v = *reinterpret_cast<const float4*>(part_e + ((long)b * L + pr) * HD + c4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        const int e = pr + K - L;
+        if (e > 0) {
+            float4* g = reinterpret_cast<float4*>(g_emb + (long)e * HD + c4);
+            float4 o = *g;
+            o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+            *g = o;
+        } else {
+            atomicAdd(g_emb + c4, acc.x); atomicAdd(g_emb + c4 + 1, acc.y); atomicAdd(g_emb + c4 + 2, acc.z); atomicAdd(g_emb + c4 + 3, acc.w);
+        }
+    } else if (idx < n4 + (long)H * L) {
+        const long i2 = idx - n4;
+        const int h = (int)(i2 / L), pr = (int)(i2 % L);
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc += part_c[((long)b * H + h) * L + pr];
+        const int e = pr + K - L;
+        if (e > 0) g_bias[(long)e * H + h] += acc;
+        else atomicAdd(g_bias + h, acc);
+    }
+}
+
+int attn_table_grads(const float* part_e, const float* part_c, int B, int L, int H, int K, float* g_emb, float* g_bias, hipStream_t st) {
+    TTMI_REQUIRE(part_e && part_c && g_emb && g_bias && B > 0 && L > 0 && H > 0 && K > 0 && aligned16(part_e) && aligned16(g_emb), "attn_table_grads: bad arguments");
+    const long n = (long)L * H * 64 / 4 + (long)H * L;
+    hipLaunchKernelGGL(table_grad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part_e, part_c, B, L, H, K, g_emb, g_bias);
+    TTMI_LAUNCH_CHECK("table_grad_reduce_kernel");
+    return TTMI_OK;
+}
+
 bool attn_dqde_supported(int Dh, int L, long ldp) { return Dh == 64 && ldp <= 8 * 512 && ldp % 8 == 0 && L >= 1; }
 int attn_dqde_groups(long ldp) { return (int)((ldp + 511) / 512); }
 
 int attn_dqde(const bf16_t* dS16, const bf16_t* dG16, long slab16, long ldp, const bf16_t* k, long ld_kv, const bf16_t* e16, long ld_e,
               const bf16_t* qp, long ld_qp, bf16_t* dq16, long ld_dq, float* dE, long ld_de, float* dcT, float* gu, int B, int L, int H,
-              hipStream_t st, float* part, float* g_emb, float* g_bias, int K) {
+              hipStream_t st, float* part, float* g_emb, float* g_bias, int K, float* part_e, float* part_c) {
     TTMI_REQUIRE(dS16 && dG16 && k && e16 && qp && dq16 && dE && dcT && gu && B > 0 && H > 0 && attn_dqde_supported(64, L, ldp),
                  "attn_dqde: bad arguments");
     const int ngroup = attn_dqde_groups(ldp);
@@ -2522,6 +2590,8 @@ int attn_dqde(const bf16_t* dS16, const bf16_t* dG16, long slab16, long ldp, con
     p.part = ngroup > 1 ? part : nullptr;
     TTMI_REQUIRE(!g_emb || (g_bias && K >= 1), "attn_dqde: direct table-gradient flush needs r_emb, r_bias gradients and the table length");
     p.g_emb = g_emb; p.g_bias = g_bias; p.K = K;
+    TTMI_REQUIRE(!part_e || (part_c && aligned16(part_e)), "attn_dqde: per-(b, h) table-gradient rows need both buffers");
+    p.part_e = part_e; p.part_c = part_c;
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("TTMI_PG_DEBUG"); dbg = e ? atoi(e) : 0; }
     p.dbg = dbg;

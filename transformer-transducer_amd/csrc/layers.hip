@@ -77,7 +77,8 @@ int g_fork_wgrad = 1;
 int g_split_weights = 0;        // ttmi_set_option(13, 1): EXPERIMENT - o_net and CoreNet.3 (the two encoder GEMMs with f32 outputs) add the second term of
                                 // their weight's bf16 split, as the joint's input layer does; needs weight shadows (the free plain-copy region holds the term)
 int g_posgrad_gemms = 0;        // ttmi_set_option(11, 1): dq / dE by the round-2 GEMM launches instead of attn_dqde_kernel (A/B)
-int g_scatter_launch = 0;       // ttmi_set_option(16, 1): attn_dqde_kernel leaves dE / dc and relpos_scatter folds them (round 3; A/B)
+int g_scatter_launch = 0;       // ttmi_set_option(16, 1): attn_dqde_kernel leaves dE / dc and relpos_scatter folds them (round 3; A/B); 2: atomics straight into
+                                // the table gradients (no per-(b, h) rows + reduction)
 int g_attn_slices = 1;          // ttmi_set_option(10, n): attention backward in n batch slices (see attn_bwd_impl)
 int g_gemm_slab = 0;            // ttmi_set_option(5, 1): position-term slab by the batched GEMM (A/B measurements)
 struct SideCtx {
@@ -556,6 +557,14 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
         // ... which then also folds its table-gradient rows straight into r_emb / r_bias' gradients (no dE / dc round trip, no relpos_scatter
         // launch: 18 x ~20 us per C2 step), unless so many rows clamp onto table row 0 that the chunked fold is the better tool (C5)
         direct_tables = onepass && L - K < 256 && !g_scatter_launch;
+        // ... by plain per-(b, h) stores + one small reduction over b on the fork stream (no atomics: 33 MB of them per C2 layer were 27 us of
+        // attn_dqde_kernel's 97) where the f32 dS slab region has the room (dq partials of the column groups first) and the batch is not sliced
+        const int ngrp = attn_dqde_groups(w.ldp);
+        const long part_dq = ngrp > 1 ? (long)ngrp * B * L * a.HD : 0;
+        const bool part_tables = direct_tables && nslice == 1 && g_scatter_launch != 2 &&
+                                 part_dq + (long)B * L * a.HD + (long)B * H * L <= (long)B * H * a.slab;
+        float* part_e = part_tables ? w.dS + part_dq : nullptr;
+        float* part_c = part_tables ? part_e + (long)B * L * a.HD : nullptr;
         // the small zero fills of this pass (dG row 0 of every slab, the dE / dc accumulators) ride in the delta kernel's launch where one
         // launch covers the batch; sliced runs keep the memsets (the accumulators must survive from slice to slice)
         const bool fillz = fastpos && nslice == 1;
@@ -605,7 +614,9 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
                     // (sequences longer than 512: the column groups' f32 partial dq rows live in the f32 dS slab region, unused on this path:
                     // B H L (L + 1) floats against groups x B L H 64)
                     CK(attn_dqde(w.dS16, w.dG16, w.slab16, w.ldp, qkv16 + a.HD, a.W3, E16, a.HD, qkv16, a.W3, w.dqkv16 + r0 * a.W3, a.W3,
-                                 w.dE, a.HD, w.dcT, g_r_w_bias, nb, L, H, st, w.dS, direct_tables ? g_r_emb : nullptr, direct_tables ? g_r_bias : nullptr, K));
+                                 w.dE, a.HD, w.dcT, g_r_w_bias, nb, L, H, st, w.dS, direct_tables ? g_r_emb : nullptr, direct_tables ? g_r_bias : nullptr, K,
+                                 part_e, part_c));
+                    if (part_tables) CK(attn_table_grads(part_e, part_c, nb, L, H, K, g_r_emb, g_r_bias, fork_stream(st)));
                     continue;
                 }
                 // dq = dS k + dG E in ONE launch: both products accumulate into the same tile, the column sums of the first (d r_w_bias) are taken
