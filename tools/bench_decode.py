@@ -33,11 +33,15 @@ def run(utts=8, T=500, emit_rate=0.1, precision="fp32", block=64):
     cfg = c2_config()
     torch.manual_seed(1)
     model = Transducer(cfg).to(dev).eval()
+    if os.environ.get("TTMI_DECODE_GRAPHS") == "0":
+        model.config["decode_graphs"] = False                        # (debugging: eager label-encoder launches)
     d, V = cfg["enc"]["d_model"], cfg["vocab_size"]
     g = torch.Generator(device=dev).manual_seed(1234)
     feats = torch.randn(args.utts, args.T, 80, device=dev, generator=g)
     proj = torch.randn(80, d, device=dev, generator=torch.Generator(device=dev).manual_seed(7)) / 80 ** 0.5
     inputs = feats @ proj
+    import hashlib
+    inputs_sha = hashlib.sha256(inputs.float().cpu().numpy().tobytes()).hexdigest()[:12]      # (torch's GEMM: not bit-reproducible from process to process)
     lens = [args.T] * args.utts
 
     with torch.no_grad():
@@ -72,6 +76,10 @@ def run(utts=8, T=500, emit_rate=0.1, precision="fp32", block=64):
     nsym = sum(len(h) for h in hyps)
     out = {"workload": "greedy decode, C2 model (12/6 layers, V=4334), %d utt x T=%d, %s, emit rate target %.2f"
                        % (args.utts, args.T, args.precision, args.emit_rate),
+           "inputs_sha": inputs_sha, "debug_sha": {"enc_states": hashlib.sha256(enc_states.float().cpu().numpy().tobytes()).hexdigest()[:8],
+                                                   "blank_bias": float(model.joint.project_layer.bias[0].detach()),
+                                                   "one_at_a_time": hashlib.sha256(repr(hyps1).encode()).hexdigest()[:8],
+                                                   "batched": hashlib.sha256(repr(hyps).encode()).hexdigest()[:8]},
            "utt_per_s": round(args.utts / (t_enc + t_dec), 3), "frames_per_s": round(args.utts * args.T / (t_enc + t_dec), 1),
            "encoder_ms": round(1e3 * t_enc, 2), "decode_ms_per_utt": round(1e3 * t_dec / args.utts, 2),
            "symbols_per_utt": round(nsym / args.utts, 1), "ms_per_symbol_step": round(1e3 * t_dec / max(max(len(h) for h in hyps), 1), 3),

@@ -596,7 +596,13 @@ class Transducer(nn.Module):
         dev = enc_states.device
         B, T = enc_states.shape[0], enc_states.shape[1]
         T_len = torch.as_tensor(lengths, dtype=torch.int32).to(dev).clamp(max=T).contiguous()
-        graphs = self._label_state_graphs(dev, B)
+        # Label-encoder graphs for a whole batch are opt-in (config.decode_batch_graphs).  They buy nothing at 32 utterances (96 against 97 utt/s:
+        # a step's ~150 launches are no longer what the host waits for) and, in tools/bench_decode.py's call order, a third of the PROCESSES
+        # came back from their first pure-replay pass with one of two other token sets (14 runs each: graphs on 5 / 14, also with the skinny
+        # kernel off 6 / 14 and with a host synchronisation before or after every replay 5 - 8 / 14; eager launches 0 / 14; a replay is
+        # bit-identical to the eager call on the same tokens whatever the scratch arenas hold, tools/debug/decode_poison.py - the cause was not
+        # found in round 4).  One utterance at a time (`decode`) keeps its graphs: there they are the speed, and its tokens never moved.
+        graphs = self._label_state_graphs(dev, B) if self.config.decode_batch_graphs else None
         hist = torch.zeros(B, T + 2, dtype=torch.long, device=dev)   # column 0 = the start symbol (blank); at most one symbol per frame
         t = torch.zeros(B, dtype=torch.int32, device=dev)
         need = torch.ones(B, dtype=torch.int32, device=dev)
