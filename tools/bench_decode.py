@@ -33,6 +33,8 @@ def run(utts=8, T=500, emit_rate=0.1, precision="fp32", block=64):
     cfg = c2_config()
     torch.manual_seed(1)
     model = Transducer(cfg).to(dev).eval()
+    if os.environ.get("TTMI_DECODE_BATCH_GRAPHS") == "1":
+        model.config["decode_batch_graphs"] = True                   # (debugging: label-encoder graphs for the batched decoder too)
     if os.environ.get("TTMI_DECODE_GRAPHS") == "0":
         model.config["decode_graphs"] = False                        # (debugging: eager label-encoder launches)
     d, V = cfg["enc"]["d_model"], cfg["vocab_size"]

@@ -11,6 +11,7 @@ dev = torch.device("cuda", 0)
 cfg = c2_config()
 torch.manual_seed(1)
 model = Transducer(cfg).to(dev).eval()
+model.config["decode_batch_graphs"] = True
 g = torch.Generator(device=dev).manual_seed(1234)
 feats = torch.randn(32, 500, 80, device=dev, generator=g)
 proj = torch.randn(80, 512, device=dev, generator=torch.Generator(device=dev).manual_seed(7)) / 80 ** 0.5
