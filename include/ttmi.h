@@ -261,6 +261,10 @@ int ttmi_gemm(const void* A, const void* B, void* C, const float* bias, const fl
               long sB1, long sB2, long sC1, long sC2, float alpha, float beta, int flags, int splitk, void* stream);
 int ttmi_gemm_nt_bf16(const void* A, const void* B, void* C, int c_dtype, const float* bias, int M, int N, int K, long lda,
                       long ldb, long ldc, void* stream);
+/* bring-up entry of the two-term weight form (option 13): C = epi(A.(B + B_lo)^T), B_lo [N, K] bf16 with B's pitch, in ONE launch - the persistent
+ * kernels walk A's K-tiles a second time against B_lo, the 128x128 kernel takes (A, B_lo) as its second operand pair */
+int ttmi_gemm_nt_bf16_two_term(const void* A, const void* B, const void* B_lo, void* C, int c_dtype, const float* bias, int relu, int M, int N, int K,
+                               long lda, long ldb, long ldc, void* stream);
 /* bring-up entry of the "exp store" epilogue of the persistent 256x256 kernel: C = bf16(exp(A.B^T + bias - shift)) with zeros in columns [N, ldc),
  * rowsum [nparts, M] = per-row partial sums (nparts >= 4 * ceil(N / 256); the entries of a row add up to its sum of exponentials) */
 int ttmi_gemm_nt_bf16_exp(const void* A, const void* B, void* C, const float* bias, float* rowsum, int nparts, const float* shift /* device, nullable */, int M, int N, int K,
@@ -291,8 +295,9 @@ int ttmi_stream_reserve_cus(void* stream, int n);
  * 7: exact-f32 products with at most n rows use the skinny 32x32 split-reduction kernel (default 128, 0 = never: greedy decode A/B);
  * 8: 0 = the fused attention kernels read the position term from a [B,H,L,L+1] bf16 slab (round-1 design) instead of forming it themselves;
  * 9: 1 = one-wave lattice kernel (round 2) instead of the workgroup-per-utterance one; 10: batch slices of the attention backward; 11: 1 = dq / dE /
- * dc by the round-2 GEMM launches instead of attn_dqde_kernel; 12: workgroups of the grid-stride LayerNorm backward kernels; 13: 1 = o_net and
- * CoreNet.3 add the second term of their weight's bf16 split (needs weight shadows; lower bf16 loss error, +3 % step time); 14: 0 = the tiled attention
+ * dc by the round-2 GEMM launches instead of attn_dqde_kernel; 12: workgroups of the grid-stride LayerNorm backward kernels; 13: 1 = the four
+ * forward GEMMs of an encoder layer (qkv_net, o_net, CoreNet.0, CoreNet.3) take the second term of their weight's bf16 split as a second K range, one launch each; 2 = o_net and
+ * CoreNet.3 only (needs weight shadows; +2 % step time, no consistent change of the bf16 loss error: profiles/r04_two_term_weights.md); 14: 0 = the tiled attention
  * forward kernel instead of the one-workgroup-per-head one; 15: 1 = the round-3 attention backward kernel instead of flash_bwd_rel2_kernel;
  * 16: 1 = the position-table gradients go through dE / dc and a relpos_scatter launch (round 3) instead of straight out of attn_dqde_kernel */
 int ttmi_set_option(int key, int value);

@@ -238,3 +238,27 @@ def test_tn_weighted_column_sums_exact(M, N):
     want_col = 3 * (A.float() * w.float()[:, None]).sum(0)
     assert torch.equal(col, want_col)
     assert torch.equal(C, want_c)
+
+
+@pytest.mark.parametrize("M,N,K,gen", [(6400, 1536, 512, 9), (6400, 512, 512, 9), (6400, 512, 2048, 9), (6400, 2048, 512, 8), (3001, 700, 128, 9),
+                                       (3001, 700, 128, 8), (6400, 2048, 512, 4), (1025, 129, 128, 9), (1000, 1536, 512, 4), (816, 2048, 512, 4), (77, 130, 72, 4)])
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_two_term_weight_one_launch_exact(M, N, K, gen, cdt):
+    """NtEpilogue::B_lo (option 13): the persistent kernels walk A's K-tiles twice, the second time against the weight's second bf16 term -
+    exact on small integers against A (B + B_lo)^T with bias and ReLU, on both generations and on the default route; rows beyond the problem untouched"""
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + gen)
+    A, B, Bl = _ints((M, K), g), _ints((N, K), g), _ints((N, K), g)
+    bias = torch.randint(-3, 4, (N,), device="cuda", generator=g).float()
+    for relu in (False, True):
+        C = torch.full((M + 1, N), 5.0, device="cuda", dtype=cdt)
+        ops.set_option(1, gen)
+        try:
+            ops.gemm_nt_bf16_two_term(A, B, Bl, C[:M], bias, relu)
+        finally:
+            ops.set_option(1, 4)
+        want = A.float() @ (B.float() + Bl.float()).t() + bias
+        if relu:
+            want = want.clamp_min(0)
+        assert torch.equal(C[:M], want.to(cdt))
+        assert bool((C[M] == 5.0).all())

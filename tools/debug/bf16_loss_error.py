@@ -32,6 +32,10 @@ from ttmi import ops
 from ttmi.train import FlatModel, FusedOptimizer, GradSync
 from warprnnt_pytorch import RNNTLoss
 
+OPT13 = 0
+for kv in filter(None, os.environ.get("TTMI_OPTIONS", "").split(",")):
+    if kv.split("=")[0] == "13":
+        OPT13 = int(kv.split("=")[1])
 dev = torch.device("cuda", 0)
 cfg = bench.c2_config()
 torch.manual_seed(1)
@@ -95,6 +99,18 @@ def report(tag):
             z, _ = O.joint_fwd(enc_s.double().cpu().numpy(), dec_s.double().cpu().numpy(), sd64)
             c = rnnt_loss_c(z.astype(np.float32), y.cpu().numpy(), il.cpu().numpy(), tl.cpu().numpy(), want_grad=False)[1].astype(np.float64)
             print("   enc %s / ORACLE joint+loss: rel err %s (signed abs %s)" % (ep, np.array2string(np.abs(c - want) / want, precision=2), np.array2string(c - want, precision=3)))
+        # the same state through the two-term weight forms of the encoders' forward GEMMs (option 13: 2 = o_net / CoreNet.3, 1 = all four)
+        os.environ["TTMI_PRECISION"] = "bf16"
+        for v in (2, 1):
+            ops.set_option(13, v)
+            enc_s, dec_s = model._encode(x, y)
+            torch.cuda.synchronize()
+            ops.set_option(13, OPT13)
+            z, _ = O.joint_fwd(enc_s.double().cpu().numpy(), dec_s.double().cpu().numpy(), sd64)
+            c = rnnt_loss_c(z.astype(np.float32), y.cpu().numpy(), il.cpu().numpy(), tl.cpu().numpy(), want_grad=False)[1].astype(np.float64)
+            print("   enc bf16 option 13=%d / ORACLE joint+loss: rel err %s (signed abs %s)  enc_state rel %.2e  dec_state rel %.2e" %
+                  (v, np.array2string(np.abs(c - want) / want, precision=2), np.array2string(c - want, precision=3),
+                   rel_err(enc_s.cpu().numpy(), enc64), rel_err(dec_s.cpu().numpy(), dec64)))
     os.environ["TTMI_PRECISION"] = "bf16"
     model.train()
 

@@ -1,4 +1,4 @@
-# same box, alternating: option 13 (second bf16 term of the o_net and CoreNet.3 weights) off / on
+# same box, alternating: option 13 (second bf16 term of the four encoder forward weights as a second K range, one launch each) off / on
 ulimit -c 0; export HSA_ENABLE_COREDUMP=0
 F="--steps 20 --warmup 5 --no-cpu-baseline --no-fp32-form --no-two-call --no-graph-form"
 for o in 0 1 0 1; do

@@ -32,6 +32,9 @@ struct NtEpilogue {
     int nparts = 0;
     const float* exp_shift = nullptr;   // device scalar, nullable = 0
     const float* rowscale = nullptr;
+    // second bf16 term of the weight (B ~ B + B_lo, same shape and pitch): C = epi(A.(B + B_lo)^T) in ONE launch of the persistent kernels,
+    // which walk A's K-tiles a second time against B_lo, or of the 128x128 kernel (as its second operand pair)
+    const bf16_t* B_lo = nullptr;
 };
 // C[M,N] = epilogue(A[M,K] . B[N,K]^T); c_dtype 0 = f32, 1 = bf16
 int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const NtEpilogue& epi, int M, int N, int K, long lda,

@@ -60,6 +60,7 @@ struct FP {
     const bf16_t* A2;
     const bf16_t* B2;
     int K2;
+    int kwrap = 0;                          // persistent NT kernels: K-tiles [kwrap, K / 64) re-read A's K-tiles [0, ..) against B2 (same pitch as B): C = A.(B + B2)^T, 0 = off
     long lda2, ldb2, sB1b, sB2b;
     float* colsum_mid;                      // column sums of the FIRST product (rows < M), atomically added; batch strides sV1 / sV2
     // v8 NT, LEAN 3 ("exp store"): C = bf16(exp(acc + bias - exp_shift)), zeros in columns [N, ldc); rowsum[(tile_n * 4 + wave column) * M + m] =
@@ -788,12 +789,14 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p_) {
     unsigned oA[2][2], oB[2][2];
     const char* baseA = nullptr;
     const char* baseB = nullptr;
+    const char* baseB2 = nullptr;
     int kch[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) kch[j] = (lane & 7) ^ ((((wave * 2 + j) * 8 + (lane >> 3)) >> 1) & 7);
     auto sources = [&](int bm, int bn) {
         baseA = reinterpret_cast<const char*>(p.A + (long)bm * p.lda);
         baseB = reinterpret_cast<const char*>(p.B + (long)bn * p.ldb);
+        baseB2 = reinterpret_cast<const char*>(p.B2 + (long)bn * p.ldb);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int rho = (wave * 2 + j) * 8 + (lane >> 3);
@@ -809,7 +812,8 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p_) {
     // kind: 0 = A h0, 1 = A h1, 2 = B h0, 3 = B h1 (also the region index inside a buffer)
     auto stage = [&](int kind, int buf, int kt) {
         char* dst = smem + buf * BUF8 + kind * HT8 + wave * 2048;
-        const char* base = (kind < 2 ? baseA : baseB) + (long)kt * (TK * 2);      // K % 64 == 0 (checked by the launcher): no tail
+        const bool second = p.kwrap && kt >= p.kwrap;                              // second weight term: A's K-tiles again, against B2
+        const char* base = (kind < 2 ? baseA : second ? baseB2 : baseB) + (long)(second ? kt - p.kwrap : kt) * (TK * 2);      // K % 64 == 0 (checked by the launcher): no tail
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const unsigned o = kind == 0 ? oA[0][j] : kind == 1 ? oA[1][j] : kind == 2 ? oB[0][j] : oB[1][j];
@@ -1367,9 +1371,11 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p_) {
     unsigned oA[4], oB[2];
     const char* baseA = nullptr;
     const char* baseB = nullptr;
+    const char* baseB2 = nullptr;
     auto sources = [&](int bm, int bn) {
         baseA = reinterpret_cast<const char*>(p.A + (long)bm * p.lda);
         baseB = reinterpret_cast<const char*>(p.B + (long)bn * p.ldb);
+        baseB2 = reinterpret_cast<const char*>(p.B2 + (long)bn * p.ldb);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = (wave * 4 + j) * 8 + (lane >> 3);
@@ -1383,8 +1389,10 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p_) {
     };
     auto stage = [&](int stg, int kt) {
         char* dst = smem + stg * STG9;
-        const char* ba = baseA + (long)kt * (TK * 2);
-        const char* bb = baseB + (long)kt * (TK * 2);
+        const bool second = p.kwrap && kt >= p.kwrap;      // the weight's second bf16 term: the same A columns again, against B2
+        const int ka = second ? kt - p.kwrap : kt;
+        const char* ba = baseA + (long)ka * (TK * 2);
+        const char* bb = (second ? baseB2 : baseB) + (long)ka * (TK * 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) glds16(ba + oA[j], dst + (wave * 4 + j) * 1024);
 #pragma unroll
@@ -2314,6 +2322,11 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     p.A2 = epi.A2; p.B2 = epi.B2; p.K2 = epi.K2; p.lda2 = epi.lda2; p.ldb2 = epi.ldb2; p.sB1b = epi.sB1b; p.sB2b = epi.sB2b; p.colsum_mid = epi.colsum_mid;
     p.rowsum = epi.rowsum; p.nparts = epi.nparts; p.exp_shift = epi.exp_shift; p.rowscale = epi.rowscale; p.csw = nullptr;
     const bool dual = epi.A2 != nullptr;
+    // second weight term (epi.B_lo, same shape, pitch and batch strides as B): the persistent kernels run the K loop twice over the same A tiles
+    // (kwrap), the 128x128 kernel takes (A, B_lo) as its second operand pair
+    const bool two_term = epi.B_lo != nullptr;
+    TTMI_REQUIRE(!two_term || (!dual && aligned16(epi.B_lo) && (g_gemm_fast_version == 4 || g_gemm_fast_version == 8 || g_gemm_fast_version == 9)),
+                 "gemm_nt_bf16: a second weight term needs a 16-byte aligned B_lo, no second operand pair and the default kernel generations");
     if (dual) TTMI_REQUIRE(epi.B2 && epi.K2 >= 8 && epi.K2 % 8 == 0 && aligned16(epi.A2) && aligned16(epi.B2) && epi.lda2 % 8 == 0 && epi.ldb2 % 8 == 0 &&
                            c_dtype == 1, "gemm_nt_bf16: bad second operand pair");
     fill_batch(p, batch);
@@ -2335,6 +2348,7 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     TTMI_REQUIRE(!needs8 || (v8 && c_dtype == 1), "gemm_nt_bf16: the exp-store / row-scale epilogues exist on the persistent 256x256 kernel only (M=%d N=%d K=%d)", M, N, K);
     const bool v9 = !needs8 && pers && ((g_gemm_fast_version == 9) || (g_gemm_fast_version == 4 && t9 >= g_num_cus * 3 / 4 && cost9 <= cost8));
     if (v9) {
+        if (two_term) { p.B2 = epi.B_lo; p.kwrap = K / TK; p.K = 2 * K; }
         p.tiles_m = cdiv(M, T9M); p.tiles_n = cdiv(N, T9N);
         // a persistent grid larger than the CUs that are actually free runs its surplus workgroups AFTER the others (twice the time):
         // with gradient all-reduce kernels resident during backward, leave them room (multi-GPU runs set option 6)
@@ -2387,6 +2401,7 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     }
     // persistent 256x256 kernel: needs several rounds of tiles per CU to amortise its pipeline fill and tail
     if (v8) {
+        if (two_term) { p.B2 = epi.B_lo; p.kwrap = K / TK; p.K = 2 * K; }
         p.tiles_m = cdiv(M, T8); p.tiles_n = cdiv(N, T8);
         const long nwg8 = (long)p.tiles_m * p.tiles_n;
 const int cus8 = nwg8 < 1024 ? std::max(8, (g_num_cus - reserved) / 8 * 8) : g_num_cus;   // encoder-sized problems only (see v9)
@@ -2438,8 +2453,12 @@ if (c_dtype == 0) {
     TTMI_REQUIRE(nwg < (1L << 31), "gemm_nt_bf16: too many tiles");
     const int ver = g_gemm_fast_version;
 #define NT_LAUNCH(TCT, NB, PP) hipLaunchKernelGGL((gemm_nt_bf16_kernel<TCT, NB, PP>), dim3((unsigned)nwg, nbatch), dim3(NTH), 2 * NB * TILE_B, st, p)
-    if (dual) {
-        hipLaunchKernelGGL((gemm_nt_bf16_kernel<bf16_t, 1, false, true>), dim3((unsigned)nwg, nbatch), dim3(NTH), 2 * TILE_B, st, p);
+    if (two_term) {
+        p.A2 = A; p.B2 = epi.B_lo; p.K2 = K; p.lda2 = lda; p.ldb2 = ldb; p.sB1b = p.sB1; p.sB2b = p.sB2; p.colsum_mid = nullptr;
+    }
+    if (dual || two_term) {
+        if (c_dtype == 1) hipLaunchKernelGGL((gemm_nt_bf16_kernel<bf16_t, 1, false, true>), dim3((unsigned)nwg, nbatch), dim3(NTH), 2 * TILE_B, st, p);
+        else hipLaunchKernelGGL((gemm_nt_bf16_kernel<float, 1, false, true>), dim3((unsigned)nwg, nbatch), dim3(NTH), 2 * TILE_B, st, p);
     } else if (c_dtype == 0) {
         if (ver >= 4) NT_LAUNCH(float, 1, false);
         else if (ver == 3) NT_LAUNCH(float, 2, true);
@@ -2644,6 +2663,14 @@ int ttmi_gemm_nt_bf16(const void* A, const void* B, void* C, int c_dtype, const 
                       long ldb, long ldc, void* stream) {
     NtEpilogue e;
     e.bias = bias;
+    return gemm_nt_bf16(static_cast<const bf16_t*>(A), static_cast<const bf16_t*>(B), C, c_dtype, e, M, N, K, lda, ldb, ldc,
+                        static_cast<hipStream_t>(stream), FastBatch());
+}
+// two-term weight (see NtEpilogue::B_lo): C = epi(A.(B + B_lo)^T) in one launch of a persistent kernel; relu != 0: ReLU after the bias
+int ttmi_gemm_nt_bf16_two_term(const void* A, const void* B, const void* B_lo, void* C, int c_dtype, const float* bias, int relu, int M, int N, int K,
+                               long lda, long ldb, long ldc, void* stream) {
+    NtEpilogue e;
+    e.bias = bias; e.relu = relu; e.B_lo = static_cast<const bf16_t*>(B_lo);
     return gemm_nt_bf16(static_cast<const bf16_t*>(A), static_cast<const bf16_t*>(B), C, c_dtype, e, M, N, K, lda, ldb, ldc,
                         static_cast<hipStream_t>(stream), FastBatch());
 }

@@ -74,8 +74,9 @@ static inline const unsigned* drop_salt_here() {
 }
 #define g_drop_salt drop_salt_here()
 int g_fork_wgrad = 1;
-int g_split_weights = 0;        // ttmi_set_option(13, 1): EXPERIMENT - o_net and CoreNet.3 (the two encoder GEMMs with f32 outputs) add the second term of
-                                // their weight's bf16 split, as the joint's input layer does; needs weight shadows (the free plain-copy region holds the term)
+int g_split_weights = 0;        // ttmi_set_option(13, v): the encoders' forward GEMMs take the second term of their weight's bf16 split (W ~ hi + lo) as a second
+                                // K range over the same A tiles, one launch each (NtEpilogue::B_lo): 1 = qkv_net, o_net, CoreNet.0, CoreNet.3; 2 = the two with f32
+                                // outputs (o_net, CoreNet.3) only.  Needs weight shadows (the free plain-copy region of the workspace holds the term)
 int g_posgrad_gemms = 0;        // ttmi_set_option(11, 1): dq / dE by the round-2 GEMM launches instead of attn_dqde_kernel (A/B)
 int g_scatter_launch = 0;       // ttmi_set_option(16, 1): attn_dqde_kernel leaves dE / dc and relpos_scatter folds them (round 3; A/B); 2: atomics straight into
                                 // the table gradients (no per-(b, h) rows + reduction)
@@ -403,7 +404,12 @@ static int attn_fwd_impl(const float* x, const float* qkv_w, const float* o_w, c
         ctx_record(ctx, 0, shq);
         if (shq) wqkv16 = sh.w16;                                                               // kept current by the optimiser step
         else CK(transpose_convert_bf16(qkv_w, (int)a.W3, d, c.wqkvT16, a.W3, st, w.wqkv16));   // Wqkv (bf16) and Wqkv^T [d, W3] for backward
-        CK(gemm_nt_bf16(x16, wqkv16, c.qkv, 1, nullptr, (int)a.BL, (int)a.W3, d, d, d, a.W3, st));
+        NtEpilogue eq;
+        if (g_split_weights == 1 && shq) {                                                      // (the plain-copy region of the workspace is free when the shadow serves)
+            CK(bf16_residual(qkv_w, wqkv16, w.wqkv16, (long)a.W3 * d, st));
+            eq.B_lo = w.wqkv16;
+        }
+        CK(gemm_nt_bf16(x16, wqkv16, c.qkv, 1, eq, (int)a.BL, (int)a.W3, d, d, d, a.W3, st));
         if (!attn_inkernel(fast, a))
             CK(add_row_bias_bf16(static_cast<bf16_t*>(c.qkv), a.W3, r_w_bias, a.BL, (int)a.HD, static_cast<bf16_t*>(c.qu), a.HD, st));
     } else {
@@ -469,13 +475,12 @@ static int attn_fwd_impl(const float* x, const float* qkv_w, const float* o_w, c
         ctx_record(ctx, 1, sho);
         if (sho) wo16 = sh.w16;
         else CK(transpose_convert_bf16(o_w, d, (int)a.HD, c.woT16, d, st, w.wo16));              // Wo (bf16) and Wo^T [HD, d] for backward
-        CK(gemm_nt_bf16(static_cast<bf16_t*>(c.O), wo16, w.a, 0, nullptr, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, st));
-        if (g_split_weights && wo16 != w.wo16) {
+        NtEpilogue eo;
+        if (g_split_weights && sho) {
             CK(bf16_residual(o_w, wo16, w.wo16, (long)d * a.HD, st));
-            NtEpilogue e2;
-            e2.addend = w.a;
-            CK(gemm_nt_bf16(static_cast<bf16_t*>(c.O), w.wo16, w.a, 0, e2, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, st));
+            eo.B_lo = w.wo16;
         }
+        CK(gemm_nt_bf16(static_cast<bf16_t*>(c.O), wo16, w.a, 0, eo, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, st));
     } else {
         CK(ttmi_launch_gemm(mk(static_cast<float*>(c.O), o_w, w.a, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, NT_, prec), st));
     }
@@ -825,16 +830,19 @@ static int ffn_fwd_impl(const float* y, const float* w1, const float* b1, const 
         else CK(transpose_convert_bf16(w1, Di, d, c.w1T16, Di, st, w.w1_16));                   // W1 (bf16) and W1^T [d, Di]
         if (sh2) w2_16 = s2.w16;
         else CK(transpose_convert_bf16(w2, d, Di, c.w2T16, d, st, w.w2_16));                    // W2 (bf16) and W2^T [Di, d]
-        NtEpilogue e1;
+        NtEpilogue e1, e2;
         e1.bias = b1; e1.relu = 1; e1.drop = d_in;
-        CK(gemm_nt_bf16(static_cast<bf16_t*>(c.h), w1_16, c.a1, 1, e1, (int)rows, Di, d, d, d, Di, st));
-        CK(gemm_nt_bf16(static_cast<bf16_t*>(c.a1), w2_16, w.f, 0, b2, (int)rows, d, Di, Di, Di, d, st));
-        if (g_split_weights && w2_16 != w.w2_16) {
-            CK(bf16_residual(w2, w2_16, w.w2_16, (long)d * Di, st));
-            NtEpilogue e2;
-            e2.addend = w.f;
-            CK(gemm_nt_bf16(static_cast<bf16_t*>(c.a1), w.w2_16, w.f, 0, e2, (int)rows, d, Di, Di, Di, d, st));
+        e2.bias = b2;
+        if (g_split_weights == 1 && sh1) {
+            CK(bf16_residual(w1, w1_16, w.w1_16, (long)d * Di, st));
+            e1.B_lo = w.w1_16;
         }
+        if (g_split_weights && sh2) {
+            CK(bf16_residual(w2, w2_16, w.w2_16, (long)d * Di, st));
+            e2.B_lo = w.w2_16;
+        }
+        CK(gemm_nt_bf16(static_cast<bf16_t*>(c.h), w1_16, c.a1, 1, e1, (int)rows, Di, d, d, d, Di, st));
+        CK(gemm_nt_bf16(static_cast<bf16_t*>(c.a1), w2_16, w.f, 0, e2, (int)rows, d, Di, Di, Di, d, st));
     } else {
         float* h = static_cast<float*>(c.h);
         float* a1 = static_cast<float*>(c.a1);

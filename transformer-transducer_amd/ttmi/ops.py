@@ -630,6 +630,17 @@ def gemm_nt_bf16(A, B, C, bias=None):
     return C
 
 
+def gemm_nt_bf16_two_term(A, B, B_lo, C, bias=None, relu=False):
+    """C[M,N] = act(A[M,K] @ (B + B_lo)[N,K]^T + bias) in one launch."""
+    M, K = A.shape
+    N = B.shape[0]
+    assert B_lo.shape == B.shape and B_lo.stride(0) == B.stride(0)
+    check(lib().ttmi_gemm_nt_bf16_two_term(_p(A), _p(B), _p(B_lo), _p(C), c_int(_DT[C.dtype]), _p(bias), c_int(1 if relu else 0), c_int(M),
+                                           c_int(N), c_int(K), c_long(A.stride(0)), c_long(B.stride(0)), c_long(C.stride(0)), _stream()),
+          "ttmi_gemm_nt_bf16_two_term")
+    return C
+
+
 def gemm_tn_bf16(A, B, C, accumulate=False, colsum_a=None):
     """C[M,N] (f32) (+)= A[K,M]^T @ B[K,N].  A, B bf16 row-major.  colsum_a (f32 [M]) += column sums of A."""
     K, M = A.shape
