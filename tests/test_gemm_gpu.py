@@ -141,3 +141,50 @@ def test_skinny_f32_epilogues_and_batches():
     assert rel_err(got, want) < 2e-6
     got, want = _run(51, 64, 51, True, False, False, nz=(1, 8), seed=15)          # per-head P.V (B stored [K, N])
     assert rel_err(got, want) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K,pad", [(2048, 4334, 1024, 0), (1792, 4334, 1024, 2), (3360, 1536, 512, 0), (1024, 128, 64, 0), (3001, 700, 96, 4),
+                                       (16000, 512, 2048, 0), (1025, 1024, 512, 0)])
+def test_large_f32_nt_on_the_persistent_kernel_exact_integers(M, N, K, pad):
+    """exact-f32 NT products with >= 1024 rows run on the persistent 256x128 LDS-DMA kernel with f32 operands (gemm_nt_f32: v_mfma_f32_16x16x4_f32
+    over ds_read_b128 fragments): integer operands are exact in f32 whatever the reduction order, so any staging / k-pairing / epilogue error
+    shows bit-for-bit - plain, bias + ReLU, and beta = 1 (accumulate into C), ragged M / N, padded pitches; same numbers with option 17 = 0"""
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randint(-4, 5, (M, K + 4 * pad), device="cuda", generator=g).float()
+    B = torch.randint(-4, 5, (N, K + 4 * pad), device="cuda", generator=g).float()
+    bias = torch.randint(-3, 4, (N,), device="cuda", generator=g).float()
+    C0 = torch.randint(-9, 10, (M + 1, N + pad), device="cuda", generator=g).float()
+    f = ops.GEMM_A_KMAJOR | ops.GEMM_B_KMAJOR
+    ref = A[:, :K].double() @ B[:, :K].double().t()
+    outs = []
+    for fast in (1, 0):
+        ops.set_option(17, fast)
+        try:
+            C1, C2, C3 = C0.clone(), C0.clone(), C0.clone()
+            ops.gemm(A, B, C1, M, N, K, A.stride(0), B.stride(0), C1.stride(0), f)
+            ops.gemm(A, B, C2, M, N, K, A.stride(0), B.stride(0), C2.stride(0), f | ops.GEMM_BIAS | ops.GEMM_RELU, bias=bias)
+            ops.gemm(A, B, C3, M, N, K, A.stride(0), B.stride(0), C3.stride(0), f | ops.GEMM_BIAS, bias=bias, beta=1.0)
+        finally:
+            ops.set_option(17, 1)
+        outs.append((C1, C2, C3))
+    C1, C2, C3 = outs[0]
+    assert torch.equal(C1[:M, :N].double(), ref)
+    assert torch.equal(C2[:M, :N].double(), (ref + bias.double()).clamp_min(0))
+    assert torch.equal(C3[:M, :N].double(), ref + bias.double() + C0[:M, :N].double())
+    for C in (C1, C2, C3):                                   # nothing outside the problem is touched
+        assert torch.equal(C[M], C0[M]) and torch.equal(C[:, N:], C0[:, N:])
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+
+
+def test_large_f32_nt_random_against_float64():
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    M, N, K = 2048, 1536, 512
+    A = torch.randn(M, K, device="cuda", generator=g)
+    B = torch.randn(N, K, device="cuda", generator=g)
+    C = torch.empty(M, N, device="cuda")
+    ops.gemm(A, B, C, M, N, K, K, K, N, ops.GEMM_A_KMAJOR | ops.GEMM_B_KMAJOR)
+    ref = A.double() @ B.double().t()
+    assert float((C.double() - ref).norm() / ref.norm()) < 5e-7

@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "transformer-transducer_amd"))
 
 
-def run(utts=8, T=500, emit_rate=0.1, precision="fp32", block=64):
+def run(utts=8, T=500, emit_rate=0.1, precision="fp32", block=None):
     """returns (result dict, model, inputs [utts,T,d], lengths, hypotheses)"""
     args = argparse.Namespace(utts=utts, T=T, emit_rate=emit_rate, precision=precision, block=block)
     os.environ["TTMI_PRECISION"] = args.precision
@@ -62,7 +62,7 @@ def run(utts=8, T=500, emit_rate=0.1, precision="fp32", block=64):
         torch.cuda.synchronize()
         t_enc = time.perf_counter() - t0
         t0 = time.perf_counter()
-        hyps1 = [model.decode(enc_states[b], lens[b], block=args.block) for b in range(args.utts)]
+        hyps1 = [model.decode(enc_states[b], lens[b], block=args.block or 64) for b in range(args.utts)]
         torch.cuda.synchronize()
         t_dec1 = time.perf_counter() - t0
         # the batched form (what recognize() runs): every utterance in lockstep over symbol steps, one label-encoder call per step
@@ -89,7 +89,7 @@ def run(utts=8, T=500, emit_rate=0.1, precision="fp32", block=64):
            "decode": "Transducer.decode_batch: the batch in lockstep over symbol steps (one joint call per scanned block, one label-encoder call per step: eager launches; a graph replay with config.decode_batch_graphs)",
            "one_utterance_at_a_time": {"utt_per_s": round(args.utts / (t_enc + t_dec1), 3), "decode_ms_per_utt": round(1e3 * t_dec1 / args.utts, 2),
                                        "tokens_identical_to_batched": hyps1 == hyps,
-                                       "host_syncs_per_utt_approx": round((nsym + args.utts * -(-args.T // args.block)) / args.utts, 1)}}
+                                       "host_syncs_per_utt_approx": round((nsym + args.utts * -(-args.T // (args.block or 64))) / args.utts, 1)}}
 
     return out, model, inputs, lens, hyps
 
@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--T", type=int, default=500)
     ap.add_argument("--emit-rate", type=float, default=0.1)
     ap.add_argument("--precision", default="fp32", choices=["bf16", "fp32"])
-    ap.add_argument("--block", type=int, default=64)
+    ap.add_argument("--block", type=int, default=None, help="frames per joint call (default: 64, or what fits one round of projection tiles)")
     a = ap.parse_args()
     print(json.dumps(run(a.utts, a.T, a.emit_rate, a.precision, a.block)[0]), flush=True)
 

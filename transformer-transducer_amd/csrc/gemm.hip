@@ -15,6 +15,7 @@
 // fragment reads are bank-conflict free.  Global loads for tile k+1 are issued before the MFMAs of
 // tile k (double-buffered LDS, one barrier per K-step).
 #include "gemm.h"
+#include "gemm_fast.h"
 
 namespace {
 
@@ -432,6 +433,18 @@ int ttmi_launch_gemm(const GemmDesc& d, hipStream_t st) {
         else hipLaunchKernelGGL(gemm_skinny_f32_kernel<false>, sgrid, dim3(NT), 0, st, p);
         TTMI_LAUNCH_CHECK("gemm_skinny_f32_kernel");
         return TTMI_OK;
+    }
+    // large exact-f32 NT products (fp32 mode: encoder / joint forward and dgrad; greedy decoding: the joint over a block of frames, the label encoder on
+    // long histories): the persistent 256x128 LDS-DMA kernel with f32 operands - 2 - 4 x the rate of the register-staged 128x128 kernel below
+    if (!bf16c && (d.flags & GEMM_A_KMAJOR) && (d.flags & GEMM_B_KMAJOR) && !(d.flags & (GEMM_ATOMIC | GEMM_MASK_AUX)) && d.splitk == 1 && d.nz1 * d.nz2 == 1 &&
+        d.c_dtype == DT_F32 && d.alpha == 1.f && (d.beta == 0.f || d.beta == 1.f) &&
+        gemm_nt_f32_ok(d.A, d.B, d.C, d.M, d.N, d.K, d.lda, d.ldb, d.ldc)) {
+        NtEpilogue e;
+        e.bias = (d.flags & GEMM_BIAS) ? d.bias : nullptr;
+        e.addend = d.beta == 1.f ? static_cast<const float*>(d.C) : nullptr;
+        e.relu = (d.flags & GEMM_RELU) ? 1 : 0;
+        e.drop = d.drop;
+        return gemm_nt_f32(static_cast<const float*>(d.A), static_cast<const float*>(d.B), static_cast<float*>(d.C), e, d.M, d.N, d.K, d.lda, d.ldb, d.ldc, st);
     }
     dim3 grid(cdiv(d.N, BN), cdiv(d.M, BM), d.nz1 * d.nz2 * d.splitk);
     TTMI_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large (M tiles %u, batch %u)", grid.y, grid.z);

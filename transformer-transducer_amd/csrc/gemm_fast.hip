@@ -1346,8 +1346,13 @@ static_assert(V9_INFLIGHT == 6, "v9: the counted vmcnt waits assume 6 LDS-DMA in
 
 // LEAN (as in v8): 1 = plain or bias-only epilogue (either output type), 2 = mask-only (bf16 output), 3 = f32 output + residual addend
 // (+ bias); launcher-checked alignment
-template <typename TC, int LEAN = 0>
+// F32IN: both operands are f32 in memory (p.A / p.B point at floats, lda / ldb count floats): a stage row is the same 128 bytes = 32 floats, every
+// fragment read the same ds_read_b128 (4 consecutive k of one row), consumed by four v_mfma_f32_16x16x4_f32 - step s takes component s of both
+// operands, i.e. the reduction runs in the order k = 16 c + 4 (lane >> 4) + s over the steps s of chunk c (any pairing of k is valid as long as A and
+// B agree).  The exact-f32 path of the fp32 mode and of greedy decoding (csrc/gemm.hip routes its large NT problems here).
+template <typename TC, int LEAN = 0, bool F32IN = false>
 __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p_) {
+    constexpr int ES = F32IN ? 4 : 2, TKE = 128 / ES;      // operand element size, k per stage
     FP p = p_;
     p.drop = drop_live(p.drop);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1355,7 +1360,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p_) {
     const int wr = wave & 3, wc = wave >> 2;               // waves w and w+4 (SIMD partners) differ in the column half
     const int grp = wave >> 2;                             // 1: runs one barrier behind
     const int ntiles = p.tiles_m * p.tiles_n;
-    const int nk = (p.K + TK - 1) / TK;
+    const int nk = (p.K + TKE - 1) / TKE;
 
     auto tile_id = [&](int it) { return (long)it * gridDim.x + (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3); };
     auto coords = [&](long id, int& bm, int& bn) {
@@ -1373,18 +1378,18 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p_) {
     const char* baseB = nullptr;
     const char* baseB2 = nullptr;
     auto sources = [&](int bm, int bn) {
-        baseA = reinterpret_cast<const char*>(p.A + (long)bm * p.lda);
-        baseB = reinterpret_cast<const char*>(p.B + (long)bn * p.ldb);
-        baseB2 = reinterpret_cast<const char*>(p.B2 + (long)bn * p.ldb);
+        baseA = reinterpret_cast<const char*>(p.A) + (long)bm * p.lda * ES;
+        baseB = reinterpret_cast<const char*>(p.B) + (long)bn * p.ldb * ES;
+        baseB2 = reinterpret_cast<const char*>(p.B2) + (long)bn * p.ldb * ES;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = (wave * 4 + j) * 8 + (lane >> 3);
-            oA[j] = (unsigned)(((long)min(r, p.M - 1 - bm) * p.lda + ((lane & 7) ^ ((r >> 1) & 7)) * 8) * 2);
+            oA[j] = (unsigned)(((long)min(r, p.M - 1 - bm) * p.lda * ES + ((lane & 7) ^ ((r >> 1) & 7)) * 16));
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int r = (wave * 2 + j) * 8 + (lane >> 3);
-            oB[j] = (unsigned)(((long)min(r, p.N - 1 - bn) * p.ldb + ((lane & 7) ^ ((r >> 1) & 7)) * 8) * 2);
+            oB[j] = (unsigned)(((long)min(r, p.N - 1 - bn) * p.ldb * ES + ((lane & 7) ^ ((r >> 1) & 7)) * 16));
         }
     };
     auto stage = [&](int stg, int kt) {
@@ -1407,7 +1412,8 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p_) {
         boff[ks] = T9M * 128 + (wc * 64 + (lane & 15)) * 128 + c;
     }
     f32x4 acc[4][4];
-    bf16x8 af[4][2], bfr[4][2];
+    using Frag = typename std::conditional<F32IN, f32x4, bf16x8>::type;
+    Frag af[4][2], bfr[4][2];
 #define V9_BAR() __builtin_amdgcn_s_barrier()
 
     int bm = 0, bn = 0;
@@ -1428,9 +1434,9 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p_) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) af[i][ks] = *reinterpret_cast<const bf16x8*>(base + aoff[ks] + i * 2048);
+                for (int i = 0; i < 4; ++i) af[i][ks] = *reinterpret_cast<const Frag*>(base + aoff[ks] + i * 2048);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bfr[i][ks] = *reinterpret_cast<const bf16x8*>(base + boff[ks] + i * 2048);
+                for (int i = 0; i < 4; ++i) bfr[i][ks] = *reinterpret_cast<const Frag*>(base + boff[ks] + i * 2048);
             }
             if (t + 2 < nk) {
                 TTMI_VM_GUARD("v9");                   // K-tile t + 1 (staged one tile ago) is older than this point
@@ -1447,8 +1453,15 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p_) {
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt][ks], af[mt][ks], acc[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < 4; ++nt) {
+                        if constexpr (F32IN) {
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[nt][ks][s4], af[mt][ks][s4], acc[mt][nt], 0, 0, 0);
+                        } else {
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt][ks], af[mt][ks], acc[mt][nt], 0, 0, 0);
+                        }
+                    }
             __builtin_amdgcn_s_setprio(0);
             V9_BAR();
             stg = stg == 2 ? 0 : stg + 1;
@@ -2227,6 +2240,7 @@ int enable_lds(K kernel, int bytes) {
 // Measured and dropped (same box, joint projection M=816000 N=4334 K=1024, v4 = 720 TFLOP/s): 256x128 3-stage ring with
 // counted vmcnt 621; persistent 256x256 with a 4-slice ring that never drains 668 (dgrad K=4352: 904 vs 938 for v6).
 int g_gemm_fast_version = 4;
+int g_f32_fast = 1;              // ttmi_set_option(17, 0): f32 NT products stay on the generic 128x128 kernel (A/B)
 int g_nt_stores = 1;             // streaming stores for bf16 outputs >= 256 MB (set_version(14 / 15) = off / on, generation unchanged)
 int g_num_cus = 0;
 int g_reserved_cus = 0;           // ttmi_set_option(6, n): process-wide default of the per-stream reservation below (measurement switch)
@@ -2473,6 +2487,37 @@ if (c_dtype == 0) {
     return TTMI_OK;
 }
 
+// ---- exact-f32 NT products on the persistent 256x128 kernel (F32IN): C[M,N] (f32) = epi(A[M,K] . B[N,K]^T), f32 operands
+bool gemm_nt_f32_ok(const void* A, const void* B, const void* C, int M, int N, int K, long lda, long ldb, long ldc) {
+    return g_f32_fast && aligned16(A) && aligned16(B) && C && M >= 1024 && N >= 128 && K >= 64 && K % 32 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
+           lda >= K && ldb >= K && ldc >= N && (long)255 * std::max(lda, ldb) * 4 + 128 < (1L << 32);
+}
+int gemm_nt_f32(const float* A, const float* B, float* C, const NtEpilogue& epi, int M, int N, int K, long lda, long ldb, long ldc, hipStream_t st) {
+    TTMI_REQUIRE(gemm_nt_f32_ok(A, B, C, M, N, K, lda, ldb, ldc), "gemm_nt_f32: shape/alignment not supported (M=%d N=%d K=%d)", M, N, K);
+    TTMI_REQUIRE(!epi.A2 && !epi.B_lo && !epi.rowsum && !epi.rowscale && !epi.mask, "gemm_nt_f32: bias / addend / ReLU / dropout epilogues only");
+    FP p;
+    p.A = reinterpret_cast<const bf16_t*>(A); p.B = reinterpret_cast<const bf16_t*>(B); p.C = C; p.bias = epi.bias; p.addend = epi.addend; p.mask = nullptr;
+    p.mask_mode = 0; p.nt = 0; p.relu = epi.relu; p.scale = epi.scale; p.drop = epi.drop;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.tiles_m = cdiv(M, T9M); p.tiles_n = cdiv(N, T9N); p.splitk = 1; p.ksteps = K / 32; p.atomic = 0; p.gm = GROUP_M; p.colsum = nullptr;
+    p.A2 = nullptr; p.B2 = nullptr; p.K2 = 0; p.lda2 = p.ldb2 = p.sB1b = p.sB2b = 0; p.colsum_mid = nullptr;
+    p.rowsum = nullptr; p.nparts = 0; p.exp_shift = nullptr; p.rowscale = nullptr; p.csw = nullptr;
+    fill_batch(p, FastBatch());
+    ensure_num_cus();
+    const long t9 = (long)p.tiles_m * p.tiles_n;
+    const int cus9 = std::max(8, (g_num_cus - reserved_cus(st)) / 8 * 8);
+    const int grid9 = (int)((std::min<long>(t9, cus9) + 7) / 8 * 8);
+    const bool base_ok = !p.relu && p.drop.p <= 0.f && aligned16(C) && ldc % 4 == 0 && (!p.bias || aligned16(p.bias));
+#define V9F_LAUNCH(L) do { if (int rc = enable_lds((gemm_nt_bf16_v9_kernel<float, L, true>), LDS9)) return rc; \
+            hipLaunchKernelGGL((gemm_nt_bf16_v9_kernel<float, L, true>), dim3((unsigned)grid9), dim3(NTH8), LDS9, st, p); } while (0)
+    if (base_ok && !p.addend) V9F_LAUNCH(1);
+    else if (base_ok && aligned16(p.addend)) V9F_LAUNCH(3);
+    else V9F_LAUNCH(0);
+#undef V9F_LAUNCH
+    TTMI_LAUNCH_CHECK("gemm_nt_bf16_v9_kernel<f32 operands>");
+    return TTMI_OK;
+}
+
 bool gemm_fast_tn_ok(const void* A, const void* B, const void* C, int M, int N, int K, long lda, long ldb) {
     return aligned16(A) && aligned16(B) && C && M > 0 && N > 0 && K >= 1 && lda % 8 == 0 && ldb % 8 == 0 &&
            lda >= ((M + 7) & ~7) && ldb >= ((N + 7) & ~7);
@@ -2591,6 +2636,7 @@ void gemm_fast_set_version(int v) {
     g_gemm_fast_version = v;
 }
 void gemm_fast_set_tn_target(int n) { g_tn_target_blocks = n; }
+void gemm_fast_set_f32(int on) { g_f32_fast = on; }
 void gemm_fast_set_reserved_cus(int n) { g_reserved_cus = n < 0 ? 0 : n; }
 void gemm_fast_stream_reserve_cus(hipStream_t st, int n) {
     int dev = 0;

@@ -1308,7 +1308,8 @@ int ttmi_set_dropout_salt(const unsigned* salt) {
 // process-wide switches for A/B measurements.  key 0: 1 = disable the fused attention kernels (bf16 pipeline only);
 // key 1: throughput-GEMM generation (see gemm_fast.hip); key 2: flash-kernel timing switches; key 3: 0 = no wgrad fork
 int ttmi_set_option(int key, int value) {
-    TTMI_REQUIRE(key >= 0 && key <= 16, "set_option: unknown key %d", key);
+    TTMI_REQUIRE(key >= 0 && key <= 17, "set_option: unknown key %d", key);
+    if (key == 17) { gemm_fast_set_f32(value); return TTMI_OK; }
     if (key == 16) { g_scatter_launch = value; return TTMI_OK; }
     if (key == 15) { flash_set_bwd_gen(value); return TTMI_OK; }
     if (key == 14) { flash_set_resident(value); return TTMI_OK; }

@@ -583,7 +583,7 @@ class Transducer(nn.Module):
         return g
 
     @torch.no_grad()
-    def decode_batch(self, enc_states, lengths, block=64):
+    def decode_batch(self, enc_states, lengths, block=None):
         """Greedy decoding of EVERY utterance of a batch at once: the token lists `decode(enc_states[b], lengths[b])` returns, for all b
         (tt/model.py:92-108 loops over the utterances, one host round trip per frame each).  The batch advances in lockstep over SYMBOL
         steps: in step s every utterance still decoding looks for its next non-blank frame (blocks of `block` frames from its own position,
@@ -591,10 +591,26 @@ class Transducer(nn.Module):
         histories and flags on the device), then ONE label-encoder call of length s + 1 re-computes all label states (every history has
         exactly s + 1 tokens - the relative-position term depends on the sequence length, so utterances of different history lengths
         could not share a call).  Host synchronisations: one 8-byte read per scanned block of the whole batch (about one per symbol step)
-        instead of one per symbol and utterance; label-encoder launches: one (graph replay) per symbol step instead of one per symbol and
-        utterance.  Same arithmetic per utterance as `decode`: same tokens."""
+        instead of one per symbol and utterance; label-encoder launches: one call per symbol step instead of one per symbol and
+        utterance.  Utterances that have run out of frames LEAVE the batch (no extra host round trip: the count of the living comes with the
+        flags, the rows from a stable sort on the device), so the long tail of a batch - the longest hypothesis of 32 synthetic utterances
+        has 105 symbols, the mean 50 - runs on a handful of rows instead of 32.  Same arithmetic per utterance as `decode`: same tokens.
+        block = frames scored per joint call (None: 64, or what lets the projection finish in one round of tiles)."""
         dev = enc_states.device
         B, T = enc_states.shape[0], enc_states.shape[1]
+        col_tiles = -(-self.joint.project_layer.weight.shape[0] // 128)
+
+        def frames_per_call(n_utt):
+            # frames scanned per joint call: 64, or fewer when that lets the projection [n_utt * block, V] - the one large product of a symbol step, on
+            # the persistent 256 x 128-tile f32 kernel from 1024 rows on - finish in ONE round of tiles over the 256 CUs (32 utterances, V = 4334:
+            # 56 frames = 7 x 34 tiles, 151 us, against 64 frames = 8 x 34 tiles in two rounds, 296 us)
+            if block is not None:
+                return block
+            row_tiles = 256 // col_tiles
+            if n_utt * 64 >= 1024 and -(-n_utt * 64 // 256) > row_tiles >= 4:
+                return max(16, row_tiles * 256 // n_utt)
+            return 64
+
         T_len = torch.as_tensor(lengths, dtype=torch.int32).to(dev).clamp(max=T).contiguous()
         # Label-encoder graphs for a whole batch are opt-in (config.decode_batch_graphs).  They buy nothing at 32 utterances (96 against 97 utt/s:
         # a step's ~150 launches are no longer what the host waits for) and, in tools/bench_decode.py's call order, a third of the PROCESSES
@@ -603,18 +619,21 @@ class Transducer(nn.Module):
         # bit-identical to the eager call on the same tokens whatever the scratch arenas hold, tools/debug/decode_poison.py - the cause was not
         # found in round 4).  One utterance at a time (`decode`) keeps its graphs: there they are the speed, and its tokens never moved.
         graphs = self._label_state_graphs(dev, B) if self.config.decode_batch_graphs else None
-        hist = torch.zeros(B, T + 2, dtype=torch.long, device=dev)   # column 0 = the start symbol (blank); at most one symbol per frame
+        final_hist = torch.zeros(B, T + 2, dtype=torch.long, device=dev)   # column 0 = the start symbol (blank); at most one symbol per frame
+        final_count = torch.zeros(B, dtype=torch.int32, device=dev)
+        hist = final_hist.clone()
+        orig = torch.arange(B, device=dev)                           # the utterance each row of the (shrinking) batch belongs to
         t = torch.zeros(B, dtype=torch.int32, device=dev)
         need = torch.ones(B, dtype=torch.int32, device=dev)
         done = torch.zeros(B, dtype=torch.int32, device=dev)
         count = torch.zeros(B, dtype=torch.int32, device=dev)
         flags = torch.zeros(2, dtype=torch.int32, device=dev)
-        key = torch.full((B,), block << 32, dtype=torch.int64, device=dev)
-        rows = torch.arange(block, device=dev, dtype=torch.long)[None, :]
-        bidx = torch.arange(B, device=dev)[:, None]
+        n_frames = frames_per_call(B)
+        key = torch.full((B,), n_frames << 32, dtype=torch.int64, device=dev)
+        rows = torch.arange(n_frames, device=dev, dtype=torch.long)[None, :]
 
         def label_states(n_hist):
-            """label-encoder outputs at the last position of every history (all of length n_hist) -> [B, 1, d]"""
+            """label-encoder outputs at the last position of every history (all of length n_hist) -> [rows of the batch, 1, d]"""
             if graphs is not None and n_hist <= graphs.MAX_L:
                 graphs.master[:, :n_hist].copy_(hist[:, :n_hist])
                 return graphs.state(n_hist)
@@ -625,19 +644,34 @@ class Transducer(nn.Module):
         while True:
             torch.sub(1, done, out=need)
             while True:
-                idx = (t.long()[:, None] + rows).clamp_(max=T - 1)                             # frames t_b .. t_b + block - 1 (beyond T_b: ignored by the scan)
-                logits = self.joint(enc_states[bidx, idx], dec_state)                             # [B, block, 1, V]
+                idx = (t.long()[:, None] + rows).clamp_(max=T - 1)                             # frames t_b .. t_b + n_frames - 1 (beyond T_b: ignored by the scan)
+                logits = self.joint(enc_states[orig[:, None], idx], dec_state)                    # [rows, n_frames, 1, V]
                 ops.greedy_scan_batch(logits[:, :, 0, :], t, T_len, need, key)
-                ops.greedy_advance(key, block, n_hist, hist, t, T_len, need, done, count, flags)
+                ops.greedy_advance(key, n_frames, n_hist, hist, t, T_len, need, done, count, flags)
                 pending, alive = flags.tolist()                                                   # the batch's one host round trip per block
                 if pending == 0:
                     break
             if alive == 0:
                 break
+            if alive < hist.shape[0] and graphs is None:
+                # finished utterances leave the batch: every later label-encoder and joint call runs on the rows still decoding (per-utterance
+                # arithmetic does not depend on who else is in the batch).  Their histories are kept; no host round trip - the row count is
+                # `alive`, the rows are the first `alive` of a stable sort by the done flag
+                final_hist.index_copy_(0, orig, hist)
+                final_count.index_copy_(0, orig, count)
+                keep = torch.argsort(done, stable=True)[:alive]
+                hist, orig, t, T_len, count = hist[keep], orig[keep], t[keep].contiguous(), T_len[keep].contiguous(), count[keep].contiguous()
+                need = torch.zeros(alive, dtype=torch.int32, device=dev)
+                done = torch.zeros(alive, dtype=torch.int32, device=dev)
+                n_frames = frames_per_call(alive)
+                key = torch.full((alive,), n_frames << 32, dtype=torch.int64, device=dev)
+                rows = torch.arange(n_frames, device=dev, dtype=torch.long)[None, :]
             n_hist += 1
             dec_state = label_states(n_hist)
-        final = hist.cpu()
-        counts = count.cpu().tolist()
+        final_hist.index_copy_(0, orig, hist)
+        final_count.index_copy_(0, orig, count)
+        final = final_hist.cpu()
+        counts = final_count.cpu().tolist()
         return [final[b, 1:1 + counts[b]].tolist() for b in range(B)]
 
     @torch.no_grad()
