@@ -761,7 +761,9 @@ static_assert(V8_STAGE_DMA == 2 && V8_INFLIGHT == 6, "v8: the counted vmcnt wait
 // (the FFN's first Linear): their epilogues
 // carry no residual / ReLU / dropout code and test nothing per store, which
 // costs the main loop registers in the general instance
-template <typename TC, int LEAN = 0>
+// KW: the K loop runs twice over A's K-tiles, the second time against p.B2 (two-term weights, NtEpilogue::B_lo) - its own instances, so that the
+// default ones carry no trace of it (the scalar selects in stage() cost the joint's three GEMMs 0.1 - 0.2 ms per C2 step when they were unconditional)
+template <typename TC, int LEAN = 0, bool KW = false>
 __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p_) {
     FP p = p_;
     p.drop = drop_live(p.drop);
@@ -796,7 +798,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p_) {
     auto sources = [&](int bm, int bn) {
         baseA = reinterpret_cast<const char*>(p.A + (long)bm * p.lda);
         baseB = reinterpret_cast<const char*>(p.B + (long)bn * p.ldb);
-        baseB2 = reinterpret_cast<const char*>(p.B2 + (long)bn * p.ldb);
+        if constexpr (KW) baseB2 = reinterpret_cast<const char*>(p.B2 + (long)bn * p.ldb);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int rho = (wave * 2 + j) * 8 + (lane >> 3);
@@ -812,7 +814,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p_) {
     // kind: 0 = A h0, 1 = A h1, 2 = B h0, 3 = B h1 (also the region index inside a buffer)
     auto stage = [&](int kind, int buf, int kt) {
         char* dst = smem + buf * BUF8 + kind * HT8 + wave * 2048;
-        const bool second = p.kwrap && kt >= p.kwrap;                              // second weight term: A's K-tiles again, against B2
+        const bool second = KW && kt >= p.kwrap;                                   // second weight term: A's K-tiles again, against B2
         const char* base = (kind < 2 ? baseA : second ? baseB2 : baseB) + (long)(second ? kt - p.kwrap : kt) * (TK * 2);      // K % 64 == 0 (checked by the launcher): no tail
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1350,7 +1352,7 @@ static_assert(V9_INFLIGHT == 6, "v9: the counted vmcnt waits assume 6 LDS-DMA in
 // fragment read the same ds_read_b128 (4 consecutive k of one row), consumed by four v_mfma_f32_16x16x4_f32 - step s takes component s of both
 // operands, i.e. the reduction runs in the order k = 16 c + 4 (lane >> 4) + s over the steps s of chunk c (any pairing of k is valid as long as A and
 // B agree).  The exact-f32 path of the fp32 mode and of greedy decoding (csrc/gemm.hip routes its large NT problems here).
-template <typename TC, int LEAN = 0, bool F32IN = false>
+template <typename TC, int LEAN = 0, bool F32IN = false, bool KW = false>            // KW: as in v8
 __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p_) {
     constexpr int ES = F32IN ? 4 : 2, TKE = 128 / ES;      // operand element size, k per stage
     FP p = p_;
@@ -1380,7 +1382,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p_) {
     auto sources = [&](int bm, int bn) {
         baseA = reinterpret_cast<const char*>(p.A) + (long)bm * p.lda * ES;
         baseB = reinterpret_cast<const char*>(p.B) + (long)bn * p.ldb * ES;
-        baseB2 = reinterpret_cast<const char*>(p.B2) + (long)bn * p.ldb * ES;
+        if constexpr (KW) baseB2 = reinterpret_cast<const char*>(p.B2) + (long)bn * p.ldb * ES;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = (wave * 4 + j) * 8 + (lane >> 3);
@@ -1394,7 +1396,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p_) {
     };
     auto stage = [&](int stg, int kt) {
         char* dst = smem + stg * STG9;
-        const bool second = p.kwrap && kt >= p.kwrap;      // the weight's second bf16 term: the same A columns again, against B2
+        const bool second = KW && kt >= p.kwrap;           // the weight's second bf16 term: the same A columns again, against B2
         const int ka = second ? kt - p.kwrap : kt;
         const char* ba = baseA + (long)ka * (TK * 2);
         const char* bb = (second ? baseB2 : baseB) + (long)ka * (TK * 2);
@@ -2374,7 +2376,10 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
         const bool lean2 = base_ok && p.mask && !p.bias && c_dtype == 1 && ldc % 8 == 0 && aligned16(p.mask);
 #define V9_LAUNCH(...) do { if (int rc = enable_lds((gemm_nt_bf16_v9_kernel<__VA_ARGS__>), LDS9)) return rc; \
             hipLaunchKernelGGL((gemm_nt_bf16_v9_kernel<__VA_ARGS__>), dim3((unsigned)grid9), dim3(NTH8), LDS9, st, p); } while (0)
-        if (c_dtype == 0) {
+        if (p.kwrap) {                                     // two-term weights (an option, off by default): the general-epilogue instances
+            if (c_dtype == 0) V9_LAUNCH(float, 0, false, true);
+            else V9_LAUNCH(bf16_t, 0, false, true);
+        } else if (c_dtype == 0) {
             if (lean1) V9_LAUNCH(float, 1);
             else if (p.addend && !p.mask && !p.relu && p.drop.p <= 0.f && ldc % 4 == 0 && aligned16(C) && aligned16(p.addend) && (!p.bias || aligned16(p.bias))) V9_LAUNCH(float, 3);
             else V9_LAUNCH(float, 0);
@@ -2420,7 +2425,16 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
         const long nwg8 = (long)p.tiles_m * p.tiles_n;
 const int cus8 = nwg8 < 1024 ? std::max(8, (g_num_cus - reserved) / 8 * 8) : g_num_cus;   // encoder-sized problems only (see v9)
         const int grid8 = (int)((std::min<long>(nwg8, cus8) + 7) / 8 * 8);   // multiple of 8: one share of every round per XCD
-if (c_dtype == 0) {
+if (p.kwrap) {
+            TTMI_REQUIRE(!needs8, "gemm_nt_bf16: no second weight term with the exp-store / row-scale epilogues");
+            if (c_dtype == 0) {
+                if (int rc = enable_lds((gemm_nt_bf16_v8_kernel<float, 0, true>), LDS8)) return rc;
+                hipLaunchKernelGGL((gemm_nt_bf16_v8_kernel<float, 0, true>), dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
+            } else {
+                if (int rc = enable_lds((gemm_nt_bf16_v8_kernel<bf16_t, 0, true>), LDS8)) return rc;
+                hipLaunchKernelGGL((gemm_nt_bf16_v8_kernel<bf16_t, 0, true>), dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
+            }
+        } else if (c_dtype == 0) {
             if (int rc = enable_lds(gemm_nt_bf16_v8_kernel<float>, LDS8)) return rc;
             hipLaunchKernelGGL(gemm_nt_bf16_v8_kernel<float>, dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
         } else if (p.rowsum) {

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libttmi.so")
+LIB_PATH = os.environ.get("TTMI_LIB") or os.path.join(_HERE, "libttmi.so")      # (TTMI_LIB: another build of the same library, for same-box A/B runs)
 _lib = None
 
 
