@@ -188,3 +188,50 @@ def test_large_f32_nt_random_against_float64():
     ops.gemm(A, B, C, M, N, K, K, K, N, ops.GEMM_A_KMAJOR | ops.GEMM_B_KMAJOR)
     ref = A.double() @ B.double().t()
     assert float((C.double() - ref).norm() / ref.norm()) < 5e-7
+
+
+@pytest.mark.parametrize("M,N,K,pad", [(800, 1536, 512, 0), (192, 1536, 512, 0), (1, 64, 32, 0), (65, 130, 96, 3), (333, 1023, 1024, 1), (2048, 4334, 1024, 0),
+                                       (3360, 512, 1024, 0), (640, 514, 64, 2)])
+def test_mid_f32_nt_64x64_tiles_exact_integers(M, N, K, pad):
+    """the 64 x 64-tile exact-f32 kernel of the label-encoder-sized products (gemm_nt_f32_mid_kernel: LDS-DMA stages, v_mfma_f32_16x16x4_f32), forced
+    with option 17 = 2: integer operands are exact whatever the reduction order - plain, bias + ReLU, accumulate; ragged M / N down to one row, pitches
+    that are / are not multiples of 4 floats (vector / element-wise stores); rows and columns outside the problem untouched; equal to option 17 = 0"""
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + pad)
+    A = torch.randint(-4, 5, (M, K + 4 * pad), device="cuda", generator=g).float()
+    B = torch.randint(-4, 5, (N, K + 4 * pad), device="cuda", generator=g).float()
+    bias = torch.randint(-3, 4, (N,), device="cuda", generator=g).float()
+    C0 = torch.randint(-9, 10, (M + 1, N + pad), device="cuda", generator=g).float()
+    f = ops.GEMM_A_KMAJOR | ops.GEMM_B_KMAJOR
+    ref = A[:, :K].double() @ B[:, :K].double().t()
+    outs = []
+    for mode in (2, 0):
+        ops.set_option(17, mode)
+        try:
+            C1, C2, C3 = C0.clone(), C0.clone(), C0.clone()
+            ops.gemm(A, B, C1, M, N, K, A.stride(0), B.stride(0), C1.stride(0), f)
+            ops.gemm(A, B, C2, M, N, K, A.stride(0), B.stride(0), C2.stride(0), f | ops.GEMM_BIAS | ops.GEMM_RELU, bias=bias)
+            ops.gemm(A, B, C3, M, N, K, A.stride(0), B.stride(0), C3.stride(0), f | ops.GEMM_BIAS, bias=bias, beta=1.0)
+        finally:
+            ops.set_option(17, 1)
+        outs.append((C1, C2, C3))
+    C1, C2, C3 = outs[0]
+    assert torch.equal(C1[:M, :N].double(), ref)
+    assert torch.equal(C2[:M, :N].double(), (ref + bias.double()).clamp_min(0))
+    assert torch.equal(C3[:M, :N].double(), ref + bias.double() + C0[:M, :N].double())
+    for C in (C1, C2, C3):
+        assert torch.equal(C[M], C0[M]) and torch.equal(C[:, N:], C0[:, N:])
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+
+
+def test_mid_f32_nt_random_against_float64():
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(6)
+    M, N, K = 800, 1536, 512
+    A = torch.randn(M, K, device="cuda", generator=g)
+    B = torch.randn(N, K, device="cuda", generator=g)
+    C = torch.empty(M, N, device="cuda")
+    ops.gemm(A, B, C, M, N, K, K, K, N, ops.GEMM_A_KMAJOR | ops.GEMM_B_KMAJOR)        # default rule: 13 x 24 tiles of 64 x 64
+    ref = A.double() @ B.double().t()
+    assert float((C.double() - ref).norm() / ref.norm()) < 5e-7

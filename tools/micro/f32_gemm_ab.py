@@ -10,27 +10,26 @@ sys.path.insert(0, os.path.join(ROOT, "transformer-transducer_amd"))
 from ttmi import ops
 
 f = ops.GEMM_A_KMAJOR | ops.GEMM_B_KMAJOR
-for M, N, K in [(2048, 4334, 1024), (1792, 4334, 1024), (2048, 1024, 512), (3360, 1536, 512), (3360, 1024, 512), (3360, 512, 1024), (1600, 1536, 512),
-                (1024, 1536, 512), (1024, 512, 1024), (2560, 1536, 512), (2560, 512, 512), (16000, 1536, 512), (16000, 512, 1024)]:
+NAMES = {3: "persistent 256x128", 2: "64x64 tiles", 0: "gemm.hip (32x32 / 128x128)", 1: "default rule"}
+for M, N, K in [(64, 1536, 512), (128, 1536, 512), (192, 1536, 512), (256, 1536, 512), (256, 512, 512), (256, 512, 1024), (384, 1536, 512), (512, 1536, 512), (512, 512, 1024),
+                (800, 1536, 512), (800, 512, 512), (800, 1024, 512), (800, 512, 1024), (1024, 1536, 512), (1200, 1536, 512), (1600, 1536, 512), (1600, 512, 1024),
+                (2048, 1536, 512), (2048, 1024, 512), (2560, 512, 512), (3360, 1536, 512), (3360, 512, 1024), (1792, 4334, 1024), (2048, 4334, 1024), (16000, 1536, 512)]:
     A = torch.randn(M, K, device="cuda")
     B = torch.randn(N, K, device="cuda")
     C = torch.empty(M, N, device="cuda")
     row = []
-    for fast in (1, 0, 2):
-        ops.set_option(17, fast & 1)
-        ops.set_option(7, 8192 if fast == 2 else 128)                # third column: the 32x32-tile kernel of the decoder-sized products, forced
+    for mode in (3, 2, 0, 1):
+        ops.set_option(17, mode)
         for _ in range(3):
             ops.gemm(A, B, C, M, N, K, K, K, N, f)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(10):
+        for _ in range(20):
             ops.gemm(A, B, C, M, N, K, K, K, N, f)
         e1.record()
         torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 100
-        row.append((us, 2.0 * M * N * K / us / 1e6))
+        us = e0.elapsed_time(e1) * 50
+        row.append("%s %7.1f us %5.1f TF" % (NAMES[mode], us, 2.0 * M * N * K / us / 1e6))
     ops.set_option(17, 1)
-    ops.set_option(7, 128)
-    print("M %6d N %5d K %5d | persistent %8.1f us %6.1f TFLOP/s | generic %8.1f us %6.1f TFLOP/s | 32x32 tiles %8.1f us %6.1f TFLOP/s" %
-          (M, N, K, row[0][0], row[0][1], row[1][0], row[1][1], row[2][0], row[2][1]))
+    print("M %5d N %5d K %5d | " % (M, N, K) + " | ".join(row))

@@ -390,6 +390,8 @@ int launch_layout(const KParams& p, dim3 grid, hipStream_t st) {
 
 }  // namespace
 
+static int g_pers_min_tiles = 512;   // f32 NT: the persistent 256 x 128 kernel from two full rounds of its tiles on, 64 x 64 tiles below (profiles/r04_f32_gemm_kernels.txt)
+static int g_mid_min_tiles = 72;     // ... and the 64 x 64-tile kernel from this many of ITS tiles on (fewer: the 32 x 32-tile kernel, whose waves split K)
 static int g_skinny_rows = 128;     // f32 products with at most this many rows go to gemm_skinny_f32_kernel (0 = never)
 void ttmi_gemm_set_skinny_rows(int rows) { g_skinny_rows = rows < 0 ? 0 : rows; }
 
@@ -421,6 +423,30 @@ int ttmi_launch_gemm(const GemmDesc& d, hipStream_t st) {
     };
     p.vecA = vec_ok(d.A, ea, d.lda, d.sA1, d.sA2);
     p.vecB = vec_ok(d.B, eb, d.ldb, d.sB1, d.sB2);
+    // exact-f32 NT products with plain epilogues leave this file when they are large enough:
+    //  - >= 1024 rows and enough 256 x 128 tiles: the persistent LDS-DMA kernel with f32 operands (fp32 mode: encoder / joint forward; greedy decoding: the
+    //    joint over a block of frames) - 1.3 - 2 x the register-staged 128 x 128 kernel below;
+    //  - a few hundred to a few thousand rows (greedy decoding: the label encoder on alive x history rows): 64 x 64 tiles through LDS
+    const int f32_mode = gemm_fast_f32_mode();
+    if (!bf16c && f32_mode != 0 && (d.flags & GEMM_A_KMAJOR) && (d.flags & GEMM_B_KMAJOR) && !(d.flags & (GEMM_ATOMIC | GEMM_MASK_AUX)) && d.splitk == 1 &&
+        d.nz1 * d.nz2 == 1 && d.c_dtype == DT_F32 && d.alpha == 1.f && (d.beta == 0.f || d.beta == 1.f)) {
+        const long t9 = (long)cdiv(d.M, 256) * cdiv(d.N, 128), t64 = (long)cdiv(d.M, 64) * cdiv(d.N, 64);
+        const bool pers_ok = f32_mode != 2 && gemm_nt_f32_ok(d.A, d.B, d.C, d.M, d.N, d.K, d.lda, d.ldb, d.ldc);
+        const bool mid_ok = f32_mode != 3 && d.drop.p <= 0.f && gemm_nt_f32_mid_ok(d.A, d.B, d.C, d.M, d.N, d.K, d.lda, d.ldb, d.ldc);
+        const bool want_pers = pers_ok && (f32_mode == 3 || !mid_ok || t9 >= g_pers_min_tiles);
+        const bool want_mid = mid_ok && !want_pers && (f32_mode == 2 || t64 >= g_mid_min_tiles);
+        if (want_pers) {
+            NtEpilogue e;
+            e.bias = (d.flags & GEMM_BIAS) ? d.bias : nullptr;
+            e.addend = d.beta == 1.f ? static_cast<const float*>(d.C) : nullptr;
+            e.relu = (d.flags & GEMM_RELU) ? 1 : 0;
+            e.drop = d.drop;
+            return gemm_nt_f32(static_cast<const float*>(d.A), static_cast<const float*>(d.B), static_cast<float*>(d.C), e, d.M, d.N, d.K, d.lda, d.ldb, d.ldc, st);
+        }
+        if (want_mid)
+            return gemm_nt_f32_mid(static_cast<const float*>(d.A), static_cast<const float*>(d.B), static_cast<float*>(d.C), (d.flags & GEMM_BIAS) ? d.bias : nullptr,
+                                   d.beta == 1.f, (d.flags & GEMM_RELU) ? 1 : 0, d.M, d.N, d.K, d.lda, d.ldb, d.ldc, st);
+    }
     // ... and products of up to 2048 rows whose 128 x 128 tiling would leave more than half of the CUs without a workgroup: the batched greedy
     // decoder's label-encoder calls (B x history rows, 512 ... 1536 columns: 16 ... 48 such tiles, each walking K in 16-wide barrier steps
     // for ~100 us; 32 x 32 tiles with the reduction split over a workgroup's waves: ~10 us.  decode_batch at 8 utterances: 26 -> 63 utt/s)
@@ -433,18 +459,6 @@ int ttmi_launch_gemm(const GemmDesc& d, hipStream_t st) {
         else hipLaunchKernelGGL(gemm_skinny_f32_kernel<false>, sgrid, dim3(NT), 0, st, p);
         TTMI_LAUNCH_CHECK("gemm_skinny_f32_kernel");
         return TTMI_OK;
-    }
-    // large exact-f32 NT products (fp32 mode: encoder / joint forward and dgrad; greedy decoding: the joint over a block of frames, the label encoder on
-    // long histories): the persistent 256x128 LDS-DMA kernel with f32 operands - 2 - 4 x the rate of the register-staged 128x128 kernel below
-    if (!bf16c && (d.flags & GEMM_A_KMAJOR) && (d.flags & GEMM_B_KMAJOR) && !(d.flags & (GEMM_ATOMIC | GEMM_MASK_AUX)) && d.splitk == 1 && d.nz1 * d.nz2 == 1 &&
-        d.c_dtype == DT_F32 && d.alpha == 1.f && (d.beta == 0.f || d.beta == 1.f) &&
-        gemm_nt_f32_ok(d.A, d.B, d.C, d.M, d.N, d.K, d.lda, d.ldb, d.ldc)) {
-        NtEpilogue e;
-        e.bias = (d.flags & GEMM_BIAS) ? d.bias : nullptr;
-        e.addend = d.beta == 1.f ? static_cast<const float*>(d.C) : nullptr;
-        e.relu = (d.flags & GEMM_RELU) ? 1 : 0;
-        e.drop = d.drop;
-        return gemm_nt_f32(static_cast<const float*>(d.A), static_cast<const float*>(d.B), static_cast<float*>(d.C), e, d.M, d.N, d.K, d.lda, d.ldb, d.ldc, st);
     }
     dim3 grid(cdiv(d.N, BN), cdiv(d.M, BM), d.nz1 * d.nz2 * d.splitk);
     TTMI_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large (M tiles %u, batch %u)", grid.y, grid.z);

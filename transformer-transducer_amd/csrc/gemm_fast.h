@@ -62,9 +62,14 @@ bool gemm_tn_group_fits(const TnProblem& q);
 int gemm_tn_bf16_group(const TnProblem* probs, int n, hipStream_t st);   // deterministic (no atomics) for problems that fit the 256x128 tiling
 void gemm_fast_set_version(int v);   // kernel generation for A/B runs, see gemm_fast.hip (default 4)
 void gemm_fast_set_tn_target(int n);
-void gemm_fast_set_f32(int on);      // 0: gemm_nt_f32_ok() answers no (A/B against the generic f32 kernel)
+void gemm_fast_set_f32(int on);      // 0: gemm_nt_f32_ok() / gemm_nt_f32_mid_ok() answer no (A/B against the f32 kernels of csrc/gemm.hip); 2 / 3: one of the two only
+int gemm_fast_f32_mode();
 // exact-f32 NT product on the persistent 256x128 kernel (f32 operands through LDS-DMA, v_mfma_f32_16x16x4_f32): C[M,N] = epi(A[M,K] . B[N,K]^T),
 // epilogue = bias / addend / ReLU / dropout of NtEpilogue; M >= 1024, N >= 128, K % 32 == 0, 16-byte aligned operands
+// mid-sized exact-f32 NT product (64 x 64 tiles, any M / N, K % 32 == 0): C = [C +] A . B^T [+ bias] [ReLU]
+bool gemm_nt_f32_mid_ok(const void* A, const void* B, const void* C, int M, int N, int K, long lda, long ldb, long ldc);
+int gemm_nt_f32_mid(const float* A, const float* B, float* C, const float* bias, int accumulate, int relu, int M, int N, int K, long lda, long ldb,
+                    long ldc, hipStream_t st);
 bool gemm_nt_f32_ok(const void* A, const void* B, const void* C, int M, int N, int K, long lda, long ldb, long ldc);
 int gemm_nt_f32(const float* A, const float* B, float* C, const NtEpilogue& epi, int M, int N, int K, long lda, long ldb, long ldc, hipStream_t st);
 void gemm_fast_set_reserved_cus(int n);   // process-wide default (measurement switch)

@@ -1586,6 +1586,125 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p_) {
 }
 
 // =====================================================================================================================
+// Mid-sized exact-f32 NT products (greedy decoding: the label encoder on alive x history = 200 .. 2000 rows; d = 512 .. 1536 columns): too few
+// 256 x 128 tiles for the persistent kernel to fill the chip, too many rows for the 32 x 32-tile kernel of csrc/gemm.hip, which re-reads every
+// operand row from L2 once per 32 output columns (31 - 34 TFLOP/s).  64 x 64 tiles, 4 waves as 2 x 2 (32 x 32 each = 2 x 2 v_mfma_f32_16x16x4_f32
+// tiles, operands swapped so a lane owns 4 consecutive columns of a row), three 16 KiB LDS stages of 32 floats of K filled by LDS-DMA with the
+// 256 x 128 kernel's swizzle and fragment reads, ONE barrier per stage, counted vmcnt; 48 KiB of LDS and < 128 registers: three workgroups per CU.
+// =====================================================================================================================
+constexpr int TMID = 64, STGM = 2 * TMID * 128, LDSM = 3 * STGM;
+constexpr int MID_INFLIGHT = STGM / (256 * 16);        // LDS-DMA instructions per wave (of 4) and stage
+static_assert(MID_INFLIGHT == 4, "mid f32: the counted vmcnt waits assume 4 LDS-DMA instructions per stage");
+
+__global__ __launch_bounds__(256, 3) void gemm_nt_f32_mid_kernel(const FP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave & 1, wc = wave >> 1;
+    const int bn = blockIdx.x * TMID, bm = blockIdx.y * TMID;
+    const int nk = p.K / 32;                               // launcher: K % 32 == 0
+    unsigned oA[2], oB[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (wave * 2 + j) * 8 + (lane >> 3);
+        const unsigned slot = (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
+        oA[j] = (unsigned)((long)min(r, p.M - 1 - bm) * p.lda * 4) + slot;
+        oB[j] = (unsigned)((long)min(r, p.N - 1 - bn) * p.ldb * 4) + slot;
+    }
+    const char* baseA = reinterpret_cast<const char*>(p.A) + (long)bm * p.lda * 4;
+    const char* baseB = reinterpret_cast<const char*>(p.B) + (long)bn * p.ldb * 4;
+    auto stage = [&](int stg, int kt) {
+        char* dst = smem + stg * STGM;
+        const char* ba = baseA + (long)kt * 128;
+        const char* bb = baseB + (long)kt * 128;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(ba + oA[j], dst + (wave * 2 + j) * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(bb + oB[j], dst + TMID * 128 + (wave * 2 + j) * 1024);
+    };
+    const int sw = (lane >> 1) & 7;
+    int aoff[2], boff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int c = ((ks * 4 + (lane >> 4)) ^ sw) << 4;
+        aoff[ks] = (wr * 32 + (lane & 15)) * 128 + c;
+        boff[ks] = TMID * 128 + (wc * 32 + (lane & 15)) * 128 + c;
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 af[2][2], bfr[2][2];
+
+    stage(0, 0);
+    if (nk > 1) { TTMI_VM_GUARD("mid"); stage(1, 1); TTMI_VM_WAIT("mid", MID_INFLIGHT); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int stg = 0;
+    for (int t = 0; t < nk; ++t) {
+        const char* base = smem + stg * STGM;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i][ks] = *reinterpret_cast<const f32x4*>(base + aoff[ks] + i * 2048);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) bfr[i][ks] = *reinterpret_cast<const f32x4*>(base + boff[ks] + i * 2048);
+        }
+        if (t + 2 < nk) {
+            TTMI_VM_GUARD("mid");                          // K-tile t + 1 (staged one tile ago) is older than this point
+            stage(stg == 0 ? 2 : stg - 1, t + 2);          // (t + 2) % 3: the stage read in iteration t - 1 (retired before that iteration's barrier)
+            TTMI_VM_WAIT("mid", MID_INFLIGHT);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // K-tile t + 1 has landed for every wave; every wave's reads of K-tile t have retired
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[nt][ks][s4], af[mt][ks][s4], acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        stg = stg == 2 ? 0 : stg + 1;
+    }
+    // epilogue: acc[mt][nt] of lane l = row wr*32 + mt*16 + (l & 15), columns wc*32 + nt*16 + 4*(l >> 4) .. +3
+    float* C = reinterpret_cast<float*>(p.C);
+    const bool vec = (p.ldc % 4 == 0) && ((reinterpret_cast<size_t>(p.C) & 15) == 0) && (!p.bias || (reinterpret_cast<size_t>(p.bias) & 15) == 0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = bm + wr * 32 + mt * 16 + (lane & 15);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n0 = bn + wc * 32 + nt * 16 + 4 * (lane >> 4);
+            if (n0 >= p.N) continue;
+            float* dst = C + (long)m * p.ldc + n0;
+            f32x4 v = acc[mt][nt];
+            if (vec && n0 + 3 < p.N) {
+                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n0);
+                if (p.addend) v += *reinterpret_cast<const f32x4*>(dst);
+                if (p.relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                *reinterpret_cast<f32x4*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (n0 + j >= p.N) continue;
+                    float y = v[j] + (p.bias ? p.bias[n0 + j] : 0.f);
+                    if (p.addend) y += dst[j];
+                    if (p.relu) y = fmaxf(y, 0.f);
+                    dst[j] = y;
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================================================
 // v8 TN (wgrad with a huge reduction: C[M,N] += A[K,M]^T B[K,N], K >> M, N): the NT v8 schedule (256x256x64 tile, 8 waves as
 // 2 x 4, two phases of 32 v_mfma_f32_16x16x32_bf16 per K-tile, waves 4-7 one barrier behind, counted vmcnt) with both operands
 // reduction-major in LDS and every fragment read through ds_read_b64_tr_b16.
@@ -2242,7 +2361,7 @@ int enable_lds(K kernel, int bytes) {
 // Measured and dropped (same box, joint projection M=816000 N=4334 K=1024, v4 = 720 TFLOP/s): 256x128 3-stage ring with
 // counted vmcnt 621; persistent 256x256 with a 4-slice ring that never drains 668 (dgrad K=4352: 904 vs 938 for v6).
 int g_gemm_fast_version = 4;
-int g_f32_fast = 1;              // ttmi_set_option(17, 0): f32 NT products stay on the generic 128x128 kernel (A/B)
+int g_f32_fast = 1;              // ttmi_set_option(17, v): 0 = f32 NT products stay on the kernels of csrc/gemm.hip (A/B); 2 = the 64x64-tile kernel wherever it can run; 3 = the persistent kernel only
 int g_nt_stores = 1;             // streaming stores for bf16 outputs >= 256 MB (set_version(14 / 15) = off / on, generation unchanged)
 int g_num_cus = 0;
 int g_reserved_cus = 0;           // ttmi_set_option(6, n): process-wide default of the per-stream reservation below (measurement switch)
@@ -2501,6 +2620,27 @@ if (p.kwrap) {
     return TTMI_OK;
 }
 
+// ---- mid-sized exact-f32 NT products: 64 x 64 tiles (gemm_nt_f32_mid_kernel); bias / accumulate / ReLU epilogue
+bool gemm_nt_f32_mid_ok(const void* A, const void* B, const void* C, int M, int N, int K, long lda, long ldb, long ldc) {
+    return g_f32_fast && aligned16(A) && aligned16(B) && C && M >= 1 && N >= 1 && K >= 32 && K % 32 == 0 && lda % 4 == 0 && ldb % 4 == 0 && lda >= K &&
+           ldb >= K && ldc >= N && (long)63 * std::max(lda, ldb) * 4 + 128 < (1L << 32) && cdiv(M, TMID) <= 65535;
+}
+int gemm_nt_f32_mid(const float* A, const float* B, float* C, const float* bias, int accumulate, int relu, int M, int N, int K, long lda, long ldb,
+                    long ldc, hipStream_t st) {
+    TTMI_REQUIRE(gemm_nt_f32_mid_ok(A, B, C, M, N, K, lda, ldb, ldc), "gemm_nt_f32_mid: shape/alignment not supported (M=%d N=%d K=%d)", M, N, K);
+    FP p;
+    p.A = reinterpret_cast<const bf16_t*>(A); p.B = reinterpret_cast<const bf16_t*>(B); p.C = C; p.bias = bias; p.addend = accumulate ? C : nullptr;
+    p.mask = nullptr; p.mask_mode = 0; p.nt = 0; p.relu = relu; p.scale = 1.f; p.drop = DropSpec();
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.tiles_m = cdiv(M, TMID); p.tiles_n = cdiv(N, TMID); p.splitk = 1; p.ksteps = K / 32; p.atomic = 0; p.gm = GROUP_M; p.colsum = nullptr;
+    p.A2 = nullptr; p.B2 = nullptr; p.K2 = 0; p.lda2 = p.ldb2 = p.sB1b = p.sB2b = 0; p.colsum_mid = nullptr;
+    p.rowsum = nullptr; p.nparts = 0; p.exp_shift = nullptr; p.rowscale = nullptr; p.csw = nullptr;
+    fill_batch(p, FastBatch());
+    hipLaunchKernelGGL(gemm_nt_f32_mid_kernel, dim3((unsigned)p.tiles_n, (unsigned)p.tiles_m), dim3(256), LDSM, st, p);
+    TTMI_LAUNCH_CHECK("gemm_nt_f32_mid_kernel");
+    return TTMI_OK;
+}
+
 // ---- exact-f32 NT products on the persistent 256x128 kernel (F32IN): C[M,N] (f32) = epi(A[M,K] . B[N,K]^T), f32 operands
 bool gemm_nt_f32_ok(const void* A, const void* B, const void* C, int M, int N, int K, long lda, long ldb, long ldc) {
     return g_f32_fast && aligned16(A) && aligned16(B) && C && M >= 1024 && N >= 128 && K >= 64 && K % 32 == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
@@ -2651,6 +2791,7 @@ void gemm_fast_set_version(int v) {
 }
 void gemm_fast_set_tn_target(int n) { g_tn_target_blocks = n; }
 void gemm_fast_set_f32(int on) { g_f32_fast = on; }
+int gemm_fast_f32_mode() { return g_f32_fast; }
 void gemm_fast_set_reserved_cus(int n) { g_reserved_cus = n < 0 ? 0 : n; }
 void gemm_fast_stream_reserve_cus(hipStream_t st, int n) {
     int dev = 0;

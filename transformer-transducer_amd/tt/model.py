@@ -595,22 +595,10 @@ class Transducer(nn.Module):
         utterance.  Utterances that have run out of frames LEAVE the batch (no extra host round trip: the count of the living comes with the
         flags, the rows from a stable sort on the device), so the long tail of a batch - the longest hypothesis of 32 synthetic utterances
         has 105 symbols, the mean 50 - runs on a handful of rows instead of 32.  Same arithmetic per utterance as `decode`: same tokens.
-        block = frames scored per joint call (None: 64, or what lets the projection finish in one round of tiles)."""
+        block = frames scored per joint call (default 64)."""
         dev = enc_states.device
         B, T = enc_states.shape[0], enc_states.shape[1]
-        col_tiles = -(-self.joint.project_layer.weight.shape[0] // 128)
-
-        def frames_per_call(n_utt):
-            # frames scanned per joint call: 64, or fewer when that lets the projection [n_utt * block, V] - the one large product of a symbol step, on
-            # the persistent 256 x 128-tile f32 kernel from 1024 rows on - finish in ONE round of tiles over the 256 CUs (32 utterances, V = 4334:
-            # 56 frames = 7 x 34 tiles, 151 us, against 64 frames = 8 x 34 tiles in two rounds, 296 us)
-            if block is not None:
-                return block
-            row_tiles = 256 // col_tiles
-            if n_utt * 64 >= 1024 and -(-n_utt * 64 // 256) > row_tiles >= 4:
-                return max(16, row_tiles * 256 // n_utt)
-            return 64
-
+        block = 64 if block is None else block                       # frames scored per joint call
         T_len = torch.as_tensor(lengths, dtype=torch.int32).to(dev).clamp(max=T).contiguous()
         # Label-encoder graphs for a whole batch are opt-in (config.decode_batch_graphs).  They buy nothing at 32 utterances (96 against 97 utt/s:
         # a step's ~150 launches are no longer what the host waits for) and, in tools/bench_decode.py's call order, a third of the PROCESSES
@@ -628,7 +616,7 @@ class Transducer(nn.Module):
         done = torch.zeros(B, dtype=torch.int32, device=dev)
         count = torch.zeros(B, dtype=torch.int32, device=dev)
         flags = torch.zeros(2, dtype=torch.int32, device=dev)
-        n_frames = frames_per_call(B)
+        n_frames = block
         key = torch.full((B,), n_frames << 32, dtype=torch.int64, device=dev)
         rows = torch.arange(n_frames, device=dev, dtype=torch.long)[None, :]
 
@@ -663,9 +651,7 @@ class Transducer(nn.Module):
                 hist, orig, t, T_len, count = hist[keep], orig[keep], t[keep].contiguous(), T_len[keep].contiguous(), count[keep].contiguous()
                 need = torch.zeros(alive, dtype=torch.int32, device=dev)
                 done = torch.zeros(alive, dtype=torch.int32, device=dev)
-                n_frames = frames_per_call(alive)
                 key = torch.full((alive,), n_frames << 32, dtype=torch.int64, device=dev)
-                rows = torch.arange(n_frames, device=dev, dtype=torch.long)[None, :]
             n_hist += 1
             dec_state = label_states(n_hist)
         final_hist.index_copy_(0, orig, hist)
