@@ -299,7 +299,9 @@ int ttmi_stream_reserve_cus(void* stream, int n);
  * forward GEMMs of an encoder layer (qkv_net, o_net, CoreNet.0, CoreNet.3) take the second term of their weight's bf16 split as a second K range, one launch each; 2 = o_net and
  * CoreNet.3 only (needs weight shadows; +2 % step time, no consistent change of the bf16 loss error: profiles/r04_two_term_weights.md); 14: 0 = the tiled attention
  * forward kernel instead of the one-workgroup-per-head one; 15: 1 = the round-3 attention backward kernel instead of flash_bwd_rel2_kernel;
- * 16: 1 = the position-table gradients go through dE / dc and a relpos_scatter launch (round 3) instead of straight out of attn_dqde_kernel */
+ * 16: 1 = the position-table gradients go through dE / dc and a relpos_scatter launch (round 3) instead of straight out of attn_dqde_kernel;
+ * 17: exact-f32 NT products: 0 = the kernels of csrc/gemm.hip only (round 1), 1 = default rule (persistent 256x128 kernel with f32 operands from 512 of its tiles on,
+ * 64x64 tiles from 72 of those on), 2 / 3 = the 64x64-tile / the persistent kernel wherever it can run */
 int ttmi_set_option(int key, int value);
 int ttmi_dropout_apply(const float* in, long n, float p, unsigned seed, float* out, void* stream);
 int ttmi_probe_arm(int slot);

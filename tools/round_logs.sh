@@ -22,3 +22,9 @@ python3 bench.py --mode decode > $O/${TAG}_decode.log 2>&1 && echo "decode done"
 python3 tools/bench_lattice.py > $O/${TAG}_lattice_bench.log 2>&1 && echo "lattice done"
 python3 tools/debug/bf16_loss_error.py --steps 50 > $O/${TAG}_bf16_loss_error.log 2>&1 && echo "bf16 diag done"
 bash tools/prof_attn.sh > $O/${TAG}_attention_layer_kernels.txt 2>&1 && echo "attn done"
+# exact-f32 NT kernels (decode / fp32 mode) against each other, and the per-kernel picture of one batched greedy-decode pass
+python3 tools/micro/f32_gemm_ab.py > $O/${TAG}_f32_gemm_kernels.txt 2>&1 && echo "f32 gemm table done"
+P=$O/prof_${TAG}_decode_batch; rm -rf $P
+rocprofv3 --kernel-trace --stats --output-format csv -d $P -- python3 tools/debug/decode_batch_only.py > $P.log 2>&1
+python3 tools/prof_summary.py $P $O/${TAG}_decode_batch_kernel_stats.csv "tools/debug/decode_batch_only.py (3 passes of decode_batch, 32 utterances), $TAG build" > /dev/null && echo "decode trace done"
+
