@@ -763,8 +763,8 @@ static_assert(V8_STAGE_DMA == 2 && V8_INFLIGHT == 6, "v8: the counted vmcnt wait
 // costs the main loop registers in the general instance
 // KW: the K loop runs twice over A's K-tiles, the second time against p.B2 (two-term weights, NtEpilogue::B_lo) - its own instances, so that the
 // default ones carry no trace of it (the scalar selects in stage() cost the joint's three GEMMs 0.1 - 0.2 ms per C2 step when they were unconditional)
-template <typename TC, int LEAN = 0, bool KW = false>
-__global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p_) {
+template <typename TC, int LEAN, bool KW>
+__device__ __forceinline__ void gemm_nt_v8_body(const FP& p_) {
     FP p = p_;
     p.drop = drop_live(p.drop);
     constexpr bool MASKED = LEAN == 2 || LEAN == 4;       // epilogues that read the mask operand (same layout as the output)
@@ -1131,6 +1131,11 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p_) {
 #undef V8_BAR
 }
 
+template <typename TC, int LEAN = 0>
+__global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) { gemm_nt_v8_body<TC, LEAN, false>(p); }
+template <typename TC, int LEAN = 0>          // two-term weights (NtEpilogue::B_lo): the K loop runs twice over A's K-tiles
+__global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kw_kernel(const FP p) { gemm_nt_v8_body<TC, LEAN, true>(p); }
+
 // =====================================================================================================================
 // v10: the v8 problem (persistent 256x256 output tiles, joint-sized GEMMs) on FOUR waves (2 x 2) with 128 x 128 wave tiles:
 // 8 x 8 v_mfma_f32_16x16x32_bf16 tiles = 256 accumulator registers per lane (AGPRs; one wave per SIMD).  v8's 128 x 64 wave
@@ -1352,8 +1357,8 @@ static_assert(V9_INFLIGHT == 6, "v9: the counted vmcnt waits assume 6 LDS-DMA in
 // fragment read the same ds_read_b128 (4 consecutive k of one row), consumed by four v_mfma_f32_16x16x4_f32 - step s takes component s of both
 // operands, i.e. the reduction runs in the order k = 16 c + 4 (lane >> 4) + s over the steps s of chunk c (any pairing of k is valid as long as A and
 // B agree).  The exact-f32 path of the fp32 mode and of greedy decoding (csrc/gemm.hip routes its large NT problems here).
-template <typename TC, int LEAN = 0, bool F32IN = false, bool KW = false>            // KW: as in v8
-__global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p_) {
+template <typename TC, int LEAN, bool F32IN, bool KW>            // KW: as in v8
+__device__ __forceinline__ void gemm_nt_v9_body(const FP& p_) {
     constexpr int ES = F32IN ? 4 : 2, TKE = 128 / ES;      // operand element size, k per stage
     FP p = p_;
     p.drop = drop_live(p.drop);
@@ -1584,6 +1589,13 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p_) {
 #undef V9_SLAB
 #undef V9_BAR
 }
+
+template <typename TC, int LEAN = 0>
+__global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kernel(const FP p) { gemm_nt_v9_body<TC, LEAN, false, false>(p); }
+template <typename TC, int LEAN = 0>          // two-term weights
+__global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v9_kw_kernel(const FP p) { gemm_nt_v9_body<TC, LEAN, false, true>(p); }
+template <int LEAN = 0>                       // f32 operands, f32 output (exact-f32 path)
+__global__ __launch_bounds__(NTH8, 1) void gemm_nt_f32_v9_kernel(const FP p) { gemm_nt_v9_body<float, LEAN, true, false>(p); }
 
 // =====================================================================================================================
 // Mid-sized exact-f32 NT products (greedy decoding: the label encoder on alive x history = 200 .. 2000 rows; d = 512 .. 1536 columns): too few
@@ -2496,8 +2508,13 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
 #define V9_LAUNCH(...) do { if (int rc = enable_lds((gemm_nt_bf16_v9_kernel<__VA_ARGS__>), LDS9)) return rc; \
             hipLaunchKernelGGL((gemm_nt_bf16_v9_kernel<__VA_ARGS__>), dim3((unsigned)grid9), dim3(NTH8), LDS9, st, p); } while (0)
         if (p.kwrap) {                                     // two-term weights (an option, off by default): the general-epilogue instances
-            if (c_dtype == 0) V9_LAUNCH(float, 0, false, true);
-            else V9_LAUNCH(bf16_t, 0, false, true);
+            if (c_dtype == 0) {
+                if (int rc = enable_lds((gemm_nt_bf16_v9_kw_kernel<float>), LDS9)) return rc;
+                hipLaunchKernelGGL((gemm_nt_bf16_v9_kw_kernel<float>), dim3((unsigned)grid9), dim3(NTH8), LDS9, st, p);
+            } else {
+                if (int rc = enable_lds((gemm_nt_bf16_v9_kw_kernel<bf16_t>), LDS9)) return rc;
+                hipLaunchKernelGGL((gemm_nt_bf16_v9_kw_kernel<bf16_t>), dim3((unsigned)grid9), dim3(NTH8), LDS9, st, p);
+            }
         } else if (c_dtype == 0) {
             if (lean1) V9_LAUNCH(float, 1);
             else if (p.addend && !p.mask && !p.relu && p.drop.p <= 0.f && ldc % 4 == 0 && aligned16(C) && aligned16(p.addend) && (!p.bias || aligned16(p.bias))) V9_LAUNCH(float, 3);
@@ -2547,11 +2564,11 @@ const int cus8 = nwg8 < 1024 ? std::max(8, (g_num_cus - reserved) / 8 * 8) : g_n
 if (p.kwrap) {
             TTMI_REQUIRE(!needs8, "gemm_nt_bf16: no second weight term with the exp-store / row-scale epilogues");
             if (c_dtype == 0) {
-                if (int rc = enable_lds((gemm_nt_bf16_v8_kernel<float, 0, true>), LDS8)) return rc;
-                hipLaunchKernelGGL((gemm_nt_bf16_v8_kernel<float, 0, true>), dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
+                if (int rc = enable_lds((gemm_nt_bf16_v8_kw_kernel<float>), LDS8)) return rc;
+                hipLaunchKernelGGL((gemm_nt_bf16_v8_kw_kernel<float>), dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
             } else {
-                if (int rc = enable_lds((gemm_nt_bf16_v8_kernel<bf16_t, 0, true>), LDS8)) return rc;
-                hipLaunchKernelGGL((gemm_nt_bf16_v8_kernel<bf16_t, 0, true>), dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
+                if (int rc = enable_lds((gemm_nt_bf16_v8_kw_kernel<bf16_t>), LDS8)) return rc;
+                hipLaunchKernelGGL((gemm_nt_bf16_v8_kw_kernel<bf16_t>), dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
             }
         } else if (c_dtype == 0) {
             if (int rc = enable_lds(gemm_nt_bf16_v8_kernel<float>, LDS8)) return rc;
@@ -2662,13 +2679,13 @@ int gemm_nt_f32(const float* A, const float* B, float* C, const NtEpilogue& epi,
     const int cus9 = std::max(8, (g_num_cus - reserved_cus(st)) / 8 * 8);
     const int grid9 = (int)((std::min<long>(t9, cus9) + 7) / 8 * 8);
     const bool base_ok = !p.relu && p.drop.p <= 0.f && aligned16(C) && ldc % 4 == 0 && (!p.bias || aligned16(p.bias));
-#define V9F_LAUNCH(L) do { if (int rc = enable_lds((gemm_nt_bf16_v9_kernel<float, L, true>), LDS9)) return rc; \
-            hipLaunchKernelGGL((gemm_nt_bf16_v9_kernel<float, L, true>), dim3((unsigned)grid9), dim3(NTH8), LDS9, st, p); } while (0)
+#define V9F_LAUNCH(L) do { if (int rc = enable_lds((gemm_nt_f32_v9_kernel<L>), LDS9)) return rc; \
+            hipLaunchKernelGGL((gemm_nt_f32_v9_kernel<L>), dim3((unsigned)grid9), dim3(NTH8), LDS9, st, p); } while (0)
     if (base_ok && !p.addend) V9F_LAUNCH(1);
     else if (base_ok && aligned16(p.addend)) V9F_LAUNCH(3);
     else V9F_LAUNCH(0);
 #undef V9F_LAUNCH
-    TTMI_LAUNCH_CHECK("gemm_nt_bf16_v9_kernel<f32 operands>");
+    TTMI_LAUNCH_CHECK("gemm_nt_f32_v9_kernel");
     return TTMI_OK;
 }
 
