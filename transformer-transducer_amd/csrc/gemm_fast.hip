@@ -1608,22 +1608,27 @@ constexpr int TMID = 64, STGM = 2 * TMID * 128, LDSM = 3 * STGM;
 constexpr int MID_INFLIGHT = STGM / (256 * 16);        // LDS-DMA instructions per wave (of 4) and stage
 static_assert(MID_INFLIGHT == 4, "mid f32: the counted vmcnt waits assume 4 LDS-DMA instructions per stage");
 
-__global__ __launch_bounds__(256, 3) void gemm_nt_f32_mid_kernel(const FP p) {
+// F32IN: f32 operands (stage = 32 floats of K, four v_mfma_f32_16x16x4_f32 per fragment pair) or bf16 operands (stage = 64 bf16 of K, one
+// v_mfma_f32_16x16x32_bf16): the label encoder's products of the bf16 TRAINING step (1632 rows: 52 - 156 tiles of 128 x 128, one K-step at a time per
+// lone workgroup, 45 - 67 us per launch) are the same mid-sized problem as the decoder's f32 ones.
+template <bool F32IN, typename TC>
+__device__ __forceinline__ void gemm_nt_mid_body(const FP& p) {
+    constexpr int ES = F32IN ? 4 : 2, TKE = 128 / ES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave & 1, wc = wave >> 1;
     const int bn = blockIdx.x * TMID, bm = blockIdx.y * TMID;
-    const int nk = p.K / 32;                               // launcher: K % 32 == 0
+    const int nk = p.K / TKE;                              // launcher: K % TKE == 0
     unsigned oA[2], oB[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int r = (wave * 2 + j) * 8 + (lane >> 3);
         const unsigned slot = (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
-        oA[j] = (unsigned)((long)min(r, p.M - 1 - bm) * p.lda * 4) + slot;
-        oB[j] = (unsigned)((long)min(r, p.N - 1 - bn) * p.ldb * 4) + slot;
+        oA[j] = (unsigned)((long)min(r, p.M - 1 - bm) * p.lda * ES) + slot;
+        oB[j] = (unsigned)((long)min(r, p.N - 1 - bn) * p.ldb * ES) + slot;
     }
-    const char* baseA = reinterpret_cast<const char*>(p.A) + (long)bm * p.lda * 4;
-    const char* baseB = reinterpret_cast<const char*>(p.B) + (long)bn * p.ldb * 4;
+    const char* baseA = reinterpret_cast<const char*>(p.A) + (long)bm * p.lda * ES;
+    const char* baseB = reinterpret_cast<const char*>(p.B) + (long)bn * p.ldb * ES;
     auto stage = [&](int stg, int kt) {
         char* dst = smem + stg * STGM;
         const char* ba = baseA + (long)kt * 128;
@@ -1646,7 +1651,8 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_f32_mid_kernel(const FP p) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 af[2][2], bfr[2][2];
+    using Frag = typename std::conditional<F32IN, f32x4, bf16x8>::type;
+    Frag af[2][2], bfr[2][2];
 
     stage(0, 0);
     if (nk > 1) { TTMI_VM_GUARD("mid"); stage(1, 1); TTMI_VM_WAIT("mid", MID_INFLIGHT); }
@@ -1658,9 +1664,9 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_f32_mid_kernel(const FP p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i][ks] = *reinterpret_cast<const f32x4*>(base + aoff[ks] + i * 2048);
+            for (int i = 0; i < 2; ++i) af[i][ks] = *reinterpret_cast<const Frag*>(base + aoff[ks] + i * 2048);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) bfr[i][ks] = *reinterpret_cast<const f32x4*>(base + boff[ks] + i * 2048);
+            for (int i = 0; i < 2; ++i) bfr[i][ks] = *reinterpret_cast<const Frag*>(base + boff[ks] + i * 2048);
         }
         if (t + 2 < nk) {
             TTMI_VM_GUARD("mid");                          // K-tile t + 1 (staged one tile ago) is older than this point
@@ -1677,43 +1683,39 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_f32_mid_kernel(const FP p) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < 2; ++nt) {
+                    if constexpr (F32IN) {
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[nt][ks][s4], af[mt][ks][s4], acc[mt][nt], 0, 0, 0);
+                        for (int s4 = 0; s4 < 4; ++s4)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[nt][ks][s4], af[mt][ks][s4], acc[mt][nt], 0, 0, 0);
+                    } else {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt][ks], af[mt][ks], acc[mt][nt], 0, 0, 0);
+                    }
+                }
         __builtin_amdgcn_s_setprio(0);
         stg = stg == 2 ? 0 : stg + 1;
     }
-    // epilogue: acc[mt][nt] of lane l = row wr*32 + mt*16 + (l & 15), columns wc*32 + nt*16 + 4*(l >> 4) .. +3
-    float* C = reinterpret_cast<float*>(p.C);
-    const bool vec = (p.ldc % 4 == 0) && ((reinterpret_cast<size_t>(p.C) & 15) == 0) && (!p.bias || (reinterpret_cast<size_t>(p.bias) & 15) == 0);
+    // epilogue: acc[mt][nt] of lane l = row wr*32 + mt*16 + (l & 15), columns wc*32 + nt*16 + 4*(l >> 4) .. +3: the general 4-column store
+    // (bias, residual addend, ReLU, ReLU / tanh mask, dropout; 16-byte or 8-byte stores on aligned interiors)
+    TC* C = reinterpret_cast<TC*>(p.C);
+    const bool vec = (p.ldc % 4 == 0) && ((reinterpret_cast<size_t>(p.C) & 15) == 0) && (!p.addend || (reinterpret_cast<size_t>(p.addend) & 15) == 0) &&
+                     (!p.mask || (reinterpret_cast<size_t>(p.mask) & 7) == 0) && (!p.bias || (reinterpret_cast<size_t>(p.bias) & 15) == 0);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int m = bm + wr * 32 + mt * 16 + (lane & 15);
-        if (m >= p.M) continue;
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int n0 = bn + wc * 32 + nt * 16 + 4 * (lane >> 4);
-            if (n0 >= p.N) continue;
-            float* dst = C + (long)m * p.ldc + n0;
-            f32x4 v = acc[mt][nt];
-            if (vec && n0 + 3 < p.N) {
-                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n0);
-                if (p.addend) v += *reinterpret_cast<const f32x4*>(dst);
-                if (p.relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-                *reinterpret_cast<f32x4*>(dst) = v;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (n0 + j >= p.N) continue;
-                    float y = v[j] + (p.bias ? p.bias[n0 + j] : 0.f);
-                    if (p.addend) y += dst[j];
-                    if (p.relu) y = fmaxf(y, 0.f);
-                    dst[j] = y;
-                }
-            }
-        }
-    }
+        for (int nt = 0; nt < 2; ++nt)
+            epi_store4<TC>(p, C, bm + wr * 32 + mt * 16 + (lane & 15), bn + wc * 32 + nt * 16 + 4 * (lane >> 4), acc[mt][nt], vec);
+}
+__global__ __launch_bounds__(256, 3) void gemm_nt_f32_mid_kernel(const FP p_) {
+    FP p = p_;
+    p.drop = drop_live(p.drop);
+    gemm_nt_mid_body<true, float>(p);
+}
+template <typename TC>
+__global__ __launch_bounds__(256, 3) void gemm_nt_bf16_mid_kernel(const FP p_) {
+    FP p = p_;
+    p.drop = drop_live(p.drop);
+    gemm_nt_mid_body<false, TC>(p);
 }
 
 // =====================================================================================================================
@@ -2374,6 +2376,7 @@ int enable_lds(K kernel, int bytes) {
 // counted vmcnt 621; persistent 256x256 with a 4-slice ring that never drains 668 (dgrad K=4352: 904 vs 938 for v6).
 int g_gemm_fast_version = 4;
 int g_f32_fast = 1;              // ttmi_set_option(17, v): 0 = f32 NT products stay on the kernels of csrc/gemm.hip (A/B); 2 = the 64x64-tile kernel wherever it can run; 3 = the persistent kernel only
+int g_bf16_mid = 32;             // set_version(16 + n): bf16 NT problems the persistent kernels leave go to the 64 x 64-tile kernel from n of its tiles on (16 = never)
 int g_nt_stores = 1;             // streaming stores for bf16 outputs >= 256 MB (set_version(14 / 15) = off / on, generation unchanged)
 int g_num_cus = 0;
 int g_reserved_cus = 0;           // ttmi_set_option(6, n): process-wide default of the per-stream reservation below (measurement switch)
@@ -2599,6 +2602,16 @@ if (p.kwrap) {
         TTMI_LAUNCH_CHECK("gemm_nt_bf16_v8_kernel");
         return TTMI_OK;
     }
+    // mid-sized problems (whatever the persistent kernels did not take: fewer than 1024 rows or too few of their tiles - the label encoder's 1632 rows):
+    // 64 x 64 tiles through a 3-stage LDS-DMA pipeline instead of 128 x 128 tiles that walk K one barrier-separated step at a time
+    if (g_bf16_mid && g_gemm_fast_version == 4 && nbatch == 1 && !dual && !two_term && K >= 64 && K % 64 == 0 && (long)cdiv(M, TMID) * cdiv(N, TMID) >= g_bf16_mid &&
+        cdiv(M, TMID) <= 65535 && (long)63 * std::max(lda, ldb) * 2 + 128 < (1L << 32)) {
+        p.tiles_m = cdiv(M, TMID); p.tiles_n = cdiv(N, TMID);
+        if (c_dtype == 0) hipLaunchKernelGGL(gemm_nt_bf16_mid_kernel<float>, dim3((unsigned)p.tiles_n, (unsigned)p.tiles_m), dim3(256), LDSM, st, p);
+        else hipLaunchKernelGGL(gemm_nt_bf16_mid_kernel<bf16_t>, dim3((unsigned)p.tiles_n, (unsigned)p.tiles_m), dim3(256), LDSM, st, p);
+        TTMI_LAUNCH_CHECK("gemm_nt_bf16_mid_kernel");
+        return TTMI_OK;
+    }
     const bool big = (g_gemm_fast_version == 6) && !dual;
     if (big && M >= 1024 && N >= 256 && nbatch == 1) {
         p.tiles_m = cdiv(M, T6); p.tiles_n = cdiv(N, T6);
@@ -2804,6 +2817,7 @@ int gemm_tn_bf16(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K
 
 void gemm_fast_set_version(int v) {
     if (v == 14 || v == 15) { g_nt_stores = v == 15; return; }
+    if (v >= 16) { g_bf16_mid = v - 16; return; }
     g_gemm_fast_version = v;
 }
 void gemm_fast_set_tn_target(int n) { g_tn_target_blocks = n; }
