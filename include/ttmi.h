@@ -289,7 +289,7 @@ int ttmi_weight_shadow_refresh(const long* table, int n, long total_tiles, void*
  * backward pass; the encoder-sized persistent GEMMs launched on `stream` (and on the library's fork streams serving it) leave n CUs to
  * them.  Per-stream state read at launch time; 0 = whole chip (default). */
 int ttmi_stream_reserve_cus(void* stream, int n);
-/* process-wide A/B switches for MEASUREMENTS ONLY (not thread-safe against concurrent launches, no product path depends on them): key 0: 1 = no fused attention kernels; 1: throughput-GEMM generation (csrc/gemm_fast.hip; 14 / 15 = streaming output stores off / on);
+/* process-wide A/B switches for MEASUREMENTS ONLY (not thread-safe against concurrent launches, no product path depends on them): key 0: 1 = no fused attention kernels; 1: throughput-GEMM generation (csrc/gemm_fast.hip; 5 = nothing persistent: every eligible NT problem on 64x64 tiles; 14 / 15 = streaming output stores off / on; 16 + n = the 64x64-tile bf16 NT kernel from n of its tiles on, 16 = never, default 48);
  * 2: flash-kernel timing bits; 3: 0 = no side-stream wgrad fork; 4: split-K workgroup target; 5: 1 = position-term slab by batched GEMM;
  * 6: process-wide default of ttmi_stream_reserve_cus for streams that never set one;
  * 7: exact-f32 products with at most n rows use the skinny 32x32 split-reduction kernel (default 128, 0 = never: greedy decode A/B);

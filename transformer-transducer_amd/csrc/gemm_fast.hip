@@ -2604,7 +2604,7 @@ if (p.kwrap) {
     }
     // mid-sized problems (whatever the persistent kernels did not take: fewer than 1024 rows or too few of their tiles - the label encoder's 1632 rows):
     // 64 x 64 tiles through a 3-stage LDS-DMA pipeline instead of 128 x 128 tiles that walk K one barrier-separated step at a time
-    if (g_bf16_mid && g_gemm_fast_version == 4 && nbatch == 1 && !dual && !two_term && K >= 64 && K % 64 == 0 && (long)cdiv(M, TMID) * cdiv(N, TMID) >= g_bf16_mid &&
+    if (g_bf16_mid && (g_gemm_fast_version == 4 || g_gemm_fast_version == 5) && nbatch == 1 && !dual && !two_term && K >= 64 && K % 64 == 0 && (long)cdiv(M, TMID) * cdiv(N, TMID) >= g_bf16_mid &&
         cdiv(M, TMID) <= 65535 && (long)63 * std::max(lda, ldb) * 2 + 128 < (1L << 32)) {
         p.tiles_m = cdiv(M, TMID); p.tiles_n = cdiv(N, TMID);
         if (c_dtype == 0) hipLaunchKernelGGL(gemm_nt_bf16_mid_kernel<float>, dim3((unsigned)p.tiles_n, (unsigned)p.tiles_m), dim3(256), LDSM, st, p);
