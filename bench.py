@@ -28,6 +28,7 @@ import torch.distributed as dist
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 MFMA_F32_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0               # HBM3E, MI355X_MICROARCH.md
+ATTN_BWD_KERNEL = "flash_bwd_rel2_kernel<mask kind>"     # what probe 3 brackets (csrc/attn_flash.hip; option 15 = 1 selects the round-3 kernel)
 
 
 def c2_config(n_enc=12, n_dec=6):
@@ -176,6 +177,37 @@ def _sha16(path):
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
+def self_launch_command(gpus, argv, port=None):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): the command line of the N-rank job this process starts as a CHILD
+    (the driver's own form: torch.distributed.run, one node, 127.0.0.1 rendezvous) - decided right after argparse, before anything touches
+    the GPU; the parent only waits and passes the exit code on (never an exec of a process that has initialised HIP)"""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(gpus, argv):
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    proc = subprocess.run(self_launch_command(gpus, argv), env=env)
+    if proc.returncode != 0:
+        sys.stderr.write("bench.py: the %d-rank job exited with code %d\n" % (gpus, proc.returncode))
+    return proc.returncode
+
+
+def dp_efficiency(value, world, n1_value):
+    """(utt/s at N) / (N x utt/s at 1) when the caller supplies the N = 1 figure; the driver computes its own from its runs"""
+    if not n1_value or world < 1:
+        return None
+    return round(float(value) / (world * float(n1_value)), 4)
+
+
 def decode_mode(args):
     """single GPU: tools/bench_decode.run (product path) + the oracle's frame-by-frame greedy loop on the host as checker and CPU baseline"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -249,9 +281,16 @@ def main():
     ap.add_argument("--fp32-steps", type=int, default=5, help="steps of the fp32-mode secondary timing (at most --steps)")
     ap.add_argument("--loss-chunk", type=int, default=0, help="utterances per chunk of the fused loss (0 = default: logits chunk <= 2 GB)")
     ap.add_argument("--emit-rate", type=float, default=0.1, help="decode mode: fraction of frames that emit a symbol (blank bias is set for it)")
+    ap.add_argument("--n1-value", type=float, default=float(os.environ.get("TTMI_BENCH_N1_VALUE", 0) or 0),
+                    help="utt/s of the N = 1 run of the same workload: the line then carries dp_efficiency = value / (N x n1-value)")
+    ap.add_argument("--no-sync-form", action="store_true", help="skip the secondary timing of train.py's loop body with its host synchronisations "
+                                                                "(fresh .int() length tensors, float(loss) every step: train.py:53,60)")
     args = ap.parse_args()
     if args.mode == "decode":
         return decode_mode(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the N ranks ourselves (child processes; nothing here has touched the GPU yet) and pass their exit code on
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     os.environ["TTMI_PRECISION"] = args.precision
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -309,6 +348,7 @@ def main():
     inputs = torch.empty(B, T, d, device=dev)
     gflags = ops.GEMM_A_KMAJOR | (ops.GEMM_BF16_MFMA if args.precision == "bf16" else 0)
     loss_sum = torch.zeros(1, device=dev)
+    host_loss = [0.0]
     probe_ms = []
 
     for kv in os.environ.get("TTMI_OPTIONS", "").split(","):          # measurement switches, e.g. TTMI_OPTIONS=3:0 (no wgrad fork); see include/ttmi.h
@@ -321,6 +361,11 @@ def main():
     os.environ["TTMI_DEFERRED_LOGITS"] = "0" if form == "two-call-eager" else ""
 
     reserve = dp_options(world)["reserve_cus"]
+    # train.py's loop body word for word needs the lengths as the loader hands them over (int64) and converts them per step (train.py:53:
+    # `.int()` makes FRESH tensors, so the shim's length check pays its two device-to-host reads every step) and reads the loss on the
+    # host (train.py:60 `float(loss)` for logging): the `train_py_sync_form` secondary times exactly that
+    ilen64, tlen64, targets64 = ilen.long(), tlen.long(), targets.long()
+    sync_form = [False]
 
     def step(timed, i=0):
         # harness front-end: fixed 80 -> d_model projection (the reference encoder has no input layer)
@@ -333,7 +378,10 @@ def main():
             loss = model.loss(inputs, ilen, targets, tlen, chunk=args.loss_chunk or None, exp_domain=form == "exp")
         else:
             logits = model(inputs, targets)                             # train.py:51
-            loss = criterion(logits, targets.int(), ilen, tlen)         # train.py:53
+            if sync_form[0]:
+                loss = criterion(logits, targets64.int(), ilen64.int(), tlen64.int())      # train.py:53 verbatim: fresh int32 tensors, two max() reads
+            else:
+                loss = criterion(logits, targets.int(), ilen, tlen)     # train.py:53
         if reserve:
             ops.reserve_cus(reserve)                  # gradient all-reduce kernels run beside backward: the persistent encoder GEMMs leave them 4 CUs per XCD (per-stream state)
         loss.backward()
@@ -341,7 +389,10 @@ def main():
         if reserve:
             ops.reserve_cus(0)                        # the next forward pass gets the whole chip (read at launch time)
         opt.step()
-        loss_sum.add_(loss.detach())
+        if sync_form[0]:
+            host_loss[0] += float(loss)               # train.py:60: the loop's own host read of the loss, every step
+        else:
+            loss_sum.add_(loss.detach())
         return loss
 
     def is_exp(f):
@@ -401,9 +452,17 @@ def main():
             os.environ["TTMI_PRECISION"] = main_prec
             os.environ["TTMI_DEFERRED_LOGITS"] = main_def
 
-    eager_two_call = explicit_form = fp32_form = graph_form = graph_issue = None
-    eager_ms, explicit_ms, graph_ms = [], [], []
+    eager_two_call = explicit_form = fp32_form = graph_form = graph_issue = sync_two_call = None
+    eager_ms, explicit_ms, graph_ms, sync_ms = [], [], [], []
     fp32_steps = max(1, min(args.steps, args.fp32_steps))
+    if form == "two-call" and not args.no_sync_form:
+        # (0) train.py:51-65 with its host synchronisations left in: the headline region reuses two int32 length
+        # tensors (the shim caches their maxima) and never reads the loss; the unchanged script converts per step and logs float(loss)
+        sync_form[0] = True
+        try:
+            sync_two_call = secondary("two-call", args.precision, args.steps, max(1, args.warmup), sync_ms)
+        finally:
+            sync_form[0] = False
     if args.precision == "bf16" and not args.no_two_call:
         # (1) the same two calls with the logits MATERIALISED (rounds 1-3's two-call form: 7.1 GB of bf16 logits written, walked twice by the
         # loss, 7.1 GB of gradient written and read), timed BEFORE any graph capture;
@@ -437,8 +496,8 @@ def main():
     if args.precision == "bf16" and not args.no_fp32_form and args.workload == "c2":
         # the fp32 mode: the path that meets north_star's 1e-4 tolerance (tests/test_configs_gpu.py), timed on the same workload
         fp32_form = secondary("two-call", "fp32", fp32_steps, 1)
-    elapsed, eager_two_call, explicit_form, fp32_form, graph_form, host_issue = max_over_ranks(
-        [elapsed, eager_two_call, explicit_form, fp32_form, graph_form, host_issue], world, dev)
+    elapsed, eager_two_call, explicit_form, fp32_form, graph_form, host_issue, sync_two_call = max_over_ranks(
+        [elapsed, eager_two_call, explicit_form, fp32_form, graph_form, host_issue, sync_two_call], world, dev)
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
@@ -497,8 +556,8 @@ def main():
         a_ms = mean_pos(attn_ms)
         attn_bytes = B * T * H * Dh * 2.0 * 6 + B * H * T * 8.0       # (q+u), k, v, dO in; dK, dV out (bf16); lse + delta (f32)
         attn_flops = 10.0 * B * H * T * T * Dh                         # S, dP, dV, dK and (in the following launch) dq products
-        roof_attn = {"bound": "hbm", "kernel": "attention backward kernel (flash_bwd_rel_kernel), one audio layer (B=%d L=%d H=%d Dh=%d): recomputes P incl. the "
-                                               "position term, writes dK / dV and dS twice (bf16) for the dq / dE products" % (B, T, H, Dh),
+        roof_attn = {"bound": "hbm", "kernel": "attention backward kernel (%s), one audio layer (B=%d L=%d H=%d Dh=%d): recomputes P incl. the "
+                                               "position term, writes dK / dV and dS twice (bf16) for the dq / dE products" % (ATTN_BWD_KERNEL, B, T, H, Dh),
                      "achieved": rate(attn_bytes, a_ms, 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": frac(rate(attn_bytes, a_ms, 1e9, 1), HBM_PEAK_GBS), "traffic": None, "kernel_ms": None if a_ms is None else round(a_ms, 4),
                      "mfma_tflops": rate(0.8 * attn_flops, a_ms, 1e12, 1),
@@ -583,6 +642,13 @@ def main():
         if form == "two-call":
             out["two_call_form"] = dict(form_entry(elapsed, step_ms, "train.py:51-53 unchanged IS the primary timed region of this run (the headline above)"),
                                         same_as_headline=True)
+        if sync_two_call is not None:
+            out["train_py_sync_form"] = form_entry(sync_two_call, sync_ms, "the same %d steps with train.py's own host synchronisations: "
+                                                   "criterion(logits, targets.int(), inputs_length.int(), targets_length.int()) on int64 loader tensors (fresh int32 "
+                                                   "tensors each step -> the length check's two max() reads, train.py:53) and float(loss) every step (train.py:60)" % args.steps)
+        eff = dp_efficiency(utt_s, world, args.n1_value)
+        if eff is not None:
+            out["dp_efficiency"] = {"value": eff, "n1_value": args.n1_value, "note": "(utt/s at N) / (N x the supplied N = 1 utt/s); target >= 0.90 at N = 8"}
         if eager_two_call is not None:
             out["two_call_materialized_form"] = form_entry(eager_two_call, eager_ms, "the same %d steps with the logits materialised (TTMI_DEFERRED_LOGITS=0: rounds 1-3's "
                                                            "two-call form), timed right after the main region and before any graph capture" % args.steps)

@@ -124,6 +124,10 @@ int ttmi_rnnt_loss_bwd(const void* logits, int dtype, long ldv, const int* label
 int ttmi_joint_exp_supported(int B, int T, int U1, int J, int V, int prec, long ldv);
 int ttmi_joint_exp_fwd_supported(int B, int T, int U1, int J, int V, int prec, long ldv);     /* forward + loss only (no gradients wanted) */
 int ttmi_joint_exp_nparts(int V);
+/* lattice rows of a chunk padded to the exp-domain wgrad's 64-row reduction tile: the row count P / srow / srow16 / emis / ctx must have
+ * room for (the pad rows get zero row factors and add exact zeros; tt/model.py:20-39 has no counterpart - the reference materialises
+ * [B, T, U+1, V] logits of exactly B*T*U1 rows) */
+long ttmi_joint_exp_padded_rows(int B, int T, int U1);
 int ttmi_joint_fwd_exp(const float* enc, const float* dec, const float* wf, const float* bf, const float* wp, const float* bp,
                        int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx, float* ws, void* P, long ldv,
                        float* rowsum, int nparts, const float* shift, const int* labels, int blank, float* emis, void* stream);

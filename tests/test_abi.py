@@ -26,6 +26,26 @@ def test_every_declared_symbol_is_exported():
         assert hasattr(lib, n), n
 
 
+def test_every_exported_symbol_is_declared():
+    """the other direction: an entry point the Python side binds must be in the published header"""
+    hdr = open(os.path.join(ROOT, "include", "ttmi.h")).read()
+    declared = set(re.findall(r"\b(ttmi_[a-z0-9_]+)\s*\(", hdr))
+    _lib()
+    so = os.path.join(PKG, "ttmi", "libttmi.so")
+    out = subprocess.check_output(["nm", "-D", "--defined-only", so], text=True)
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("ttmi_")}
+    assert exported, "no ttmi_* exports found"
+    assert exported - declared == set(), "exported but not declared in include/ttmi.h: %s" % sorted(exported - declared)
+    assert declared - exported == set(), "declared but not exported: %s" % sorted(declared - exported)
+    # and everything ttmi/ops.py / ttmi/train.py / ttmi/frontend.py call through ctypes is a declared name
+    used = set()
+    for d, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith(".py"):
+                used |= set(re.findall(r"\.(ttmi_[a-z0-9_]+)\b", open(os.path.join(d, f)).read()))
+    assert used - declared == set(), "bound in Python but not declared: %s" % sorted(used - declared)
+
+
 def test_argument_validation_without_gpu():
     lib = _lib()
     lib.ttmi_last_error.restype = ctypes.c_char_p

@@ -641,7 +641,7 @@ class Transducer(nn.Module):
                     break
             if alive == 0:
                 break
-            if alive < hist.shape[0] and graphs is None:
+            if alive < hist.shape[0] and graphs is None and self.config.decode_batch_shrink is not False:
                 # finished utterances leave the batch: every later label-encoder and joint call runs on the rows still decoding (per-utterance
                 # arithmetic does not depend on who else is in the batch).  Their histories are kept; no host round trip - the row count is
                 # `alive`, the rows are the first `alive` of a stable sort by the done flag

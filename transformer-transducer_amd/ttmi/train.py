@@ -133,10 +133,12 @@ class GradSync:
     reduced asynchronously the moment all of its parameters have accumulated.  xGMI is a point-to-point mesh,
     so few large messages beat many small ones: default 32 MB buckets -> ~6 calls for the 193 MB payload."""
 
-    def __init__(self, flat, bucket_mb=32, group=None, tail_mb=None, tail_buckets=2, always_reduce=False):
+    def __init__(self, flat, bucket_mb=32, group=None, tail_mb=None, tail_buckets=2, always_reduce=False, broadcast=True):
         """tail_mb: size of the first `tail_buckets` buckets (the parameters whose gradients arrive LAST - audio-encoder layer 0 first in
         parameter order): the all-reduce of the bucket that completes last cannot overlap anything, so it is kept small (default
-        bucket_mb / 4)"""
+        bucket_mb / 4).  broadcast (world > 1): rank 0's parameters are broadcast to every rank and the replicas' bit patterns are
+        compared before the first step ("same seed OR rank-0 broadcast" - nn.DataParallel re-broadcasts every step,
+        train.py:214-219; here once, and again on request after a checkpoint was loaded on one rank: `broadcast_parameters()`)."""
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.buckets, self.bucket_of = [], {}
@@ -165,6 +167,50 @@ class GradSync:
                 hook = self._make_hook(i)
                 p.register_post_accumulate_grad_hook(hook)      # gradients that arrive through autograd
                 p._ttmi_on_grad = hook                           # gradients written in place by the HIP backward kernels
+        if self.world > 1 and broadcast:
+            self.broadcast_parameters()
+
+    # ---- replica consistency (one-off collectives, outside the step)
+    def broadcast_parameters(self, src=0, optimizer=None, check=True):
+        """every rank takes rank `src`'s parameters (ONE broadcast of the flat buffer: 193 MB at C2) and, when given, its optimiser state and
+        counters (resume: load_checkpoint on rank 0 only, then this); bf16 weight shadows are rebuilt; `check` compares the replicas after"""
+        if self.world <= 1:
+            return
+        dist.broadcast(self.flat.flat, src, group=self.group)
+        if optimizer is not None:
+            for buf in optimizer.state:
+                dist.broadcast(buf, src, group=self.group)
+            meta = torch.tensor([optimizer.lr, float(optimizer.steps_taken), float(optimizer.global_step), float(optimizer.current_epoch)],
+                                dtype=torch.float64, device=self.flat.flat.device)
+            dist.broadcast(meta, src, group=self.group)
+            lr, steps, gstep, epoch = meta.tolist()
+            optimizer.lr, optimizer.steps_taken = lr, int(steps)
+            optimizer.global_step, optimizer.current_epoch = int(gstep), int(epoch)
+        if self.flat.shadow is not None:
+            self.flat.refresh_shadows()
+        if check:
+            self.check_replicas()
+
+    def replica_checksum(self):
+        """order-independent-free 64-bit checksum of the parameters' BIT PATTERNS (two weighted integer sums): equal on every rank iff
+        the replicas agree (up to a 2^-64-class collision); a float sum would hide sign / NaN differences"""
+        bits = self.flat.flat.view(torch.int32).to(torch.int64)
+        idx = torch.arange(1, bits.numel() + 1, device=bits.device, dtype=torch.int64)
+        return torch.stack([bits.sum(), (bits * (idx % 65521 + 1)).sum()])
+
+    def check_replicas(self):
+        """raises on EVERY rank when the ranks' parameters differ (call it any time between steps, e.g. once per epoch)"""
+        if self.world <= 1:
+            return True
+        c = self.replica_checksum()
+        lo, hi = c.clone(), c.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("GradSync: the data-parallel replicas' parameters differ (rank %d checksum %s; min %s max %s over ranks): "
+                               "a checkpoint loaded on one rank, or different seeds - call broadcast_parameters()"
+                               % (dist.get_rank(self.group), c.tolist(), lo.tolist(), hi.tolist()))
+        return True
 
     def _make_hook(self, i):
         def hook(_param=None):
