@@ -235,10 +235,10 @@ int ttmi_spec_mask(float* x, int B, int T, int F, const int* time_spans, int n_t
  * The effective gradient is g * grad_scale (1/world_size after a SUM all-reduce) clipped to max_norm (max_norm <= 0: not clipped).
  * A step whose *normsq is inf / NaN is DROPPED (parameters and state untouched) whatever max_norm is: the exp-domain loss form fails with
  * NaN costs and gradients by construction, and such a step must not reach the weights.
- * hyper (device float[2], nullable): the values that change between steps, read by the kernels at RUN time so that a step captured into a
+ * hyper (device float[3], nullable): the values that change between steps, read by the kernels at RUN time so that a step captured into a
  * HIP graph follows them - hyper[0] = learning rate (replaces `lr`: tt/optim.py:30-33 decay_lr, train.py:257), hyper[1] = optimiser steps
- * taken; every *_step call with hyper != NULL first advances hyper[1] by one on the device (Adam's bias corrections 1 - beta^hyper[1]
- * replace the host's `step`). */
+ * TAKEN, hyper[2] = steps DROPPED; every *_step call with hyper != NULL first advances hyper[1] by one on the device - or, when *normsq is
+ * not finite, hyper[2]: a dropped step consumes no bias-correction step (Adam's corrections 1 - beta^hyper[1] replace the host's `step`). */
 int ttmi_sumsq(const float* x, long n, float* out, void* stream);
 int ttmi_sgd_step(float* p, const float* g, float* mom, long n, float lr, float momentum, float weight_decay, int nesterov,
                   float max_norm, const float* normsq, float grad_scale, float* hyper, void* stream);

@@ -253,7 +253,7 @@ def test_decode_graphs_match_eager_and_follow_weight_updates():
                         joint=dict(input_size=128, inner_size=48), vocab_size=29, dropout=0.0))
     torch.manual_seed(9)
     model = Transducer(cfg).cuda().eval()
-    model.config["decode_batch_graphs"] = True              # batches take the graph path too (opt-in since round 4: tt/model.py decode_batch)
+    model.config["decode_batch_graphs"] = True              # batches take the graph path too (the default again since round 5: tt/model.py decode_batch)
     with torch.no_grad():
         model.joint.project_layer.bias[0] += 0.4             # some blank frames between the emissions
     x = torch.randn(3, 70, 64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(10))

@@ -33,8 +33,8 @@ def run(utts=8, T=500, emit_rate=0.1, precision="fp32", block=None):
     cfg = c2_config()
     torch.manual_seed(1)
     model = Transducer(cfg).to(dev).eval()
-    if os.environ.get("TTMI_DECODE_BATCH_GRAPHS") == "1":
-        model.config["decode_batch_graphs"] = True                   # (debugging: label-encoder graphs for the batched decoder too)
+    if os.environ.get("TTMI_DECODE_BATCH_GRAPHS") in ("0", "1"):
+        model.config["decode_batch_graphs"] = os.environ["TTMI_DECODE_BATCH_GRAPHS"] == "1"      # (A/B: label-encoder graphs while the batch is complete - the default - or eager launches throughout)
     if os.environ.get("TTMI_DECODE_GRAPHS") == "0":
         model.config["decode_graphs"] = False                        # (debugging: eager label-encoder launches)
     d, V = cfg["enc"]["d_model"], cfg["vocab_size"]
@@ -86,7 +86,7 @@ def run(utts=8, T=500, emit_rate=0.1, precision="fp32", block=None):
            "encoder_ms": round(1e3 * t_enc, 2), "decode_ms_per_utt": round(1e3 * t_dec / args.utts, 2),
            "symbols_per_utt": round(nsym / args.utts, 1), "ms_per_symbol_step": round(1e3 * t_dec / max(max(len(h) for h in hyps), 1), 3),
            "host_syncs_per_batch": blocks[0], "host_syncs_per_utt": round(blocks[0] / args.utts, 1),
-           "decode": "Transducer.decode_batch: the batch in lockstep over symbol steps (one joint call per scanned block, one label-encoder call per step: eager launches; a graph replay with config.decode_batch_graphs)",
+           "decode": "Transducer.decode_batch: the batch in lockstep over symbol steps (one joint call per scanned block, one label-encoder call per step: a graph replay while the batch is complete, eager launches on the shrinking rows after)",
            "one_utterance_at_a_time": {"utt_per_s": round(args.utts / (t_enc + t_dec1), 3), "decode_ms_per_utt": round(1e3 * t_dec1 / args.utts, 2),
                                        "tokens_identical_to_batched": hyps1 == hyps,
                                        "host_syncs_per_utt_approx": round((nsym + args.utts * -(-args.T // (args.block or 64))) / args.utts, 1)}}

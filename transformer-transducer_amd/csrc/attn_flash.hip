@@ -15,6 +15,7 @@
 // 4 waves per workgroup; a wave owns 32 queries (fwd) / 32 keys (bwd); K/V (fwd) or (q+u)/dO (bwd) tiles are staged in
 // LDS with the row XOR swizzle chunk ^= (row >> 1) & (chunks-1).  Head dims 32 and 64.
 #include "attn_flash.h"
+#include "rowops.h"
 #include <stdlib.h>
 
 void ttmi_probe_begin(int slot, hipStream_t st);
@@ -2812,10 +2813,7 @@ int flash_attn_bwd(const FlashParams& p, hipStream_t st) {
     const bool reach_known = p.mask_kind == 2 || (p.mask_kind == 4 && p.mask_left >= 0 && p.mask_right >= 0 && p.mask_left + p.mask_right > 0);
     if (reach_known && ((long)p.mask_left + p.mask_right + 1 + 128 + 64) * 2 <= p.L && !(p.debug & 4)) {
         const size_t bytes = (size_t)p.B * p.H * p.slab16 * sizeof(bf16_t);
-        if (hipMemsetAsync(p.dS16, 0, bytes, st) != hipSuccess || hipMemsetAsync(p.dG16, 0, bytes, st) != hipSuccess) {
-            ttmi_set_error("flash_attn_bwd: hipMemsetAsync failed");
-            return TTMI_EINVAL;
-        }
+        if (fill_zero(p.dS16, bytes, st) != TTMI_OK || fill_zero(p.dG16, bytes, st) != TTMI_OK) return TTMI_EINVAL;
         q.bwd_skip = 1;
     }
     bf16_t* zg = p.zero_dg_row0 ? p.dG16 : nullptr;

@@ -181,9 +181,18 @@ const bf16_t* ctx_weightT(const void* ctx, int slot, const float* w, int R, int 
     }
     if (known && !shadowed) return ctx_copy;                      // the forward made this copy itself
     Shadow sh;
-    if (shadow_of(w, R, C, ldT, sh)) return sh.wT16;              // same registration as in the forward (kept current by the optimiser step)
-    *rc = transpose_convert_bf16(w, R, C, ctx_copy, ldT, st);     // the shadow is gone (or the context is unknown): same values, made now
+    if (known && shadow_of(w, R, C, ldT, sh)) return sh.wT16;     // same registration as in the forward (kept current by the optimiser step)
+    // the shadow is gone, or the context is UNKNOWN (its record was dropped - a second backward over a retained graph, or the table's
+    // overflow clear): never trust whatever shadow is registered NOW for a forward that may have made its own copy - the
+    // f32 weight gives the same values, made now
+    *rc = transpose_convert_bf16(w, R, C, ctx_copy, ldT, st);
     return ctx_copy;
+}
+// a backward call has read every slot of its context: drop the record (the table holds LIVE forward contexts only, so the overflow clear
+// below 4096 entries - which would also forget live ones - is never reached by a training loop)
+void ctx_forget(const void* ctx) {
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    g_ctx_shadowed.erase(ctx);
 }
 
 struct AttnDims {
@@ -340,12 +349,7 @@ void flash_inkernel(FlashParams& f, const AttnDims& a, const AttnCtx& c, const b
 }
 
 int memset2d(void* p, size_t pitch, size_t width, size_t height, hipStream_t st) {
-    hipError_t e = hipMemset2DAsync(p, pitch, 0, width, height, st);
-    if (e != hipSuccess) {
-        ttmi_set_error("memset2d: %s", hipGetErrorString(e));
-        return (int)e;
-    }
-    return TTMI_OK;
+    return fill_zero2d(p, pitch, width, height, st);        // a kernel, not a memset node (rowops.hip: graph replays)
 }
 
 // batched over (b, h): z1 = b, z2 = h
@@ -712,6 +716,7 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
         const bf16_t* wqkvT16 = ctx_weightT(ctx, 0, qkv_w, (int)a.W3, d, a.W3, c.wqkvT16, st, &rc);
         CK(rc);
         CK(gemm_nt_bf16(w.dqkv16, wqkvT16, dx, 0, e, (int)a.BL, d, (int)a.W3, a.W3, a.W3, d, st));
+        ctx_forget(ctx);
     } else {
         CK(wgrad(w.dqkv, x, g_qkv_w, (int)a.W3, d, (int)a.BL, a.W3, d, d, prec, st));
         GemmDesc g = mk(w.dqkv, qkv_w, dx, (int)a.BL, d, (int)a.W3, a.W3, d, d, NN_, prec);
@@ -901,6 +906,7 @@ static int ffn_bwd_impl(const float* dz, const float* y, const float* w1, const 
         CK(rc);
         const bf16_t* w2T16 = ctx_weightT(ctx, 1, w2, d, Di, d, c.w2T16, st, &rc);
         CK(rc);
+        ctx_forget(ctx);
         if (out) out[0] = ttmi_wgrad_desc{w.dres16, a1, g_w2, nullptr, d, Di, (int)rows, (long)d, (long)Di, (long)Di};
         else CK(gemm_tn_bf16(w.dres16, a1, g_w2, d, Di, (int)rows, d, Di, Di, 1, fork_stream(st)));
         NtEpilogue e;

@@ -46,7 +46,12 @@ __device__ __forceinline__ bool step_dropped(const float* normsq) {
 // by-value arguments): hyper[0] = learning rate, hyper[1] = number of optimiser steps taken so far (Adam's bias-correction exponent,
 // advanced on the device by optim_tick_kernel).  A step captured into a HIP graph (ttmi.train.GraphedStep) therefore follows
 // Optimizer.decay_lr() (tt/optim.py:30-33, train.py:257) and Adam's step count under replay - by-value arguments are frozen at capture.
-__global__ void optim_tick_kernel(float* __restrict__ hyper) { hyper[1] += 1.f; }
+// A DROPPED step (non-finite norm) does not consume a step count - Adam's bias corrections would otherwise run ahead of m and v, which
+// the drop leaves untouched - and is counted in hyper[2], which the host may poll without synchronising the step.
+__global__ void optim_tick_kernel(float* __restrict__ hyper, const float* __restrict__ normsq) {
+    if (step_dropped(normsq)) hyper[2] += 1.f;
+    else hyper[1] += 1.f;
+}
 // coef = grad_scale * min(1, max_norm / (grad_scale * sqrt(normsq) + 1e-6))   (torch.nn.utils.clip_grad_norm_)
 __device__ __forceinline__ float clip_coef(const float* normsq, float max_norm, float grad_scale) {
     if (!normsq || max_norm <= 0.f) return grad_scale;
@@ -135,11 +140,12 @@ int ttmi_sumsq(const float* x, long n, float* out, void* stream) {
 
 // torch.optim.SGD step on a flat buffer with the gradient clip folded in (normsq may be NULL = no clipping).
 // The effective gradient is g * grad_scale (e.g. 1/world_size after a SUM all-reduce), clipped to max_norm.
-// hyper (device, may be NULL): see optim_tick_kernel above - hyper[0] replaces `lr` at run time.  A non-finite *normsq drops the step.
+// hyper (device float[3], may be NULL): see optim_tick_kernel above - hyper[0] replaces `lr` at run time, hyper[1] counts the steps TAKEN,
+// hyper[2] the steps dropped.  A non-finite *normsq drops the step.
 int ttmi_sgd_step(float* p, const float* g, float* mom, long n, float lr, float momentum, float weight_decay, int nesterov,
                   float max_norm, const float* normsq, float grad_scale, float* hyper, void* stream) {
     TTMI_REQUIRE(p && g && n > 0 && (mom || momentum == 0.f), "sgd_step: bad arguments");
-    if (hyper) hipLaunchKernelGGL(optim_tick_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), hyper);
+    if (hyper) hipLaunchKernelGGL(optim_tick_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), hyper, normsq);
     hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, mom, n, lr,
                        momentum, weight_decay, nesterov, max_norm, normsq, grad_scale, hyper);
     TTMI_LAUNCH_CHECK("sgd_kernel");
@@ -151,7 +157,7 @@ int ttmi_adam_step(float* p, const float* g, float* m, float* v, long n, float l
                    float weight_decay, int step, float max_norm, const float* normsq, float grad_scale, float* hyper, void* stream) {
     TTMI_REQUIRE(p && g && m && v && n > 0 && (step > 0 || hyper), "adam_step: bad arguments");
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);      // (replaced on the device when hyper is given)
-    if (hyper) hipLaunchKernelGGL(optim_tick_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), hyper);
+    if (hyper) hipLaunchKernelGGL(optim_tick_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), hyper, normsq);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n, lr, beta1,
                        beta2, eps, weight_decay, bc1, bc2, max_norm, normsq, grad_scale, hyper);
     TTMI_LAUNCH_CHECK("adam_kernel");
@@ -162,7 +168,7 @@ int ttmi_adam_step(float* p, const float* g, float* m, float* v, long n, float l
 int ttmi_adadelta_step(float* p, const float* g, float* square_avg, float* acc_delta, long n, float lr, float rho, float eps,
                        float weight_decay, float max_norm, const float* normsq, float grad_scale, float* hyper, void* stream) {
     TTMI_REQUIRE(p && g && square_avg && acc_delta && n > 0 && rho >= 0.f && rho <= 1.f && eps > 0.f, "adadelta_step: bad arguments");
-    if (hyper) hipLaunchKernelGGL(optim_tick_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), hyper);
+    if (hyper) hipLaunchKernelGGL(optim_tick_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), hyper, normsq);
     hipLaunchKernelGGL(adadelta_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, square_avg, acc_delta, n, lr,
                        rho, eps, weight_decay, max_norm, normsq, grad_scale, hyper);
     TTMI_LAUNCH_CHECK("adadelta_kernel");

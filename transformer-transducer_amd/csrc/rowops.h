@@ -72,7 +72,8 @@ int joint_tanh_fwd_emis(const float* PE, const float* PD, const float* bias, int
 // dpre = dH * (1 - H^2);  dPE[b,t,:] = sum_u dpre, dPD[b,u,:] += sum_t dpre (atomic; caller zeroes dPD)
 int joint_tanh_bwd(const void* dH, const void* H, int h_dtype, int B, int T, int U1, int J, float* dPE, float* dPD,
                    hipStream_t st);
-int fill_zero(void* p, size_t bytes, hipStream_t st);
+int fill_zero(void* p, size_t bytes, hipStream_t st);             // a KERNEL (graph-safe), never a memset node: see rowops.hip
+int fill_zero2d(void* p, size_t pitch, size_t width, size_t height, hipStream_t st);
 // dst (bf16) = src (f32), n elements
 int convert_bf16(const float* src, bf16_t* dst, long n, hipStream_t st);
 // lo (bf16) = src - float(hi): the second term of the two-term bf16 split src ~ hi + lo

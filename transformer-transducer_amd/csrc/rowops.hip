@@ -1260,7 +1260,7 @@ int greedy_advance(unsigned long long* key, int B, int n, int n_hist, long* hist
                    int* count, int* flags, hipStream_t st) {
     TTMI_REQUIRE(key && hist && t && T_len && need && done && count && flags && B > 0 && n > 0 && n_hist >= 1 && n_hist < ld_hist,
                  "greedy_advance: bad arguments");
-    if (hipMemsetAsync(flags, 0, 2 * sizeof(int), st) != hipSuccess) { ttmi_set_error("greedy_advance: memset failed"); return TTMI_EINVAL; }
+    if (fill_zero(flags, 2 * sizeof(int), st) != TTMI_OK) return TTMI_EINVAL;
     hipLaunchKernelGGL(greedy_advance_kernel, dim3(cdiv(B, 64)), dim3(64), 0, st, key, B, n, n_hist, hist, ld_hist, t, T_len, need, done, count, flags);
     TTMI_LAUNCH_CHECK("greedy_advance_kernel");
     return TTMI_OK;
@@ -1482,10 +1482,76 @@ int joint_tanh_bwd(const void* dH, const void* H, int h_dtype, int B, int T, int
     return TTMI_OK;
 }
 
+// Zero fills are KERNELS, never hipMemsetAsync / hipMemset2DAsync (round 5): a memset NODE inside a captured HIP graph is not ordered
+// against its neighbouring kernel nodes by ROCm 7.2's packet-capture graph launch (DEBUG_CLR_GRAPH_PACKET_CAPTURE, on by default) - the
+// 2-D fill of the position slab's column 0 (attn_fwd_impl, fp32 path) landed before OR after the GEMMs around it from replay to replay, and
+// the greedy decoder's label-encoder graphs came back with other token sets in a third of the processes (tools/debug/replay_divergence.py:
+// hipMemset2DAsync 7 / 7 bad passes, this kernel 0 / 4, packet capture off 0 / 4).  TTMI_MEMSET_KERNEL=0 restores the
+// runtime's memsets (to reproduce the failure only).
+__global__ __launch_bounds__(256) void zero_bytes_kernel(char* __restrict__ p, size_t head, size_t n16, size_t tail) {
+    // [p, p + head) bytes up to the first 16-byte boundary, then n16 16-byte pieces, then `tail` bytes
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x, gsz = (size_t)gridDim.x * 256;
+    uint4* q = reinterpret_cast<uint4*>(p + head);
+    const uint4 z = {0u, 0u, 0u, 0u};
+    for (size_t i = gid; i < n16; i += gsz) q[i] = z;
+    if (gid < head) p[gid] = 0;
+    if (gid < tail) p[head + n16 * 16 + gid] = 0;
+}
+// rows of `width2` 2-byte elements every `pitch2` elements
+__global__ __launch_bounds__(256) void zero2d_kernel(unsigned short* __restrict__ p, size_t pitch2, size_t width2, size_t height) {
+    const size_t n = width2 * height;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / width2, c = i - r * width2;
+        p[r * pitch2 + c] = 0;
+    }
+}
+static int g_memset_kernel = -1;
+static bool memset_by_kernel() {
+    if (g_memset_kernel < 0) {
+        const char* e = getenv("TTMI_MEMSET_KERNEL");
+        g_memset_kernel = e ? atoi(e) : 1;
+    }
+    return g_memset_kernel != 0;
+}
+
 int fill_zero(void* p, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return TTMI_OK;
+    TTMI_REQUIRE(p, "fill_zero: null pointer");
+    if (memset_by_kernel()) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+        size_t head = (16 - (a & 15)) & 15;
+        if (head > bytes) head = bytes;
+        const size_t n16 = (bytes - head) / 16, tail = bytes - head - n16 * 16;
+        size_t nb = (n16 + 255) / 256;
+        if (nb < 1) nb = 1;
+        if (nb > 8192) nb = 8192;
+        hipLaunchKernelGGL(zero_bytes_kernel, dim3((unsigned)nb), dim3(256), 0, st, static_cast<char*>(p), head, n16, tail);
+        TTMI_LAUNCH_CHECK("zero_bytes_kernel");
+        return TTMI_OK;
+    }
     hipError_t e = hipMemsetAsync(p, 0, bytes, st);
     if (e != hipSuccess) {
         ttmi_set_error("fill_zero: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return TTMI_OK;
+}
+
+// `height` rows of `width` bytes, `pitch` bytes apart
+int fill_zero2d(void* p, size_t pitch, size_t width, size_t height, hipStream_t st) {
+    if (width == 0 || height == 0) return TTMI_OK;
+    TTMI_REQUIRE(p, "fill_zero2d: null pointer");
+    if (memset_by_kernel() && pitch % 2 == 0 && width % 2 == 0 && (reinterpret_cast<uintptr_t>(p) & 1) == 0) {
+        const size_t n = (width / 2) * height;
+        size_t nb = (n + 255) / 256;
+        if (nb > 8192) nb = 8192;
+        hipLaunchKernelGGL(zero2d_kernel, dim3((unsigned)nb), dim3(256), 0, st, static_cast<unsigned short*>(p), pitch / 2, width / 2, height);
+        TTMI_LAUNCH_CHECK("zero2d_kernel");
+        return TTMI_OK;
+    }
+    hipError_t e = hipMemset2DAsync(p, pitch, 0, width, height, st);
+    if (e != hipSuccess) {
+        ttmi_set_error("fill_zero2d: %s", hipGetErrorString(e));
         return (int)e;
     }
     return TTMI_OK;

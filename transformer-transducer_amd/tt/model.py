@@ -218,6 +218,8 @@ def _meta_functions():
     # (not stride / is_contiguous: the eager logits are a [..., :V] view of a pitched buffer - those come from the real tensor)
     for name in ("shape", "dtype", "device", "ndim", "is_cuda", "is_cpu", "layout", "is_sparse", "is_quantized", "is_meta", "is_nested",
                  "requires_grad", "itemsize", "names"):
+        # (grad_fn / is_leaf / grad are NOT answered here: they are the real logits' autograd state - a caller that checks `logits.grad_fn`
+        # must see the joint's node - so they materialise, with the one-time warning below when that costs gigabytes)
         fns.add(getattr(T, name).__get__)
     return frozenset(fns)
 
@@ -235,6 +237,8 @@ class DeferredLogits(torch.Tensor):
     logits tensor.  Metadata (`shape`, `size()`, `dim()`, `dtype`, `device`, `is_cuda`, `numel()`, `len()`, `requires_grad`) is answered
     from the handle.  Implementation: a storage-less wrapper subclass (`Tensor._make_wrapper_subclass`) whose `__torch_function__`
     swaps the handle for the real logits before any function that is not a metadata query runs."""
+
+    _warned_big = False
 
     @staticmethod
     def __new__(cls, joint, enc_state, dec_state, prec):
@@ -274,6 +278,13 @@ class DeferredLogits(torch.Tensor):
     def materialize(self):
         """-> the real logits (produced on first use under the grad mode of the forward call that made the handle, then kept)"""
         if self._real is None:
+            nbytes = self.numel() * self.element_size()
+            if nbytes >= (1 << 30) and not DeferredLogits._warned_big:
+                import warnings
+                DeferredLogits._warned_big = True
+                warnings.warn("DeferredLogits: a use other than RNNTLoss / shape queries is forming the real [B, T, U+1, V] logits (%.1f GB, kept "
+                              "for the life of the handle); pass the handle straight to RNNTLoss to stay on the fused path, or set "
+                              "TTMI_DEFERRED_LOGITS=0 if the logits are wanted anyway" % (nbytes / 2.0 ** 30))
             with torch.set_grad_enabled(self._grad_mode):
                 self._real = self._produce()
         return self._real
@@ -291,6 +302,11 @@ class DeferredLogits(torch.Tensor):
         ops.weights_fresh()
         exp = self._prec == 1 and os.environ.get("TTMI_DEFERRED_EXP", "1") != "0"
         chunk = j.default_loss_chunk(B, T, U1, exp, self._prec)
+        if exp and not ops.joint_exp_supported(chunk, T, U1, j.forward_layer.out_features, j.project_layer.out_features, self._prec,
+                                               fwd_only=not (grad and self.requires_grad)):
+            # the exp-domain kernels do not take this problem: the plain fused form runs, and ITS chunk is the memory form's (about 2 GB of
+            # logits per chunk, not the 32 GB budget of the form that never holds them)
+            chunk = j.default_loss_chunk(B, T, U1, False, self._prec)
         return _JointLossFn.apply(self._enc, self._dec, j.forward_layer.weight, j.forward_layer.bias, j.project_layer.weight,
                                   j.project_layer.bias, labels, act_lens, label_lens, self._prec, int(chunk), reduction,
                                   j.exp_shift_state(self._enc.device) if exp else None, grad, int(blank))
@@ -313,9 +329,18 @@ class DeferredLogits(torch.Tensor):
 
     @classmethod
     def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
-        # reached only by callers below the Python API (the handle has no storage): give them the real values, detached
+        # reached only by callers below the Python API (the handle has no storage): give them the real values.  Those values are
+        # DETACHED - a foreign op applied at this level to a handle that needs gradients would silently cut the encoders off the graph,
+        # so that case raises (grad mode on and the handle requires grad); inference / no_grad callers get the values
         import torch.utils._pytree as pytree
-        args, kwargs = pytree.tree_map_only(DeferredLogits, lambda a: a.materialize().detach(), (args, kwargs or {}))
+
+        def real(a):
+            if a.requires_grad and torch.is_grad_enabled():
+                raise RuntimeError("DeferredLogits reached %s below the Python API while it requires grad: the op would run on detached "
+                                   "logits and lose the gradient into the encoders.  Call logits.materialize() first (or set "
+                                   "TTMI_DEFERRED_LOGITS=0)" % (func,))
+            return a.materialize().detach()
+        args, kwargs = pytree.tree_map_only(DeferredLogits, real, (args, kwargs or {}))
         return func(*args, **kwargs)
 
 
@@ -423,7 +448,7 @@ class _LabelStateGraphs:
             cur.wait_stream(self.stream)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, pool=self.pool, stream=self.stream):
-                out = self.decoder(tok)[:, -1:, :]
+                out = self.decoder(tok)[:, -1:, :].clone()       # (keeps [B, 1, d] alive per graph, not the stack's whole [B, L, d] output)
             assert ops.scratch_generation(self.device, self.stream) == self.arena, "scratch arena grew during a capture"
             entry = self.graphs[L] = (graph, tok, out)
         graph, tok, out = entry
@@ -600,13 +625,15 @@ class Transducer(nn.Module):
         B, T = enc_states.shape[0], enc_states.shape[1]
         block = 64 if block is None else block                       # frames scored per joint call
         T_len = torch.as_tensor(lengths, dtype=torch.int32).to(dev).clamp(max=T).contiguous()
-        # Label-encoder graphs for a whole batch are opt-in (config.decode_batch_graphs).  They buy nothing at 32 utterances (96 against 97 utt/s:
-        # a step's ~150 launches are no longer what the host waits for) and, in tools/bench_decode.py's call order, a third of the PROCESSES
-        # came back from their first pure-replay pass with one of two other token sets (14 runs each: graphs on 5 / 14, also with the skinny
-        # kernel off 6 / 14 and with a host synchronisation before or after every replay 5 - 8 / 14; eager launches 0 / 14; a replay is
-        # bit-identical to the eager call on the same tokens whatever the scratch arenas hold, tools/debug/decode_poison.py - the cause was not
-        # found in round 4).  One utterance at a time (`decode`) keeps its graphs: there they are the speed, and its tokens never moved.
-        graphs = self._label_state_graphs(dev, B) if self.config.decode_batch_graphs else None
+        # Label-encoder graphs serve the symbol steps in which the batch is still COMPLETE (one replay instead of ~150 launches; a graph is
+        # captured for a fixed row count); as soon as an utterance has finished the rows shrink and the calls are eager launches on the rows
+        # still decoding - which is worth more than the replay (96 utt/s with a fixed batch of 32, 212 with shrinking rows).
+        # config.decode_batch_graphs = False: eager launches throughout.  Round 4 had made the graphs opt-in because a third of the processes
+        # came back from their first pure-replay pass with other tokens; round 5 found the cause - a hipMemset2DAsync NODE in the captured
+        # label encoder (column 0 of the fp32 path's position slab) that ROCm 7.2's graph launch does not order against the kernels around
+        # it - and removed every memset node from the library (csrc/rowops.hip fill_zero*, DESIGN.md section 4j,
+        # tests/test_decode_graphs_gpu.py).
+        graphs = self._label_state_graphs(dev, B) if self.config.decode_batch_graphs is not False else None
         final_hist = torch.zeros(B, T + 2, dtype=torch.long, device=dev)   # column 0 = the start symbol (blank); at most one symbol per frame
         final_count = torch.zeros(B, dtype=torch.int32, device=dev)
         hist = final_hist.clone()
@@ -622,7 +649,7 @@ class Transducer(nn.Module):
 
         def label_states(n_hist):
             """label-encoder outputs at the last position of every history (all of length n_hist) -> [rows of the batch, 1, d]"""
-            if graphs is not None and n_hist <= graphs.MAX_L:
+            if graphs is not None and n_hist <= graphs.MAX_L and hist.shape[0] == graphs.batch:
                 graphs.master[:, :n_hist].copy_(hist[:, :n_hist])
                 return graphs.state(n_hist)
             return self.decoder(hist[:, :n_hist].contiguous())[:, -1:, :]
@@ -641,7 +668,7 @@ class Transducer(nn.Module):
                     break
             if alive == 0:
                 break
-            if alive < hist.shape[0] and graphs is None and self.config.decode_batch_shrink is not False:
+            if alive < hist.shape[0] and self.config.decode_batch_shrink is not False:
                 # finished utterances leave the batch: every later label-encoder and joint call runs on the rows still decoding (per-utterance
                 # arithmetic does not depend on who else is in the batch).  Their histories are kept; no host round trip - the row count is
                 # `alive`, the rows are the first `alive` of a stable sort by the done flag

@@ -280,7 +280,8 @@ class FusedOptimizer:
         # what changes between steps lives on the DEVICE, where the update kernels read it at run time: (learning rate, optimiser steps taken).
         # A step captured into a HIP graph (GraphedStep) would otherwise replay the values of the moment of capture - decay_lr() silently
         # ignored, Adam's bias correction frozen.  `lr` and `steps_taken` are host mirrors; assigning to them writes the device copy.
-        self.hyper = torch.zeros(2, dtype=torch.float32, device=flat.flat.device)
+        # hyper[2] counts the steps the device DROPPED (non-finite gradient norm): those consume no step count (`dropped_steps()`).
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=flat.flat.device)
         self.lr = lr
         self.global_step = 1                # tt/optim.py:8
         self.current_epoch = 0
@@ -303,6 +304,13 @@ class FusedOptimizer:
     def steps_taken(self, value):
         self._steps = int(value)
         self.hyper[1:2].fill_(float(self._steps))
+
+    def dropped_steps(self):
+        """steps the update kernels dropped because the gradient norm was not finite (device counter; reading it waits for the stream).
+        A dropped step leaves parameters, state AND the device's step count untouched; the host mirror is re-read here."""
+        h = self.hyper.tolist()
+        self._steps = int(h[1])
+        return int(h[2])
 
     def host_counters(self):
         return self.global_step, self._steps
@@ -358,6 +366,8 @@ class FusedOptimizer:
 
     def state_dict(self):
         n = len(self.flat.params)
+        if self.flat.flat.is_cuda:
+            self.dropped_steps()            # the step count that goes into the checkpoint is the device's (dropped steps do not count)
         if self.kind == "sgd":
             group = dict(lr=self.lr, momentum=self.momentum, dampening=0, weight_decay=self.weight_decay, nesterov=self.nesterov)
             state = {}
@@ -435,8 +445,9 @@ class GraphedStep:
       runs in `thread_local` error mode so that the process group's watchdog thread may keep polling its events;
     * the exp-domain loss form's range check (tt.model._ExpShift) is looked at between replays: after a raised flag (that replay's step was
       dropped on the device: NaN gradients) the NEXT call runs ONE eager step in place of a replay - the plain loss form, which re-seeds
-      the shift - and returns its loss; the call after that captures again (a capture executes nothing) and replays.  Every batch gets
-      exactly one optimiser update.
+      the shift - and returns its loss; the call after that captures again (a capture executes nothing) and replays.  The batch of
+      the FLAGGED replay is lost (its step was dropped on the device: no update, `optimizer.dropped_steps()` counts it); every other
+      batch gets exactly one optimiser update.
     Host-side counters (`optimizer.global_step`, its step-count mirror) are restored after a capture - which runs `step_fn`'s Python once
     without executing a step - and advanced by one per replay.  The `warmup` eager steps of the constructor ARE real steps on whatever the
     static input tensors hold (they update the weights and the counters); fill the static inputs with the first batch before constructing."""
