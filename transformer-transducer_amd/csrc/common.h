@@ -37,8 +37,11 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     __hip_bfloat16 b = __float2bfloat16(f);
     return *reinterpret_cast<bf16_t*>(&b);
 }
+// ONE v_cvt_pk_bf16_f32 (round 5; converting each half and OR-ing them cost a second instruction per pair - same rounding, same bits)
+typedef float ttmi_f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 ttmi_bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(ttmi_f32x2_t{lo, hi}, ttmi_bf16x2_t));
 }
 
 // sum over the 64 lanes, returned in every lane: five DPP adds inside the rows of 16, two row broadcasts, one readlane (the __shfl_xor

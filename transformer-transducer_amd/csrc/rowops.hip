@@ -731,9 +731,11 @@ __global__ __launch_bounds__(256) void joint_tanh_fwd_kernel(const float* __rest
 
 // bf16 pipeline (J % 4 == 0): 4 columns per thread, 8-byte stores; tanh(x) = 1 - 2 / (1 + e^(2x)) on v_exp_f32 / v_rcp_f32 (relative
 // error ~1e-6, three orders below the bf16 rounding of H) - the libm tanhf made this kernel instruction-bound at 1.7 TB/s
+// (round 5: v_exp_f32 / v_rcp_f32 themselves - `__expf` + `__frcp_rn` compiled to the IEEE division sequence, two v_div_scale, v_div_fmas,
+// v_div_fixup and four fmas around the v_rcp: 17 vector instructions per element where 5 do; both hardware ops are good to 1 ulp)
 __device__ __forceinline__ float fast_tanh(float x) {
-    const float e = __expf(2.f * x);                       // inf for large x -> 1 - 0; 0 for very negative x -> 1 - 2
-    return 1.f - 2.f * __frcp_rn(1.f + e);
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);      // e^(2x): inf for large x -> 1 - 0; 0 for very negative x -> 1 - 2
+    return fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + e), 1.f);
 }
 __global__ __launch_bounds__(256) void joint_tanh_fwd_bf16x4_kernel(const float* __restrict__ PE, const float* __restrict__ PD,
                                                                     const float* __restrict__ bias, int T, int U1, int J,
@@ -791,9 +793,36 @@ __device__ __forceinline__ float dpp_row_sum(float v) {
     if constexpr (FULL64) v += mv(v, std::integral_constant<int, 0x143>(), std::integral_constant<int, 0xC>());   // row_bcast:31 into rows 2 and 3
     return v;
 }
-constexpr int JT_TT = 4;             // frames per block: the label-encoder rows PD[b, u, :] (and, with EMIS, the rows of Wp16 of b's labels) are
+// FOUR sums at once (the EMIS dot products of one lattice row): a two-step transpose inside every quad leaves lane l with value l & 3
+// summed over its quad (9 instructions), two row rotates and the row / half swaps finish it: EVERY lane holds value l & 3 summed over the
+// 64 lanes (FULL64; else over its half of 32) - 13 cross-lane instructions where four dpp_row_sum chains took 24
+// DPP moves + 24 adds (round 5: the kernel was bound by its vector instructions, not by its stores)
+template <bool FULL64>
+__device__ __forceinline__ float dpp_row_sum4(float a0, float a1, float a2, float a3, int lane) {
+    auto mv = [](float x, auto ctrl, auto rmask) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(rmask)::value, 0xF, false));
+    };
+    const bool p = lane & 1, q = lane & 2;
+    // pairs: the even lane ends with values {0, 2}, the odd one with {1, 3}
+    const float b0 = (p ? a1 : a0) + mv(p ? a0 : a1, std::integral_constant<int, 0xB1>(), std::integral_constant<int, 0xF>());      // quad_perm [1,0,3,2]
+    const float b1 = (p ? a3 : a2) + mv(p ? a2 : a3, std::integral_constant<int, 0xB1>(), std::integral_constant<int, 0xF>());
+    // pairs of pairs: lane l of the quad ends with value l
+    float v = (q ? b1 : b0) + mv(q ? b0 : b1, std::integral_constant<int, 0x4E>(), std::integral_constant<int, 0xF>());              // quad_perm [2,3,0,1]
+    v += mv(v, std::integral_constant<int, 0x124>(), std::integral_constant<int, 0xF>());     // row_ror:4
+    v += mv(v, std::integral_constant<int, 0x128>(), std::integral_constant<int, 0xF>());     // row_ror:8: every lane holds its row's sum of value l & 3
+    // across the rows of 16 the lane-in-row (= value index) must be kept: gfx950's row / half swaps (row_bcast would hand every lane of the
+    // next row lane 15's value).  v_permlane16_swap D, S: rows 1, 3 of D <-> rows 0, 2 of S; with D = S = v, D + S = rows (0 + 1) and (2 + 3)
+    auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+    v = __int_as_float(s16[0]) + __int_as_float(s16[1]);
+    if constexpr (FULL64) {                                                                    // v_permlane32_swap: upper half of D <-> lower half of S
+        auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+        v = __int_as_float(s32[0]) + __int_as_float(s32[1]);
+    }
+    return v;                                                                                  // every lane: value l & 3 summed over the 64 (32) lanes
+}
+constexpr int JT_TT_DEFAULT = 4, JT_TT = JT_TT_DEFAULT;             // frames per block: the label-encoder rows PD[b, u, :] (and, with EMIS, the rows of Wp16 of b's labels) are
                                      // read once per u and used for four frames - these L2 reads, not the 2 bytes per element of output, held the kernel at 3.2 TB/s
-template <bool EMIS>
+template <bool EMIS, int JT_TT = JT_TT_DEFAULT>
 __global__ __launch_bounds__(256) void joint_tanh_fwd_bf16x8_kernel(const float* __restrict__ PE, const float* __restrict__ PD,
                                                                     const float* __restrict__ bias, int T, int U1, int J,
                                                                     bf16_t* __restrict__ H, JointEmis em) {
@@ -860,13 +889,11 @@ __global__ __launch_bounds__(256) void joint_tanh_fwd_bf16x8_kernel(const float*
                         db = fmaf(hv[i], wb[i], db); dl = fmaf(hv[i], wl[i], dl);
                         db32 = fmaf(th[i], wb32[i], db32); dl32 = fmaf(th[i], wl32[i], dl32);
                     }
-                    // sum over the lanes of this wave that hold the row (all 64, or an aligned group of tpr = 32): the group's last lane gets it
-                    if (tpr >= 64) { db = dpp_row_sum<true>(db); dl = dpp_row_sum<true>(dl); db32 = dpp_row_sum<true>(db32); dl32 = dpp_row_sum<true>(dl32); }
-                    else { db = dpp_row_sum<false>(db); dl = dpp_row_sum<false>(dl); db32 = dpp_row_sum<false>(db32); dl32 = dpp_row_sum<false>(dl32); }
-                    if ((tin & 63) == 63 || (tpr == 32 && (tin & 31) == 31)) {
-                        float* q = part + (((long)tt * U1 + u) * nw + (tin >> 6)) * 4;
-                        *reinterpret_cast<float4*>(q) = make_float4(db, dl, db32, dl32);
-                    }
+                    // sum over the lanes of this wave that hold the row (all 64, or an aligned group of tpr = 32): the group's last FOUR lanes
+                    // get the four sums (value index = lane & 3)
+                    const float sv = tpr >= 64 ? dpp_row_sum4<true>(db, dl, db32, dl32, tin) : dpp_row_sum4<false>(db, dl, db32, dl32, tin);
+                    if ((tin & (tpr >= 64 ? 63 : 31)) < 4)
+                        part[(((long)tt * U1 + u) * nw + (tin >> 6)) * 4 + (tin & 3)] = sv;
                 }
             }
         }
@@ -1446,10 +1473,18 @@ int joint_tanh_fwd_emis(const float* PE, const float* PD, const float* bias, int
     TTMI_REQUIRE(aligned16(emis), "joint_tanh_fwd_emis: emis must be 16-byte aligned");
     JointEmis em;
     em.Wp16 = Wp16; em.Wp32 = Wp32; em.bp = bp; em.labels = labels; em.out = emis; em.V = V; em.blank = blank;
-    const size_t part_bytes = (size_t)JT_TT * U1 * (J / 8 >= 64 ? J / 8 / 64 : 1) * 4 * sizeof(float);
+    static int tt_env = -1;
+    if (tt_env < 0) { const char* e = getenv("TTMI_JOINT_TT"); tt_env = e ? atoi(e) : 8; }
+    // 8 frames per block where there are frames to spare: the label rows of Wp16 / Wp32 and the PD row are read once per u for eight frames
+    // (570 -> 545 us at C2, same box; TTMI_JOINT_TT=4 for A/B)
+    const int TT = (tt_env == 8 && T >= 64) ? 8 : JT_TT;
+    const size_t part_bytes = (size_t)TT * U1 * (J / 8 >= 64 ? J / 8 / 64 : 1) * 4 * sizeof(float);
     if ((J == 256 || J == 512 || J == 1024 || J == 2048) && aligned16(PE) && aligned16(PD) && aligned16(bias) && aligned16(H) && aligned16(Wp16) &&
         aligned16(Wp32) && part_bytes <= 60 * 1024) {
-        hipLaunchKernelGGL(joint_tanh_fwd_bf16x8_kernel<true>, dim3(B * cdiv(T, JT_TT)), dim3(256), part_bytes, st,
+        if (TT == 8)
+            hipLaunchKernelGGL((joint_tanh_fwd_bf16x8_kernel<true, 8>), dim3(B * cdiv(T, 8)), dim3(256), part_bytes, st, PE, PD, bias, T, U1, J, H, em);
+        else
+            hipLaunchKernelGGL((joint_tanh_fwd_bf16x8_kernel<true, JT_TT_DEFAULT>), dim3(B * cdiv(T, JT_TT)), dim3(256), part_bytes, st,
                            PE, PD, bias, T, U1, J, H, em);
         TTMI_LAUNCH_CHECK("joint_tanh_fwd_bf16x8_kernel<emis>");
         return TTMI_OK;
