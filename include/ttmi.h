@@ -86,6 +86,9 @@ int ttmi_embed_bwd(const long* tokens, const float* dout, long n, int d, int V, 
 int ttmi_joint_logits_dtype(int prec, int J);
 size_t ttmi_joint_ctx_floats(int B, int T, int U1, int J);
 size_t ttmi_joint_ws_floats(int B, int T, int U1, int J, int V);
+/* the same for a given precision code: prec 2 (TTMI_PRECISION=bf16x3: the f32 data flow of prec 0 with its large dense products on the bf16
+ * MFMA in three terms, hi . hi + lo . hi + hi . lo) needs room for the split operands behind the ordinary workspace */
+size_t ttmi_joint_ws_floats_prec(int B, int T, int U1, int J, int V, int prec);
 int ttmi_joint_fwd(const float* enc, const float* dec, const float* wf, const float* bf, const float* wp, const float* bp,
                    int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx, float* ws, void* logits, long ldv,
                    void* stream);

@@ -172,8 +172,11 @@ def test_c4_joint_dims_vs_torch(monkeypatch):
 
 
 # ----------------------------------------------------------------------------------------------- C2 end to end
-def test_c2_full_model_fp32_end_to_end(monkeypatch):
-    """BASELINE configs[1] model (12 audio / 6 label layers, d_model=512, Di=1024, J=1024, V=4334, K=410/42; 48.2 M parameters, random
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+def test_c2_full_model_fp32_end_to_end(monkeypatch, mode):
+    """(mode bf16x3, round 5: the same data flow with the large dense products in three bf16 terms - the quick parity mode must meet the
+    SAME bounds as the exact-f32 one.)
+    BASELINE configs[1] model (12 audio / 6 label layers, d_model=512, Di=1024, J=1024, V=4334, K=410/42; 48.2 M parameters, random
     init) at B=2, T=500, U=50 in fp32: logits, loss, input gradient and EVERY parameter gradient against the float64 oracle.
 
     ReLU decisions: among the 12.6 M FFN hidden units of this run a handful have pre-activations within f32 rounding noise of zero
@@ -188,7 +191,7 @@ def test_c2_full_model_fp32_end_to_end(monkeypatch):
     from tt.model import Transducer
     from ttmi import ops
     from warprnnt_pytorch import RNNTLoss
-    monkeypatch.setenv("TTMI_PRECISION", "fp32")
+    monkeypatch.setenv("TTMI_PRECISION", mode)
     cfg = bench.c2_config()
     cfg["dropout"] = 0.0
     torch.manual_seed(1)
@@ -241,7 +244,7 @@ def test_c2_full_model_fp32_end_to_end(monkeypatch):
         if e > worst[1]:
             worst = (name, e)
         assert e < TOL, (name, e)
-    print("C2 end to end fp32: loss rel %.2e, dinputs %.2e, worst gradient %s %.2e, ReLU units decided differently from float64: %d"
+    print("C2 end to end " + mode + ": loss rel %.2e, dinputs %.2e, worst gradient %s %.2e, ReLU units decided differently from float64: %d"
           % (abs(float(loss.detach()) - want["loss"]) / want["loss"], rel_err(x.grad.cpu().numpy(), want["dinputs"]), worst[0], worst[1], flips))
 
 

@@ -32,7 +32,7 @@ inline size_t al4(size_t n) { return (n + 3) & ~size_t(3); }
 GemmDesc mk(const float* A, const float* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int flags, int prec) {
     GemmDesc d;
     d.A = A; d.B = B; d.C = C; d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc;
-    d.flags = flags | (prec ? GEMM_BF16_MFMA : 0);
+    d.flags = flags | (prec == 1 ? GEMM_BF16_MFMA : 0);      // (prec 2 = bf16x3: f32 data flow; the big dense products go through x3_* below, the rest stays exact f32)
     return d;
 }
 
@@ -58,6 +58,48 @@ int wgrad(const float* dY, const float* X, float* gW, int M, int N, int K, long 
         int rc__ = (expr);       \
         if (rc__) return rc__;   \
     } while (0)
+
+// ---- TTMI_PRECISION=bf16x3 (prec 2, round 5): the parity mode's f32 data flow with its large dense products on the bf16 MFMA in three
+// terms (rowops.hip split3_kernel): A . B^T ~ A_hi B_hi + A_lo B_hi + A_hi B_lo - one launch of the throughput kernels over the tripled
+// reduction (NT / NN), three accumulating launches on the [hi | lo] planes (TN: weight gradients).  Relative error ~2^-16 per product against
+// 2^-24 (exact f32) and 2^-8 (bf16); tests/test_bf16x3_gpu.py holds the mode to the fp32 mode's own 1e-4 bounds.  `scratch`: bf16 elements.
+inline int x3_pad(int n) { return (n + 63) / 64 * 64; }
+inline size_t x3_al(size_t n) { return (n + 63) & ~(size_t)63; }
+inline size_t x3_nt_elems(long M, long N, int K) { return x3_al((size_t)M * 3 * x3_pad(K)) + x3_al((size_t)N * 3 * x3_pad(K)); }
+inline size_t x3_tn_elems(long K, int M, int N) { return x3_al((size_t)K * 2 * x3_pad(M)) + x3_al((size_t)K * 2 * x3_pad(N)); }
+// big enough to be worth two split passes and the throughput kernels
+inline bool x3_worth(long M, long N, long K) { return M >= 256 && N >= 64 && K >= 64 && M * N * K >= (1L << 27); }
+// C[M,N] = epi(A[M,K] . B[N,K]^T)
+int x3_nt(const float* A, const float* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, const NtEpilogue& e, bf16_t* scratch,
+          hipStream_t st) {
+    const int Kp = x3_pad(K);
+    bf16_t* A3 = scratch;
+    bf16_t* B3 = A3 + x3_al((size_t)M * 3 * Kp);
+    CK(split3_bf16(A, lda, M, K, Kp, 0, A3, st));
+    CK(split3_bf16(B, ldb, N, K, Kp, 1, B3, st));
+    return gemm_nt_bf16(A3, B3, C, 0, e, M, N, 3 * Kp, 3L * Kp, 3L * Kp, ldc, st);
+}
+// C[M,N] = epi(A[M,K] . B[K,N]) (B row-major [K, N]: a dgrad against the weight as stored)
+int x3_nn(const float* A, const float* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, const NtEpilogue& e, bf16_t* scratch,
+          hipStream_t st) {
+    const int Kp = x3_pad(K);
+    bf16_t* A3 = scratch;
+    bf16_t* B3 = A3 + x3_al((size_t)M * 3 * Kp);
+    CK(split3_bf16(A, lda, M, K, Kp, 0, A3, st));
+    CK(split3_transpose_bf16(B, ldb, K, N, Kp, true, B3, st));
+    return gemm_nt_bf16(A3, B3, C, 0, e, M, N, 3 * Kp, 3L * Kp, 3L * Kp, ldc, st);
+}
+// C[M,N] += A[K,M]^T . B[K,N] (atomically: a weight gradient)
+int x3_tn(const float* A, const float* B, float* C, int M, int N, long K, long lda, long ldb, long ldc, bf16_t* scratch, hipStream_t st) {
+    const int Mp = x3_pad(M), Np = x3_pad(N);
+    bf16_t* A2 = scratch;
+    bf16_t* B2 = A2 + x3_al((size_t)K * 2 * Mp);
+    CK(split3_bf16(A, lda, K, M, Mp, 2, A2, st));
+    CK(split3_bf16(B, ldb, K, N, Np, 2, B2, st));
+    CK(gemm_tn_bf16(A2, B2, C, M, N, (int)K, 2L * Mp, 2L * Np, ldc, 1, st));
+    CK(gemm_tn_bf16(A2 + Mp, B2, C, M, N, (int)K, 2L * Mp, 2L * Np, ldc, 1, st));
+    return gemm_tn_bf16(A2, B2 + Np, C, M, N, (int)K, 2L * Mp, 2L * Np, ldc, 1, st);
+}
 
 // ---- intra-call concurrency: weight-gradient GEMMs feed nothing downstream inside a backward call, so they are forked onto a
 // library-owned side stream (one per caller stream) and joined before the call returns (scratch buffers they read are reused by
@@ -231,7 +273,7 @@ GemmDesc mkx(const void* A, int adt, const void* B, int bdt, void* C, int cdt, i
     GemmDesc d;
     d.A = A; d.B = B; d.C = C; d.a_dtype = adt; d.b_dtype = bdt; d.c_dtype = cdt;
     d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc;
-    d.flags = flags | (prec ? GEMM_BF16_MFMA : 0);
+    d.flags = flags | (prec == 1 ? GEMM_BF16_MFMA : 0);
     return d;
 }
 
@@ -1052,6 +1094,17 @@ size_t ttmi_joint_ws_floats(int B, int T, int U1, int J, int V) {
            al4((size_t)J * (((size_t)V + 63) / 64 * 64));
 }
 
+// scratch of the bf16x3 products behind the ordinary joint workspace (prec 2): the backward's two big ones use it one after the other
+static size_t joint_x3_floats(int B, int T, int U1, int J, int V) {
+    const long M = (long)B * T * U1;
+    const size_t fwd = x3_nt_elems(M, V, J), dgrad = x3_nt_elems(M, J, V), wg = x3_tn_elems(M, V, J);
+    const size_t m = fwd > dgrad ? (fwd > wg ? fwd : wg) : (dgrad > wg ? dgrad : wg);
+    return (m + 1) / 2 + 64;
+}
+size_t ttmi_joint_ws_floats_prec(int B, int T, int U1, int J, int V, int prec) {
+    return ttmi_joint_ws_floats(B, T, U1, J, V) + (prec == 2 ? 64 + joint_x3_floats(B, T, U1, J, V) : 0);
+}
+
 // rowsum != nullptr: the "exp store" form of the fused joint + loss fast path (logits become exp(z - *shift), see ttmi_joint_fwd_exp)
 static int joint_fwd_impl(const float* enc, const float* dec, const float* wf, const float* bf, const float* wp, const float* bp,
                           int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx, float* ws, void* logits, long ldv,
@@ -1109,7 +1162,13 @@ static int joint_fwd_impl(const float* enc, const float* dec, const float* wf, c
         GemmDesc g = mk(Hh, wp, static_cast<float*>(logits), M, V, J, J, J, ldv, NT_ | GEMM_BIAS, prec);
         g.bias = bp;
         ttmi_probe_begin(0, st);
-        const int rc = ttmi_launch_gemm(g, st);
+        int rc;
+        if (prec == 2 && x3_worth(M, V, J)) {       // bf16x3: the projection in three bf16 terms on the throughput kernel (scratch behind the workspace)
+            NtEpilogue e3;
+            e3.bias = bp;
+            bf16_t* x3 = reinterpret_cast<bf16_t*>(ws + ((ttmi_joint_ws_floats(B, T, U1, J, V) + 63) & ~(size_t)63));
+            rc = x3_nt(Hh, wp, static_cast<float*>(logits), M, V, J, J, J, ldv, e3, x3, st);
+        } else rc = ttmi_launch_gemm(g, st);
         ttmi_probe_end(0, st);
         CK(rc);
         return TTMI_OK;
@@ -1187,8 +1246,14 @@ static int joint_bwd_impl(const void* dlogits, long ldg, const float* enc, const
         const float* dZ = static_cast<const float*>(dlogits);
         float* dH = ws;
         CK(colsum(dZ, ldg, M, V, 1, 1, 0, 0, 0, 0, g_bp, st));
-        CK(wgrad(dZ, Hh, g_wp, V, J, M, ldg, J, J, prec, st));
-        CK(ttmi_launch_gemm(mk(dZ, wp, dH, M, J, V, ldg, J, J, NN_, prec), st));
+        if (prec == 2 && x3_worth(M, V, J)) {
+            bf16_t* x3 = reinterpret_cast<bf16_t*>(ws + ((ttmi_joint_ws_floats(B, T, U1, J, V) + 63) & ~(size_t)63));
+            CK(x3_tn(dZ, Hh, g_wp, V, J, M, ldg, J, J, x3, st));
+            CK(x3_nn(dZ, wp, dH, M, J, V, ldg, J, J, NtEpilogue(), x3, st));
+        } else {
+            CK(wgrad(dZ, Hh, g_wp, V, J, M, ldg, J, J, prec, st));
+            CK(ttmi_launch_gemm(mk(dZ, wp, dH, M, J, V, ldg, J, J, NN_, prec), st));
+        }
         CK(fill_zero(dPD, sizeof(float) * (size_t)B * U1 * J, st));
         CK(joint_tanh_bwd(dH, Hh, 0, B, T, U1, J, dPE, dPD, st));
     } else {

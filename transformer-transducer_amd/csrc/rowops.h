@@ -83,6 +83,11 @@ int bf16_residual_f32(const float* src, float* r, long n, hipStream_t st);
 // dst[c, r] (bf16, pitch ldd >= R, columns [R, ldd) zero) = src[r, c] (f32, [R, C] dense)
 // plain (optional): also the untransposed bf16 copy [R, C] (forward passes get both from one read of the weight)
 int transpose_convert_bf16(const float* src, int R, int C, bf16_t* dst, long ldd, hipStream_t st, bf16_t* plain = nullptr);
+// bf16x3 mode: src f32 [R, C] (pitch ld) -> dst bf16 [R, 3 Cp] as blocks [hi | lo | hi] (mode 0: the A-like operand) or [hi | hi | lo]
+// (mode 1: the B-like operand), or [R, 2 Cp] as [hi | lo] (mode 2: the planes of a TN product); columns [C, Cp) of every block zero;
+// and the three-block forms of the transpose (dst [C, 3 Rp])
+int split3_bf16(const float* src, long ld, long R, int C, int Cp, int mode, bf16_t* dst, hipStream_t st);
+int split3_transpose_bf16(const float* src, long ld, int R, int C, int Rp, bool hhl, bf16_t* dst, hipStream_t st);
 // one launch rebuilding the plain + transposed bf16 copies of every weight in `table` (device, n rows of 8 longs, see rowops.hip)
 int shadow_refresh(const long* table, int n, long total_tiles, hipStream_t st);
 // out[c] += sum_r in[r*ld + c] for a bf16 matrix (atomic; caller zeroes / accumulates)

@@ -1041,6 +1041,63 @@ __global__ void bf16_residual_f32_kernel(const float* __restrict__ src, float* _
     if (i < n) r[i] = src[i] - bf16_to_f32(f32_to_bf16(src[i]));
 }
 
+// ---- TTMI_PRECISION=bf16x3 (round 5): an f32 operand as THREE bf16 blocks along its reduction dimension.  With x = hi + lo + O(2^-17 |x|)
+// (hi = bf16(x), lo = bf16(x - hi)), A . B^T ~ A_hi B_hi + A_lo B_hi + A_hi B_lo: the "A-like" operand is laid out [hi | lo | hi], the "B-like"
+// one [hi | hi | lo], and ONE bf16 MFMA GEMM over the tripled reduction gives the product to ~2^-16 relative per term (the dropped lo . lo term),
+// at three sixteenths of the exact-f32 MFMA's cycles.  dst [R, 3 Cp] bf16, block b of row r at dst[r * 3 Cp + b * Cp ...], columns [C, Cp) zero.
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, long ld, long R, int C, int Cp, int hhl,
+                                                     bf16_t* __restrict__ dst) {
+    const long q4 = Cp >> 2, n = R * q4;
+    const bool vec = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+        const long r = idx / q4;
+        const int c = (int)(idx - r * q4) * 4;
+        float x[4];
+        const float* sp = src + r * ld + c;
+        if (vec && c + 3 < C) {
+            const float4 v = *reinterpret_cast<const float4*>(sp);
+            x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] = c + i < C ? sp[i] : 0.f;
+        }
+        uint2 hi, lo;
+        hi.x = pack_bf16x2(x[0], x[1]);
+        hi.y = pack_bf16x2(x[2], x[3]);
+        lo.x = pack_bf16x2(x[0] - __uint_as_float(hi.x << 16), x[1] - __uint_as_float(hi.x & 0xffff0000u));
+        lo.y = pack_bf16x2(x[2] - __uint_as_float(hi.y << 16), x[3] - __uint_as_float(hi.y & 0xffff0000u));
+        bf16_t* d = dst + r * (hhl == 2 ? 2 : 3) * Cp + c;
+        *reinterpret_cast<uint2*>(d) = hi;
+        *reinterpret_cast<uint2*>(d + Cp) = hhl == 1 ? hi : lo;
+        if (hhl != 2) *reinterpret_cast<uint2*>(d + 2 * Cp) = hhl ? lo : hi;     // (mode 2: two blocks [hi | lo], the planes of a TN product)
+    }
+}
+// the same of the TRANSPOSE: src f32 [R, C] (pitch ld) -> dst [C, 3 Rp], dst[c * 3 Rp + b * Rp + r], rows r in [R, Rp) zero (weights only: small)
+__global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __restrict__ src, long ld, int R, int C, int Rp, int hhl,
+                                                               bf16_t* __restrict__ dst) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        tile[ty + 8 * k][tx] = (r < R && c < C) ? src[(long)r * ld + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (c < C && r < Rp) {
+            const float x = tile[tx][ty + 8 * k];
+            const bf16_t hi = f32_to_bf16(x), lo = f32_to_bf16(x - bf16_to_f32(hi));
+            bf16_t* d = dst + (long)c * 3 * Rp + r;
+            d[0] = hi;
+            d[Rp] = hhl ? hi : lo;
+            d[2 * Rp] = hhl ? lo : hi;
+        }
+    }
+}
+
 __global__ void convert_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i + 3 < n) {
@@ -1610,6 +1667,21 @@ int convert_bf16(const float* src, bf16_t* dst, long n, hipStream_t st) {
     TTMI_REQUIRE(src && dst && n > 0 && aligned16(src) && (reinterpret_cast<uintptr_t>(dst) & 7) == 0, "convert_bf16: bad arguments");
     hipLaunchKernelGGL(convert_bf16_kernel, dim3(cdiv((n + 3) / 4, 256)), dim3(256), 0, st, src, dst, n);
     TTMI_LAUNCH_CHECK("convert_bf16_kernel");
+    return TTMI_OK;
+}
+
+int split3_bf16(const float* src, long ld, long R, int C, int Cp, int hhl, bf16_t* dst, hipStream_t st) {
+    TTMI_REQUIRE(src && dst && R > 0 && C > 0 && Cp >= C && Cp % 8 == 0 && ld >= C && aligned16(dst), "split3_bf16: bad arguments");
+    long nb = (R * (Cp / 4) + 255) / 256;
+    if (nb > 65536) nb = 65536;
+    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)nb), dim3(256), 0, st, src, ld, R, C, Cp, hhl, dst);
+    TTMI_LAUNCH_CHECK("split3_kernel");
+    return TTMI_OK;
+}
+int split3_transpose_bf16(const float* src, long ld, int R, int C, int Rp, bool hhl, bf16_t* dst, hipStream_t st) {
+    TTMI_REQUIRE(src && dst && R > 0 && C > 0 && Rp >= R && Rp % 8 == 0 && ld >= C && aligned16(dst), "split3_transpose_bf16: bad arguments");
+    hipLaunchKernelGGL(split3_transpose_kernel, dim3(cdiv(C, 32), cdiv(Rp, 32)), dim3(256), 0, st, src, ld, R, C, Rp, hhl ? 1 : 0, dst);
+    TTMI_LAUNCH_CHECK("split3_transpose_kernel");
     return TTMI_OK;
 }
 

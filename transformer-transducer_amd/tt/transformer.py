@@ -16,8 +16,11 @@ from ttmi.ops import MaskSpec
 
 
 def default_precision():
-    """0 = exact-f32 MFMA (parity path), 1 = bf16 MFMA with f32 accumulate (throughput path)."""
-    return 1 if os.environ.get("TTMI_PRECISION", "fp32").lower() in ("bf16", "1") else 0
+    """0 = exact-f32 MFMA (parity path), 1 = bf16 MFMA with f32 accumulate (throughput path), 2 = bf16x3: the parity path's f32 data flow
+    with its large dense products on the bf16 MFMA in three terms (hi . hi + lo . hi + hi . lo: ~2^-16 relative per product - the quick parity
+    mode; read per call from TTMI_PRECISION = fp32 | bf16 | bf16x3)."""
+    v = os.environ.get("TTMI_PRECISION", "fp32").lower()
+    return 1 if v in ("bf16", "1") else (2 if v in ("bf16x3", "2") else 0)
 
 
 _mask_cache = {}     # id(mask tensor) -> (weakref, version, MaskSpec): every layer of a stack gets the same mask tensor

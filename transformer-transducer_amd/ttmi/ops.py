@@ -431,9 +431,9 @@ def joint_fwd(enc, dec, wf, bf, wp, bp, prec):
     J, V = wf.shape[0], wp.shape[0]
     L_ = lib()
     L_.ttmi_joint_ctx_floats.restype = ctypes.c_size_t
-    L_.ttmi_joint_ws_floats.restype = ctypes.c_size_t
+    L_.ttmi_joint_ws_floats_prec.restype = ctypes.c_size_t
     ctx = _f32(L_.ttmi_joint_ctx_floats(c_int(B), c_int(T), c_int(U1), c_int(J)), enc.device)
-    ws = scratch(L_.ttmi_joint_ws_floats(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(V)), enc.device)
+    ws = scratch(L_.ttmi_joint_ws_floats_prec(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(V), c_int(prec)), enc.device)
     dt = joint_logits_dtype(prec, J)
     if dt is torch.bfloat16:
         buf, logits = padded_empty((B, T, U1, V), dt, enc.device)
@@ -453,8 +453,8 @@ def joint_bwd(dlogits, enc, dec, wf, wp, ctx, prec, grads, out=None):
     U1, dd = dec.shape[1], dec.shape[2]
     J, V = wf.shape[0], wp.shape[0]
     L_ = lib()
-    L_.ttmi_joint_ws_floats.restype = ctypes.c_size_t
-    ws = scratch(L_.ttmi_joint_ws_floats(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(V)), enc.device)
+    L_.ttmi_joint_ws_floats_prec.restype = ctypes.c_size_t
+    ws = scratch(L_.ttmi_joint_ws_floats_prec(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(V), c_int(prec)), enc.device)
     dt = joint_logits_dtype(prec, J)
     ldg = row_pitch(dlogits)
     if dt is torch.bfloat16:
@@ -499,9 +499,9 @@ def joint_fwd_exp(enc, dec, wf, bf, wp, bp, prec, shift=None, labels=None, blank
     J, V = wf.shape[0], wp.shape[0]
     L_ = lib()
     L_.ttmi_joint_ctx_floats.restype = ctypes.c_size_t
-    L_.ttmi_joint_ws_floats.restype = ctypes.c_size_t
+    L_.ttmi_joint_ws_floats_prec.restype = ctypes.c_size_t
     ctx = _f32(L_.ttmi_joint_ctx_floats(c_int(B), c_int(T), c_int(U1), c_int(J)), enc.device)
-    ws = scratch(L_.ttmi_joint_ws_floats(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(V)), enc.device)
+    ws = scratch(L_.ttmi_joint_ws_floats_prec(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(V), c_int(prec)), enc.device)
     # room for the lattice rows padded to the wgrad's 64-row reduction tile (ttmi_joint_bwd_exp zero-fills the pad rows: include/ttmi.h)
     rows, ldv = B * T * U1, (V + 63) // 64 * 64
     rows_p = exp_padded_rows(B, T, U1)
