@@ -409,10 +409,19 @@ size_t ttmi_attn_ctx_floats(int B, int L, int d, int H, int Dh, int prec) {
     AttnCtx c(b, AttnDims(B, L, d, H, Dh, 1), attn_fast(prec, d, H, Dh));
     return b.floats();
 }
+// bf16x3 (prec 2): scratch of the sub-layer's dense products in three bf16 terms, behind the ordinary workspace (one product at a time)
+static size_t attn_x3_floats(const AttnDims& a) {
+    size_t m = x3_nt_elems(a.BL, a.W3, a.d);
+    const size_t c[] = {x3_nt_elems(a.BL, a.d, (int)a.HD), x3_tn_elems(a.BL, a.d, (int)a.HD), x3_nt_elems(a.BL, a.HD, a.d),
+                        x3_tn_elems(a.BL, (int)a.W3, a.d), x3_nt_elems(a.BL, a.d, (int)a.W3)};
+    for (size_t v : c) m = v > m ? v : m;
+    return (m + 1) / 2 + 128;
+}
 size_t ttmi_attn_ws_floats(int B, int L, int d, int H, int Dh, int prec) {
     Bump b(nullptr);
-    AttnWs w(b, AttnDims(B, L, d, H, Dh, 1), attn_fast(prec, d, H, Dh));
-    return b.floats();
+    const AttnDims a(B, L, d, H, Dh, 1);
+    AttnWs w(b, a, attn_fast(prec, d, H, Dh));
+    return b.floats() + (prec == 2 ? 64 + attn_x3_floats(a) : 0);
 }
 
 // RelLearnableMultiHeadAttn.forward (tt/transformer.py:106-177), batch-major: x,y f32 [B,L,d].
@@ -438,6 +447,7 @@ static int attn_fwd_impl(const float* x, const float* qkv_w, const float* o_w, c
     Bump bc(ctx), bw(ws);
     AttnCtx c(bc, a, fast);
     AttnWs w(bw, a, fast);
+    bf16_t* x3 = prec == 2 ? reinterpret_cast<bf16_t*>(ws + ((bw.floats() + 63) & ~(size_t)63)) : nullptr;     // bf16x3: split operands of the dense products
     const float scale = 1.0f / sqrtf((float)Dh);
     // 1. qkv = x Wqkv^T ; 2. qu = q + r_w_bias
     TTMI_REQUIRE(!x16_in || (fast && aligned16(x16_in)), "attn_fwd: a bf16 copy of x is taken by the bf16 pipeline only (16-byte aligned)");
@@ -459,7 +469,8 @@ static int attn_fwd_impl(const float* x, const float* qkv_w, const float* o_w, c
         if (!attn_inkernel(fast, a))
             CK(add_row_bias_bf16(static_cast<bf16_t*>(c.qkv), a.W3, r_w_bias, a.BL, (int)a.HD, static_cast<bf16_t*>(c.qu), a.HD, st));
     } else {
-        CK(ttmi_launch_gemm(mk(x, qkv_w, static_cast<float*>(c.qkv), (int)a.BL, (int)a.W3, d, d, d, a.W3, NT_, prec), st));
+        if (x3 && x3_worth(a.BL, a.W3, d)) CK(x3_nt(x, qkv_w, static_cast<float*>(c.qkv), (int)a.BL, (int)a.W3, d, d, d, a.W3, NtEpilogue(), x3, st));
+        else CK(ttmi_launch_gemm(mk(x, qkv_w, static_cast<float*>(c.qkv), (int)a.BL, (int)a.W3, d, d, d, a.W3, NT_, prec), st));
         CK(add_row_bias(static_cast<float*>(c.qkv), a.W3, r_w_bias, a.BL, (int)a.HD, static_cast<float*>(c.qu), a.HD, st));
     }
     // 3. effective tables for this length (clamped rows when L > K); the fused kernels' bf16 copy comes out of the same launch
@@ -527,6 +538,8 @@ static int attn_fwd_impl(const float* x, const float* qkv_w, const float* o_w, c
             eo.B_lo = w.wo16;
         }
         CK(gemm_nt_bf16(static_cast<bf16_t*>(c.O), wo16, w.a, 0, eo, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, st));
+    } else if (x3 && x3_worth(a.BL, d, a.HD)) {
+        CK(x3_nt(static_cast<float*>(c.O), o_w, w.a, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, NtEpilogue(), x3, st));
     } else {
         CK(ttmi_launch_gemm(mk(static_cast<float*>(c.O), o_w, w.a, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, NT_, prec), st));
     }
@@ -561,6 +574,7 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
     Bump bc(const_cast<float*>(ctx)), bw(ws);
     AttnCtx c(bc, a, fast);
     AttnWs w(bw, a, fast, keep);
+    bf16_t* x3 = prec == 2 ? reinterpret_cast<bf16_t*>(ws + ((bw.floats() + 63) & ~(size_t)63)) : nullptr;
     TTMI_REQUIRE(!out || (fast && keep && aligned16(keep)), "attn_bwd_defer: bf16 pipeline and a 16-byte aligned keep buffer required");
     const float scale = 1.0f / sqrtf((float)Dh);
     // 1. dres = LN'(dy) -> dx (doubles as the residual gradient)
@@ -588,6 +602,9 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
         if (out) out[0] = ttmi_wgrad_desc{w.dres16, c.O, g_o_w, nullptr, d, (int)a.HD, (int)a.BL, (long)d, (long)a.HD, (long)a.HD};
         else CK(gemm_tn_bf16(w.dres16, static_cast<bf16_t*>(c.O), g_o_w, d, (int)a.HD, (int)a.BL, d, a.HD, a.HD, 1, fork_stream(st)));
         CK(gemm_nt_bf16(w.dres16, woT16, w.dO, 1, nullptr, (int)a.BL, (int)a.HD, d, d, d, a.HD, st));
+    } else if (x3 && x3_worth(a.BL, a.HD, d)) {
+        CK(x3_tn(da, static_cast<float*>(c.O), g_o_w, d, (int)a.HD, a.BL, d, a.HD, a.HD, x3, st));
+        CK(x3_nn(da, o_w, static_cast<float*>(w.dO), (int)a.BL, (int)a.HD, d, d, a.HD, a.HD, NtEpilogue(), x3, st));
     } else {
         CK(wgrad(da, static_cast<float*>(c.O), g_o_w, d, (int)a.HD, (int)a.BL, d, a.HD, a.HD, prec, st));
         CK(ttmi_launch_gemm(mk(da, o_w, static_cast<float*>(w.dO), (int)a.BL, (int)a.HD, d, d, a.HD, a.HD, NN_, prec), st));
@@ -759,6 +776,11 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
         CK(rc);
         CK(gemm_nt_bf16(w.dqkv16, wqkvT16, dx, 0, e, (int)a.BL, d, (int)a.W3, a.W3, a.W3, d, st));
         ctx_forget(ctx);
+    } else if (x3 && x3_worth(a.BL, d, a.W3)) {
+        CK(x3_tn(w.dqkv, x, g_qkv_w, (int)a.W3, d, a.BL, a.W3, d, d, x3, st));
+        NtEpilogue ea;
+        ea.addend = dx;                                           // dx += dqkv Wqkv (dx holds the residual-branch gradient)
+        CK(x3_nn(w.dqkv, qkv_w, dx, (int)a.BL, d, (int)a.W3, a.W3, d, d, ea, x3, st));
     } else {
         CK(wgrad(w.dqkv, x, g_qkv_w, (int)a.W3, d, (int)a.BL, a.W3, d, d, prec, st));
         GemmDesc g = mk(w.dqkv, qkv_w, dx, (int)a.BL, d, (int)a.W3, a.W3, d, d, NN_, prec);
@@ -841,10 +863,16 @@ size_t ttmi_ffn_ctx_floats(long rows, int d, int Di, int prec) {
     FfnCtx c(b, rows, d, Di, ffn_fast(prec, d, Di));
     return b.floats();
 }
+static size_t ffn_x3_floats(long rows, int d, int Di) {
+    size_t m = x3_nt_elems(rows, Di, d);
+    const size_t c[] = {x3_nt_elems(rows, d, Di), x3_tn_elems(rows, d, Di), x3_tn_elems(rows, Di, d)};
+    for (size_t v : c) m = v > m ? v : m;
+    return (m + 1) / 2 + 128;
+}
 size_t ttmi_ffn_ws_floats(long rows, int d, int Di, int prec) {
     Bump b(nullptr);
     FfnWs w(b, rows, d, Di, ffn_fast(prec, d, Di));
-    return b.floats();
+    return b.floats() + (prec == 2 ? 64 + ffn_x3_floats(rows, d, Di) : 0);
 }
 
 // z = LN(y + W2 relu(W1 LN(y) + b1) + b2), the SAME (ln_g, ln_b) in both norms.
@@ -894,12 +922,21 @@ static int ffn_fwd_impl(const float* y, const float* w1, const float* b1, const 
         float* h = static_cast<float*>(c.h);
         float* a1 = static_cast<float*>(c.a1);
         CK(ln_fwd(y, nullptr, ln_g, ln_b, rows, d, 1e-5f, nullptr, h, c.mean1, c.rstd1, st));
+        bf16_t* x3 = prec == 2 ? reinterpret_cast<bf16_t*>(ws + ((bw.floats() + 63) & ~(size_t)63)) : nullptr;
+        if (x3 && x3_worth(rows, Di, d)) {
+            NtEpilogue e1, e2;
+            e1.bias = b1; e1.relu = 1; e1.drop = d_in;
+            e2.bias = b2;
+            CK(x3_nt(h, w1, a1, (int)rows, Di, d, d, d, Di, e1, x3, st));
+            CK(x3_nt(a1, w2, w.f, (int)rows, d, Di, Di, Di, d, e2, x3, st));
+        } else {
         GemmDesc g = mk(h, w1, a1, (int)rows, Di, d, d, d, Di, NT_ | GEMM_BIAS | GEMM_RELU, prec);
         g.bias = b1; g.drop = d_in;
         CK(ttmi_launch_gemm(g, st));
         GemmDesc g2 = mk(a1, w2, w.f, (int)rows, d, Di, Di, Di, d, NT_ | GEMM_BIAS, prec);
         g2.bias = b2;
         CK(ttmi_launch_gemm(g2, st));
+        }
     }
     CK(ln_fwd(y, w.f, ln_g, ln_b, rows, d, 1e-5f, c.s2, z, c.mean2, c.rstd2, st, z16_out, d_out, d_layer));
     return TTMI_OK;
@@ -961,6 +998,15 @@ static int ffn_bwd_impl(const float* dz, const float* y, const float* w1, const 
         const float* a1 = static_cast<const float*>(c.a1);
         const float* h = static_cast<const float*>(c.h);
         float* da1 = static_cast<float*>(w.da1);
+        bf16_t* x3 = prec == 2 ? reinterpret_cast<bf16_t*>(ws + ((bw.floats() + 63) & ~(size_t)63)) : nullptr;
+        if (x3 && x3_worth(rows, Di, d)) {
+            CK(x3_tn(df, a1, g_w2, d, Di, rows, d, Di, Di, x3, st));
+            CK(x3_nn(df, w2, da1, (int)rows, Di, d, d, Di, Di, NtEpilogue(), x3, st));
+            CK(relu_mask_scale(da1, a1, rows * Di, inv_keep, st));           // the ReLU' (and dropout) mask of the exact-f32 path's epilogue: da1 = a1 > 0 ? da1 / keep : 0
+            CK(colsum(da1, Di, rows, Di, 1, 1, 0, 0, 0, 0, g_b1, st));
+            CK(x3_tn(da1, h, g_w1, Di, d, rows, Di, d, d, x3, st));
+            CK(x3_nn(da1, w1, w.dh, (int)rows, d, Di, Di, d, d, NtEpilogue(), x3, st));
+        } else {
         CK(wgrad(df, a1, g_w2, d, Di, (int)rows, d, Di, Di, prec, st));
         GemmDesc g = mk(df, w2, da1, (int)rows, Di, d, d, Di, Di, NN_ | GEMM_MASK_AUX, prec);
         g.aux = a1; g.alpha = inv_keep;
@@ -968,6 +1014,7 @@ static int ffn_bwd_impl(const float* dz, const float* y, const float* w1, const 
         CK(colsum(da1, Di, rows, Di, 1, 1, 0, 0, 0, 0, g_b1, st));
         CK(wgrad(da1, h, g_w1, Di, d, (int)rows, Di, d, d, prec, st));
         CK(ttmi_launch_gemm(mk(da1, w1, w.dh, (int)rows, d, Di, Di, d, d, NN_, prec), st));
+        }
     }
     // (skip_pre_norm: the layer-level call - w.dh and w.dres stay in the workspace for the attention sub-layer's paired LayerNorm backward)
     if (!skip_pre_norm) CK(ln_bwd(w.dh, y, c.mean1, c.rstd1, ln_g, w.dres, rows, d, dy, g_ln_g, g_ln_b, st));
@@ -1097,9 +1144,9 @@ size_t ttmi_joint_ws_floats(int B, int T, int U1, int J, int V) {
 // scratch of the bf16x3 products behind the ordinary joint workspace (prec 2): the backward's two big ones use it one after the other
 static size_t joint_x3_floats(int B, int T, int U1, int J, int V) {
     const long M = (long)B * T * U1;
-    const size_t fwd = x3_nt_elems(M, V, J), dgrad = x3_nt_elems(M, J, V), wg = x3_tn_elems(M, V, J);
-    const size_t m = fwd > dgrad ? (fwd > wg ? fwd : wg) : (dgrad > wg ? dgrad : wg);
-    return (m + 1) / 2 + 64;
+    const size_t fwd = x3_nt_elems(M, V, J);
+    const size_t bwd = x3_al((size_t)M * 3 * x3_pad(V)) + x3_al((size_t)M * 2 * x3_pad(J)) + x3_al((size_t)J * 3 * x3_pad(V));   // Z3 + H2 + WT3 (joint_bwd_impl)
+    return ((fwd > bwd ? fwd : bwd) + 1) / 2 + 64;
 }
 size_t ttmi_joint_ws_floats_prec(int B, int T, int U1, int J, int V, int prec) {
     return ttmi_joint_ws_floats(B, T, U1, J, V) + (prec == 2 ? 64 + joint_x3_floats(B, T, U1, J, V) : 0);
@@ -1245,12 +1292,23 @@ static int joint_bwd_impl(const void* dlogits, long ldg, const float* enc, const
         const float* Hh = ctx;
         const float* dZ = static_cast<const float*>(dlogits);
         float* dH = ws;
-        CK(colsum(dZ, ldg, M, V, 1, 1, 0, 0, 0, 0, g_bp, st));
         if (prec == 2 && x3_worth(M, V, J)) {
+            // bf16x3: ONE three-block split of dZ ([hi | lo | hi], 14 GB read once at C2) serves the dgrad (the tripled reduction) and, as its
+            // first two blocks, the wgrad's planes; g_bp = column sums of dZ ride in the wgrad launches (hi + lo: dZ to 2^-17 per element)
             bf16_t* x3 = reinterpret_cast<bf16_t*>(ws + ((ttmi_joint_ws_floats(B, T, U1, J, V) + 63) & ~(size_t)63));
-            CK(x3_tn(dZ, Hh, g_wp, V, J, M, ldg, J, J, x3, st));
-            CK(x3_nn(dZ, wp, dH, M, J, V, ldg, J, J, NtEpilogue(), x3, st));
+            const int Vp = x3_pad(V), Jp = x3_pad(J);
+            bf16_t* Z3 = x3;
+            bf16_t* H2 = Z3 + x3_al((size_t)M * 3 * Vp);
+            bf16_t* WT3 = H2 + x3_al((size_t)M * 2 * Jp);
+            CK(split3_bf16(dZ, ldg, M, V, Vp, 0, Z3, st));
+            CK(split3_bf16(Hh, J, M, J, Jp, 2, H2, st));
+            CK(split3_transpose_bf16(wp, J, V, J, Vp, true, WT3, st));
+            CK(gemm_tn_bf16(Z3, H2, g_wp, V, J, M, 3L * Vp, 2L * Jp, J, 1, st, g_bp));
+            CK(gemm_tn_bf16(Z3 + Vp, H2, g_wp, V, J, M, 3L * Vp, 2L * Jp, J, 1, st, g_bp));
+            CK(gemm_tn_bf16(Z3, H2 + Jp, g_wp, V, J, M, 3L * Vp, 2L * Jp, J, 1, st));
+            CK(gemm_nt_bf16(Z3, WT3, dH, 0, NtEpilogue(), M, J, 3 * Vp, 3L * Vp, 3L * Vp, J, st));
         } else {
+            CK(colsum(dZ, ldg, M, V, 1, 1, 0, 0, 0, 0, g_bp, st));
             CK(wgrad(dZ, Hh, g_wp, V, J, M, ldg, J, J, prec, st));
             CK(ttmi_launch_gemm(mk(dZ, wp, dH, M, J, V, ldg, J, J, NN_, prec), st));
         }

@@ -87,6 +87,7 @@ int transpose_convert_bf16(const float* src, int R, int C, bf16_t* dst, long ldd
 // (mode 1: the B-like operand), or [R, 2 Cp] as [hi | lo] (mode 2: the planes of a TN product); columns [C, Cp) of every block zero;
 // and the three-block forms of the transpose (dst [C, 3 Rp])
 int split3_bf16(const float* src, long ld, long R, int C, int Cp, int mode, bf16_t* dst, hipStream_t st);
+int relu_mask_scale(float* g, const float* a, long n, float scale, hipStream_t st);
 int split3_transpose_bf16(const float* src, long ld, int R, int C, int Rp, bool hhl, bf16_t* dst, hipStream_t st);
 // one launch rebuilding the plain + transposed bf16 copies of every weight in `table` (device, n rows of 8 longs, see rowops.hip)
 int shadow_refresh(const long* table, int n, long total_tiles, hipStream_t st);

@@ -1670,6 +1670,19 @@ int convert_bf16(const float* src, bf16_t* dst, long n, hipStream_t st) {
     return TTMI_OK;
 }
 
+__global__ __launch_bounds__(256) void relu_mask_scale_kernel(float* __restrict__ g, const float* __restrict__ a, long n, float scale) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) g[i] = a[i] > 0.f ? g[i] * scale : 0.f;
+}
+// g[i] = a[i] > 0 ? g[i] * scale : 0 (the generic f32 GEMM's GEMM_MASK_AUX epilogue as a pass of its own: bf16x3 mode's FFN dgrad)
+int relu_mask_scale(float* g, const float* a, long n, float scale, hipStream_t st) {
+    TTMI_REQUIRE(g && a && n > 0, "relu_mask_scale: bad arguments");
+    long nb = (n + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(relu_mask_scale_kernel, dim3((unsigned)nb), dim3(256), 0, st, g, a, n, scale);
+    TTMI_LAUNCH_CHECK("relu_mask_scale_kernel");
+    return TTMI_OK;
+}
+
 int split3_bf16(const float* src, long ld, long R, int C, int Cp, int hhl, bf16_t* dst, hipStream_t st) {
     TTMI_REQUIRE(src && dst && R > 0 && C > 0 && Cp >= C && Cp % 8 == 0 && ld >= C && aligned16(dst), "split3_bf16: bad arguments");
     long nb = (R * (Cp / 4) + 255) / 256;
