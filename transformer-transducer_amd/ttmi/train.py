@@ -133,13 +133,18 @@ class GradSync:
     reduced asynchronously the moment all of its parameters have accumulated.  xGMI is a point-to-point mesh,
     so few large messages beat many small ones: default 32 MB buckets -> ~6 calls for the 193 MB payload."""
 
-    def __init__(self, flat, bucket_mb=32, group=None, tail_mb=None, tail_buckets=2, always_reduce=False, broadcast=True):
+    def __init__(self, flat, bucket_mb=32, group=None, tail_mb=None, tail_buckets=2, always_reduce=False, broadcast=True, auto_finish=False):
         """tail_mb: size of the first `tail_buckets` buckets (the parameters whose gradients arrive LAST - audio-encoder layer 0 first in
         parameter order): the all-reduce of the bucket that completes last cannot overlap anything, so it is kept small (default
         bucket_mb / 4).  broadcast (world > 1): rank 0's parameters are broadcast to every rank and the replicas' bit patterns are
         compared before the first step ("same seed OR rank-0 broadcast" - nn.DataParallel re-broadcasts every step,
-        train.py:214-219; here once, and again on request after a checkpoint was loaded on one rank: `broadcast_parameters()`)."""
+        train.py:214-219; here once, and again on request after a checkpoint was loaded on one rank: `broadcast_parameters()`).
+        auto_finish: for loops that cannot call `finish()` themselves (the reference's own `train()`, train.py:51-65, driven by
+        ttmi.dp_train): the first gradient of a step queues an end-of-backward callback (autograd's queue_callback, as DDP does) that
+        waits for the reductions and turns the SUMS into MEANS in place, so that whatever follows `loss.backward()` -
+        `clip_grad_norm_(model.parameters(), ...)`, then `optimizer.step()` with world = 1 - sees the global-batch gradient."""
         self.flat, self.group = flat, group
+        self.auto_finish, self._queued, self.finished = auto_finish, False, False
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.buckets, self.bucket_of = [], {}
         tail_mb = bucket_mb / 4.0 if tail_mb is None else tail_mb
@@ -217,6 +222,9 @@ class GradSync:
             if self.seen[i]:                # a parameter reports once per step, whichever path (in-place / autograd) is first
                 return
             self.seen[i] = True
+            if self.auto_finish and not self._queued:
+                self._queued = True
+                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
             b = self.bucket_of[i]
             self.pending[b] += 1
             if self.cuda:
@@ -239,7 +247,15 @@ class GradSync:
                     cur.wait_stream(st)
         self.works.append(dist.all_reduce(self.flat.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    def _end_of_backward(self):
+        """auto_finish: runs when the backward pass that fired the first hook completes"""
+        self.finish()
+        if self.world > 1:
+            self.flat.grad.mul_(1.0 / self.world)      # SUM -> mean over the ranks (each rank's loss is its local-batch mean)
+        self.finished = True
+
     def start_step(self):
+        self._queued, self.finished = False, False
         self.pending = [0] * len(self.buckets)
         self.seen = [False] * len(self.flat.params)
         self.writers = [set() for _ in self.buckets]
