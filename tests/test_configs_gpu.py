@@ -197,11 +197,18 @@ def test_c2_full_model_fp32_end_to_end(monkeypatch, mode):
     torch.manual_seed(1)
     model = Transducer(cfg).cuda().eval()
     assert sum(p.numel() for p in model.parameters()) == 48222862
-    B, T, U, V = 2, 500, 50, 4334
+    _end_to_end_vs_oracle(monkeypatch, model, mode, 2, 500, 50, 4334, [500, 431], [50, 37], 12, 6, None)
+
+
+def _end_to_end_vs_oracle(monkeypatch, model, mode, B, T, U, V, tl, ul, n_enc, n_dec, audio_mask):
+    """logits, loss, input gradient and every parameter gradient of `model` (already in the wanted TTMI_PRECISION) against the float64 oracle,
+    the oracle fed the ReLU decisions the HIP path took (see test_c2_full_model_fp32_end_to_end)"""
+    from ttmi import ops
+    from warprnnt_pytorch import RNNTLoss
     gen = torch.Generator().manual_seed(1234)
     inp = torch.randn(B, T, 512, generator=gen)
     tgt = torch.randint(1, V, (B, U), generator=gen)
-    tl, ul = np.array([T, 431], dtype=np.int32), np.array([U, 37], dtype=np.int32)
+    tl, ul = np.array(tl, dtype=np.int32), np.array(ul, dtype=np.int32)
     saved = []                                               # (FFN ctx, rows, d, Di) of every layer's forward, in host issue order
     real_layer_fwd = ops.layer_fwd
 
@@ -219,13 +226,13 @@ def test_c2_full_model_fp32_end_to_end(monkeypatch, mode):
     torch.cuda.synchronize()
     sd64 = {k: (v.detach().cpu().numpy().astype(np.float64) if v.dtype == torch.float32 else v.detach().cpu().numpy())
             for k, v in model.state_dict().items()}
-    assert len(saved) == 18                                  # 12 audio layers (queued first), then 6 label layers
+    assert len(saved) == n_enc + n_dec                       # the audio layers (queued first), then the label layers
     for n, (ctx, rows, d, Di, lead) in enumerate(saved):
         off = (rows * d * 4 + 255) // 256 * 256 // 4        # FfnCtx (csrc/layers.hip): h [rows, d] f32, then a1 [rows, Di] f32, 256-byte aligned
         a1 = ctx[off:off + rows * Di].view(*lead, Di)
-        key = ("encoder.layers.%d" % n) if n < 12 else ("decoder.layers.%d" % (n - 12))
+        key = ("encoder.layers.%d" % n) if n < n_enc else ("decoder.layers.%d" % (n - n_enc))
         sd64[key + ".relu_active"] = (a1 > 0).cpu().numpy()
-    own = O.transducer_fwd(inp.numpy().astype(np.float64), tgt.numpy(), {k: v for k, v in sd64.items() if not k.endswith("relu_active")})[1]
+    own = O.transducer_fwd(inp.numpy().astype(np.float64), tgt.numpy(), {k: v for k, v in sd64.items() if not k.endswith("relu_active")}, audio_mask)[1]
     flips = 0
     for i, (ca, cf) in enumerate(own[0]):                    # the oracle's own decisions differ from the HIP path's only on near-zero units
         diff = cf["relu_on"] != sd64["encoder.layers.%d.relu_active" % i]
@@ -234,7 +241,7 @@ def test_c2_full_model_fp32_end_to_end(monkeypatch, mode):
             z1 = np.abs((cf["h"] @ sd64["encoder.layers.%d.MultiHeadAttention.pos_ff.CoreNet.0.weight" % i].T +
                          sd64["encoder.layers.%d.MultiHeadAttention.pos_ff.CoreNet.0.bias" % i])[diff])
             assert z1.max() < 1e-5, (i, z1.max())
-    want = O.transducer_loss_and_grads(inp.numpy().astype(np.float64), tgt.numpy(), tl, ul, sd64)
+    want = O.transducer_loss_and_grads(inp.numpy().astype(np.float64), tgt.numpy(), tl, ul, sd64, audio_mask)
     assert rel_err(logits.detach().cpu().numpy(), want["logits"]) < TOL
     assert abs(float(loss.detach()) - want["loss"]) / want["loss"] < TOL
     assert rel_err(x.grad.cpu().numpy(), want["dinputs"]) < TOL
@@ -244,8 +251,31 @@ def test_c2_full_model_fp32_end_to_end(monkeypatch, mode):
         if e > worst[1]:
             worst = (name, e)
         assert e < TOL, (name, e)
-    print("C2 end to end " + mode + ": loss rel %.2e, dinputs %.2e, worst gradient %s %.2e, ReLU units decided differently from float64: %d"
+    print("end to end " + mode + (" (streaming mask)" if audio_mask is not None else "") + ": loss rel %.2e, dinputs %.2e, worst gradient %s %.2e, ReLU units decided differently from float64: %d"
           % (abs(float(loss.detach()) - want["loss"]) / want["loss"], rel_err(x.grad.cpu().numpy(), want["dinputs"]), worst[0], worst[1], flips))
+
+
+
+@pytest.mark.parametrize("streaming,mode", [("band", "fp32"), ("chunk", "bf16x3")])
+def test_c4_streaming_model_end_to_end(monkeypatch, streaming, mode):
+    """BASELINE configs[3] model end to end (joint_streaming.yaml: 18 audio / 2 label layers, d_inner 2048, joint 2048, V = 6485; 85.6 M
+    parameters) under its streaming masks - band context_mask(left=64, right=0) and the 16-frame chunk mask with 64 left frames - at B = 2,
+    T = 300, U = 30 against the float64 oracle fed the equivalent mask tensor: logits, loss, input gradient, every parameter gradient
+    (C4 had been covered component-wise only).  The band case runs the exact-f32 mode, the chunk case the bf16x3 mode."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from tt.model import Transducer
+    monkeypatch.setenv("TTMI_PRECISION", mode)
+    cfg = bench.c4_config(streaming)
+    cfg["dropout"] = 0.0
+    torch.manual_seed(1)
+    model = Transducer(cfg).cuda().eval()
+    assert sum(p.numel() for p in model.parameters()) == 85605525
+    T = 300
+    mask = (O.context_mask(T, 64, 0) if streaming == "band" else O.chunk_mask(T, 16, 64))[:, :, None]      # [qlen, klen, 1], tt/transformer.py:154-159
+    _end_to_end_vs_oracle(monkeypatch, model, mode, 2, T, 30, 6485, [T, 251], [30, 22], 18, 2, mask)
 
 
 def test_c2_full_model_bf16_exp_form_end_to_end(monkeypatch):
