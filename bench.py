@@ -595,6 +595,21 @@ def main():
                                                    "logits [%d,%d,%d,%d] %s" % (lf and round(lf, 3), lb and round(lb, 3), B_launch, T, U1, V, "bf16" if es == 2 else "f32"),
                          "achieved": loss_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac(loss_gbs, HBM_PEAK_GBS),
                          "traffic": None, "kernel_ms": None if l_ms is None else round(l_ms, 4)}
+        # HBM-side traffic of the secondary lines' kernels from the committed PMC passes (tools/update_pmc_json.py), valid for the kernel
+        # sources they were measured on and for the default workload
+        pmc2 = os.path.join(ROOT, "profiles", "pmc_secondary_kernels.json")
+        if os.path.exists(pmc2) and args.workload == "c2" and (B, T, U) == (32, 500, 50) and args.precision == "bf16":
+            j2 = json.load(open(pmc2))
+            for line, roof in (("attn", roof_attn), ("loss", roof_loss), ("wgrad", roof_wgrad)):
+                ent = j2.get("lines", {}).get(line) or {}
+                if line == "loss" and j2.get("loss_form") != ran_form:
+                    continue
+                fresh = all(_sha16(os.path.join(ROOT, "transformer-transducer_amd", "csrc", f)) == h for f, h in (ent.get("sources") or {}).items())
+                if ent.get("traffic") is not None and fresh:
+                    roof["traffic"] = ent["traffic"]
+                    roof["pmc"] = {"measured_at_commit": j2.get("commit"), "source": j2.get("source")}
+                elif ent.get("traffic") is not None:
+                    roof["pmc"] = {"stale": "kernel source changed since the PMC passes: traffic withheld"}
         lattice_run = args.workload == "c5"             # BASELINE configs[4] is the lattice's HBM-roofline run: the loss op is its dominant-kernel line
         out = {
             "metric": "utterances/sec (fwd+bwd) on 80-d fbank T=%d U=%d" % (T, U), "value": round(utt_s, 3), "unit": "utt/s",

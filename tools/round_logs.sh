@@ -8,12 +8,12 @@ python3 bench.py --steps 50 --warmup 10 > $O/${TAG}_bench_c2.log 2>&1 && tail -c
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_bench_c2_20steps.log 2>&1 && echo "driver-form run done"
 # the other BASELINE workloads: sustained figures (10 warm-up + 50 timed steps, median / p10 / p90 in the line) ...
 for w in c4-band c4-chunk c5; do
-  python3 bench.py --workload $w --steps 50 --warmup 10 --no-cpu-baseline --no-fp32-form --no-graph-form > $O/${TAG}_bench_$w.log 2>&1 && echo "$w done"
+  python3 bench.py --workload $w --steps 50 --warmup 10 --no-cpu-baseline --no-fp32-form --no-graph-form --no-sync-form > $O/${TAG}_bench_$w.log 2>&1 && echo "$w done"
 done
 # ... and their kernel statistics / step attribution (one trace per workload)
 for w in c4-band c5; do
   P=$O/prof_${TAG}_$w; rm -rf $P
-  rocprofv3 --kernel-trace --stats --output-format csv -d $P -- python3 bench.py --workload $w --steps 4 --warmup 2 --no-cpu-baseline --no-two-call --no-fp32-form --no-graph-form > $P.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $P -- python3 bench.py --workload $w --steps 4 --warmup 2 --no-cpu-baseline --no-two-call --no-fp32-form --no-graph-form --no-sync-form > $P.log 2>&1
   python3 tools/prof_summary.py $P profiles/${TAG}_bench_${w}_kernel_stats.csv "bench.py --workload $w --steps 4 --warmup 2 (6 steps), $TAG build" > /dev/null
   python3 tools/kernel_exclusive.py $P > profiles/${TAG}_bench_${w}_step_attribution.txt && echo "$w profile done"
 done

@@ -44,3 +44,43 @@ j = {
 }
 json.dump(j, open(os.path.join(ROOT, "profiles", "pmc_joint_projection.json"), "w"), indent=1)
 print(json.dumps(j, indent=1))
+
+
+# ---- the secondary roofline lines of bench.py (roofline_attn / roofline_loss / roofline_wgrad): per-launch HBM-side traffic of their kernels from
+# the same three passes (the counters existed in profiles/ but the bench line said null)
+def kernel_values(d, counter, pattern):
+    out = []
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if pattern in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                out.append(float(r["Counter_Value"]))
+    return out
+
+
+def sha16(rel):
+    return hashlib.sha256(open(os.path.join(ROOT, "transformer-transducer_amd", "csrc", rel), "rb").read()).hexdigest()[:16]
+
+
+def traffic_of(patterns):
+    """sum over the kernels of one line: mean over launches of 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes), None when a kernel did not run"""
+    total, parts = 0.0, {}
+    for pat in patterns:
+        f, w = kernel_values(sys.argv[1], "FETCH_SIZE", pat), kernel_values(sys.argv[2], "WRITE_SIZE", pat)
+        if not f or not w:
+            return None, parts
+        parts[pat] = {"fetch_size_kb": mean(f), "write_size_kb": mean(w), "launches": len(f)}
+        total += (2.0 * mean(f) + mean(w)) * 1024.0
+    return total, parts
+
+
+sec = {"commit": sys.argv[4], "round": sys.argv[5], "loss_form": FORM,
+       "source": "profiles/%s_pmc_joint_kernels.txt (the same three rocprofv3 --pmc passes); traffic = 2 * FETCH_SIZE + WRITE_SIZE per launch, "
+                 "mean over the launches of the profiled steps (audio-sized launches only for the attention kernel: L = 500)" % sys.argv[5],
+       "lines": {}}
+for line, pats, srcs in (("attn", ["flash_bwd_rel2_kernel<0>"], ["attn_flash.hip"]),
+                         ("loss", ["rnnt_prep_exp_kernel", "rnnt_lattice_lds_kernel", "rnnt_scale_exp_kernel"], ["rnnt.hip"]),
+                         ("wgrad", ["gemm_tn_bf16_group_kernel"], ["gemm_fast.hip"])):
+    t, parts = traffic_of(pats)
+    sec["lines"][line] = {"traffic": t, "kernels": parts, "sources": {f: sha16(f) for f in srcs}}
+json.dump(sec, open(os.path.join(ROOT, "profiles", "pmc_secondary_kernels.json"), "w"), indent=1)
+print(json.dumps(sec, indent=1))
