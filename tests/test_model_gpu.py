@@ -345,10 +345,15 @@ def test_sparse_greedy_decode_identical_tokens(name, graphs):
         assert h == g["%s/tokens%d" % (name, b)].tolist(), b
 
 
+@pytest.mark.parametrize("block", [64, 5, 0])
 @pytest.mark.parametrize("name", ["tiny_klong", "tiny_kshort"])
-def test_beam_search_identical_tokens(name):
+def test_beam_search_identical_tokens(name, block, monkeypatch):
     """Transducer.recognize_beam_search (the reference's beam search, tt/model.py:110-198, quirks included) on the HIP model: the token lists
-    of the reference run"""
+    of the reference run - with the device-side form of round 5 (blocks of frames scored against the lead hypothesis' label state, one
+    label-encoder call and one host read per expansion; block = 64 and 5) and with the per-frame restatement of round 2 (block = 0)"""
+    from tt.model import Transducer
+    real = Transducer.beam_search
+    monkeypatch.setattr(Transducer, "beam_search", lambda self, e, l, beam_width=5: real(self, e, l, beam_width=beam_width, block=block))
     import os
     from conftest import GOLDEN
     z, sd = load_golden(name)
