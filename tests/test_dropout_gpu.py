@@ -103,3 +103,57 @@ def test_full_size_layer_on_the_persistent_kernels_matches_oracle(monkeypatch):
     names = {v: k for k, v in O._LAYER_KEYS.items()}
     for n, prm_t in layer.named_parameters():
         assert rel_err(prm_t.grad.cpu().numpy(), g[names[n]]) < 6e-2, n
+
+
+def test_bf16x3_layer_with_dropout_matches_oracle_with_same_masks(monkeypatch):
+    """TTMI_PRECISION=bf16x3 at a size where its dense products take the three-term route (1024 rows, d = 512, Di = 1024: x3_worth in
+    csrc/layers.hip) in TRAINING mode: the FFN's bias + ReLU + dropout epilogue on the tripled-K kernel, the ReLU' / dropout mask of its
+    dgrad as a pass of its own (relu_mask_scale), the residual accumulation of the qkv dgrad - forward, dx and every parameter gradient
+    against the float64 oracle fed the same masks AND the ReLU decisions the HIP path took (one of the 1 M hidden units decided differently -
+    a pre-activation within rounding noise of zero - moves the bias gradient by 1e-3 at this size), at the exact-f32 mode's 1e-4."""
+    from tt.encoder import BaseEncoder
+    from ttmi import ops
+    from ttmi.ops import MaskSpec
+    monkeypatch.setenv("TTMI_PRECISION", "bf16x3")
+    p, B, L, d, Di, H, Dh = 0.2, 8, 128, 512, 1024, 8, 64
+    torch.manual_seed(5)
+    layer = BaseEncoder(k_len=96, n_head=H, d_model=d, d_head=Dh, d_inner=Di, dropout=p).cuda().train()
+    x = torch.randn(B, L, d, generator=torch.Generator().manual_seed(3))
+    cot = torch.randn(B, L, d, generator=torch.Generator().manual_seed(4))
+    torch.manual_seed(79)
+    s_attn = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    s_ffn = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    torch.manual_seed(79)
+    xg = x.cuda().requires_grad_(True)
+    saved = []
+    real_layer_fwd = ops.layer_fwd
+    monkeypatch.setattr(ops, "layer_fwd", lambda *a, **k: (saved.append(real_layer_fwd(*a, **k)), saved[-1])[1])
+    y = layer.forward_bm(xg, MaskSpec(1))                    # causal mask (the label encoder's)
+    (y * cot.cuda()).sum().backward()
+    # the ReLU decisions the HIP path took (a1 is stored after the dropout: a1 > 0 <=> active AND kept; a dropped unit's decision is moot),
+    # read from the FFN context (csrc/layers.hip FfnCtx, f32 layout: h [rows, d], then a1 [rows, Di], 256-byte aligned)
+    rows = B * L
+    off = (rows * d * 4 + 255) // 256 * 256 // 4
+    a1 = saved[0][4][off:off + rows * Di].view(B, L, Di)
+
+    def mult(n, seed, shape):
+        return ops.dropout_multipliers(n, p, seed, "cuda").cpu().numpy().astype(np.float64).reshape(shape)
+
+    sd = {"encoder.layers.0." + k: v.detach().cpu().numpy().astype(np.float64) for k, v in layer.state_dict().items()}
+    prm = O.layer_params(sd, "encoder.", 0)
+    prm["drop_attn"] = mult(B * L * d, s_attn ^ 0xA1, (B, L, d))
+    prm["drop_ff_in"] = mult(B * L * Di, s_ffn ^ 0xB2, (B, L, Di))
+    prm["drop_ff_out"] = mult(B * L * d, s_ffn ^ 0xC3, (B, L, d))
+    prm["drop_layer"] = mult(B * L * d, s_ffn ^ 0xD4, (B, L, d))
+    own = O.layer_fwd(x.numpy().astype(np.float64), prm, O.look_ahead_mask(L)[:, :, None])[1][1]
+    kept = prm["drop_ff_in"] != 0
+    flips = (own["relu_on"] != (a1 > 0).cpu().numpy()) & kept
+    prm["relu_active"] = np.where(kept, (a1 > 0).cpu().numpy(), own["relu_on"])
+    want, cache = O.layer_fwd(x.numpy().astype(np.float64), prm, O.look_ahead_mask(L)[:, :, None])
+    dx, g = O.layer_bwd(cot.numpy().astype(np.float64), cache, prm)
+    tol = 1e-4
+    e_y, e_dx = rel_err(y.detach().cpu().numpy(), want), rel_err(xg.grad.cpu().numpy(), dx)
+    names = {v: k for k, v in O._LAYER_KEYS.items()}
+    worst = max(((rel_err(t.grad.cpu().numpy(), g[names[n]]), n) for n, t in layer.named_parameters()))
+    print("bf16x3 layer with dropout: out %.2e, dx %.2e, worst gradient %s %.2e, ReLU units decided differently from float64: %d" % (e_y, e_dx, worst[1], worst[0], int(flips.sum())))
+    assert e_y < tol and e_dx < tol and worst[0] < tol, (e_y, e_dx, worst)
