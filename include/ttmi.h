@@ -251,6 +251,11 @@ int ttmi_adam_step(float* p, const float* g, float* m, float* v, long n, float l
 int ttmi_adadelta_step(float* p, const float* g, float* square_avg, float* acc_delta, long n, float lr, float rho, float eps,
                        float weight_decay, float max_norm, const float* normsq, float grad_scale, float* hyper, void* stream);
 
+/* Mark a stream that is itself forked from the caller's main stream (the label encoder's side stream, tt/model.py _encode): calls on it never
+ * fork onto the library's own side streams inside a stream capture (no reference counterpart; ttmi_set_option(18, 1) lets the capturing stream
+ * itself fork as in eager mode). */
+int ttmi_stream_set_nofork(void* stream, int on);
+
 /* Device word (nullable) mixed into every dropout seed when a kernel starts.  Seeds are drawn on the host per sub-layer call; in a step that
  * is captured as a HIP graph they are baked into the kernel arguments, so the caller bumps this word on the device before each replay
  * (ttmi.train.GraphedStep) and every step still draws fresh masks.  Forward and backward of one step must see the same value. */

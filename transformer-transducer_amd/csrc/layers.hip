@@ -116,6 +116,7 @@ static inline const unsigned* drop_salt_here() {
 }
 #define g_drop_salt drop_salt_here()
 int g_fork_wgrad = 1;
+int g_capture_forks = 0;        // ttmi_set_option(18, 1): fork inside a stream capture too, from streams not marked by ttmi_stream_set_nofork (round 5, see fork_stream)
 int g_split_weights = 0;        // ttmi_set_option(13, v): the encoders' forward GEMMs take the second term of their weight's bf16 split (W ~ hi + lo) as a second
                                 // K range over the same A tiles, one launch each (NtEpilogue::B_lo): 1 = qkv_net, o_net, CoreNet.0, CoreNet.3; 2 = the two with f32
                                 // outputs (o_net, CoreNet.3) only.  Needs weight shadows (the free plain-copy region of the workspace holds the term)
@@ -136,6 +137,8 @@ struct SideCtx {
 // only ever used by the thread that owns its caller stream's work.
 constexpr int MAX_SIDE = 64;
 SideCtx g_side[MAX_SIDE];
+hipStream_t g_nofork[MAX_SIDE];
+int g_nnofork = 0;
 int g_nside = 0;
 std::mutex g_side_mu;
 
@@ -161,10 +164,17 @@ SideCtx* side_for(hipStream_t main) {
 // so far), or `main` itself when forking is disabled / unavailable
 hipStream_t fork_stream(hipStream_t main) {
     if (!g_fork_wgrad) return main;
-    // no forks inside a stream capture: a fork off the label encoder's side stream (itself forked from the capturing stream) crashes
-    // hipStreamEndCapture on ROCm 7.2 (tools/debug/graph_bisect.py); what the forks overlap in a captured step are a few small GEMMs
+    // forks inside a stream capture: a fork off the label encoder's side stream (itself forked from the capturing stream) crashes
+    // hipStreamEndCapture on ROCm 7.2 (tools/debug/graph_bisect.py).  Round 5: callers mark such second-level streams
+    // (ttmi_stream_set_nofork); with option 18 the capturing stream itself forks as in eager mode (its table-gradient reductions and
+    // ungrouped weight gradients become parallel branches of the graph), marked streams never do inside a capture
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(main, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return main;
+    if (hipStreamIsCapturing(main, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        if (!g_capture_forks) return main;
+        std::lock_guard<std::mutex> lock(g_side_mu);
+        for (int i = 0; i < g_nnofork; ++i)
+            if (g_nofork[i] == main) return main;
+    }
     SideCtx* c = side_for(main);
     if (!c) return main;
     hipEvent_t e = c->ev[c->next];
@@ -1424,6 +1434,23 @@ int ttmi_stream_reserve_cus(void* stream, int n) {
     return TTMI_OK;
 }
 
+// A stream that is itself a fork of the caller's main stream (the label encoder's side stream): library calls on it never fork again inside a
+// stream capture (nested forks crash hipStreamEndCapture on ROCm 7.2); eager launches are unaffected.
+int ttmi_stream_set_nofork(void* stream, int on) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    for (int i = 0; i < g_nnofork; ++i)
+        if (g_nofork[i] == st) {
+            if (!on) g_nofork[i] = g_nofork[--g_nnofork];
+            return TTMI_OK;
+        }
+    if (on) {
+        TTMI_REQUIRE(g_nnofork < MAX_SIDE, "stream_set_nofork: table full");
+        g_nofork[g_nnofork++] = st;
+    }
+    return TTMI_OK;
+}
+
 // Device word (nullable) that every dropout site mixes into its seed when its kernel starts: seeds are drawn on the host per call and, in a
 // step captured as a HIP graph, baked into the kernel arguments; bumping this word on the device before each replay gives every step
 // new masks.  Forward and backward of one step must see the same value.  Process-wide; nullptr (default) = seeds used as passed.
@@ -1437,7 +1464,8 @@ int ttmi_set_dropout_salt(const unsigned* salt) {
 // process-wide switches for A/B measurements.  key 0: 1 = disable the fused attention kernels (bf16 pipeline only);
 // key 1: throughput-GEMM generation (see gemm_fast.hip); key 2: flash-kernel timing switches; key 3: 0 = no wgrad fork
 int ttmi_set_option(int key, int value) {
-    TTMI_REQUIRE(key >= 0 && key <= 17, "set_option: unknown key %d", key);
+    TTMI_REQUIRE(key >= 0 && key <= 18, "set_option: unknown key %d", key);
+    if (key == 18) { g_capture_forks = value; return TTMI_OK; }
     if (key == 17) { gemm_fast_set_f32(value); return TTMI_OK; }
     if (key == 16) { g_scatter_launch = value; return TTMI_OK; }
     if (key == 15) { flash_set_bwd_gen(value); return TTMI_OK; }

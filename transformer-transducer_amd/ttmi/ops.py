@@ -692,6 +692,8 @@ def side_stream(device):
     st = _side_streams.get(key)
     if st is None:
         st = _side_streams[key] = torch.cuda.Stream(device=device)
+        # a second-level stream (forked from the caller's main stream): library calls on it never fork again inside a stream capture
+        check(lib().ttmi_stream_set_nofork(c_void_p(st.cuda_stream), c_int(1)), "ttmi_stream_set_nofork")
     return st
 
 
