@@ -87,3 +87,20 @@ def test_failing_call_order_20_passes_identical_tokens():
             os.environ.pop("TTMI_PRECISION", None)
         else:
             os.environ["TTMI_PRECISION"] = prev
+
+
+def test_fresh_processes_agree_under_the_interleaved_reproducer():
+    """tools/debug/replay_divergence.py in fresh processes (the divergence was a per-PROCESS event: 2 of 7 plain, 7 of 7 with an eager label-encoder call
+    interleaved after every replay): capture pass, `decode` per utterance, three pure-replay passes with every replayed state checked against eager - no
+    mismatching state, and all passes, the eager batched decoder (shrinking and fixed rows) and the per-utterance decoder return one token set"""
+    import json
+    import subprocess
+    env = dict(os.environ, TRACE="1", UTTS="16", TTMI_PRECISION="fp32")
+    env.pop("TTMI_MEMSET_KERNEL", None)
+    for _ in range(2):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "debug", "replay_divergence.py")], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res = json.loads(out.stdout.strip().splitlines()[-1])
+        assert res["n_events"] == 0, res["events"]
+        tokens = {res[k] for k in ("W", "S", "P1", "P2", "P3", "E", "EN", "SE")}
+        assert len(tokens) == 1, res
