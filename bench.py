@@ -521,7 +521,8 @@ def main():
             return None if a is None else round(a / pk, 4)
 
         k_ms = mean_pos(probe_ms)
-        peak = MFMA_BF16_PEAK_TFLOPS if args.precision == "bf16" else MFMA_F32_PEAK_TFLOPS
+        # bf16x3: every algorithmic multiply-add is three bf16 MFMA terms (hi.hi + lo.hi + hi.lo), so the ceiling for ALGORITHMIC flops is a third of the bf16 peak
+        peak = {"bf16": MFMA_BF16_PEAK_TFLOPS, "bf16x3": round(MFMA_BF16_PEAK_TFLOPS / 3.0, 1)}.get(args.precision, MFMA_F32_PEAK_TFLOPS)
         ach = rate(flop_launch, k_ms, 1e12)
         traffic = None          # HBM-side bytes of one launch from the committed PMC passes (only valid for the default workload)
         mfma_busy = None

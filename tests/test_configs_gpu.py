@@ -240,7 +240,9 @@ def _end_to_end_vs_oracle(monkeypatch, model, mode, B, T, U, V, tl, ul, n_enc, n
         if diff.any():
             z1 = np.abs((cf["h"] @ sd64["encoder.layers.%d.MultiHeadAttention.pos_ff.CoreNet.0.weight" % i].T +
                          sd64["encoder.layers.%d.MultiHeadAttention.pos_ff.CoreNet.0.bias" % i])[diff])
-            assert z1.max() < 1e-5, (i, z1.max())
+            # a unit may be decided differently only where its pre-activation (O(1) units) is within the mode's own error of zero: exact f32 1e-5;
+            # bf16x3 (three-term products in the attention core too: ~4e-6 per product, 18 layers deep) 5e-5
+            assert z1.max() < (1e-5 if mode == "fp32" else 5e-5), (i, z1.max())
     want = O.transducer_loss_and_grads(inp.numpy().astype(np.float64), tgt.numpy(), tl, ul, sd64, audio_mask)
     assert rel_err(logits.detach().cpu().numpy(), want["logits"]) < TOL
     assert abs(float(loss.detach()) - want["loss"]) / want["loss"] < TOL

@@ -95,6 +95,60 @@ def test_bf16_sources(a_k, b_k):
     assert rel_err(got, want) < 1e-5      # operands exactly representable -> only f32 accumulation error
 
 
+@pytest.mark.parametrize("a_k,b_k", LAYOUTS)
+@pytest.mark.parametrize("M,N,K", [(200, 130, 51), (129, 257, 100), (256, 128, 64)])
+def test_three_term_bf16_layouts_and_edges(a_k, b_k, M, N, K):
+    """GEMM_BF16X3 (TTMI_PRECISION=bf16x3: the attention core's batched products): f32 operands split into bf16 hi + lo while they are staged,
+    hi.hi + lo.hi + hi.lo on the bf16 MFMA.  32 batches so that the K-major shapes pass the skinny-kernel routing and reach the 128 x 128 kernel."""
+    from ttmi import ops
+    got, want = _run(M, N, K, a_k, b_k, False, flags_extra=ops.GEMM_BF16X3, nz=(4, 8), seed=M + N + K)
+    assert rel_err(got, want) < 2e-5
+    plain, _ = _run(M, N, K, a_k, b_k, True, nz=(4, 8), seed=M + N + K)
+    assert rel_err(got, want) < 0.02 * rel_err(plain, want)      # ... and it is not the one-term bf16 product
+
+
+@pytest.mark.parametrize("a_k,b_k", LAYOUTS)
+def test_three_term_bf16_exact_small_integers_and_epilogues(a_k, b_k):
+    from ttmi import ops
+    got, want = _run(160, 96, 80, a_k, b_k, False, flags_extra=ops.GEMM_BF16X3, nz=(8, 8), seed=99)    # lo = 0: bit-exact, any lane-map slip shows
+    assert np.array_equal(got, want.astype(np.float32))
+    got, want = _run(150, 70, 40, a_k, b_k, False, flags_extra=ops.GEMM_BF16X3 | ops.GEMM_BIAS | ops.GEMM_RELU, nz=(8, 8), seed=1)
+    assert rel_err(got, want) < 2e-5
+    got, want = _run(150, 70, 40, a_k, b_k, False, flags_extra=ops.GEMM_BF16X3, nz=(8, 8), beta=1.0, alpha=0.5, seed=3)
+    assert rel_err(got, want) < 2e-5
+    if not a_k:
+        got, want = _run(90, 70, 1000, a_k, b_k, False, flags_extra=ops.GEMM_BF16X3 | ops.GEMM_ATOMIC, splitk=5, seed=4)
+        assert rel_err(got, want) < 2e-5
+
+
+@pytest.mark.parametrize("a_k", [True, False])
+@pytest.mark.parametrize("M,K", [(500, 500), (130, 37), (257, 64), (128, 96)])
+def test_three_term_bf16_panel64_kernel(a_k, M, K):
+    """GEMM_BF16X3 with 64 n-major columns (P V, dS K, P^T dO ... of the attention core) leaves the 128 x 128 kernel for x3_panel64_kernel: the [M, K] slab
+    straight from global memory into MFMA fragments, B through LDS; edge rows, K that is no multiple of the 32-wide strip (or of 4), beta = 1, atomics"""
+    from ttmi import ops
+    got, want = _run(M, 64, K, a_k, False, False, flags_extra=ops.GEMM_BF16X3, nz=(3, 4), seed=M + K)
+    assert rel_err(got, want) < 2e-5
+    got, want = _run(M, 64, K, a_k, False, False, flags_extra=ops.GEMM_BF16X3, nz=(3, 4), seed=99)
+    assert np.array_equal(got, want.astype(np.float32))
+    got, want = _run(M, 64, K, a_k, False, False, flags_extra=ops.GEMM_BF16X3, nz=(2, 2), beta=1.0, seed=5)
+    assert rel_err(got, want) < 2e-5
+    got, want = _run(M, 64, K, a_k, False, False, flags_extra=ops.GEMM_BF16X3 | ops.GEMM_ATOMIC, nz=(2, 2), seed=6)
+    assert rel_err(got, want) < 2e-5
+
+
+@pytest.mark.parametrize("M,N", [(500, 500), (33, 70), (256, 31), (40, 128)])
+def test_three_term_bf16_rows_nt64_kernel(M, N):
+    """GEMM_BF16X3, both operands k-major with K = 64 (q E^T, (q + u) k^T, dO V^T): x3_rows_nt64_kernel - a workgroup writes 32 complete rows"""
+    from ttmi import ops
+    got, want = _run(M, N, 64, True, True, False, flags_extra=ops.GEMM_BF16X3, nz=(3, 4), seed=M + N)
+    assert rel_err(got, want) < 2e-5
+    got, want = _run(M, N, 64, True, True, False, flags_extra=ops.GEMM_BF16X3, nz=(3, 4), seed=99)
+    assert np.array_equal(got, want.astype(np.float32))
+    got, want = _run(M, N, 64, True, True, False, flags_extra=ops.GEMM_BF16X3 | ops.GEMM_BIAS, nz=(2, 2), beta=1.0, seed=7)
+    assert rel_err(got, want) < 2e-5
+
+
 def test_linearity_large():
     """size-independent property at a joint-sized K panel: GEMM(A1 + A2) == GEMM(A1) + GEMM(A2) (f32 path)"""
     from ttmi import ops

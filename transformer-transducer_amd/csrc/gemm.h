@@ -11,6 +11,7 @@ enum GemmFlags {
     GEMM_A_KMAJOR = 16,  // A[m*lda + k]  (else A[k*lda + m])
     GEMM_B_KMAJOR = 32,  // B[n*ldb + k]  (else B[k*ldb + n])
     GEMM_BF16_MFMA = 64, // compute with v_mfma_f32_32x32x16_bf16 (else exact-f32 v_mfma_f32_32x32x2_f32)
+    GEMM_BF16X3 = 128,   // f32 operands, f32 C: three bf16 MFMA terms hi.hi + lo.hi + hi.lo (TTMI_PRECISION=bf16x3, round 5); ignored with GEMM_BF16_MFMA
 };
 
 struct GemmDesc {

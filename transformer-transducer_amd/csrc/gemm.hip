@@ -80,7 +80,9 @@ __device__ __forceinline__ float4 load4(const S* p, int nvalid, bool vec) {
 }
 
 // Staging of one 128 x BK operand tile.  KMAJOR: element (r,k) at src[r*ld + k]; else src[k*ld + r].
-template <typename S, bool KMAJOR, bool BF16C>
+// X3 (BF16C only, f32 sources): a tile is staged TWICE - hi = bf16(x) at `lds`, lo = bf16(x - hi) at `lds` + 2 * TILE_BYTES - for the three-term
+// product of the bf16x3 parity mode
+template <typename S, bool KMAJOR, bool BF16C, bool X3 = false>
 struct Stager {
     using C = Cfg<BF16C>;
     static constexpr int NV = KMAJOR ? (128 * C::BK / 4) / NT : ((C::BK / 4) * 32 + NT - 1) / NT;   // float4 groups / thread
@@ -123,6 +125,12 @@ struct Stager {
                     w.x = pack_bf16x2(v[s].x, v[s].y);
                     w.y = pack_bf16x2(v[s].z, v[s].w);
                     *reinterpret_cast<uint2*>(lds + (row * C::LD + kq * 4) * 2) = w;
+                    if constexpr (X3) {
+                        uint2 l;
+                        l.x = pack_bf16x2(v[s].x - __uint_as_float(w.x << 16), v[s].y - __uint_as_float(w.x & 0xffff0000u));
+                        l.y = pack_bf16x2(v[s].z - __uint_as_float(w.y << 16), v[s].w - __uint_as_float(w.y & 0xffff0000u));
+                        *reinterpret_cast<uint2*>(lds + 2 * C::TILE_BYTES + (row * C::LD + kq * 4) * 2) = l;
+                    }
                 } else {
                     float* d = reinterpret_cast<float*>(lds) + row * C::LD + kq * 4;
                     d[0] = v[s].x; d[1] = v[s].y; d[2] = v[s].z; d[3] = v[s].w;
@@ -146,6 +154,12 @@ struct Stager {
                             w.x = pack_bf16x2(tr[rr][0], tr[rr][1]);
                             w.y = pack_bf16x2(tr[rr][2], tr[rr][3]);
                             *reinterpret_cast<uint2*>(lds + (row * C::LD + kb * 4) * 2) = w;
+                            if constexpr (X3) {
+                                uint2 l;
+                                l.x = pack_bf16x2(tr[rr][0] - __uint_as_float(w.x << 16), tr[rr][1] - __uint_as_float(w.x & 0xffff0000u));
+                                l.y = pack_bf16x2(tr[rr][2] - __uint_as_float(w.y << 16), tr[rr][3] - __uint_as_float(w.y & 0xffff0000u));
+                                *reinterpret_cast<uint2*>(lds + 2 * C::TILE_BYTES + (row * C::LD + kb * 4) * 2) = l;
+                            }
                         } else {
                             float* dd = reinterpret_cast<float*>(lds) + row * C::LD + kb * 4;
                             dd[0] = tr[rr][0]; dd[1] = tr[rr][1]; dd[2] = tr[rr][2]; dd[3] = tr[rr][3];
@@ -157,15 +171,16 @@ struct Stager {
     }
 };
 
-template <typename SA, typename SB, typename TC, bool AK, bool BKM, bool BF16C>
+template <typename SA, typename SB, typename TC, bool AK, bool BKM, bool BF16C, bool X3 = false>
 __global__ __launch_bounds__(NT) void gemm_kernel(const KParams p_) {
     KParams p = p_;
     p.drop = drop_live(p.drop);
     using C = Cfg<BF16C>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // layout: [buf0: A | B][buf1: A | B]
-    auto ldsA = [&](int buf) -> char* { return smem + buf * 2 * C::TILE_BYTES; };
-    auto ldsB = [&](int buf) -> char* { return smem + buf * 2 * C::TILE_BYTES + C::TILE_BYTES; };
+    // layout: [buf0: A | B][buf1: A | B]; X3: [buf: A_hi | B_hi | A_lo | B_lo]
+    constexpr int PER_BUF = X3 ? 4 : 2;
+    auto ldsA = [&](int buf) -> char* { return smem + buf * PER_BUF * C::TILE_BYTES; };
+    auto ldsB = [&](int buf) -> char* { return smem + buf * PER_BUF * C::TILE_BYTES + C::TILE_BYTES; };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -187,8 +202,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const KParams p_) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    Stager<SA, AK, BF16C> sa;
-    Stager<SB, BKM, BF16C> sb;
+    Stager<SA, AK, BF16C, X3> sa;
+    Stager<SB, BKM, BF16C, X3> sb;
     if (nk > 0) {
         sa.load(A, p.lda, bm, p.M, kbeg, kend, p.vecA, tid);
         sb.load(B, p.ldb, bn, p.N, kbeg, kend, p.vecB, tid);
@@ -221,6 +236,23 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const KParams p_) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                if constexpr (X3) {                               // + lo . hi + hi . lo (the lo tiles sit 2 tiles behind their hi tiles)
+                    bf16x8 al[2], bl[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int row = wm * 64 + i * 32 + (lane & 31);
+                        al[i] = *reinterpret_cast<const bf16x8*>(la + 2 * C::TILE_BYTES + (row * C::LD + kof) * 2);
+                        const int col = wn * 64 + i * 32 + (lane & 31);
+                        bl[i] = *reinterpret_cast<const bf16x8*>(lb + 2 * C::TILE_BYTES + (col * C::LD + kof) * 2);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bf[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bl[j], acc[i][j], 0, 0, 0);
+                        }
+                }
             }
         } else {
             const float* fa = reinterpret_cast<const float*>(la);
@@ -371,21 +403,233 @@ __global__ __launch_bounds__(NT) void gemm_skinny_f32_kernel(const KParams p_) {
 }
 
 
-template <typename SA, typename SB, typename TC, bool AK, bool BKM, bool BF16C>
+// ---------------------------------------------------------------------------------------------------------------------
+// TTMI_PRECISION=bf16x3: the attention core's batched products (round 5).  Every one of them streams one [L, L] f32 slab per (batch, head)
+// - 256 MB at B = 32, H = 8, L = 500 - against operands of Dh = 64 columns.  Through the 128 x 128 kernel above they ran at 1.2 TB/s of that
+// slab whatever the arithmetic (exact f32 and three-term bf16 within 3 %): a tile walks its 128 slab rows in 128-byte strips, one barrier-separated
+// step per strip with two workgroups per CU, so the bytes in flight - not the MFMA - set the pace (tools/debug/bench_generic_gemm.py; the library's
+// f32 batched product on the same operands: 95 us reading, 179 us writing the slab).  Two shapes cover them:
+//   x3_panel64_kernel   C[M, 64] (+)= A[M, K] B[K, 64]    (P V, dS K, dG E: A k-major; P^T dO, dS^T (q + u), dG^T q: A m-major).  The slab operand A has
+//       no reuse across waves (a wave's 32 rows meet all 64 columns), so it goes from global memory straight into the MFMA A fragments - split
+//       into bf16 hi + lo in registers, the next 32-wide strip already in flight - and only the small B strip (32 x 64, L2-resident) passes
+//       through LDS, transposed and split once per workgroup: one barrier per strip, 20 KB of LDS, four to five workgroups per CU.
+//   x3_rows_nt64_kernel C[M, N] (+)= A[M, 64] B[N, 64]^T (+ bias)   (q E^T, (q + u) k^T, dO V^T).  A workgroup owns 32 COMPLETE rows of the slab
+//       - one contiguous 64 KB region - and its waves take the 32-column blocks in turn: both operands straight from global memory (k-major,
+//       L2-resident) into fragments, no LDS, no barrier.
+// Both: three bf16 MFMA terms hi.hi + lo.hi + hi.lo per fragment pair, f32 accumulation.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split8(const float4 a, const float4 b, bf16x8& hi, bf16x8& lo) {
+    u32x4 h, l;
+    h.x = pack_bf16x2(a.x, a.y); h.y = pack_bf16x2(a.z, a.w); h.z = pack_bf16x2(b.x, b.y); h.w = pack_bf16x2(b.z, b.w);
+    l.x = pack_bf16x2(a.x - __uint_as_float(h.x << 16), a.y - __uint_as_float(h.x & 0xffff0000u));
+    l.y = pack_bf16x2(a.z - __uint_as_float(h.y << 16), a.w - __uint_as_float(h.y & 0xffff0000u));
+    l.z = pack_bf16x2(b.x - __uint_as_float(h.z << 16), b.y - __uint_as_float(h.z & 0xffff0000u));
+    l.w = pack_bf16x2(b.z - __uint_as_float(h.w << 16), b.w - __uint_as_float(h.w & 0xffff0000u));
+    hi = __builtin_bit_cast(bf16x8, h);
+    lo = __builtin_bit_cast(bf16x8, l);
+}
+
+constexpr int P64_BM = 128;      // rows per workgroup; KC = strip width, KC + 8 = LDS pitch of a B column (bf16 elements)
+
+template <bool AK, int KC>
+__global__ __launch_bounds__(NT) void x3_panel64_kernel(const KParams p) {
+    constexpr int P64_KC = KC, P64_LD = KC + 8, NKK = KC / 16, NB = KC / 32;
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][2][64 * P64_LD];      // [stage][hi | lo][column n][k]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, g = lane >> 5;
+    const int bm = blockIdx.x * P64_BM;
+    const int z = blockIdx.y, z1 = z / p.nz2, z2 = z % p.nz2;
+    const float* A = reinterpret_cast<const float*>(p.A) + z1 * p.sA1 + z2 * p.sA2;
+    const float* B = reinterpret_cast<const float*>(p.B) + z1 * p.sB1 + z2 * p.sB2;
+    float* Cp = reinterpret_cast<float*>(p.C) + z1 * p.sC1 + z2 * p.sC2;
+    const int row = bm + 32 * wave + r;
+    const int rowc = min(row, p.M - 1);                    // rows past the matrix are loaded from its last row and never stored
+    const int nc = (p.K + P64_KC - 1) / P64_KC;
+
+    // lane (r, g) of a 32x32x16 MFMA supplies k = 8 g ... 8 g + 7 of its row: two float4 per 16-wide block, two blocks per strip
+    auto load_a = [&](int k0, float4* d) {
+        if constexpr (AK) {
+            const float* ap = A + (long)rowc * p.lda;
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const int k = k0 + 16 * kk + 8 * g;
+                d[2 * kk] = load4<float>(ap + k, p.K - k, p.vecA);
+                d[2 * kk + 1] = load4<float>(ap + k + 4, p.K - k - 4, p.vecA);
+            }
+        } else {                                           // A stored [K, M]: 32 consecutive rows per load instruction
+            const float* ap = A + rowc;
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                const int k = k0 + 16 * kk + 8 * g;
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = (k + i < p.K) ? ap[(long)(k + i) * p.lda] : 0.f;
+                d[2 * kk] = make_float4(v[0], v[1], v[2], v[3]);
+                d[2 * kk + 1] = make_float4(v[4], v[5], v[6], v[7]);
+            }
+        }
+    };
+    // B strip [KC k][64 n] (n contiguous): thread (kp = tid >> 4, n4 = 4 (tid & 15)) takes rows 2 kp, 2 kp + 1 (+ 32 per further block) of four columns
+    const int kp = tid >> 4, n4 = (tid & 15) * 4;
+    auto load_b = [&](int k0, float4* d) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2 * NB; ++s2) {
+            const int k = k0 + 32 * (s2 >> 1) + 2 * kp + (s2 & 1);
+            d[s2] = load4<float>(B + (long)k * p.ldb + n4, k < p.K ? 4 : 0, p.vecB);
+        }
+    };
+    auto store_b = [&](int st, const float4* d) {
+        unsigned* hi = reinterpret_cast<unsigned*>(Bs[st][0]);
+        unsigned* lo = reinterpret_cast<unsigned*>(Bs[st][1]);
+#pragma unroll
+        for (int b2 = 0; b2 < NB; ++b2) {
+            const float x0[4] = {d[2 * b2].x, d[2 * b2].y, d[2 * b2].z, d[2 * b2].w}, x1[4] = {d[2 * b2 + 1].x, d[2 * b2 + 1].y, d[2 * b2 + 1].z, d[2 * b2 + 1].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned h = pack_bf16x2(x0[i], x1[i]);
+                const unsigned l = pack_bf16x2(x0[i] - __uint_as_float(h << 16), x1[i] - __uint_as_float(h & 0xffff0000u));
+                hi[(n4 + i) * (P64_LD / 2) + 16 * b2 + kp] = h;
+                lo[(n4 + i) * (P64_LD / 2) + 16 * b2 + kp] = l;
+            }
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    float4 ra[2 * NKK], rn[2 * NKK], rb[2 * NB];
+    if (nc > 0) {
+        load_a(0, ra);
+        load_b(0, rb);
+        store_b(0, rb);
+    }
+    __syncthreads();
+    for (int c = 0; c < nc; ++c) {
+        const int cur = c & 1;
+        const bool more = c + 1 < nc;
+        if (more) {
+            load_a((c + 1) * P64_KC, rn);
+            load_b((c + 1) * P64_KC, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            bf16x8 ah, al;
+            split8(ra[2 * kk], ra[2 * kk + 1], ah, al);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int off = (32 * j + r) * P64_LD + 16 * kk + 8 * g;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bs[cur][0][off]);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bs[cur][1][off]);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+            }
+        }
+        if (more) store_b(cur ^ 1, rb);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2 * NKK; ++i) ra[i] = rn[i];
+    }
+    // C/D map of the 32x32 MFMA: col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
+    const bool atomic = p.flags & GEMM_ATOMIC;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = bm + 32 * wave + (i & 3) + 8 * (i >> 2) + 4 * g;
+            if (m >= p.M) continue;
+            float* cp = Cp + (long)m * p.ldc + 32 * j + r;
+            if (atomic) atomicAdd(cp, acc[j][i]);
+            else *cp = p.beta != 0.f ? acc[j][i] + *cp : acc[j][i];
+        }
+}
+
+__global__ __launch_bounds__(NT) void x3_rows_nt64_kernel(const KParams p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, g = lane >> 5;
+    const int bm = blockIdx.x * 32;
+    const int z = blockIdx.y, z1 = z / p.nz2, z2 = z % p.nz2;
+    const float* A = reinterpret_cast<const float*>(p.A) + z1 * p.sA1 + z2 * p.sA2;
+    const float* B = reinterpret_cast<const float*>(p.B) + z1 * p.sB1 + z2 * p.sB2;
+    float* Cp = reinterpret_cast<float*>(p.C) + z1 * p.sC1 + z2 * p.sC2;
+    const float* bias = (p.flags & GEMM_BIAS) ? p.bias + z1 * p.sBias1 + z2 * p.sBias2 : nullptr;
+    bf16x8 ah[4], al[4];
+    {
+        const float4* ap = reinterpret_cast<const float4*>(A + (long)min(bm + r, p.M - 1) * p.lda + 8 * g);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) split8(ap[4 * kk], ap[4 * kk + 1], ah[kk], al[kk]);
+    }
+    const int ncb = (p.N + 31) >> 5;
+    auto load_b = [&](int j, float4* d) {
+        const float4* bp = reinterpret_cast<const float4*>(B + (long)min(32 * j + r, p.N - 1) * p.ldb + 8 * g);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            d[2 * kk] = bp[4 * kk];
+            d[2 * kk + 1] = bp[4 * kk + 1];
+        }
+    };
+    float4 bc[8], bn[8];
+    if (wave < ncb) load_b(wave, bc);
+    for (int j = wave; j < ncb; j += 4) {
+        if (j + 4 < ncb) load_b(j + 4, bn);
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 bh, bl;
+            split8(bc[2 * kk], bc[2 * kk + 1], bh, bl);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk], bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kk], bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk], bl, acc, 0, 0, 0);
+        }
+        const int n = 32 * j + r;
+        if (n < p.N) {
+            const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = bm + (i & 3) + 8 * (i >> 2) + 4 * g;
+                if (m >= p.M) continue;
+                float* cp = Cp + (long)m * p.ldc + n;
+                float v = acc[i] + bv;
+                if (p.beta != 0.f) v += *cp;
+                *cp = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bc[i] = bn[i];
+    }
+}
+
+static int g_x3_attn_kernels = 1;      // TTMI_X3_ATTN_KERNELS=0: the attention core of the bf16x3 mode back on the 128 x 128 kernel (A/B runs)
+
+template <typename SA, typename SB, typename TC, bool AK, bool BKM, bool BF16C, bool X3 = false>
 int launch_t(const KParams& p, dim3 grid, hipStream_t st) {
-    const size_t lds = 4 * Cfg<BF16C>::TILE_BYTES;
-    hipLaunchKernelGGL((gemm_kernel<SA, SB, TC, AK, BKM, BF16C>), grid, dim3(NT), lds, st, p);
+    const size_t lds = (X3 ? 8 : 4) * Cfg<BF16C>::TILE_BYTES;
+    if constexpr (X3) {                                           // 80 KB of dynamic LDS: above the default limit
+        static bool once = false;
+        if (!once) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<SA, SB, TC, AK, BKM, BF16C, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                ttmi_set_error("gemm: LDS attribute");
+                return TTMI_EINVAL;
+            }
+            once = true;
+        }
+    }
+    hipLaunchKernelGGL((gemm_kernel<SA, SB, TC, AK, BKM, BF16C, X3>), grid, dim3(NT), lds, st, p);
     TTMI_LAUNCH_CHECK("gemm_kernel");
     return TTMI_OK;
 }
 
-template <typename SA, typename SB, typename TC, bool BF16C>
+template <typename SA, typename SB, typename TC, bool BF16C, bool X3 = false>
 int launch_layout(const KParams& p, dim3 grid, hipStream_t st) {
     const bool ak = p.flags & GEMM_A_KMAJOR, bk = p.flags & GEMM_B_KMAJOR;
-    if (ak && bk) return launch_t<SA, SB, TC, true, true, BF16C>(p, grid, st);
-    if (ak && !bk) return launch_t<SA, SB, TC, true, false, BF16C>(p, grid, st);
-    if (!ak && !bk) return launch_t<SA, SB, TC, false, false, BF16C>(p, grid, st);
-    return launch_t<SA, SB, TC, false, true, BF16C>(p, grid, st);
+    if (ak && bk) return launch_t<SA, SB, TC, true, true, BF16C, X3>(p, grid, st);
+    if (ak && !bk) return launch_t<SA, SB, TC, true, false, BF16C, X3>(p, grid, st);
+    if (!ak && !bk) return launch_t<SA, SB, TC, false, false, BF16C, X3>(p, grid, st);
+    return launch_t<SA, SB, TC, false, true, BF16C, X3>(p, grid, st);
 }
 
 }  // namespace
@@ -463,6 +707,39 @@ int ttmi_launch_gemm(const GemmDesc& d, hipStream_t st) {
     dim3 grid(cdiv(d.N, BN), cdiv(d.M, BM), d.nz1 * d.nz2 * d.splitk);
     TTMI_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large (M tiles %u, batch %u)", grid.y, grid.z);
     const int key = (bf16c ? 8 : 0) | (d.a_dtype << 2) | (d.b_dtype << 1) | d.c_dtype;
+    if (key == 0 && (d.flags & GEMM_BF16X3)) {
+        static const bool env_once = [] {
+            const char* e = getenv("TTMI_X3_ATTN_KERNELS");
+            if (e && e[0] == '0') g_x3_attn_kernels = 0;
+            return true;
+        }();
+        (void)env_once;
+        const bool plain = d.alpha == 1.f && (d.beta == 0.f || d.beta == 1.f) && d.splitk == 1 && d.drop.p <= 0.f && (long)d.nz1 * d.nz2 <= 65535;
+        const bool ak = d.flags & GEMM_A_KMAJOR, bkm = d.flags & GEMM_B_KMAJOR;
+        if (g_x3_attn_kernels && plain && d.N == 64 && !bkm && p.vecB && (!ak || p.vecA) && !(d.flags & ~(GEMM_BF16X3 | GEMM_A_KMAJOR | GEMM_ATOMIC)) &&
+            (!(d.flags & GEMM_ATOMIC) || d.beta == 0.f)) {
+            dim3 pg(cdiv(d.M, P64_BM), d.nz1 * d.nz2);
+            static const int kc_env = [] { const char* e = getenv("TTMI_X3_KC"); return e ? atoi(e) : 0; }();
+            if (ak && kc_env == 64) hipLaunchKernelGGL((x3_panel64_kernel<true, 64>), pg, dim3(NT), 0, st, p);
+            else if (ak) hipLaunchKernelGGL((x3_panel64_kernel<true, 32>), pg, dim3(NT), 0, st, p);
+            else if (kc_env == 64) hipLaunchKernelGGL((x3_panel64_kernel<false, 64>), pg, dim3(NT), 0, st, p);
+            else hipLaunchKernelGGL((x3_panel64_kernel<false, 32>), pg, dim3(NT), 0, st, p);
+            TTMI_LAUNCH_CHECK("x3_panel64_kernel");
+            return TTMI_OK;
+        }
+        if (g_x3_attn_kernels && plain && d.K == 64 && ak && bkm && p.vecA && p.vecB &&
+            !(d.flags & ~(GEMM_BF16X3 | GEMM_A_KMAJOR | GEMM_B_KMAJOR | GEMM_BIAS))) {
+            hipLaunchKernelGGL(x3_rows_nt64_kernel, dim3(cdiv(d.M, 32), d.nz1 * d.nz2), dim3(NT), 0, st, p);
+            TTMI_LAUNCH_CHECK("x3_rows_nt64_kernel");
+            return TTMI_OK;
+        }
+        // bf16x3 parity mode: the 128 x 128 kernel with every f32 tile staged as bf16 hi + lo and three bf16 MFMA terms per fragment pair (K-steps of 32:
+        // the split-K chunking above assumed 16-wide steps - re-round it)
+        int kc = (d.K + d.splitk - 1) / d.splitk;
+        kc = (kc + 31) / 32 * 32;
+        p.kchunk = kc > 0 ? kc : 32;
+        return launch_layout<float, float, float, true, true>(p, grid, st);
+    }
     switch (key) {
         case 0: return launch_layout<float, float, float, false>(p, grid, st);
         case 8: return launch_layout<float, float, float, true>(p, grid, st);

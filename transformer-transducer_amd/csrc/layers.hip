@@ -32,7 +32,7 @@ inline size_t al4(size_t n) { return (n + 3) & ~size_t(3); }
 GemmDesc mk(const float* A, const float* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int flags, int prec) {
     GemmDesc d;
     d.A = A; d.B = B; d.C = C; d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc;
-    d.flags = flags | (prec == 1 ? GEMM_BF16_MFMA : 0);      // (prec 2 = bf16x3: f32 data flow; the big dense products go through x3_* below, the rest stays exact f32)
+    d.flags = flags | (prec == 1 ? GEMM_BF16_MFMA : (prec == 2 ? GEMM_BF16X3 : 0));      // (prec 2 = bf16x3: f32 data flow; the big dense products go through x3_* below, the rest through the generic kernel's three-term form)
     return d;
 }
 
@@ -283,7 +283,7 @@ GemmDesc mkx(const void* A, int adt, const void* B, int bdt, void* C, int cdt, i
     GemmDesc d;
     d.A = A; d.B = B; d.C = C; d.a_dtype = adt; d.b_dtype = bdt; d.c_dtype = cdt;
     d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.ldc = ldc;
-    d.flags = flags | (prec == 1 ? GEMM_BF16_MFMA : 0);
+    d.flags = flags | (prec == 1 ? GEMM_BF16_MFMA : (prec == 2 ? GEMM_BF16X3 : 0));
     return d;
 }
 

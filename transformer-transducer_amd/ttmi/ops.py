@@ -117,7 +117,7 @@ def rnnt_loss_bwd(logits, labels, act_lens, label_lens, blank, workspace, grad_o
 
 
 # ----------------------------------------------------------------------------- generic GEMM (tests / bring-up)
-GEMM_BIAS, GEMM_RELU, GEMM_ATOMIC, GEMM_MASK_AUX, GEMM_A_KMAJOR, GEMM_B_KMAJOR, GEMM_BF16_MFMA = 1, 2, 4, 8, 16, 32, 64
+GEMM_BIAS, GEMM_RELU, GEMM_ATOMIC, GEMM_MASK_AUX, GEMM_A_KMAJOR, GEMM_B_KMAJOR, GEMM_BF16_MFMA, GEMM_BF16X3 = 1, 2, 4, 8, 16, 32, 64, 128
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 
 
