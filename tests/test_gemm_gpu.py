@@ -137,7 +137,7 @@ def test_three_term_bf16_panel64_kernel(a_k, M, K):
     assert rel_err(got, want) < 2e-5
 
 
-@pytest.mark.parametrize("M,N", [(500, 500), (33, 70), (256, 31), (40, 128)])
+@pytest.mark.parametrize("M,N", [(500, 500), (33, 70), (256, 31), (40, 128), (70, 1100), (64, 513)])
 def test_three_term_bf16_rows_nt64_kernel(M, N):
     """GEMM_BF16X3, both operands k-major with K = 64 (q E^T, (q + u) k^T, dO V^T): x3_rows_nt64_kernel - a workgroup writes 32 complete rows"""
     from ttmi import ops
@@ -147,6 +147,21 @@ def test_three_term_bf16_rows_nt64_kernel(M, N):
     assert np.array_equal(got, want.astype(np.float32))
     got, want = _run(M, N, 64, True, True, False, flags_extra=ops.GEMM_BF16X3 | ops.GEMM_BIAS, nz=(2, 2), beta=1.0, seed=7)
     assert rel_err(got, want) < 2e-5
+
+
+def test_three_term_bf16_panel64_unaligned_slab():
+    """the pitch-(L+1) view of dG (attention backward, dq += dG E): a k-major slab one float off 16-byte alignment with an odd pitch"""
+    from ttmi import ops
+    L, D, Z = 77, 64, 6
+    g = torch.Generator(device="cuda").manual_seed(5)
+    slab = torch.randn(Z * L * (L + 1) + 8, device="cuda", generator=g)
+    e = torch.randn(L, D, device="cuda", generator=g)
+    out = torch.randn(Z, L, D, device="cuda", generator=g)
+    want = out.double() + torch.as_strided(slab[1:], (Z, L, L), (L * (L + 1), L + 1, 1)).double() @ e.double()
+    ops.gemm(slab[1:], e, out, L, D, L, L + 1, D, D, ops.GEMM_A_KMAJOR | ops.GEMM_BF16X3, beta=1.0, nz1=2, nz2=3,
+             sA=(3 * L * (L + 1), L * (L + 1)), sB=(0, 0), sC=(3 * L * D, L * D))
+    torch.cuda.synchronize()
+    assert float((out.double() - want).norm() / want.norm()) < 2e-5
 
 
 def test_linearity_large():

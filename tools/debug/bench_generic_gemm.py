@@ -31,11 +31,15 @@ def main():
     o = torch.empty(Z, L, D, device="cuda")
     p = torch.randn(Z, L, L, device="cuda", generator=g)
     AK, BK = ops.GEMM_A_KMAJOR, ops.GEMM_B_KMAJOR
+    qkv = torch.randn(B, L, 3 * H * D, device="cuda", generator=g)
+    pp = torch.randn(Z * L * (L + 1) + 8, device="cuda", generator=g)[1:]      # the pitch-(L+1) view starts one float into its slab
     cases = [
         ("q.k^T   [500x500x64]  A k-major, B k-major", lambda f: ops.gemm(q, k, s, L, L, D, D, D, L, AK | BK | f, nz1=B, nz2=H, sA=(H * L * D, L * D), sB=(H * L * D, L * D), sC=(H * L * L, L * L)), 4.0 * Z * L * L),
+        ("qu.k^T  [500x500x64]  beta=1, slices of a [B,L,3HD] qkv", lambda f: ops.gemm(qkv, qkv[0, 0, H * D:], s, L, L, D, 3 * H * D, 3 * H * D, L, AK | BK | f, beta=1.0, nz1=B, nz2=H, sA=(L * 3 * H * D, D), sB=(L * 3 * H * D, D), sC=(H * L * L, L * L)), 4.0 * Z * L * L),
         ("p.v     [500x64x500]  A k-major, B n-major", lambda f: ops.gemm(p, k, o, L, D, L, L, D, D, AK | f, nz1=B, nz2=H, sA=(H * L * L, L * L), sB=(H * L * D, L * D), sC=(H * L * D, L * D)), 4.0 * Z * L * L),
         ("p^T.do  [500x64x500]  A m-major, B n-major", lambda f: ops.gemm(p, k, o, L, D, L, L, D, D, f, nz1=B, nz2=H, sA=(H * L * L, L * L), sB=(H * L * D, L * D), sC=(H * L * D, L * D)), 4.0 * Z * L * L),
         ("ds.k    [500x64x500]  beta=1", lambda f: ops.gemm(p, k, o, L, D, L, L, D, D, AK | f, beta=1.0, nz1=B, nz2=H, sA=(H * L * L, L * L), sB=(H * L * D, L * D), sC=(H * L * D, L * D)), 4.0 * Z * L * L),
+        ("dg.e    [500x64x500]  pitch L+1 view, beta=1", lambda f: ops.gemm(pp, k, o, L, D, L, L + 1, D, D, AK | f, beta=1.0, nz1=B, nz2=H, sA=(H * L * (L + 1), L * (L + 1)), sB=(H * L * D, L * D), sC=(H * L * D, L * D)), 4.0 * Z * L * L),
     ]
     for name, fn, big_bytes in cases:
         for label, f in (("f32", 0), ("x3", ops.GEMM_BF16X3)):

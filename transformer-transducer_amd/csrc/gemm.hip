@@ -547,10 +547,34 @@ __global__ __launch_bounds__(NT) void x3_panel64_kernel(const KParams p) {
         }
 }
 
-__global__ __launch_bounds__(NT) void x3_rows_nt64_kernel(const KParams p) {
+constexpr int RN_CG = 256, RN_NP = RN_CG + 8;      // columns per pass through the LDS tile, its row pitch (4 RN_NP = 32 mod 64 banks: the two row groups of a store miss each other)
+
+__global__ __launch_bounds__(NT, 4) void x3_rows_nt64_kernel(const KParams p) {
+    // The 32 x 32 accumulators have lanes along COLUMNS: stored directly, every instruction leaves two 128-byte row pieces that straddle cache
+    // lines (row pitch 2000 bytes).  The workgroup's 32 rows pass through an LDS tile instead and leave row by row in line-aligned pieces, 16 bytes
+    // per lane where a row piece is 16-byte aligned (158 -> 145 us at 512 columns per pass).
+    // 256 columns per pass (34 KB of LDS, four workgroups per CU): 135 us at B = 32, H = 8, L = 500, 192 us with beta = 1 (512 columns, two
+    // workgroups per CU: 150 / 200; 128 columns: 155 / 231).  With 512-column passes the kernel took 110 us with the write-out skipped and 77 us
+    // with the products skipped (tools/debug/bench_generic_gemm.py).  Measured and NOT faster: the operand rows in whole lines through a
+    // wave-private LDS image instead of fragment-shaped loads (145), two column blocks of operand rows in flight (146), eight waves with every
+    // load of a pass in flight and one contiguous run of 16-byte stores (167, spills).  The library's batched f32 product: 179 us.
+    extern __shared__ __attribute__((aligned(16))) float rn_tile[];      // [32][RN_NP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, g = lane >> 5;
-    const int bm = blockIdx.x * 32;
-    const int z = blockIdx.y, z1 = z / p.nz2, z2 = z % p.nz2;
+    // workgroups are dealt to the 8 XCDs round-robin, and every row block of a (batch, head) slab reads ALL of its B rows: numbered as launched,
+    // each XCD's L2 fetches every B once (FETCH_SIZE: 288 MB = A + 8 x B at B = 32, L = 500).  Renumbered (p.kchunk = 1: the launcher's switch)
+    // so that the row blocks of one slab run on ONE XCD, next to each other in time: same box, alternating, 200 / 204 -> 192 / 193 us with beta = 1,
+    // 137 +- 2 either way without; the C2 step 113.86 / 113.92 -> 113.49 / 113.68 ms.
+    int bx = blockIdx.x, z = blockIdx.y;
+    if (p.kchunk == 1) {
+        const unsigned total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if ((total & 7) == 0) {
+            const unsigned t = (lin & 7) * (total >> 3) + (lin >> 3);
+            bx = t % gridDim.x;
+            z = t / gridDim.x;
+        }
+    }
+    const int bm = bx * 32;
+    const int z1 = z / p.nz2, z2 = z % p.nz2;
     const float* A = reinterpret_cast<const float*>(p.A) + z1 * p.sA1 + z2 * p.sA2;
     const float* B = reinterpret_cast<const float*>(p.B) + z1 * p.sB1 + z2 * p.sB2;
     float* Cp = reinterpret_cast<float*>(p.C) + z1 * p.sC1 + z2 * p.sC2;
@@ -561,7 +585,6 @@ __global__ __launch_bounds__(NT) void x3_rows_nt64_kernel(const KParams p) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) split8(ap[4 * kk], ap[4 * kk + 1], ah[kk], al[kk]);
     }
-    const int ncb = (p.N + 31) >> 5;
     auto load_b = [&](int j, float4* d) {
         const float4* bp = reinterpret_cast<const float4*>(B + (long)min(32 * j + r, p.N - 1) * p.ldb + 8 * g);
 #pragma unroll
@@ -571,35 +594,73 @@ __global__ __launch_bounds__(NT) void x3_rows_nt64_kernel(const KParams p) {
         }
     };
     float4 bc[8], bn[8];
-    if (wave < ncb) load_b(wave, bc);
-    for (int j = wave; j < ncb; j += 4) {
-        if (j + 4 < ncb) load_b(j + 4, bn);
-        f32x16 acc;
+    for (int cg = 0; cg < p.N; cg += RN_CG) {
+        const int ncols = min(p.N - cg, RN_CG), ncb = (ncols + 31) >> 5, j0 = cg >> 5;
+        if (wave < ncb) load_b(j0 + wave, bc);
+        for (int j = wave; j < ncb; j += 4) {
+            if (j + 4 < ncb) load_b(j0 + j + 4, bn);
+            f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 bh, bl;
-            split8(bc[2 * kk], bc[2 * kk + 1], bh, bl);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk], bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kk], bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk], bl, acc, 0, 0, 0);
+            for (int kk = 0; kk < 4; ++kk) {
+                bf16x8 bh, bl;
+                split8(bc[2 * kk], bc[2 * kk + 1], bh, bl);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk], bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kk], bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk], bl, acc, 0, 0, 0);
+            }
+            const int nl = 32 * j + r;
+            if (nl < ncols) {
+                const float bv = bias ? bias[cg + nl] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) rn_tile[((i & 3) + 8 * (i >> 2) + 4 * g) * RN_NP + nl] = acc[i] + bv;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bc[i] = bn[i];
         }
-        const int n = 32 * j + r;
-        if (n < p.N) {
-            const float bv = bias ? bias[n] : 0.f;
+        __syncthreads();
+        for (int rr = wave; rr < 32 && bm + rr < p.M; rr += 4) {
+            float* crow = Cp + (long)(bm + rr) * p.ldc + cg;
+            const int mis = (int)((reinterpret_cast<uintptr_t>(crow) >> 2) & 31);      // floats past the 128-byte line the row piece starts in
+            const float* trow = rn_tile + rr * RN_NP;
+            // (beta = 1 - the content scores added onto the shifted position term: all of the row's reads in flight before its first store; a load
+            // per store serialised on the aliasing stores and took 405 us against 135 us without the accumulation)
+            if ((reinterpret_cast<uintptr_t>(crow) & 15) == 0 && (ncols & 3) == 0) {
+                // 16-byte-aligned row piece (the pitch-L views): 16 bytes per lane, instruction boundaries still on 128-byte lines - three
+                // instructions a row instead of nine
+                const int mis4 = mis >> 2, n4 = ncols >> 2;
+                float4 cv[RN_CG / 256 + 1];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int m = bm + (i & 3) + 8 * (i >> 2) + 4 * g;
-                if (m >= p.M) continue;
-                float* cp = Cp + (long)m * p.ldc + n;
-                float v = acc[i] + bv;
-                if (p.beta != 0.f) v += *cp;
-                *cp = v;
+                for (int it = 0; it < RN_CG / 256 + 1; ++it) {
+                    const int c4 = lane - mis4 + 64 * it;
+                    cv[it] = (p.beta != 0.f && c4 >= 0 && c4 < n4) ? reinterpret_cast<const float4*>(crow)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int it = 0; it < RN_CG / 256 + 1; ++it) {
+                    const int c4 = lane - mis4 + 64 * it;
+                    if (c4 < 0 || c4 >= n4) continue;
+                    const float4 t = reinterpret_cast<const float4*>(trow)[c4];
+                    reinterpret_cast<float4*>(crow)[c4] = make_float4(t.x + cv[it].x, t.y + cv[it].y, t.z + cv[it].z, t.w + cv[it].w);
+                }
+            } else if (p.beta != 0.f) {
+                float cv[RN_CG / 64 + 1];
+#pragma unroll
+                for (int it = 0; it < RN_CG / 64 + 1; ++it) {
+                    const int c = lane - mis + 64 * it;
+                    cv[it] = (c >= 0 && c < ncols) ? crow[c] : 0.f;
+                }
+#pragma unroll
+                for (int it = 0; it < RN_CG / 64 + 1; ++it) {
+                    const int c = lane - mis + 64 * it;
+                    if (c >= 0 && c < ncols) crow[c] = trow[c] + cv[it];
+                }
+            } else {
+                for (int c = lane - mis; c < ncols; c += 64)
+                    if (c >= 0) crow[c] = trow[c];
             }
         }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) bc[i] = bn[i];
+        if (cg + RN_CG < p.N) __syncthreads();
     }
 }
 
@@ -716,7 +777,8 @@ int ttmi_launch_gemm(const GemmDesc& d, hipStream_t st) {
         (void)env_once;
         const bool plain = d.alpha == 1.f && (d.beta == 0.f || d.beta == 1.f) && d.splitk == 1 && d.drop.p <= 0.f && (long)d.nz1 * d.nz2 <= 65535;
         const bool ak = d.flags & GEMM_A_KMAJOR, bkm = d.flags & GEMM_B_KMAJOR;
-        if (g_x3_attn_kernels && plain && d.N == 64 && !bkm && p.vecB && (!ak || p.vecA) && !(d.flags & ~(GEMM_BF16X3 | GEMM_A_KMAJOR | GEMM_ATOMIC)) &&
+        // (a k-major slab that is not 16-byte aligned - the pitch-(L+1) view of dG - loads its fragments in single floats: 214 -> 178 us)
+        if (g_x3_attn_kernels && plain && d.N == 64 && !bkm && p.vecB && !(d.flags & ~(GEMM_BF16X3 | GEMM_A_KMAJOR | GEMM_ATOMIC)) &&
             (!(d.flags & GEMM_ATOMIC) || d.beta == 0.f)) {
             dim3 pg(cdiv(d.M, P64_BM), d.nz1 * d.nz2);
             static const int kc_env = [] { const char* e = getenv("TTMI_X3_KC"); return e ? atoi(e) : 0; }();
@@ -729,7 +791,18 @@ int ttmi_launch_gemm(const GemmDesc& d, hipStream_t st) {
         }
         if (g_x3_attn_kernels && plain && d.K == 64 && ak && bkm && p.vecA && p.vecB &&
             !(d.flags & ~(GEMM_BF16X3 | GEMM_A_KMAJOR | GEMM_B_KMAJOR | GEMM_BIAS))) {
-            hipLaunchKernelGGL(x3_rows_nt64_kernel, dim3(cdiv(d.M, 32), d.nz1 * d.nz2), dim3(NT), 0, st, p);
+            constexpr int rn_lds = 32 * RN_NP * 4;             // (the attribute call matters from 512-column passes on: 66.5 KB)
+            static bool rn_attr = false;
+            if (!rn_attr) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(x3_rows_nt64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, rn_lds) != hipSuccess) {
+                    ttmi_set_error("gemm: LDS attribute (x3_rows_nt64_kernel)");
+                    return TTMI_EINVAL;
+                }
+                rn_attr = true;
+            }
+            static const int rn_xcd = [] { const char* e = getenv("TTMI_X3_XCD"); return e ? atoi(e) : 1; }();
+            p.kchunk = rn_xcd;                                 // (K = 64 is fixed in this kernel: the field carries the numbering switch)
+            hipLaunchKernelGGL(x3_rows_nt64_kernel, dim3(cdiv(d.M, 32), d.nz1 * d.nz2), dim3(NT), rn_lds, st, p);
             TTMI_LAUNCH_CHECK("x3_rows_nt64_kernel");
             return TTMI_OK;
         }
