@@ -691,7 +691,7 @@ def main():
         if x3_form is not None:
             out["bf16x3_form"] = {"ms_per_step": round(1e3 * x3_form / fp32_steps, 3), "value": round(world * B * fp32_steps / x3_form, 3), "unit": "utt/s",
                                   "dtype": "f32 data, bf16 MFMA in three terms", "steps": fp32_steps,
-                                  "note": "TTMI_PRECISION=bf16x3: the fp32 mode's data flow with its large dense products as hi.hi + lo.hi + hi.lo on the bf16 MFMA "
+                                  "note": "TTMI_PRECISION=bf16x3: the fp32 mode's data flow with its dense and attention-core products as hi.hi + lo.hi + hi.lo on the bf16 MFMA "
                                           "(~2^-16 relative per product); loss and every gradient within 1e-4 of the float64 oracle "
                                           "(tests/test_configs_gpu.py::test_c2_full_model_fp32_end_to_end[bf16x3]): the quick parity mode"}
         if world == 1 and not args.no_cpu_baseline:
