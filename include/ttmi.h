@@ -89,6 +89,9 @@ size_t ttmi_joint_ws_floats(int B, int T, int U1, int J, int V);
 /* the same for a given precision code: prec 2 (TTMI_PRECISION=bf16x3: the f32 data flow of prec 0 with its large dense products on the bf16
  * MFMA in three terms, hi . hi + lo . hi + hi . lo) needs room for the split operands behind the ordinary workspace */
 size_t ttmi_joint_ws_floats_prec(int B, int T, int U1, int J, int V, int prec);
+/* ... and ctx: prec 2 keeps the hidden rows as two bf16 blocks [hi | lo] instead of one f32, columns padded to a multiple of 64: callers that
+ * pass prec 2 to ttmi_joint_fwd / ttmi_joint_bwd size ctx with this one (the same size as ttmi_joint_ctx_floats when J % 64 == 0) */
+size_t ttmi_joint_ctx_floats_prec(int B, int T, int U1, int J, int prec);
 int ttmi_joint_fwd(const float* enc, const float* dec, const float* wf, const float* bf, const float* wp, const float* bp,
                    int B, int T, int U1, int de, int dd, int J, int V, int prec, float* ctx, float* ws, void* logits, long ldv,
                    void* stream);
@@ -277,6 +280,10 @@ int ttmi_gemm_nt_bf16(const void* A, const void* B, void* C, int c_dtype, const 
  * kernels walk A's K-tiles a second time against B_lo, the 128x128 kernel takes (A, B_lo) as its second operand pair */
 int ttmi_gemm_nt_bf16_two_term(const void* A, const void* B, const void* B_lo, void* C, int c_dtype, const float* bias, int relu, int M, int N, int K,
                                long lda, long ldb, long ldc, void* stream);
+/* ... with the second walk limited to A's first k_lo columns (0 = all K): C = act(A.B^T + A[:, :k_lo].B_lo[:, :k_lo]^T + bias) - the layout of the
+ * bf16x3 products, A = [hi | lo], B = [hi | hi], B_lo = lo (k_lo = K / 2) */
+int ttmi_gemm_nt_bf16_two_term_klo(const void* A, const void* B, const void* B_lo, void* C, int c_dtype, const float* bias, int relu, int M, int N, int K,
+                                   int k_lo, long lda, long ldb, long ldc, void* stream);
 /* bring-up entry of the "exp store" epilogue of the persistent 256x256 kernel: C = bf16(exp(A.B^T + bias - shift)) with zeros in columns [N, ldc),
  * rowsum [nparts, M] = per-row partial sums (nparts >= 4 * ceil(N / 256); the entries of a row add up to its sum of exponentials) */
 int ttmi_gemm_nt_bf16_exp(const void* A, const void* B, void* C, const float* bias, float* rowsum, int nparts, const float* shift /* device, nullable */, int M, int N, int K,

@@ -262,3 +262,23 @@ def test_two_term_weight_one_launch_exact(M, N, K, gen, cdt):
             want = want.clamp_min(0)
         assert torch.equal(C[:M], want.to(cdt))
         assert bool((C[M] == 5.0).all())
+
+
+@pytest.mark.parametrize("M,N,Kh,gen", [(6400, 1536, 512, 9), (6400, 512, 2048, 8), (3001, 700, 128, 9), (3001, 700, 128, 8), (6400, 2048, 512, 4),
+                                        (1000, 1536, 512, 4), (77, 130, 64, 4)])
+def test_two_term_weight_second_walk_over_a_prefix_exact(M, N, Kh, gen):
+    """NtEpilogue::K_lo (the bf16x3 products' layout): A = [A1 | A2] (K = 2 Kh), B = [B1 | B2] with pitch 3 Kh and B_lo = the third block of B's rows:
+    C = A1 B1^T + A2 B2^T + A1 B_lo^T in one launch - exact on small integers on both persistent generations, the default route and the 128 x 128 kernel"""
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + Kh + gen)
+    A, B3 = _ints((M, 2 * Kh), g), _ints((N, 3 * Kh), g)
+    bias = torch.randint(-3, 4, (N,), device="cuda", generator=g).float()
+    C = torch.full((M + 1, N), 5.0, device="cuda")
+    ops.set_option(1, gen)
+    try:
+        ops.gemm_nt_bf16_two_term(A, B3[:, :2 * Kh], B3[:, 2 * Kh:], C[:M], bias, False, k_lo=Kh)
+    finally:
+        ops.set_option(1, 4)
+    want = A.float() @ B3[:, :2 * Kh].float().t() + A[:, :Kh].float() @ B3[:, 2 * Kh:].float().t() + bias
+    assert torch.equal(C[:M], want)
+    assert bool((C[M] == 5.0).all())

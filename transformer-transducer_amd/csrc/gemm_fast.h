@@ -35,6 +35,9 @@ struct NtEpilogue {
     // second bf16 term of the weight (B ~ B + B_lo, same shape and pitch): C = epi(A.(B + B_lo)^T) in ONE launch of the persistent kernels,
     // which walk A's K-tiles a second time against B_lo, or of the 128x128 kernel (as its second operand pair)
     const bf16_t* B_lo = nullptr;
+    // ... with K_lo != 0 the second walk covers A's first K_lo columns only: C = epi(A.B^T + A[:, :K_lo].B_lo[:, :K_lo]^T) - the bf16x3 products,
+    // A = [hi | lo], B = [hi | hi], B_lo = lo: hi.hi + lo.hi + hi.lo without a third copy of A's hi block (K_lo % 64 == 0, <= K)
+    int K_lo = 0;
 };
 // C[M,N] = epilogue(A[M,K] . B[N,K]^T); c_dtype 0 = f32, 1 = bf16
 int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const NtEpilogue& epi, int M, int N, int K, long lda,

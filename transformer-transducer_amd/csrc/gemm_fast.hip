@@ -2477,6 +2477,8 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     const bool two_term = epi.B_lo != nullptr;
     TTMI_REQUIRE(!two_term || (!dual && aligned16(epi.B_lo) && (g_gemm_fast_version == 4 || g_gemm_fast_version == 8 || g_gemm_fast_version == 9)),
                  "gemm_nt_bf16: a second weight term needs a 16-byte aligned B_lo, no second operand pair and the default kernel generations");
+    const int k_lo = two_term ? (epi.K_lo ? epi.K_lo : K) : 0;      // columns of A that meet B_lo
+    TTMI_REQUIRE(!two_term || (k_lo > 0 && k_lo <= K && (k_lo == K || k_lo % TK == 0)), "gemm_nt_bf16: K_lo = %d must be a multiple of %d inside K = %d", k_lo, TK, K);
     if (dual) TTMI_REQUIRE(epi.B2 && epi.K2 >= 8 && epi.K2 % 8 == 0 && aligned16(epi.A2) && aligned16(epi.B2) && epi.lda2 % 8 == 0 && epi.ldb2 % 8 == 0 &&
                            c_dtype == 1, "gemm_nt_bf16: bad second operand pair");
     fill_batch(p, batch);
@@ -2498,7 +2500,7 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     TTMI_REQUIRE(!needs8 || (v8 && c_dtype == 1), "gemm_nt_bf16: the exp-store / row-scale epilogues exist on the persistent 256x256 kernel only (M=%d N=%d K=%d)", M, N, K);
     const bool v9 = !needs8 && pers && ((g_gemm_fast_version == 9) || (g_gemm_fast_version == 4 && t9 >= g_num_cus * 3 / 4 && cost9 <= cost8));
     if (v9) {
-        if (two_term) { p.B2 = epi.B_lo; p.kwrap = K / TK; p.K = 2 * K; }
+        if (two_term) { p.B2 = epi.B_lo; p.kwrap = K / TK; p.K = K + k_lo; }
         p.tiles_m = cdiv(M, T9M); p.tiles_n = cdiv(N, T9N);
         // a persistent grid larger than the CUs that are actually free runs its surplus workgroups AFTER the others (twice the time):
         // with gradient all-reduce kernels resident during backward, leave them room (multi-GPU runs set option 6)
@@ -2559,7 +2561,7 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     }
     // persistent 256x256 kernel: needs several rounds of tiles per CU to amortise its pipeline fill and tail
     if (v8) {
-        if (two_term) { p.B2 = epi.B_lo; p.kwrap = K / TK; p.K = 2 * K; }
+        if (two_term) { p.B2 = epi.B_lo; p.kwrap = K / TK; p.K = K + k_lo; }
         p.tiles_m = cdiv(M, T8); p.tiles_n = cdiv(N, T8);
         const long nwg8 = (long)p.tiles_m * p.tiles_n;
 const int cus8 = nwg8 < 1024 ? std::max(8, (g_num_cus - reserved) / 8 * 8) : g_num_cus;   // encoder-sized problems only (see v9)
@@ -2631,7 +2633,7 @@ if (p.kwrap) {
     const int ver = g_gemm_fast_version;
 #define NT_LAUNCH(TCT, NB, PP) hipLaunchKernelGGL((gemm_nt_bf16_kernel<TCT, NB, PP>), dim3((unsigned)nwg, nbatch), dim3(NTH), 2 * NB * TILE_B, st, p)
     if (two_term) {
-        p.A2 = A; p.B2 = epi.B_lo; p.K2 = K; p.lda2 = lda; p.ldb2 = ldb; p.sB1b = p.sB1; p.sB2b = p.sB2; p.colsum_mid = nullptr;
+        p.A2 = A; p.B2 = epi.B_lo; p.K2 = k_lo; p.lda2 = lda; p.ldb2 = ldb; p.sB1b = p.sB1; p.sB2b = p.sB2; p.colsum_mid = nullptr;
     }
     if (dual || two_term) {
         if (c_dtype == 1) hipLaunchKernelGGL((gemm_nt_bf16_kernel<bf16_t, 1, false, true>), dim3((unsigned)nwg, nbatch), dim3(NTH), 2 * TILE_B, st, p);
@@ -2903,6 +2905,13 @@ int ttmi_gemm_nt_bf16_two_term(const void* A, const void* B, const void* B_lo, v
                                long lda, long ldb, long ldc, void* stream) {
     NtEpilogue e;
     e.bias = bias; e.relu = relu; e.B_lo = static_cast<const bf16_t*>(B_lo);
+    return gemm_nt_bf16(static_cast<const bf16_t*>(A), static_cast<const bf16_t*>(B), C, c_dtype, e, M, N, K, lda, ldb, ldc,
+                        static_cast<hipStream_t>(stream), FastBatch());
+}
+int ttmi_gemm_nt_bf16_two_term_klo(const void* A, const void* B, const void* B_lo, void* C, int c_dtype, const float* bias, int relu, int M, int N, int K,
+                                   int k_lo, long lda, long ldb, long ldc, void* stream) {
+    NtEpilogue e;
+    e.bias = bias; e.relu = relu; e.B_lo = static_cast<const bf16_t*>(B_lo); e.K_lo = k_lo;
     return gemm_nt_bf16(static_cast<const bf16_t*>(A), static_cast<const bf16_t*>(B), C, c_dtype, e, M, N, K, lda, ldb, ldc,
                         static_cast<hipStream_t>(stream), FastBatch());
 }

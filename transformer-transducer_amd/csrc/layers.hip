@@ -69,25 +69,38 @@ inline size_t x3_nt_elems(long M, long N, int K) { return x3_al((size_t)M * 3 * 
 inline size_t x3_tn_elems(long K, int M, int N) { return x3_al((size_t)K * 2 * x3_pad(M)) + x3_al((size_t)K * 2 * x3_pad(N)); }
 // big enough to be worth two split passes and the throughput kernels
 inline bool x3_worth(long M, long N, long K) { return M >= 256 && N >= 64 && K >= 64 && M * N * K >= (1L << 27); }
+// Two layouts of the same three terms.  Products with thousands of rows (the audio encoder, the joint) run on the persistent kernels, whose K loop can
+// walk A's first K-tiles a second time against another B (NtEpilogue::B_lo / K_lo): A = [hi | lo], B = [hi | hi] with B_lo = lo - no third copy of A's
+// hi block is written or read.  The smaller ones keep A = [hi | lo | hi] against B = [hi | hi | lo] in one plain launch (the 64 x 64-tile kernel).
+inline bool x3_two_block(long M) { return M >= 4096; }
+static int x3_launch(const bf16_t* A3, const bf16_t* B3, float* C, int M, int N, int Kp, long ldc, const NtEpilogue& e, bool two_block, hipStream_t st) {
+    if (!two_block) return gemm_nt_bf16(A3, B3, C, 0, e, M, N, 3 * Kp, 3L * Kp, 3L * Kp, ldc, st);
+    NtEpilogue e2 = e;
+    e2.B_lo = B3 + 2 * Kp;
+    e2.K_lo = Kp;
+    return gemm_nt_bf16(A3, B3, C, 0, e2, M, N, 2 * Kp, 2L * Kp, 3L * Kp, ldc, st);
+}
 // C[M,N] = epi(A[M,K] . B[N,K]^T)
 int x3_nt(const float* A, const float* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, const NtEpilogue& e, bf16_t* scratch,
           hipStream_t st) {
     const int Kp = x3_pad(K);
+    const bool two = x3_two_block(M);
     bf16_t* A3 = scratch;
     bf16_t* B3 = A3 + x3_al((size_t)M * 3 * Kp);
-    CK(split3_bf16(A, lda, M, K, Kp, 0, A3, st));
+    CK(split3_bf16(A, lda, M, K, Kp, two ? 2 : 0, A3, st));
     CK(split3_bf16(B, ldb, N, K, Kp, 1, B3, st));
-    return gemm_nt_bf16(A3, B3, C, 0, e, M, N, 3 * Kp, 3L * Kp, 3L * Kp, ldc, st);
+    return x3_launch(A3, B3, C, M, N, Kp, ldc, e, two, st);
 }
 // C[M,N] = epi(A[M,K] . B[K,N]) (B row-major [K, N]: a dgrad against the weight as stored)
 int x3_nn(const float* A, const float* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, const NtEpilogue& e, bf16_t* scratch,
           hipStream_t st) {
     const int Kp = x3_pad(K);
+    const bool two = x3_two_block(M);
     bf16_t* A3 = scratch;
     bf16_t* B3 = A3 + x3_al((size_t)M * 3 * Kp);
-    CK(split3_bf16(A, lda, M, K, Kp, 0, A3, st));
+    CK(split3_bf16(A, lda, M, K, Kp, two ? 2 : 0, A3, st));
     CK(split3_transpose_bf16(B, ldb, K, N, Kp, true, B3, st));
-    return gemm_nt_bf16(A3, B3, C, 0, e, M, N, 3 * Kp, 3L * Kp, 3L * Kp, ldc, st);
+    return x3_launch(A3, B3, C, M, N, Kp, ldc, e, two, st);
 }
 // C[M,N] += A[K,M]^T . B[K,N] (atomically: a weight gradient)
 int x3_tn(const float* A, const float* B, float* C, int M, int N, long K, long lda, long ldb, long ldc, bf16_t* scratch, hipStream_t st) {
@@ -1146,6 +1159,15 @@ int ttmi_joint_logits_dtype(int prec, int J) { return joint_fast(prec, J) ? 1 : 
 
 // (room for the lattice rows padded to 64: the exp-domain wgrad reduces over whole 64-row K-tiles, ttmi_joint_exp_padded_rows)
 size_t ttmi_joint_ctx_floats(int B, int T, int U1, int J) { return al4(((size_t)B * T * U1 + 63) / 64 * 64 * J); }
+// prec 2 keeps H as two bf16 blocks per row [hi | lo] (columns padded to 64) instead of one f32: the same size unless J is no multiple of 64
+size_t ttmi_joint_ctx_floats_prec(int B, int T, int U1, int J, int prec) {
+    const size_t f = ttmi_joint_ctx_floats(B, T, U1, J);
+    if (prec != 2) return f;
+    const size_t x = al4((size_t)B * T * U1 * x3_pad(J) + 64);
+    return x > f ? x : f;
+}
+// does the joint of this size run its bf16x3 form with H in three-block rows (prec 2 only)?
+static bool joint_x3_h3(long M, int V, int J) { return x3_worth(M, V, J) && J % 4 == 0; }
 size_t ttmi_joint_ws_floats(int B, int T, int U1, int J, int V) {
     return al4((size_t)B * T * U1 * J) + 2 * al4((size_t)B * T * J) + 2 * al4((size_t)B * U1 * J) +
            al4((size_t)J * (((size_t)V + 63) / 64 * 64));
@@ -1213,6 +1235,23 @@ static int joint_fwd_impl(const float* enc, const float* dec, const float* wf, c
             CK(ttmi_launch_gemm(g2, st));
         }
     }
+    if (!fast && prec == 2 && joint_x3_h3(M, V, J)) {
+        // bf16x3: the projection in three bf16 terms on the throughput kernel.  H leaves the tanh kernel already split - ctx holds the rows
+        // [hi | lo] (ttmi_joint_ctx_floats_prec) the GEMM reads, its hi block a second time against the weight's lo block - and only the
+        // weight is split here ([hi | hi | lo], behind the workspace)
+        const int Jp = x3_pad(J);
+        bf16_t* H2 = reinterpret_cast<bf16_t*>(ctx);
+        bf16_t* W3 = reinterpret_cast<bf16_t*>(ws + ((ttmi_joint_ws_floats(B, T, U1, J, V) + 63) & ~(size_t)63));
+        CK(joint_tanh_fwd_x3(PE, PD, bf, B, T, U1, J, Jp, H2, st));
+        CK(split3_bf16(wp, J, V, J, Jp, 1, W3, st));
+        NtEpilogue e3;
+        e3.bias = bp;
+        ttmi_probe_begin(0, st);
+        const int rc = x3_launch(H2, W3, static_cast<float*>(logits), M, V, Jp, ldv, e3, true, st);
+        ttmi_probe_end(0, st);
+        CK(rc);
+        return TTMI_OK;
+    }
     if (!fast) {
         float* Hh = ctx;
         CK(joint_tanh_fwd(PE, PD, bf, B, T, U1, J, Hh, 0, st));
@@ -1220,7 +1259,7 @@ static int joint_fwd_impl(const float* enc, const float* dec, const float* wf, c
         g.bias = bp;
         ttmi_probe_begin(0, st);
         int rc;
-        if (prec == 2 && x3_worth(M, V, J)) {       // bf16x3: the projection in three bf16 terms on the throughput kernel (scratch behind the workspace)
+        if (prec == 2 && x3_worth(M, V, J)) {       // (J % 4 != 0: f32 H, split by a pass of its own)
             NtEpilogue e3;
             e3.bias = bp;
             bf16_t* x3 = reinterpret_cast<bf16_t*>(ws + ((ttmi_joint_ws_floats(B, T, U1, J, V) + 63) & ~(size_t)63));
@@ -1303,27 +1342,34 @@ static int joint_bwd_impl(const void* dlogits, long ldg, const float* enc, const
         const float* dZ = static_cast<const float*>(dlogits);
         float* dH = ws;
         if (prec == 2 && x3_worth(M, V, J)) {
-            // bf16x3: ONE three-block split of dZ ([hi | lo | hi], 14 GB read once at C2) serves the dgrad (the tripled reduction) and, as its
-            // first two blocks, the wgrad's planes; g_bp = column sums of dZ ride in the wgrad launches (hi + lo: dZ to 2^-17 per element)
+            // bf16x3: ONE split of dZ ([hi | lo], 14 GB read once at C2) serves the dgrad (three terms: K_lo) and, as planes, the wgrad; g_bp = column sums of dZ ride in the wgrad launches (hi + lo: dZ to 2^-17 per element)
             bf16_t* x3 = reinterpret_cast<bf16_t*>(ws + ((ttmi_joint_ws_floats(B, T, U1, J, V) + 63) & ~(size_t)63));
             const int Vp = x3_pad(V), Jp = x3_pad(J);
-            bf16_t* Z3 = x3;
-            bf16_t* H2 = Z3 + x3_al((size_t)M * 3 * Vp);
+            bf16_t* Z2 = x3;                                // [hi | lo] rows of dZ (room for three blocks: joint_x3_floats)
+            bf16_t* H2 = Z2 + x3_al((size_t)M * 3 * Vp);
             bf16_t* WT3 = H2 + x3_al((size_t)M * 2 * Jp);
-            CK(split3_bf16(dZ, ldg, M, V, Vp, 0, Z3, st));
-            CK(split3_bf16(Hh, J, M, J, Jp, 2, H2, st));
+            const bool h3 = joint_x3_h3(M, V, J);          // the forward left H as [hi | lo] rows in ctx: they ARE the planes
+            if (h3) H2 = reinterpret_cast<bf16_t*>(ctx);
+            else CK(split3_bf16(Hh, J, M, J, Jp, 2, H2, st));
+            CK(split3_bf16(dZ, ldg, M, V, Vp, 2, Z2, st));
             CK(split3_transpose_bf16(wp, J, V, J, Vp, true, WT3, st));
-            CK(gemm_tn_bf16(Z3, H2, g_wp, V, J, M, 3L * Vp, 2L * Jp, J, 1, st, g_bp));
-            CK(gemm_tn_bf16(Z3 + Vp, H2, g_wp, V, J, M, 3L * Vp, 2L * Jp, J, 1, st, g_bp));
-            CK(gemm_tn_bf16(Z3, H2 + Jp, g_wp, V, J, M, 3L * Vp, 2L * Jp, J, 1, st));
-            CK(gemm_nt_bf16(Z3, WT3, dH, 0, NtEpilogue(), M, J, 3 * Vp, 3L * Vp, 3L * Vp, J, st));
+            CK(gemm_tn_bf16(Z2, H2, g_wp, V, J, M, 2L * Vp, 2L * Jp, J, 1, st, g_bp));
+            CK(gemm_tn_bf16(Z2 + Vp, H2, g_wp, V, J, M, 2L * Vp, 2L * Jp, J, 1, st, g_bp));
+            CK(gemm_tn_bf16(Z2, H2 + Jp, g_wp, V, J, M, 2L * Vp, 2L * Jp, J, 1, st));
+            CK(x3_launch(Z2, WT3, dH, M, J, Vp, J, NtEpilogue(), true, st));       // dgrad: the hi block of dZ a second time against the weight's lo block
+            if (h3) {
+                CK(fill_zero(dPD, sizeof(float) * (size_t)B * U1 * J, st));
+                CK(joint_tanh_bwd_x3(dH, H2, B, T, U1, J, Jp, dPE, dPD, st));
+            }
         } else {
             CK(colsum(dZ, ldg, M, V, 1, 1, 0, 0, 0, 0, g_bp, st));
             CK(wgrad(dZ, Hh, g_wp, V, J, M, ldg, J, J, prec, st));
             CK(ttmi_launch_gemm(mk(dZ, wp, dH, M, J, V, ldg, J, J, NN_, prec), st));
         }
-        CK(fill_zero(dPD, sizeof(float) * (size_t)B * U1 * J, st));
-        CK(joint_tanh_bwd(dH, Hh, 0, B, T, U1, J, dPE, dPD, st));
+        if (!(prec == 2 && joint_x3_h3(M, V, J))) {
+            CK(fill_zero(dPD, sizeof(float) * (size_t)B * U1 * J, st));
+            CK(joint_tanh_bwd(dH, Hh, 0, B, T, U1, J, dPE, dPD, st));
+        }
     } else {
         TTMI_REQUIRE(ldg % 8 == 0 && aligned16(dlogits), "joint_bwd: bf16 dlogits need 16-byte alignment and pitch %% 8 == 0");
         const bf16_t* H16 = reinterpret_cast<const bf16_t*>(ctx);

@@ -984,6 +984,74 @@ __global__ __launch_bounds__(256) void joint_tanh_bwd_kernel(const TH* __restric
         if (t0 + tt < T) dPE[((long)b * T + t0 + tt) * J + j] = accE[tt];
 }
 
+// bf16x3 (round 5): H never exists in f32.  It leaves the forward kernel as the two-block row [hi | lo] (hi = bf16(h), lo = bf16(h - hi); pitch
+// 2 Jp bf16, columns [J, Jp) of both blocks zero) - the A operand of the three-term projection as that GEMM reads it (the hi block twice: NtEpilogue::K_lo)
+// and the planes of the weight gradient - and the backward forms 1 - (hi + lo)^2.  Saves the split pass over H in the forward and the one in the
+// backward (2 x 6.6 GB at C2).  tanh through v_exp_f32 / v_rcp_f32: absolute error ~1e-7, below the 2^-17 of the split itself.
+__global__ __launch_bounds__(256) void joint_tanh_fwd_x3_kernel(const float* __restrict__ PE, const float* __restrict__ PD,
+                                                                const float* __restrict__ bias, int T, int U1, int J, int Jp,
+                                                                bf16_t* __restrict__ H3) {
+    const long bt = blockIdx.x;
+    const int b = (int)(bt / T);
+    for (int j = threadIdx.x * 4; j < Jp; j += 1024) {
+        bf16_t* h = H3 + bt * U1 * 2 * Jp + j;
+        if (j >= J) {                                   // pad columns (J % 4 == 0: a thread's four columns are all real or all pad)
+            for (int u = 0; u < U1; ++u) {
+                bf16_t* row = h + (long)u * 2 * Jp;
+                *reinterpret_cast<uint2*>(row) = make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(row + Jp) = make_uint2(0u, 0u);
+            }
+            continue;
+        }
+        const float4 pe = *reinterpret_cast<const float4*>(PE + bt * J + j), bi = *reinterpret_cast<const float4*>(bias + j);
+        const float e0 = pe.x + bi.x, e1 = pe.y + bi.y, e2 = pe.z + bi.z, e3 = pe.w + bi.w;
+        const float* pd = PD + (long)b * U1 * J + j;
+#pragma unroll 3
+        for (int u = 0; u < U1; ++u) {
+            const float4 d = *reinterpret_cast<const float4*>(pd + (long)u * J);
+            const float t0 = fast_tanh(e0 + d.x), t1 = fast_tanh(e1 + d.y), t2 = fast_tanh(e2 + d.z), t3 = fast_tanh(e3 + d.w);
+            uint2 hi, lo;
+            hi.x = pack_bf16x2(t0, t1);
+            hi.y = pack_bf16x2(t2, t3);
+            lo.x = pack_bf16x2(t0 - __uint_as_float(hi.x << 16), t1 - __uint_as_float(hi.x & 0xffff0000u));
+            lo.y = pack_bf16x2(t2 - __uint_as_float(hi.y << 16), t3 - __uint_as_float(hi.y & 0xffff0000u));
+            bf16_t* row = h + (long)u * 2 * Jp;
+            *reinterpret_cast<uint2*>(row) = hi;
+            *reinterpret_cast<uint2*>(row + Jp) = lo;
+        }
+    }
+}
+
+// dpre = dH (1 - H^2) with H = hi + lo from the two-block rows; dPE[b,t,:] = sum_u dpre, dPD[b,u,:] += sum_t dpre (the f32 kernel's structure)
+__global__ __launch_bounds__(256) void joint_tanh_bwd_x3_kernel(const float* __restrict__ dH, const bf16_t* __restrict__ H3, int T, int U1, int J,
+                                                                int Jp, float* __restrict__ dPE, float* __restrict__ dPD) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= J) return;
+    const int t0 = blockIdx.y * JT_TC;
+    const int b = blockIdx.z;
+    float accE[JT_TC];
+#pragma unroll
+    for (int i = 0; i < JT_TC; ++i) accE[i] = 0.f;
+    for (int u = 0; u < U1; ++u) {
+        float accD = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < JT_TC; ++tt) {
+            const int t = t0 + tt;
+            if (t < T) {
+                const long row = ((long)b * T + t) * U1 + u;
+                const float h = bf16_to_f32(H3[row * 2 * Jp + j]) + bf16_to_f32(H3[row * 2 * Jp + Jp + j]);
+                const float v = dH[row * J + j] * (1.f - h * h);
+                accE[tt] += v;
+                accD += v;
+            }
+        }
+        atomicAdd(dPD + ((long)b * U1 + u) * J + j, accD);
+    }
+#pragma unroll
+    for (int tt = 0; tt < JT_TC; ++tt)
+        if (t0 + tt < T) dPE[((long)b * T + t0 + tt) * J + j] = accE[tt];
+}
+
 constexpr int JT_TC4 = 16;     // frames per block of the kernel below (32: fewer atomics but 0.52 -> 0.87 ms, too few blocks in flight; measured round 3)
 // bf16 pipeline: dP = dH * (1 - H^2) was already formed in the dgrad GEMM's epilogue; this only reduces it:
 // dPE[b,t,:] = sum_u dP[b,t,u,:], dPD[b,u,:] += sum_t dP[b,t,u,:].  4 columns per thread, 8-byte loads.
@@ -1571,6 +1639,20 @@ int joint_tanh_bwd(const void* dH, const void* H, int h_dtype, int B, int T, int
         hipLaunchKernelGGL(joint_tanh_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, static_cast<const bf16_t*>(dH),
                            static_cast<const bf16_t*>(H), T, U1, J, dPE, dPD);
     TTMI_LAUNCH_CHECK("joint_tanh_bwd_kernel");
+    return TTMI_OK;
+}
+
+int joint_tanh_fwd_x3(const float* PE, const float* PD, const float* bias, int B, int T, int U1, int J, int Jp, bf16_t* H3, hipStream_t st) {
+    TTMI_REQUIRE(PE && PD && bias && H3 && B > 0 && T > 0 && U1 > 0 && J > 0 && J % 4 == 0 && Jp >= J && Jp % 4 == 0 && aligned16(PE) && aligned16(PD) &&
+                 aligned16(bias) && aligned16(H3), "joint_tanh_fwd_x3: bad arguments");
+    hipLaunchKernelGGL(joint_tanh_fwd_x3_kernel, dim3(B * T), dim3(256), 0, st, PE, PD, bias, T, U1, J, Jp, H3);
+    TTMI_LAUNCH_CHECK("joint_tanh_fwd_x3_kernel");
+    return TTMI_OK;
+}
+int joint_tanh_bwd_x3(const float* dH, const bf16_t* H3, int B, int T, int U1, int J, int Jp, float* dPE, float* dPD, hipStream_t st) {
+    TTMI_REQUIRE(dH && H3 && dPE && dPD && B > 0 && T > 0 && U1 > 0 && J > 0 && Jp >= J, "joint_tanh_bwd_x3: bad arguments");
+    hipLaunchKernelGGL(joint_tanh_bwd_x3_kernel, dim3(cdiv(J, 256), cdiv(T, JT_TC), B), dim3(256), 0, st, dH, H3, T, U1, J, Jp, dPE, dPD);
+    TTMI_LAUNCH_CHECK("joint_tanh_bwd_x3_kernel");
     return TTMI_OK;
 }
 

@@ -430,9 +430,9 @@ def joint_fwd(enc, dec, wf, bf, wp, bp, prec):
     U1, dd = dec.shape[1], dec.shape[2]
     J, V = wf.shape[0], wp.shape[0]
     L_ = lib()
-    L_.ttmi_joint_ctx_floats.restype = ctypes.c_size_t
+    L_.ttmi_joint_ctx_floats_prec.restype = ctypes.c_size_t
     L_.ttmi_joint_ws_floats_prec.restype = ctypes.c_size_t
-    ctx = _f32(L_.ttmi_joint_ctx_floats(c_int(B), c_int(T), c_int(U1), c_int(J)), enc.device)
+    ctx = _f32(L_.ttmi_joint_ctx_floats_prec(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(prec)), enc.device)
     ws = scratch(L_.ttmi_joint_ws_floats_prec(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(V), c_int(prec)), enc.device)
     dt = joint_logits_dtype(prec, J)
     if dt is torch.bfloat16:
@@ -498,9 +498,9 @@ def joint_fwd_exp(enc, dec, wf, bf, wp, bp, prec, shift=None, labels=None, blank
     U1, dd = dec.shape[1], dec.shape[2]
     J, V = wf.shape[0], wp.shape[0]
     L_ = lib()
-    L_.ttmi_joint_ctx_floats.restype = ctypes.c_size_t
+    L_.ttmi_joint_ctx_floats_prec.restype = ctypes.c_size_t
     L_.ttmi_joint_ws_floats_prec.restype = ctypes.c_size_t
-    ctx = _f32(L_.ttmi_joint_ctx_floats(c_int(B), c_int(T), c_int(U1), c_int(J)), enc.device)
+    ctx = _f32(L_.ttmi_joint_ctx_floats_prec(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(prec)), enc.device)
     ws = scratch(L_.ttmi_joint_ws_floats_prec(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(V), c_int(prec)), enc.device)
     # room for the lattice rows padded to the wgrad's 64-row reduction tile (ttmi_joint_bwd_exp zero-fills the pad rows: include/ttmi.h)
     rows, ldv = B * T * U1, (V + 63) // 64 * 64
@@ -630,11 +630,16 @@ def gemm_nt_bf16(A, B, C, bias=None):
     return C
 
 
-def gemm_nt_bf16_two_term(A, B, B_lo, C, bias=None, relu=False):
-    """C[M,N] = act(A[M,K] @ (B + B_lo)[N,K]^T + bias) in one launch."""
+def gemm_nt_bf16_two_term(A, B, B_lo, C, bias=None, relu=False, k_lo=0):
+    """C[M,N] = act(A[M,K] @ (B + B_lo)[N,K]^T + bias) in one launch; k_lo != 0: B_lo meets A's first k_lo columns only."""
     M, K = A.shape
     N = B.shape[0]
-    assert B_lo.shape == B.shape and B_lo.stride(0) == B.stride(0)
+    assert B_lo.shape[0] == B.shape[0] and B_lo.stride(0) == B.stride(0)
+    if k_lo:
+        check(lib().ttmi_gemm_nt_bf16_two_term_klo(_p(A), _p(B), _p(B_lo), _p(C), c_int(_DT[C.dtype]), _p(bias), c_int(1 if relu else 0), c_int(M),
+                                                   c_int(N), c_int(K), c_int(k_lo), c_long(A.stride(0)), c_long(B.stride(0)), c_long(C.stride(0)), _stream()),
+              "ttmi_gemm_nt_bf16_two_term_klo")
+        return C
     check(lib().ttmi_gemm_nt_bf16_two_term(_p(A), _p(B), _p(B_lo), _p(C), c_int(_DT[C.dtype]), _p(bias), c_int(1 if relu else 0), c_int(M),
                                            c_int(N), c_int(K), c_long(A.stride(0)), c_long(B.stride(0)), c_long(C.stride(0)), _stream()),
           "ttmi_gemm_nt_bf16_two_term")
