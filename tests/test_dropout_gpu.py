@@ -105,9 +105,11 @@ def test_full_size_layer_on_the_persistent_kernels_matches_oracle(monkeypatch):
         assert rel_err(prm_t.grad.cpu().numpy(), g[names[n]]) < 6e-2, n
 
 
-def test_bf16x3_layer_with_dropout_matches_oracle_with_same_masks(monkeypatch):
-    """TTMI_PRECISION=bf16x3 at a size where its dense products take the three-term route (1024 rows, d = 512, Di = 1024: x3_worth in
-    csrc/layers.hip) in TRAINING mode: the FFN's bias + ReLU + dropout epilogue on the tripled-K kernel, the ReLU' / dropout mask of its
+@pytest.mark.parametrize("B", [8, 40])
+def test_bf16x3_layer_with_dropout_matches_oracle_with_same_masks(monkeypatch, B):
+    """TTMI_PRECISION=bf16x3 at sizes where its dense products take the three-term route (1024 rows: operands as [hi | lo | hi] x [hi | hi | lo] in one
+    plain launch; 5120 rows: [hi | lo] x [hi | hi] with the hi block walked a second time against the weight's lo block on the persistent kernels,
+    one split of dY shared by a sub-layer's weight and input gradients; d = 512, Di = 1024: x3_worth / x3_two_block in csrc/layers.hip) in TRAINING mode: the FFN's bias + ReLU + dropout epilogue on the tripled-K kernel, the ReLU' / dropout mask of its
     dgrad as a pass of its own (relu_mask_scale), the residual accumulation of the qkv dgrad - forward, dx and every parameter gradient
     against the float64 oracle fed the same masks AND the ReLU decisions the HIP path took (one of the 1 M hidden units decided differently -
     a pre-activation within rounding noise of zero - moves the bias gradient by 1e-3 at this size), at the exact-f32 mode's 1e-4."""
@@ -115,7 +117,7 @@ def test_bf16x3_layer_with_dropout_matches_oracle_with_same_masks(monkeypatch):
     from ttmi import ops
     from ttmi.ops import MaskSpec
     monkeypatch.setenv("TTMI_PRECISION", "bf16x3")
-    p, B, L, d, Di, H, Dh = 0.2, 8, 128, 512, 1024, 8, 64
+    p, L, d, Di, H, Dh = 0.2, 128, 512, 1024, 8, 64
     torch.manual_seed(5)
     layer = BaseEncoder(k_len=96, n_head=H, d_model=d, d_head=Dh, d_inner=Di, dropout=p).cuda().train()
     x = torch.randn(B, L, d, generator=torch.Generator().manual_seed(3))

@@ -92,13 +92,15 @@ int x3_nt(const float* A, const float* B, float* C, int M, int N, int K, long ld
     return x3_launch(A3, B3, C, M, N, Kp, ldc, e, two, st);
 }
 // C[M,N] = epi(A[M,K] . B[K,N]) (B row-major [K, N]: a dgrad against the weight as stored)
+// a_ready: the [hi | lo] rows of A already sit at the head of `scratch` - left there by the x3_tn of the same A just before (a sub-layer's weight gradient
+// and its input gradient read the same dY: one split pass instead of two)
 int x3_nn(const float* A, const float* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, const NtEpilogue& e, bf16_t* scratch,
-          hipStream_t st) {
+          hipStream_t st, bool a_ready = false) {
     const int Kp = x3_pad(K);
     const bool two = x3_two_block(M);
     bf16_t* A3 = scratch;
     bf16_t* B3 = A3 + x3_al((size_t)M * 3 * Kp);
-    CK(split3_bf16(A, lda, M, K, Kp, two ? 2 : 0, A3, st));
+    if (!(a_ready && two)) CK(split3_bf16(A, lda, M, K, Kp, two ? 2 : 0, A3, st));
     CK(split3_transpose_bf16(B, ldb, K, N, Kp, true, B3, st));
     return x3_launch(A3, B3, C, M, N, Kp, ldc, e, two, st);
 }
@@ -627,7 +629,7 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
         CK(gemm_nt_bf16(w.dres16, woT16, w.dO, 1, nullptr, (int)a.BL, (int)a.HD, d, d, d, a.HD, st));
     } else if (x3 && x3_worth(a.BL, a.HD, d)) {
         CK(x3_tn(da, static_cast<float*>(c.O), g_o_w, d, (int)a.HD, a.BL, d, a.HD, a.HD, x3, st));
-        CK(x3_nn(da, o_w, static_cast<float*>(w.dO), (int)a.BL, (int)a.HD, d, d, a.HD, a.HD, NtEpilogue(), x3, st));
+        CK(x3_nn(da, o_w, static_cast<float*>(w.dO), (int)a.BL, (int)a.HD, d, d, a.HD, a.HD, NtEpilogue(), x3, st, true));
     } else {
         CK(wgrad(da, static_cast<float*>(c.O), g_o_w, d, (int)a.HD, (int)a.BL, d, a.HD, a.HD, prec, st));
         CK(ttmi_launch_gemm(mk(da, o_w, static_cast<float*>(w.dO), (int)a.BL, (int)a.HD, d, d, a.HD, a.HD, NN_, prec), st));
@@ -803,7 +805,7 @@ static int attn_bwd_impl(const float* dy, const float* x, const float* qkv_w, co
         CK(x3_tn(w.dqkv, x, g_qkv_w, (int)a.W3, d, a.BL, a.W3, d, d, x3, st));
         NtEpilogue ea;
         ea.addend = dx;                                           // dx += dqkv Wqkv (dx holds the residual-branch gradient)
-        CK(x3_nn(w.dqkv, qkv_w, dx, (int)a.BL, d, (int)a.W3, a.W3, d, d, ea, x3, st));
+        CK(x3_nn(w.dqkv, qkv_w, dx, (int)a.BL, d, (int)a.W3, a.W3, d, d, ea, x3, st, true));
     } else {
         CK(wgrad(w.dqkv, x, g_qkv_w, (int)a.W3, d, (int)a.BL, a.W3, d, d, prec, st));
         GemmDesc g = mk(w.dqkv, qkv_w, dx, (int)a.BL, d, (int)a.W3, a.W3, d, d, NN_, prec);
@@ -1024,11 +1026,11 @@ static int ffn_bwd_impl(const float* dz, const float* y, const float* w1, const 
         bf16_t* x3 = prec == 2 ? reinterpret_cast<bf16_t*>(ws + ((bw.floats() + 63) & ~(size_t)63)) : nullptr;
         if (x3 && x3_worth(rows, Di, d)) {
             CK(x3_tn(df, a1, g_w2, d, Di, rows, d, Di, Di, x3, st));
-            CK(x3_nn(df, w2, da1, (int)rows, Di, d, d, Di, Di, NtEpilogue(), x3, st));
+            CK(x3_nn(df, w2, da1, (int)rows, Di, d, d, Di, Di, NtEpilogue(), x3, st, true));
             CK(relu_mask_scale(da1, a1, rows * Di, inv_keep, st));           // the ReLU' (and dropout) mask of the exact-f32 path's epilogue: da1 = a1 > 0 ? da1 / keep : 0
             CK(colsum(da1, Di, rows, Di, 1, 1, 0, 0, 0, 0, g_b1, st));
             CK(x3_tn(da1, h, g_w1, Di, d, rows, Di, d, d, x3, st));
-            CK(x3_nn(da1, w1, w.dh, (int)rows, d, Di, Di, d, d, NtEpilogue(), x3, st));
+            CK(x3_nn(da1, w1, w.dh, (int)rows, d, Di, Di, d, d, NtEpilogue(), x3, st, true));
         } else {
         CK(wgrad(df, a1, g_w2, d, Di, (int)rows, d, Di, Di, prec, st));
         GemmDesc g = mk(df, w2, da1, (int)rows, Di, d, d, Di, Di, NN_ | GEMM_MASK_AUX, prec);

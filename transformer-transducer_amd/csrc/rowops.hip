@@ -1022,34 +1022,55 @@ __global__ __launch_bounds__(256) void joint_tanh_fwd_x3_kernel(const float* __r
     }
 }
 
-// dpre = dH (1 - H^2) with H = hi + lo from the two-block rows; dPE[b,t,:] = sum_u dpre, dPD[b,u,:] += sum_t dpre (the f32 kernel's structure)
+// dpre = dH (1 - H^2) with H = hi + lo from the two-block rows; dPE[b,t,:] = sum_u dpre, dPD[b,u,:] += sum_t dpre.  Four columns per thread (16-byte
+// loads of dH, 8-byte loads of the two H blocks), the column sums of a wave re-dealt through LDS for lane-contiguous atomics - the structure of
+// joint_sum_bwd_bf16x4_kernel below (the one-column form of the f32 kernel took 1.80 ms at C2)
+constexpr int JT_TCX = 16;
 __global__ __launch_bounds__(256) void joint_tanh_bwd_x3_kernel(const float* __restrict__ dH, const bf16_t* __restrict__ H3, int T, int U1, int J,
                                                                 int Jp, float* __restrict__ dPE, float* __restrict__ dPD) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= J) return;
-    const int t0 = blockIdx.y * JT_TC;
+    __shared__ float xch[4 * 256];
+    const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const bool act = j < J;                            // (whole waves stay alive: the exchange is per wave)
+    const int t0 = blockIdx.y * JT_TCX;
     const int b = blockIdx.z;
-    float accE[JT_TC];
+    float accE[JT_TCX][4];
 #pragma unroll
-    for (int i = 0; i < JT_TC; ++i) accE[i] = 0.f;
+    for (int i = 0; i < JT_TCX; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) accE[i][c] = 0.f;
     for (int u = 0; u < U1; ++u) {
-        float accD = 0.f;
+        float accD[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int tt = 0; tt < JT_TC; ++tt) {
+        for (int tt = 0; tt < JT_TCX; ++tt) {
             const int t = t0 + tt;
-            if (t < T) {
+            if (t < T && act) {
                 const long row = ((long)b * T + t) * U1 + u;
-                const float h = bf16_to_f32(H3[row * 2 * Jp + j]) + bf16_to_f32(H3[row * 2 * Jp + Jp + j]);
-                const float v = dH[row * J + j] * (1.f - h * h);
-                accE[tt] += v;
-                accD += v;
+                const float4 g = *reinterpret_cast<const float4*>(dH + row * J + j);
+                const uint2 hi = *reinterpret_cast<const uint2*>(H3 + row * 2 * Jp + j), lo = *reinterpret_cast<const uint2*>(H3 + row * 2 * Jp + Jp + j);
+                const float h[4] = {__uint_as_float(hi.x << 16) + __uint_as_float(lo.x << 16), __uint_as_float(hi.x & 0xffff0000u) + __uint_as_float(lo.x & 0xffff0000u),
+                                    __uint_as_float(hi.y << 16) + __uint_as_float(lo.y << 16), __uint_as_float(hi.y & 0xffff0000u) + __uint_as_float(lo.y & 0xffff0000u)};
+                const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float v = gv[c] * (1.f - h[c] * h[c]);
+                    accE[tt][c] += v;
+                    accD[c] += v;
+                }
             }
         }
-        atomicAdd(dPD + ((long)b * U1 + u) * J + j, accD);
+        float* xw = xch + (threadIdx.x >> 6) * 256;
+        *reinterpret_cast<float4*>(xw + (threadIdx.x & 63) * 4) = make_float4(accD[0], accD[1], accD[2], accD[3]);
+        float* d = dPD + ((long)b * U1 + u) * J + (blockIdx.x * 256 + (threadIdx.x & ~63)) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int col = 64 * c + (threadIdx.x & 63);
+            if ((blockIdx.x * 256 + (threadIdx.x & ~63)) * 4 + col < J) atomicAdd(d + col, xw[col]);
+        }
     }
 #pragma unroll
-    for (int tt = 0; tt < JT_TC; ++tt)
-        if (t0 + tt < T) dPE[((long)b * T + t0 + tt) * J + j] = accE[tt];
+    for (int tt = 0; tt < JT_TCX; ++tt)
+        if (t0 + tt < T && act)
+            *reinterpret_cast<float4*>(dPE + ((long)b * T + t0 + tt) * J + j) = make_float4(accE[tt][0], accE[tt][1], accE[tt][2], accE[tt][3]);
 }
 
 constexpr int JT_TC4 = 16;     // frames per block of the kernel below (32: fewer atomics but 0.52 -> 0.87 ms, too few blocks in flight; measured round 3)
@@ -1650,8 +1671,9 @@ int joint_tanh_fwd_x3(const float* PE, const float* PD, const float* bias, int B
     return TTMI_OK;
 }
 int joint_tanh_bwd_x3(const float* dH, const bf16_t* H3, int B, int T, int U1, int J, int Jp, float* dPE, float* dPD, hipStream_t st) {
-    TTMI_REQUIRE(dH && H3 && dPE && dPD && B > 0 && T > 0 && U1 > 0 && J > 0 && Jp >= J, "joint_tanh_bwd_x3: bad arguments");
-    hipLaunchKernelGGL(joint_tanh_bwd_x3_kernel, dim3(cdiv(J, 256), cdiv(T, JT_TC), B), dim3(256), 0, st, dH, H3, T, U1, J, Jp, dPE, dPD);
+    TTMI_REQUIRE(dH && H3 && dPE && dPD && B > 0 && T > 0 && U1 > 0 && J > 0 && J % 4 == 0 && Jp >= J && Jp % 4 == 0 && aligned16(dH) && aligned16(dPE) &&
+                 (reinterpret_cast<uintptr_t>(H3) & 7) == 0, "joint_tanh_bwd_x3: bad arguments");
+    hipLaunchKernelGGL(joint_tanh_bwd_x3_kernel, dim3(cdiv(J, 1024), cdiv(T, JT_TCX), B), dim3(256), 0, st, dH, H3, T, U1, J, Jp, dPE, dPD);
     TTMI_LAUNCH_CHECK("joint_tanh_bwd_x3_kernel");
     return TTMI_OK;
 }
