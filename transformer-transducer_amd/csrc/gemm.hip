@@ -547,6 +547,112 @@ __global__ __launch_bounds__(NT) void x3_panel64_kernel(const KParams p) {
         }
 }
 
+// The k-major slab form with LINE-ALIGNED strips.  A 128-byte strip of a row whose pitch is 2000 bytes straddles two cache lines, and in
+// x3_panel64_kernel<true> the second half of each is gone from the L2 by the time the next strip asks for it: TCC_MISS = 2 x the slab's lines,
+// 515 MB fetched for 256 MB (rocprofv3 --pmc, profiles/r05_bf16x3_attention_core_kernels.txt).  The line phase of a row start repeats every 8 rows
+// when the pitch is a multiple of 4 floats, so a wave takes the 32 rows {r0 + 8 i} - ONE phase phi - and its strips are k in [32 c - phi, 32 c - phi + 32):
+// every load instruction reads whole lines, every line once.  The four waves of a workgroup hold four of the eight phases of a 256-row range (two
+// workgroups per range), each reading the B strip at its own offset: B sits in LDS as a ring of four 32-k strips (strip c + 1 being written while
+// c - 1 and c are read; strip -1 = zeros for the k < 0 head of phase-shifted rows).
+constexpr int PK_LD = 40;
+__global__ __launch_bounds__(NT) void x3_panel64_kphase_kernel(const KParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[4][2][64 * PK_LD];      // [ring slot][hi | lo][column n][k within the strip]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, g = lane >> 5;
+    const int R0 = 256 * (blockIdx.x >> 1), rho = 4 * (blockIdx.x & 1) + wave;
+    const int z = blockIdx.y, z1 = z / p.nz2, z2 = z % p.nz2;
+    const float* A = reinterpret_cast<const float*>(p.A) + z1 * p.sA1 + z2 * p.sA2;
+    const float* B = reinterpret_cast<const float*>(p.B) + z1 * p.sB1 + z2 * p.sB2;
+    float* Cp = reinterpret_cast<float*>(p.C) + z1 * p.sC1 + z2 * p.sC2;
+    const int row = R0 + rho + 8 * r;
+    const float* ap = A + (long)min(row, p.M - 1) * p.lda;      // rows past the matrix: loaded from its last row (another phase: slower, not wrong), never stored
+    const int phi = (int)((reinterpret_cast<uintptr_t>(A + (long)min(R0 + rho, p.M - 1) * p.lda) >> 2) & 31);      // floats between the line start and the wave's row starts
+    const int nc = (p.K + 31 + 31) / 32;                        // strips c with 32 c - phi < K for the largest phase (31): the same count for every wave (barriers)
+
+    auto load_a = [&](int c, float4* d) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int k = 32 * c - phi + 16 * kk + 8 * g;       // a multiple of 4 (the slab is 16-byte aligned, its pitch a multiple of 4 floats)
+            d[2 * kk] = load4<float>(ap + k, k >= 0 ? p.K - k : 0, 1);
+            d[2 * kk + 1] = load4<float>(ap + k + 4, k + 4 >= 0 ? p.K - k - 4 : 0, 1);
+        }
+    };
+    const int kp = tid >> 4, n4 = (tid & 15) * 4;
+    auto load_b = [&](int s, float4* d) {                        // strip s: rows 32 s + 2 kp, + 1 of four columns (rows >= K: zeros)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int k = 32 * s + 2 * kp + s2;
+            d[s2] = load4<float>(B + (long)k * p.ldb + n4, k < p.K ? 4 : 0, p.vecB);
+        }
+    };
+    auto store_b = [&](int slot, const float4* d) {
+        unsigned* hi = reinterpret_cast<unsigned*>(Bs[slot][0]);
+        unsigned* lo = reinterpret_cast<unsigned*>(Bs[slot][1]);
+        const float x0[4] = {d[0].x, d[0].y, d[0].z, d[0].w}, x1[4] = {d[1].x, d[1].y, d[1].z, d[1].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned h = pack_bf16x2(x0[i], x1[i]);
+            const unsigned l = pack_bf16x2(x0[i] - __uint_as_float(h << 16), x1[i] - __uint_as_float(h & 0xffff0000u));
+            hi[(n4 + i) * (PK_LD / 2) + kp] = h;
+            lo[(n4 + i) * (PK_LD / 2) + kp] = l;
+        }
+    };
+    // four consecutive k (a multiple of 4: inside one strip) of column n from the ring
+    auto ring4 = [&](int plane, int n, int k) -> uint2 {
+        return *reinterpret_cast<const uint2*>(&Bs[(k >> 5) & 3][plane][n * PK_LD + (k & 31)]);      // k = -phi ... -1: strip -1 = slot 3, zeroed below
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    float4 ra[4], rn[4], rb[2];
+    for (int i = tid; i < 2 * 64 * PK_LD / 2; i += NT) reinterpret_cast<unsigned*>(Bs[3][0])[i] = 0u;      // both planes of slot 3 (contiguous)
+    load_a(0, ra);
+    load_b(0, rb);
+    store_b(0, rb);
+    __syncthreads();
+    for (int c = 0; c < nc; ++c) {
+        const bool more = c + 1 < nc;
+        if (more) {
+            load_a(c + 1, rn);
+            load_b(c + 1, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 ah, al;
+            split8(ra[2 * kk], ra[2 * kk + 1], ah, al);
+            const int k = 32 * c - phi + 16 * kk + 8 * g;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = 32 * j + r;
+                const uint2 h0 = ring4(0, n, k), h1 = ring4(0, n, k + 4), l0 = ring4(1, n, k), l1 = ring4(1, n, k + 4);
+                const u32x4 hv = {h0.x, h0.y, h1.x, h1.y}, lv = {l0.x, l0.y, l1.x, l1.y};
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, hv), bl = __builtin_bit_cast(bf16x8, lv);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+            }
+        }
+        if (more) store_b((c + 1) & 3, rb);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = rn[i];
+    }
+    // C/D map of the 32x32 MFMA: col = lane & 31, tile row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5); tile row q is matrix row R0 + rho + 8 q
+    const bool atomic = p.flags & GEMM_ATOMIC;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = R0 + rho + 8 * ((i & 3) + 8 * (i >> 2) + 4 * g);
+            if (m >= p.M) continue;
+            float* cp = Cp + (long)m * p.ldc + 32 * j + r;
+            if (atomic) atomicAdd(cp, acc[j][i]);
+            else *cp = p.beta != 0.f ? acc[j][i] + *cp : acc[j][i];
+        }
+}
+
 constexpr int RN_CG = 256, RN_NP = RN_CG + 8;      // columns per pass through the LDS tile, its row pitch (4 RN_NP = 32 mod 64 banks: the two row groups of a store miss each other)
 
 __global__ __launch_bounds__(NT, 4) void x3_rows_nt64_kernel(const KParams p) {
@@ -781,6 +887,12 @@ int ttmi_launch_gemm(const GemmDesc& d, hipStream_t st) {
         if (g_x3_attn_kernels && plain && d.N == 64 && !bkm && p.vecB && !(d.flags & ~(GEMM_BF16X3 | GEMM_A_KMAJOR | GEMM_ATOMIC)) &&
             (!(d.flags & GEMM_ATOMIC) || d.beta == 0.f)) {
             dim3 pg(cdiv(d.M, P64_BM), d.nz1 * d.nz2);
+            static const int kphase_env = [] { const char* e = getenv("TTMI_X3_KPHASE"); return e ? atoi(e) : 1; }();
+            if (ak && p.vecA && kphase_env) {
+                hipLaunchKernelGGL(x3_panel64_kphase_kernel, dim3(2 * cdiv(d.M, 256), d.nz1 * d.nz2), dim3(NT), 0, st, p);
+                TTMI_LAUNCH_CHECK("x3_panel64_kphase_kernel");
+                return TTMI_OK;
+            }
             static const int kc_env = [] { const char* e = getenv("TTMI_X3_KC"); return e ? atoi(e) : 0; }();
             if (ak && kc_env == 64) hipLaunchKernelGGL((x3_panel64_kernel<true, 64>), pg, dim3(NT), 0, st, p);
             else if (ak) hipLaunchKernelGGL((x3_panel64_kernel<true, 32>), pg, dim3(NT), 0, st, p);
