@@ -425,7 +425,7 @@ def joint_logits_dtype(prec, J):
 
 
 def joint_fwd(enc, dec, wf, bf, wp, bp, prec):
-    """-> logits [B,T,U1,V]: f32 dense (prec 0), or a [..., :V] view of a pitch-roundup(V,64) buffer (bf16: prec 1; f32: prec 2)"""
+    """-> logits [B,T,U1,V] (f32: prec 0 / 2, bf16: prec 1), a [..., :V] view of a pitch-roundup(V,64) buffer"""
     B, T, de = enc.shape
     U1, dd = dec.shape[1], dec.shape[2]
     J, V = wf.shape[0], wp.shape[0]
@@ -435,15 +435,11 @@ def joint_fwd(enc, dec, wf, bf, wp, bp, prec):
     ctx = _f32(L_.ttmi_joint_ctx_floats_prec(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(prec)), enc.device)
     ws = scratch(L_.ttmi_joint_ws_floats_prec(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(V), c_int(prec)), enc.device)
     dt = joint_logits_dtype(prec, J)
-    if dt is torch.bfloat16 or prec == 2:
-        # (bf16x3: f32 rows of V = 4334 floats start 8 bytes off every second time - the projection's epilogue then stores float by float, 12 of
-        # the forward GEMM's 21 ms at C2; on a pitch of roundup(V, 64) every row piece is whole 16-byte stores.  The loss and its gradient
-        # take the pitch as they do for bf16 logits)
-        buf, logits = padded_empty((B, T, U1, V), dt, enc.device)
-        ldv = buf.shape[-1]
-    else:
-        logits = torch.empty(B, T, U1, V, dtype=dt, device=enc.device)
-        ldv = V
+    # (f32 logits too: rows of V = 4334 floats start 8 bytes off every second time - the projection's epilogue then stores float by float, 12 of
+    # the bf16x3 mode's 21 ms forward GEMM at C2; on a pitch of roundup(V, 64) every row piece is whole 16-byte stores.  The loss and its
+    # gradient take the pitch as they do for bf16 logits)
+    buf, logits = padded_empty((B, T, U1, V), dt, enc.device)
+    ldv = buf.shape[-1]
     check(L_.ttmi_joint_fwd(_p(enc), _p(dec), _p(wf), _p(bf), _p(wp), _p(bp), c_int(B), c_int(T), c_int(U1), c_int(de),
                             c_int(dd), c_int(J), c_int(V), c_int(prec), _p(ctx), _p(ws), _p(logits), c_long(ldv), _stream()),
           "ttmi_joint_fwd")
