@@ -60,6 +60,7 @@ struct FP {
     const bf16_t* A2;
     const bf16_t* B2;
     int K2;
+    int walk = 0;                           // v8 NT kernel: 1 = every XCD walks whole GROUP_M row groups of its own (groups xcd, xcd + 8, ...): an A panel enters ONE L2
     int kwrap = 0;                          // persistent NT kernels: K-tiles [kwrap, K / 64) re-read A's K-tiles [0, ..) against B2 (same pitch as B): C = A.(B + B2)^T, 0 = off
     long lda2, ldb2, sB1b, sB2b;
     float* colsum_mid;                      // column sums of the FIRST product (rows < M), atomically added; batch strides sV1 / sV2
@@ -776,7 +777,21 @@ __device__ __forceinline__ void gemm_nt_v8_body(const FP& p_) {
 
     // persistent tile walk: in every round the 32 workgroups of one XCD (ids equal mod 8) take 32 consecutive ids = an
     // 8-tall x 4-wide window of the GROUP_M-grouped order
-    auto tile_id = [&](int it) { return (long)it * gridDim.x + (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3); };
+    // p.walk = 1 (TTMI_TILE_WALK): the XCD owns the row groups xcd, xcd + 8, ... and its 32 workgroups walk them tile by tile - the 8 A panels of a group
+    // are then fetched into one L2 instead of the four or five that share a group in the default walk (2.28 x the algorithmic traffic on the forward)
+    const int w_nloc = gridDim.x >> 3, w_xcd = blockIdx.x & 7, w_loc = blockIdx.x >> 3;
+    const int w_per_group = GROUP_M * p.tiles_n, w_ngroups = (p.tiles_m + GROUP_M - 1) / GROUP_M;
+    const int w_own = w_ngroups > w_xcd ? (w_ngroups - w_xcd + 7) >> 3 : 0;
+    const bool w_last = w_own > 0 && ((w_ngroups - 1) & 7) == w_xcd;      // the (possibly short) last group is this XCD's
+    const long w_owned = (long)w_own * w_per_group - (w_last ? (long)(w_ngroups * GROUP_M - p.tiles_m) * p.tiles_n : 0);
+    auto tile_id = [&](int it) -> long {
+        if (p.walk) {
+            const long s = (long)it * w_nloc + w_loc;
+            if (s >= w_owned) return (long)p.tiles_m * p.tiles_n;          // past this XCD's share
+            return ((long)w_xcd + 8 * (s / w_per_group)) * w_per_group + s % w_per_group;
+        }
+        return (long)it * gridDim.x + (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    };
     auto coords = [&](long id, int& bm, int& bn) {
         const int per_group = GROUP_M * p.tiles_n;
         const int group = (int)(id / per_group), in = (int)(id % per_group);
@@ -867,7 +882,7 @@ __device__ __forceinline__ void gemm_nt_v8_body(const FP& p_) {
 #define V8_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define V8_BAR() __builtin_amdgcn_s_barrier()
 
-    const int rounds = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int rounds = p.walk ? (int)((w_owned + w_nloc - 1) / w_nloc) : (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
     // (a per-XCD start stagger lived here: with the lean epilogue and streaming stores it measures as a 0.05 ms loss - phase offsets do not
     // persist, see DESIGN.md - and is gone)
     int bm = 0, bn = 0;
@@ -2563,6 +2578,8 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     if (v8) {
         if (two_term) { p.B2 = epi.B_lo; p.kwrap = K / TK; p.K = K + k_lo; }
         p.tiles_m = cdiv(M, T8); p.tiles_n = cdiv(N, T8);
+        static const int walk_env = [] { const char* e = getenv("TTMI_TILE_WALK"); return e ? atoi(e) : 0; }();
+        p.walk = walk_env;
         const long nwg8 = (long)p.tiles_m * p.tiles_n;
 const int cus8 = nwg8 < 1024 ? std::max(8, (g_num_cus - reserved) / 8 * 8) : g_num_cus;   // encoder-sized problems only (see v9)
         const int grid8 = (int)((std::min<long>(nwg8, cus8) + 7) / 8 * 8);   // multiple of 8: one share of every round per XCD
