@@ -893,10 +893,8 @@ int ttmi_launch_gemm(const GemmDesc& d, hipStream_t st) {
                 TTMI_LAUNCH_CHECK("x3_panel64_kphase_kernel");
                 return TTMI_OK;
             }
-            static const int kc_env = [] { const char* e = getenv("TTMI_X3_KC"); return e ? atoi(e) : 0; }();
-            if (ak && kc_env == 64) hipLaunchKernelGGL((x3_panel64_kernel<true, 64>), pg, dim3(NT), 0, st, p);
-            else if (ak) hipLaunchKernelGGL((x3_panel64_kernel<true, 32>), pg, dim3(NT), 0, st, p);
-            else if (kc_env == 64) hipLaunchKernelGGL((x3_panel64_kernel<false, 64>), pg, dim3(NT), 0, st, p);
+            // (64-wide strips were measured: k-major 120 -> 125 us, m-major 106 -> 97 us at three workgroups per CU instead of four; 32 stays)
+            if (ak) hipLaunchKernelGGL((x3_panel64_kernel<true, 32>), pg, dim3(NT), 0, st, p);
             else hipLaunchKernelGGL((x3_panel64_kernel<false, 32>), pg, dim3(NT), 0, st, p);
             TTMI_LAUNCH_CHECK("x3_panel64_kernel");
             return TTMI_OK;
