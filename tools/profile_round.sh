@@ -26,5 +26,5 @@ for k in "gemm_nt_bf16_v8_kernel<unsigned short, 3>" "gemm_nt_bf16_v8_kernel<uns
 done
 python3 tools/pmc_summary.py $OUT/sq SQ "gemm_nt_bf16_v8_kernel<unsigned short, 3>" "gemm_nt_bf16_v8_kernel<unsigned short, 4>" "gemm_tn_bf16_v8_kernel<2>" "gemm_nt_bf16_v8_kernel<unsigned short, 1>" "gemm_tn_bf16_v8_kernel<1>" "flash_bwd_rel2_kernel<0>" "flash_fwd_res_kernel<0>" "attn_dqde_kernel" | sort >> $F
 python3 tools/update_pmc_json.py $OUT/fetch $OUT/write $OUT/sq $COMMIT $TAG > $OUT/pmc_json.log
-cp profiles/${TAG}_* profiles/pmc_joint_projection.json gpurun_out/ 2>/dev/null || true
+cp profiles/${TAG}_* profiles/pmc_joint_projection.json profiles/pmc_secondary_kernels.json gpurun_out/ 2>/dev/null || true
 tail -3 $OUT/pmc_json.log
