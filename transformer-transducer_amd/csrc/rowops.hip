@@ -561,6 +561,40 @@ __global__ __launch_bounds__(WPB * 64) void softmax_fwd_kernel(float* __restrict
     }
 }
 
+// rows of up to 512 columns (every C2 / C4 attention): the row stays in registers - one read, one write, one mask test and one exp per element where
+// the kernel above walks the row three times (147 -> 84 us at B = 32, H = 8, L = 500, the fp32 / bf16x3 modes' attention)
+__global__ __launch_bounds__(WPB * 64) void softmax_fwd_reg_kernel(float* __restrict__ S, long nrows, int nh, int L, long ld, long slab, float scale,
+                                                                   const MaskDesc m) {
+    const long r = wave_row();
+    if (r >= nrows) return;
+    const int lane = threadIdx.x & 63;
+    const int i = (int)(r % L);
+    const long sl = r / L;
+    const int b = (int)(sl / nh);
+    float* row = S + sl * slab + (long)i * ld;
+    float v[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int j = lane + 64 * q;
+        v[q] = (j < L && !masked_at(m, b, i, j)) ? row[j] * scale : -INFINITY;
+        mx = fmaxf(mx, v[q]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        v[q] = __expf(v[q] - mx);
+        sum += v[q];
+    }
+    const float inv = 1.f / wave_sum(sum);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int j = lane + 64 * q;
+        if (j < L) row[j] = v[q] * inv;
+    }
+}
+
 __global__ __launch_bounds__(WPB * 64) void softmax_bwd_kernel(float* __restrict__ dP, const float* __restrict__ P, long nrows,
                                                                int L, long ld, long slab, float scale) {
     const long r = wave_row();
@@ -1521,7 +1555,8 @@ int softmax_fwd(float* S, int nb, int nh, int L, long ld, long slab, float scale
     TTMI_REQUIRE(S && nb > 0 && nh > 0 && L > 0, "softmax_fwd: bad arguments");
     TTMI_REQUIRE((m.kind != MASK_TENSOR && m.kind != MASK_INTERVAL) || m.ptr, "softmax_fwd: tensor mask without pointer");
     const long nrows = (long)nb * nh * L;
-    hipLaunchKernelGGL(softmax_fwd_kernel, dim3(cdiv(nrows, WPB)), dim3(WPB * 64), 0, st, S, nrows, nh, L, ld, slab, scale, m);
+    if (L <= 512) hipLaunchKernelGGL(softmax_fwd_reg_kernel, dim3(cdiv(nrows, WPB)), dim3(WPB * 64), 0, st, S, nrows, nh, L, ld, slab, scale, m);
+    else hipLaunchKernelGGL(softmax_fwd_kernel, dim3(cdiv(nrows, WPB)), dim3(WPB * 64), 0, st, S, nrows, nh, L, ld, slab, scale, m);
     TTMI_LAUNCH_CHECK("softmax_fwd_kernel");
     return TTMI_OK;
 }
