@@ -547,6 +547,113 @@ __global__ __launch_bounds__(NT) void x3_panel64_kernel(const KParams p) {
         }
 }
 
+// The m-major slab form (A stored [K, M]: P^T dO, dS^T (q + u), dG^T q) with 64 rows per wave.  In x3_panel64_kernel<false> a load instruction covers 32
+// consecutive m of two k rows - 128-byte pieces of 2000-byte rows, each straddling two cache lines that the neighbouring wave asks for again (TCC_REQ 2 x
+// the slab's lines, 434 MB fetched for 256 MB).  Here lane l of a wave is row m0 + l for 64 rows: one load per k row, 256 contiguous bytes, three lines
+// where the two 128-byte pieces took four.  The 32 x 32 x 16 MFMA wants lanes 32 - 63 to hold k + 8 ... k + 15 of rows 0 - 31, which sit in lanes 0 - 31 of
+// other registers: v_permlane32_swap of the registers of k and k + 8 yields the fragment element of BOTH 32-row tiles in one instruction.
+template <int DUMMY>
+__global__ __launch_bounds__(NT) void x3_panel64_m64_kernel(const KParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][2][64 * 40];      // [stage][hi | lo][column n][k]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, g = lane >> 5;
+    const int m0 = blockIdx.x * 256 + 64 * wave;
+    const int z = blockIdx.y, z1 = z / p.nz2, z2 = z % p.nz2;
+    const float* A = reinterpret_cast<const float*>(p.A) + z1 * p.sA1 + z2 * p.sA2;
+    const float* B = reinterpret_cast<const float*>(p.B) + z1 * p.sB1 + z2 * p.sB2;
+    float* Cp = reinterpret_cast<float*>(p.C) + z1 * p.sC1 + z2 * p.sC2;
+    const float* ap = A + min(m0 + lane, p.M - 1);              // rows past the matrix: the last row's values, never stored
+    const int nc = (p.K + 31) / 32;
+    auto load_a = [&](int k0, float* d) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) d[k] = (k0 + k < p.K) ? ap[(long)(k0 + k) * p.lda] : 0.f;
+    };
+    const int kp = tid >> 4, n4 = (tid & 15) * 4;
+    auto load_b = [&](int k0, float4* d) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int k = k0 + 2 * kp + s2;
+            d[s2] = load4<float>(B + (long)k * p.ldb + n4, k < p.K ? 4 : 0, p.vecB);
+        }
+    };
+    auto store_b = [&](int st, const float4* d) {
+        unsigned* hi = reinterpret_cast<unsigned*>(Bs[st][0]);
+        unsigned* lo = reinterpret_cast<unsigned*>(Bs[st][1]);
+        const float x0[4] = {d[0].x, d[0].y, d[0].z, d[0].w}, x1[4] = {d[1].x, d[1].y, d[1].z, d[1].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned h = pack_bf16x2(x0[i], x1[i]);
+            const unsigned l = pack_bf16x2(x0[i] - __uint_as_float(h << 16), x1[i] - __uint_as_float(h & 0xffff0000u));
+            hi[(n4 + i) * 20 + kp] = h;
+            lo[(n4 + i) * 20 + kp] = l;
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][j][i] = 0.f;
+    float ra[32], rn[32];
+    float4 rb[2];
+    if (nc > 0) {
+        load_a(0, ra);
+        load_b(0, rb);
+        store_b(0, rb);
+    }
+    __syncthreads();
+    for (int c = 0; c < nc; ++c) {
+        const int cur = c & 1;
+        const bool more = c + 1 < nc;
+        if (more) {
+            load_a((c + 1) * 32, rn);
+            load_b((c + 1) * 32, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            float t0[8], t1[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(ra[16 * kk + i]), __float_as_int(ra[16 * kk + 8 + i]), false, false);
+                t0[i] = __int_as_float(sw[0]);                  // lanes 0 - 31: rows 0 - 31 at k + i; lanes 32 - 63: rows 0 - 31 at k + 8 + i
+                t1[i] = __int_as_float(sw[1]);                  // the same of rows 32 - 63
+            }
+            bf16x8 ah[2], al[2];
+            split8(make_float4(t0[0], t0[1], t0[2], t0[3]), make_float4(t0[4], t0[5], t0[6], t0[7]), ah[0], al[0]);
+            split8(make_float4(t1[0], t1[1], t1[2], t1[3]), make_float4(t1[4], t1[5], t1[6], t1[7]), ah[1], al[1]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int off = (32 * j + r) * 40 + 16 * kk + 8 * g;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&Bs[cur][0][off]);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&Bs[cur][1][off]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bh, acc[t][j], 0, 0, 0);
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], bh, acc[t][j], 0, 0, 0);
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bl, acc[t][j], 0, 0, 0);
+                }
+            }
+        }
+        if (more) store_b(cur ^ 1, rb);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 32; ++i) ra[i] = rn[i];
+    }
+    const bool atomic = p.flags & GEMM_ATOMIC;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = m0 + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * g;
+                if (m >= p.M) continue;
+                float* cp = Cp + (long)m * p.ldc + 32 * j + r;
+                if (atomic) atomicAdd(cp, acc[t][j][i]);
+                else *cp = p.beta != 0.f ? acc[t][j][i] + *cp : acc[t][j][i];
+            }
+}
+
 // The k-major slab form with LINE-ALIGNED strips.  A 128-byte strip of a row whose pitch is 2000 bytes straddles two cache lines, and in
 // x3_panel64_kernel<true> the second half of each is gone from the L2 by the time the next strip asks for it: TCC_MISS = 2 x the slab's lines,
 // 515 MB fetched for 256 MB (rocprofv3 --pmc, profiles/r05_bf16x3_attention_core_kernels.txt).  The line phase of a row start repeats every 8 rows
@@ -894,7 +1001,9 @@ int ttmi_launch_gemm(const GemmDesc& d, hipStream_t st) {
                 return TTMI_OK;
             }
             // (64-wide strips were measured: k-major 120 -> 125 us, m-major 106 -> 97 us at three workgroups per CU instead of four; 32 stays)
+            static const int m64_env = [] { const char* e = getenv("TTMI_X3_M64"); return e ? atoi(e) : 1; }();
             if (ak) hipLaunchKernelGGL((x3_panel64_kernel<true, 32>), pg, dim3(NT), 0, st, p);
+            else if (m64_env) hipLaunchKernelGGL((x3_panel64_m64_kernel<0>), dim3(cdiv(d.M, 256), d.nz1 * d.nz2), dim3(NT), 0, st, p);
             else hipLaunchKernelGGL((x3_panel64_kernel<false, 32>), pg, dim3(NT), 0, st, p);
             TTMI_LAUNCH_CHECK("x3_panel64_kernel");
             return TTMI_OK;
