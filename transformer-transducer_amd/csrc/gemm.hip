@@ -990,7 +990,8 @@ int ttmi_launch_gemm(const GemmDesc& d, hipStream_t st) {
         (void)env_once;
         const bool plain = d.alpha == 1.f && (d.beta == 0.f || d.beta == 1.f) && d.splitk == 1 && d.drop.p <= 0.f && (long)d.nz1 * d.nz2 <= 65535;
         const bool ak = d.flags & GEMM_A_KMAJOR, bkm = d.flags & GEMM_B_KMAJOR;
-        // (a k-major slab that is not 16-byte aligned - the pitch-(L+1) view of dG - loads its fragments in single floats: 214 -> 178 us)
+        // (a k-major slab that is not 16-byte aligned - the pitch-(L+1) view of dG - loads its fragments in single floats: 214 -> 178 us.  Tried: lanes along k,
+        // one 256-byte load per row at any alignment, the 32 x 64 piece transposed into fragments through a wave-private LDS image: correct, 213 us at 200 registers)
         if (g_x3_attn_kernels && plain && d.N == 64 && !bkm && p.vecB && !(d.flags & ~(GEMM_BF16X3 | GEMM_A_KMAJOR | GEMM_ATOMIC)) &&
             (!(d.flags & GEMM_ATOMIC) || d.beta == 0.f)) {
             dim3 pg(cdiv(d.M, P64_BM), d.nz1 * d.nz2);
