@@ -770,7 +770,10 @@ __global__ __launch_bounds__(NT, 4) void x3_rows_nt64_kernel(const KParams p) {
     // workgroups per CU: 150 / 200; 128 columns: 155 / 231).  With 512-column passes the kernel took 110 us with the write-out skipped and 77 us
     // with the products skipped (tools/debug/bench_generic_gemm.py).  Measured and NOT faster: the operand rows in whole lines through a
     // wave-private LDS image instead of fragment-shaped loads (145), two column blocks of operand rows in flight (146), eight waves with every
-    // load of a pass in flight and one contiguous run of 16-byte stores (167, spills).  The library's batched f32 product: 179 us.
+    // load of a pass in flight and one contiguous run of 16-byte stores (167, spills); no LDS tile at all - two adjacent column blocks per wave, v_permlane32_swap of their
+    // accumulators so that a store instruction is one row's 64 consecutive columns (146; 147 with two row tiles per wave, i.e. half the B reads).  SQ counters of the
+    // tile form (tools/debug/pmc_rows_kernel.sh): 1364 VALU + 609 SALU + 40 load + 26 store + 90 LDS instructions per wave, a wave lives 31 us at 85 % of the
+    // resident-wave capacity and waits on memory for 64 % of it.  The library's batched f32 product: 179 us.
     extern __shared__ __attribute__((aligned(16))) float rn_tile[];      // [32][RN_NP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, g = lane >> 5;
     // workgroups are dealt to the 8 XCDs round-robin, and every row block of a (batch, head) slab reads ALL of its B rows: numbered as launched,
