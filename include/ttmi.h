@@ -288,6 +288,11 @@ int ttmi_gemm_nt_bf16_two_term_klo(const void* A, const void* B, const void* B_l
  * rowsum [nparts, M] = per-row partial sums (nparts >= 4 * ceil(N / 256); the entries of a row add up to its sum of exponentials) */
 int ttmi_gemm_nt_bf16_exp(const void* A, const void* B, void* C, const float* bias, float* rowsum, int nparts, const float* shift /* device, nullable */, int M, int N, int K,
                           long lda, long ldb, long ldc, void* stream);
+/* bring-up entry of the "row factor" epilogue of the persistent 256x256 kernel (the joint's dgrad in the exp-domain loss form, the adjoint of
+ * tt/model.py:34-38 with the loss gradient kept factored): C = bf16((A.B^T) * (1 - mask^2) * rowscale[m]) and, in place, mask <- rowscale[m] * mask
+ * (mask bf16 [M, ldc], the layout of C; rowscale f32 [M]) */
+int ttmi_gemm_nt_bf16_rowscale(const void* A, const void* B, void* C, void* mask, const float* rowscale, int M, int N, int K, long lda, long ldb, long ldc,
+                               void* stream);
 int ttmi_gemm_tn_bf16(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int accumulate,
                       float* colsum_a /* nullable: colsum_a[m] += sum_k A[k][m] */, void* stream);
 /* bring-up entry of the weighted column sums (persistent 256x256 TN kernel only: K >= 32768, M >= 1024, N % 256 == 0, N >= 1024):
@@ -320,7 +325,9 @@ int ttmi_stream_reserve_cus(void* stream, int n);
  * forward kernel instead of the one-workgroup-per-head one; 15: 1 = the round-3 attention backward kernel instead of flash_bwd_rel2_kernel;
  * 16: 1 = the position-table gradients go through dE / dc and a relpos_scatter launch (round 3) instead of straight out of attn_dqde_kernel;
  * 17: exact-f32 NT products: 0 = the kernels of csrc/gemm.hip only (round 1), 1 = default rule (persistent 256x128 kernel with f32 operands from 512 of its tiles on,
- * 64x64 tiles from 72 of those on), 2 / 3 = the 64x64-tile / the persistent kernel wherever it can run */
+ * 64x64 tiles from 72 of those on), 2 / 3 = the 64x64-tile / the persistent kernel wherever it can run; 18: 1 = fork inside a stream capture;
+ * 19: bits selecting the direct-store instances of the persistent 256x256 NT kernel (round 6: accumulators leave as 16-byte row pieces without the trip through LDS):
+ * 1 = exp store (joint forward), 2 = bias-only bf16 outputs, 4 = row factor (joint dgrad) */
 int ttmi_set_option(int key, int value);
 int ttmi_dropout_apply(const float* in, long n, float p, unsigned seed, float* out, void* stream);
 int ttmi_probe_arm(int slot);

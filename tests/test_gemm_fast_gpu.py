@@ -282,3 +282,107 @@ def test_two_term_weight_second_walk_over_a_prefix_exact(M, N, Kh, gen):
     want = A.float() @ B3[:, :2 * Kh].float().t() + A[:, :Kh].float() @ B3[:, 2 * Kh:].float().t() + bias
     assert torch.equal(C[:M], want)
     assert bool((C[M] == 5.0).all())
+
+
+def _exp_call(A, B, P, bias, rs, M, N, K, ld, shift=None):
+    import ctypes
+    from ttmi import ops
+    p = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+    ops.check(ops.lib().ttmi_gemm_nt_bf16_exp(p(A), p(B), p(P), p(bias), p(rs), rs.shape[0], p(shift), M, N, K, ctypes.c_long(K), ctypes.c_long(K),
+                                              ctypes.c_long(ld), ops._stream()), "ttmi_gemm_nt_bf16_exp")
+
+
+@pytest.mark.parametrize("M,N,K,pad", [(1024, 256, 64, 0), (1024, 256, 128, 0), (2048, 264, 320, 0), (5000, 4334, 1024, 18), (3000, 1024, 4352, 0),
+                                       (70000, 1100, 512, 4), (1025, 257, 1024, 7)])
+def test_direct_store_bias_instance_exact(M, N, K, pad):
+    """v8d<1> (round 6, option 19 bit 2): the persistent 256x256 kernel with the B rows permuted in the fragment reads so that a lane ends with 8
+    consecutive output columns and stores them without the LDS transpose.  Exact on small integers for 1..68 K-tiles, ragged M / N (the element-wise
+    tail of the last 8-column group), padded pitch (pad columns untouched), several rounds of tiles per CU; and the same bits as v8."""
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + 6)
+    A, B = _ints((M, K), g), _ints((N, K), g)
+    bias = torch.randint(-3, 4, (N,), device="cuda", generator=g).float()
+    out = []
+    for bits in (2, 32, 0):                                   # 32: v8 with the staging spread evenly over its two phases (v8b)
+        Cfull = torch.full((M, N + pad), 5.0, device="cuda", dtype=torch.bfloat16)
+        ops.set_option(1, 8)
+        ops.set_option(19, bits)
+        try:
+            ops.gemm_nt_bf16(A, B, Cfull[:, :N], bias)
+        finally:
+            ops.set_option(1, 4)
+            ops.set_option(19, 0)
+        assert torch.equal(Cfull[:, :N], (A.float() @ B.float().t() + bias).to(torch.bfloat16)), bits
+        if pad:
+            assert bool((Cfull[:, N:] == 5.0).all())
+        out.append(Cfull)
+    assert torch.equal(out[0], out[2]) and torch.equal(out[1], out[2])
+
+
+@pytest.mark.parametrize("M,N,K,ld", [(5000, 4334, 1024, 4352), (33600, 1000, 256, 1024), (1041, 300, 128, 304), (2048, 256, 192, 256)])
+def test_direct_store_exp_instance_matches_v8(M, N, K, ld):
+    """v8d<3> (option 19 bit 1): exp store - the same bf16 bits as v8's exp store in every column incl. the zero pad columns (the accumulation order of
+    a tile is unchanged), row-sum partials equal to rounding (another order inside a wave's 64 columns), both against a float64 product"""
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    A = (torch.randn(M, K, device="cuda", generator=g) * 0.5).tanh().to(torch.bfloat16)
+    B = (torch.randn(N, K, device="cuda", generator=g) * 0.03).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g) * 0.1
+    shift = torch.full((1,), 0.25, device="cuda")
+    nparts = 4 * ((N + 255) // 256)
+    res = []
+    for bits in (1, 0, 32):
+        P = torch.full((M, ld), 7.0, dtype=torch.bfloat16, device="cuda")
+        rs = torch.zeros(nparts, M, device="cuda")
+        ops.set_option(1, 8)                                  # the persistent kernel at every size it can run
+        ops.set_option(19, bits)
+        try:
+            _exp_call(A, B, P, bias, rs, M, N, K, ld, shift)
+        finally:
+            ops.set_option(1, 4)
+            ops.set_option(19, 0)
+        res.append((P, rs))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[2][0], res[1][0]) and torch.equal(res[2][1], res[1][1])          # v8b: v8's epilogue, bit for bit
+    assert bool((res[0][0][:, N:] == 0).all())
+    s0, s1 = res[0][1].sum(0), res[1][1].sum(0)
+    assert float(((s0 - s1).abs() / s1).max()) < 2e-6
+    assert float(((res[0][1] - res[1][1]).abs() / res[1][1].abs().clamp_min(1e-30)).max()) < 4e-6     # per 64-column partial
+    rows = torch.randint(0, M, (512,), device="cuda", generator=g)
+    want = torch.exp(A[rows].double() @ B.double().t() + bias.double() - 0.25)
+    got = res[0][0][rows, :N].double()
+    assert float(((got - want).abs() / want).max()) < 4.2e-3                      # bf16 rounding of the stored value
+    assert float(((s0[rows].double() - want.sum(1)).abs() / want.sum(1)).max()) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(5000, 1024, 4352), (33600, 256, 1024), (1041, 1024, 128), (3000, 328, 256)])
+def test_direct_store_row_factor_instance_matches_v8(M, N, K):
+    """v8d<4> (option 19 bit 4): dH = (A.B^T) * (1 - h^2) * s_r with h <- s_r h in place - the same bits as v8's instance in both outputs, and
+    both against float64 (N = 328: the ragged last 8-column group goes element-wise in both)"""
+    import ctypes
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + 4)
+    A = (torch.randn(M, K, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    B = (torch.randn(N, K, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    H0 = (torch.randn(M, N, device="cuda", generator=g)).tanh().to(torch.bfloat16)
+    sr = torch.rand(M, device="cuda", generator=g) + 0.5
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    res = []
+    for bits in (4, 0, 32):
+        H = H0.clone()
+        C = torch.full((M, N), 3.0, dtype=torch.bfloat16, device="cuda")
+        ops.set_option(1, 8)
+        ops.set_option(19, bits)
+        try:
+            ops.check(ops.lib().ttmi_gemm_nt_bf16_rowscale(p(A), p(B), p(C), p(H), p(sr), M, N, K, ctypes.c_long(K), ctypes.c_long(K), ctypes.c_long(N),
+                                                           ops._stream()), "ttmi_gemm_nt_bf16_rowscale")
+        finally:
+            ops.set_option(1, 4)
+            ops.set_option(19, 0)
+        res.append((C, H))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[2][0], res[1][0]) and torch.equal(res[2][1], res[1][1])
+    want = (A.double() @ B.double().t()) * (1 - H0.double() ** 2) * sr.double()[:, None]
+    err = (res[0][0].double() - want).abs().max() / want.abs().max()
+    assert float(err) < 5e-3
+    assert torch.equal(res[0][1], (H0.float() * sr[:, None]).to(torch.bfloat16))
