@@ -156,9 +156,9 @@ def check_file(name, tmp_path, expect):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_gemm_fast_counted_waits(tmp_path):
     """the persistent GEMMs' LDS-DMA pipelines: v8 (NT and TN, 256x256: three half-tiles = 6 DMA instructions stay in flight), the
-    3-stage 256x128 kernels (NT v9 with bf16 and with f32 operands, TN v9, the grouped wgrad: one stage = 6), v10 (one stage = 8), the 64x64-tile
+    3-stage 256x128 kernels (NT v9 with bf16 and with f32 operands, TN v9, the grouped wgrad: one stage = 6), the 64x64-tile
     exact-f32 kernel of the decoder-sized products (3 stages of 4)"""
-    check_file("gemm_fast", tmp_path, {"v8": (4, 6), "v9": (3, 6), "v10": (1, 8), "mid": (1, 4)})
+    check_file("gemm_fast", tmp_path, {"v8": (4, 6), "v9": (3, 6), "mid": (1, 4)})
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")

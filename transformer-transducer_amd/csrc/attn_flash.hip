@@ -1874,382 +1874,9 @@ extern "C" int ttmi_debug_bwd_stamps(unsigned long long* out, int n) {
 namespace {
 #endif
 
-// ------------------------------------------------------------------ backward, third generation (round 5): 16 keys per wave, FOUR waves per SIMD
-// EXPERIMENT, compiled only with `make EXTRA=-DTTMI_BWD3` and selected with ttmi_set_option(15, 3): VERDICT r4's "a different
-// kernel" at four waves per SIMD, built and measured.  Correct on every shape of tests/test_flash_gpu.py (47 / 47 with TTMI_OPTIONS=15:3) and
-// SLOWER than flash_bwd_rel2_kernel: 250 - 257 us against 163 - 164 us per C2 audio layer on one box.  Two findings: (1) the step does not fit 128
-// registers - dK^T / dV^T (32) + k / v fragments (16) + staging state (7) + lane constants leave ~70 for a phase whose fragment reads the
-// compiler wants in flight together (166 registers unconstrained); capped at 128 it spills 28 - 35, among them the k / v fragments, and
-// every scratch reload is a vector-memory wait that also drains the tile prefetch just issued; (2) even without the spills the per-step
-// chain (wait, park, barrier, G tiles, skew, scores, element loop, transposed reads, dK / dV) is as long as rel2's - half the elements per
-// lane shorten only the element loop - so four half-size waves per SIMD buy what two full-size ones already have.  The way down from
-// 0.24 ms per layer is fewer, fatter steps with the next step's products issued under this step's element loop (a hand-scheduled
-// stream), not more waves.
-#ifdef TTMI_BWD3
-// flash_bwd_rel2_kernel is at what two waves per SIMD and 254 registers reach: a wave spends most of its life on its own
-// dependency chains (LDS round trips, MFMA chains, transcendental latencies) and 96 of its registers hold dK / dV / k / v of its 32 keys.
-// Here a wave owns SIXTEEN keys on v_mfma_f32_16x16x32_bf16 tiles (dK^T / dV^T: 32 accumulator registers, k / v: 16), eight waves per
-// 128-key workgroup, <= 128 registers, two workgroups per CU = four waves per SIMD to overlap each other's chains.  Same LDS layout, staging
-// (by the first four waves, exactly rel2's 256 threads), rings and single barrier per step as rel2; same products, same operands, same
-// slab outputs.  Layout of a 16 x 16 tile D = A . B: lane (i = l & 15, g = l >> 4) holds A[i][8g .. 8g + 7], B[8g .. 8g + 7][i] and
-// D[4g + r][i], r = 0 .. 3: the key sits on the lane (i), a lane's four rows are four CONSECUTIVE queries (row statistics: one 16-byte
-// LDS read per tile).  The wave's position window is 47 columns = three 16-column blocks; query tile t = 0 (queries 0 .. 15 of the step)
-// meets blocks 1 and 2, tile t = 1 blocks 0 and 1 - four G tiles, eight MFMAs; element (query qi = 16 t + 4 g + r, key jj) sits at window
-// column 31 - qi + jj = lane (15 - 4 g - r + jj) & 15 of the SAME row of 16 lanes, in the higher block iff jj > 4 g + r: one packed bf16
-// pair and one ds_bpermute per element, as in rel2 (8 per step instead of 16).
-constexpr int BWD3_LDS = BWD2_LDS;
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <int MK>
-__global__ __launch_bounds__(512, 4) void flash_bwd_rel3_kernel(const FlashParams p) {
-    constexpr int DH = 64;
-    using T = Tile<DH>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* etile = smem;                                          // ring of 256 extended-table rows (slot = (p' - L) & 255)
-    char* ptile = smem + 256 * 128;                              // plain q rows, ring of 128 (slot = row & 127)
-    char* qtile = ptile + 128 * 128;                             // q + u rows, same ring
-    char* dotile = qtile + 128 * 128;                            // two dO tiles of 32 rows (step parity)
-    float* ctile = reinterpret_cast<float*>(dotile + 64 * 128);  // extended bias, ring of 256
-    float* lse_s = ctile + 256;                                  // [2][32] row statistics of the tile (step parity)
-    float* del_s = lse_s + 64;
-    int* lo_s = reinterpret_cast<int*>(del_s + 64);              // MK == 4: the tile's key intervals
-    int* hi_s = lo_s + 64;
-    float* u_s = reinterpret_cast<float*>(hi_s + 64);            // r_w_bias of this head
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g4 = lane >> 4, jj = lane & 15;
-    const bool stager = wave < 4;                                // waves 0 .. 3 stage every tile (rel2's 256 threads), all eight compute
-    const int z = blockIdx.y, b = z / p.H, h = z % p.H;
-    const int L = p.L;
-    const int jw0 = blockIdx.x * 128;
-    const int jw = jw0 + 16 * wave;
-    const int j = jw + jj;
-    const int jc = min(j, L - 1);
-    const bool kvalid = j < L;
-    const bf16_t* krow = p.k + ((long)b * L + jc) * p.ld_kv + h * DH;
-    const bf16_t* vrow = p.v + ((long)b * L + jc) * p.ld_kv + h * DH;
-    bf16x8 kf[2], vf[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        kf[ks] = *reinterpret_cast<const bf16x8*>(krow + 32 * ks + 8 * g4);
-        vf[ks] = *reinterpret_cast<const bf16x8*>(vrow + 32 * ks + 8 * g4);
-    }
-    f32x4v dk[4], dv[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4v{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
-    const bf16_t* dobase = p.dO + (long)b * L * p.ld_o + h * DH;
-    const bf16_t* pbase = p.qp + (long)b * L * p.ld_qp + h * DH;
-    const bf16_t* ebase = p.e16 + h * DH;
-    const float* cbase = p.cT + (long)h * L;
-    bf16_t* ds16 = p.dS16 + (long)z * p.slab16;
-    bf16_t* dg16 = p.dG16 + (long)z * p.slab16;
-    const __amdgpu_buffer_rsrc_t rs_ds = __builtin_amdgcn_make_buffer_rsrc(ds16, 0, (int)(p.slab16 * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_dg = __builtin_amdgcn_make_buffer_rsrc(dg16, 0, (int)(p.slab16 * 2), 0x00020000);
-    constexpr unsigned OOB = 0xFFFFFF00u;
-    const int ldp = (int)p.ldp;
-    const float c2 = p.scale * 1.4426950408889634f;                         // scale * log2(e)
-    const unsigned lds0 = (unsigned)(size_t)smem;
-    // ---- staging (waves 0 .. 3 only; `sw` = this thread as one of rel2's 256: rows of 8 chunks)
-    const int sw = wave & 3, st_tid = tid & 255;
-    const int rib = 8 * sw + (lane >> 3);
-    const int csrc8 = ((lane & 7) ^ ((rib >> 1) & 7)) * 8;
-    auto tab_row = [&](int pe) -> int { return min(max(pe < L ? pe : pe - L - 1, 0), L - 1); };
-    const unsigned ld_e2 = (unsigned)p.ld_e * 2u, ld_o2 = (unsigned)p.ld_o * 2u, ld_qp2 = (unsigned)p.ld_qp * 2u;
-    const float* lse_z = p.lse + (long)z * L;
-    const float* del_z = p.delta + (long)z * L;
-    auto dma_e_block = [&](int pe0) {
-        lds_dma16_s(ebase, (unsigned)tab_row(pe0 + rib) * ld_e2 + csrc8 * 2, lds0 + (((pe0 - L) & 255) + 8 * sw) * 128);
-    };
-    auto patch_zero_row = [&](int pe0) {
-        if (pe0 + rib == L) *reinterpret_cast<u32x4_t*>(etile + (((pe0 - L) & 255) + rib) * 128 + (lane & 7) * 16) = u32x4_t{0u, 0u, 0u, 0u};
-    };
-    auto dma_do = [&](int i0, int par) {
-        lds_dma16_s(dobase, (unsigned)min(i0 + rib, L - 1) * ld_o2 + csrc8 * 2, lds0 + (256 + 128 + 128) * 128 + par * 4096 + sw * 1024);
-    };
-    auto add_u = [&](u32x4_t v) -> u32x4_t {
-        const float4 ua = *reinterpret_cast<const float4*>(u_s + (st_tid & 7) * 8), ub = *reinterpret_cast<const float4*>(u_s + (st_tid & 7) * 8 + 4);
-        u32x4_t o;
-        o[0] = cvt_pk2(__uint_as_float(v[0] << 16) + ua.x, __uint_as_float(v[0] & 0xffff0000u) + ua.y);
-        o[1] = cvt_pk2(__uint_as_float(v[1] << 16) + ua.z, __uint_as_float(v[1] & 0xffff0000u) + ua.w);
-        o[2] = cvt_pk2(__uint_as_float(v[2] << 16) + ub.x, __uint_as_float(v[2] & 0xffff0000u) + ub.y);
-        o[3] = cvt_pk2(__uint_as_float(v[3] << 16) + ub.z, __uint_as_float(v[3] & 0xffff0000u) + ub.w);
-        return o;
-    };
-    u32x4_t ppre = {0u, 0u, 0u, 0u};
-    float cpre = 0.f, lse_pre = 0.f, del_pre = 0.f;
-    int lo_pre = 0, hi_pre = 0;
-    auto prefetch = [&](int i0, int par) {                                   // everything tile i0 needs that is not in LDS yet (stagers)
-        const int wbase = L - 32 - i0 + jw0;
-        dma_do(i0, par);
-        dma_e_block(wbase);
-        ppre = ld16_async_s(pbase, (unsigned)min(i0 + 32 + (st_tid >> 3), L - 1) * ld_qp2 + (st_tid & 7) * 16);
-        cpre = ld4f_async_s(cbase, (unsigned)tab_row(wbase + (st_tid & 31)) * 4u);
-        const unsigned ii4 = (unsigned)min(i0 + (st_tid & 31), L - 1) * 4u;
-        lse_pre = ld4f_async_s(lse_z, ii4);
-        del_pre = ld4f_async_s(del_z, ii4);
-        if constexpr (MK == 4) {
-            const int* r = reinterpret_cast<const int*>(p.mask) + (long)b * p.mask_sb;
-            lo_pre = ld4i_async_s(r, 2u * ii4);
-            hi_pre = ld4i_async_s(r, 2u * ii4 + 4u);
-        }
-    };
-    int ibeg = 0, iend = L;
-    if (p.bwd_skip) {
-        ibeg = max(0, jw0 - p.mask_right) & ~63;
-        iend = (int)min((long)L, (long)jw0 + 127 + p.mask_left + 1);
-        if (iend <= ibeg) { ibeg = 0; iend = 0; }
-    }
-    // ---- prologue (rel2's): the 160 window rows above the first tile's new block, its plain q rows (+ u), their bias, the first prefetch
-    if (ibeg < iend) {
-        const int wb = L - ibeg + jw0;
-        u32x4_t q0 = {0u, 0u, 0u, 0u};
-        float cv = 0.f;
-        bool cok = false;
-        if (stager) {
-#pragma unroll
-            for (int k = 0; k < 5; ++k) dma_e_block(wb + 32 * k);
-            q0 = *reinterpret_cast<const u32x4_t*>(pbase + (long)min(ibeg + (st_tid >> 3), L - 1) * p.ld_qp + (st_tid & 7) * 8);
-            cok = wb + st_tid != L;
-            cv = cbase[tab_row(wb + st_tid)];
-            if (st_tid < DH) u_s[st_tid] = p.u[h * DH + st_tid];
-            prefetch(ibeg, 0);
-        }
-        __syncthreads();                                                     // u_s
-        if (stager) {
-            const int slot = (ibeg + (st_tid >> 3)) & 127;
-            *reinterpret_cast<u32x4_t*>(ptile + T::off(slot, st_tid & 7)) = q0;
-            *reinterpret_cast<u32x4_t*>(qtile + T::off(slot, st_tid & 7)) = add_u(q0);
-            if (st_tid < 160) ctile[(wb + st_tid - L) & 255] = cok ? cv : 0.f;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int k = 0; k < 5; ++k) patch_zero_row(wb + 32 * k);
-        }
-    }
-    // lane parts of the slab byte offsets (a lane whose key does not exist carries an offset past the slab: the hardware drops its stores)
-    const unsigned v_ds = kvalid ? (unsigned)((4 * g4 * ldp + j) * 2) : OOB;                       // dS16[i][j]
-    const unsigned v_lo = kvalid ? (unsigned)((4 * g4 * (ldp - 1) + L - 1 + j) * 2) : OOB;         // dG16, j <= i
-    const unsigned v_hi = kvalid ? (unsigned)((4 * g4 * (ldp - 1) + ldp + j - 2) * 2) : OOB;       // dG16, j >= i + 2
-    const int jq = jj - 4 * g4;                                                                   // element r takes the higher block iff jq > r
-    const int bp0 = 4 * (16 * g4 + ((15 - 4 * g4 + jj) & 15));                                     // bpermute byte address of element r = 0 (r: one lane down, mod 16)
-    // fragment reads of the swizzled tiles (rel2's trick): chunk 4 ks + g of row r sits at r * 128 + (((4 ks + g) ^ ((r >> 1) & 7)) << 4) = r * 128 +
-    // (sw ^ (ks << 6)), sw = (g ^ ((r >> 1) & 7)) << 4; every row read is jj or jj + 1 plus a multiple of 16: two lane constants, one v_xad per read
-    const unsigned sw0 = (unsigned)((g4 ^ ((jj >> 1) & 7)) << 4), sw1 = (unsigned)((g4 ^ (((jj + 1) >> 1) & 7)) << 4);
-    const unsigned jrow = (unsigned)jj * 128u;
-    auto frag = [&](const char* tile, unsigned rowbytes, unsigned sw, int ks) -> bf16x8 {
-        return *reinterpret_cast<const bf16x8*>(tile + ((sw ^ (unsigned)(ks << 6)) + rowbytes));
-    };
-    // transposed reads: row 4 g + ((lane >> 2) & 3) [+ 16], column 16 dt + 4 (lane & 3): one lane constant, the d-tile flips bits 5 - 6
-    const int rq4 = 4 * g4 + ((lane >> 2) & 3), c4 = 4 * (lane & 3);
-    const unsigned trc = (unsigned)(rq4 * 128 + ((((c4 >> 3) ^ ((rq4 >> 1) & 7)) << 4) | ((c4 & 7) * 2)));
-    constexpr int SLAB_STORES_PER_STEP3 = 2 * 8;
-    auto mfma16 = [](bf16x8 a, bf16x8 bb, f32x4v c) -> f32x4v { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, c, 0, 0, 0); };
-
-    auto step = [&](int i0, int par, bool first) {
-        if (stager) {
-            // the prefetch of this tile: issued one step ago, in front of that step's 16 slab store instructions (the very first tile: in front of nothing)
-            if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else TTMI_VM_WAIT("bwdrel3", SLAB_STORES_PER_STEP3);
-            asm volatile("" : "+v"(ppre), "+v"(cpre), "+v"(lse_pre), "+v"(del_pre), "+v"(lo_pre), "+v"(hi_pre));
-            const int slot = (i0 + 32 + (st_tid >> 3)) & 127;
-            *reinterpret_cast<u32x4_t*>(ptile + T::off(slot, st_tid & 7)) = ppre;
-            *reinterpret_cast<u32x4_t*>(qtile + T::off(slot, st_tid & 7)) = add_u(ppre);
-            const int wbase = L - 32 - i0 + jw0;
-            ctile[(wbase + (st_tid & 31) - L) & 255] = wbase + (st_tid & 31) != L ? cpre : 0.f;
-            patch_zero_row(wbase);
-            lse_s[32 * par + (st_tid & 31)] = lse_pre * 1.4426950408889634f;
-            del_s[32 * par + (st_tid & 31)] = del_pre * p.scale;
-            if constexpr (MK == 4) {
-                lo_s[32 * par + (st_tid & 31)] = lo_pre;
-                hi_s[32 * par + (st_tid & 31)] = hi_pre;
-            }
-        }
-        __syncthreads();                                                     // the only barrier of a step
-        if (stager && i0 + 32 < iend) {
-            prefetch(i0 + 32, par ^ 1);
-            TTMI_VM_GUARD("bwdrel3");
-        }
-        const char* qcur = qtile + (i0 & 127) * 128;
-        const char* docur = dotile + par * 4096;
-        f32x4v s[2], dp[2];
-        // ---- position term: four G tiles (t = 0: blocks 1, 2; t = 1: blocks 0, 1), skewed onto the key lanes
-        {
-            const int pe_w = L - 32 - i0 + jw;                               // p' of the wave's window column 0
-            auto gtile = [&](int t, int blk) -> f32x4v {
-                const int pe0 = pe_w + 16 * blk;
-                const int erow = (pe0 + jj - L) & 255;                       // ring slot of this lane's table row (B operand: lane = window column)
-                const float cvv = ctile[erow];
-                f32x4v g = {cvv, cvv, cvv, cvv};
-                const unsigned eb = (unsigned)erow * 128u;
-                const unsigned qlo = (unsigned)((i0 + 16 * t + jj) & 127) * 128u, qup = (unsigned)((i0 + 16 * t + jj + 1) & 127) * 128u;    // A operand: lane = query row
-                if (pe0 + 15 <= L - 1 || pe0 >= L + 1) {
-                    const bool up = pe0 >= L + 1;
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const bf16x8 qa = frag(ptile, up ? qup : qlo, up ? sw1 : sw0, ks);
-                        const bf16x8 ef = frag(etile, eb, sw0, ks);
-                        g = mfma16(qa, ef, g);
-                    }
-                } else {                                                     // the block that holds p' = L: columns below it take q_i, columns above it q_{i+1}
-                    const bool lower = pe0 + jj <= L - 1;
-                    bf16x8 zero;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) zero[e] = (__bf16)0.0f;
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const bf16x8 qa = frag(ptile, qlo, sw0, ks);
-                        const bf16x8 qb = frag(ptile, qup, sw1, ks);
-                        const bf16x8 ef = frag(etile, eb, sw0, ks);
-                        g = mfma16(qa, lower ? ef : zero, g);
-                        g = mfma16(qb, lower ? zero : ef, g);
-                    }
-                }
-                return g;
-            };
-            unsigned pk[2][4];
-            {
-                const f32x4v a = gtile(0, 1), c = gtile(0, 2);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pk[0][r] = cvt_pk2(a[r], c[r]);
-            }
-            __builtin_amdgcn_sched_barrier(0);                               // (phase fences: left alone the compiler front-loads every LDS read of the step - 166 registers)
-            {
-                const f32x4v a = gtile(1, 0), c = gtile(1, 1);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pk[1][r] = cvt_pk2(a[r], c[r]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            int bps = bp0, jqs = jq;
-            asm volatile("" : "+v"(bps), "+v"(jqs));
-            unsigned got[2][4];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    got[t][r] = (unsigned)__builtin_amdgcn_ds_bpermute((int)((((unsigned)(bps - 4 * r)) & 60u) | (unsigned)(64 * g4)), (int)pk[t][r]);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[t][r] = __uint_as_float(jqs > r ? (got[t][r] & 0xffff0000u) : (got[t][r] << 16));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        dp[0] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        dp[1] = f32x4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const bf16x8 qa = frag(qcur + 2048 * t, jrow, sw0, ks);
-                const bf16x8 da = frag(docur + 2048 * t, jrow, sw0, ks);
-                s[t] = mfma16(qa, kf[ks], s[t]);
-                dp[t] = mfma16(da, vf[ks], dp[t]);
-            }
-        __builtin_amdgcn_sched_barrier(0);
-        const int s_ds = i0 * ldp * 2, s_dg = i0 * (ldp - 1) * 2;            // row part of the slab offsets (wave-uniform)
-        // pad columns [L, ldp) of both slabs feed the K loop of the dq / dE products and must be zero: the lanes whose key index falls there write the zeros
-        if (jw + 15 >= L && jw < ldp) {                                       // (wave-uniform: only the wave that straddles L)
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int qi = 16 * t + 4 * g4 + r;
-                    const unsigned vz = (!kvalid && j < ldp && i0 + qi < L) ? (unsigned)((4 * g4 * ldp + j) * 2) : OOB;
-                    __builtin_amdgcn_raw_buffer_store_b16((bf16_t)0, rs_ds, vz, s_ds + (16 * t + r) * ldp * 2, 0);
-                    __builtin_amdgcn_raw_buffer_store_b16((bf16_t)0, rs_dg, vz, s_ds + (16 * t + r) * ldp * 2, 0);
-                }
-        }
-        const bool interior = (i0 + 32 <= L) && (jw + 15 <= i0 || jw >= i0 + 33);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const float4 lse4 = *reinterpret_cast<const float4*>(lse_s + 32 * par + 16 * t + 4 * g4);
-            const float4 del4 = *reinterpret_cast<const float4*>(del_s + 32 * par + 16 * t + 4 * g4);
-            const float lsev[4] = {lse4.x, lse4.y, lse4.z, lse4.w}, delv[4] = {del4.x, del4.y, del4.z, del4.w};
-            int lov[4] = {0, 0, 0, 0}, hiv[4] = {0, 0, 0, 0};
-            if constexpr (MK == 4) {
-                const int4 l4 = *reinterpret_cast<const int4*>(lo_s + 32 * par + 16 * t + 4 * g4), h4 = *reinterpret_cast<const int4*>(hi_s + 32 * par + 16 * t + 4 * g4);
-                lov[0] = l4.x; lov[1] = l4.y; lov[2] = l4.z; lov[3] = l4.w;
-                hiv[0] = h4.x; hiv[1] = h4.y; hiv[2] = h4.z; hiv[3] = h4.w;
-            }
-            if (interior) {
-                const unsigned v_g = (p.debug & 2) ? OOB : (jw < i0 ? v_lo : v_hi);
-                const unsigned v_d = (p.debug & 2) ? OOB : v_ds;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rq = 16 * t + r, q = rq + 4 * g4;
-                    float pr = __builtin_amdgcn_exp2f(fmaf(s[t][r], c2, -lsev[r]));
-                    float ds = pr * fmaf(dp[t][r], p.scale, -delv[r]);
-                    if constexpr (MK != 0) {
-                        const bool msk = MK == 4 ? (bool)((int)(j < lov[r]) | (int)(j > hiv[r])) : is_masked<MK>(p, b, i0 + q, jc);
-                        pr = msk ? 0.f : pr;
-                        ds = msk ? 0.f : ds;
-                    }
-                    s[t][r] = pr;
-                    dp[t][r] = ds;
-                    const bf16_t d16 = f32_to_bf16(ds);
-                    __builtin_amdgcn_raw_buffer_store_b16(d16, rs_ds, v_d, s_ds + rq * ldp * 2, 0);
-                    __builtin_amdgcn_raw_buffer_store_b16(d16, rs_dg, v_g, s_dg + rq * (ldp - 1) * 2, 0);
-                }
-            } else {
-                const int dj = j - i0 - 4 * g4;                              // j - i = dj - rq
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rq = 16 * t + r, q = rq + 4 * g4;
-                    const bool rowok = i0 + q < L;
-                    float pr = __builtin_amdgcn_exp2f(fmaf(s[t][r], c2, -lsev[r]));
-                    float ds = pr * fmaf(dp[t][r], p.scale, -delv[r]);
-                    bool dead = !rowok;
-                    if constexpr (MK != 0) dead = (bool)((int)dead | (int)(MK == 4 ? (bool)((int)(j < lov[r]) | (int)(j > hiv[r])) : is_masked<MK>(p, b, min(i0 + q, L - 1), jc)));
-                    pr = dead ? 0.f : pr;
-                    ds = dead ? 0.f : ds;
-                    s[t][r] = pr;
-                    dp[t][r] = ds;
-                    const bf16_t d16 = f32_to_bf16(ds);
-                    const unsigned v_d = rowok ? v_ds : OOB;
-                    const unsigned v_g = (rowok && dj != rq + 1) ? (dj <= rq ? v_lo : v_hi) : OOB;
-                    __builtin_amdgcn_raw_buffer_store_b16(d16, rs_ds, v_d, s_ds + rq * ldp * 2, 0);
-                    __builtin_amdgcn_raw_buffer_store_b16(d16, rs_dg, v_g, s_dg + rq * (ldp - 1) * 2, 0);
-                }
-            }
-        }
-        // ---- dV^T += dO^T . P, dK^T += (q + u)^T . dS: B operand = the lane's eight values (slot e = 4 t + r <-> query 16 t + 4 g + r), A operand by
-        // transposed LDS reads (each row of 16 lanes: the 4 x 16 block of rows 4 g + (0 .. 3) [+ 16], columns of the d-tile)
-        __builtin_amdgcn_sched_barrier(0);
-        bf16x8 pb, dsb;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { pb[4 * t + r] = (__bf16)s[t][r]; dsb[4 * t + r] = (__bf16)dp[t][r]; }
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const unsigned o_lo = trc ^ (unsigned)(dt << 5), o_hi = o_lo + 2048u;
-            const bf16x8 a_do = __builtin_shufflevector(tr16(docur + o_lo), tr16(docur + o_hi), 0, 1, 2, 3, 4, 5, 6, 7);
-            const bf16x8 a_qu = __builtin_shufflevector(tr16(qcur + o_lo), tr16(qcur + o_hi), 0, 1, 2, 3, 4, 5, 6, 7);
-            dv[dt] = mfma16(a_do, pb, dv[dt]);
-            dk[dt] = mfma16(a_qu, dsb, dk[dt]);
-        }
-    };
-    for (int i0 = ibeg; i0 < iend; i0 += 64) {
-        step(i0, 0, i0 == ibeg);
-        if (i0 + 32 < iend) step(i0 + 32, 1, false);
-    }
-    if (kvalid) {
-        // lane (key j, g) holds d = 16 dt + 4 g + (0 .. 3) of dK^T / dV^T
-        float* dkrow = p.dK + ((long)b * L + j) * p.ld_dkv + h * DH;
-        float* dvrow = p.dV + ((long)b * L + j) * p.ld_dkv + h * DH;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const int d = 16 * dt + 4 * g4;
-            if (p.dK16) {
-                const long o16 = ((long)b * L + j) * p.ld_dkv + h * DH + d;
-                uint2 wk, wv;
-                wk.x = cvt_pk2(dk[dt][0], dk[dt][1]); wk.y = cvt_pk2(dk[dt][2], dk[dt][3]);
-                wv.x = cvt_pk2(dv[dt][0], dv[dt][1]); wv.y = cvt_pk2(dv[dt][2], dv[dt][3]);
-                *reinterpret_cast<uint2*>(p.dK16 + o16) = wk;
-                *reinterpret_cast<uint2*>(p.dV16 + o16) = wv;
-            } else {
-                *reinterpret_cast<float4*>(dkrow + d) = make_float4(dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]);
-                *reinterpret_cast<float4*>(dvrow + d) = make_float4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
-            }
-        }
-    }
-}
-#endif  // TTMI_BWD3
+// (A third-generation backward - 16 keys per wave on 16x16x32 tiles, eight waves per workgroup, four waves per SIMD at <= 128 registers - was built and measured in
+// round 5: correct on all 47 cases of tests/test_flash_gpu.py and SLOWER, 250 - 257 us against 163 - 164 us per C2 audio layer, with 28 - 35 spilled registers and a
+// per-step dependency chain as long as this kernel's.  Its source is in the history at commit d7f784a (flash_bwd_rel3_kernel); DESIGN.md section 4j has the findings.)
 
 // ------------------------------------------------------------------ backward (dK, dV, dS)
 template <int DH, int MK>
@@ -3197,16 +2824,8 @@ int flash_attn_bwd(const FlashParams& p, hipStream_t st) {
     if (p.Dh == 64) hipLaunchKernelGGL(flash_delta_kernel<64>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta, p.zero_f32, p.zero_f32 ? p.zero_n : 0L, zg, p.slab16, (int)p.ldp);
     else hipLaunchKernelGGL(flash_delta_kernel<32>, dim3(cdiv(n, 256)), dim3(256), 0, st, p.dO, p.o, p.ld_o, p.B, p.L, p.H, p.delta, p.zero_f32, p.zero_f32 ? p.zero_n : 0L, zg, p.slab16, (int)p.ldp);
     // in-kernel position term: (64 + 32 + 64 + 256) tile rows + cext ring + lse / delta + lo / hi + 4 private images of [64][36] bf16
-#ifdef TTMI_BWD3
-#define BWD3_TRY(MKV) (p.e16 && p.Dh == 64 && g_bwd_gen >= 3 && \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(flash_bwd_rel3_kernel<MKV>), hipFuncAttributeMaxDynamicSharedMemorySize, BWD3_LDS) == hipSuccess && \
-        (hipLaunchKernelGGL((flash_bwd_rel3_kernel<MKV>), grid, dim3(512), BWD3_LDS, st, q), true))
-#else
-#define BWD3_TRY(MKV) false
-#endif
 #define BWD_LAUNCH(MKV) do { \
-        if (BWD3_TRY(MKV)) { \
-        } else if (p.e16 && p.Dh == 64 && g_bwd_gen >= 2) { \
+        if (p.e16 && p.Dh == 64 && g_bwd_gen >= 2) { \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(flash_bwd_rel2_kernel<MKV>), hipFuncAttributeMaxDynamicSharedMemorySize, BWD2_LDS) != hipSuccess) { ttmi_set_error("flash_attn_bwd: LDS attribute"); return TTMI_EINVAL; } \
             hipLaunchKernelGGL((flash_bwd_rel2_kernel<MKV>), grid, dim3(256), BWD2_LDS, st, q); \
         } else if (p.e16) { \

@@ -65,7 +65,6 @@ bool gemm_tn_group_fits(const TnProblem& q);
 int gemm_tn_bf16_group(const TnProblem* probs, int n, hipStream_t st);   // deterministic (no atomics) for problems that fit the 256x128 tiling
 void gemm_fast_set_version(int v);   // kernel generation for A/B runs, see gemm_fast.hip (default 4)
 void gemm_fast_set_tn_target(int n);
-void gemm_fast_set_direct(int bits);  // direct-store instances of the persistent 256x256 NT kernel: 1 = exp store, 2 = bias-only, 4 = row factor (ttmi_set_option(19, bits))
 void gemm_fast_set_f32(int on);      // 0: gemm_nt_f32_ok() / gemm_nt_f32_mid_ok() answer no (A/B against the f32 kernels of csrc/gemm.hip); 2 / 3: one of the two only
 int gemm_fast_f32_mode();
 // exact-f32 NT product on the persistent 256x128 kernel (f32 operands through LDS-DMA, v_mfma_f32_16x16x4_f32): C[M,N] = epi(A[M,K] . B[N,K]^T),

@@ -26,9 +26,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-#ifndef V10_SCHED
-#define V10_SCHED 1
-#endif
 constexpr int TM = 128, TN_ = 128, TK = 64, NTH = 256;
 constexpr int TILE_B = 128 * 64 * 2;        // 16 KiB per operand tile
 constexpr int GROUP_M = 8;
@@ -497,121 +494,6 @@ __global__ __launch_bounds__(NTH, NBUF == 1 ? 4 : 2) void gemm_tn_bf16_kernel(co
     store_tile<float>(acc, p, reinterpret_cast<float*>(p.C), bm, bn, wm, wn, lane, false);
 }
 
-// =====================================================================================================================
-// v6: 256x256x64 tile, 8 waves (4x2), each wave 64x128 (2x4 MFMA tiles, 128 accumulator registers), double-buffered
-// 2 x 64 KiB LDS, one workgroup per CU.  Half the L2->LDS bytes per FLOP of the 128x128 kernels.
-// =====================================================================================================================
-constexpr int T6 = 256, NTH6 = 512, STAGE6 = 2 * 256 * 64 * 2;   // 64 KiB per stage (A 32 KiB | B 32 KiB)
-
-template <typename TC>
-__global__ __launch_bounds__(NTH6, 1) void gemm_nt_bf16_v6_kernel(const FP p_) {
-    FP p = p_;
-    p.drop = drop_live(p.drop);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;                       // 4 x 2 waves, wave tile 64 (M) x 128 (N)
-    int tm, tn;
-    tile_of(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
-    const int bm = tm * T6, bn = tn * T6;
-
-    const bf16_t* asrc[4];
-    const bf16_t* bsrc[4];
-    int chunkk[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int R = (wave * 4 + j) * 8 + (lane >> 3);            // 0..255
-        chunkk[j] = (lane & 7) ^ ((R >> 1) & 7);
-        asrc[j] = p.A + (long)min(bm + R, p.M - 1) * p.lda + chunkk[j] * 8;
-        bsrc[j] = p.B + (long)min(bn + R, p.N - 1) * p.ldb + chunkk[j] * 8;
-    }
-    const void* zsrc = &g_zero16;
-    auto issue = [&](int buf, int kt) {
-        char* base = smem + buf * STAGE6;
-        const bool tail = (kt + 1) * TK > p.K;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool zero = tail && (kt * TK + chunkk[j] * 8 >= p.K);
-            glds16(zero ? zsrc : (const void*)(asrc[j] + (long)kt * TK), base + (wave * 4 + j) * 1024);
-            glds16(zero ? zsrc : (const void*)(bsrc[j] + (long)kt * TK), base + STAGE6 / 2 + (wave * 4 + j) * 1024);
-        }
-    };
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nk = (p.K + TK - 1) / TK;
-    const int sw = (lane >> 1) & 7;
-    const int rowa = wm * 64 + (lane & 31), rowb = wn * 128 + (lane & 31);
-    auto frag = [&](const char* la, const char* lb, int kk, bf16x8 (&af)[2], bf16x8 (&bf)[4]) {
-        const int c = ((kk * 2 + (lane >> 5)) ^ sw) << 4;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(la + (rowa + i * 32) * 128 + c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(lb + (rowb + j * 32) * 128 + c);
-    };
-    auto mma = [&](const bf16x8 (&af)[2], const bf16x8 (&bf)[4]) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-    };
-    issue(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) issue(cur ^ 1, kt + 1);
-        const char* la = smem + cur * STAGE6;
-        const char* lb = la + STAGE6 / 2;
-        bf16x8 a0[2], b0[4], a1[2], b1[4];
-        frag(la, lb, 0, a0, b0);
-        frag(la, lb, 1, a1, b1);
-        __builtin_amdgcn_s_setprio(1);
-        mma(a0, b0);
-        __builtin_amdgcn_s_setprio(0);
-        frag(la, lb, 2, a0, b0);
-        __builtin_amdgcn_s_setprio(1);
-        mma(a1, b1);
-        __builtin_amdgcn_s_setprio(0);
-        frag(la, lb, 3, a1, b1);
-        __builtin_amdgcn_s_setprio(1);
-        mma(a0, b0);
-        mma(a1, b1);
-        __builtin_amdgcn_s_setprio(0);
-        __syncthreads();
-    }
-    // epilogue (wave tile 64 x 128)
-    TC* C = reinterpret_cast<TC*>(p.C);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = bn + wn * 128 + j * 32 + (lane & 31);
-            if (n >= p.N) continue;
-            const float bv = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m >= p.M) continue;
-                float v = acc[i][j][r] + bv;
-                const long ci = (long)m * p.ldc + n;
-                if (p.addend) v += p.addend[ci];
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (p.mask) {
-                    const float mv = bf16_to_f32(p.mask[ci]);
-                    v = p.mask_mode ? v * (1.f - mv * mv) : (mv > 0.f ? v * p.scale : 0.f);
-                }
-                v *= drop_mult(p.drop, (unsigned long long)ci);
-                if constexpr (sizeof(TC) == 4) reinterpret_cast<float*>(C)[ci] = v;
-                else reinterpret_cast<bf16_t*>(C)[ci] = f32_to_bf16(v);
-            }
-        }
-}
-
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -764,9 +646,7 @@ static_assert(V8_STAGE_DMA == 2 && V8_INFLIGHT == 6, "v8: the counted vmcnt wait
 // costs the main loop registers in the general instance
 // KW: the K loop runs twice over A's K-tiles, the second time against p.B2 (two-term weights, NtEpilogue::B_lo) - its own instances, so that the
 // default ones carry no trace of it (the scalar selects in stage() cost the joint's three GEMMs 0.1 - 0.2 ms per C2 step when they were unconditional)
-// BAL (round 6, ttmi_set_option(19, 32)): the staging instructions spread evenly over the two phases - phase A of K-tile t stages A(h1) AND B(h1) of K-tile t+1
-// (4 LDS-DMA instructions per wave), phase B stages A(h0) and B(h0) of K-tile t+2 (4) and its counted wait leaves those two half-tiles in flight - instead of 2 + 6
-template <typename TC, int LEAN, bool KW, bool BAL = false>
+template <typename TC, int LEAN, bool KW>
 __device__ __forceinline__ void gemm_nt_v8_body(const FP& p_) {
     FP p = p_;
     p.drop = drop_live(p.drop);
@@ -839,11 +719,10 @@ __device__ __forceinline__ void gemm_nt_v8_body(const FP& p_) {
             glds16(base + o, dst + j * 1024);
         }
     };
-    auto prologue = [&]() {                       // K-tile 0 complete + three half-tiles of K-tile 1 (BAL: two)
+    auto prologue = [&]() {                       // K-tile 0 complete + three half-tiles of K-tile 1
         stage(0, 0, 0); stage(2, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
         // K-tile 0 must have landed at the loop's first wait; tile 1's three half-tiles may fly (one K-tile only: that wait is a full drain)
-        if constexpr (BAL) { if (nk > 1) { TTMI_VM_GUARD("v8b"); stage(0, 1, 1); stage(2, 1, 1); } }
-        else if (nk > 1) { TTMI_VM_GUARD("v8"); stage(0, 1, 1); stage(2, 1, 1); stage(3, 1, 1); }
+        if (nk > 1) { TTMI_VM_GUARD("v8"); stage(0, 1, 1); stage(2, 1, 1); stage(3, 1, 1); }
     };
 
     // fragment addresses: row rho = wr*64 + mt*16 + (lane & 15) (A) / wc*32 + nt*16 + (lane & 15) (B); (rho >> 1) & 7 = (lane >> 1) & 7
@@ -916,8 +795,7 @@ __device__ __forceinline__ void gemm_nt_v8_body(const FP& p_) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if constexpr (BAL) { if (nk > 1) TTMI_VM_WAIT("v8b", 2 * V8_STAGE_DMA); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-        else if (nk > 1) TTMI_VM_WAIT("v8", V8_INFLIGHT);
+        if (nk > 1) TTMI_VM_WAIT("v8", V8_INFLIGHT);
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         V8_BAR();
         if (wr == 1) V8_BAR();                     // waves 4-7 run one barrier behind
@@ -929,10 +807,7 @@ __device__ __forceinline__ void gemm_nt_v8_body(const FP& p_) {
             read_a(base, 0);
             read_b(base, 0);
             read_b(base, 1);
-            if (t + 1 < nk) {
-                stage(1, d ^ 1, t + 1);
-                if constexpr (BAL) stage(3, d ^ 1, t + 1);       // B(h1) of the other buffer: last read in phase A of K-tile t - 1
-            }
+            if (t + 1 < nk) stage(1, d ^ 1, t + 1);
             V8_LGKM0();                            // A(h0), B(h0), B(h1) are re-staged next phase: their reads must have retired
             V8_BAR();
             mma(0, 0);
@@ -941,15 +816,9 @@ __device__ __forceinline__ void gemm_nt_v8_body(const FP& p_) {
             // phase B: rows h1
             read_a(base, 1);
             if (more) {
-                if constexpr (BAL) {
-                    TTMI_VM_GUARD("v8b");           // K-tile t + 1 is older than this point: A(h1), B(h1) issued in phase A, A(h0), B(h0) one tile ago
-                    stage(0, d, t + 2); stage(2, d, t + 2);
-                    TTMI_VM_WAIT("v8b", 2 * V8_STAGE_DMA);
-                } else {
                 TTMI_VM_GUARD("v8");                // everything of K-tile t + 1 (A(h1) issued in phase A, the rest one tile ago) is older than this point
                 stage(0, d, t + 2); stage(2, d, t + 2); stage(3, d, t + 2);
                 TTMI_VM_WAIT("v8", V8_INFLIGHT);
-                }
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -1163,722 +1032,6 @@ template <typename TC, int LEAN = 0>
 __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kernel(const FP p) { gemm_nt_v8_body<TC, LEAN, false>(p); }
 template <typename TC, int LEAN = 0>          // two-term weights (NtEpilogue::B_lo): the K loop runs twice over A's K-tiles
 __global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8_kw_kernel(const FP p) { gemm_nt_v8_body<TC, LEAN, true>(p); }
-template <int LEAN>                           // balanced staging (BAL)
-__global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8b_kernel(const FP p) { gemm_nt_v8_body<bf16_t, LEAN, false, true>(p); }
-
-// =====================================================================================================================
-// v8d ("direct store", round 6): v8's tile, staging, K loop and barrier stagger with ONE change that makes the accumulator layout
-// store-shaped.  The MFMA's row operand is the B fragment, and its 16 rows may be ANY 16 of the wave's 64 output columns: block
-// ni = 2 P + q takes the columns 32 P + 8 g + 4 q + j (g, j = 0..3) as its MFMA rows 4 g + j, so lane (row = lane & 15, g = lane >> 4)
-// ends a tile holding the 8 CONSECUTIVE columns 32 P + 8 g .. + 7 of its row in the registers of blocks 2 P and 2 P + 1: one 16-byte
-// bf16 store per (16-row slab, P) - 16 rows x 64 bytes per instruction, the same 16 store instructions per wave and tile as v8 - with
-// no trip through LDS and no LDS access at all between two K loops (v8: 32 ds_write_b64 + 16 ds_read_b128 per wave and tile behind a
-// compiler-placed vmcnt(0) that parks the epilogue until the next tile's prefetch has landed).  The B half-tiles are staged with a
-// swizzle of their own - 16-byte slot = chunk ^ (((row >> 1) & 1) | (((row >> 3) & 3) << 1)) - under which the permuted fragment read
-// stays conflict-free on ds_read_b128's 16-lane groups: the rows 8 g + 4 q + {0..3} of the four g meet chunks c, c, c ^ 1, c ^ 1 and land
-// in slots c ^ {0, 1}, c ^ {6, 7}, c ^ {3, 2}, c ^ {5, 4}, both row parities each = 16 distinct bank groups.  The bias (LEAN 1 / 3) travels
-// in registers: the next tile's 16 column biases are requested behind its operand prefetch and become the accumulators' start values.
-// Instances: LEAN 1 = bias-only bf16 output, 3 = exp store + row-sum partials (joint forward), 4 = tanh' mask x row factor, mask operand
-// rewritten scaled (joint dgrad of the exp-domain form).  Selected by ttmi_set_option(19, bits): 1 = LEAN 3, 2 = LEAN 1, 4 = LEAN 4.
-// =====================================================================================================================
-constexpr int LDS8D = 2 * BUF8 + 8 * 256;          // two operand buffers + one 64-float bias row per wave
-__device__ const float g_exp_pad = -3.0e38f;        // bias of the exp-store form's pad columns: exp2 of it is the exact zero the padded pitch needs
-template <int LEAN>
-__device__ __forceinline__ void gemm_nt_v8d_body(const FP& p) {
-    static_assert(LEAN == 1 || LEAN == 3 || LEAN == 4, "v8d: bias, exp-store and row-factor epilogues");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int nk = p.K / TK;                       // K % 64 == 0 (launcher)
-
-    auto tile_id = [&](int it) -> long { return (long)it * gridDim.x + (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3); };
-    auto coords = [&](long id, int& bm, int& bn) {
-        const int per_group = GROUP_M * p.tiles_n;
-        const int group = (int)(id / per_group), in = (int)(id % per_group);
-        const int first = group * GROUP_M;
-        const int gsz = min(p.tiles_m - first, GROUP_M);
-        bm = (first + in % gsz) * T8;
-        bn = (in / gsz) * T8;
-    };
-    // staging as in v8 (instruction j of wave w fills half-tile rows rho = (2w + j) * 8 + (lane >> 3), slot lane & 7); the B half-tiles use
-    // the swizzle of the permuted fragment read
-    unsigned oA[2][2], oB[2][2];
-    const char* baseA = nullptr;
-    const char* baseB = nullptr;
-    auto sources = [&](int bm, int bn) {
-        baseA = reinterpret_cast<const char*>(p.A + (long)bm * p.lda);
-        baseB = reinterpret_cast<const char*>(p.B + (long)bn * p.ldb);
-        int ln = lane;
-        asm volatile("" : "+v"(ln));                   // recomputed per tile: hoisted out of the tile loop these lane constants cost 7 spilled registers
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int rho = (wave * 2 + j) * 8 + (ln >> 3);
-            const int ka = (ln & 7) ^ ((rho >> 1) & 7);
-            const int kb = (ln & 7) ^ (((rho >> 1) & 1) | (((rho >> 3) & 3) << 1));
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int ra = min((rho >> 6) * 128 + h * 64 + (rho & 63), p.M - 1 - bm);
-                const int rb = min((rho >> 5) * 64 + h * 32 + (rho & 31), p.N - 1 - bn);
-                oA[h][j] = (unsigned)(((long)ra * p.lda + ka * 8) * 2);
-                oB[h][j] = (unsigned)(((long)rb * p.ldb + kb * 8) * 2);
-            }
-        }
-    };
-    auto stage = [&](int kind, int buf, int kt) {      // kind: 0 = A h0, 1 = A h1, 2 = B h0, 3 = B h1
-        char* dst = smem + buf * BUF8 + kind * HT8 + wave * 2048;
-        const char* base = (kind < 2 ? baseA : baseB) + (long)kt * (TK * 2);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const unsigned o = kind == 0 ? oA[0][j] : kind == 1 ? oA[1][j] : kind == 2 ? oB[0][j] : oB[1][j];
-            glds16(base + o, dst + j * 1024);
-        }
-    };
-    // the wave's 64 column biases travel like an operand tile: ONE 4-byte LDS-DMA per wave and output tile into its own row, issued with K-tile 0 (so
-    // the counted wait that publishes K-tile 0 publishes it), columns beyond N from a pad word (0, or -3e38 in the exp-store form)
-    constexpr bool BIAS_INIT = LEAN == 1 || LEAN == 3;
-    char* brow = smem + 2 * BUF8 + wave * 256;
-    auto prologue = [&](int bn_) {
-        stage(0, 0, 0); stage(2, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
-        if constexpr (BIAS_INIT) {
-            const int col = bn_ + wc * 64 + lane;
-            const float* src = (p.bias && col < p.N) ? p.bias + col : (LEAN == 3 && col >= p.N) ? &g_exp_pad : reinterpret_cast<const float*>(&g_zero16);
-            glds4(src, brow);
-        }
-        if (nk > 1) { TTMI_VM_GUARD("v8d"); stage(0, 1, 1); stage(2, 1, 1); stage(3, 1, 1); }
-    };
-    // fragments: A as in v8; B block q of half P: row wc*32 + 8 gi + 4 q + ji with gi = (lane >> 2) & 3, ji = lane & 3 (MFMA row lane & 15 = 4 gi + ji)
-    int aoff[2], boff[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const int ch = ks * 4 + (lane >> 4);
-        aoff[ks] = (wr * 64 + (lane & 15)) * 128 + ((ch ^ ((lane >> 1) & 7)) << 4);
-        boff[ks] = (wc * 32 + ((lane & 12) << 1) + (lane & 3)) * 128 + ((ch ^ (((lane >> 1) & 1) | (((lane >> 2) & 3) << 1))) << 4);
-    }
-    f32x4 acc[8][4];
-    bf16x8 af[4][2], bfr[2][2][2];
-    auto read_a = [&](const char* base, int h) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) af[mt][ks] = *reinterpret_cast<const bf16x8*>(base + h * HT8 + aoff[ks] + mt * 2048);
-    };
-    auto read_b = [&](const char* base, int h) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-                bfr[h][q][ks] = *reinterpret_cast<const bf16x8*>(base + (2 + h) * HT8 + boff[ks] + q * 512);
-    };
-    auto mma = [&](int mh, int nh) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    acc[mh * 4 + mt][nh * 2 + q] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nh][q][ks], af[mt][ks], acc[mh * 4 + mt][nh * 2 + q], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    };
-#define V8_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#define V8_BAR() __builtin_amdgcn_s_barrier()
-
-    const int g = lane >> 4, wrow = lane & 15;
-    // block ni starts from the biases of its columns 32 (ni >> 1) + 8 g + 4 (ni & 1) + {0..3}: four 16-byte reads of the wave's row, issued as asm so that the
-    // compiler does not drain the vector-memory counter (output stores, the next K-tile's LDS-DMA) in front of an LDS access it cannot place
-    const unsigned brow_lds = (unsigned)(size_t)brow + g * 32;
-    const int rounds = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    int bm = 0, bn = 0;
-    bool live = tile_id(0) < ntiles;
-    f32x4 nb[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    if (live) { coords(tile_id(0), bm, bn); sources(bm, bn); prologue(bn); }
-    const float eshift2 = (LEAN == 3 && p.exp_shift ? *p.exp_shift : 0.f) * 1.4426950408889634f;
-    for (int it = 0; it < rounds && live; ++it) {
-        if (nk > 1) TTMI_VM_WAIT("v8d", V8_INFLIGHT);
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr (BIAS_INIT) {
-            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:128\n\tds_read_b128 %3, %4 offset:144\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(nb[0]), "=&v"(nb[1]), "=&v"(nb[2]), "=&v"(nb[3]) : "v"(brow_lds) : "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = nb[j];
-        V8_BAR();
-        if (wr == 1) V8_BAR();                     // waves 4-7 run one barrier behind
-        for (int t = 0; t < nk; ++t) {
-            const int d = t & 1;
-            const char* base = smem + d * BUF8;
-            const bool more = t + 2 < nk;
-            read_a(base, 0);
-            read_b(base, 0);
-            read_b(base, 1);
-            if (t + 1 < nk) stage(1, d ^ 1, t + 1);
-            V8_LGKM0();
-            V8_BAR();
-            mma(0, 0);
-            mma(0, 1);
-            V8_BAR();
-            read_a(base, 1);
-            if (more) {
-                TTMI_VM_GUARD("v8d");
-                stage(0, d, t + 2); stage(2, d, t + 2); stage(3, d, t + 2);
-                TTMI_VM_WAIT("v8d", V8_INFLIGHT);
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            V8_LGKM0();
-            V8_BAR();
-            mma(1, 1);
-            mma(1, 0);
-            V8_BAR();
-        }
-        if (wr == 0) V8_BAR();                     // realign: every wave has finished reading the operand buffers
-
-        const int cbm = bm, cbn = bn;
-        live = tile_id(it + 1) < ntiles;
-        if (live) {
-            coords(tile_id(it + 1), bm, bn);
-            sources(bm, bn);
-            prologue(bn);
-        }
-
-        // epilogue of (cbm, cbn): acc[sl][2 P + q][j] = C[cbm + wr*128 + sl*16 + wrow][cbn + wc*64 + 32 P + 8 g + 4 q + j]
-        const int row0 = cbm + wr * 128 + wrow;
-        const int col0 = cbn + wc * 64 + g * 8;
-        const int climit = LEAN == 3 ? (int)p.ldc : p.N;
-        bf16_t* crow0 = reinterpret_cast<bf16_t*>(p.C) + (long)row0 * p.ldc + col0;
-        auto store8 = [&](bf16_t* dst, int c, const u32x4& o) {
-            if (c + 7 < climit) {
-                if (p.nt) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(dst));
-                else *reinterpret_cast<u32x4*>(dst) = o;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (c + j < climit) dst[j] = (bf16_t)(o[j >> 1] >> ((j & 1) * 16));
-            }
-        };
-        if constexpr (LEAN == 1 || LEAN == 3) {
-            const long part = (long)((cbn / T8) * 4 + wc) * p.M;
-#pragma unroll
-            for (int sl = 0; sl < 8; ++sl) {
-                const int m = row0 + sl * 16;
-                u32x4 o[2];
-                float rs = 0.f;
-#pragma unroll
-                for (int P = 0; P < 2; ++P) {
-                    f32x4 v0 = acc[sl][2 * P], v1 = acc[sl][2 * P + 1];
-                    if constexpr (LEAN == 3) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            v0[j] = __builtin_amdgcn_exp2f(v0[j] * 1.4426950408889634f - eshift2);
-                            v1[j] = __builtin_amdgcn_exp2f(v1[j] * 1.4426950408889634f - eshift2);
-                            rs += v0[j];
-                            rs += v1[j];
-                        }
-                    }
-                    o[P] = u32x4{pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
-                }
-                if constexpr (LEAN == 3) {
-                    rs += __shfl_xor(rs, 16, 64);
-                    rs += __shfl_xor(rs, 32, 64);
-                    if (g == 0 && m < p.M) p.rowsum[part + m] = rs;       // part-major: 16 consecutive rows per store
-                }
-                if (m < p.M) {
-#pragma unroll
-                    for (int P = 0; P < 2; ++P) store8(crow0 + (long)(sl * 16) * p.ldc + 32 * P, col0 + 32 * P, o[P]);
-                }
-            }
-        } else {
-            // LEAN 4: dH = acc * (1 - h^2) * s_r, h <- s_r h; the mask vectors and row factors of slab sl + 1 are requested before slab sl is formed
-            bf16_t* mrow0 = const_cast<bf16_t*>(p.mask) + (long)row0 * p.ldc + col0;
-            u32x4 mkc[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}}, mkn[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
-            float rsc_c = 0.f, rsc_n = 0.f;
-            auto fetch = [&](int sl, u32x4 (&dst)[2], float& rsv) {
-                const int m = row0 + sl * 16;
-                if (m < p.M) {
-                    rsv = p.rowscale[m];
-#pragma unroll
-                    for (int P = 0; P < 2; ++P)
-                        if (col0 + 32 * P + 7 < p.N) dst[P] = *reinterpret_cast<const u32x4*>(mrow0 + (long)(sl * 16) * p.ldc + 32 * P);
-                }
-            };
-            fetch(0, mkc, rsc_c);
-#pragma unroll
-            for (int sl = 0; sl < 8; ++sl) {
-                if (sl + 1 < 8) fetch(sl + 1, mkn, rsc_n);
-                const int m = row0 + sl * 16;
-                if (m < p.M) {
-#pragma unroll
-                    for (int P = 0; P < 2; ++P) {
-                        const int c = col0 + 32 * P;
-                        bf16_t* dst = crow0 + (long)(sl * 16) * p.ldc + 32 * P;
-                        bf16_t* mp = mrow0 + (long)(sl * 16) * p.ldc + 32 * P;
-                        if (c + 7 < p.N) {
-                            float v[8] = {acc[sl][2 * P][0], acc[sl][2 * P][1], acc[sl][2 * P][2], acc[sl][2 * P][3],
-                                          acc[sl][2 * P + 1][0], acc[sl][2 * P + 1][1], acc[sl][2 * P + 1][2], acc[sl][2 * P + 1][3]};
-                            u32x4 ms;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const float lo = __uint_as_float(mkc[P][j] << 16), hi = __uint_as_float(mkc[P][j] & 0xffff0000u);
-                                v[2 * j] *= (1.f - lo * lo) * rsc_c;
-                                v[2 * j + 1] *= (1.f - hi * hi) * rsc_c;
-                                ms[j] = pack_bf16x2(lo * rsc_c, hi * rsc_c);
-                            }
-                            *reinterpret_cast<u32x4*>(mp) = ms;
-                            const u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-                            if (p.nt) __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(dst));
-                            else *reinterpret_cast<u32x4*>(dst) = o;
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j)
-                                if (c + j < p.N) {
-                                    const float mv = bf16_to_f32(mp[j]);
-                                    const float y = acc[sl][2 * P + (j >> 2)][j & 3] * (1.f - mv * mv) * rsc_c;
-                                    mp[j] = f32_to_bf16(mv * rsc_c);
-                                    dst[j] = f32_to_bf16(y);
-                                }
-                        }
-                    }
-                }
-                mkc[0] = mkn[0]; mkc[1] = mkn[1]; rsc_c = rsc_n;
-            }
-        }
-    }
-#undef V8_LGKM0
-#undef V8_BAR
-}
-template <int LEAN>
-__global__ __launch_bounds__(NTH8, 1) void gemm_nt_bf16_v8d_kernel(const FP p) { gemm_nt_v8d_body<LEAN>(p); }
-
-// =====================================================================================================================
-// v11 ("two workgroups per CU", round 6): the persistent kernel's per-tile fixed cost is matrix-core idle time, so here a CU holds TWO
-// independent 256-thread workgroups (one wave per SIMD each, so every SIMD has one wave of either), each walking its own 256 (M) x 128 (N)
-// output tiles with v8's 128 x 64 wave tile (4 waves as 2 x 2, 128 accumulator registers, 384 B of fragment reads per MFMA - round 2's version of
-// this idea used 64 x 64 wave tiles at 512 B per MFMA and 32-wide K-tiles whose 64-byte row pieces touched every line twice).  Nothing couples the two
-// workgroups: one's epilogue (exp / convert / stores) and tile-start waits run under the other's K loop, and inside the K loops the
-// hardware interleaves the two waves of a SIMD (fragment reads of one under the MFMAs of the other).
-// LDS: 80 KiB per workgroup = a ring of five 16 KiB slots; a K-tile (64 deep) is three items in ring order - A rows h0 (the first 64 rows of
-// each wave-row), B (128 columns), A rows h1 - staged by LDS-DMA (4 instructions per wave and item), item i in slot i % 5:
-//     barrier 1 of K-tile t: items 3t, 3t+1 landed (counted vmcnt(8): two items stay in flight) | stage item 3t+4 | read A h0 + B fragments | 32 MFMAs
-//     barrier 2 of K-tile t: item 3t+2 landed (vmcnt(8))                                        | stage items 3t+5, 3t+6 | read A h1 | 32 MFMAs
-// (a slot is re-staged behind the barrier that follows its last read; an item is read behind the barrier that follows its wait).
-// No LDS is left for output images or bias rows: the accumulator layout is v8d's store-shaped one (B rows permuted in the fragment read, 16-byte pieces
-// straight to memory), the bias is folded into the epilogue.
-// =====================================================================================================================
-constexpr int NTH11 = 256, SL11 = 128 * 64 * 2, NSL11 = 5, LDS11 = NSL11 * SL11, T11N = 128;
-constexpr int V11_ITEM_DMA = SL11 / (NTH11 * 16);          // LDS-DMA instructions per wave and item
-constexpr int V11_INFLIGHT = 2 * V11_ITEM_DMA;             // what the counted waits leave in flight: two items
-static_assert(V11_ITEM_DMA == 4 && V11_INFLIGHT == 8, "v11: the counted vmcnt waits assume 4 LDS-DMA instructions per wave and item");
-
-template <int LEAN>          // 1 = bias-only bf16 output, 3 = exp store + row-sum partials
-__global__ __launch_bounds__(NTH11, 2) void gemm_nt_bf16_v11_kernel(const FP p) {
-    static_assert(LEAN == 1 || LEAN == 3, "v11: bias and exp-store epilogues");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int nk = p.K / TK;                       // K % 64 == 0, K >= 128 (launcher)
-    const int nitems = 3 * nk;
-
-    auto tile_id = [&](int it) -> long { return (long)it * gridDim.x + (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3); };
-    auto coords = [&](long id, int& bm, int& bn) {
-        const int per_group = GROUP_M * p.tiles_n;
-        const int group = (int)(id / per_group), in = (int)(id % per_group);
-        const int first = group * GROUP_M;
-        const int gsz = min(p.tiles_m - first, GROUP_M);
-        bm = (first + in % gsz) * T8;
-        bn = (in / gsz) * T11N;
-    };
-    // staging: instruction j of wave w fills slot rows rho = (4w + j) * 8 + (lane >> 3), 16-byte slot lane & 7 <- source chunk (lane & 7) ^ swizzle(rho)
-    unsigned oA[2][4], oB[4];
-    const char* baseA = nullptr;
-    const char* baseB = nullptr;
-    auto sources = [&](int bm, int bn) {
-        baseA = reinterpret_cast<const char*>(p.A + (long)bm * p.lda);
-        baseB = reinterpret_cast<const char*>(p.B + (long)bn * p.ldb);
-        int ln = lane;
-        asm volatile("" : "+v"(ln));                   // recomputed per tile (hoisted, these lane constants spill)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int rho = (wave * 4 + j) * 8 + (ln >> 3);
-            const int ka = (ln & 7) ^ ((rho >> 1) & 7);
-            const int kb = (ln & 7) ^ (((rho >> 1) & 1) | (((rho >> 3) & 3) << 1));
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int ra = min((rho >> 6) * 128 + h * 64 + (rho & 63), p.M - 1 - bm);
-                oA[h][j] = (unsigned)(((long)ra * p.lda + ka * 8) * 2);
-            }
-            const int rb = min(rho, p.N - 1 - bn);
-            oB[j] = (unsigned)(((long)rb * p.ldb + kb * 8) * 2);
-        }
-    };
-    // item i of the tile: K-tile i / 3, kind i % 3 (0 = A h0, 1 = B, 2 = A h1), slot i % 5 (the caller keeps the three counters)
-    auto stage = [&](int kind, int kt, int slot) {
-        char* dst = smem + slot * SL11 + wave * 4096;
-        const char* base = (kind == 1 ? baseB : baseA) + (long)kt * (TK * 2);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned o = kind == 0 ? oA[0][j] : kind == 2 ? oA[1][j] : oB[j];
-            glds16(base + o, dst + j * 1024);
-        }
-    };
-    int aoff[2], boff[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const int ch = ks * 4 + (lane >> 4);
-        aoff[ks] = (wr * 64 + (lane & 15)) * 128 + ((ch ^ ((lane >> 1) & 7)) << 4);
-        boff[ks] = (wc * 64 + ((lane & 12) << 1) + (lane & 3)) * 128 + ((ch ^ (((lane >> 1) & 1) | (((lane >> 2) & 3) << 1))) << 4);
-    }
-    f32x4 acc[8][4];
-    bf16x8 af[4][2], bfr[2][2][2];
-    auto read_a = [&](const char* base) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) af[mt][ks] = *reinterpret_cast<const bf16x8*>(base + aoff[ks] + mt * 2048);
-    };
-    auto read_b = [&](const char* base) {
-#pragma unroll
-        for (int P = 0; P < 2; ++P)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) bfr[P][q][ks] = *reinterpret_cast<const bf16x8*>(base + boff[ks] + P * 4096 + q * 512);
-    };
-    auto mma = [&](int mh, int nh) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    acc[mh * 4 + mt][nh * 2 + q] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nh][q][ks], af[mt][ks], acc[mh * 4 + mt][nh * 2 + q], 0, 0, 0);
-    };
-#define V11_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#define V11_BAR() __builtin_amdgcn_s_barrier()
-    const int g = lane >> 4, wrow = lane & 15;
-    const int rounds = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    int bm = 0, bn = 0;
-    bool live = tile_id(0) < ntiles;
-    // prologue of a tile: items 0..4 = K-tile 0 complete + A h0 and B of K-tile 1 into slots 0..4 (every wave has passed the barrier behind the previous
-    // tile's last fragment read)
-    auto prologue = [&]() { stage(0, 0, 0); stage(1, 0, 1); stage(2, 0, 2); TTMI_VM_GUARD("v11"); stage(0, 1, 3); stage(1, 1, 4); };
-    if (live) { coords(tile_id(0), bm, bn); sources(bm, bn); prologue(); }
-    const float eshift2 = (LEAN == 3 && p.exp_shift ? *p.exp_shift : 0.f) * 1.4426950408889634f;
-    for (int it = 0; it < rounds && live; ++it) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // ring state: s0 = slot of item 3t (A h0 of this K-tile); the next item to stage is `nxt` (kind nkind of K-tile nkt) into slot sn
-        int s0 = 0, nxt = 5, nkind = 2, nkt = 1, sn = 0;
-        auto stage_next = [&]() {
-            if (nxt < nitems) stage(nkind, nkt, sn);
-            ++nxt;
-            nkind = nkind == 2 ? 0 : nkind + 1;
-            nkt += nkind == 0 ? 1 : 0;
-            sn = sn == NSL11 - 1 ? 0 : sn + 1;
-        };
-        for (int t = 0; t < nk; ++t) {
-            const int s1 = s0 + 1 >= NSL11 ? s0 + 1 - NSL11 : s0 + 1, s2 = s0 + 2 >= NSL11 ? s0 + 2 - NSL11 : s0 + 2;
-            // barrier 1: items 3t, 3t+1 landed; issued so far: up to item 3t+3 (the tile's last K-tile: up to 3t+2 only)
-            if (t + 1 < nk) TTMI_VM_WAIT("v11", V11_INFLIGHT);
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            V11_BAR();
-            if (t > 0) { TTMI_VM_GUARD("v11"); stage_next(); }                   // item 3t+4 into the slot of A h1 of K-tile t-1
-            read_a(smem + s0 * SL11);
-            read_b(smem + s1 * SL11);
-            V11_LGKM0();
-            __builtin_amdgcn_s_setprio(1);
-            mma(0, 0);
-            mma(0, 1);
-            __builtin_amdgcn_s_setprio(0);
-            // barrier 2: item 3t+2 landed; issued so far: up to item 3t+4
-            if (t + 2 < nk) TTMI_VM_WAIT("v11", V11_INFLIGHT);
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            V11_BAR();
-            TTMI_VM_GUARD("v11");
-            stage_next(); stage_next();                                          // items 3t+5, 3t+6 into the slots of A h0 and B of this K-tile
-            read_a(smem + s2 * SL11);
-            V11_LGKM0();
-            __builtin_amdgcn_s_setprio(1);
-            mma(1, 1);
-            mma(1, 0);
-            __builtin_amdgcn_s_setprio(0);
-            s0 = s0 + 3 >= NSL11 ? s0 + 3 - NSL11 : s0 + 3;
-        }
-        V11_BAR();                                  // every wave has read its last fragments: the slots are free for the next tile
-
-        const int cbm = bm, cbn = bn;
-        // the 16 column biases of the lane (exp store: in log2 units, shift folded in; pad columns -> exp2(-inf) = 0), requested before the next tile's prefetch
-        float bq[2][8];
-        {
-            const int col0b = cbn + wc * 64 + g * 8;
-#pragma unroll
-            for (int P = 0; P < 2; ++P)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int col = col0b + 32 * P + j;
-                    const float b = p.bias ? p.bias[min(col, p.N - 1)] : 0.f;
-                    bq[P][j] = LEAN == 3 ? (col < p.N ? b * 1.4426950408889634f - eshift2 : -__builtin_inff()) : b;
-                }
-        }
-        live = tile_id(it + 1) < ntiles;
-        if (live) { coords(tile_id(it + 1), bm, bn); sources(bm, bn); prologue(); }
-
-        // epilogue of (cbm, cbn): acc[sl][2 P + q][j] = C[cbm + wr*128 + sl*16 + wrow][cbn + wc*64 + 32 P + 8 g + 4 q + j]
-        const int row0 = cbm + wr * 128 + wrow;
-        const int col0 = cbn + wc * 64 + g * 8;
-        const int climit = LEAN == 3 ? (int)p.ldc : p.N;
-        bf16_t* crow0 = reinterpret_cast<bf16_t*>(p.C) + (long)row0 * p.ldc + col0;
-        const long part = (long)(cbn / 64 + wc) * p.M;
-#pragma unroll
-        for (int sl = 0; sl < 8; ++sl) {
-            const int m = row0 + sl * 16;
-            u32x4 o[2];
-            float rs = 0.f;
-#pragma unroll
-            for (int P = 0; P < 2; ++P) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float a = acc[sl][2 * P + (j >> 2)][j & 3];
-                    if constexpr (LEAN == 3) { v[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(a, 1.4426950408889634f, bq[P][j])); rs += v[j]; }
-                    else v[j] = a + bq[P][j];
-                }
-                o[P] = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-            }
-            if constexpr (LEAN == 3) {
-                rs += __shfl_xor(rs, 16, 64);
-                rs += __shfl_xor(rs, 32, 64);
-                if (g == 0 && m < p.M) p.rowsum[part + m] = rs;
-            }
-            if (m < p.M) {
-#pragma unroll
-                for (int P = 0; P < 2; ++P) {
-                    bf16_t* dst = crow0 + (long)(sl * 16) * p.ldc + 32 * P;
-                    const int c = col0 + 32 * P;
-                    if (c + 7 < climit) {
-                        if (p.nt) __builtin_nontemporal_store(o[P], reinterpret_cast<u32x4*>(dst));
-                        else *reinterpret_cast<u32x4*>(dst) = o[P];
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            if (c + j < climit) dst[j] = (bf16_t)(o[P][j >> 1] >> ((j & 1) * 16));
-                    }
-                }
-            }
-        }
-    }
-#undef V11_LGKM0
-#undef V11_BAR
-}
-
-// =====================================================================================================================
-// v10: the v8 problem (persistent 256x256 output tiles, joint-sized GEMMs) on FOUR waves (2 x 2) with 128 x 128 wave tiles:
-// 8 x 8 v_mfma_f32_16x16x32_bf16 tiles = 256 accumulator registers per lane (AGPRs; one wave per SIMD).  v8's 128 x 64 wave
-// tiles read (128 + 64) x 64 x 2 B of fragments per wave and K-tile: 8 waves x 24 KiB + 64 KiB of staging = 256 KiB through
-// a 128 B/cycle LDS port = 2048 cycles, exactly the 2048 cycles the MFMAs of the same K-tile need - v8 is LDS-bound.  Here
-// 4 waves x 32 KiB + 64 KiB = 192 KiB = 1536 cycles.  The vendor library's assembly kernel for these shapes has the same
-// macro tile / wave tile (MT256x256x64, 4 waves) and runs the joint forward 8 % faster than v8.
-// K-step = 32 (one MFMA depth): five 32 KiB LDS stages (A 256 rows x 64 B | B 256 rows x 64 B, 16-byte slot q of row r holds
-// source chunk q ^ (-(r >> 2) & 3): a fragment = 16 rows x 64 B, conflict-free for ds_read_b128's four 16-lane groups
-// {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... - the plain (r >> 2) & 3 swizzle is 2-way conflicted on them), staged by global_load_lds four steps ahead.
-// Step s, every wave:  [8 global_load_lds of step s+4] [16 ds_read_b128 = fragments of step s+1 into the other register set]
-// [64 MFMAs on step s]  s_waitcnt lgkmcnt(0); every second step: vmcnt(8), s_barrier.   One barrier per 128 MFMAs; with a single wave per SIMD the
-// overlap of LDS reads / DMA issue with the MFMAs is the in-order issue of independent instructions between MFMAs.
-// =====================================================================================================================
-constexpr int T10 = 256, NTH10 = 256, KS10 = 32, HALF10 = 256 * KS10 * 2, STG10 = 2 * HALF10;
-constexpr int NST10 = 5, LDS10 = NST10 * STG10;      // the epilogue's images live in stage 4 (free between tiles)
-constexpr int V10_STAGE_DMA = STG10 / (NTH10 * 16);    // LDS-DMA instructions per wave and stage = what the counted waits leave in flight (one stage)
-static_assert(V10_STAGE_DMA == 8, "v10: the counted vmcnt waits assume 8 LDS-DMA instructions per stage");
-
-template <typename TC, int DBG = 0>
-__global__ __launch_bounds__(NTH10, 1) void gemm_nt_bf16_v10_kernel(const FP p_) {
-    FP p = p_;
-    p.drop = drop_live(p.drop);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int ns = p.K / KS10;                                  // K % 64 == 0 (launcher): even, >= 4
-
-    auto tile_id = [&](int it) { return (long)it * gridDim.x + (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3); };
-    auto coords = [&](long id, int& bm, int& bn) {
-        const int per_group = GROUP_M * p.tiles_n;
-        const int group = (int)(id / per_group), in = (int)(id % per_group);
-        const int first = group * GROUP_M;
-        const int gsz = min(p.tiles_m - first, GROUP_M);
-        bm = (first + in % gsz) * T10;
-        bn = (in / gsz) * T10;
-    };
-    // staging: wave w fills rows w*64 .. w*64+63 of both operands, instruction j rows rho = w*64 + j*16 + (lane >> 2), slot lane & 3,
-    // which must hold source chunk (lane & 3) ^ (-(rho >> 2) & 3) = (lane & 3) ^ (-(lane >> 4) & 3)
-    unsigned oA[4], oB[4];
-    const char* baseA = nullptr;
-    const char* baseB = nullptr;
-    const int kc = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
-    auto sources = [&](int bm, int bn) {
-        baseA = reinterpret_cast<const char*>(p.A + (long)bm * p.lda);
-        baseB = reinterpret_cast<const char*>(p.B + (long)bn * p.ldb);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int rho = wave * 64 + j * 16 + (lane >> 2);
-            const int ra = min(rho, p.M - 1 - bm), rb = min(rho, p.N - 1 - bn);
-            oA[j] = (unsigned)(((long)ra * p.lda + kc * 8) * 2);
-            oB[j] = (unsigned)(((long)rb * p.ldb + kc * 8) * 2);
-        }
-    };
-    auto stage = [&](int s) {
-        char* dst = smem + (s % NST10) * STG10 + wave * 4096;
-        const char* ba = baseA + (long)s * (KS10 * 2);
-        const char* bb = baseB + (long)s * (KS10 * 2);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(ba + oA[j], dst + j * 1024);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(bb + oB[j], dst + HALF10 + j * 1024);
-    };
-    auto prologue = [&]() { stage(0); stage(1); stage(2); TTMI_VM_GUARD("v10"); stage(3); };      // steps 0, 1, 2 must have landed at the tile's first wait
-
-    // fragment t of A: rows wr*128 + t*16 + (lane & 15), chunk lane >> 4 at slot (lane >> 4) ^ (-(lane >> 2) & 3)
-    const int fsw = ((lane >> 4) ^ ((0 - (lane >> 2)) & 3)) << 4;
-    const int aoff = (wr * 128 + (lane & 15)) * 64 + fsw;
-    const int boff = HALF10 + (wc * 128 + (lane & 15)) * 64 + fsw;
-    // The accumulators are pinned to AGPRs and the step is laid out by hand (inline asm): left to the register allocator the 256
-    // accumulators and 128 fragment registers get mixed across both files and every MFMA drags v_accvgpr moves along (1.04 PFLOP/s
-    // at 8192^3 against v8's 1.49).  Order inside a step: 16 groups of [DMA issue (every other group) | one ds_read_b128 of the
-    // next step's fragments | 4 MFMAs of this step].
-    f32x4 acc[8][8];
-    bf16x8 af[2][8], bfr[2][8];
-    const unsigned lds0 = (unsigned)(size_t)smem;              // LDS byte offset = low half of the flat shared address
-#define V10_DSREAD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
-#define V10_MFMA(c, a, b) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
-    auto step = [&](int s, int cur, auto full) {
-        constexpr bool FULL = decltype(full)::value;
-        const bool st = !(DBG & 2) && (FULL || s + 4 < ns), rd = !(DBG & 1) && (FULL || s + 1 < ns);
-        const unsigned fa = lds0 + ((s + 1) % NST10) * STG10 + aoff, fb = lds0 + ((s + 1) % NST10) * STG10 + boff;
-        char* dst = smem + ((s + 4) % NST10) * STG10 + wave * 4096;
-        const char* ba = baseA + (long)(s + 4) * (KS10 * 2);
-        const char* bb = baseB + (long)(s + 4) * (KS10 * 2);
-        const int nx = cur ^ 1;
-        if constexpr (FULL && !(DBG & 2)) TTMI_VM_GUARD("v10"); // everything staged in earlier steps (s + 3 and older) is older than this step's eight DMA instructions
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            if (st && (g & 1) == 0) {
-                const int j = g >> 1;
-                if (j < 4) glds16(ba + oA[j], dst + j * 1024);
-                else glds16(bb + oB[j - 4], dst + HALF10 + (j - 4) * 1024);
-            }
-            if (rd && g < 8) {                                  // both operands' fragment g: all reads are out by mid-step
-                switch (g) {
-                    case 0: V10_DSREAD(af[nx][0], fa, 0); V10_DSREAD(bfr[nx][0], fb, 0); break;
-                    case 1: V10_DSREAD(af[nx][1], fa, 1024); V10_DSREAD(bfr[nx][1], fb, 1024); break;
-                    case 2: V10_DSREAD(af[nx][2], fa, 2048); V10_DSREAD(bfr[nx][2], fb, 2048); break;
-                    case 3: V10_DSREAD(af[nx][3], fa, 3072); V10_DSREAD(bfr[nx][3], fb, 3072); break;
-                    case 4: V10_DSREAD(af[nx][4], fa, 4096); V10_DSREAD(bfr[nx][4], fb, 4096); break;
-                    case 5: V10_DSREAD(af[nx][5], fa, 5120); V10_DSREAD(bfr[nx][5], fb, 5120); break;
-                    case 6: V10_DSREAD(af[nx][6], fa, 6144); V10_DSREAD(bfr[nx][6], fb, 6144); break;
-                    default: V10_DSREAD(af[nx][7], fa, 7168); V10_DSREAD(bfr[nx][7], fb, 7168); break;
-                }
-            }
-#pragma unroll
-            for (int q = g * 4; q < g * 4 + 4; ++q) V10_MFMA(acc[q >> 3][q & 7], bfr[cur][q & 7], af[cur][q >> 3]);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (cur == 1) {
-            // one barrier per TWO steps (128 MFMAs): with five stages the region a step overwrites was last read two steps earlier, i.e.
-            // before the previous barrier; the barrier publishes the DMA data of the next two steps (s+2, s+3 - only s+4 stays in flight)
-            // (the counted wait belongs to the FULL steps, whose eight DMA instructions are unconditional: the tile's last steps, where staging
-            // is a run-time condition, drain - a path on which the loads are skipped and the counted wait taken would be unprovable in the ISA)
-            if (FULL && !(DBG & 2)) TTMI_VM_WAIT("v10", V10_STAGE_DMA);
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-    };
-    auto read0 = [&]() {                                       // fragments of step 0 into set 0 (tile start)
-        const unsigned fa = lds0 + aoff, fb = lds0 + boff;
-        V10_DSREAD(af[0][0], fa, 0); V10_DSREAD(af[0][1], fa, 1024); V10_DSREAD(af[0][2], fa, 2048); V10_DSREAD(af[0][3], fa, 3072);
-        V10_DSREAD(af[0][4], fa, 4096); V10_DSREAD(af[0][5], fa, 5120); V10_DSREAD(af[0][6], fa, 6144); V10_DSREAD(af[0][7], fa, 7168);
-        V10_DSREAD(bfr[0][0], fb, 0); V10_DSREAD(bfr[0][1], fb, 1024); V10_DSREAD(bfr[0][2], fb, 2048); V10_DSREAD(bfr[0][3], fb, 3072);
-        V10_DSREAD(bfr[0][4], fb, 4096); V10_DSREAD(bfr[0][5], fb, 5120); V10_DSREAD(bfr[0][6], fb, 6144); V10_DSREAD(bfr[0][7], fb, 7168);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-
-    const int rounds = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    int bm = 0, bn = 0;
-    bool live = tile_id(0) < ntiles;
-    if (live) { coords(tile_id(0), bm, bn); sources(bm, bn); prologue(); }
-    for (int it = 0; it < rounds && live; ++it) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        TTMI_VM_WAIT("v10", V10_STAGE_DMA);                                // steps 0, 1, 2 have landed (3 may be in flight)
-        __builtin_amdgcn_s_barrier();
-        read0();
-        int s = 0;
-        for (; s + 5 < ns; s += 2) {
-            step(s, 0, std::true_type());
-            step(s + 1, 1, std::true_type());
-        }
-        for (; s < ns; s += 2) {
-            step(s, 0, std::false_type());
-            step(s + 1, 1, std::false_type());
-        }
-
-        const int cbm = bm, cbn = bn;
-        live = tile_id(it + 1) < ntiles;
-        if (live) { coords(tile_id(it + 1), bm, bn); sources(bm, bn); prologue(); }
-
-        // epilogue: acc[mi][ni][j] = C[cbm + wr*128 + mi*16 + (lane & 15)][cbn + wc*128 + ni*16 + (lane >> 4)*4 + j]; 16 rows x 64 columns at a
-        // time through the wave's private f32 image (v8's layout: chunk c of row r at slot c ^ r)
-        TC* C = reinterpret_cast<TC*>(p.C);
-        char* img = smem + 4 * STG10 + wave * 8192;          // stage 4: not touched by the next tile's prologue (stages 0..3)
-        const bool vec = (p.ldc % 4 == 0) && ((reinterpret_cast<size_t>(p.C) & 15) == 0) &&
-                         (!p.addend || (reinterpret_cast<size_t>(p.addend) & 15) == 0) &&
-                         (!p.mask || (reinterpret_cast<size_t>(p.mask) & 7) == 0) && (!p.bias || (reinterpret_cast<size_t>(p.bias) & 15) == 0);
-        const int wrow = lane & 15, wq = lane >> 4;
-        const bool plain8 = vec && p.ldc % 8 == 0;
-#define V10_SLAB(I) case I: _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) \
-            *reinterpret_cast<f32x4*>(img + hf * 4096 + wrow * 256 + (((ni * 4 + wq) ^ wrow) << 4)) = acc[I][hf * 4 + ni]; break;
-#pragma unroll 1
-        for (int mi = 0; mi < 8; ++mi) {
-            switch (mi) { V10_SLAB(0) V10_SLAB(1) V10_SLAB(2) V10_SLAB(3) V10_SLAB(4) V10_SLAB(5) V10_SLAB(6) V10_SLAB(7) }
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const char* im = img + hf * 4096;
-                const int nb = cbn + wc * 128 + hf * 64;
-                if (sizeof(TC) == 2 && plain8) {
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int r = q * 8 + (lane >> 3);
-                        const int c8 = lane & 7;
-                        const f32x4 x0 = *reinterpret_cast<const f32x4*>(im + r * 256 + (((2 * c8) ^ r) << 4));
-                        const f32x4 x1 = *reinterpret_cast<const f32x4*>(im + r * 256 + (((2 * c8 + 1) ^ r) << 4));
-                        if constexpr (sizeof(TC) == 2)
-                            epi_store8_bf16(p, reinterpret_cast<bf16_t*>(C), cbm + wr * 128 + mi * 16 + r, nb + c8 * 8, x0, x1, vec);
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int r = q * 4 + (lane >> 4);
-                        const int c = (lane & 15) ^ r;
-                        const f32x4 x = *reinterpret_cast<const f32x4*>(im + r * 256 + ((lane & 15) << 4));
-                        epi_store4<TC>(p, C, cbm + wr * 128 + mi * 16 + r, nb + c * 4, x, vec);
-                    }
-                }
-            }
-        }
-#undef V10_SLAB
-    }
-#undef V10_DSREAD
-#undef V10_MFMA
-}
 
 // =====================================================================================================================
 // v9: the v8 schedule for mid-sized outputs (the encoder GEMMs: 16000 rows x 512..2048 columns, K = 512..2048), where 256x256
@@ -2914,13 +2067,15 @@ int enable_lds(K kernel, int bytes) {
 // ttmi_set_option(1, v) - A/B measurements: 1 = 128x128 double-buffered, 3 = 1 + software-pipelined fragment reads,
 // 4 (default) = single 32 KiB buffer, 4 workgroups per CU, one fragment set (stays under 128 VGPRs without spills; NT +15 % at
 // the joint shapes; TN +8 % once each XCD owns a K-range) with the persistent 256x256 kernel (v8) for outputs of >= 1024 tiles,
-// 5 = 4 without v8, 6 = the earlier double-buffered 256x256 kernel wherever it fits, 8 = v8 wherever it fits.
+// 5 = 4 without v8, 8 = v8 wherever it fits, 9 = the persistent 256x128 kernel (v9) wherever it fits.
 // Measured and dropped (same box, joint projection M=816000 N=4334 K=1024, v4 = 720 TFLOP/s): 256x128 3-stage ring with
-// counted vmcnt 621; persistent 256x256 with a 4-slice ring that never drains 668 (dgrad K=4352: 904 vs 938 for v6).
+// counted vmcnt 621; persistent 256x256 with a 4-slice ring that never drains 668; the double-buffered 256x256 kernel without the wave stagger (v6, rounds 1 - 5);
+// 4 waves x 128x128 wave tiles with AGPR accumulators (v10, rounds 1 - 5: 1.36 vs 1.55 PFLOP/s at 8192^3); round 6 (commit 70a15b4, profiles/r06_joint_gemm_variants.txt):
+// accumulators stored straight from a store-shaped layout without the LDS transpose (+1 .. +3.5 % time), two free-running 4-wave workgroups per CU
+// on 256x128 tiles (1.5 - 1.7 x the time), the 8 LDS-DMA instructions of a K-tile spread 4 + 4 over the two phases (+-1 %).
 int g_gemm_fast_version = 4;
 int g_f32_fast = 1;              // ttmi_set_option(17, v): 0 = f32 NT products stay on the kernels of csrc/gemm.hip (A/B); 2 = the 64x64-tile kernel wherever it can run; 3 = the persistent kernel only
 int g_bf16_mid = 32;             // set_version(16 + n): bf16 NT problems the persistent kernels leave go to the 64 x 64-tile kernel from n of its tiles on (16 = never)
-int g_v8_direct = 0;             // ttmi_set_option(19, bits): the direct-store instances of the persistent 256x256 kernel (v8d): 1 = exp store, 2 = bias-only, 4 = row factor
 int g_nt_stores = 1;             // streaming stores for bf16 outputs >= 256 MB (set_version(14 / 15) = off / on, generation unchanged)
 int g_num_cus = 0;
 int g_reserved_cus = 0;           // ttmi_set_option(6, n): process-wide default of the per-stream reservation below (measurement switch)
@@ -3077,32 +2232,6 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
         TTMI_LAUNCH_CHECK("gemm_nt_bf16_v9_kernel");
         return TTMI_OK;
     }
-    if (pers && N >= 256 && g_gemm_fast_version >= 10 && g_gemm_fast_version <= 13) {
-        p.tiles_m = cdiv(M, T10); p.tiles_n = cdiv(N, T10);
-        const long nwg10 = (long)p.tiles_m * p.tiles_n;
-        const int cus10 = nwg10 < 1024 ? std::max(8, (g_num_cus - reserved) / 8 * 8) : g_num_cus;
-        const int grid10 = (int)((std::min<long>(nwg10, cus10) + 7) / 8 * 8);
-        if (c_dtype == 0) {
-            if (int rc = enable_lds(gemm_nt_bf16_v10_kernel<float>, LDS10)) return rc;
-            hipLaunchKernelGGL(gemm_nt_bf16_v10_kernel<float>, dim3((unsigned)grid10), dim3(NTH10), LDS10, st, p);
-        } else {
-            if (g_gemm_fast_version == 11) {
-                if (int rc = enable_lds(gemm_nt_bf16_v10_kernel<bf16_t, 1>, LDS10)) return rc;
-                hipLaunchKernelGGL((gemm_nt_bf16_v10_kernel<bf16_t, 1>), dim3((unsigned)grid10), dim3(NTH10), LDS10, st, p);
-            } else if (g_gemm_fast_version == 12) {
-                if (int rc = enable_lds(gemm_nt_bf16_v10_kernel<bf16_t, 2>, LDS10)) return rc;
-                hipLaunchKernelGGL((gemm_nt_bf16_v10_kernel<bf16_t, 2>), dim3((unsigned)grid10), dim3(NTH10), LDS10, st, p);
-            } else if (g_gemm_fast_version == 13) {
-                if (int rc = enable_lds(gemm_nt_bf16_v10_kernel<bf16_t, 3>, LDS10)) return rc;
-                hipLaunchKernelGGL((gemm_nt_bf16_v10_kernel<bf16_t, 3>), dim3((unsigned)grid10), dim3(NTH10), LDS10, st, p);
-            } else {
-            if (int rc = enable_lds(gemm_nt_bf16_v10_kernel<bf16_t>, LDS10)) return rc;
-            hipLaunchKernelGGL(gemm_nt_bf16_v10_kernel<bf16_t>, dim3((unsigned)grid10), dim3(NTH10), LDS10, st, p);
-            }
-        }
-        TTMI_LAUNCH_CHECK("gemm_nt_bf16_v10_kernel");
-        return TTMI_OK;
-    }
     // persistent 256x256 kernel: needs several rounds of tiles per CU to amortise its pipeline fill and tail
     if (v8) {
         if (two_term) { p.B2 = epi.B_lo; p.kwrap = K / TK; p.K = K + k_lo; }
@@ -3127,49 +2256,9 @@ if (p.kwrap) {
         } else if (p.rowsum) {
             TTMI_REQUIRE(!p.addend && !p.mask && !p.relu && p.drop.p <= 0.f && ldc % 8 == 0 && aligned16(C) && p.nparts >= 4 * p.tiles_n,
                          "gemm_nt_bf16: exp store needs a plain bf16 output with pitch %% 8 == 0 and nparts >= 4 * column tiles");
-            if (g_v8_direct & 32) {
-                if (int rc = enable_lds((gemm_nt_bf16_v8b_kernel<3>), LDS8)) return rc;
-                hipLaunchKernelGGL((gemm_nt_bf16_v8b_kernel<3>), dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
-                TTMI_LAUNCH_CHECK("gemm_nt_bf16_v8b_kernel");
-                return TTMI_OK;
-            }
-            if ((g_v8_direct & 8) && K >= 128) {
-                p.tiles_n = 2 * cdiv(N, T8);           // every one of the 4 * ceil(N / 256) row-sum partials is written (a strip beyond N stores zeros)
-                const int grid11 = (int)((std::min<long>((long)p.tiles_m * p.tiles_n, 2L * g_num_cus) + 7) / 8 * 8);
-                if (int rc = enable_lds((gemm_nt_bf16_v11_kernel<3>), LDS11)) return rc;
-                hipLaunchKernelGGL((gemm_nt_bf16_v11_kernel<3>), dim3((unsigned)grid11), dim3(NTH11), LDS11, st, p);
-                TTMI_LAUNCH_CHECK("gemm_nt_bf16_v11_kernel");
-                return TTMI_OK;
-            }
-            if ((g_v8_direct & 1) && (!p.bias || aligned16(p.bias))) {
-                if (int rc = enable_lds((gemm_nt_bf16_v8d_kernel<3>), LDS8D)) return rc;
-                hipLaunchKernelGGL((gemm_nt_bf16_v8d_kernel<3>), dim3((unsigned)grid8), dim3(NTH8), LDS8D, st, p);
-                TTMI_LAUNCH_CHECK("gemm_nt_bf16_v8d_kernel");
-                return TTMI_OK;
-            }
             if (int rc = enable_lds((gemm_nt_bf16_v8_kernel<bf16_t, 3>), LDS8)) return rc;
             hipLaunchKernelGGL((gemm_nt_bf16_v8_kernel<bf16_t, 3>), dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
         } else if (!p.addend && !p.mask && !p.relu && p.drop.p <= 0.f && ldc % 8 == 0 && aligned16(C) && (!p.bias || aligned16(p.bias))) {
-            if (g_v8_direct & 32) {
-                if (int rc = enable_lds((gemm_nt_bf16_v8b_kernel<1>), LDS8)) return rc;
-                hipLaunchKernelGGL((gemm_nt_bf16_v8b_kernel<1>), dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
-                TTMI_LAUNCH_CHECK("gemm_nt_bf16_v8b_kernel");
-                return TTMI_OK;
-            }
-            if ((g_v8_direct & 16) && K >= 128) {
-                p.tiles_n = cdiv(N, T11N);
-                const int grid11 = (int)((std::min<long>((long)p.tiles_m * p.tiles_n, 2L * g_num_cus) + 7) / 8 * 8);
-                if (int rc = enable_lds((gemm_nt_bf16_v11_kernel<1>), LDS11)) return rc;
-                hipLaunchKernelGGL((gemm_nt_bf16_v11_kernel<1>), dim3((unsigned)grid11), dim3(NTH11), LDS11, st, p);
-                TTMI_LAUNCH_CHECK("gemm_nt_bf16_v11_kernel");
-                return TTMI_OK;
-            }
-            if (g_v8_direct & 2) {
-                if (int rc = enable_lds((gemm_nt_bf16_v8d_kernel<1>), LDS8D)) return rc;
-                hipLaunchKernelGGL((gemm_nt_bf16_v8d_kernel<1>), dim3((unsigned)grid8), dim3(NTH8), LDS8D, st, p);
-                TTMI_LAUNCH_CHECK("gemm_nt_bf16_v8d_kernel");
-                return TTMI_OK;
-            }
             if (int rc = enable_lds((gemm_nt_bf16_v8_kernel<bf16_t, 1>), LDS8)) return rc;
             hipLaunchKernelGGL((gemm_nt_bf16_v8_kernel<bf16_t, 1>), dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
         } else if (!p.addend && !p.mask && p.relu && !p.rowscale && ldc % 8 == 0 && aligned16(C) && (!p.bias || aligned16(p.bias))) {
@@ -3178,18 +2267,6 @@ if (p.kwrap) {
         } else if (p.rowscale) {
             TTMI_REQUIRE(!p.addend && p.mask && p.mask_mode == 1 && !p.bias && !p.relu && p.drop.p <= 0.f && ldc % 8 == 0 && aligned16(C) && aligned16(p.mask),
                          "gemm_nt_bf16: the row factor needs the tanh-mask bf16 epilogue");
-            if (g_v8_direct & 32) {
-                if (int rc = enable_lds((gemm_nt_bf16_v8b_kernel<4>), LDS8)) return rc;
-                hipLaunchKernelGGL((gemm_nt_bf16_v8b_kernel<4>), dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
-                TTMI_LAUNCH_CHECK("gemm_nt_bf16_v8b_kernel");
-                return TTMI_OK;
-            }
-            if (g_v8_direct & 4) {
-                if (int rc = enable_lds((gemm_nt_bf16_v8d_kernel<4>), LDS8D)) return rc;
-                hipLaunchKernelGGL((gemm_nt_bf16_v8d_kernel<4>), dim3((unsigned)grid8), dim3(NTH8), LDS8D, st, p);
-                TTMI_LAUNCH_CHECK("gemm_nt_bf16_v8d_kernel");
-                return TTMI_OK;
-            }
             if (int rc = enable_lds((gemm_nt_bf16_v8_kernel<bf16_t, 4>), LDS8)) return rc;
             hipLaunchKernelGGL((gemm_nt_bf16_v8_kernel<bf16_t, 4>), dim3((unsigned)grid8), dim3(NTH8), LDS8, st, p);
         } else if (!p.addend && p.mask && !p.bias && !p.relu && p.drop.p <= 0.f && ldc % 8 == 0 && aligned16(C) && aligned16(p.mask)) {
@@ -3210,20 +2287,6 @@ if (p.kwrap) {
         if (c_dtype == 0) hipLaunchKernelGGL(gemm_nt_bf16_mid_kernel<float>, dim3((unsigned)p.tiles_n, (unsigned)p.tiles_m), dim3(256), LDSM, st, p);
         else hipLaunchKernelGGL(gemm_nt_bf16_mid_kernel<bf16_t>, dim3((unsigned)p.tiles_n, (unsigned)p.tiles_m), dim3(256), LDSM, st, p);
         TTMI_LAUNCH_CHECK("gemm_nt_bf16_mid_kernel");
-        return TTMI_OK;
-    }
-    const bool big = (g_gemm_fast_version == 6) && !dual;
-    if (big && M >= 1024 && N >= 256 && nbatch == 1) {
-        p.tiles_m = cdiv(M, T6); p.tiles_n = cdiv(N, T6);
-        const long nwg6 = (long)p.tiles_m * p.tiles_n;
-        if (c_dtype == 0) {
-            if (int rc = enable_lds(gemm_nt_bf16_v6_kernel<float>, 2 * STAGE6)) return rc;
-            hipLaunchKernelGGL(gemm_nt_bf16_v6_kernel<float>, dim3((unsigned)nwg6), dim3(NTH6), 2 * STAGE6, st, p);
-        } else {
-            if (int rc = enable_lds(gemm_nt_bf16_v6_kernel<bf16_t>, 2 * STAGE6)) return rc;
-            hipLaunchKernelGGL(gemm_nt_bf16_v6_kernel<bf16_t>, dim3((unsigned)nwg6), dim3(NTH6), 2 * STAGE6, st, p);
-        }
-        TTMI_LAUNCH_CHECK("gemm_nt_bf16_v6_kernel");
         return TTMI_OK;
     }
     const long nwg = (long)p.tiles_m * p.tiles_n;
@@ -3420,7 +2483,6 @@ void gemm_fast_set_version(int v) {
     if (v >= 16) { g_bf16_mid = v - 16; return; }
     g_gemm_fast_version = v;
 }
-void gemm_fast_set_direct(int bits) { g_v8_direct = bits; }
 void gemm_fast_set_tn_target(int n) { g_tn_target_blocks = n; }
 void gemm_fast_set_f32(int on) { g_f32_fast = on; }
 int gemm_fast_f32_mode() { return g_f32_fast; }

@@ -62,7 +62,7 @@ int wgrad(const float* dY, const float* X, float* gW, int M, int N, int K, long 
 // ---- TTMI_PRECISION=bf16x3 (prec 2, round 5): the parity mode's f32 data flow with its large dense products on the bf16 MFMA in three
 // terms (rowops.hip split3_kernel): A . B^T ~ A_hi B_hi + A_lo B_hi + A_hi B_lo - one launch of the throughput kernels over the tripled
 // reduction (NT / NN), three accumulating launches on the [hi | lo] planes (TN: weight gradients).  Relative error ~2^-16 per product against
-// 2^-24 (exact f32) and 2^-8 (bf16); tests/test_bf16x3_gpu.py holds the mode to the fp32 mode's own 1e-4 bounds.  `scratch`: bf16 elements.
+// 2^-24 (exact f32) and 2^-8 (bf16); tests/test_configs_gpu.py (full C2 / C4 models, a layer with dropout) and tests/test_gemm_gpu.py hold the mode to the fp32 mode's own 1e-4 bounds.  `scratch`: bf16 elements.
 inline int x3_pad(int n) { return (n + 63) / 64 * 64; }
 inline size_t x3_al(size_t n) { return (n + 63) & ~(size_t)63; }
 inline size_t x3_nt_elems(long M, long N, int K) { return x3_al((size_t)M * 3 * x3_pad(K)) + x3_al((size_t)N * 3 * x3_pad(K)); }
@@ -1512,8 +1512,7 @@ int ttmi_set_dropout_salt(const unsigned* salt) {
 // process-wide switches for A/B measurements.  key 0: 1 = disable the fused attention kernels (bf16 pipeline only);
 // key 1: throughput-GEMM generation (see gemm_fast.hip); key 2: flash-kernel timing switches; key 3: 0 = no wgrad fork
 int ttmi_set_option(int key, int value) {
-    TTMI_REQUIRE(key >= 0 && key <= 19, "set_option: unknown key %d", key);
-    if (key == 19) { gemm_fast_set_direct(value); return TTMI_OK; }
+    TTMI_REQUIRE(key >= 0 && key <= 18, "set_option: unknown key %d", key);
     if (key == 18) { g_capture_forks = value; return TTMI_OK; }
     if (key == 17) { gemm_fast_set_f32(value); return TTMI_OK; }
     if (key == 16) { g_scatter_launch = value; return TTMI_OK; }

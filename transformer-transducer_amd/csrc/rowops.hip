@@ -923,8 +923,8 @@ __global__ __launch_bounds__(256) void joint_tanh_fwd_bf16x8_kernel(const float*
                         db = fmaf(hv[i], wb[i], db); dl = fmaf(hv[i], wl[i], dl);
                         db32 = fmaf(th[i], wb32[i], db32); dl32 = fmaf(th[i], wl32[i], dl32);
                     }
-                    // sum over the lanes of this wave that hold the row (all 64, or an aligned group of tpr = 32): the group's last FOUR lanes
-                    // get the four sums (value index = lane & 3)
+                    // sum over the lanes of this wave that hold the row (all 64, or an aligned group of tpr = 32): EVERY lane of the group ends with the sum
+                    // of value index lane & 3; the group's first four lanes store them
                     const float sv = tpr >= 64 ? dpp_row_sum4<true>(db, dl, db32, dl32, tin) : dpp_row_sum4<false>(db, dl, db32, dl32, tin);
                     if ((tin & (tpr >= 64 ? 63 : 31)) < 4)
                         part[(((long)tt * U1 + u) * nw + (tin >> 6)) * 4 + (tin & 3)] = sv;
@@ -1736,6 +1736,14 @@ __global__ __launch_bounds__(256) void zero2d_kernel(unsigned short* __restrict_
         p[r * pitch2 + c] = 0;
     }
 }
+// the same for odd widths / pitches / addresses: single bytes
+__global__ __launch_bounds__(256) void zero2d_bytes_kernel(unsigned char* __restrict__ p, size_t pitch, size_t width, size_t height) {
+    const size_t n = width * height;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / width, c = i - r * width;
+        p[r * pitch + c] = 0;
+    }
+}
 static int g_memset_kernel = -1;
 static bool memset_by_kernel() {
     if (g_memset_kernel < 0) {
@@ -1772,11 +1780,13 @@ int fill_zero(void* p, size_t bytes, hipStream_t st) {
 int fill_zero2d(void* p, size_t pitch, size_t width, size_t height, hipStream_t st) {
     if (width == 0 || height == 0) return TTMI_OK;
     TTMI_REQUIRE(p, "fill_zero2d: null pointer");
-    if (memset_by_kernel() && pitch % 2 == 0 && width % 2 == 0 && (reinterpret_cast<uintptr_t>(p) & 1) == 0) {
-        const size_t n = (width / 2) * height;
+    if (memset_by_kernel()) {                        // never a runtime memset NODE unless TTMI_MEMSET_KERNEL=0 asks for it (unordered under graph replay)
+        const bool even = pitch % 2 == 0 && width % 2 == 0 && (reinterpret_cast<uintptr_t>(p) & 1) == 0;
+        const size_t n = (even ? width / 2 : width) * height;
         size_t nb = (n + 255) / 256;
         if (nb > 8192) nb = 8192;
-        hipLaunchKernelGGL(zero2d_kernel, dim3((unsigned)nb), dim3(256), 0, st, static_cast<unsigned short*>(p), pitch / 2, width / 2, height);
+        if (even) hipLaunchKernelGGL(zero2d_kernel, dim3((unsigned)nb), dim3(256), 0, st, static_cast<unsigned short*>(p), pitch / 2, width / 2, height);
+        else hipLaunchKernelGGL(zero2d_bytes_kernel, dim3((unsigned)nb), dim3(256), 0, st, static_cast<unsigned char*>(p), pitch, width, height);
         TTMI_LAUNCH_CHECK("zero2d_kernel");
         return TTMI_OK;
     }

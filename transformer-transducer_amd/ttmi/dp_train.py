@@ -62,8 +62,9 @@ class DataParallelOptimizer:
 
 def wrap_for_data_parallel(model, optimizer, bucket_mb=32):
     """-> (DataParallelOptimizer, GradSync) for a model whose parameters `optimizer` (tt.optim.Optimizer) has already re-pointed at its
-    flat buffers; rank 0's parameters are broadcast and the replicas compared"""
-    sync = GradSync(optimizer.flat, bucket_mb=bucket_mb, auto_finish=True)
+    flat buffers; the caller broadcasts rank 0's parameters and optimiser state (`sync.broadcast_parameters(src=0, optimizer=optimizer)`), which also
+    compares the replicas"""
+    sync = GradSync(optimizer.flat, bucket_mb=bucket_mb, auto_finish=True, broadcast=False)     # main() broadcasts once, with the optimiser state
     return DataParallelOptimizer(optimizer, sync), sync
 
 
@@ -112,13 +113,14 @@ def main(argv=None):
         visualizer = SummaryWriter(exp_name)
     index2word, word2index = generate_dictionary(config.data.vocab)
 
-    def loader(kind, shuffle):
+    def loader(kind, shuffle, shard):
         ds = AudioDataset(config.data, kind, word2index)
-        sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=shuffle) if world > 1 else None
+        sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=shuffle) if shard and world > 1 else None
         return torch.utils.data.DataLoader(ds, batch_size=config.data.batch_size, shuffle=shuffle and sampler is None, sampler=sampler,
                                            num_workers=12), sampler
-    training_data, train_sampler = loader('train', config.data.shuffle)
-    validate_data, _ = loader('dev', False) if rank == 0 else (None, None)
+    training_data, train_sampler = loader('train', config.data.shuffle, shard=True)
+    # the dev set is scored by rank 0 ALONE and WHOLE (train.py:180-184 walks the full set): no sampler, or the logged CER would cover 1 / world of it
+    validate_data, _ = loader('dev', False, shard=False) if rank == 0 else (None, None)
 
     torch.manual_seed(config.training.seed)                 # the same initial weights everywhere (and rank 0's are broadcast below)
     torch.cuda.manual_seed(config.training.seed)

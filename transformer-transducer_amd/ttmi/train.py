@@ -185,6 +185,7 @@ class GradSync:
         if optimizer is not None:
             for buf in optimizer.state:
                 dist.broadcast(buf, src, group=self.group)
+            optimizer.dropped_steps()           # the source rank's step count is the DEVICE's (a dropped step consumes none): refresh the host mirror first
             meta = torch.tensor([optimizer.lr, float(optimizer.steps_taken), float(optimizer.global_step), float(optimizer.current_epoch)],
                                 dtype=torch.float64, device=self.flat.flat.device)
             dist.broadcast(meta, src, group=self.group)
@@ -199,9 +200,16 @@ class GradSync:
     def replica_checksum(self):
         """order-independent-free 64-bit checksum of the parameters' BIT PATTERNS (two weighted integer sums): equal on every rank iff
         the replicas agree (up to a 2^-64-class collision); a float sum would hide sign / NaN differences"""
-        bits = self.flat.flat.view(torch.int32).to(torch.int64)
-        idx = torch.arange(1, bits.numel() + 1, device=bits.device, dtype=torch.int64)
-        return torch.stack([bits.sum(), (bits * (idx % 65521 + 1)).sum()])
+        bits32 = self.flat.flat.view(torch.int32)
+        s0 = torch.zeros((), dtype=torch.int64, device=bits32.device)
+        s1 = torch.zeros((), dtype=torch.int64, device=bits32.device)
+        chunk = 1 << 22                     # 4 M elements at a time: three 32 MB temporaries instead of three of the buffer's size (1.2 GB at C2, 2 GB at C4)
+        for off in range(0, bits32.numel(), chunk):
+            b = bits32[off:off + chunk].to(torch.int64)
+            w = torch.arange(off + 1, off + 1 + b.numel(), device=b.device, dtype=torch.int64) % 65521 + 1
+            s0 += b.sum()
+            s1 += (b * w).sum()
+        return torch.stack([s0, s1])
 
     def check_replicas(self):
         """raises on EVERY rank when the ranks' parameters differ (call it any time between steps, e.g. once per epoch)"""
@@ -297,7 +305,7 @@ class FusedOptimizer:
         # A step captured into a HIP graph (GraphedStep) would otherwise replay the values of the moment of capture - decay_lr() silently
         # ignored, Adam's bias correction frozen.  `lr` and `steps_taken` are host mirrors; assigning to them writes the device copy.
         # hyper[2] counts the steps the device DROPPED (non-finite gradient norm): those consume no step count (`dropped_steps()`).
-        self.hyper = torch.zeros(4, dtype=torch.float32, device=flat.flat.device)
+        self.hyper = torch.zeros(3, dtype=torch.float32, device=flat.flat.device)      # {lr, steps taken, steps dropped}: include/ttmi.h, csrc/optim.hip
         self.lr = lr
         self.global_step = 1                # tt/optim.py:8
         self.current_epoch = 0
