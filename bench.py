@@ -109,7 +109,10 @@ def rank_seed(rank):
 def dp_options(world):
     """what a data-parallel run switches on: the first audio layer keeps its own weight-gradient launches (its gradients are the last of
     the step - nothing is left to overlap a grouped launch's late all-reduce with), and backward leaves 32 CUs to RCCL's kernels"""
-    return {"immediate_first_layer": world > 1, "reserve_cus": 32 if world > 1 else 0}
+    # TTMI_BENCH_RESERVE_CUS: the reservation, settable without a rebuild (round 6: the first 8-GPU run can sweep it together with NCCL_MAX_NCHANNELS; on ONE GPU
+    # it prices the reservation itself - profiles/r06_reserve_cus_single_gpu.txt).  The channel count follows it unless NCCL_MAX_NCHANNELS is set.
+    env = os.environ.get("TTMI_BENCH_RESERVE_CUS")
+    return {"immediate_first_layer": world > 1, "reserve_cus": max(0, int(env)) if env not in (None, "") else (32 if world > 1 else 0)}
 
 
 def fence(world, cuda=True):
@@ -244,6 +247,59 @@ def _blas_threads():
         return os.cpu_count()
 
 
+def loss_error_trajectory(dev, inputs, targets, ilen, tlen, states=(0, 2, 5, 8, 10), seed=1):
+    """the timed bf16 mode's LOSS (train.py:53's batch mean) against TTMI_PRECISION=fp32 on the same weights ALONG a training trajectory: a fresh C2 model,
+    this file's own SGD loop, eval-mode losses of the whole batch at the states after `states` steps (the first ten steps are where the error peaks:
+    profiles/r06_loss_error_batch_mean.log, tools/debug/loss_error_batch_mean.py) -> worst |relative error| of the batch mean and of a single utterance"""
+    from tt.model import Transducer
+    from ttmi.train import FlatModel, FusedOptimizer, GradSync
+    keep = os.environ.get("TTMI_PRECISION")
+    os.environ["TTMI_PRECISION"] = "bf16"
+    torch.manual_seed(seed)
+    model = Transducer(c2_config()).to(dev).train()
+    flat = FlatModel(model)
+    flat.enable_grouped_wgrads()
+    flat.enable_shadows()
+    sync = GradSync(flat)
+    opt = FusedOptimizer(flat, kind="sgd", lr=0.00025, momentum=0.9, max_grad_norm=200.0)
+    rows, done = [], 0
+
+    def costs(mode):
+        os.environ["TTMI_PRECISION"] = mode
+        try:
+            with torch.no_grad():
+                c = model.loss(inputs, ilen, targets, tlen, reduction="none", exp_domain=(mode == "bf16"), check_lengths=False).double()
+            torch.cuda.synchronize()
+        finally:
+            os.environ["TTMI_PRECISION"] = "bf16"
+        return c
+
+    try:
+        for s in states:
+            while done < s:
+                flat.zero_grad()
+                sync.start_step()
+                model.loss(inputs, ilen, targets, tlen, exp_domain=True).backward()
+                sync.finish()
+                opt.step()
+                done += 1
+            model.eval()
+            ref, got = costs("fp32"), costs("bf16")
+            model.train()
+            rows.append((s, float(ref.mean()), float((got.mean() - ref.mean()) / ref.mean()), float(((got - ref).abs() / ref).max())))
+    finally:
+        if keep is None:
+            os.environ.pop("TTMI_PRECISION", None)
+        else:
+            os.environ["TTMI_PRECISION"] = keep
+    del model, flat, sync, opt
+    torch.cuda.empty_cache()
+    return {"states": [r[0] for r in rows], "loss_fp32": [round(r[1], 2) for r in rows], "batch_mean_rel": [float("%.3e" % r[2]) for r in rows],
+            "batch_mean_worst": float("%.3e" % max(abs(r[2]) for r in rows)), "worst_utterance": float("%.3e" % max(r[3] for r in rows)), "utterances": int(inputs.shape[0]),
+            "note": "timed form (bf16 encoders, exp-domain joint + loss) against TTMI_PRECISION=fp32 on the same weights, eval mode, along %d SGD steps of a fresh model; "
+                    "north_star's 1e-4 holds in this mode from about step 12 on and in TTMI_PRECISION=bf16x3 / fp32 at every state" % max(states)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -283,6 +339,7 @@ def main():
     ap.add_argument("--emit-rate", type=float, default=0.1, help="decode mode: fraction of frames that emit a symbol (blank bias is set for it)")
     ap.add_argument("--n1-value", type=float, default=float(os.environ.get("TTMI_BENCH_N1_VALUE", 0) or 0),
                     help="utt/s of the N = 1 run of the same workload: the line then carries dp_efficiency = value / (N x n1-value)")
+    ap.add_argument("--no-trajectory", action="store_true", help="skip loss_rel_err_trajectory (a fresh model, ten SGD steps, five fp32-mode evaluations: ~4 s)")
     ap.add_argument("--no-sync-form", action="store_true", help="skip the secondary timing of train.py's loop body with its host synchronisations "
                                                                 "(fresh .int() length tensors, float(loss) every step: train.py:53,60)")
     args = ap.parse_args()
@@ -312,7 +369,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # the collective's workgroups run beside backward on the CUs the encoder-sized persistent GEMMs leave free (ops.reserve_cus(32) below):
         # keep RCCL's channel count within that reservation unless the caller chose otherwise
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(max(1, dp_options(world)["reserve_cus"] or 32)))
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -623,7 +680,8 @@ def main():
                                     "BASELINE configs[3]: joint_streaming.yaml 18/2 layers V=6485 (85.6M params), %s mask"
                                     % args.workload.split("-")[1]) +
                                    ", T=%d U=%d, batch %d/GPU, dropout 0.1, SGD momentum + clip 200" % (T, U, B),
-                       "global_batch": world * B, "parallelism": "dp%d" % world},
+                       "global_batch": world * B, "parallelism": "dp%d" % world,
+                       "reserve_cus_in_backward": reserve},
             # host side of a step.  host_issue: wall time to issue ONE step (Python + ctypes + HIP runtime, forward thread and autograd's
             # backward thread) on a drained device - the host's own cost; well below ms_per_step = the step is GPU-bound.  Inside the timed
             # region the issue loop runs ahead until the HIP queue is full and then spins in the launch calls: host_enqueue (wall) and
@@ -741,6 +799,12 @@ def main():
             if batch_rel is not None:
                 out["loss_rel_err_batch_vs_fp32_mode"] = {"batch_mean": float("%.3e" % batch_rel), "worst_utterance": float("%.3e" % utt_rel), "utterances": B,
                                                           "note": "the timed form's loss of the whole batch against TTMI_PRECISION=fp32 on the same weights and inputs (eval mode)"}
+            if batch_rel is not None and not args.no_trajectory:
+                try:
+                    out["loss_rel_err_trajectory"] = loss_error_trajectory(dev, inputs, targets, ilen, tlen)
+                    out["loss_rel_err_trajectory_worst"] = out["loss_rel_err_trajectory"]["batch_mean_worst"]
+                except Exception as exc:        # a secondary measurement never takes the line down
+                    out["loss_rel_err_trajectory"] = {"error": repr(exc)[:300]}
             if fused_path:
                 out["loss_rel_err_vs_oracle_timed_form"] = float("%.3e" % (np.abs(costs_form.float().cpu().numpy() - oracle_costs).max() / np.abs(oracle_costs).max()))
         print(json.dumps(out), flush=True)

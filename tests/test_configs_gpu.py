@@ -349,8 +349,9 @@ def test_c2_bf16_loss_error_bound_along_a_training_trajectory(monkeypatch):
     so the same few hundredths of a nat are a several times larger RELATIVE error.  Measured over the rounds' builds (tools/debug/
     bf16_loss_error.py, profiles/r0*_bf16_loss_error*.log): 2e-6 ... 1.9e-4 per utterance, of which the encoders' bf16 operands alone
     (oracle joint + lattice on the GPU's encoder states) carry 1e-6 ... 1.9e-4 - systematic weight rounding that does not average out over
-    an alignment's ~550 emissions.  What is asserted is the bound that HOLDS in this mode: 3e-4 per utterance at every state; `north_star`'s
-    1e-4 is met by TTMI_PRECISION=fp32 (test_c2_full_model_fp32_end_to_end: <= 1e-6) and, in this mode, only at some states."""
+    an alignment's ~550 emissions.  What is asserted is the bound that HOLDS in this mode: 3e-4 per utterance AND on the batch mean (round 6) at every state,
+    1e-4 on the batch mean at the last one; `north_star`'s 1e-4 is met by TTMI_PRECISION=fp32 / bf16x3 (test_c2_full_model_fp32_end_to_end: <= 1e-6 / 1.3e-7)
+    at every state and, in this mode, from about step 12 of this trajectory on."""
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -397,8 +398,16 @@ def test_c2_bf16_loss_error_bound_along_a_training_trajectory(monkeypatch):
             assert int(stt.flag) == 0
             z, _ = O.joint_fwd(enc_s.double().cpu().numpy(), dec_s.double().cpu().numpy(), sd64)
         c_enc = rnnt_loss_c(z.astype(np.float32), y.cpu().numpy(), il.cpu().numpy(), tl.cpu().numpy(), want_grad=False)[1].astype(np.float64)
+        # round 6: the quantity BASELINE names is the LOSS of the batch (train.py:53's mean over B = 32), here against TTMI_PRECISION=fp32 on the same weights (the mode
+        # test_c2_full_model_fp32_end_to_end holds within 1e-6 of the oracle)
+        with torch.no_grad():
+            c16 = model.loss(inputs, ilen, targets, tlen, reduction="none", exp_domain=True, check_lengths=False).double()
+            monkeypatch.setenv("TTMI_PRECISION", "fp32")
+            c32 = model.loss(inputs, ilen, targets, tlen, reduction="none", check_lengths=False).double()
+            monkeypatch.setenv("TTMI_PRECISION", "bf16")
+        batch = float((c16.mean() - c32.mean()) / c32.mean())
         model.train()
-        return (float(np.max(np.abs(costs.double().cpu().numpy() - want) / want)), float(np.max(np.abs(c_enc - want) / want)), float(want.mean()))
+        return (float(np.max(np.abs(costs.double().cpu().numpy() - want) / want)), float(np.max(np.abs(c_enc - want) / want)), float(want.mean()), batch)
 
     done, seen = 0, []
     for stop in (0, 10, 25):
@@ -412,8 +421,108 @@ def test_c2_bf16_loss_error_bound_along_a_training_trajectory(monkeypatch):
             done += 1
         torch.cuda.synchronize()
         seen.append((stop,) + errors())
-    print("bf16 loss error along the trajectory (worst of 2 utterances; timed form / encoder states only / oracle cost): "
-          + "; ".join("step %d: %.2e / %.2e / %.0f" % s for s in seen))
-    for stop, e_timed, e_enc, cost in seen:
+    print("bf16 loss error along the trajectory (worst of 2 utterances; timed form / encoder states only / oracle cost / batch mean of 32 vs fp32 mode): "
+          + "; ".join("step %d: %.2e / %.2e / %.0f / %+.2e" % s for s in seen))
+    for stop, e_timed, e_enc, cost, batch in seen:
         assert e_timed < 3e-4 and e_enc < 3e-4, (stop, e_timed, e_enc)
+        # the batch mean is NOT a tighter quantity than the worst utterance while the model is in its first descent: the rounding of the SHARED weights moves every
+        # utterance's cost the same way (profiles/r06_loss_error_batch_mean.log: 32 of 32 utterances on one side at steps 2 - 10, batch mean up to 2.1e-4 over two seeds);
+        # from about step 12 on the signs mix and the mean is 1e-5 class
+        assert abs(batch) < 3e-4, (stop, batch)
+    assert abs(seen[-1][4]) < 1e-4, seen[-1]            # (measured -1.3e-6 / -3.2e-7 at step 25)
     assert seen[-1][3] < 0.25 * seen[0][3]              # the loop did train (4450 -> ~430)
+
+
+# ----------------------------------------------------------------------------------------------- C5: the TIMED form against the oracle
+def _oracle_joint_loss_chunked(enc, dec, sd, labels, B_total, frames=64):
+    """oracle.joint_fwd (float64) + the C lattice + oracle.joint_bwd for ONE utterance trimmed to its own lattice, evaluated in chunks of `frames`
+    frames so that no [T, U+1, V] float64 array exists (7 GB in f32 at T=2000, U=200 is what the C lattice needs).
+    -> cost, d enc [T, d], d dec [U+1, d], parameter gradients (of cost / B_total)"""
+    T, U1 = enc.shape[0], dec.shape[0]
+    V = sd["joint.project_layer.weight"].shape[0]
+    z32 = np.empty((1, T, U1, V), dtype=np.float32)
+    hs = []
+    for t0 in range(0, T, frames):
+        z, cache = O.joint_fwd(enc[None, t0:t0 + frames], dec[None], sd)
+        z32[0, t0:t0 + frames] = z[0]
+        hs.append(cache["h"])
+        del z
+    _, costs, dz = rnnt_loss_c(z32, labels[None], np.array([T], np.int32), np.array([U1 - 1], np.int32), reduction="sum")
+    del z32
+    grads, denc, ddec = {}, np.zeros_like(enc), np.zeros_like(dec)
+    for i, t0 in enumerate(range(0, T, frames)):
+        g = {}
+        de, dd = O.joint_bwd(dz[:, t0:t0 + frames].astype(np.float64) / B_total, dict(enc=enc[None, t0:t0 + frames], dec=dec[None], h=hs[i]), sd, g)
+        denc[t0:t0 + frames] = de[0]
+        ddec += dd[0]
+        for k, v in g.items():
+            grads[k] = grads.get(k, 0) + v
+        hs[i] = None
+    return float(costs[0]), denc, ddec, grads
+
+
+def test_c5_timed_form_vs_oracle(monkeypatch):
+    """BASELINE configs[4] in the form bench.py TIMES (VERDICT r5 missing item 3; so far held to the repo's own fp32 pipeline only): exp-domain joint + loss at
+    T = 2000, U = 200 - U + 1 = 201 labels: the multi-wave alpha / beta kernel with its LDS hand-off ring; both encoders on the L > K branch of
+    tt/transformer.py:128-132 (tables of 410 / 64 rows) - B = 2 with a ragged second utterance, on the GPU's own bf16 encoder states.  Each utterance is
+    held to the oracle on its OWN trimmed lattice (what train.py:32-35's trimming means for a batch): oracle.joint_fwd in float64 + the C lattice +
+    oracle.joint_bwd.  Bounds: those of test_exp_domain_vs_oracle (costs 8e-5, loss 5e-5, gradients bf16 class)."""
+    from tt.model import Transducer, _JointLossFn
+    from tt.utils import AttrDict
+    import ttmi.ops as ops
+    monkeypatch.setenv("TTMI_PRECISION", "bf16")
+    side = dict(n_layer=1, d_model=512, n_head=8, d_head=64, d_inner=256)
+    cfg = AttrDict(dict(enc=dict(side, max_input_length=410), dec=dict(side, max_target_length=64),
+                        joint=dict(input_size=1024, inner_size=1024), vocab_size=4334, dropout=0.0))
+    torch.manual_seed(6)
+    model = Transducer(cfg).cuda().train()
+    B, T, U, V = 2, 2000, 200, 4334
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn(B, T, 512, device="cuda", generator=g)
+    y = torch.randint(1, V, (B, U), device="cuda", generator=g)
+    al = torch.tensor([T, 1111], dtype=torch.int32, device="cuda")
+    ll = torch.tensor([U, 77], dtype=torch.int32, device="cuda")
+    y[0, 9] = 0                                              # a label equal to the blank
+    with torch.no_grad():
+        enc_s, dec_s = model._encode(x, y)
+    j = model.joint
+    st = j.exp_shift_state(x.device)
+    st.set(0.0)
+    calls = []
+    orig = ops.joint_bwd_exp
+    monkeypatch.setattr(ops, "joint_bwd_exp", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    enc_l, dec_l = enc_s.clone().requires_grad_(True), dec_s.clone().requires_grad_(True)
+    model.zero_grad()
+    chunk = j.default_loss_chunk(B, T, U + 1, True, 1)
+    costs = _JointLossFn.apply(enc_l, dec_l, j.forward_layer.weight, j.forward_layer.bias, j.project_layer.weight, j.project_layer.bias,
+                               y.int().contiguous(), al, ll, 1, chunk, "none", st, True).detach().cpu().numpy()
+    loss = _JointLossFn.apply(enc_l, dec_l, j.forward_layer.weight, j.forward_layer.bias, j.project_layer.weight, j.project_layer.bias,
+                              y.int().contiguous(), al, ll, 1, chunk, "mean", st, True)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert calls and int(st.flag) == 0                       # the exp-domain kernels ran, no range flag
+    sd = {"joint." + k: v.detach().double().cpu().numpy() for k, v in j.state_dict().items()}
+    enc_h, dec_h = enc_s.double().cpu().numpy(), dec_s.double().cpu().numpy()
+    want_costs, denc, ddec, grads = [], np.zeros_like(enc_h), np.zeros_like(dec_h), {}
+    for b in range(B):
+        Tb, Ub = int(al[b]), int(ll[b])
+        c, de, dd, gb = _oracle_joint_loss_chunked(enc_h[b, :Tb], dec_h[b, :Ub + 1], sd, y[b, :Ub].int().cpu().numpy(), B)
+        want_costs.append(c)
+        denc[b, :Tb], ddec[b, :Ub + 1] = de, dd
+        for k, v in gb.items():
+            grads[k] = grads.get(k, 0) + v
+    want_costs = np.array(want_costs)
+    ec = np.abs(costs - want_costs) / want_costs
+    el = abs(float(loss.detach()) - want_costs.mean()) / want_costs.mean()
+    errs = {"denc": rel_err(enc_l.grad.cpu().numpy(), denc), "ddec": rel_err(dec_l.grad.cpu().numpy(), ddec)}
+    for k, p in j.named_parameters():
+        errs["g_" + k] = rel_err(p.grad.cpu().numpy(), grads["joint." + k])
+    print("C5 timed form vs oracle (T=%d U=%d, ragged %d / %d): costs rel %s, loss rel %.2e, %s"
+          % (T, U, int(al[1]), int(ll[1]), ["%.2e" % e for e in ec], el, ", ".join("%s %.2e" % kv for kv in errs.items())))
+    assert float(enc_l.grad[1, int(al[1]):].abs().max()) == 0 and float(dec_l.grad[1, int(ll[1]) + 1:].abs().max()) == 0       # nothing outside the ragged lattice
+    # measured (profiles/r06_c5_timed_form_oracle_test.log): costs 1.0e-5 / 2.6e-5, loss 2.5e-6, d enc 5.3e-3, d dec 2.1e-2, joint weights 1.8e-2 - 1.9e-2, projection bias
+    # 2.7e-5: the sums over 2000 frames of bf16-rounded dH rows are what T = 200 (1.5e-2 in test_exp_domain_vs_oracle) has ten times fewer of
+    assert ec.max() < 8e-5 and el < 5e-5
+    for k, e in errs.items():
+        assert e < 3e-2, (k, e)
+    assert errs["g_project_layer.bias"] < 5e-3
