@@ -200,6 +200,24 @@ def test_c2_full_model_fp32_end_to_end(monkeypatch, mode):
     _end_to_end_vs_oracle(monkeypatch, model, mode, 2, 500, 50, 4334, [500, 431], [50, 37], 12, 6, None)
 
 
+def test_c2_model_long_utterance_bf16x3_end_to_end(monkeypatch):
+    """the same 12 / 6 model at T = 1000, U = 100 (half of C5's lengths, the size the float64 oracle still finishes in a minute) in the quick
+    parity mode: both encoders on the L > K branch of tt/transformer.py:128-132 (tables of 410 / 42 rows against 1000 frames / 101 labels: relative positions
+    beyond the table clamp onto row 0 and their gradients fold back onto it), the lattice on the multi-wave alpha / beta kernel (U + 1 = 101 > 64).
+    Logits, loss, input gradient and every parameter gradient within 1e-4 of the float64 oracle."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from tt.model import Transducer
+    monkeypatch.setenv("TTMI_PRECISION", "bf16x3")
+    cfg = bench.c2_config()
+    cfg["dropout"] = 0.0
+    torch.manual_seed(3)
+    model = Transducer(cfg).cuda().eval()
+    _end_to_end_vs_oracle(monkeypatch, model, "bf16x3", 1, 1000, 100, 4334, [1000], [100], 12, 6, None)
+
+
 def _end_to_end_vs_oracle(monkeypatch, model, mode, B, T, U, V, tl, ul, n_enc, n_dec, audio_mask):
     """logits, loss, input gradient and every parameter gradient of `model` (already in the wanted TTMI_PRECISION) against the float64 oracle,
     the oracle fed the ReLU decisions the HIP path took (see test_c2_full_model_fp32_end_to_end)"""
