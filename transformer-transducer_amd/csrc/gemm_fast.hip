@@ -1202,6 +1202,40 @@ __device__ __forceinline__ void gemm_nt_v9_body(const FP& p_) {
             }
             const int lm0 = cbm + wr * 64 + (sizeof(TC) == 2 ? (lane >> 3) : (lane >> 4));
             TC* lrow0 = C + (long)lm0 * p.ldc + ln0;
+            if constexpr (LEAN == 3 && sizeof(TC) == 4) {
+                // residual epilogue (round 6): ALL 16 addend vectors of the lane are requested before the first slab goes through LDS - their latency is paid once, together with
+                // the wait for the next tile's prefetch, instead of once per slab inside the rolled loop (these are one-round launches: FFN2 forward 16000 x 512 x 1024 took
+                // 50 - 54 us against 21 - 29 us for the same shape without the addend).  The slab loop is unrolled here so that the 64 registers are indexed statically.
+                f32x4 ad[4][4];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        ad[mi][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (lfull && lm0 + mi * 16 + q * 4 < p.M)
+                            ad[mi][q] = *reinterpret_cast<const f32x4*>(p.addend + (long)(lm0 + mi * 16 + q * 4) * p.ldc + ln0);
+                    }
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<f32x4*>(img + wrow * 256 + (((ni * 4 + wq) ^ wrow) << 4)) = acc[mi][ni];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = q * 4 + (lane >> 4);
+                        const f32x4 x = *reinterpret_cast<const f32x4*>(img + r * 256 + (((lane & 15) ^ r) << 4));
+                        const int m = lm0 + mi * 16 + q * 4;
+                        if (lfull) {
+                            if (m < p.M) {
+                                f32x4 o = {x[0] + lb[0], x[1] + lb[1], x[2] + lb[2], x[3] + lb[3]};
+                                o += ad[mi][q];
+                                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(lrow0) + (long)(mi * 16 + q * 4) * p.ldc) = o;
+                            }
+                        } else {
+                            epi_store4<TC>(p, C, m, ln0, x, vec);
+                        }
+                    }
+                }
+            } else {
 #pragma unroll 1
             for (int mi = 0; mi < 4; ++mi) {
                 switch (mi) { V9_SLAB(0) V9_SLAB(1) V9_SLAB(2) V9_SLAB(3) }
@@ -1254,6 +1288,7 @@ __device__ __forceinline__ void gemm_nt_v9_body(const FP& p_) {
                         }
                     }
                 }
+            }
             }
         } else {
 #pragma unroll 1
