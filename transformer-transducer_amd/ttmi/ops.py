@@ -408,6 +408,10 @@ def layer_bwd(dz, x, x16, y, pa, pf, ctx_a, ctx_f, prec, grads, mask=None, p_att
         keep_a = torch.empty(L_.ttmi_attn_bwd_keep_bytes(c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh)), dtype=torch.uint8, device=x.device)
         keep_f = torch.empty(L_.ttmi_ffn_bwd_keep_bytes(c_long(B * L), c_int(d), c_int(Di)), dtype=torch.uint8, device=x.device)
         out = (WgradDesc * 4)()
+    for nm, t in (("dz", dz), ("x", x), ("y", y), ("ctx_attn", ctx_a), ("ctx_ffn", ctx_f), ("ws", ws), ("dx", dx)):
+        if t is None or t.data_ptr() == 0:      # (round 6: one bench run in ~40 died here with the library's anonymous "null pointer"; name the tensor next time)
+            raise ValueError("layer_bwd: %s is %s (x %s, prec %d, stream %#x)" % (nm, "None" if t is None else "an empty tensor of shape %s" % (tuple(t.shape),),
+                                                                                 tuple(x.shape), prec, torch.cuda.current_stream(x.device).cuda_stream))
     check(L_.ttmi_layer_bwd(_p(dz), _p(x), _p(x16), _p(y), _p(pa["qkv_w"]), _p(pa["o_w"]), _p(pa["ln_g"]), _p(pa["r_emb"]), _p(pa["r_w_bias"]),
                             _p(pa["r_bias"]), _p(pf["ff_w1"]), _p(pf["ff_w2"]), _p(pf["ff_ln_g"]), c_int(B), c_int(L), c_int(d), c_int(H), c_int(Dh),
                             c_int(K), c_int(Di), *(mask or MaskSpec()).args(), c_int(prec), c_float(p_attn), ctypes.c_uint(seed_attn),
