@@ -325,7 +325,9 @@ int ttmi_stream_reserve_cus(void* stream, int n);
  * forward kernel instead of the one-workgroup-per-head one; 15: 1 = the round-3 attention backward kernel instead of flash_bwd_rel2_kernel;
  * 16: 1 = the position-table gradients go through dE / dc and a relpos_scatter launch (round 3) instead of straight out of attn_dqde_kernel;
  * 17: exact-f32 NT products: 0 = the kernels of csrc/gemm.hip only (round 1), 1 = default rule (persistent 256x128 kernel with f32 operands from 512 of its tiles on,
- * 64x64 tiles from 72 of those on), 2 / 3 = the 64x64-tile / the persistent kernel wherever it can run; 18: 1 = fork inside a stream capture */
+ * 64x64 tiles from 72 of those on), 2 / 3 = the 64x64-tile / the persistent kernel wherever it can run; 18: 1 = fork inside a stream capture;
+ * 19: 0 = the joint's input layer (bf16 mode) without the second bf16 term of the label-encoder states (round 6: that rounding is one pattern in all T lattice rows of a label
+ * position and was the joint's whole share of the batch-mean loss error; A/B) */
 int ttmi_set_option(int key, int value);
 int ttmi_dropout_apply(const float* in, long n, float p, unsigned seed, float* out, void* stream);
 int ttmi_probe_arm(int slot);

@@ -240,6 +240,9 @@ def _bench_like(dev, world, rank, steps, hooks, graph=False):
                     first_replay = keep.cpu().numpy()
         else:
             one_step()
+            if step == 1:
+                torch.cuda.synchronize()
+                _bench_like.second_step_grad = keep.cpu().numpy()      # one update after the common state (see below)
     torch.cuda.synchronize()
     # graph runs report the gradient of their FIRST replay: bf16 training is chaotic from run to run (f32 atomic-order noise of 1e-7 flips
     # bf16 roundings downstream and reaches 1e-3 after two more steps, 1e-2 after three: tools/debug/eager_repeat3.py), so gradients are
@@ -265,7 +268,7 @@ def _solo_bench(port, q):
     out = _bench_like(dev, 1, 0, 3, hooks=True)
     dist.barrier()
     dist.destroy_process_group()
-    q.put(out)
+    q.put(out + (_bench_like.second_step_grad,))
 
 
 def test_single_rank_rccl_bench_step_on_one_gpu(monkeypatch):
@@ -278,13 +281,19 @@ def test_single_rank_rccl_bench_step_on_one_gpu(monkeypatch):
     q = ctx.Queue()
     p = ctx.Process(target=_solo_bench, args=(port, q))
     p.start()
-    grad, params, n_works, exp_ran, n_buckets = q.get(timeout=900)
+    grad, params, n_works, exp_ran, n_buckets, grad1 = q.get(timeout=900)
     p.join(120)
     assert p.exitcode == 0
     assert exp_ran and n_buckets >= 4 and n_works >= n_buckets - 1
     want_grad, want_params, _, _, _ = _bench_like(torch.device("cuda", 0), 1, 0, 3, hooks=False)
-    # grouped weight gradients are bit-reproducible; the joint's and the first layer's K-split sums land in f32 atomic order
-    assert rel_err(grad, want_grad) < 1e-4
+    want_grad1 = _bench_like.second_step_grad
+    # grouped weight gradients are bit-reproducible; the joint's and the first layer's K-split sums land in f32 atomic order.  The gradients are held to 1e-4 ONE update after
+    # the common state (as the graphed twin below); two updates later the outcome is bimodal in this fixed-seed test since round 6's numerics - 9e-8 ... 4e-7, or 9.0e-4 ... 9.6e-4
+    # in about half of the runs: ONE FFN unit whose pre-activation sits within the runs' 3e-8 parameter distance of zero is decided differently, and a single ReLU decision is
+    # worth 1 / sqrt(#units) = 3.5e-4 ... 1e-3 of the gradient (test_c2_full_model_fp32_end_to_end documents the same effect against the oracle)
+    print("RCCL-side step vs plain: gradients one update after the common state %.2e, two updates %.2e, parameters %.2e"
+          % (rel_err(grad1, want_grad1), rel_err(grad, want_grad), rel_err(params, want_params)))
+    assert rel_err(grad1, want_grad1) < 1e-4 and rel_err(grad, want_grad) < 5e-3
     assert rel_err(params, want_params) < 1e-6
 
 
@@ -318,7 +327,7 @@ def test_single_rank_rccl_graphed_step_on_one_gpu(monkeypatch):
     assert exp_ran and n_buckets >= 4 and n_works >= n_buckets - 1
     want_grad, want_params, _, _, _ = _graph_twin(torch.device("cuda", 0), 1, 0, 5)
     print("graphed RCCL step vs eager twin: gradients of the first replay %.2e, parameters after 5 steps %.2e" % (rel_err(grad, want_grad), rel_err(params, want_params)))
-    assert rel_err(grad, want_grad) < 1e-4             # (measured 7e-7: f32 atomic order)
+    assert rel_err(grad, want_grad) < 5e-3             # (7e-7 ... 2e-6: f32 atomic order; 3e-3 when a ReLU unit at zero is decided differently after the two eager warm-up steps, see above)
     assert rel_err(params, want_params) < 5e-6         # (two chaotic steps later: measured 3e-10 .. 6e-7, as between two eager runs)
 
 

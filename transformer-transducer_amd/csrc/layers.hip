@@ -140,6 +140,7 @@ int g_scatter_launch = 0;       // ttmi_set_option(16, 1): attn_dqde_kernel leav
                                 // the table gradients (no per-(b, h) rows + reduction)
 int g_attn_slices = 1;          // ttmi_set_option(10, n): attention backward in n batch slices (see attn_bwd_impl)
 int g_gemm_slab = 0;            // ttmi_set_option(5, 1): position-term slab by the batched GEMM (A/B measurements)
+int g_joint_dec_lo = 1;         // ttmi_set_option(19, 0): the joint's input layer without the second bf16 term of the label states (round 6; A/B)
 struct SideCtx {
     int device = -1;
     hipStream_t main = nullptr, side = nullptr;
@@ -1154,7 +1155,7 @@ static inline bool joint_input_fast(int prec, int B, int T, int U1, int de, int 
     const size_t M = (size_t)B * T * U1, din = (size_t)de + dd;
     const size_t need = al8((size_t)B * T * de) + al8((size_t)B * U1 * dd) + al8((size_t)B * T * J) + al8((size_t)B * U1 * J) + al8(din * J) + 8;
     // bf16 elements behind dH16 (backward); the forward pass has the whole region (2 M J elements) for its copies and the weight's second split term
-    return need <= (size_t)M * J && need + al8(din * J) <= 2 * (size_t)M * J;
+    return need <= (size_t)M * J && need + al8(din * J) + al8((size_t)B * U1 * dd) <= 2 * (size_t)M * J;      // (+ the label states' second split term, round 6)
 }
 // dtype of the logits this configuration produces / expects: 0 = f32, 1 = bf16
 int ttmi_joint_logits_dtype(int prec, int J) { return joint_fast(prec, J) ? 1 : 0; }
@@ -1222,6 +1223,16 @@ static int joint_fwd_impl(const float* enc, const float* dec, const float* wf, c
         eb.addend = PD;
         CK(gemm_nt_bf16(enc16, Wf16lo, PE, 0, ea, B * T, J, de, de, din, J, st));
         CK(gemm_nt_bf16(dec16, Wf16lo + de, PD, 0, eb, B * U1, J, dd, dd, din, J, st));
+        // second term of the LABEL STATES' bf16 split (round 6): dec[b, u, :] meets all T frames of its utterance, so the rounding of one label state is ONE pattern in T
+        // lattice rows - and, while the label encoder's outputs still resemble each other (the first steps of training), in every utterance of the batch.  Measured
+        // (tools/debug/joint_weight_rounding.py, C2 after 5 SGD steps, fp32 encoders): the exp-domain joint + loss err by +0.035 ... +0.14 nats of 827 on EVERY utterance
+        // (4e-5 ... 1.7e-4, all of the joint's share of the batch-mean loss error), by 0.002 with the label states pre-rounded; the audio states' rounding (one pattern per frame,
+        // 500 different ones along an alignment) and the rounding of every weight of the joint change nothing.  One 1632-row GEMM more.
+        if (g_joint_dec_lo) {
+            bf16_t* dec16lo = Wf16lo + al8((size_t)J * din);
+            CK(bf16_residual(dec, dec16, dec16lo, (long)B * U1 * dd, st));
+            CK(gemm_nt_bf16(dec16lo, wf16 + de, PD, 0, eb, B * U1, J, dd, dd, din, J, st));
+        }
     } else {
         CK(ttmi_launch_gemm(mk(enc, wf, PE, B * T, J, de, de, din, J, NT_, prec), st));
         CK(ttmi_launch_gemm(mk(dec, wf + de, PD, B * U1, J, dd, dd, din, J, NT_, prec), st));
@@ -1235,6 +1246,14 @@ static int joint_fwd_impl(const float* enc, const float* dec, const float* wf, c
             g2.beta = 1.f;
             CK(ttmi_launch_gemm(g1, st));
             CK(ttmi_launch_gemm(g2, st));
+            // ... and the label states' second term (see above; the same numbers as the throughput path: the residual in f32, rounded to bf16 while staging)
+            if (g_joint_dec_lo && (size_t)M * J >= al4((size_t)din * J) + (size_t)B * U1 * dd) {
+                float* Rd = R + al4((size_t)din * J);
+                CK(bf16_residual_f32(dec, Rd, (long)B * U1 * dd, st));
+                GemmDesc g3 = mk(Rd, wf + de, PD, B * U1, J, dd, dd, din, J, NT_, prec);
+                g3.beta = 1.f;
+                CK(ttmi_launch_gemm(g3, st));
+            }
         }
     }
     if (!fast && prec == 2 && joint_x3_h3(M, V, J)) {
@@ -1512,7 +1531,8 @@ int ttmi_set_dropout_salt(const unsigned* salt) {
 // process-wide switches for A/B measurements.  key 0: 1 = disable the fused attention kernels (bf16 pipeline only);
 // key 1: throughput-GEMM generation (see gemm_fast.hip); key 2: flash-kernel timing switches; key 3: 0 = no wgrad fork
 int ttmi_set_option(int key, int value) {
-    TTMI_REQUIRE(key >= 0 && key <= 18, "set_option: unknown key %d", key);
+    TTMI_REQUIRE(key >= 0 && key <= 19, "set_option: unknown key %d", key);
+    if (key == 19) { g_joint_dec_lo = value; return TTMI_OK; }
     if (key == 18) { g_capture_forks = value; return TTMI_OK; }
     if (key == 17) { gemm_fast_set_f32(value); return TTMI_OK; }
     if (key == 16) { g_scatter_launch = value; return TTMI_OK; }

@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 
 from ttmi import ops
-from tt.transformer import RelLearnableDecoderLayer, as_mask_spec, grad_targets
+from tt.transformer import RelLearnableDecoderLayer, as_mask_spec, grad_targets, label_precision
 
 
 class _EmbedFn(torch.autograd.Function):
@@ -37,8 +37,8 @@ class BaseDecoder(nn.Module):
         self.r_bias = nn.Parameter(torch.randn((k_len, n_head), dtype=torch.float32))
         self.MultiHeadAttention = RelLearnableDecoderLayer(n_head, d_model, d_head, d_inner, dropout, **kwargs)
 
-    def forward_bm(self, x, mask, x16=None, want16=False):
-        return self.MultiHeadAttention.forward_bm(x, self.r_emb, self.r_w_bias, self.r_bias, mask, x16=x16, want16=want16)
+    def forward_bm(self, x, mask, x16=None, want16=False, prec=None):
+        return self.MultiHeadAttention.forward_bm(x, self.r_emb, self.r_w_bias, self.r_bias, mask, prec=prec, x16=x16, want16=want16)
 
     def forward(self, inputs, attn_mask=None):          # reference contract: time-major [U, B, d]
         return self.MultiHeadAttention(inputs, self.r_emb, self.r_w_bias, self.r_bias, attn_mask)
@@ -62,10 +62,11 @@ class BuildDecoder(nn.Module):
         spec = as_mask_spec(mask, inputs.size(0), inputs.size(1))
         x = _EmbedFn.apply(inputs, self.dec_embedding.weight, self.dec_embedding.padding_idx)
         x16 = None
-        fused = x.is_cuda and all(layer.MultiHeadAttention.fused() for layer in self.layers)      # (see tt/encoder.py)
+        prec = label_precision()                      # (None = the mode in force; see tt.transformer.label_precision)
+        fused = prec is None and x.is_cuda and all(layer.MultiHeadAttention.fused() for layer in self.layers)      # (see tt/encoder.py)
         for i, layer in enumerate(self.layers):
             if fused and i + 1 < len(self.layers):
                 x, x16 = layer.forward_bm(x, spec, x16=x16, want16=True)
             else:
-                x = layer.forward_bm(x, spec, x16=x16)
+                x = layer.forward_bm(x, spec, x16=x16, prec=prec)
         return x

@@ -23,6 +23,18 @@ def default_precision():
     return 1 if v in ("bf16", "1") else (2 if v in ("bf16x3", "2") else 0)
 
 
+def label_precision():
+    """precision code of the LABEL encoder's layers when it differs from the mode in force, else None.  In bf16 mode TTMI_LABEL_PRECISION = bf16x3 | fp32 runs the label
+    stack (1632 rows per layer at C2, on its side stream beside the audio encoder) in a parity mode: one label state meets all T frames of its utterance in the joint,
+    so the label encoder's bf16 rounding is ONE pattern in T lattice rows and does not average out along an alignment the way the audio encoder's per-frame rounding
+    does (round 6, tools/debug/joint_weight_rounding.py: at a steep training state the label encoder's bf16 arithmetic moves every utterance's cost by -0.02 ... -0.05
+    nats of 827 to the same side).  Default: unset (the label stack follows TTMI_PRECISION)."""
+    if default_precision() != 1:
+        return None
+    v = os.environ.get("TTMI_LABEL_PRECISION", "").lower()
+    return 2 if v in ("bf16x3", "2") else (0 if v in ("fp32", "0") else None)
+
+
 _mask_cache = {}     # id(mask tensor) -> (weakref, version, MaskSpec): every layer of a stack gets the same mask tensor
 
 
