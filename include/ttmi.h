@@ -319,9 +319,10 @@ int ttmi_stream_reserve_cus(void* stream, int n);
  * 7: exact-f32 products with at most n rows use the skinny 32x32 split-reduction kernel (default 128, 0 = never: greedy decode A/B);
  * 8: 0 = the fused attention kernels read the position term from a [B,H,L,L+1] bf16 slab (round-1 design) instead of forming it themselves;
  * 9: 1 = one-wave lattice kernel (round 2) instead of the workgroup-per-utterance one; 10: batch slices of the attention backward; 11: 1 = dq / dE /
- * dc by the round-2 GEMM launches instead of attn_dqde_kernel; 12: workgroups of the grid-stride LayerNorm backward kernels; 13: 1 = the four
+ * dc by the round-2 GEMM launches instead of attn_dqde_kernel; 12: workgroups of the grid-stride LayerNorm backward kernels; 13 (default 2 since round 6): 1 = the four
  * forward GEMMs of an encoder layer (qkv_net, o_net, CoreNet.0, CoreNet.3) take the second term of their weight's bf16 split as a second K range, one launch each; 2 = o_net and
- * CoreNet.3 only (needs weight shadows; +2 % step time, no consistent change of the bf16 loss error: profiles/r04_two_term_weights.md); 14: 0 = the tiled attention
+ * CoreNet.3 only; + 4 = all four in stacks of fewer than 4096 rows (the label encoder); 0 = off (2: +0.4 ms per C2 step - with the label encoder's value pass
+ * of tt.model the timed mode's batch-mean loss stays within 8.1e-5 of the fp32 mode over 56 training states, profiles/r06_loss_error_batch_mean_fixed.log); 14: 0 = the tiled attention
  * forward kernel instead of the one-workgroup-per-head one; 15: 1 = the round-3 attention backward kernel instead of flash_bwd_rel2_kernel;
  * 16: 1 = the position-table gradients go through dE / dc and a relpos_scatter launch (round 3) instead of straight out of attn_dqde_kernel;
  * 17: exact-f32 NT products: 0 = the kernels of csrc/gemm.hip only (round 1), 1 = default rule (persistent 256x128 kernel with f32 operands from 512 of its tiles on,

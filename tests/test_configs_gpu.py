@@ -367,9 +367,9 @@ def test_c2_bf16_loss_error_bound_along_a_training_trajectory(monkeypatch):
     so the same few hundredths of a nat are a several times larger RELATIVE error.  Measured over the rounds' builds (tools/debug/
     bf16_loss_error.py, profiles/r0*_bf16_loss_error*.log): 2e-6 ... 1.9e-4 per utterance, of which the encoders' bf16 operands alone
     (oracle joint + lattice on the GPU's encoder states) carry 1e-6 ... 1.9e-4 - systematic weight rounding that does not average out over
-    an alignment's ~550 emissions.  What is asserted is the bound that HOLDS in this mode: 3e-4 per utterance AND on the batch mean (round 6) at every state,
-    1e-4 on the batch mean at the last one; `north_star`'s 1e-4 is met by TTMI_PRECISION=fp32 / bf16x3 (test_c2_full_model_fp32_end_to_end: <= 1e-6 / 1.3e-7)
-    at every state and, in this mode, from about step 12 of this trajectory on."""
+    an alignment's ~550 emissions.  What is asserted: 3e-4 per utterance of the B = 2 oracle sample and - since round 6 - `north_star`'s 1e-4 on the BATCH MEAN of 32 against
+    the fp32 mode at every state visited (0 / 2 / 5 / 10 / 25); per utterance 1e-4 is met by TTMI_PRECISION=fp32 / bf16x3 (test_c2_full_model_fp32_end_to_end: <= 1e-6 / 1.3e-7)
+    and, in this mode, with ttmi_set_option(13, 1)."""
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -428,7 +428,7 @@ def test_c2_bf16_loss_error_bound_along_a_training_trajectory(monkeypatch):
         return (float(np.max(np.abs(costs.double().cpu().numpy() - want) / want)), float(np.max(np.abs(c_enc - want) / want)), float(want.mean()), batch)
 
     done, seen = 0, []
-    for stop in (0, 10, 25):
+    for stop in (0, 2, 5, 10, 25):          # (2 and 5: the steepest states of the descent, where the batch mean read 1e-4 ... 3e-4 before round 6's two measures)
         while done < stop:
             flat.zero_grad()
             sync.start_step()
@@ -443,12 +443,12 @@ def test_c2_bf16_loss_error_bound_along_a_training_trajectory(monkeypatch):
           + "; ".join("step %d: %.2e / %.2e / %.0f / %+.2e" % s for s in seen))
     for stop, e_timed, e_enc, cost, batch in seen:
         assert e_timed < 3e-4 and e_enc < 3e-4, (stop, e_timed, e_enc)
-        # the batch mean is NOT a tighter quantity than the worst utterance while the model is in its first descent: the rounding of the SHARED weights moves every
-        # utterance's cost the same way (profiles/r06_loss_error_batch_mean.log: 32 of 32 utterances on one side at steps 2 - 10, batch mean up to 2.1e-4 over two seeds, 3.1e-4 at step 5 in one
-        # of five bench runs - the steepest state, which this test does not visit; at steps 0 / 10 / 25 it has read 2e-5 / 7e-5 ... 1.5e-4 / 2e-6);
-        # from about step 12 on the signs mix and the mean is 1e-5 class
-        assert abs(batch) < 3e-4, (stop, batch)
-    assert abs(seen[-1][4]) < 1e-4, seen[-1]            # (measured -1.3e-6 / -3.2e-7 at step 25)
+        # round 6: the quantity BASELINE names - the loss of the batch - within north_star's 1e-4 at EVERY state.  What made it 2e-4 ... 3e-4 at steps 2 - 10 was rounding that is
+        # ONE pattern in many lattice rows: the label states' (one label state meets all T frames; their second bf16 term enters the joint's input layer, and their VALUE comes
+        # from a gradient-free pass of the label encoder in bf16x3: tt.model.Transducer._label_states) and the weights' (the audio encoder's f32-output GEMMs take their weight's
+        # second term: ttmi_set_option(13, 2)).  Measured with both over 56 states of four trajectories: batch mean <= 8.1e-5, worst utterance 1.3e-4
+        # (profiles/r06_loss_error_batch_mean_fixed.log; this trajectory: <= 4.9e-5)
+        assert abs(batch) < 1e-4, (stop, batch)
     assert seen[-1][3] < 0.25 * seen[0][3]              # the loop did train (4450 -> ~430)
 
 

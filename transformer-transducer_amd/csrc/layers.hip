@@ -132,14 +132,20 @@ static inline const unsigned* drop_salt_here() {
 #define g_drop_salt drop_salt_here()
 int g_fork_wgrad = 1;
 int g_capture_forks = 0;        // ttmi_set_option(18, 1): fork inside a stream capture too, from streams not marked by ttmi_stream_set_nofork (round 5, see fork_stream)
-int g_split_weights = 0;        // ttmi_set_option(13, v): the encoders' forward GEMMs take the second term of their weight's bf16 split (W ~ hi + lo) as a second
+int g_split_weights = 2;        // ttmi_set_option(13, v), default 2 since round 6 (with the label value pass: the timed mode's batch-mean loss within 1e-4 at every state measured): the encoders' forward GEMMs take the second term of their weight's bf16 split (W ~ hi + lo) as a second
                                 // K range over the same A tiles, one launch each (NtEpilogue::B_lo): 1 = qkv_net, o_net, CoreNet.0, CoreNet.3; 2 = the two with f32
-                                // outputs (o_net, CoreNet.3) only.  Needs weight shadows (the free plain-copy region of the workspace holds the term)
+                                // outputs (o_net, CoreNet.3) only; + 4: all four in stacks of fewer than 4096 rows (the label encoder).  The term lives in the sub-layer's workspace
 int g_posgrad_gemms = 0;        // ttmi_set_option(11, 1): dq / dE by the round-2 GEMM launches instead of attn_dqde_kernel (A/B)
 int g_scatter_launch = 0;       // ttmi_set_option(16, 1): attn_dqde_kernel leaves dE / dc and relpos_scatter folds them (round 3; A/B); 2: atomics straight into
                                 // the table gradients (no per-(b, h) rows + reduction)
 int g_attn_slices = 1;          // ttmi_set_option(10, n): attention backward in n batch slices (see attn_bwd_impl)
 int g_gemm_slab = 0;            // ttmi_set_option(5, 1): position-term slab by the batched GEMM (A/B measurements)
+// which of an encoder layer's forward GEMMs take the weight's second term: option 13 = 1 all four, 2 the two with f32 outputs; bit 2 (4, round 6): all four, but only in
+// stacks of fewer than 4096 rows - the LABEL encoder, whose every rounding is replicated over the T frames of the joint (5 = both encoders, 4 = the label encoder alone)
+static inline bool split_w(long rows, bool f32_out) {
+    const int m = g_split_weights & 3;
+    return (m == 1 || (m == 2 && f32_out)) || ((g_split_weights & 4) && rows < 4096);
+}
 int g_joint_dec_lo = 1;         // ttmi_set_option(19, 0): the joint's input layer without the second bf16 term of the label states (round 6; A/B)
 struct SideCtx {
     int device = -1;
@@ -348,6 +354,7 @@ struct AttnWs {   // scratch (union of forward and backward needs)
     float *E, *cT, *dE, *dcT, *a, *dS, *dqkv, *delta;
     void* dO;
     bf16_t *wqkv16, *wo16, *dqkv16, *dres16, *dS16, *dG16, *E16, *kT16, *ET16;
+    bf16_t *wqkv16lo = nullptr, *wo16lo = nullptr;      // second bf16 term of the two forward weights (option 13), whether or not a shadow serves the first
     long ldp, slab16;
     AttnWs(Bump& b, const AttnDims& a, bool fast, void* keep = nullptr) {
         E = b.take<float>((size_t)a.L * a.HD);
@@ -370,6 +377,8 @@ struct AttnWs {   // scratch (union of forward and backward needs)
             ET16 = b.take<bf16_t>((size_t)a.H * a.Dh * ldp);
             wqkv16 = b.take<bf16_t>(a.W3 * a.d);
             wo16 = b.take<bf16_t>(a.HD * a.d);
+            wqkv16lo = b.take<bf16_t>(a.W3 * a.d);
+            wo16lo = b.take<bf16_t>(a.HD * a.d);
             dqkv16 = b.take<bf16_t>(a.BL * a.W3);
             dres16 = b.take<bf16_t>(a.BL * a.d);
             if (keep) {      // deferred weight gradients: their A operands must outlive this call (ttmi_attn_bwd_defer)
@@ -487,9 +496,9 @@ static int attn_fwd_impl(const float* x, const float* qkv_w, const float* o_w, c
         if (shq) wqkv16 = sh.w16;                                                               // kept current by the optimiser step
         else CK(transpose_convert_bf16(qkv_w, (int)a.W3, d, c.wqkvT16, a.W3, st, w.wqkv16));   // Wqkv (bf16) and Wqkv^T [d, W3] for backward
         NtEpilogue eq;
-        if (g_split_weights == 1 && shq) {                                                      // (the plain-copy region of the workspace is free when the shadow serves)
-            CK(bf16_residual(qkv_w, wqkv16, w.wqkv16, (long)a.W3 * d, st));
-            eq.B_lo = w.wqkv16;
+        if (split_w(a.BL, false)) {
+            CK(bf16_residual(qkv_w, wqkv16, w.wqkv16lo, (long)a.W3 * d, st));
+            eq.B_lo = w.wqkv16lo;
         }
         CK(gemm_nt_bf16(x16, wqkv16, c.qkv, 1, eq, (int)a.BL, (int)a.W3, d, d, d, a.W3, st));
         if (!attn_inkernel(fast, a))
@@ -559,9 +568,9 @@ static int attn_fwd_impl(const float* x, const float* qkv_w, const float* o_w, c
         if (sho) wo16 = sh.w16;
         else CK(transpose_convert_bf16(o_w, d, (int)a.HD, c.woT16, d, st, w.wo16));              // Wo (bf16) and Wo^T [HD, d] for backward
         NtEpilogue eo;
-        if (g_split_weights && sho) {
-            CK(bf16_residual(o_w, wo16, w.wo16, (long)d * a.HD, st));
-            eo.B_lo = w.wo16;
+        if (split_w(a.BL, true)) {
+            CK(bf16_residual(o_w, wo16, w.wo16lo, (long)d * a.HD, st));
+            eo.B_lo = w.wo16lo;
         }
         CK(gemm_nt_bf16(static_cast<bf16_t*>(c.O), wo16, w.a, 0, eo, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, st));
     } else if (x3 && x3_worth(a.BL, d, a.HD)) {
@@ -865,6 +874,7 @@ struct FfnWs {
     float *f, *dres, *dh;
     void* da1;
     bf16_t *w1_16, *w2_16, *dres16;
+    bf16_t *w1_16lo = nullptr, *w2_16lo = nullptr;     // second bf16 term of the two forward weights (option 13)
     FfnWs(Bump& b, long rows, int d, int Di, bool fast, void* keep = nullptr) {
         f = b.take<float>(rows * d);
         dres = b.take<float>(rows * d);
@@ -874,6 +884,8 @@ struct FfnWs {
         if (fast) {
             w1_16 = b.take<bf16_t>((size_t)Di * d);
             w2_16 = b.take<bf16_t>((size_t)Di * d);
+            w1_16lo = b.take<bf16_t>((size_t)Di * d);
+            w2_16lo = b.take<bf16_t>((size_t)Di * d);
             dres16 = b.take<bf16_t>(rows * d);
             if (keep) {      // deferred weight gradients (ttmi_ffn_bwd_defer)
                 da1 = keep;
@@ -934,13 +946,13 @@ static int ffn_fwd_impl(const float* y, const float* w1, const float* b1, const 
         NtEpilogue e1, e2;
         e1.bias = b1; e1.relu = 1; e1.drop = d_in;
         e2.bias = b2;
-        if (g_split_weights == 1 && sh1) {
-            CK(bf16_residual(w1, w1_16, w.w1_16, (long)d * Di, st));
-            e1.B_lo = w.w1_16;
+        if (split_w(rows, false)) {
+            CK(bf16_residual(w1, w1_16, w.w1_16lo, (long)d * Di, st));
+            e1.B_lo = w.w1_16lo;
         }
-        if (g_split_weights && sh2) {
-            CK(bf16_residual(w2, w2_16, w.w2_16, (long)d * Di, st));
-            e2.B_lo = w.w2_16;
+        if (split_w(rows, true)) {
+            CK(bf16_residual(w2, w2_16, w.w2_16lo, (long)d * Di, st));
+            e2.B_lo = w.w2_16lo;
         }
         CK(gemm_nt_bf16(static_cast<bf16_t*>(c.h), w1_16, c.a1, 1, e1, (int)rows, Di, d, d, d, Di, st));
         CK(gemm_nt_bf16(static_cast<bf16_t*>(c.a1), w2_16, w.f, 0, e2, (int)rows, d, Di, Di, Di, d, st));

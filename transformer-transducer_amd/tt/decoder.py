@@ -57,12 +57,13 @@ class BuildDecoder(nn.Module):
         self.layers[0].MultiHeadAttention.dec_attn.first_layer = True
         self.layers[0].MultiHeadAttention.pos_ff.first_layer = True
 
-    def forward(self, inputs, mask=None):
+    def forward(self, inputs, mask=None, prec=None):
+        """prec (not in the reference's signature; None = label_precision() / the mode in force): precision code of this call's layers"""
         ops.weights_fresh()
         spec = as_mask_spec(mask, inputs.size(0), inputs.size(1))
         x = _EmbedFn.apply(inputs, self.dec_embedding.weight, self.dec_embedding.padding_idx)
         x16 = None
-        prec = label_precision()                      # (None = the mode in force; see tt.transformer.label_precision)
+        prec = label_precision() if prec is None else prec      # (None = the mode in force; see tt.transformer.label_precision)
         fused = prec is None and x.is_cuda and all(layer.MultiHeadAttention.fused() for layer in self.layers)      # (see tt/encoder.py)
         for i, layer in enumerate(self.layers):
             if fused and i + 1 < len(self.layers):

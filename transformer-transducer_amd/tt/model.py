@@ -13,7 +13,7 @@ from ttmi import ops
 from ttmi.ops import MaskSpec
 from tt.decoder import BuildDecoder
 from tt.encoder import BuildEncoder
-from tt.transformer import default_precision, grad_targets
+from tt.transformer import label_value_precision, default_precision, grad_targets
 from tt.utils import context_mask, look_ahead_mask  # noqa: F401  (re-exported like the reference module)
 
 
@@ -528,14 +528,31 @@ class Transducer(nn.Module):
             if not capturing:
                 targets.record_stream(side)
             with torch.cuda.stream(side):
-                dec_state = self.decoder(targets, MaskSpec(1))
+                dec_state = self._label_states(targets)
             main.wait_stream(side)
             if not capturing:
                 dec_state.record_stream(main)
         else:
             enc_state = self.encoder(inputs, audio_mask)
-            dec_state = self.decoder(targets, MaskSpec(1))                  # == look_ahead_mask(targets)[:, :, None]
+            dec_state = self._label_states(targets)
         return enc_state, dec_state
+
+    def _label_states(self, targets):
+        """the label encoder on the padded targets (mask == look_ahead_mask(targets)[:, :, None]).  With TTMI_LABEL_VALUE_PRECISION (tt.transformer.label_value_precision) the
+        states' VALUE comes from a second, gradient-free pass in a parity mode, on the same dropout masks (the CPU generator the seeds are drawn from is rewound for it), and
+        the gradient flows through the bf16 pass: one label state meets all T frames of its utterance in the joint, so the label encoder's bf16 rounding is one pattern in T
+        lattice rows - and, while its outputs still resemble each other (the first steps of training), in every utterance of the batch (round 6)."""
+        vp = label_value_precision()
+        if vp is None or not targets.is_cuda:
+            return self.decoder(targets, MaskSpec(1))
+        rng = torch.get_rng_state()
+        dec = self.decoder(targets, MaskSpec(1))
+        after = torch.get_rng_state()
+        torch.set_rng_state(rng)
+        with torch.no_grad():
+            hi = self.decoder(targets, MaskSpec(1), prec=vp)
+        torch.set_rng_state(after)
+        return dec + (hi - dec.detach())
 
     def _audio_mask(self, inputs):
         """Reference behaviour is audio_mask=None (tt/model.py:60-61).  Opt-in `config.streaming` (absent in the

@@ -35,6 +35,18 @@ def label_precision():
     return 2 if v in ("bf16x3", "2") else (0 if v in ("fp32", "0") else None)
 
 
+def label_value_precision():
+    """TTMI_LABEL_VALUE_PRECISION = bf16x3 (default in bf16 mode since round 6) | fp32 | off: the label encoder's states take their VALUE from a second, gradient-free pass
+    in that parity mode while the gradient still flows through the bf16 pass (tt.model.Transducer._label_states) - the forward-only form of TTMI_LABEL_PRECISION: the loss
+    sees accurate label states, the backward pass costs what it cost (+0.75 ms per C2 step, on the label encoder's side stream).  With the two-term weights of the
+    audio encoder's f32-output GEMMs (ttmi_set_option(13, 2), the library's default) the timed mode's batch-mean loss stays within 8.1e-5 of the fp32 mode over 56 states of
+    four training trajectories (profiles/r06_loss_error_batch_mean_fixed.log; 2e-4 ... 3e-4 without them).  None = off / not bf16 mode."""
+    if default_precision() != 1:
+        return None
+    v = os.environ.get("TTMI_LABEL_VALUE_PRECISION", "bf16x3").lower()
+    return 2 if v in ("bf16x3", "2") else (0 if v in ("fp32",) else None)
+
+
 _mask_cache = {}     # id(mask tensor) -> (weakref, version, MaskSpec): every layer of a stack gets the same mask tensor
 
 
