@@ -1165,7 +1165,7 @@ static inline size_t al8(size_t n) { return (n + 7) & ~(size_t)7; }
 static inline bool joint_input_fast(int prec, int B, int T, int U1, int de, int dd, int J) {
     if (!joint_fast(prec, J) || de % 8 || dd % 8 || (long)B * T < 1024) return false;
     const size_t M = (size_t)B * T * U1, din = (size_t)de + dd;
-    const size_t need = al8((size_t)B * T * de) + al8((size_t)B * U1 * dd) + al8((size_t)B * T * J) + al8((size_t)B * U1 * J) + al8(din * J) + 8;
+    const size_t need = al8((size_t)B * T * de) + al8((size_t)B * U1 * dd) + al8((size_t)B * T * J) + 2 * al8((size_t)B * U1 * J) + al8(din * J) + 8;   // (2: dPD's two terms)
     // bf16 elements behind dH16 (backward); the forward pass has the whole region (2 M J elements) for its copies and the weight's second split term
     return need <= (size_t)M * J && need + al8(din * J) + al8((size_t)B * U1 * dd) <= 2 * (size_t)M * J;      // (+ the label states' second split term, round 6)
 }
@@ -1458,6 +1458,16 @@ static int joint_bwd_impl(const void* dlogits, long ldg, const float* enc, const
         CK(gemm_tn_bf16(dPD16, dec16, g_wf + de, J, dd, B * U1, J, dd, din, 1, fork_stream(st)));
         CK(gemm_nt_bf16(dPE16, wfT16, denc, 0, nullptr, B * T, de, J, J, J, de, st));
         CK(gemm_nt_bf16(dPD16, wfT16 + (size_t)de * J, ddec, 0, nullptr, B * U1, dd, J, J, J, dd, st));
+        if (g_joint_dec_lo) {
+            // dPD's second bf16 term: each entry is a sum over T frames that 32 blocks per label state add in f32 atomic order, and that 1e-7 noise decides the
+            // bf16 rounding of one or two of the B U1 J entries differently from run to run - a whole row of d(label states) then moves by 1e-5 of the largest
+            // entry, the label encoder's bias gradients by 2e-5 (tools/debug/step0_repro.py).  With the second term the noise stays 1e-7; one B U1-row GEMM more
+            bf16_t* dPD16lo = WfT16 + al8((size_t)din * J);
+            CK(bf16_residual(dPD, dPD16, dPD16lo, (long)B * U1 * J, st));
+            NtEpilogue el;
+            el.addend = ddec;
+            CK(gemm_nt_bf16(dPD16lo, wfT16 + (size_t)de * J, ddec, 0, el, B * U1, dd, J, J, J, dd, st));
+        }
         join_stream(st);
         return TTMI_OK;
     }
