@@ -39,7 +39,7 @@ def c2_config(n_enc=12, n_dec=6):
                          enc=dict(side, type="attention", max_input_length=410, left_context=10, right_context=2, n_layer=n_enc),
                          dec=dict(side, type="attention", max_target_length=42, n_layer=n_dec),
                          joint=dict(input_size=1024, inner_size=1024), vocab_size=4334, share_weight=False, dropout=0.1,
-                         overlap_label_encoder=True))
+                         overlap_label_encoder=os.environ.get("TTMI_BENCH_OVERLAP_LABEL", "1") != "0"))
 
 
 def c4_config(streaming):
@@ -52,7 +52,7 @@ def c4_config(streaming):
                          enc=dict(side, type="attention", max_input_length=410, left_context=10, right_context=2, n_layer=18),
                          dec=dict(side, type="attention", max_target_length=42, n_layer=2),
                          joint=dict(input_size=1024, inner_size=2048), vocab_size=6485, share_weight=False, dropout=0.1,
-                         overlap_label_encoder=True, streaming=st))
+                         overlap_label_encoder=os.environ.get("TTMI_BENCH_OVERLAP_LABEL", "1") != "0", streaming=st))
 
 
 def flops_per_utt(cfg, T, U1):

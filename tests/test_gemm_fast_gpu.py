@@ -123,6 +123,28 @@ def test_persistent_256x128_kernel_exact(M, N, K, pad, cdt):
         assert bool((Cfull[:, N:] == 5.0).all())
 
 
+@pytest.mark.parametrize("reserve", [1, 4, 5, 13, 32, 100])
+@pytest.mark.parametrize("gen,M,N,K", [(9, 16000, 512, 512), (9, 16000, 1024, 512), (9, 3001, 700, 320), (9, 1024, 128, 64), (8, 16000, 2048, 512), (8, 3001, 700, 320)])
+def test_persistent_grids_of_any_size_exact(reserve, gen, M, N, K):
+    """data-parallel backward leaves `reserve` CUs to the collective's kernels: the persistent NT kernels then run on EXACTLY 256 - reserve workgroups (round 6; rounded
+    down to a multiple of 8 before, a reservation of 4 turned one round of the encoder's 252-tile GEMMs into two).  Any grid size, same bits: the XCDs' shares of a
+    round differ by one workgroup"""
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + reserve)
+    A, B = _ints((M, K), g), _ints((N, K), g)
+    bias = torch.randint(-3, 4, (N,), device="cuda", generator=g).float()
+    want = (A.float() @ B.float().t() + bias).to(torch.bfloat16)
+    C = torch.full((M, N), 5.0, device="cuda", dtype=torch.bfloat16)
+    ops.set_option(1, gen)
+    ops.reserve_cus(reserve)
+    try:
+        ops.gemm_nt_bf16(A, B, C, bias)
+    finally:
+        ops.reserve_cus(0)
+        ops.set_option(1, 4)
+    assert torch.equal(C, want)
+
+
 @pytest.mark.parametrize("M,N,K", [(1024, 1024, 32768), (1124, 1024, 40000), (2048, 1024, 33001), (4334, 1024, 65600),
                                    (1349, 2048, 34048), (1024, 1536, 32768)])
 def test_persistent_256_wgrad_kernel_exact(M, N, K):

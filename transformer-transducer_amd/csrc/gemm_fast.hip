@@ -672,7 +672,8 @@ __device__ __forceinline__ void gemm_nt_v8_body(const FP& p_) {
             if (s >= w_owned) return (long)p.tiles_m * p.tiles_n;          // past this XCD's share
             return ((long)w_xcd + 8 * (s / w_per_group)) * w_per_group + s % w_per_group;
         }
-        return (long)it * gridDim.x + (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+        // (grids that are no multiple of 8 - data-parallel backward leaves 256 - r CUs: the first gridDim.x & 7 XCDs hold one workgroup more)
+        return (long)it * gridDim.x + (blockIdx.x & 7) * (gridDim.x >> 3) + min((int)(blockIdx.x & 7), (int)(gridDim.x & 7)) + (blockIdx.x >> 3);
     };
     auto coords = [&](long id, int& bm, int& bn) {
         const int per_group = GROUP_M * p.tiles_n;
@@ -1065,7 +1066,9 @@ __device__ __forceinline__ void gemm_nt_v9_body(const FP& p_) {
     const int ntiles = p.tiles_m * p.tiles_n;
     const int nk = (p.K + TKE - 1) / TKE;
 
-    auto tile_id = [&](int it) { return (long)it * gridDim.x + (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3); };
+    // workgroups with equal id mod 8 share an XCD: they take consecutive tiles of every round; a grid that is no multiple of 8 (data-parallel backward leaves
+    // 256 - r CUs to this kernel) has one workgroup more on its first gridDim.x & 7 XCDs
+    auto tile_id = [&](int it) { return (long)it * gridDim.x + (blockIdx.x & 7) * (gridDim.x >> 3) + min((int)(blockIdx.x & 7), (int)(gridDim.x & 7)) + (blockIdx.x >> 3); };
     auto coords = [&](long id, int& bm, int& bn) {
         const int per_group = GROUP_M * p.tiles_n;
         const int group = (int)(id / per_group), in = (int)(id % per_group);
@@ -2226,7 +2229,9 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     const long t9 = (long)cdiv(M, T9M) * cdiv(N, T9N), t8 = (long)cdiv(M, T8) * cdiv(N, T8);
     const bool pers = nbatch == 1 && M >= 1024 && N >= 128 && K >= 128 && K % TK == 0 && !dual;
     const int reserved = reserved_cus(st);
-    const int cus_avail = std::max(8, (g_num_cus - reserved) / 8 * 8);
+    // CUs the NT kernels may fill: all of them, or - while communication kernels hold `reserved` CUs - EXACTLY the rest (round 6: rounded down to a multiple of 8 a
+    // reservation of 1 ... 8 CUs left 248, and the encoder's 252-tile backward GEMMs took two rounds instead of one: +1.3 ms per step for any reservation at all)
+    const int cus_avail = reserved > 0 ? std::max(8, g_num_cus - reserved) : g_num_cus;
     const double cost9 = (double)cdiv(t9, cus_avail), cost8 = N >= 256 ? 1.8 * cdiv(t8, t8 < 1024 ? cus_avail : g_num_cus) : 1e30;
     // the exp-store / row-scale epilogues exist on the 256x256 kernel only: callers ask gemm_fast_joint_exp_ok() first
     const bool needs8 = epi.rowsum || epi.rowscale;
@@ -2238,8 +2243,7 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
         p.tiles_m = cdiv(M, T9M); p.tiles_n = cdiv(N, T9N);
         // a persistent grid larger than the CUs that are actually free runs its surplus workgroups AFTER the others (twice the time):
         // with gradient all-reduce kernels resident during backward, leave them room (multi-GPU runs set option 6)
-        const int cus9 = std::max(8, (g_num_cus - reserved) / 8 * 8);
-        const int grid9 = (int)((std::min<long>(t9, cus9) + 7) / 8 * 8);
+        const int grid9 = reserved > 0 ? (int)std::min<long>(t9, cus_avail) : (int)((std::min<long>(t9, cus_avail) + 7) / 8 * 8);
         // lean epilogue instances (nothing tested per store): plain / bias-only for both output types, mask-only for bf16
         const bool base_ok = !p.addend && !p.relu && p.drop.p <= 0.f && aligned16(C) && (!p.bias || aligned16(p.bias));
         const bool lean1 = base_ok && !p.mask && ldc % (c_dtype == 0 ? 4 : 8) == 0;
@@ -2274,8 +2278,9 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
         static const int walk_env = [] { const char* e = getenv("TTMI_TILE_WALK"); return e ? atoi(e) : 0; }();
         p.walk = walk_env;
         const long nwg8 = (long)p.tiles_m * p.tiles_n;
-const int cus8 = nwg8 < 1024 ? std::max(8, (g_num_cus - reserved) / 8 * 8) : g_num_cus;   // encoder-sized problems only (see v9)
-        const int grid8 = (int)((std::min<long>(nwg8, cus8) + 7) / 8 * 8);   // multiple of 8: one share of every round per XCD
+        const int cus8 = nwg8 < 1024 ? cus_avail : g_num_cus;   // encoder-sized problems only (see v9)
+        const int grid8 = reserved > 0 && nwg8 < 1024 ? (int)std::min<long>(nwg8, cus8) : (int)((std::min<long>(nwg8, cus8) + 7) / 8 * 8);   // multiple of 8: one share of every round per XCD
+        if (grid8 & 7) p.walk = 0;
 if (p.kwrap) {
             TTMI_REQUIRE(!needs8, "gemm_nt_bf16: no second weight term with the exp-store / row-scale epilogues");
             if (c_dtype == 0) {

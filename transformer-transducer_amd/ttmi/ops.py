@@ -699,7 +699,8 @@ def side_stream(device):
     key = (device.type, device.index)
     st = _side_streams.get(key)
     if st is None:
-        st = _side_streams[key] = torch.cuda.Stream(device=device)
+        # TTMI_SIDE_STREAM_PRIORITY (A/B knob, round 6): torch clamps it to the device's range; lower number = served first
+        st = _side_streams[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get("TTMI_SIDE_STREAM_PRIORITY", "0")))
         # a second-level stream (forked from the caller's main stream): library calls on it never fork again inside a stream capture
         check(lib().ttmi_stream_set_nofork(c_void_p(st.cuda_stream), c_int(1)), "ttmi_stream_set_nofork")
     return st
