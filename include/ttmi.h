@@ -328,7 +328,9 @@ int ttmi_stream_reserve_cus(void* stream, int n);
  * 17: exact-f32 NT products: 0 = the kernels of csrc/gemm.hip only (round 1), 1 = default rule (persistent 256x128 kernel with f32 operands from 512 of its tiles on,
  * 64x64 tiles from 72 of those on), 2 / 3 = the 64x64-tile / the persistent kernel wherever it can run; 18: 1 = fork inside a stream capture;
  * 19: 0 = the joint's input layer (bf16 mode) without the second bf16 term of the label-encoder states (round 6: that rounding is one pattern in all T lattice rows of a label
- * position and was the joint's whole share of the batch-mean loss error; A/B) */
+ * position and was the joint's whole share of the batch-mean loss error; A/B);
+ * 20: 0 = grouped weight gradients never cut an XCD's surplus tiles into K-pieces (default 1: under a CU reservation - ttmi_stream_reserve_cus - 256 tiles on 224 ... 248
+ * workgroups end with one atomically added piece per workgroup instead of a second round; without a reservation the launches stay free of atomics either way) */
 int ttmi_set_option(int key, int value);
 int ttmi_dropout_apply(const float* in, long n, float p, unsigned seed, float* out, void* stream);
 int ttmi_probe_arm(int slot);

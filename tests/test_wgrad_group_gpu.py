@@ -48,6 +48,34 @@ def test_exact_integers_all_shapes_of_a_layer_and_a_misfit():
             assert torch.equal(col, wcol), A.shape
 
 
+@pytest.mark.parametrize("reserve,layers", [(8, 4), (32, 4), (4, 4), (32, 3), (64, 5), (32, 1)])
+def test_surplus_tiles_as_k_pieces_under_a_cu_reservation(reserve, layers):
+    """data-parallel backward (ttmi_stream_reserve_cus): the four-layer launch is 256 tiles - one round of 256 workgroups, two of 248 or 224.  The kernel then cuts
+    the few surplus tiles of every XCD's list into K-pieces, one per workgroup, added atomically (round 6; exact here: integer sums in any order).  Option 20 = 0
+    keeps whole tiles; both give the same numbers, as does the unreserved launch"""
+    from ttmi import ops
+    g = torch.Generator(device="cuda").manual_seed(13 + reserve + layers)
+    K = 8192
+    shapes = [(1536, 512, False), (512, 512, False), (1024, 512, True), (512, 1024, False)] * layers
+    ops_in = [(_ints((K, M), g, -1, 2), _ints((K, N), g, -1, 2), torch.randint(-8, 9, (M, N), device="cuda", generator=g).float(),
+               torch.randint(-8, 9, (M,), device="cuda", generator=g).float() if cs else None) for M, N, cs in shapes]
+    want = [(C + A.float().t() @ B.float(), None if col is None else col + A.float().sum(0)) for A, B, C, col in ops_in]
+    for pieces in (1, 0):
+        probs = [(A, B, C.clone(), None if col is None else col.clone()) for A, B, C, col in ops_in]
+        ops.set_option(20, pieces)
+        ops.reserve_cus(reserve)
+        try:
+            _group(probs)
+            torch.cuda.synchronize()
+        finally:
+            ops.reserve_cus(0)
+            ops.set_option(20, 1)
+        for (A, B, C, col), (wc, wcol) in zip(probs, want):
+            assert torch.equal(C, wc), (pieces, A.shape, B.shape)
+            if col is not None:
+                assert torch.equal(col, wcol), (pieces, A.shape)
+
+
 def test_padded_pitches_and_long_reduction():
     """operands that are column slices of wider buffers (row pitch > width), K = 16000 as in a C2 step"""
     g = torch.Generator(device="cuda").manual_seed(12)

@@ -76,6 +76,7 @@ int gemm_nt_f32_mid(const float* A, const float* B, float* C, const float* bias,
 bool gemm_nt_f32_ok(const void* A, const void* B, const void* C, int M, int N, int K, long lda, long ldb, long ldc);
 int gemm_nt_f32(const float* A, const float* B, float* C, const NtEpilogue& epi, int M, int N, int K, long lda, long ldb, long ldc, hipStream_t st);
 void gemm_fast_set_reserved_cus(int n);   // process-wide default (measurement switch)
+void gemm_fast_set_tn_group_pieces(int on);   // grouped weight gradients under a CU reservation: surplus tiles as K-pieces (default on)
 void gemm_fast_stream_reserve_cus(hipStream_t st, int n);   // per-stream state: launches on `st` (and on fork streams aliased to it) leave n CUs free
 void gemm_fast_alias_stream(hipStream_t child, hipStream_t parent);
 //   // CUs left free by the mid-sized persistent GEMMs (for concurrent RCCL kernels)

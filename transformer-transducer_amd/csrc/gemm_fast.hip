@@ -1930,6 +1930,8 @@ struct TnGroupProb {
 struct TnGroup {
     TnGroupProb pr[16];
     int n, total;
+    int pieces;                     // != 0: an XCD whose tile list is a few tiles longer than a whole number of rounds cuts the surplus tiles along K, one piece per
+                                    // workgroup, added atomically (data-parallel backward on 256 - r CUs: 256 tiles would otherwise take two rounds)
 };
 
 __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_group_kernel(const TnGroup g) {
@@ -1940,14 +1942,23 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_group_kernel(const TnGro
     const int grp = wave >> 2;
     const int xcd = blockIdx.x & 7, cu = blockIdx.x >> 3, ncu = gridDim.x >> 3;
     const int per_x = (g.total + 7) / 8;                   // XCD x owns tiles [x * per_x, (x + 1) * per_x): consecutive tiles = one problem's
-    const int hi = min((xcd + 1) * per_x, g.total);
+    const int lo_x = min(xcd * per_x, g.total), hi = min((xcd + 1) * per_x, g.total);
+    // items of this XCD: its tiles, whole - unless (g.pieces) the last round would be a small one: then its s tiles are cut into P = ncu / s pieces along K each
+    // (every workgroup ends with one piece of 1 / P tile instead of s workgroups running a whole second tile)
+    const int n_x = hi - lo_x, n_rounds = n_x / ncu, n_sur = n_x - n_rounds * ncu;
+    const int P = (g.pieces && n_sur > 0 && 2 * n_sur <= ncu) ? ncu / n_sur : 0;
+    const int n_whole = P ? n_rounds * ncu : n_x;
+    const int n_items = n_whole + (P ? n_sur * P : 0);
 
     unsigned oA[4], oB[2];
     const char* baseA = nullptr;
     const char* baseB = nullptr;
     long lda = 0, ldb = 0;
     int nk = 0, q = 0;
-    auto item = [&](int it, int& bm, int& bn, int& tn) {
+    bool piece = false;                                    // the current item is a K-piece of a tile (added atomically)
+    auto item = [&](int v, int& bm, int& bn, int& tn) {    // v: index into this XCD's item list
+        piece = v >= n_whole;
+        const int it = lo_x + (piece ? n_whole + (v - n_whole) / P : v);
         q = 0;
         while (q + 1 < g.n && it >= g.pr[q + 1].tile0) ++q;
         const TnGroupProb& pr = g.pr[q];
@@ -1959,6 +1970,13 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_group_kernel(const TnGro
         nk = pr.K / TK;
         baseA = reinterpret_cast<const char*>(pr.A);
         baseB = reinterpret_cast<const char*>(pr.B);
+        if (piece) {                                       // K-tiles [k0, k1) of the tile (host: every problem has >= 2 P K-tiles when pieces are on)
+            const int part = (v - n_whole) % P;
+            const long k0 = (long)part * nk / P, k1 = (long)(part + 1) * nk / P;
+            baseA += k0 * TK * lda * 2;
+            baseB += k0 * TK * ldb * 2;
+            nk = (int)(k1 - k0);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = (wave * 4 + j) * 2 + (lane >> 5);
@@ -2000,8 +2018,8 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_group_kernel(const TnGro
 #define V9_BAR() __builtin_amdgcn_s_barrier()
 
     int bm = 0, bn = 0, tn = 0;
-    int it = xcd * per_x + cu;
-    bool live = it < hi;
+    int it = cu;
+    bool live = it < n_items;
     if (live) { item(it, bm, bn, tn); stage(0, 0); if (nk > 1) { TTMI_VM_GUARD("v9"); stage(1, 1); } }
     while (live) {
 #pragma unroll
@@ -2010,6 +2028,7 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_group_kernel(const TnGro
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         cs = f32x4{0.f, 0.f, 0.f, 0.f};
         const TnGroupProb cur = g.pr[q];
+        const bool cpiece = piece;
         const int cs_mt = (cur.colsum && tn < 2) ? __builtin_amdgcn_readfirstlane(tn * 2 + wc) : -1;
         const int cnk = nk;
         if (cnk > 1) TTMI_VM_WAIT("v9", V9_INFLIGHT);
@@ -2069,11 +2088,11 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_group_kernel(const TnGro
 
         const int cbm = bm, cbn = bn;
         it += ncu;
-        live = it < hi;
+        live = it < n_items;
         if (live) { item(it, bm, bn, tn); stage(0, 0); if (nk > 1) { TTMI_VM_GUARD("v9"); stage(1, 1); } }
 
         // C += tile: 16 rows at a time through a private LDS image in stage 2 (free until the next tile's K-tile 2), one 256-byte row per
-        // instruction; this workgroup is the only writer of these elements
+        // instruction; this workgroup is the only writer of these elements - unless the item was a K-piece: its P writers add atomically
         float* img = reinterpret_cast<float*>(smem + 2 * STG9 + wave * 4096);
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
@@ -2081,15 +2100,21 @@ __global__ __launch_bounds__(NTH8, 1) void gemm_tn_bf16_group_kernel(const TnGro
             for (int ni = 0; ni < 4; ++ni)
                 *reinterpret_cast<f32x4*>(img + (lane & 15) * 64 + ((ni * 4 + (lane >> 4)) ^ (lane & 15)) * 4) = acc[mi][ni];
             float* crow = cur.C + (long)(cbm + wr * 64 + mi * 16) * cur.ldc + cbn + wc * 64 + lane;
-            float old[16];
+            if (cpiece) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) old[r] = crow[(long)r * cur.ldc];
+                for (int r = 0; r < 16; ++r) atomicAdd(crow + (long)r * cur.ldc, img[r * 64 + (((lane >> 2) ^ r) << 2) + (lane & 3)]);
+            } else {
+                float old[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) crow[(long)r * cur.ldc] = old[r] + img[r * 64 + (((lane >> 2) ^ r) << 2) + (lane & 3)];
+                for (int r = 0; r < 16; ++r) old[r] = crow[(long)r * cur.ldc];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) crow[(long)r * cur.ldc] = old[r] + img[r * 64 + (((lane >> 2) ^ r) << 2) + (lane & 3)];
+            }
         }
         if (cs_mt >= 0 && lane < 16) {
             float* c = cur.colsum + cbm + wr * 64 + cs_mt * 16 + lane;
-            *c = *c + cs[0];
+            if (cpiece) atomicAdd(c, cs[0]);
+            else *c = *c + cs[0];
         }
     }
 #undef V9_BAR
@@ -2116,6 +2141,7 @@ int g_f32_fast = 1;              // ttmi_set_option(17, v): 0 = f32 NT products 
 int g_bf16_mid = 32;             // set_version(16 + n): bf16 NT problems the persistent kernels leave go to the 64 x 64-tile kernel from n of its tiles on (16 = never)
 int g_nt_stores = 1;             // streaming stores for bf16 outputs >= 256 MB (set_version(14 / 15) = off / on, generation unchanged)
 int g_num_cus = 0;
+int g_tn_group_pieces = 1;        // ttmi_set_option(20, 0): grouped weight gradients never cut surplus tiles into K-pieces (A/B; see TnGroup::pieces)
 int g_reserved_cus = 0;           // ttmi_set_option(6, n): process-wide default of the per-stream reservation below (measurement switch)
 // CUs the mid-sized persistent GEMMs leave to concurrently running communication kernels: PER-STREAM state (ttmi_stream_reserve_cus), so a
 // data-parallel backward pass on one stream does not change what another stream or thread launches.  Library-owned fork streams answer
@@ -2237,6 +2263,8 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
     const bool needs8 = epi.rowsum || epi.rowscale;
     const bool v8 = nbatch == 1 && !dual && nt_v8_eligible(M, N, K);
     TTMI_REQUIRE(!needs8 || (v8 && c_dtype == 1), "gemm_nt_bf16: the exp-store / row-scale epilogues exist on the persistent 256x256 kernel only (M=%d N=%d K=%d)", M, N, K);
+    // (measured and dropped, round 6: under a CU reservation, handing a problem of barely more tiles than workgroups - the encoder's 252 on 224 - to the 64 x 64-tile
+    // kernel instead of a second persistent round: +0.4 ms per step, profiles/r06_reserve_cus_single_gpu.txt)
     const bool v9 = !needs8 && pers && ((g_gemm_fast_version == 9) || (g_gemm_fast_version == 4 && t9 >= g_num_cus * 3 / 4 && cost9 <= cost8));
     if (v9) {
         if (two_term) { p.B2 = epi.B_lo; p.kwrap = K / TK; p.K = K + k_lo; }
@@ -2527,6 +2555,7 @@ void gemm_fast_set_tn_target(int n) { g_tn_target_blocks = n; }
 void gemm_fast_set_f32(int on) { g_f32_fast = on; }
 int gemm_fast_f32_mode() { return g_f32_fast; }
 void gemm_fast_set_reserved_cus(int n) { g_reserved_cus = n < 0 ? 0 : n; }
+void gemm_fast_set_tn_group_pieces(int on) { g_tn_group_pieces = on; }
 void gemm_fast_stream_reserve_cus(hipStream_t st, int n) {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -2556,12 +2585,18 @@ int gemm_tn_bf16_group(const TnProblem* probs, int n, hipStream_t st) {
     }
     if (int rc = enable_lds(gemm_tn_bf16_group_kernel, LDS9)) return rc;
     TnGroup g;
-    g.n = 0; g.total = 0;
+    g.n = 0; g.total = 0; g.pieces = 0;
+    int min_nkt = 1 << 30;
     // data-parallel backward: leave the CUs reserved on this stream to RCCL's kernels, like the v8 / v9 launches do (a persistent grid
     // larger than the CUs that are free runs its surplus workgroups after the others anyway)
-    const int cus = std::max(8, (g_num_cus - reserved_cus(st)) / 8 * 8);
+    const int reserved = reserved_cus(st);
+    const int cus = std::max(8, (g_num_cus - reserved) / 8 * 8);
     auto flush = [&]() -> int {
         if (g.n == 0) return TTMI_OK;
+        // K-pieces for an XCD's surplus tiles only while CUs are reserved (the unreserved launches stay free of atomics: bit-reproducible) and only if the shortest
+        // reduction still gives every piece a few K-tiles (P <= cus / 8 pieces per tile)
+        g.pieces = reserved > 0 && min_nkt >= 2 * (cus / 8) && g_tn_group_pieces;
+        min_nkt = 1 << 30;
         const bool probe = g.total >= 128;      // timing probe 4: a grouped launch that fills at least half the chip
         if (probe) ttmi_probe_begin(4, st);
         hipLaunchKernelGGL(gemm_tn_bf16_group_kernel, dim3((unsigned)cus), dim3(NTH8), LDS9, st, g);
@@ -2580,6 +2615,7 @@ int gemm_tn_bf16_group(const TnProblem* probs, int n, hipStream_t st) {
         d.A = q.A; d.B = q.B; d.C = q.C; d.colsum = q.colsum; d.M = q.M; d.N = q.N; d.K = q.K; d.tiles_m = q.M / T9M;
         d.lda = q.lda; d.ldb = q.ldb; d.ldc = q.ldc; d.tile0 = g.total;
         g.total += d.tiles_m * (q.N / T9N);
+        min_nkt = std::min(min_nkt, q.K / TK);
         if (++g.n == 16) { if (int rc = flush()) return rc; }
     }
     return flush();

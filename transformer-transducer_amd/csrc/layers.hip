@@ -1553,8 +1553,9 @@ int ttmi_set_dropout_salt(const unsigned* salt) {
 // process-wide switches for A/B measurements.  key 0: 1 = disable the fused attention kernels (bf16 pipeline only);
 // key 1: throughput-GEMM generation (see gemm_fast.hip); key 2: flash-kernel timing switches; key 3: 0 = no wgrad fork
 int ttmi_set_option(int key, int value) {
-    TTMI_REQUIRE(key >= 0 && key <= 19, "set_option: unknown key %d", key);
+    TTMI_REQUIRE(key >= 0 && key <= 20, "set_option: unknown key %d", key);
     if (key == 19) { g_joint_dec_lo = value; return TTMI_OK; }
+    if (key == 20) { gemm_fast_set_tn_group_pieces(value); return TTMI_OK; }
     if (key == 18) { g_capture_forks = value; return TTMI_OK; }
     if (key == 17) { gemm_fast_set_f32(value); return TTMI_OK; }
     if (key == 16) { g_scatter_launch = value; return TTMI_OK; }
