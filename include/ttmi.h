@@ -330,7 +330,8 @@ int ttmi_stream_reserve_cus(void* stream, int n);
  * 19: 0 = the joint's input layer (bf16 mode) without the second bf16 term of the label-encoder states (round 6: that rounding is one pattern in all T lattice rows of a label
  * position and was the joint's whole share of the batch-mean loss error; A/B);
  * 20: 0 = grouped weight gradients never cut an XCD's surplus tiles into K-pieces (default 1: under a CU reservation - ttmi_stream_reserve_cus - 256 tiles on 224 ... 248
- * workgroups end with one atomically added piece per workgroup instead of a second round; without a reservation the launches stay free of atomics either way) */
+ * workgroups end with one atomically added piece per workgroup instead of a second round; without a reservation the launches stay free of atomics either way);
+ * 21: 0 = the joint's sums over frames (dPD) by f32 atomics as in rounds 1 - 5 (default 1: partial rows + an ordered second pass - the same bits in every run, same time) */
 int ttmi_set_option(int key, int value);
 int ttmi_dropout_apply(const float* in, long n, float p, unsigned seed, float* out, void* stream);
 int ttmi_probe_arm(int slot);

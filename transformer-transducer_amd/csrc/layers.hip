@@ -146,6 +146,7 @@ static inline bool split_w(long rows, bool f32_out) {
     const int m = g_split_weights & 3;
     return (m == 1 || (m == 2 && f32_out)) || ((g_split_weights & 4) && rows < 4096);
 }
+int g_joint_dpd_two_pass = 1;   // ttmi_set_option(21, 0): the joint's sums over frames by f32 atomics (rounds 1 - 5; A/B)
 int g_joint_dec_lo = 1;         // ttmi_set_option(19, 0): the joint's input layer without the second bf16 term of the label states (round 6; A/B)
 struct SideCtx {
     int device = -1;
@@ -1435,8 +1436,15 @@ static int joint_bwd_impl(const void* dlogits, long ldg, const float* enc, const
             }
             CK(gemm_tn_bf16(dZ, Hs, g_wp, V, J, Mp, ldg, J, J, 1, st, g_bp, FastBatch(), static_cast<const bf16_t*>(srow16)));
         }
-        CK(fill_zero(dPD, sizeof(float) * (size_t)B * U1 * J, st));
-        CK(joint_tanh_bwd(dH16, nullptr, 1, B, T, U1, J, dPE, dPD, st));
+        // the (t, u) sums of dP: two passes through partial rows behind dH16 (the second half of the first workspace region is free until the input layer's backward
+        // parks its operands there) - no atomics, dPD bit-reproducible; option 21 = 0: the one-pass kernel with f32 atomics on dPD
+        float* part = reinterpret_cast<float*>(dH16 + al8((size_t)M * J));
+        if (g_joint_dpd_two_pass && J % 4 == 0 && 2 * joint_sum_bwd_part_floats(B, T, U1, J) + 16 <= (size_t)M * J) {
+            CK(joint_sum_bwd_two_pass(dH16, B, T, U1, J, dPE, dPD, part, st));
+        } else {
+            CK(fill_zero(dPD, sizeof(float) * (size_t)B * U1 * J, st));
+            CK(joint_tanh_bwd(dH16, nullptr, 1, B, T, U1, J, dPE, dPD, st));
+        }
     }
     if (joint_input_fast(prec, B, T, U1, de, dd, J)) {
         // forward_layer's backward on the throughput kernels; the bf16 operands sit behind dH16 in the first workspace region
@@ -1553,9 +1561,10 @@ int ttmi_set_dropout_salt(const unsigned* salt) {
 // process-wide switches for A/B measurements.  key 0: 1 = disable the fused attention kernels (bf16 pipeline only);
 // key 1: throughput-GEMM generation (see gemm_fast.hip); key 2: flash-kernel timing switches; key 3: 0 = no wgrad fork
 int ttmi_set_option(int key, int value) {
-    TTMI_REQUIRE(key >= 0 && key <= 20, "set_option: unknown key %d", key);
+    TTMI_REQUIRE(key >= 0 && key <= 21, "set_option: unknown key %d", key);
     if (key == 19) { g_joint_dec_lo = value; return TTMI_OK; }
     if (key == 20) { gemm_fast_set_tn_group_pieces(value); return TTMI_OK; }
+    if (key == 21) { g_joint_dpd_two_pass = value; return TTMI_OK; }
     if (key == 18) { g_capture_forks = value; return TTMI_OK; }
     if (key == 17) { gemm_fast_set_f32(value); return TTMI_OK; }
     if (key == 16) { g_scatter_launch = value; return TTMI_OK; }

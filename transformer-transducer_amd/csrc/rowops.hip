@@ -1152,6 +1152,63 @@ __global__ __launch_bounds__(256) void joint_sum_bwd_bf16x4_kernel(const bf16_t*
             *reinterpret_cast<float4*>(dPE + ((long)b * T + t0 + tt) * J + j) = make_float4(accE[tt][0], accE[tt][1], accE[tt][2], accE[tt][3]);
 }
 
+// Two-pass form of the kernel above (round 6): the block's sums over its 16 frames go to part[b, t / 16, u, :] by plain 16-byte stores instead of 53 M f32 atomics on
+// dPD, and joint_dpd_reduce_kernel adds the ceil(T / 16) partial rows of every label state in a fixed order - dPD (and with it the gradient of the label states)
+// is the same bits in every run.  214 MB written and read again at C2 against the atomics' memory-side serialisation.
+__global__ __launch_bounds__(256) void joint_sum_bwd_bf16x4_part_kernel(const bf16_t* __restrict__ dP, int T, int U1, int J,
+                                                                        float* __restrict__ dPE, float* __restrict__ part) {
+    const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const bool act = j < J;
+    const int t0 = blockIdx.y * JT_TC4;
+    const int b = blockIdx.z;
+    float accE[JT_TC4][4];
+#pragma unroll
+    for (int i = 0; i < JT_TC4; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) accE[i][c] = 0.f;
+    float* prow = part + (((long)b * gridDim.y + blockIdx.y) * U1) * J + j;
+    for (int u = 0; u < U1; ++u) {
+        float accD[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tt = 0; tt < JT_TC4; ++tt) {
+            const int t = t0 + tt;
+            if (t < T && act) {
+                const uint2 w = *reinterpret_cast<const uint2*>(dP + (((long)b * T + t) * U1 + u) * J + j);
+                const float v[4] = {__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                                    __uint_as_float(w.y & 0xffff0000u)};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { accE[tt][c] += v[c]; accD[c] += v[c]; }
+            }
+        }
+        if (act) *reinterpret_cast<float4*>(prow + (long)u * J) = make_float4(accD[0], accD[1], accD[2], accD[3]);
+    }
+#pragma unroll
+    for (int tt = 0; tt < JT_TC4; ++tt)
+        if (t0 + tt < T && act)
+            *reinterpret_cast<float4*>(dPE + ((long)b * T + t0 + tt) * J + j) = make_float4(accE[tt][0], accE[tt][1], accE[tt][2], accE[tt][3]);
+}
+// dPD[b, u, :] = sum over the nt partial rows, in order (uj4 = U1 * J / 4 float4 per utterance)
+__global__ __launch_bounds__(256) void joint_dpd_reduce_kernel(const float4* __restrict__ part, int nt, long uj4, long n4, float4* __restrict__ dPD) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const long b = i / uj4, r = i - b * uj4;
+    const float4* src = part + b * nt * uj4 + r;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 4 <= nt; k += 4) {
+        const float4 a0 = src[(long)k * uj4], a1 = src[(long)(k + 1) * uj4], a2 = src[(long)(k + 2) * uj4], a3 = src[(long)(k + 3) * uj4];
+        s.x += a0.x; s.y += a0.y; s.z += a0.z; s.w += a0.w;
+        s.x += a1.x; s.y += a1.y; s.z += a1.z; s.w += a1.w;
+        s.x += a2.x; s.y += a2.y; s.z += a2.z; s.w += a2.w;
+        s.x += a3.x; s.y += a3.y; s.z += a3.z; s.w += a3.w;
+    }
+    for (; k < nt; ++k) {
+        const float4 a = src[(long)k * uj4];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    dPD[i] = s;
+}
+
 // lo[i] = bf16(src[i] - float(hi[i])): the second term of a two-term bf16 split of an f32 weight (hi = bf16(src))
 __global__ void bf16_residual_kernel(const float* __restrict__ src, const bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1695,6 +1752,21 @@ int joint_tanh_bwd(const void* dH, const void* H, int h_dtype, int B, int T, int
         hipLaunchKernelGGL(joint_tanh_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, static_cast<const bf16_t*>(dH),
                            static_cast<const bf16_t*>(H), T, U1, J, dPE, dPD);
     TTMI_LAUNCH_CHECK("joint_tanh_bwd_kernel");
+    return TTMI_OK;
+}
+
+size_t joint_sum_bwd_part_floats(int B, int T, int U1, int J) { return (size_t)B * cdiv(T, JT_TC4) * U1 * J; }
+// dPE / dPD from dP = dH (1 - H^2) (bf16, formed in the dgrad epilogue) without atomics: part = joint_sum_bwd_part_floats() floats of scratch, 16-byte aligned
+int joint_sum_bwd_two_pass(const bf16_t* dP, int B, int T, int U1, int J, float* dPE, float* dPD, float* part, hipStream_t st) {
+    TTMI_REQUIRE(dP && dPE && dPD && part && B > 0 && T > 0 && U1 > 0 && J > 0 && J % 4 == 0 && aligned16(dPE) && aligned16(dPD) && aligned16(part) &&
+                 (reinterpret_cast<uintptr_t>(dP) & 7) == 0, "joint_sum_bwd_two_pass: bad arguments");
+    const int nt = cdiv(T, JT_TC4);
+    hipLaunchKernelGGL(joint_sum_bwd_bf16x4_part_kernel, dim3(cdiv(J, 1024), nt, B), dim3(256), 0, st, dP, T, U1, J, dPE, part);
+    TTMI_LAUNCH_CHECK("joint_sum_bwd_bf16x4_part_kernel");
+    const long uj4 = (long)U1 * J / 4, n4 = (long)B * uj4;
+    hipLaunchKernelGGL(joint_dpd_reduce_kernel, dim3((unsigned)cdiv(n4, 256L)), dim3(256), 0, st, reinterpret_cast<const float4*>(part), nt, uj4, n4,
+                       reinterpret_cast<float4*>(dPD));
+    TTMI_LAUNCH_CHECK("joint_dpd_reduce_kernel");
     return TTMI_OK;
 }
 
