@@ -321,7 +321,7 @@ int ttmi_stream_reserve_cus(void* stream, int n);
  * 9: 1 = one-wave lattice kernel (round 2) instead of the workgroup-per-utterance one; 10: batch slices of the attention backward; 11: 1 = dq / dE /
  * dc by the round-2 GEMM launches instead of attn_dqde_kernel; 12: workgroups of the grid-stride LayerNorm backward kernels; 13 (default 2 since round 6): 1 = the four
  * forward GEMMs of an encoder layer (qkv_net, o_net, CoreNet.0, CoreNet.3) take the second term of their weight's bf16 split as a second K range, one launch each; 2 = o_net and
- * CoreNet.3 only; + 4 = all four in stacks of fewer than 4096 rows (the label encoder); 0 = off (2: +0.4 ms per C2 step - with the label encoder's value pass
+ * CoreNet.3 only, in stacks of at least 4096 rows (the audio encoder; the label states' value has its own pass); + 4 = all four in stacks of fewer than 4096 rows (the label encoder); 0 = off (2: +0.4 ms per C2 step - with the label encoder's value pass
  * of tt.model the timed mode's batch-mean loss stays within 8.1e-5 of the fp32 mode over 56 training states, profiles/r06_loss_error_batch_mean_fixed.log); 14: 0 = the tiled attention
  * forward kernel instead of the one-workgroup-per-head one; 15: 1 = the round-3 attention backward kernel instead of flash_bwd_rel2_kernel;
  * 16: 1 = the position-table gradients go through dE / dc and a relpos_scatter launch (round 3) instead of straight out of attn_dqde_kernel;

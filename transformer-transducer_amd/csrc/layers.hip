@@ -134,7 +134,7 @@ int g_fork_wgrad = 1;
 int g_capture_forks = 0;        // ttmi_set_option(18, 1): fork inside a stream capture too, from streams not marked by ttmi_stream_set_nofork (round 5, see fork_stream)
 int g_split_weights = 2;        // ttmi_set_option(13, v), default 2 since round 6 (with the label value pass: the timed mode's batch-mean loss within 1e-4 at every state measured): the encoders' forward GEMMs take the second term of their weight's bf16 split (W ~ hi + lo) as a second
                                 // K range over the same A tiles, one launch each (NtEpilogue::B_lo): 1 = qkv_net, o_net, CoreNet.0, CoreNet.3; 2 = the two with f32
-                                // outputs (o_net, CoreNet.3) only; + 4: all four in stacks of fewer than 4096 rows (the label encoder).  The term lives in the sub-layer's workspace
+                                // outputs (o_net, CoreNet.3) only, in stacks of at least 4096 rows (the audio encoder); + 4: all four in stacks of fewer than 4096 rows (the label encoder).  The term lives in the sub-layer's workspace
 int g_posgrad_gemms = 0;        // ttmi_set_option(11, 1): dq / dE by the round-2 GEMM launches instead of attn_dqde_kernel (A/B)
 int g_scatter_launch = 0;       // ttmi_set_option(16, 1): attn_dqde_kernel leaves dE / dc and relpos_scatter folds them (round 3; A/B); 2: atomics straight into
                                 // the table gradients (no per-(b, h) rows + reduction)
@@ -144,7 +144,9 @@ int g_gemm_slab = 0;            // ttmi_set_option(5, 1): position-term slab by 
 // stacks of fewer than 4096 rows - the LABEL encoder, whose every rounding is replicated over the T frames of the joint (5 = both encoders, 4 = the label encoder alone)
 static inline bool split_w(long rows, bool f32_out) {
     const int m = g_split_weights & 3;
-    return (m == 1 || (m == 2 && f32_out)) || ((g_split_weights & 4) && rows < 4096);
+    // (2 means the AUDIO-sized stacks: the label encoder's VALUE comes from its own bf16x3 pass, tt/model.py::_label_states, so second terms in its bf16 pass bought nothing -
+    // twelve launches of the 128 x 128 two-source kernel on the side stream, 0.43 ms of kernel time per C2 step; without that pass ask for 6 = 2 + 4)
+    return (m == 1 || (m == 2 && f32_out && rows >= 4096)) || ((g_split_weights & 4) && rows < 4096);
 }
 int g_joint_dpd_two_pass = 1;   // ttmi_set_option(21, 0): the joint's sums over frames by f32 atomics (rounds 1 - 5; A/B)
 int g_joint_dec_lo = 1;         // ttmi_set_option(19, 0): the joint's input layer without the second bf16 term of the label states (round 6; A/B)

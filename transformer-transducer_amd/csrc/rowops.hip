@@ -128,14 +128,23 @@ __global__ __launch_bounds__(WPB * 64) void ln_fwd_row_kernel(const float* __res
     const unsigned long long base = (unsigned long long)r * d;
     float v[KV][4];
     float sum = 0.f;
+    // all of the row's loads first, unconditionally (a chunk past d reads the row's first columns and is dropped): under `if (c0 < d)` every chunk's loads sat in a
+    // block of their own with s_waitcnt vmcnt(0) behind them - two 16-byte loads in flight per lane instead of four (round 6, the ISA)
+    float4 xa[KV], xw[KV];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) xa[k] = *reinterpret_cast<const float4*>(x + base + (k * 256 + lane * 4 < d ? k * 256 + lane * 4 : 0));
+    if (res) {
+#pragma unroll
+        for (int k = 0; k < KV; ++k) xw[k] = *reinterpret_cast<const float4*>(res + base + (k * 256 + lane * 4 < d ? k * 256 + lane * 4 : 0));
+    }
 #pragma unroll
     for (int k = 0; k < KV; ++k) {
         const int c0 = k * 256 + lane * 4;
         if (c0 < d) {
-            const float4 a = *reinterpret_cast<const float4*>(x + base + c0);
+            const float4 a = xa[k];
             v[k][0] = a.x; v[k][1] = a.y; v[k][2] = a.z; v[k][3] = a.w;
             if (res) {
-                const float4 w = *reinterpret_cast<const float4*>(res + base + c0);
+                const float4 w = xw[k];
                 float m[4];
                 drop_mult4(rdrop, base + c0, m);
                 v[k][0] += w.x * m[0]; v[k][1] += w.y * m[1]; v[k][2] += w.z * m[2]; v[k][3] += w.w * m[3];
@@ -998,18 +1007,22 @@ __global__ __launch_bounds__(256) void joint_tanh_bwd_kernel(const TH* __restric
     for (int i = 0; i < JT_TC; ++i) accE[i] = 0.f;
     for (int u = 0; u < U1; ++u) {
         float accD = 0.f;
+        // (all 32 loads unconditional, frames past T clamped and dropped: under `if (t < T)` each pair waited alone - see joint_sum_bwd_bf16x4_part_kernel)
+        TH hv[JT_TC], gv[JT_TC];
 #pragma unroll
         for (int tt = 0; tt < JT_TC; ++tt) {
-            const int t = t0 + tt;
-            if (t < T) {
-                const long o = (((long)b * T + t) * U1 + u) * J + j;
-                float h, g;
-                if constexpr (sizeof(TH) == 4) { h = H[o]; g = dH[o]; }
-                else { h = bf16_to_f32(H[o]); g = bf16_to_f32(dH[o]); }
-                const float v = g * (1.f - h * h);
-                accE[tt] += v;
-                accD += v;
-            }
+            const long o = (((long)b * T + min(t0 + tt, T - 1)) * U1 + u) * J + j;
+            hv[tt] = H[o];
+            gv[tt] = dH[o];
+        }
+#pragma unroll
+        for (int tt = 0; tt < JT_TC; ++tt) {
+            float h, g;
+            if constexpr (sizeof(TH) == 4) { h = hv[tt]; g = gv[tt]; }
+            else { h = bf16_to_f32(hv[tt]); g = bf16_to_f32(gv[tt]); }
+            const float v = t0 + tt < T ? g * (1.f - h * h) : 0.f;
+            accE[tt] += v;
+            accD += v;
         }
         atomicAdd(dPD + ((long)b * U1 + u) * J + j, accD);
     }
@@ -1065,6 +1078,7 @@ __global__ __launch_bounds__(256) void joint_tanh_bwd_x3_kernel(const float* __r
     __shared__ float xch[4 * 256];
     const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
     const bool act = j < J;                            // (whole waves stay alive: the exchange is per wave)
+    const int jc = act ? j : 0;
     const int t0 = blockIdx.y * JT_TCX;
     const int b = blockIdx.z;
     float accE[JT_TCX][4];
@@ -1074,19 +1088,30 @@ __global__ __launch_bounds__(256) void joint_tanh_bwd_x3_kernel(const float* __r
         for (int c = 0; c < 4; ++c) accE[i][c] = 0.f;
     for (int u = 0; u < U1; ++u) {
         float accD[4] = {0.f, 0.f, 0.f, 0.f};
+        // (loads unconditional in two batches of eight frames, frames past T / columns past J clamped and dropped: under `if (t < T && act)` every frame's three
+        // loads waited alone - see joint_sum_bwd_bf16x4_part_kernel)
 #pragma unroll
-        for (int tt = 0; tt < JT_TCX; ++tt) {
-            const int t = t0 + tt;
-            if (t < T && act) {
-                const long row = ((long)b * T + t) * U1 + u;
-                const float4 g = *reinterpret_cast<const float4*>(dH + row * J + j);
-                const uint2 hi = *reinterpret_cast<const uint2*>(H3 + row * 2 * Jp + j), lo = *reinterpret_cast<const uint2*>(H3 + row * 2 * Jp + Jp + j);
+        for (int half = 0; half < 2; ++half) {
+            float4 g8[JT_TCX / 2];
+            uint2 hi8[JT_TCX / 2], lo8[JT_TCX / 2];
+#pragma unroll
+            for (int k = 0; k < JT_TCX / 2; ++k) {
+                const long row = ((long)b * T + min(t0 + half * (JT_TCX / 2) + k, T - 1)) * U1 + u;
+                g8[k] = *reinterpret_cast<const float4*>(dH + row * J + jc);
+                hi8[k] = *reinterpret_cast<const uint2*>(H3 + row * 2 * Jp + jc);
+                lo8[k] = *reinterpret_cast<const uint2*>(H3 + row * 2 * Jp + Jp + jc);
+            }
+#pragma unroll
+            for (int k = 0; k < JT_TCX / 2; ++k) {
+                const int tt = half * (JT_TCX / 2) + k;
+                const uint2 hi = hi8[k], lo = lo8[k];
                 const float h[4] = {__uint_as_float(hi.x << 16) + __uint_as_float(lo.x << 16), __uint_as_float(hi.x & 0xffff0000u) + __uint_as_float(lo.x & 0xffff0000u),
                                     __uint_as_float(hi.y << 16) + __uint_as_float(lo.y << 16), __uint_as_float(hi.y & 0xffff0000u) + __uint_as_float(lo.y & 0xffff0000u)};
-                const float gv[4] = {g.x, g.y, g.z, g.w};
+                const float gv[4] = {g8[k].x, g8[k].y, g8[k].z, g8[k].w};
+                const bool ok = t0 + tt < T && act;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float v = gv[c] * (1.f - h[c] * h[c]);
+                    const float v = ok ? gv[c] * (1.f - h[c] * h[c]) : 0.f;
                     accE[tt][c] += v;
                     accD[c] += v;
                 }
@@ -1159,6 +1184,7 @@ __global__ __launch_bounds__(256) void joint_sum_bwd_bf16x4_part_kernel(const bf
                                                                         float* __restrict__ dPE, float* __restrict__ part) {
     const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
     const bool act = j < J;
+    const int jc = act ? j : 0;
     const int t0 = blockIdx.y * JT_TC4;
     const int b = blockIdx.z;
     float accE[JT_TC4][4];
@@ -1166,19 +1192,25 @@ __global__ __launch_bounds__(256) void joint_sum_bwd_bf16x4_part_kernel(const bf
     for (int i = 0; i < JT_TC4; ++i)
 #pragma unroll
         for (int c = 0; c < 4; ++c) accE[i][c] = 0.f;
-    float* prow = part + (((long)b * gridDim.y + blockIdx.y) * U1) * J + j;
+    float* prow = part + (((long)b * gridDim.y + blockIdx.y) * U1) * J + jc;
+    // every load unconditional (frames past T and columns past J read a clamped address and are dropped by a select): under `if (t < T && act)` each of the sixteen
+    // loads got a block of its own with s_waitcnt vmcnt(0) behind it - ONE 8-byte load in flight per lane, 3.0 TB/s (the ISA of rounds 3 - 6's kernel above)
+    const bf16_t* src = dP + ((long)b * T * U1) * J + jc;
+    long roff[JT_TC4];
+#pragma unroll
+    for (int tt = 0; tt < JT_TC4; ++tt) roff[tt] = (long)min(t0 + tt, T - 1) * U1 * J;
     for (int u = 0; u < U1; ++u) {
+        uint2 w[JT_TC4];
+#pragma unroll
+        for (int tt = 0; tt < JT_TC4; ++tt) w[tt] = *reinterpret_cast<const uint2*>(src + roff[tt] + (long)u * J);
         float accD[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tt = 0; tt < JT_TC4; ++tt) {
-            const int t = t0 + tt;
-            if (t < T && act) {
-                const uint2 w = *reinterpret_cast<const uint2*>(dP + (((long)b * T + t) * U1 + u) * J + j);
-                const float v[4] = {__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
-                                    __uint_as_float(w.y & 0xffff0000u)};
+            const bool ok = t0 + tt < T;                     // (block-uniform)
+            const float v[4] = {ok ? __uint_as_float(w[tt].x << 16) : 0.f, ok ? __uint_as_float(w[tt].x & 0xffff0000u) : 0.f,
+                                ok ? __uint_as_float(w[tt].y << 16) : 0.f, ok ? __uint_as_float(w[tt].y & 0xffff0000u) : 0.f};
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { accE[tt][c] += v[c]; accD[c] += v[c]; }
-            }
+            for (int c = 0; c < 4; ++c) { accE[tt][c] += v[c]; accD[c] += v[c]; }
         }
         if (act) *reinterpret_cast<float4*>(prow + (long)u * J) = make_float4(accD[0], accD[1], accD[2], accD[3]);
     }
