@@ -2278,8 +2278,11 @@ int gemm_nt_bf16(const bf16_t* A, const bf16_t* B, void* C, int c_dtype, const N
         const bool lean2 = base_ok && p.mask && !p.bias && c_dtype == 1 && ldc % 8 == 0 && aligned16(p.mask);
 #define V9_LAUNCH(...) do { if (int rc = enable_lds((gemm_nt_bf16_v9_kernel<__VA_ARGS__>), LDS9)) return rc; \
             hipLaunchKernelGGL((gemm_nt_bf16_v9_kernel<__VA_ARGS__>), dim3((unsigned)grid9), dim3(NTH8), LDS9, st, p); } while (0)
-        if (p.kwrap) {                                     // two-term weights (an option, off by default): the general-epilogue instances
-            if (c_dtype == 0) {
+        if (p.kwrap) {                                     // two-term weights (option 13): the plain / bias-only f32 instance (o_net, CoreNet.3: the default since round 6), else the general epilogue
+            if (c_dtype == 0 && lean1) {
+                if (int rc = enable_lds((gemm_nt_bf16_v9_kw_kernel<float, 1>), LDS9)) return rc;
+                hipLaunchKernelGGL((gemm_nt_bf16_v9_kw_kernel<float, 1>), dim3((unsigned)grid9), dim3(NTH8), LDS9, st, p);
+            } else if (c_dtype == 0) {
                 if (int rc = enable_lds((gemm_nt_bf16_v9_kw_kernel<float>), LDS9)) return rc;
                 hipLaunchKernelGGL((gemm_nt_bf16_v9_kw_kernel<float>), dim3((unsigned)grid9), dim3(NTH8), LDS9, st, p);
             } else {
