@@ -606,7 +606,7 @@ def main():
         ms_step = 1e3 * elapsed / args.steps
         utt_s = world * B * args.steps / elapsed
         U1, J = U + 1, cfg["joint"]["inner_size"]
-        fused_path = form in ("exp", "fused") or (form == "two-call" and args.precision == "bf16")       # bf16 two-call: deferred logits -> the fused op
+        fused_path = form in ("exp", "fused") or (form == "two-call" and args.precision in ("bf16", "bf16x3"))       # bf16 / bf16x3 two-call: deferred logits -> the fused op
         B_launch = B if not fused_path else (args.loss_chunk or model.default_loss_chunk(B, T, U1, form != "fused"))      # utterances per joint-projection launch
         flop_launch = 2.0 * B_launch * T * U1 * J * V                            # one joint-projection launch
         def mean_pos(vals):
@@ -794,7 +794,9 @@ def main():
                                   "dtype": "f32 data, bf16 MFMA in three terms", "steps": x3_steps,
                                   "note": "TTMI_PRECISION=bf16x3: the fp32 mode's data flow with its dense and attention-core products as hi.hi + lo.hi + hi.lo on the bf16 MFMA "
                                           "(~2^-16 relative per product); loss and every gradient within 1e-4 of the float64 oracle "
-                                          "(tests/test_configs_gpu.py::test_c2_full_model_fp32_end_to_end[bf16x3]): the quick parity mode"}
+                                          "(tests/test_configs_gpu.py::test_c2_full_model_fp32_end_to_end[bf16x3]): the quick parity mode.  Since round 6 the logits of "
+                                          "this mode are a deferred handle too (one fused joint + loss op over the whole batch, the loss gradient written as the bf16 planes "
+                                          "the joint's backward multiplies; TTMI_DEFERRED_LOGITS=0 restores the materialised two-call path: +5 ms)"}
         if label_form is not None:
             out["throughput_form"] = {"ms_per_step": round(1e3 * label_form / args.steps, 3), "value": round(world * B * args.steps / label_form, 3), "unit": "utt/s", "steps": args.steps,
                                       "note": "TTMI_LABEL_VALUE_PRECISION=off and ttmi_set_option(13, 0): the timed step without round 6's parity measures (rounds 1 - 5's headline "

@@ -109,6 +109,18 @@ int ttmi_rnnt_loss_fwd(const void* logits, int dtype, long ldv, const int* label
 int ttmi_rnnt_loss_bwd(const void* logits, int dtype, long ldv, const int* labels, const int* act_lens, const int* label_lens,
                        int B, int T, int U1, int V, int blank, const void* workspace, const float* grad_out,
                        int grad_out_stride, float scale, void* grad, long ldg, void* stream);
+/* bf16x3 mode (TTMI_PRECISION=bf16x3, prec 2; no reference counterpart - the reference's loss is warprnnt_pytorch's, tt/model.py:5): the gradient of f32 logits
+ * written OVER them as the two bf16 planes the three-term joint backward multiplies - row r becomes [hi(0 .. ldv) | lo(0 .. ldv)], hi = bf16(g), lo = bf16(g - hi),
+ * 2 ldv bf16 in the bytes of ldv f32, columns [V, ldv) zero in both planes - so that ttmi_joint_bwd_split need not read d logits again to split them.  Ask the two
+ * _ok functions first (rows 16-byte aligned, pitch == roundup(V, 64), the product large enough for the three-term kernels); otherwise use ttmi_rnnt_loss_bwd +
+ * ttmi_joint_bwd.  Workspace / grad_out / scale as in ttmi_rnnt_loss_bwd; the other arguments of ttmi_joint_bwd_split as in ttmi_joint_bwd. */
+int ttmi_rnnt_loss_bwd_split_ok(long ldv, const void* logits);
+int ttmi_rnnt_loss_bwd_split(void* logits, long ldv, const int* labels, const int* act_lens, const int* label_lens, int B, int T, int U1, int V,
+                             int blank, const void* workspace, const float* grad_out, int grad_out_stride, float scale, void* stream);
+int ttmi_joint_bwd_split_ok(int B, int T, int U1, int J, int V, int prec, long ldg);
+int ttmi_joint_bwd_split(const void* dlogits_split, long ldg, const float* enc, const float* dec, const float* wf, const float* wp, int B,
+                         int T, int U1, int de, int dd, int J, int V, int prec, const float* ctx, float* ws, float* denc, float* ddec,
+                         float* g_wf, float* g_bf, float* g_wp, float* g_bp, void* stream);
 
 /* ---- fused joint + loss fast path ("exp-domain" forms; training-sized bf16 problems, ask ttmi_joint_exp_supported first) --------
  * Replaces the pair JointNet.forward + RNNTLoss (train.py:47-53) when the caller wants the loss only.  The projection GEMM's epilogue

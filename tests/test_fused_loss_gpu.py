@@ -313,6 +313,27 @@ def test_sums_over_frames_in_two_passes_are_reproducible(monkeypatch):
     assert rel_err(atomic[2], runs[0][2]) < 1e-4 and rel_err(atomic[1], runs[0][1]) < 1e-4
 
 
+@pytest.mark.parametrize("J,V", [(1024, 4334), (2048, 6485)])
+def test_bf16x3_loss_gradient_written_as_planes(monkeypatch, J, V):
+    """bf16x3 mode, round 6: the loss gradient overwrites the f32 logits as the two bf16 planes [hi | lo] the joint's three-term backward multiplies
+    (ttmi_rnnt_loss_bwd_split + ttmi_joint_bwd_split) instead of f32 values that a split pass reads again.  Same planes, same products: every gradient as with
+    TTMI_X3_SPLIT_GRAD=0 up to the weight gradients' atomic order; ragged lengths and a label equal to the blank included (_training_sized)"""
+    import ttmi.ops as ops
+    model, x, y, al, ll = _training_sized(monkeypatch, "bf16x3", J, V)
+    seen = []
+    inner = ops.rnnt_loss_bwd_split
+    monkeypatch.setattr(ops, "rnnt_loss_bwd_split", lambda *a, **k: (seen.append(1), inner(*a, **k))[1])
+    planes = _run(model, x, y, al, ll, chunk=4)
+    assert len(seen) == 2                                     # two chunks, both through the split form
+    monkeypatch.setenv("TTMI_X3_SPLIT_GRAD", "0")
+    plain = _run(model, x, y, al, ll, chunk=4)
+    assert len(seen) == 2
+    assert planes[0] == plain[0]
+    assert rel_err(planes[1], plain[1]) < 1e-6
+    for n in plain[2]:
+        assert rel_err(planes[2][n], plain[2][n]) < 2e-6, n
+
+
 def test_exp_domain_long_label_sequences(monkeypatch):
     """U + 1 = 201 labels per lattice column block (C5's label length: the 4-slot variant of the alpha / beta kernel) at T = 320, B = 4
     (257 280 rows in one chunk), ragged lengths: exp-domain form against the plain bf16 form and the fp32 pipeline"""

@@ -1363,10 +1363,12 @@ int ttmi_joint_fwd_exp(const float* enc, const float* dec, const float* wf, cons
 // srow != nullptr: exp-domain form, d logits[r, :] = srow[r] * dlogits[r, :] (see ttmi_joint_bwd_exp); ctx is then scaled in place
 static int joint_bwd_impl(const void* dlogits, long ldg, const float* enc, const float* dec, const float* wf, const float* wp, int B,
                           int T, int U1, int de, int dd, int J, int V, int prec, float* ctx, float* ws, float* denc, float* ddec,
-                          float* g_wf, float* g_bf, float* g_wp, float* g_bp, const float* srow, const void* srow16, void* stream) {
+                          float* g_wf, float* g_bf, float* g_wp, float* g_bp, const float* srow, const void* srow16, void* stream, bool presplit = false) {
     TTMI_REQUIRE(dlogits && enc && dec && wf && wp && ctx && ws && denc && ddec && g_wf && g_bf && g_wp && g_bp,
                  "joint_bwd: null pointer");
     TTMI_REQUIRE(ldg >= V, "joint_bwd: bad pitch");
+    // presplit (bf16x3, round 6): d logits arrive as the two bf16 planes [hi | lo] per row (pitch 2 ldg bf16 in the bytes of ldg f32: ttmi_rnnt_loss_bwd_split)
+    TTMI_REQUIRE(!presplit || (prec == 2 && x3_worth((long)B * T * U1, V, J) && ldg == x3_pad(V)), "joint_bwd: pre-split d logits need the bf16x3 path and pitch == roundup(V, 64)");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool fast = joint_fast(prec, J);
     float* dPE = ws + al4((size_t)B * T * U1 * J);
@@ -1387,7 +1389,8 @@ static int joint_bwd_impl(const void* dlogits, long ldg, const float* enc, const
             const bool h3 = joint_x3_h3(M, V, J);          // the forward left H as [hi | lo] rows in ctx: they ARE the planes
             if (h3) H2 = reinterpret_cast<bf16_t*>(ctx);
             else CK(split3_bf16(Hh, J, M, J, Jp, 2, H2, st));
-            CK(split3_bf16(dZ, ldg, M, V, Vp, 2, Z2, st));
+            if (presplit) Z2 = reinterpret_cast<bf16_t*>(const_cast<void*>(dlogits));      // the loss gradient kernel wrote the planes itself: no second pass over 14 GB
+            else CK(split3_bf16(dZ, ldg, M, V, Vp, 2, Z2, st));
             CK(split3_transpose_bf16(wp, J, V, J, Vp, true, WT3, st));
             CK(gemm_tn_bf16(Z2, H2, g_wp, V, J, M, 2L * Vp, 2L * Jp, J, 1, st, g_bp));
             CK(gemm_tn_bf16(Z2 + Vp, H2, g_wp, V, J, M, 2L * Vp, 2L * Jp, J, 1, st, g_bp));
@@ -1494,6 +1497,17 @@ int ttmi_joint_bwd(const void* dlogits, long ldg, const float* enc, const float*
                    float* g_wf, float* g_bf, float* g_wp, float* g_bp, void* stream) {
     return joint_bwd_impl(dlogits, ldg, enc, dec, wf, wp, B, T, U1, de, dd, J, V, prec, const_cast<float*>(ctx), ws, denc, ddec, g_wf,
                           g_bf, g_wp, g_bp, nullptr, nullptr, stream);
+}
+
+// bf16x3: d logits already split into [hi | lo] bf16 planes per row by ttmi_rnnt_loss_bwd_split (ldg = the f32 pitch the planes replaced)
+int ttmi_joint_bwd_split_ok(int B, int T, int U1, int J, int V, int prec, long ldg) {
+    return prec == 2 && x3_worth((long)B * T * U1, V, J) && ldg == x3_pad(V);
+}
+int ttmi_joint_bwd_split(const void* dlogits_split, long ldg, const float* enc, const float* dec, const float* wf, const float* wp, int B,
+                         int T, int U1, int de, int dd, int J, int V, int prec, const float* ctx, float* ws, float* denc, float* ddec,
+                         float* g_wf, float* g_bf, float* g_wp, float* g_bp, void* stream) {
+    return joint_bwd_impl(dlogits_split, ldg, enc, dec, wf, wp, B, T, U1, de, dd, J, V, prec, const_cast<float*>(ctx), ws, denc, ddec, g_wf,
+                          g_bf, g_wp, g_bp, nullptr, nullptr, stream, true);
 }
 
 // P (patched by ttmi_rnnt_loss_bwd_exp) and the row factors srow (f32) / srow16 (bf16) stand for d logits = srow[r] * P[r, :].

@@ -591,6 +591,77 @@ __global__ __launch_bounds__(LSE_WAVES * 64) void rnnt_grad_kernel(
 }
 
 
+// bf16x3 mode (round 6): the gradient of f32 logits written IN PLACE as the two bf16 planes the joint's backward multiplies - row r becomes [hi(0 .. ldv) | lo(0 .. ldv)],
+// hi = bf16(g), lo = bf16(g - hi): 2 ldv bf16 in the bytes of ldv f32 - so that nothing has to read the 14 GB of d logits again only to split them (5.3 ms per C2 step).
+// One wave per row; the row is read completely (KV 16-byte vectors per lane, unconditional loads of a clamped index: all in flight) and the wave waits for ALL of its
+// loads before its first store: the planes overwrite columns other lanes have not consumed yet.  Columns [V, ldv) leave as zeros in both planes.  ldv % 4 == 0, rows
+// 16-byte aligned, ldv <= 256 KV.
+template <int KV>
+__global__ __launch_bounds__(LSE_WAVES * 64) void rnnt_grad_split_kernel(
+    float* logits, long ldv, const int* __restrict__ labels, const int* __restrict__ act_lens, const int* __restrict__ label_lens, int B, int T,
+    int U1, int V, int blank, const float* __restrict__ lse, const acc_t* __restrict__ alpha_d, const acc_t* __restrict__ beta_d,
+    const acc_t* __restrict__ ll, const float* __restrict__ grad_out, int grad_out_stride, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * LSE_WAVES + (threadIdx.x >> 6);
+    if (row >= (long)B * T * U1) return;
+    const int u = (int)(row % U1);
+    const long bt = row / U1;
+    const int t = (int)(bt % T);
+    const int b = (int)(bt / T);
+    const int Tb = clampi(act_lens[b], 1, T), Ub = clampi(label_lens[b], 0, U1 - 1);
+    const bool valid = (t < Tb) && (u <= Ub);
+    float* r = logits + row * ldv;
+    const int nvec = (int)(ldv >> 2);
+    float4 x[KV];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) x[k] = *reinterpret_cast<const float4*>(r + 4 * min(lane + 64 * k, nvec - 1));
+    float c = 0.f, eb = 0.f, el = 0.f, gs = 0.f;
+    int yv = -1;
+    if (valid) {
+        const acc_t* al = alpha_d + (long)b * diag_stride(T, U1);
+        const acc_t* be = beta_d + (long)b * diag_stride(T, U1);
+        const long di = (long)(t + u) * U1 + u;
+        const float l = lse[row];
+        const acc_t a = al[di] - ll[b * 2];
+        c = (float)(a + be[di]) - l;
+        gs = scale * grad_out[(long)b * grad_out_stride];
+        const float lpb = r[blank] - l;
+        if (t == Tb - 1 && u == Ub) eb = __expf((float)a + lpb);
+        else if (t < Tb - 1) eb = __expf((float)(a + be[di + U1]) + lpb);
+        if (u < Ub) {
+            yv = clampi(labels[(long)b * (U1 - 1) + u], 0, V - 1);
+            el = __expf((float)(a + be[di + U1 + 1]) + (r[yv] - l));
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the whole row (and r[blank], r[yv]) is in registers before any lane overwrites a byte of it
+    __builtin_amdgcn_wave_barrier();
+    auto f = [&](float v, int col) -> float {
+        float e = __expf(v + c);
+        e -= (col == blank) ? eb : 0.f;
+        e -= (col == yv) ? el : 0.f;
+        return (valid && col < V) ? gs * e : 0.f;
+    };
+    bf16_t* hi = reinterpret_cast<bf16_t*>(r);
+    bf16_t* lo = hi + ldv;
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+        const int vi = lane + 64 * k;
+        if (vi < nvec) {
+            const float g[4] = {f(x[k].x, 4 * vi), f(x[k].y, 4 * vi + 1), f(x[k].z, 4 * vi + 2), f(x[k].w, 4 * vi + 3)};
+            bf16_t h[4];
+            uint2 wh, wl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[j] = f32_to_bf16(g[j]);
+            wh.x = (unsigned)h[0] | ((unsigned)h[1] << 16);
+            wh.y = (unsigned)h[2] | ((unsigned)h[3] << 16);
+            wl.x = (unsigned)f32_to_bf16(g[0] - bf16_to_f32(h[0])) | ((unsigned)f32_to_bf16(g[1] - bf16_to_f32(h[1])) << 16);
+            wl.y = (unsigned)f32_to_bf16(g[2] - bf16_to_f32(h[2])) | ((unsigned)f32_to_bf16(g[3] - bf16_to_f32(h[3])) << 16);
+            *reinterpret_cast<uint2*>(hi + 4 * vi) = wh;
+            *reinterpret_cast<uint2*>(lo + 4 * vi) = wl;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ exp-domain variant (fused joint + loss fast path)
 // The joint's projection GEMM stored P[row, v] = exp(logit - shift) in bf16 plus per-row partial sums of the unrounded values
 // (gemm_fast.hip, "exp store" epilogue).  Nothing below walks the rows: the forward needs S = sum of the partials and two entries
@@ -853,6 +924,33 @@ int ttmi_rnnt_loss_bwd(const void* logits, int dtype, long ldv, const int* label
                            w.lse, w.alpha, w.beta, w.ll, grad_out, grad_out_stride, scale, static_cast<bf16_t*>(grad), ldg);
     ttmi_probe_end(2, st);
     TTMI_LAUNCH_CHECK("rnnt_grad_kernel");
+    return TTMI_OK;
+}
+
+// bf16x3 mode: the gradient of f32 logits [rows, ldv] written over them as two bf16 planes per row, [hi | lo] with pitch 2 ldv bf16 - the operand layout of the joint's
+// three-term backward (ttmi_joint_bwd_split), which then skips its own split pass over d logits.  Same workspace and scale semantics as ttmi_rnnt_loss_bwd.
+int ttmi_rnnt_loss_bwd_split_ok(long ldv, const void* logits) {
+    return ldv % 64 == 0 && ldv <= 256L * 32 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0;
+}
+int ttmi_rnnt_loss_bwd_split(void* logits, long ldv, const int* labels, const int* act_lens, const int* label_lens, int B, int T, int U1, int V,
+                             int blank, const void* workspace, const float* grad_out, int grad_out_stride, float scale, void* stream) {
+    TTMI_REQUIRE(logits && (labels || U1 == 1) && act_lens && label_lens && workspace && grad_out, "rnnt_loss_bwd_split: null pointer");
+    TTMI_REQUIRE(B > 0 && T > 0 && U1 > 0 && V > 0 && ldv >= V && blank >= 0 && blank < V, "rnnt_loss_bwd_split: bad shape");
+    TTMI_REQUIRE(ttmi_rnnt_loss_bwd_split_ok(ldv, logits), "rnnt_loss_bwd_split: rows must be 16-byte aligned with a pitch %% 64 == 0 of at most 8192 floats (pitch %ld)", ldv);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Ws w = carve(const_cast<void*>(workspace), B, T, U1);
+    const long rows = (long)B * T * U1;
+    const int kv = (int)cdiv(ldv / 4, 64L);
+    ttmi_probe_begin(2, st);
+#define SPLIT_LAUNCH(KV) hipLaunchKernelGGL(rnnt_grad_split_kernel<KV>, dim3(cdiv(rows, LSE_WAVES)), dim3(LSE_WAVES * 64), 0, st, static_cast<float*>(logits), ldv, labels, \
+                           act_lens, label_lens, B, T, U1, V, blank, w.lse, w.alpha, w.beta, w.ll, grad_out, grad_out_stride, scale)
+    if (kv <= 8) SPLIT_LAUNCH(8);
+    else if (kv <= 17) SPLIT_LAUNCH(17);
+    else if (kv <= 26) SPLIT_LAUNCH(26);
+    else SPLIT_LAUNCH(32);
+#undef SPLIT_LAUNCH
+    ttmi_probe_end(2, st);
+    TTMI_LAUNCH_CHECK("rnnt_grad_split_kernel");
     return TTMI_OK;
 }
 

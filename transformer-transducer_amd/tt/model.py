@@ -162,7 +162,11 @@ class _JointLossFn(torch.autograd.Function):
             if st is not None and not st.valid:                 # the plain form's log-sum-exp pass seeds the shift for the next step
                 ops.rnnt_shift_seed(ws, al, ll, c1 - c0, T, U1, st.nxt)
                 seeded = True
-            if need:
+            if need and ops.joint_loss_split_supported(logits, wf_.shape[0], prec):
+                # bf16x3: the gradient leaves the loss kernel as the two bf16 planes the joint's three-term backward multiplies (round 6: no split pass over d logits)
+                planes = ops.rnnt_loss_bwd_split(logits, lab, al, ll, blank, ws, one, 0, scale)
+                ops.joint_bwd_split(planes, enc[c0:c1], dec[c0:c1], wf_, wp_, saved, prec, g, out=(denc[c0:c1], ddec[c0:c1]))
+            elif need:
                 grad = ops.rnnt_loss_bwd(logits, lab, al, ll, blank, ws, one, 0, scale, inplace=True)
                 ops.joint_bwd(grad, enc[c0:c1], dec[c0:c1], wf_, wp_, saved, prec, g, out=(denc[c0:c1], ddec[c0:c1]))
             del logits, saved
@@ -202,13 +206,15 @@ class _JointLossFn(torch.autograd.Function):
 def deferred_logits_enabled(config, prec):
     """does Transducer.forward hand out a DeferredLogits handle?  TTMI_DEFERRED_LOGITS=0 / 1 (read per call, like TTMI_PRECISION) or
     config.deferred_logits (True / False) decide; unset: on in the bf16 pipeline (the throughput mode - its logits are 7 GB of bf16 per
-    C2 step that train.py:51-53 only ever hands to the loss), off in the fp32 parity mode."""
+    C2 step that train.py:51-53 only ever hands to the loss) and, since round 6, in the bf16x3 mode (14 GB of f32 logits and 14 GB of gradient:
+    fused, the loss gradient leaves its kernel as the bf16 planes the joint's three-term backward multiplies - 98.5 -> 93.4 ms per C2 step), off in
+    the fp32 parity mode."""
     env = os.environ.get("TTMI_DEFERRED_LOGITS")
     if env is not None and env != "":
         return env != "0"
     if config is not None and config.deferred_logits is not None:
         return bool(config.deferred_logits)
-    return prec == 1
+    return prec in (1, 2)
 
 
 def _meta_functions():
@@ -394,7 +400,7 @@ class JointNet(nn.Module):
         chunk * T * U1 % 64 == 0 and fell back to the plain form otherwise - half of all real batches at B = 32)."""
         prec = default_precision() if prec is None else prec
         es = 2 if ops.joint_logits_dtype(prec, self.forward_layer.out_features) is torch.bfloat16 else 4
-        budget = (32 << 30) if exp_domain else (2 << 30)
+        budget = (32 << 30) if (exp_domain or prec == 2) else (2 << 30)     # (bf16x3: the speed form as well - C2 in eight chunks 108 ms, in one 93.4)
         chunk = max(1, min(B, int(budget // (es * T * U1 * self.project_layer.out_features))))
         n = -(-B // chunk)
         return -(-B // n)

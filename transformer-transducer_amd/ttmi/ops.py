@@ -480,6 +480,43 @@ def joint_bwd(dlogits, enc, dec, wf, wp, ctx, prec, grads, out=None):
     return denc, ddec
 
 
+def joint_loss_split_supported(logits, J, prec):
+    """bf16x3 mode: may the loss gradient be written over the f32 logits as the two bf16 planes the joint's backward multiplies (no split pass over d logits)?"""
+    if prec != 2 or logits.dtype is not torch.float32 or os.environ.get("TTMI_X3_SPLIT_GRAD", "1") == "0":
+        return False
+    B, T, U1, V = logits.shape
+    ld = row_pitch(logits)
+    return (ld is not None and bool(lib().ttmi_rnnt_loss_bwd_split_ok(c_long(ld), _p(logits))) and
+            bool(lib().ttmi_joint_bwd_split_ok(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(V), c_int(prec), c_long(ld))))
+
+
+def rnnt_loss_bwd_split(logits, labels, act_lens, label_lens, blank, workspace, grad_out, grad_out_stride, scale):
+    """the f32 logits are REPLACED by their gradient's bf16 planes [hi | lo] per row (ttmi_rnnt_loss_bwd_split); -> the same tensor, to be handed to
+    joint_bwd_split only"""
+    _need_cuda(logits, labels, act_lens, label_lens, workspace, grad_out)
+    B, T, U1, V = logits.shape
+    check(lib().ttmi_rnnt_loss_bwd_split(_p(logits), c_long(row_pitch(logits)), _p(labels), _p(act_lens), _p(label_lens), c_int(B), c_int(T), c_int(U1),
+                                         c_int(V), c_int(blank), _p(workspace), _p(grad_out), c_int(grad_out_stride), c_float(scale), _stream()),
+          "ttmi_rnnt_loss_bwd_split")
+    return logits
+
+
+def joint_bwd_split(planes, enc, dec, wf, wp, ctx, prec, grads, out=None):
+    """joint_bwd for d logits that rnnt_loss_bwd_split left as bf16 planes in the logits' own buffer"""
+    B, T, de = enc.shape
+    U1, dd = dec.shape[1], dec.shape[2]
+    J, V = wf.shape[0], wp.shape[0]
+    L_ = lib()
+    L_.ttmi_joint_ws_floats_prec.restype = ctypes.c_size_t
+    ws = scratch(L_.ttmi_joint_ws_floats_prec(c_int(B), c_int(T), c_int(U1), c_int(J), c_int(V), c_int(prec)), enc.device)
+    denc, ddec = (torch.empty_like(enc), torch.empty_like(dec)) if out is None else out
+    assert denc.is_contiguous() and ddec.is_contiguous() and denc.shape == enc.shape and ddec.shape == dec.shape
+    check(L_.ttmi_joint_bwd_split(_p(planes), c_long(row_pitch(planes)), _p(enc), _p(dec), _p(wf), _p(wp), c_int(B), c_int(T), c_int(U1), c_int(de),
+                                  c_int(dd), c_int(J), c_int(V), c_int(prec), _p(ctx), _p(ws), _p(denc), _p(ddec), _p(grads["wf"]),
+                                  _p(grads["bf"]), _p(grads["wp"]), _p(grads["bp"]), _stream()), "ttmi_joint_bwd_split")
+    return denc, ddec
+
+
 # ---- fused joint + loss fast path (exp-domain forms, include/ttmi.h)
 def joint_exp_supported(B, T, U1, J, V, prec, fwd_only=False):
     ldv = (V + 63) // 64 * 64
