@@ -343,7 +343,8 @@ int ttmi_stream_reserve_cus(void* stream, int n);
  * position and was the joint's whole share of the batch-mean loss error; A/B);
  * 20: 0 = grouped weight gradients never cut an XCD's surplus tiles into K-pieces (default 1: under a CU reservation - ttmi_stream_reserve_cus - 256 tiles on 224 ... 248
  * workgroups end with one atomically added piece per workgroup instead of a second round; without a reservation the launches stay free of atomics either way);
- * 21: 0 = the joint's sums over frames (dPD) by f32 atomics as in rounds 1 - 5 (default 1: partial rows + an ordered second pass - the same bits in every run, same time) */
+ * 21: 0 = the joint's sums over frames (dPD) by f32 atomics as in rounds 1 - 5 (default 1: partial rows + an ordered second pass - the same bits in every run, same time);
+ * 22: 0 = bf16x3 weight gradients as three accumulating launches (round 5) instead of one launch over the plane pairs + a fold */
 int ttmi_set_option(int key, int value);
 int ttmi_dropout_apply(const float* in, long n, float p, unsigned seed, float* out, void* stream);
 int ttmi_probe_arm(int slot);

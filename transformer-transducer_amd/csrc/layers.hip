@@ -66,7 +66,8 @@ int wgrad(const float* dY, const float* X, float* gW, int M, int N, int K, long 
 inline int x3_pad(int n) { return (n + 63) / 64 * 64; }
 inline size_t x3_al(size_t n) { return (n + 63) & ~(size_t)63; }
 inline size_t x3_nt_elems(long M, long N, int K) { return x3_al((size_t)M * 3 * x3_pad(K)) + x3_al((size_t)N * 3 * x3_pad(K)); }
-inline size_t x3_tn_elems(long K, int M, int N) { return x3_al((size_t)K * 2 * x3_pad(M)) + x3_al((size_t)K * 2 * x3_pad(N)); }
+// (+ the 2 Mp x 2 Np f32 block of the one-launch form of x3_tn, in bf16 elements)
+inline size_t x3_tn_elems(long K, int M, int N) { return x3_al((size_t)K * 2 * x3_pad(M)) + x3_al((size_t)K * 2 * x3_pad(N)) + x3_al((size_t)8 * x3_pad(M) * x3_pad(N)); }
 // big enough to be worth two split passes and the throughput kernels
 inline bool x3_worth(long M, long N, long K) { return M >= 256 && N >= 64 && K >= 64 && M * N * K >= (1L << 27); }
 // Two layouts of the same three terms.  Products with thousands of rows (the audio encoder, the joint) run on the persistent kernels, whose K loop can
@@ -105,12 +106,22 @@ int x3_nn(const float* A, const float* B, float* C, int M, int N, int K, long ld
     return x3_launch(A3, B3, C, M, N, Kp, ldc, e, two, st);
 }
 // C[M,N] += A[K,M]^T . B[K,N] (atomically: a weight gradient)
+int g_x3_tn_one_launch = 1;     // ttmi_set_option(22, 0): the three accumulating launches of round 5 (A/B)
 int x3_tn(const float* A, const float* B, float* C, int M, int N, long K, long lda, long ldb, long ldc, bf16_t* scratch, hipStream_t st) {
     const int Mp = x3_pad(M), Np = x3_pad(N);
     bf16_t* A2 = scratch;
     bf16_t* B2 = A2 + x3_al((size_t)K * 2 * Mp);
     CK(split3_bf16(A, lda, K, M, Mp, 2, A2, st));
     CK(split3_bf16(B, ldb, K, N, Np, 2, B2, st));
+    // round 6: ONE launch over the plane pairs as they lie - [hi | lo]^T [hi | lo] = the four blocks hi^T hi, hi^T lo, lo^T hi, lo^T lo of a 2 Mp x 2 Np product -
+    // and a fold of the first three into C.  A third more flops than the three launches (the lo^T lo block is computed and dropped), but four times the tiles in one
+    // grid: an encoder weight gradient is 8 ... 48 tiles of 256 x 128, a fraction of the chip three times over (3 x 40 us at C2; 40 + 2 x 5 us this way)
+    if (g_x3_tn_one_launch && K % 64 == 0 && K >= 4096 && K < 32768 && (2 * Mp) % 256 == 0 && (2 * Np) % 128 == 0 && (size_t)Mp * Np <= ((size_t)1 << 23)) {
+        float* T = reinterpret_cast<float*>(B2 + x3_al((size_t)K * 2 * Np));
+        CK(fill_zero(T, sizeof(float) * (size_t)4 * Mp * Np, st));
+        CK(gemm_tn_bf16(A2, B2, T, 2 * Mp, 2 * Np, (int)K, 2L * Mp, 2L * Np, 2L * Np, 1, st));
+        return x3_fold_blocks(T, Mp, Np, C, M, N, ldc, st);
+    }
     CK(gemm_tn_bf16(A2, B2, C, M, N, (int)K, 2L * Mp, 2L * Np, ldc, 1, st));
     CK(gemm_tn_bf16(A2 + Mp, B2, C, M, N, (int)K, 2L * Mp, 2L * Np, ldc, 1, st));
     return gemm_tn_bf16(A2, B2 + Np, C, M, N, (int)K, 2L * Mp, 2L * Np, ldc, 1, st);
@@ -1577,10 +1588,11 @@ int ttmi_set_dropout_salt(const unsigned* salt) {
 // process-wide switches for A/B measurements.  key 0: 1 = disable the fused attention kernels (bf16 pipeline only);
 // key 1: throughput-GEMM generation (see gemm_fast.hip); key 2: flash-kernel timing switches; key 3: 0 = no wgrad fork
 int ttmi_set_option(int key, int value) {
-    TTMI_REQUIRE(key >= 0 && key <= 21, "set_option: unknown key %d", key);
+    TTMI_REQUIRE(key >= 0 && key <= 22, "set_option: unknown key %d", key);
     if (key == 19) { g_joint_dec_lo = value; return TTMI_OK; }
     if (key == 20) { gemm_fast_set_tn_group_pieces(value); return TTMI_OK; }
     if (key == 21) { g_joint_dpd_two_pass = value; return TTMI_OK; }
+    if (key == 22) { g_x3_tn_one_launch = value; return TTMI_OK; }
     if (key == 18) { g_capture_forks = value; return TTMI_OK; }
     if (key == 17) { gemm_fast_set_f32(value); return TTMI_OK; }
     if (key == 16) { g_scatter_launch = value; return TTMI_OK; }

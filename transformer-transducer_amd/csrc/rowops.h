@@ -75,6 +75,7 @@ int joint_tanh_bwd(const void* dH, const void* H, int h_dtype, int B, int T, int
 // bf16x3: H as two-block rows [hi | lo] (pitch 2 Jp bf16) instead of f32, and the backward from them (rowops.hip)
 int joint_tanh_fwd_x3(const float* PE, const float* PD, const float* bias, int B, int T, int U1, int J, int Jp, bf16_t* H3, hipStream_t st);
 int joint_tanh_bwd_x3(const float* dH, const bf16_t* H3, int B, int T, int U1, int J, int Jp, float* dPE, float* dPD, hipStream_t st);
+int x3_fold_blocks(const float* T, int Mp, int Np, float* C, int M, int N, long ldc, hipStream_t st);
 size_t joint_sum_bwd_part_floats(int B, int T, int U1, int J);
 int joint_sum_bwd_two_pass(const bf16_t* dP, int B, int T, int U1, int J, float* dPE, float* dPD, float* part, hipStream_t st);
 int fill_zero(void* p, size_t bytes, hipStream_t st);             // a KERNEL (graph-safe), never a memset node: see rowops.hip

@@ -1787,6 +1787,21 @@ int joint_tanh_bwd(const void* dH, const void* H, int h_dtype, int B, int T, int
     return TTMI_OK;
 }
 
+// C[i, j] += T[i, j] + T[i, Np + j] + T[Mp + i, j]: the three terms of a bf16x3 weight gradient out of the one-launch block product (layers.hip x3_tn)
+__global__ __launch_bounds__(256) void x3_fold_blocks_kernel(const float* __restrict__ T, int Mp, int Np, float* __restrict__ C, int M, int N, long ldc) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)M * N) return;
+    const int r = (int)(i / N), c = (int)(i - (long)r * N);
+    const long ldt = 2L * Np;
+    C[(long)r * ldc + c] += T[r * ldt + c] + T[r * ldt + Np + c] + T[(long)(Mp + r) * ldt + c];
+}
+int x3_fold_blocks(const float* T, int Mp, int Np, float* C, int M, int N, long ldc, hipStream_t st) {
+    TTMI_REQUIRE(T && C && M > 0 && N > 0 && Mp >= M && Np >= N && ldc >= N, "x3_fold_blocks: bad arguments");
+    hipLaunchKernelGGL(x3_fold_blocks_kernel, dim3((unsigned)cdiv((long)M * N, 256L)), dim3(256), 0, st, T, Mp, Np, C, M, N, ldc);
+    TTMI_LAUNCH_CHECK("x3_fold_blocks_kernel");
+    return TTMI_OK;
+}
+
 size_t joint_sum_bwd_part_floats(int B, int T, int U1, int J) { return (size_t)B * cdiv(T, JT_TC4) * U1 * J; }
 // dPE / dPD from dP = dH (1 - H^2) (bf16, formed in the dgrad epilogue) without atomics: part = joint_sum_bwd_part_floats() floats of scratch, 16-byte aligned
 int joint_sum_bwd_two_pass(const bf16_t* dP, int B, int T, int U1, int J, float* dPE, float* dPD, float* part, hipStream_t st) {
