@@ -228,3 +228,43 @@ def test_no_untagged_counted_waits_elsewhere(tmp_path):
         for kname, body in kernels_of(asm).items():
             ins, _ = parse(body)
             assert not any(x.get("untagged") for x in ins), kname
+
+
+def _alone_loads(body):
+    """vector loads whose NEXT vm wait is vmcnt(0) with no other load issued in between -> (alone, loads)"""
+    lines = [l.strip() for l in body.splitlines()]
+    loads = [i for i, l in enumerate(lines) if re.match(r"(global|buffer|flat)_load", l)]
+    alone = 0
+    for k, i in enumerate(loads):
+        nxt = loads[k + 1] if k + 1 < len(loads) else len(lines)
+        if any(l.startswith("s_waitcnt") and "vmcnt(0)" in l for l in lines[i + 1:nxt]):
+            alone += 1
+    return alone, len(loads)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_frame_loads_of_the_joint_sums_stay_in_flight(tmp_path):
+    """round 6: written as `if (t < T && act) { load; add }` in an unrolled loop, each of a label position's sixteen frame loads compiled into a block of its own with
+    s_waitcnt vmcnt(0) behind it - one load in flight per lane, 3.0 TB/s for three rounds.  The unconditional form (clamped address, selected value) must keep
+    compiling to loads issued back to back: at most the last load of a batch may be followed by a full drain.  Same for the fp32 / bf16x3 forms and the loss
+    gradient that overwrites its logits with bf16 planes (its ONE vmcnt(0) is deliberate: the whole row must be in registers before the first store)"""
+    asm = compile_isa("rowops", tmp_path)
+    seen = 0
+    for kname, body in kernels_of(asm).items():
+        if "joint_sum_bwd_bf16x4_part_kernel" in kname:
+            alone, loads = _alone_loads(body)
+            assert loads == 16 and alone <= 1, (kname, alone, loads)
+            seen += 1
+        elif "joint_tanh_bwd_kernel" in kname or "joint_tanh_bwd_x3_kernel" in kname:
+            alone, loads = _alone_loads(body)
+            assert loads >= 32 and alone <= 2, (kname, alone, loads)
+            seen += 1
+    assert seen == 4
+    asm = compile_isa("rnnt", tmp_path)
+    seen = 0
+    for kname, body in kernels_of(asm).items():
+        if "rnnt_grad_split_kernel" in kname:
+            alone, loads = _alone_loads(body)
+            assert alone <= 6, (kname, alone, loads)          # (the row's vectors in one batch; the scalars of the row - lse, alpha, beta, labels - are few)
+            seen += 1
+    assert seen == 4
