@@ -21,6 +21,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--states", default="0,2,5,8,10,12,15,20,25,40")
 ap.add_argument("--seeds", default="1,2")
 ap.add_argument("--modes", default="bf16", help="comma list of timed modes to score against fp32 (bf16, bf16x3)")
+ap.add_argument("--workload", default="c2", choices=["c2", "c4-band", "c4-chunk", "c5"], help="BASELINE configuration: model and batch shape as bench.py --workload")
 args = ap.parse_args()
 os.environ["TTMI_PRECISION"] = "bf16"
 import bench
@@ -29,12 +30,16 @@ from ttmi.train import FlatModel, FusedOptimizer, GradSync
 
 dev = torch.device("cuda", 0)
 B, T, U, V, d = 32, 500, 50, 4334, 512
+if args.workload.startswith("c4"):
+    V = 6485
+elif args.workload == "c5":
+    B, T, U = 8, 2000, 200
 states = sorted(int(v) for v in args.states.split(","))
 out = []
 for seed in (int(v) for v in args.seeds.split(",")):
     os.environ["TTMI_PRECISION"] = "bf16"
     torch.manual_seed(seed)
-    model = Transducer(bench.c2_config()).to(dev).train()
+    model = Transducer(bench.c4_config(args.workload[3:]) if args.workload.startswith("c4") else bench.c2_config()).to(dev).train()
     flat = FlatModel(model)
     flat.enable_grouped_wgrads()
     flat.enable_shadows()
