@@ -688,7 +688,19 @@ __global__ __launch_bounds__(256) void rnnt_prep_exp_kernel(
     if (t >= Tb || u > Ub) return;
     const long rows = (long)B * T * U1;
     float S = 0.f;
-    for (int i = 0; i < nparts; ++i) S += rowsum[i * rows + row];        // part-major: coalesced across the block's rows
+    {   // part-major: coalesced across the block's rows.  Eight partial sums in flight per row (a plain runtime loop issued one load per wait); the sum is
+        // taken in the same order as before: ((((0 + p0) + p1) + ...) - the loads are hoisted, not the adds
+        const float* rp = rowsum + row;
+        int i = 0;
+        for (; i + 8 <= nparts; i += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = rp[(long)(i + k) * rows];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) S += v[k];
+        }
+        for (; i < nparts; ++i) S += rp[(long)i * rows];
+    }
     const float cur = shift_cur ? *shift_cur : 0.f;
     float zb = 0.f, zy = 0.f;
     if (emis) {
