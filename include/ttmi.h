@@ -320,6 +320,11 @@ int ttmi_gemm_tn_bf16_wsum(const void* A, const void* B, float* C, int M, int N,
 int ttmi_weight_shadow_register(const float* w, int R, int C, const void* w16, const void* wT16, long ldT);
 int ttmi_weight_shadow_clear(const float* w /* NULL = all */);
 int ttmi_weight_shadow_refresh(const long* table, int n, long total_tiles, void* stream);
+/* round 6: the second term of a shadowed weight's bf16 split, w16lo = bf16(w - float(w16)) (the operand of ttmi_set_option(13, ...)), kept with the shadows: one
+ * buffer of twice the plain copies' size, w16lo at w16 + lo_delta elements; ttmi_weight_shadow_refresh_lo rebuilds all three copies in its one launch.  Without
+ * it every forward call that takes the second term forms it itself (one small launch per GEMM). */
+int ttmi_weight_shadow_register_lo(const float* w, const void* w16lo);
+int ttmi_weight_shadow_refresh_lo(const long* table, int n, long total_tiles, long lo_delta, void* stream);
 
 /* data-parallel runs (train.py:55-56,214-219 replaced by one process per GPU + RCCL): the gradient all-reduce kernels run beside the
  * backward pass; the encoder-sized persistent GEMMs launched on `stream` (and on the library's fork streams serving it) leave n CUs to

@@ -231,7 +231,7 @@ void join_stream(hipStream_t main) {
 // ---- bf16 shadows of GEMM weights (ttmi_weight_shadow_*): a training loop keeps a plain and a transposed bf16 copy of every weight,
 // rebuilt once per optimiser step (one launch), instead of converting every weight in every forward call (118 launches per step at C2).
 // Registered by the caller, looked up by the f32 weight pointer; a shadow is used only if its geometry is the one the call needs.
-struct Shadow { int R, C; const bf16_t* w16; const bf16_t* wT16; long ldT; };
+struct Shadow { int R, C; const bf16_t* w16; const bf16_t* wT16; long ldT; const bf16_t* w16lo = nullptr; };     // w16lo: bf16(w - float(w16)), kept current with the others (nullable)
 std::unordered_map<const void*, Shadow> g_shadows;
 std::mutex g_shadow_mu;
 
@@ -511,8 +511,8 @@ static int attn_fwd_impl(const float* x, const float* qkv_w, const float* o_w, c
         else CK(transpose_convert_bf16(qkv_w, (int)a.W3, d, c.wqkvT16, a.W3, st, w.wqkv16));   // Wqkv (bf16) and Wqkv^T [d, W3] for backward
         NtEpilogue eq;
         if (split_w(a.BL, false)) {
-            CK(bf16_residual(qkv_w, wqkv16, w.wqkv16lo, (long)a.W3 * d, st));
-            eq.B_lo = w.wqkv16lo;
+            if (shq && sh.w16lo) eq.B_lo = sh.w16lo;       // (kept current by the optimiser step with the shadow itself)
+            else { CK(bf16_residual(qkv_w, wqkv16, w.wqkv16lo, (long)a.W3 * d, st)); eq.B_lo = w.wqkv16lo; }
         }
         CK(gemm_nt_bf16(x16, wqkv16, c.qkv, 1, eq, (int)a.BL, (int)a.W3, d, d, d, a.W3, st));
         if (!attn_inkernel(fast, a))
@@ -583,8 +583,8 @@ static int attn_fwd_impl(const float* x, const float* qkv_w, const float* o_w, c
         else CK(transpose_convert_bf16(o_w, d, (int)a.HD, c.woT16, d, st, w.wo16));              // Wo (bf16) and Wo^T [HD, d] for backward
         NtEpilogue eo;
         if (split_w(a.BL, true)) {
-            CK(bf16_residual(o_w, wo16, w.wo16lo, (long)d * a.HD, st));
-            eo.B_lo = w.wo16lo;
+            if (sho && sh.w16lo) eo.B_lo = sh.w16lo;
+            else { CK(bf16_residual(o_w, wo16, w.wo16lo, (long)d * a.HD, st)); eo.B_lo = w.wo16lo; }
         }
         CK(gemm_nt_bf16(static_cast<bf16_t*>(c.O), wo16, w.a, 0, eo, (int)a.BL, d, (int)a.HD, a.HD, a.HD, d, st));
     } else if (x3 && x3_worth(a.BL, d, a.HD)) {
@@ -961,12 +961,12 @@ static int ffn_fwd_impl(const float* y, const float* w1, const float* b1, const 
         e1.bias = b1; e1.relu = 1; e1.drop = d_in;
         e2.bias = b2;
         if (split_w(rows, false)) {
-            CK(bf16_residual(w1, w1_16, w.w1_16lo, (long)d * Di, st));
-            e1.B_lo = w.w1_16lo;
+            if (sh1 && s1.w16lo) e1.B_lo = s1.w16lo;
+            else { CK(bf16_residual(w1, w1_16, w.w1_16lo, (long)d * Di, st)); e1.B_lo = w.w1_16lo; }
         }
         if (split_w(rows, true)) {
-            CK(bf16_residual(w2, w2_16, w.w2_16lo, (long)d * Di, st));
-            e2.B_lo = w.w2_16lo;
+            if (sh2 && s2.w16lo) e2.B_lo = s2.w16lo;
+            else { CK(bf16_residual(w2, w2_16, w.w2_16lo, (long)d * Di, st)); e2.B_lo = w.w2_16lo; }
         }
         CK(gemm_nt_bf16(static_cast<bf16_t*>(c.h), w1_16, c.a1, 1, e1, (int)rows, Di, d, d, d, Di, st));
         CK(gemm_nt_bf16(static_cast<bf16_t*>(c.a1), w2_16, w.f, 0, e2, (int)rows, d, Di, Di, Di, d, st));
@@ -1236,14 +1236,17 @@ static int joint_fwd_impl(const float* enc, const float* dec, const float* wf, c
         CK(convert_bf16(dec, dec16, (long)B * U1 * dd, st));
         Shadow sh;
         const bf16_t* wf16 = Wf16;
-        if (shadow_of(wf, J, din, J, sh)) wf16 = sh.w16;
+        const bool shf = shadow_of(wf, J, din, J, sh);
+        if (shf) wf16 = sh.w16;
         else CK(convert_bf16(wf, Wf16, (long)J * din, st));
         CK(gemm_nt_bf16(enc16, wf16, PE, 0, nullptr, B * T, J, de, de, din, J, st));
         CK(gemm_nt_bf16(dec16, wf16 + de, PD, 0, nullptr, B * U1, J, dd, dd, din, J, st));
         // second term of the weight's bf16 split (w ~ w16 + lo16): the rounding of [We | Wd] is ONE pattern applied to every frame and label, so
         // its effect on the loss does not average out over a batch; two small GEMMs more (1 % of the projection's work) take it out
-        bf16_t* Wf16lo = Wf16 + al8((size_t)J * din);
-        CK(bf16_residual(wf, wf16, Wf16lo, (long)J * din, st));
+        bf16_t* Wf16lo_ws = Wf16 + al8((size_t)J * din);
+        const bf16_t* Wf16lo = Wf16lo_ws;
+        if (shf && sh.w16lo) Wf16lo = sh.w16lo;
+        else CK(bf16_residual(wf, wf16, Wf16lo_ws, (long)J * din, st));
         NtEpilogue ea, eb;
         ea.addend = PE;
         eb.addend = PD;
@@ -1255,7 +1258,7 @@ static int joint_fwd_impl(const float* enc, const float* dec, const float* wf, c
         // (4e-5 ... 1.7e-4, all of the joint's share of the batch-mean loss error), by 0.002 with the label states pre-rounded; the audio states' rounding (one pattern per frame,
         // 500 different ones along an alignment) and the rounding of every weight of the joint change nothing.  One 1632-row GEMM more.
         if (g_joint_dec_lo) {
-            bf16_t* dec16lo = Wf16lo + al8((size_t)J * din);
+            bf16_t* dec16lo = Wf16lo_ws + al8((size_t)J * din);
             CK(bf16_residual(dec, dec16, dec16lo, (long)B * U1 * dd, st));
             CK(gemm_nt_bf16(dec16lo, wf16 + de, PD, 0, eb, B * U1, J, dd, dd, din, J, st));
         }
@@ -1548,6 +1551,19 @@ int ttmi_weight_shadow_clear(const float* w) {
 }
 int ttmi_weight_shadow_refresh(const long* table, int n, long total_tiles, void* stream) {
     return shadow_refresh(table, n, total_tiles, static_cast<hipStream_t>(stream));
+}
+// the second term of every shadowed weight's bf16 split, w16lo = bf16(w - float(w16)), at w16 + lo_delta elements (one buffer twice the size): registered per
+// weight, refreshed by the same launch as the other two copies
+int ttmi_weight_shadow_register_lo(const float* w, const void* w16lo) {
+    TTMI_REQUIRE(w && w16lo && aligned16(w16lo), "weight_shadow_register_lo: bad arguments");
+    std::lock_guard<std::mutex> lock(g_shadow_mu);
+    auto it = g_shadows.find(w);
+    TTMI_REQUIRE(it != g_shadows.end(), "weight_shadow_register_lo: the weight has no registered shadow");
+    it->second.w16lo = static_cast<const bf16_t*>(w16lo);
+    return TTMI_OK;
+}
+int ttmi_weight_shadow_refresh_lo(const long* table, int n, long total_tiles, long lo_delta, void* stream) {
+    return shadow_refresh(table, n, total_tiles, static_cast<hipStream_t>(stream), lo_delta);
 }
 
 // CUs that the encoder-sized persistent GEMMs launched on `stream` leave free (for RCCL's kernels running beside a data-parallel

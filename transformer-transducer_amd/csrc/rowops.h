@@ -96,7 +96,7 @@ int split3_bf16(const float* src, long ld, long R, int C, int Cp, int mode, bf16
 int relu_mask_scale(float* g, const float* a, long n, float scale, hipStream_t st);
 int split3_transpose_bf16(const float* src, long ld, int R, int C, int Rp, bool hhl, bf16_t* dst, hipStream_t st);
 // one launch rebuilding the plain + transposed bf16 copies of every weight in `table` (device, n rows of 8 longs, see rowops.hip)
-int shadow_refresh(const long* table, int n, long total_tiles, hipStream_t st);
+int shadow_refresh(const long* table, int n, long total_tiles, hipStream_t st, long lo_delta = 0);
 // out[c] += sum_r in[r*ld + c] for a bf16 matrix (atomic; caller zeroes / accumulates)
 int colsum_bf16(const bf16_t* in, long ld, long rows, int cols, float* out, hipStream_t st, int nz1 = 1, int nz2 = 1, long si1 = 0,
                 long si2 = 0, long so2 = 0);   // batch z = z1*nz2+z2 reads in + z1*si1 + z2*si2, adds into out + z2*so2

@@ -1354,7 +1354,7 @@ __global__ __launch_bounds__(256) void transpose_convert_kernel(const float* __r
 
 // the same tile transpose for MANY weights in one launch (the bf16 shadows of ttmi.train.FlatModel, refreshed once per optimiser step):
 // table row = (src f32*, R, C, dstT bf16*, ldd, plain bf16*, first tile, tiles along C); block b serves the weight whose tile range holds b
-__global__ __launch_bounds__(256) void shadow_refresh_kernel(const long* __restrict__ table, int n) {
+__global__ __launch_bounds__(256) void shadow_refresh_kernel(const long* __restrict__ table, int n, long lo_delta) {
     __shared__ float tile[32][33];
     __shared__ long ent[8];
     if (threadIdx.x == 0) {
@@ -1378,7 +1378,11 @@ __global__ __launch_bounds__(256) void shadow_refresh_kernel(const long* __restr
         const int r = r0 + i, c = c0 + tx;
         const float v = (r < R && c < C) ? src[(long)r * C + c] : 0.f;
         tile[i][tx] = v;
-        if (plain && r < R && c < C) plain[(long)r * C + c] = f32_to_bf16(v);
+        if (plain && r < R && c < C) {
+            const bf16_t h = f32_to_bf16(v);
+            plain[(long)r * C + c] = h;
+            if (lo_delta) plain[lo_delta + (long)r * C + c] = f32_to_bf16(v - bf16_to_f32(h));     // second term of the weight's bf16 split (round 6: option 13's operand, once per step)
+        }
     }
     __syncthreads();
     if (dst)
@@ -1973,9 +1977,9 @@ int transpose_convert_bf16(const float* src, int R, int C, bf16_t* dst, long ldd
     return TTMI_OK;
 }
 
-int shadow_refresh(const long* table, int n, long total_tiles, hipStream_t st) {
-    TTMI_REQUIRE(table && n > 0 && total_tiles > 0 && total_tiles < (1L << 31), "shadow_refresh: bad arguments");
-    hipLaunchKernelGGL(shadow_refresh_kernel, dim3((unsigned)total_tiles), dim3(256), 0, st, table, n);
+int shadow_refresh(const long* table, int n, long total_tiles, hipStream_t st, long lo_delta) {
+    TTMI_REQUIRE(table && n > 0 && total_tiles > 0 && total_tiles < (1L << 31) && lo_delta >= 0, "shadow_refresh: bad arguments");
+    hipLaunchKernelGGL(shadow_refresh_kernel, dim3((unsigned)total_tiles), dim3(256), 0, st, table, n, lo_delta);
     TTMI_LAUNCH_CHECK("shadow_refresh_kernel");
     return TTMI_OK;
 }

@@ -66,7 +66,8 @@ class FlatModel:
         if dev.type != "cuda":
             raise ValueError("bf16 weight shadows need the parameters on the GPU")
         ents = [(p, o) for p, o in zip(self.params, self.offsets) if p.dim() == 2 and p.shape[1] % 8 == 0 and p.shape[0] >= 64]
-        plain = torch.zeros(sum((p.numel() + 7) // 8 * 8 for p, _ in ents), dtype=torch.bfloat16, device=dev)
+        n_plain = sum((p.numel() + 7) // 8 * 8 for p, _ in ents)
+        plain = torch.zeros(2 * n_plain, dtype=torch.bfloat16, device=dev)        # [bf16(w) of every weight | bf16(w - bf16(w)) of every weight]: the second halves serve option 13
         ldts = [(p.shape[0] + 63) // 64 * 64 if p.shape[0] % 8 else p.shape[0] for p, _ in ents]
         trans = torch.zeros(sum((p.shape[1] * ld + 7) // 8 * 8 for (p, _), ld in zip(ents, ldts)), dtype=torch.bfloat16, device=dev)
         rows, po, to, tile0 = [], 0, 0, 0
@@ -78,11 +79,12 @@ class FlatModel:
             rows.append([p.data_ptr(), R, C, wT16.data_ptr(), ld, w16.data_ptr(), tile0, tx])
             ops.check(L.ttmi_weight_shadow_register(ops.c_void_p(p.data_ptr()), ops.c_int(R), ops.c_int(C), ops.c_void_p(w16.data_ptr()),
                                                     ops.c_void_p(wT16.data_ptr()), ops.c_long(ld)), "ttmi_weight_shadow_register")
+            ops.check(L.ttmi_weight_shadow_register_lo(ops.c_void_p(p.data_ptr()), ops.c_void_p(w16.data_ptr() + 2 * n_plain)), "ttmi_weight_shadow_register_lo")
             po += (R * C + 7) // 8 * 8
             to += (C * ld + 7) // 8 * 8
             tile0 += tx * ty
         self.shadow = dict(plain=plain, trans=trans, table=torch.tensor(rows, dtype=torch.int64, device=dev), n=len(rows), tiles=tile0,
-                           version=-1, ptrs=[r[0] for r in rows])
+                           version=-1, ptrs=[r[0] for r in rows], lo_delta=n_plain)
         _shadowed.append(weakref.ref(self))
         self.refresh_shadows()
         return self
@@ -91,8 +93,8 @@ class FlatModel:
         sh = self.shadow
         if sh is None:
             return
-        ops.check(ops.lib().ttmi_weight_shadow_refresh(ops.c_void_p(sh["table"].data_ptr()), ops.c_int(sh["n"]), ops.c_long(sh["tiles"]),
-                                                       ops._stream()), "ttmi_weight_shadow_refresh")
+        ops.check(ops.lib().ttmi_weight_shadow_refresh_lo(ops.c_void_p(sh["table"].data_ptr()), ops.c_int(sh["n"]), ops.c_long(sh["tiles"]),
+                                                          ops.c_long(sh["lo_delta"]), ops._stream()), "ttmi_weight_shadow_refresh_lo")
         sh["version"] = self._versions()
 
     def _versions(self):
